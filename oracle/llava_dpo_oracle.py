@@ -1,0 +1,547 @@
+"""CPU oracle for the LLaVA-1.5 DPO training step.  TEST INFRASTRUCTURE - NOT THE PRODUCT.
+
+Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may import this
+file, and only as the checker.  The product path (vl-rlhf_amd/) never imports it and fails
+loudly when the HIP library is missing.
+
+This is a plain-PyTorch fp32 RESTATEMENT (no HuggingFace / trl / reference import) of the
+algorithm on the reference's DPO hot path.  Each function cites the reference lines it
+follows (paths relative to /root/reference).  Where the arithmetic lives in a third-party
+dependency that is not vendored in the reference (transformers==4.41.0, trl==0.8.1,
+torch AdamW) the published algorithm is restated and the call site is cited.
+
+Parity status: PINNED.  tests/test_oracle_golden.py checks every function here against
+tests/golden/*.npz, which oracle/make_golden.py generated in the build container by
+running the reference's own functions (get_batch_logps, dpo_loss, collator, LLaVA merge,
+get_diff_ids) composed with the installed HF CLIP / projector / LLaMA modules.
+
+`emulate_bf16=True` rounds every tensor the HIP path stores as bf16 (weights, GEMM outputs,
+norm/rope/attention/activation outputs, residual stream) to bf16 and back, so the HIP path
+can be compared against it with a tight tolerance; fp32 mode is the reference-exact one.
+"""
+import difflib
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+IGNORE_INDEX = -100
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def _rt(x, on):
+    return x.to(torch.bfloat16).to(torch.float32) if on else x
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Collator + concatenation (integer work)
+# ----------------------------------------------------------------------------------------------------------
+def collate(features: List[dict], pad_token_id: int = 0, label_pad_token_id: int = IGNORE_INDEX) -> dict:
+    """src/vlrlhf/base/collator.py:26-68 (decoder-only branch): chosen_/rejected_ right-padded, prompt_
+    left-padded; ids -> pad_token_id, labels -> label_pad_token_id, masks -> 0; *_logps -> float tensor;
+    everything else passed through as a list."""
+    out = {}
+    for k in features[0].keys():
+        if k.endswith("_input_ids") or k.endswith("_attention_mask") or k.endswith("_labels"):
+            if k.endswith("_input_ids"):
+                pad = pad_token_id
+            elif k.endswith("_labels"):
+                pad = label_pad_token_id
+            else:
+                pad = 0
+            n = max(len(f[k]) for f in features)
+            t = torch.full((len(features), n), pad, dtype=torch.long)
+            for i, f in enumerate(features):
+                v = torch.tensor(f[k], dtype=torch.long)
+                if "prompt" in k:
+                    t[i, n - len(v):] = v
+                else:
+                    t[i, : len(v)] = v
+            out[k] = t
+        elif k.endswith("_logps"):
+            out[k] = torch.tensor([f[k] for f in features])
+        else:
+            out[k] = [f[k] for f in features]
+    return out
+
+
+def concatenated_inputs(batch: dict, label_pad_token_id: int = IGNORE_INDEX, padding_value: int = 0) -> dict:
+    """src/vlrlhf/base/trainer.py:124-146 + trl==0.8.1 DPOTrainer.concatenated_inputs (not vendored; call site
+    trainer.py:132-134): pad chosen/rejected tensors on the right to the common max length and stack chosen over
+    rejected; every image tensor / list is DUPLICATED (trainer.py:138-142)."""
+    n = max(batch["chosen_input_ids"].shape[1], batch["rejected_input_ids"].shape[1])
+    out = {}
+    for field, pad in (("input_ids", padding_value), ("attention_mask", 0), ("labels", label_pad_token_id)):
+        parts = []
+        for side in ("chosen", "rejected"):
+            t = batch[f"{side}_{field}"]
+            if t.shape[1] < n:
+                t = torch.cat([t, torch.full((t.shape[0], n - t.shape[1]), pad, dtype=t.dtype)], dim=1)
+            parts.append(t)
+        out[f"concatenated_{field}"] = torch.cat(parts, dim=0)
+    if "img_input_dict" in batch:
+        d = {}
+        for k, v in batch["img_input_dict"].items():
+            if isinstance(v, torch.Tensor):
+                d[k] = torch.cat([v, v], dim=0)
+            elif isinstance(v, list):
+                d[k] = v + v
+            else:
+                raise ValueError(f"Unsupported type {type(v)} for concatenation.")
+        out["concatenated_img_input_dict"] = d
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Vision tower + projector (third-party arithmetic: transformers CLIPVisionModel, LlavaMultiModalProjector;
+# call sites src/vlrlhf/models/Llava/__init__.py:178-191)
+# ----------------------------------------------------------------------------------------------------------
+def quick_gelu(x):
+    return x * torch.sigmoid(1.702 * x)
+
+
+def clip_vit_features(pixel_values, W: Dict[str, torch.Tensor], cfg: dict, emulate_bf16=False,
+                      prefix="vision_tower.vision_model."):
+    """hidden_states[-2] of the CLIP ViT with the CLS token dropped (Llava/__init__.py:178-183).  Pre-LN encoder:
+    x += out_proj(attn(LN1(x))); x += fc2(quick_gelu(fc1(LN2(x)))).  Only layers 0..L-2 are evaluated."""
+    r = lambda t: _rt(t, emulate_bf16)  # noqa: E731
+    B = pixel_values.shape[0]
+    D, P, nh = cfg["vit_hidden"], cfg["patch_size"], cfg["vit_heads"]
+    g = cfg["image_size"] // P
+    w_pe = W[prefix + "embeddings.patch_embedding.weight"].reshape(D, -1)          # [D, 3*P*P]
+    patches = pixel_values.reshape(B, 3, g, P, g, P).permute(0, 2, 4, 1, 3, 5).reshape(B, g * g, 3 * P * P)
+    x = r(patches) @ r(w_pe).t()
+    cls = W[prefix + "embeddings.class_embedding"].reshape(1, 1, D).expand(B, 1, D)
+    x = torch.cat([cls, x], dim=1) + W[prefix + "embeddings.position_embedding.weight"][None]
+    eps = cfg.get("vit_ln_eps", 1e-5)
+    x = r(F.layer_norm(x, (D,), W[prefix + "pre_layrnorm.weight"], W[prefix + "pre_layrnorm.bias"], eps))
+    hd = D // nh
+    n_eval = cfg["vit_layers"] - 1          # vision_feature_layer = -2
+    for i in range(n_eval):
+        p = f"{prefix}encoder.layers.{i}."
+        h = r(F.layer_norm(x, (D,), W[p + "layer_norm1.weight"], W[p + "layer_norm1.bias"], eps))
+        q = r(h @ r(W[p + "self_attn.q_proj.weight"]).t() + W[p + "self_attn.q_proj.bias"])
+        k = r(h @ r(W[p + "self_attn.k_proj.weight"]).t() + W[p + "self_attn.k_proj.bias"])
+        v = r(h @ r(W[p + "self_attn.v_proj.weight"]).t() + W[p + "self_attn.v_proj.bias"])
+        T = x.shape[1]
+        q, k, v = (t.reshape(B, T, nh, hd).transpose(1, 2) for t in (q, k, v))
+        a = torch.softmax((q @ k.transpose(-1, -2)) * (hd ** -0.5), dim=-1) @ v
+        a = r(a.transpose(1, 2).reshape(B, T, D))
+        x = r(x + (a @ r(W[p + "self_attn.out_proj.weight"]).t() + W[p + "self_attn.out_proj.bias"]))
+        h = r(F.layer_norm(x, (D,), W[p + "layer_norm2.weight"], W[p + "layer_norm2.bias"], eps))
+        h = r(quick_gelu(h @ r(W[p + "mlp.fc1.weight"]).t() + W[p + "mlp.fc1.bias"]))
+        x = r(x + (h @ r(W[p + "mlp.fc2.weight"]).t() + W[p + "mlp.fc2.bias"]))
+    return x[:, 1:]
+
+
+def projector(feat, W, emulate_bf16=False, prefix="multi_modal_projector."):
+    """Linear -> GELU(erf) -> Linear (transformers LlavaMultiModalProjector; call site Llava/__init__.py:191)."""
+    r = lambda t: _rt(t, emulate_bf16)  # noqa: E731
+    h = r(F.gelu(r(feat) @ r(W[prefix + "linear_1.weight"]).t() + W[prefix + "linear_1.bias"]))
+    return r(h @ r(W[prefix + "linear_2.weight"]).t() + W[prefix + "linear_2.bias"])
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Image/text merge
+# ----------------------------------------------------------------------------------------------------------
+def merge_input_ids_with_image_features(image_features, inputs_embeds, input_ids, attention_mask, labels,
+                                        image_token_index: int, pad_token_id: int,
+                                        ignore_index: int = IGNORE_INDEX):
+    """src/vlrlhf/models/Llava/__init__.py:36-109, restated position-wise.
+
+    Every `<image>` id expands to P = image_features.shape[1] slots.  Rows are right-aligned ("left padding")
+    unless some row ends with the MODEL's pad id (:39) - the collator pads with 0/unk, the model pad id is 32001,
+    so in training the branch is always "left" and the offset is zero when every row has one image.
+    Returns (embeds, attention_mask, labels, position_ids, image_position_map) in the reference's order (:109).
+
+    Difference kept on purpose: the reference finds the image slots as "rows of the output that are still all
+    zero" (:87-88), so a text token whose embedding row is exactly zero would be mistaken for an image slot and
+    trip the count check (:90-94).  Here slots are found by position; the same ValueError is raised when the
+    number of image slots and image features disagree."""
+    n_img, P, H = image_features.shape
+    B, T = input_ids.shape
+    left_padding = not bool((input_ids[:, -1] == pad_token_id).any())
+    is_img = input_ids == image_token_index
+    S = int(is_img.sum(-1).max()) * (P - 1) + T
+    new_pos = torch.cumsum(is_img.long() * (P - 1) + 1, dim=-1) - 1
+    nb_image_pad = S - 1 - new_pos[:, -1]
+    if left_padding:
+        new_pos = new_pos + nb_image_pad[:, None]
+    out = torch.zeros(B, S, H, dtype=inputs_embeds.dtype)
+    out_mask = torch.zeros(B, S, dtype=attention_mask.dtype)
+    out_labels = torch.full((B, S), ignore_index, dtype=input_ids.dtype)
+    written = torch.zeros(B, S, dtype=torch.bool)
+    bi, ti = torch.where(~is_img)
+    dst = new_pos[bi, ti]
+    out[bi, dst] = inputs_embeds[bi, ti]
+    out_mask[bi, dst] = attention_mask[bi, ti]
+    if labels is not None:
+        out_labels[bi, dst] = labels[bi, ti]
+    written[bi, dst] = True
+    free = ~written
+    img_map = free & ((free.long().cumsum(-1) - 1) >= nb_image_pad[:, None])
+    if int(img_map.sum()) != n_img * P:
+        raise ValueError(
+            f"The input provided to the model are wrong. The number of image tokens is {int(is_img.sum())} while"
+            f" the number of image given to the model is {n_img}. This prevents correct indexing and breaks batch"
+            " generation.")
+    out[img_map] = image_features.reshape(-1, H).to(out.dtype)
+    out_mask = out_mask | img_map.to(out_mask.dtype)
+    position_ids = (out_mask.cumsum(-1) - 1).masked_fill(out_mask == 0, 1)
+    bi, ti = torch.where(input_ids == pad_token_id)
+    out[bi, new_pos[bi, ti]] = 0
+    return out, out_mask, (out_labels if labels is not None else None), position_ids, img_map
+
+
+# ----------------------------------------------------------------------------------------------------------
+# LLaMA decoder (third-party arithmetic: transformers LlamaForCausalLM; call site Llava/__init__.py:232-243)
+# ----------------------------------------------------------------------------------------------------------
+def rms_norm(x, w, eps):
+    v = x.float().pow(2).mean(-1, keepdim=True)
+    return w * (x * torch.rsqrt(v + eps))
+
+
+def rope_tables(position_ids, head_dim, theta=10000.0):
+    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    ang = position_ids[..., None].float() * inv          # [B,S,hd/2]
+    emb = torch.cat([ang, ang], dim=-1)
+    return emb.cos(), emb.sin()
+
+
+def apply_rope(x, cos, sin):
+    """x [B,nh,S,hd]; rotate-half convention."""
+    hd = x.shape[-1]
+    x1, x2 = x[..., : hd // 2], x[..., hd // 2:]
+    rot = torch.cat([-x2, x1], dim=-1)
+    return x * cos[:, None] + rot * sin[:, None]
+
+
+def causal_padding_bias(attention_mask):
+    """additive [B,1,S,S]: key j visible to query i iff j <= i and attention_mask[b,j] != 0."""
+    B, S = attention_mask.shape
+    causal = torch.ones(S, S, dtype=torch.bool).tril()
+    vis = causal[None] & (attention_mask[:, None, :] != 0)
+    return torch.zeros(B, 1, S, S).masked_fill(~vis[:, None], torch.finfo(torch.float32).min)
+
+
+def llama_hidden(embeds, attention_mask, position_ids, W, cfg, emulate_bf16=False,
+                 prefix="language_model.model.", collect=None):
+    """All decoder layers + final RMSNorm -> hidden [B,S,H] (what lm_head consumes)."""
+    r = lambda t: _rt(t, emulate_bf16)  # noqa: E731
+    B, S, H = embeds.shape
+    nh = cfg["heads"]
+    hd = H // nh
+    eps = cfg.get("rms_eps", 1e-5)
+    cos, sin = rope_tables(position_ids, hd, cfg.get("rope_theta", 10000.0))
+    bias = causal_padding_bias(attention_mask)
+    x = r(embeds)
+    for i in range(cfg["layers"]):
+        p = f"{prefix}layers.{i}."
+        h = r(rms_norm(x, W[p + "input_layernorm.weight"], eps))
+        q = r(h @ r(W[p + "self_attn.q_proj.weight"]).t())
+        k = r(h @ r(W[p + "self_attn.k_proj.weight"]).t())
+        v = r(h @ r(W[p + "self_attn.v_proj.weight"]).t())
+        q, k, v = (t.reshape(B, S, nh, hd).transpose(1, 2) for t in (q, k, v))
+        q, k = r(apply_rope(q, cos, sin)), r(apply_rope(k, cos, sin))
+        att = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(hd) + bias, dim=-1)
+        a = r((att @ v).transpose(1, 2).reshape(B, S, H))
+        x = r(x + a @ r(W[p + "self_attn.o_proj.weight"]).t())
+        h = r(rms_norm(x, W[p + "post_attention_layernorm.weight"], eps))
+        gate = r(h @ r(W[p + "mlp.gate_proj.weight"]).t())
+        up = r(h @ r(W[p + "mlp.up_proj.weight"]).t())
+        act = r(F.silu(gate) * up)
+        x = r(x + act @ r(W[p + "mlp.down_proj.weight"]).t())
+        if collect is not None:
+            collect.append(x)
+    return r(rms_norm(x, W[prefix + "norm.weight"], eps))
+
+
+def lm_logits(hidden, W, emulate_bf16=False, key="language_model.lm_head.weight"):
+    return hidden @ _rt(W[key], emulate_bf16).t()
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Log-probabilities and the DPO loss
+# ----------------------------------------------------------------------------------------------------------
+def get_diff_ids(a_seq, b_seq, min_match_size=3):
+    """src/vlrlhf/utils/diff_lib.py:116-125,73-83,135-163,173-180: indices of a_seq / b_seq that lie in a
+    'replace' span - a gap between two kept matching blocks (SequenceMatcher blocks shorter than
+    min_match_size are dropped, the terminating empty block is kept) that is non-empty on BOTH sides."""
+    blocks = difflib.SequenceMatcher(None, a_seq, b_seq).get_matching_blocks()
+    kept = [m for m in blocks[:-1] if m[2] >= min_match_size] + [blocks[-1]]
+    a_ids, b_ids = [], []
+    a_prev, b_prev = 0, 0
+    for m in kept:
+        a_gap, b_gap = (a_prev, m[0]), (b_prev, m[1])
+        if a_gap[0] != a_gap[1] and b_gap[0] != b_gap[1]:
+            a_ids += range(*a_gap)
+            b_ids += range(*b_gap)
+        a_prev, b_prev = m[0] + m[2], m[1] + m[2]
+    # trailing gap after the last kept block (diff_lib.py:73-83 closes the span list at len(seq)); the last kept
+    # block is the zero-length terminator at (len(a), len(b)), so this gap is empty - kept for fidelity.
+    a_gap, b_gap = (a_prev, len(a_seq)), (b_prev, len(b_seq))
+    if a_gap[0] != a_gap[1] and b_gap[0] != b_gap[1]:
+        a_ids += range(*a_gap)
+        b_ids += range(*b_gap)
+    return sorted(set(a_ids)), sorted(set(b_ids))
+
+
+def ddpo_shared_mask(labels, label_pad_token_id=IGNORE_INDEX, min_match_size=3):
+    """src/vlrlhf/base/trainer.py:161-184: mask (on the SHIFTED labels, pad -> 0) of tokens that differ between
+    the chosen half and the rejected half of the batch."""
+    sh = labels[:, 1:].clone()
+    sh[sh == label_pad_token_id] = 0
+    n = sh.shape[0] // 2
+    assert n * 2 == sh.shape[0]
+    m = torch.zeros_like(sh, dtype=torch.bool)
+    for i in range(n):
+        c, rj = get_diff_ids(sh[i].tolist(), sh[n + i].tolist(), min_match_size)
+        m[i, c] = True
+        m[n + i, rj] = True
+    return m
+
+
+def get_batch_logps(logits, labels, average_log_prob=False, label_pad_token_id=IGNORE_INDEX,
+                    mask_shared_tokens=False):
+    """src/vlrlhf/base/trainer.py:148-188 (decoder-only)."""
+    if logits.shape[:-1] != labels.shape:
+        raise ValueError("Logits (batch and sequence length dim) and labels must have the same shape.")
+    tgt = labels[:, 1:].clone()
+    lg = logits[:, :-1, :]
+    mask = tgt != label_pad_token_id
+    tgt[~mask] = 0
+    tok = torch.gather(lg.float().log_softmax(-1), 2, tgt[..., None]).squeeze(2)
+    if mask_shared_tokens:
+        mask = mask & ddpo_shared_mask(labels, label_pad_token_id)
+    s = (tok * mask).sum(-1)
+    return s / mask.sum(-1) if average_log_prob else s
+
+
+def dpo_loss(policy_chosen_logps, policy_rejected_logps, reference_chosen_logps, reference_rejected_logps,
+             beta=0.1, label_smoothing=0.0, loss_type="sigmoid", reference_free=False):
+    """src/vlrlhf/base/trainer.py:244-301."""
+    pi = policy_chosen_logps - policy_rejected_logps
+    ref = torch.zeros(1, dtype=pi.dtype) if reference_free else reference_chosen_logps - reference_rejected_logps
+    x = pi - ref
+    if loss_type in ("sigmoid", "ddpo"):
+        losses = -F.logsigmoid(beta * x) * (1 - label_smoothing) - F.logsigmoid(-beta * x) * label_smoothing
+    elif loss_type == "hinge":
+        losses = torch.relu(1 - beta * x)
+    elif loss_type == "ipo":
+        losses = (x - 1 / (2 * beta)) ** 2
+    elif loss_type == "kto_pair":
+        chosen_kl = (policy_chosen_logps - reference_chosen_logps).mean().clamp(min=0)
+        rejected_kl = (policy_rejected_logps - reference_rejected_logps).mean().clamp(min=0)
+        cl = policy_chosen_logps - reference_chosen_logps
+        rl = policy_rejected_logps - reference_rejected_logps
+        losses = torch.cat((1 - torch.sigmoid(beta * (cl - rejected_kl)), 1 - torch.sigmoid(beta * (chosen_kl - rl))), 0)
+    else:
+        raise ValueError(f"Unknown loss type: {loss_type}. Should be one of ['sigmoid', 'hinge', 'ipo', 'kto_pair']")
+    chosen_rewards = beta * (policy_chosen_logps - reference_chosen_logps).detach()
+    rejected_rewards = beta * (policy_rejected_logps - reference_rejected_logps).detach()
+    return losses, chosen_rewards, rejected_rewards
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Whole model / whole step
+# ----------------------------------------------------------------------------------------------------------
+def llava_forward(W, cfg, input_ids, attention_mask, labels, pixel_values, emulate_bf16=False,
+                  dedupe_images=True, return_hidden=False):
+    """src/vlrlhf/models/Llava/__init__.py:111-271 on the training path: embed -> ViT(hidden_states[-2], no CLS)
+    -> projector -> merge -> decoder -> logits.  Returns (logits fp32, merged labels, aux).
+    `dedupe_images`: the concatenated batch carries every image twice (trainer.py:138-142); the ViT is frozen and
+    deterministic so it is evaluated once per distinct image and the features are repeated - identical result."""
+    emb = _rt(W["language_model.model.embed_tokens.weight"], emulate_bf16)[input_ids]
+    n = pixel_values.shape[0]
+    if dedupe_images and n % 2 == 0 and torch.equal(pixel_values[: n // 2], pixel_values[n // 2:]):
+        feat = clip_vit_features(pixel_values[: n // 2], W, cfg, emulate_bf16)
+        img = projector(feat, W, emulate_bf16)
+        img = torch.cat([img, img], dim=0)
+    else:
+        feat = clip_vit_features(pixel_values, W, cfg, emulate_bf16)
+        img = projector(feat, W, emulate_bf16)
+    merged, mask, mlabels, pos, img_map = merge_input_ids_with_image_features(
+        img, emb, input_ids, attention_mask, labels, cfg["image_token"], cfg.get("model_pad_token_id", cfg["image_token"] + 1))
+    hidden = llama_hidden(merged, mask, pos, W, cfg, emulate_bf16)
+    aux = dict(vit_feat=feat, image_features=img, merged=merged, mask=mask, pos=pos, img_map=img_map, hidden=hidden)
+    if return_hidden:
+        return hidden, mlabels, aux
+    return lm_logits(hidden, W, emulate_bf16), mlabels, aux
+
+
+def concatenated_forward(W, cfg, batch, loss_type="sigmoid", emulate_bf16=False):
+    """src/vlrlhf/base/trainer.py:190-242 -> (chosen_logps, rejected_logps, chosen_logits, rejected_logits)."""
+    cb = concatenated_inputs(batch)
+    n = batch["chosen_labels"].shape[0]
+    logits, labels, _ = llava_forward(W, cfg, cb["concatenated_input_ids"], cb["concatenated_attention_mask"],
+                                      cb["concatenated_labels"], cb["concatenated_img_input_dict"]["pixel_values"],
+                                      emulate_bf16)
+    lp = get_batch_logps(logits, labels, mask_shared_tokens=(loss_type == "ddpo"))
+    return lp[:n], lp[n:], logits[:n], logits[n:]
+
+
+def compute_loss(W_policy, W_ref, cfg, batch, beta=0.1, loss_type="sigmoid", label_smoothing=0.0,
+                 reference_free=False, emulate_bf16=False):
+    """trl==0.8.1 DPOTrainer.get_batch_loss_metrics (not vendored; reached from src/vlrlhf/base/trainer.py:303-305):
+    policy pass with grad, reference pass without (or batch['reference_*_logps'] when present), dpo_loss,
+    loss = losses.mean(), eight metrics."""
+    pc, pr, pcl, prl = concatenated_forward(W_policy, cfg, batch, loss_type, emulate_bf16)
+    with torch.no_grad():
+        if "reference_chosen_logps" in batch and "reference_rejected_logps" in batch:
+            rc, rr = batch["reference_chosen_logps"], batch["reference_rejected_logps"]
+        else:
+            rc, rr, _, _ = concatenated_forward(W_ref, cfg, batch, loss_type, emulate_bf16)
+    losses, cr, rrw = dpo_loss(pc, pr, rc, rr, beta, label_smoothing, loss_type, reference_free)
+    metrics = {
+        "rewards/chosen": cr.mean(), "rewards/rejected": rrw.mean(),
+        "rewards/accuracies": (cr > rrw).float().mean(), "rewards/margins": (cr - rrw).mean(),
+        "logps/rejected": pr.detach().mean(), "logps/chosen": pc.detach().mean(),
+        "logits/rejected": prl.detach().mean(), "logits/chosen": pcl.detach().mean(),
+    }
+    return losses.mean(), metrics
+
+
+def trainable_names(W, freeze_vision_tower=True):
+    return [k for k in W if not (freeze_vision_tower and k.startswith("vision_tower."))]
+
+
+def is_no_decay(name: str) -> bool:
+    """transformers Trainer.get_decay_parameter_names: LayerNorm/RMSNorm weights and biases get no weight decay."""
+    return ("norm" in name) or name.endswith(".bias")
+
+
+def clip_grad_norm_(grads: Dict[str, torch.Tensor], max_norm: float):
+    """torch.nn.utils.clip_grad_norm_ (L2): total = sqrt(sum g^2); g *= min(1, max_norm / (total + 1e-6))."""
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).float()
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    for g in grads.values():
+        g.mul_(coef)
+    return total
+
+
+def adamw_step(W, grads, state, lr, beta1=0.9, beta2=0.98, eps=1e-6, weight_decay=0.0, step: Optional[int] = None):
+    """torch.optim.AdamW single step (decoupled decay): p *= 1 - lr*wd; m,v EMA; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)."""
+    state["step"] = (state.get("step", 0) + 1) if step is None else step
+    t = state["step"]
+    bc1, bc2 = 1 - beta1 ** t, 1 - beta2 ** t
+    for k, g in grads.items():
+        m = state.setdefault("m." + k, torch.zeros_like(W[k]))
+        v = state.setdefault("v." + k, torch.zeros_like(W[k]))
+        wd = 0.0 if is_no_decay(k) else weight_decay
+        W[k].mul_(1 - lr * wd)
+        m.mul_(beta1).add_(g, alpha=1 - beta1)
+        v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+        denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+        W[k].addcdiv_(m, denom, value=-lr / bc1)
+
+
+def dpo_train_step(W_policy, W_ref, cfg, batch, optim: dict, state: dict, beta=0.1, loss_type="sigmoid",
+                   emulate_bf16=False):
+    """One full optimizer step on the CPU: forward x2, loss, backward (torch autograd on the restated forward),
+    clip, AdamW.  Returns (loss, metrics, grads, total_norm)."""
+    names = trainable_names(W_policy)
+    leaves = {k: W_policy[k].detach().clone().requires_grad_(True) for k in names}
+    Wp = dict(W_policy)
+    Wp.update(leaves)
+    loss, metrics = compute_loss(Wp, W_ref, cfg, batch, beta, loss_type, emulate_bf16=emulate_bf16)
+    loss.backward()
+    grads = {k: leaves[k].grad for k in names if leaves[k].grad is not None}
+    total = clip_grad_norm_(grads, optim["max_grad_norm"])
+    with torch.no_grad():
+        adamw_step(W_policy, grads, state, optim["lr"], optim["beta1"], optim["beta2"], optim["eps"],
+                   optim["weight_decay"])
+    return loss.detach(), metrics, grads, total
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Synthetic workload of SURVEY.md section 8(d) (shared by tests and bench so both sides see identical inputs)
+# ----------------------------------------------------------------------------------------------------------
+def synthetic_pixels(n, image_size, seed):
+    import numpy as np
+    g = np.random.Generator(np.random.PCG64(seed))
+    px = g.integers(0, 256, size=(n, 3, image_size, image_size), dtype=np.uint8).astype(np.float32) / 255.0
+    mean = np.array(CLIP_MEAN, dtype=np.float32)[None, :, None, None]
+    std = np.array(CLIP_STD, dtype=np.float32)[None, :, None, None]
+    return torch.from_numpy((px - mean) / std)
+
+
+def synthetic_batch(pairs, text_len, image_token, vocab_hi, image_size, seed, ragged=False, prompt_frac=0.5):
+    """BOS at 0, one <image> at index 4, ids U{3..vocab_hi-1}; prompt shared by chosen and rejected; labels = ids
+    with the prompt -> -100.  ragged: response lengths U{text_len/8 .. text_len/2}, right-padded 0 / -100 / 0."""
+    import numpy as np
+    g = np.random.Generator(np.random.PCG64(seed))
+    lp = int(text_len * prompt_frac)
+    rows = []
+    for _ in range(pairs):
+        prompt = g.integers(3, vocab_hi, size=lp).tolist()
+        prompt[0] = 1
+        prompt[4] = image_token
+        lens = [text_len - lp, text_len - lp]
+        if ragged:
+            lens = [int(g.integers(max(2, (text_len - lp) // 8), text_len - lp + 1)) for _ in range(2)]
+        resp = [g.integers(3, vocab_hi, size=n).tolist() for n in lens]
+        rows.append(dict(
+            prompt_input_ids=prompt, prompt_attention_mask=[1] * lp,
+            chosen_input_ids=prompt + resp[0], chosen_attention_mask=[1] * (lp + lens[0]),
+            chosen_labels=[-100] * lp + resp[0],
+            rejected_input_ids=prompt + resp[1], rejected_attention_mask=[1] * (lp + lens[1]),
+            rejected_labels=[-100] * lp + resp[1], img_path="synthetic"))
+    batch = collate(rows)
+    batch["img_input_dict"] = dict(pixel_values=synthetic_pixels(pairs, image_size, seed + 7))
+    return batch
+
+
+def random_weights(cfg, seed=0, std=0.02, dtype=torch.float32):
+    """Random LLaVA-shaped weights with transformers==4.41.0 checkpoint names."""
+    g = torch.Generator().manual_seed(seed)
+    W = {}
+
+    def rnd(*shape, s=std):
+        return (torch.randn(*shape, generator=g) * s).to(dtype)
+
+    D, P, H, I, V = cfg["vit_hidden"], cfg["patch_size"], cfg["hidden"], cfg["inter"], cfg["vocab"]
+    ntok = (cfg["image_size"] // P) ** 2 + 1
+    vp = "vision_tower.vision_model."
+    W[vp + "embeddings.class_embedding"] = rnd(D)
+    W[vp + "embeddings.patch_embedding.weight"] = rnd(D, 3, P, P)
+    W[vp + "embeddings.position_embedding.weight"] = rnd(ntok, D)
+    for nm in ("pre_layrnorm", "post_layernorm"):
+        W[vp + nm + ".weight"] = 1 + rnd(D, s=0.05)
+        W[vp + nm + ".bias"] = rnd(D)
+    for i in range(cfg["vit_layers"]):
+        p = f"{vp}encoder.layers.{i}."
+        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            W[p + f"self_attn.{nm}.weight"] = rnd(D, D, s=cfg.get("vit_std", std))
+            W[p + f"self_attn.{nm}.bias"] = rnd(D)
+        for nm in ("layer_norm1", "layer_norm2"):
+            W[p + nm + ".weight"] = 1 + rnd(D, s=0.05)
+            W[p + nm + ".bias"] = rnd(D)
+        W[p + "mlp.fc1.weight"] = rnd(cfg["vit_mlp"], D, s=cfg.get("vit_std", std))
+        W[p + "mlp.fc1.bias"] = rnd(cfg["vit_mlp"])
+        W[p + "mlp.fc2.weight"] = rnd(D, cfg["vit_mlp"], s=cfg.get("vit_std", std))
+        W[p + "mlp.fc2.bias"] = rnd(D)
+    W["multi_modal_projector.linear_1.weight"] = rnd(H, D)
+    W["multi_modal_projector.linear_1.bias"] = rnd(H)
+    W["multi_modal_projector.linear_2.weight"] = rnd(H, H)
+    W["multi_modal_projector.linear_2.bias"] = rnd(H)
+    lp = "language_model.model."
+    W[lp + "embed_tokens.weight"] = rnd(V, H)
+    for i in range(cfg["layers"]):
+        p = f"{lp}layers.{i}."
+        for nm in ("q_proj", "k_proj", "v_proj", "o_proj"):
+            W[p + f"self_attn.{nm}.weight"] = rnd(H, H)
+        W[p + "mlp.gate_proj.weight"] = rnd(I, H)
+        W[p + "mlp.up_proj.weight"] = rnd(I, H)
+        W[p + "mlp.down_proj.weight"] = rnd(H, I)
+        W[p + "input_layernorm.weight"] = 1 + rnd(H, s=0.05)
+        W[p + "post_attention_layernorm.weight"] = 1 + rnd(H, s=0.05)
+    W[lp + "norm.weight"] = 1 + rnd(H, s=0.05)
+    W["language_model.lm_head.weight"] = rnd(V, H)
+    return W
+
+
+LLAVA_1_5_7B = dict(vit_hidden=1024, vit_mlp=4096, vit_layers=24, vit_heads=16, image_size=336, patch_size=14,
+                    hidden=4096, inter=11008, layers=32, heads=32, vocab=32064, image_token=32000,
+                    model_pad_token_id=32001, rms_eps=1e-5, rope_theta=10000.0)

@@ -1,0 +1,189 @@
+"""Pins the CPU oracle (oracle/llava_dpo_oracle.py) against golden vectors produced from the REFERENCE's own
+functions (oracle/make_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import llava_dpo_oracle as O
+from tests.golden_util import GOLDEN, load_case, t
+
+CASES = ["llava_tiny", "llava_hipsmall"]
+
+
+def close(a, b, tol=3e-5):
+    """max-abs error relative to the tensor's scale (fp32 accumulation-order noise only)."""
+    return float((a - b).abs().max()) <= tol * (float(b.abs().max()) + 1e-12)
+LOSS_TYPES = ["sigmoid", "hinge", "ipo", "kto_pair", "ddpo"]
+
+
+@pytest.fixture(scope="module")
+def ka():
+    return np.load(os.path.join(GOLDEN, "known_answers.npz"))
+
+
+def test_collator_known_answer(ka):
+    rows = json.loads(bytes(ka["collator_rows_json"]).decode())
+    got = O.collate(rows)
+    for k in ka.files:
+        if k.startswith("collator.") :
+            name = k[len("collator."):]
+            exp = torch.from_numpy(ka[k])
+            assert torch.equal(got[name].to(exp.dtype), exp) if exp.dtype != torch.float32 else torch.allclose(got[name].float(), exp), name
+    assert got["img_path"] == ["a.jpg", "b.jpg"]
+    # left-padded prompt, right-padded answers
+    assert got["prompt_input_ids"].tolist() == [[1, 2, 3], [0, 1, 2]]
+    assert got["chosen_labels"].tolist() == [[-100, -100, -100, 4, 5], [-100, -100, 4, -100, -100]]
+
+
+def test_dpo_loss_known_answers(ka):
+    pc, pr, rc, rr = (torch.from_numpy(ka[f"kl.{n}"]) for n in ("pc", "pr", "rc", "rr"))
+    n = 0
+    for lt in LOSS_TYPES:
+        for ls in (0.0, 0.2):
+            for rf in (False, True):
+                for beta in (0.1, 0.5):
+                    key = f"kl.{lt}.ls{ls}.rf{int(rf)}.b{beta}"
+                    l, c, r = O.dpo_loss(pc, pr, rc, rr, beta, ls, lt, rf)
+                    assert torch.allclose(l, t(ka, key + ".losses"), rtol=1e-6, atol=1e-6), key
+                    assert torch.allclose(c, t(ka, key + ".cr"), rtol=1e-6, atol=1e-6)
+                    assert torch.allclose(r, t(ka, key + ".rr"), rtol=1e-6, atol=1e-6)
+                    n += 1
+    assert n == 40
+    l, _, _ = O.dpo_loss(pc, pr, pc, pr)
+    assert torch.allclose(l, t(ka, "kl.ln2")) and abs(float(l[0]) - 0.6931471824645996) < 1e-7
+    with pytest.raises(ValueError):
+        O.dpo_loss(pc, pr, rc, rr, loss_type="nope")
+
+
+def test_get_batch_logps_known_answers(ka):
+    logits, labels = t(ka, "lp.logits"), t(ka, "lp.labels")
+    assert torch.allclose(O.get_batch_logps(logits, labels), t(ka, "lp.sum"), rtol=1e-6, atol=1e-5)
+    assert torch.allclose(O.get_batch_logps(logits, labels, average_log_prob=True), t(ka, "lp.avg"), rtol=1e-6, atol=1e-5)
+    assert torch.allclose(O.get_batch_logps(logits, labels, mask_shared_tokens=True), t(ka, "lp.ddpo"), rtol=1e-6, atol=1e-5)
+    with pytest.raises(ValueError):
+        O.get_batch_logps(logits[:, :-1], labels)
+    # SURVEY Appendix A.2 known answer for the DDPO index sets
+    sh = labels[:, 1:].clone()
+    sh[sh == -100] = 0
+    c, r = O.get_diff_ids(sh[0].tolist(), sh[2].tolist(), 3)
+    assert c == ka["lp.ddpo_c0"].tolist() and r == ka["lp.ddpo_r0"].tolist()
+    assert c == [5, 6] or set([5, 6]).issubset(c)
+    assert set(r) >= {5, 6, 7}
+
+
+def test_merge_known_answer(ka):
+    fe, fm, fl, pos, imap = O.merge_input_ids_with_image_features(
+        t(ka, "mg.feats"), t(ka, "mg.emb"), t(ka, "mg.ids"), t(ka, "mg.am"), t(ka, "mg.lab"),
+        image_token_index=50, pad_token_id=99)
+    assert torch.equal(fe, t(ka, "mg.out_emb"))
+    assert torch.equal(fm, t(ka, "mg.out_mask"))
+    assert torch.equal(fl, t(ka, "mg.out_labels"))
+    assert torch.equal(pos, t(ka, "mg.out_pos"))
+    assert torch.equal(imap, t(ka, "mg.out_map"))
+    assert fm[0].tolist() == [1, 1, 1, 1, 1, 1, 1, 1, 0, 0]
+    assert pos[0].tolist() == [0, 1, 2, 3, 4, 5, 6, 7, 1, 1]
+    with pytest.raises(ValueError):
+        O.merge_input_ids_with_image_features(t(ka, "mg.feats")[:1], t(ka, "mg.emb"), t(ka, "mg.ids"), t(ka, "mg.am"),
+                                              t(ka, "mg.lab"), 50, 99)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_forward_matches_reference_composite(case):
+    z, cfg, W, W_ref, batch, rows = load_case(case)
+    # collator + concatenation are integer-exact
+    got = O.collate(rows)
+    for k in ("chosen_input_ids", "chosen_attention_mask", "chosen_labels", "rejected_input_ids",
+              "rejected_labels", "prompt_input_ids", "prompt_attention_mask"):
+        assert torch.equal(got[k], batch[k]), k
+    cb = O.concatenated_inputs(batch)
+    for k in ("concatenated_input_ids", "concatenated_attention_mask", "concatenated_labels"):
+        assert torch.equal(cb[k], t(z, "cat." + k)), k
+    assert cb["concatenated_img_input_dict"]["pixel_values"].shape[0] == 2 * batch["chosen_input_ids"].shape[0]
+    B = batch["chosen_input_ids"].shape[0]
+    with torch.no_grad():
+        logits, labels, aux = O.llava_forward(W, cfg, cb["concatenated_input_ids"], cb["concatenated_attention_mask"],
+                                              cb["concatenated_labels"],
+                                              cb["concatenated_img_input_dict"]["pixel_values"])
+    assert close(aux["vit_feat"], t(z, "vit_feat"))
+    assert close(aux["image_features"][:B], t(z, "image_features"))
+    assert close(aux["merged"], t(z, "merged_embeds"))
+    assert torch.equal(aux["mask"], t(z, "merged_mask"))
+    assert torch.equal(labels, t(z, "merged_labels"))
+    assert torch.equal(aux["pos"], t(z, "merged_pos"))
+    assert torch.equal(aux["img_map"], t(z, "image_position_map"))
+    valid = aux["mask"].bool()
+    assert close(aux["hidden"][valid], t(z, "hidden_last")[valid])
+    assert close(logits[valid], t(z, "logits")[valid])
+    lp = O.get_batch_logps(logits, labels)
+    assert torch.allclose(lp, t(z, "policy_logps"), rtol=1e-5, atol=2e-4)
+    assert torch.allclose(O.get_batch_logps(logits, labels, average_log_prob=True), t(z, "policy_logps_avg"), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(O.get_batch_logps(logits, labels, mask_shared_tokens=True), t(z, "policy_logps_ddpo"), rtol=1e-5, atol=2e-4)
+    m = O.ddpo_shared_mask(labels)
+    for b in range(B):
+        assert torch.where(m[b])[0].tolist() == z[f"ddpo_chosen_ids_{b}"].tolist()
+        assert torch.where(m[B + b])[0].tolist() == z[f"ddpo_rejected_ids_{b}"].tolist()
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_losses_all_types(case):
+    z, cfg, W, W_ref, batch, rows = load_case(case)
+    for lt in LOSS_TYPES:
+        with torch.no_grad():
+            pc, pr, _, _ = O.concatenated_forward(W, cfg, batch, lt)
+            rc, rr, _, _ = O.concatenated_forward(W_ref, cfg, batch, lt)
+        key = "ref_logps_ddpo" if lt == "ddpo" else "ref_logps"
+        assert torch.allclose(torch.cat([rc, rr]), t(z, key), rtol=1e-5, atol=2e-4)
+        losses, cr, rrw = O.dpo_loss(pc, pr, rc, rr, cfg["beta"], 0.0, lt)
+        assert torch.allclose(losses, t(z, f"loss_{lt}"), rtol=1e-3, atol=2e-5), lt
+        assert torch.allclose(cr, t(z, f"chosen_rewards_{lt}"), rtol=1e-3, atol=2e-5)
+        assert torch.allclose(rrw, t(z, f"rejected_rewards_{lt}"), rtol=1e-3, atol=2e-5)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_train_step_grads_and_adamw(case):
+    z, cfg, W, W_ref, batch, rows = load_case(case)
+    W0 = W
+    W = {k: v.clone() for k, v in W.items()}
+    state = {}
+    loss, metrics, grads, total = O.dpo_train_step(W, W_ref, cfg, batch, cfg["optim"], state, cfg["beta"])
+    assert abs(float(loss) - float(z["loss_mean_sigmoid"])) < 2e-6 + 1e-5 * abs(float(loss))
+    assert abs(float(total) - float(z["grad_norm"])) < 1e-4 * float(z["grad_norm"])
+    assert abs(float(total) - float(z["clip_total_norm"])) < 1e-4 * float(z["grad_norm"])
+    coef = min(1.0, cfg["optim"]["max_grad_norm"] / (float(total) + 1e-6))
+    ng = 0
+    for k in z.files:
+        if k.startswith("grad."):
+            name = k[5:]
+            exp = t(z, k) * coef          # oracle returns clipped grads
+            g = grads[name]
+            scale = float(exp.abs().max()) + 1e-12
+            assert float((g - exp).abs().max()) < 2e-4 * scale + 1e-7, name
+            ng += 1
+    assert ng == len(grads)
+    na = 0
+    for k in z.files:
+        if k.startswith("after_step.") :
+            name = k[len("after_step."):]
+            # Adam's first step is +-lr wherever |g| >> eps, so elements whose gradient is at the 1e-7 noise
+            # floor (below eps=1e-6) legitimately differ by O(lr*noise/eps): compare the UPDATE in L2
+            upd = t(z, k) - W0[name]
+            assert float(((W[name] - W0[name]) - upd).norm()) <= 1e-3 * float(upd.norm()) + 1e-9, name
+            assert float((W[name] - t(z, k)).abs().max()) <= 0.02 * cfg["optim"]["lr"], name
+            na += 1
+    assert na > 0
+    sq = sum(float((W[n].double() ** 2).sum()) for n in O.trainable_names(W))
+    assert abs(sq - float(z["after_step_sqnorm"])) < 1e-6 * sq
+    exp_keys = {"rewards/chosen", "rewards/rejected", "rewards/accuracies", "rewards/margins", "logps/rejected",
+                "logps/chosen", "logits/rejected", "logits/chosen"}
+    assert set(metrics) == exp_keys
+
+
+def test_bf16_emulation_close_to_fp32():
+    z, cfg, W, W_ref, batch, rows = load_case("llava_hipsmall")
+    with torch.no_grad():
+        l32, _ = O.compute_loss(W, W_ref, cfg, batch, cfg["beta"])
+        l16, _ = O.compute_loss(W, W_ref, cfg, batch, cfg["beta"], emulate_bf16=True)
+    assert abs(float(l32) - float(l16)) < 0.05
