@@ -1,0 +1,159 @@
+/* vlr.h - C ABI of libvlr_hip.so, the MI355X (gfx950) DPO-step library.
+ *
+ * Drop-in boundary.  The reference (TideDra/VL-RLHF) has no FFI: its hot path is Python that
+ * bottoms out in torch/transformers/trl native code.  These entry points are what a binding for that path binds
+ * instead; each cites the reference interface (file:line under /root/reference) whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless said otherwise; "bf16" tensors are raw uint16 bit patterns;
+ *   - row-major, leading dimensions (`ld*`) in ELEMENTS; no allocation inside: the caller passes workspaces;
+ *   - every function enqueues on `stream` and returns immediately: 0 = ok, non-zero = error, message from
+ *     vlr_last_error() (thread-local).  Argument errors map to Python ValueError in the host mirror;
+ *   - thread-compatible, not thread-safe per stream; one process per GPU.
+ */
+#ifndef VLR_H
+#define VLR_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* vlr_stream_t; /* == hipStream_t */
+
+const char* vlr_last_error(void);
+int vlr_abi_version(void);
+
+/* ---- GEMM (replaces torch.nn.functional.linear / its autograd on cuBLAS: every nn.Linear under
+ *      LlavaForRL.forward, src/vlrlhf/models/Llava/__init__.py:178,191,232) --------------------------------------
+ * layout 0 (NT): C[M,N] = A[M,K] . B[N,K]^T         forward   y = x W^T
+ * layout 1 (NN): C[M,N] = A[M,K] . B[K,N]           dgrad     dx = dy W
+ * layout 2 (TN): C[M,N] = A[K,M]^T . B[K,N]         wgrad     dW = dy^T x
+ * epilogue: v = act(acc + bias[n]) + residual[m,n] (+ C[m,n] if accumulate); act 0 none, 1 quick_gelu, 2 gelu(erf).
+ * C is bf16 (out_f32 = 0) or fp32. */
+int vlr_gemm_bf16(int layout, const void* A, const void* B, void* C, const void* bias, const void* residual, int M,
+                  int N, int K, int lda, int ldb, int ldc, int ldr, int act, int accumulate, int out_f32,
+                  vlr_stream_t stream);
+
+/* ---- normalisation / activations (transformers LlamaRMSNorm, CLIP LayerNorm, SwiGLU, GELU; call sites
+ *      Llava/__init__.py:178-191,232) ------------------------------------------------------------------------- */
+int vlr_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int M, int H, float eps, vlr_stream_t stream);
+int vlr_rmsnorm_bwd_workspace_bytes(int H);
+int vlr_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
+                    void* dw, int dw_accumulate, void* workspace, int M, int H, vlr_stream_t stream);
+int vlr_layernorm_fwd(const void* x, const void* w, const void* b, void* y, int M, int D, float eps, vlr_stream_t stream);
+int vlr_vit_embed_ln(const void* patch_embeds, const void* cls, const void* pos, const void* w, const void* b, void* y,
+                     int n_img, int T, int D, float eps, vlr_stream_t stream);
+int vlr_im2col(const float* pixel_values, void* patches, int n_img, int image_size, int patch, int Kp, vlr_stream_t stream);
+int vlr_rope_table(float* cos_t, float* sin_t, int max_pos, int head_dim, float theta, vlr_stream_t stream);
+int vlr_rope(void* qkv, const int* pos, const float* cos_t, const float* sin_t, int M, int H, int head_dim, int ld,
+             int max_pos, int backward, vlr_stream_t stream);
+int vlr_swiglu_fwd(const void* gate_up, void* act, int M, int I, vlr_stream_t stream);
+int vlr_swiglu_bwd(void* gate_up_inout, const void* dact, int M, int I, vlr_stream_t stream);
+int vlr_gelu_fwd(const void* z, void* h, long n, vlr_stream_t stream);
+int vlr_gelu_bwd(const void* z, const void* dh, void* dz, long n, vlr_stream_t stream);
+int vlr_colsum_workspace_bytes(int C);
+int vlr_colsum(const void* X, int R, int C, int ld, void* out, int accumulate, void* workspace, vlr_stream_t stream);
+int vlr_gather_rows(const void* src, const int* rows, void* dst, int R, int H, vlr_stream_t stream);
+int vlr_scatter_rows(const void* src, const int* rows, void* dst, int R, int H, vlr_stream_t stream);
+int vlr_cast_f32_to_bf16(const float* src, void* dst, long n, vlr_stream_t stream);
+int vlr_cast_bf16_to_f32(const void* src, float* dst, long n, vlr_stream_t stream);
+int vlr_rowdot(const void* X, const float* v, float* out, int M, int H, vlr_stream_t stream);
+
+/* ---- attention (transformers LlamaAttention / CLIPAttention, eager semantics: fp32 softmax, causal + key padding
+ *      for the decoder, full for the ViT; replaces flash-attn 2.5.8 too, utils/auto_load.py:49-56,534) -------------
+ * q/k/v: column blocks of a fused [batch*S][ld] buffer (head h = columns h*head_dim..).  lse: [batch][heads][Sp]
+ * floats, Sp = S rounded up to 64, log2 domain.  key_mask: [batch][S] int32 (0 = padded key) or NULL. */
+int vlr_attn_fwd(const void* q, const void* k, const void* v, int ld, void* o, int ldo, float* lse,
+                 const int* key_mask, int batch, int S, int heads, int head_dim, int causal, float scale,
+                 vlr_stream_t stream);
+int vlr_attn_bwd(const void* q, const void* k, const void* v, int ld, const void* o, const void* dout, int ldo,
+                 const float* lse, float* delta_ws, const int* key_mask, void* dq, void* dk, void* dv, int ldd,
+                 int batch, int S, int heads, int head_dim, int causal, float scale, vlr_stream_t stream);
+
+/* ---- image/text merge (LlavaForRL._merge_input_ids_with_image_features, Llava/__init__.py:36-109) ---------------
+ * info[0] receives the number of image slots found; the caller compares it with n_feat_rows*dup and raises the
+ * reference's ValueError (:90-94) on mismatch.  `dup` = how many batch halves share one feature table (the
+ * reference duplicates every image, base/trainer.py:138-142; the frozen ViT runs once per distinct image here). */
+int vlr_merge_index(const long* input_ids, const long* attention_mask, const long* labels, int Bn, int T, int S, int P,
+                    int image_token, int pad_token, int n_feat_rows, int dup, int* src, int* out_mask,
+                    long* out_labels, int* out_pos, unsigned char* img_map, int* inv_map, int* info, vlr_stream_t stream);
+int vlr_merge_fwd(const int* src, const long* input_ids, const void* embed_table, const void* feats, void* out, int Bn,
+                  int T, int S, int H, vlr_stream_t stream);
+int vlr_merge_bwd(const void* dmerged, const int* src, const int* inv_map, const long* input_ids, void* dfeats,
+                  void* dembed_table, int Bn, int T, int S, int H, int n_feat_rows, int dup, vlr_stream_t stream);
+
+/* ---- log-probabilities (VLDPOTrainer.get_batch_logps, base/trainer.py:148-188) ------------------------------- */
+int vlr_build_rows(const long* labels, const unsigned char* shared_mask, int Bn, int S, int label_pad, int* rows,
+                   int* tgt, int* seq_off, vlr_stream_t stream);
+int vlr_logp_rows(const float* logits, const int* row_idx, const int* tgt, int R, int V, long ld, float* tok_logp,
+                  float* lse, vlr_stream_t stream);
+int vlr_dlogits_rows(const float* logits, const int* tgt, const float* lse, const int* seq_off, int nseq,
+                     const float* dlogps, int average, int R, int V, long ld, void* dlogits, long ldd,
+                     vlr_stream_t stream);
+int vlr_seq_sum(const float* tok_logp, const int* seq_off, int nseq, int average, float* out, vlr_stream_t stream);
+
+/* ---- DPO loss, forward + backward (VLDPOTrainer.dpo_loss, base/trainer.py:244-301).
+ * loss_type 0 sigmoid|ddpo, 1 hinge, 2 ipo, 3 kto_pair (losses has 2n entries).  dpc/dpr = d(sum_i g_i*loss_i)/d
+ * policy_{chosen,rejected}_logps with g = grad_losses or 1/len(losses) when NULL (trl: loss = losses.mean()). */
+int vlr_dpo_loss(const float* pc, const float* pr, const float* rc, const float* rr, int n, float beta,
+                 float label_smoothing, int loss_type, int reference_free, float* losses, float* chosen_rewards,
+                 float* rejected_rewards, float* dpc, float* dpr, float* loss_mean, const float* grad_losses,
+                 vlr_stream_t stream);
+
+/* ---- optimizer on flat buffers (torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW as driven by the HF Trainer;
+ *      hyper-parameters scripts/dpo_llava.sh:35-41).  out3 = {grad norm, clip coefficient * gscale, raw sum g^2};
+ *      vlr_adamw_step reads coef[1] on the device (no host sync). */
+int vlr_grad_sqnorm_workspace_bytes(void);
+int vlr_grad_sqnorm(const void* grads, long n, float max_norm, float gscale, float extra_sq, void* workspace,
+                    float* out3, vlr_stream_t stream);
+int vlr_adamw_step(float* master, float* m, float* v, const void* grads, void* params_bf16, long n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int step, const float* coef,
+                   vlr_stream_t stream);
+
+/* ---- composed passes (transformers LlamaDecoderLayer / CLIPEncoderLayer forward + autograd backward) ---------- */
+typedef struct {
+    int hidden, inter, heads, head_dim;
+    float rms_eps;
+    int max_pos;            /* rows of the rope tables */
+    const float* rope_cos;  /* [max_pos][head_dim/2] */
+    const float* rope_sin;
+} vlr_llama_cfg;
+typedef struct {  /* bf16 weights of one decoder layer; q|k|v and gate|up are stored fused */
+    const void* ln1; const void* wqkv; const void* wo; const void* ln2; const void* wgu; const void* wdown;
+} vlr_layer_weights;
+typedef struct {  /* bf16 gradient buffers, same shapes */
+    void* ln1; void* wqkv; void* wo; void* ln2; void* wgu; void* wdown;
+} vlr_layer_grads;
+typedef struct {  /* activations one layer keeps for its backward (caller-allocated) */
+    void* xn1; float* rstd1; void* qkv; void* attn; float* lse; void* x_mid; void* xn2; float* rstd2; void* gu;
+    void* act; void* x_out;
+} vlr_layer_acts;
+typedef struct {  /* scratch shared by all layers in the backward */
+    void* dact; void* dxn; void* dattn; void* dqkv; void* dx_mid; float* delta; void* norm_ws;
+} vlr_layer_bwd_ws;
+
+int vlr_decoder_layer_fwd(const vlr_llama_cfg* cfg, const vlr_layer_weights* w, const vlr_layer_acts* a,
+                          const void* x_in, const int* pos, const int* key_mask, int batch, int S,
+                          vlr_stream_t stream);
+int vlr_decoder_layer_bwd(const vlr_llama_cfg* cfg, const vlr_layer_weights* w, const vlr_layer_grads* g,
+                          int accumulate, const vlr_layer_acts* a, const vlr_layer_bwd_ws* ws, const void* x_in,
+                          const void* dx_out, void* dx_in, const int* pos, const int* key_mask, int batch, int S,
+                          vlr_stream_t stream);
+
+typedef struct {
+    int hidden, mlp, heads, head_dim;
+    float ln_eps;
+} vlr_vit_cfg;
+typedef struct {  /* bf16; q|k|v fused [3D][D] + bias [3D] */
+    const void* ln1_w; const void* ln1_b; const void* wqkv; const void* bqkv; const void* wo; const void* bo;
+    const void* ln2_w; const void* ln2_b; const void* w1; const void* b1; const void* w2; const void* b2;
+} vlr_vit_layer_weights;
+typedef struct { void* xn; void* qkv; void* attn; void* h; } vlr_vit_ws;   /* [M][D], [M][3D], [M][D], [M][mlp] */
+int vlr_vit_layer_fwd(const vlr_vit_cfg* cfg, const vlr_vit_layer_weights* w, const vlr_vit_ws* ws, void* x_inout,
+                      int n_img, int T, vlr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,616 @@
+"""Kernel-level parity: every vlr_* entry point (called through the C ABI) against a plain PyTorch fp32 reference of
+the same op / the CPU oracle, on seeded inputs.  Needs a real MI355X:  pytest -m gpu"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import llava_dpo_oracle as O  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope="module")
+def hip():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from vlrlhf import _hip
+    _hip.lib()
+    return _hip
+
+
+DEV = "cuda"
+
+
+def rnd(*shape, scale=1.0, seed=0, dtype=torch.bfloat16):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(DEV)
+
+
+def relerr(a, b):
+    a, b = a.float(), b.float()
+    return float((a - b).abs().max()) / (float(b.abs().max()) + 1e-12)
+
+
+def check(a, b, tol, what=""):
+    e = relerr(a, b)
+    assert math.isfinite(e) and e <= tol, f"{what}: rel err {e:.3e} > {tol:.1e}"
+
+
+# ---------------------------------------------------------------------------------------------------- GEMM
+GEMM_SHAPES = [(256, 256, 128), (128, 128, 64), (200, 136, 72), (1000, 512, 320), (96, 1032, 256), (2048, 4096, 1024)]
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("shape", GEMM_SHAPES)
+def test_gemm_layouts(hip, layout, shape):
+    M, N, K = shape
+    if layout == 2 and (M % 4 or N % 4):
+        pytest.skip("alignment")
+    a = rnd(M, K, seed=1)
+    b = rnd(N, K, seed=2)
+    ref = a.float() @ b.float().t()
+    A = a if layout != 2 else a.t().contiguous()           # TN: A stored [K][M]
+    Bm = b if layout == 0 else b.t().contiguous()          # NN/TN: B stored [K][N]
+    lda = K if layout != 2 else M
+    ldb = K if layout == 0 else N
+    c = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    hip.call("vlr_gemm_bf16", layout, A, Bm, c, None, None, M, N, K, lda, ldb, N, 0, 0, 0, 0)
+    torch.cuda.synchronize()
+    check(c, ref, 8e-3, f"gemm layout {layout} {shape}")
+
+
+def test_gemm_asymmetric_identity(hip):
+    """A = I with an asymmetric B catches row/col swaps in the C write (guide rule 16)."""
+    n = 128
+    a = torch.eye(n, dtype=torch.bfloat16, device=DEV)
+    b = (torch.arange(n * n, device=DEV).reshape(n, n) % 251).to(torch.bfloat16)
+    c = torch.empty(n, n, dtype=torch.bfloat16, device=DEV)
+    hip.call("vlr_gemm_bf16", 0, a, b, c, None, None, n, n, n, n, n, n, 0, 0, 0, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(c.float(), b.float().t())
+
+
+def test_gemm_epilogues(hip):
+    M, N, K = 300, 264, 136
+    a, b = rnd(M, K, seed=3, scale=0.3), rnd(N, K, seed=4, scale=0.3)
+    bias, res = rnd(N, seed=5), rnd(M, N, seed=6)
+    base = a.float() @ b.float().t()
+    for act, fn in ((0, lambda x: x), (1, lambda x: x * torch.sigmoid(1.702 * x)), (2, lambda x: F.gelu(x))):
+        c = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        hip.call("vlr_gemm_bf16", 0, a, b, c, bias, res, M, N, K, K, K, N, N, act, 0, 0)
+        torch.cuda.synchronize()
+        check(c, fn(base + bias.float()) + res.float(), 8e-3, f"epilogue act {act}")
+    # accumulate into bf16 C, and fp32 output with accumulate
+    c = rnd(M, N, seed=7)
+    c0 = c.clone()
+    hip.call("vlr_gemm_bf16", 0, a, b, c, None, None, M, N, K, K, K, N, 0, 0, 1, 0)
+    torch.cuda.synchronize()
+    check(c, base + c0.float(), 8e-3, "accumulate bf16")
+    cf = torch.ones(M, N, dtype=torch.float32, device=DEV)
+    hip.call("vlr_gemm_bf16", 0, a, b, cf, bias, None, M, N, K, K, K, N, 0, 0, 1, 1)
+    torch.cuda.synchronize()
+    check(cf, base + bias.float() + 1.0, 1e-4, "fp32 out")
+    # strided C (column block of a wider buffer) - how q|k|v and gate|up are produced
+    wide = torch.zeros(M, 2 * N, dtype=torch.bfloat16, device=DEV)
+    hip.call("vlr_gemm_bf16", 0, a, b, wide[:, N:], None, None, M, N, K, K, K, 2 * N, 0, 0, 0, 0)
+    torch.cuda.synchronize()
+    check(wide[:, N:], base, 8e-3, "strided C")
+    assert float(wide[:, :N].abs().max()) == 0.0
+
+
+def test_gemm_bad_args(hip):
+    a = rnd(8, 8)
+    with pytest.raises(ValueError):
+        hip.call("vlr_gemm_bf16", 7, a, a, a, None, None, 8, 8, 8, 8, 8, 8, 0, 0, 0, 0)
+    with pytest.raises(ValueError):
+        hip.call("vlr_gemm_bf16", 0, a, a, a, None, None, 8, 8, 7, 8, 8, 8, 0, 0, 0, 0)
+
+
+# ------------------------------------------------------------------------------------------------ norms etc.
+@pytest.mark.parametrize("M,H", [(37, 256), (513, 4096), (64, 1024)])
+def test_rmsnorm_fwd_bwd(hip, M, H):
+    x, w, dy, dres = rnd(M, H, seed=1), (1 + 0.1 * rnd(H, seed=2).float()).bfloat16(), rnd(M, H, seed=3), rnd(M, H, seed=4)
+    y = torch.empty_like(x)
+    rstd = torch.empty(M, dtype=torch.float32, device=DEV)
+    hip.call("vlr_rmsnorm_fwd", x, w, y, rstd, M, H, 1e-5)
+    xf = x.float().requires_grad_(True)
+    wf = w.float().requires_grad_(True)
+    ref = O.rms_norm(xf, wf, 1e-5)
+    torch.cuda.synchronize()
+    check(y, ref, 6e-3, "rmsnorm fwd")
+    check(rstd, torch.rsqrt(x.float().pow(2).mean(-1) + 1e-5), 1e-5, "rstd")
+    (ref * dy.float()).sum().backward()
+    ws = torch.empty(hip.helper("vlr_rmsnorm_bwd_workspace_bytes", H), dtype=torch.uint8, device=DEV)
+    dx = torch.empty_like(x)
+    dw = rnd(H, seed=9)
+    dw0 = dw.clone()
+    hip.call("vlr_rmsnorm_bwd", dy, x, w, rstd, dres, dx, dw, 1, ws, M, H)
+    torch.cuda.synchronize()
+    check(dx, xf.grad + dres.float(), 8e-3, "rmsnorm dx")
+    check(dw, wf.grad + dw0.float(), 8e-3, "rmsnorm dw (accumulate)")
+    hip.call("vlr_rmsnorm_bwd", dy, x, w, rstd, None, dx, dw, 0, ws, M, H)
+    torch.cuda.synchronize()
+    check(dx, xf.grad, 8e-3, "rmsnorm dx no residual")
+    check(dw, wf.grad, 8e-3, "rmsnorm dw")
+
+
+def test_layernorm_and_vit_embed(hip):
+    M, D = 77, 1024
+    x, w, b = rnd(M, D, seed=1), rnd(D, seed=2), rnd(D, seed=3)
+    y = torch.empty_like(x)
+    hip.call("vlr_layernorm_fwd", x, w, b, y, M, D, 1e-5)
+    torch.cuda.synchronize()
+    check(y, F.layer_norm(x.float(), (D,), w.float(), b.float(), 1e-5), 8e-3, "layernorm")
+    n, T = 3, 17
+    pe, cls, pos = rnd(n * (T - 1), D, seed=4), rnd(D, seed=5), rnd(T, D, seed=6)
+    out = torch.empty(n * T, D, dtype=torch.bfloat16, device=DEV)
+    hip.call("vlr_vit_embed_ln", pe, cls, pos, w, b, out, n, T, D, 1e-5)
+    torch.cuda.synchronize()
+    emb = torch.cat([cls.float().expand(n, 1, D), pe.float().reshape(n, T - 1, D)], 1) + pos.float()[None]
+    check(out, F.layer_norm(emb, (D,), w.float(), b.float(), 1e-5).reshape(n * T, D), 8e-3, "vit embed+ln")
+
+
+def test_im2col(hip):
+    n, S, Pp = 2, 56, 14
+    Kp = 592
+    px = torch.randn(n, 3, S, S, device=DEV)
+    out = torch.empty(n * 16, Kp, dtype=torch.bfloat16, device=DEV)
+    hip.call("vlr_im2col", px, out, n, S, Pp, Kp)
+    torch.cuda.synchronize()
+    g = S // Pp
+    ref = px.reshape(n, 3, g, Pp, g, Pp).permute(0, 2, 4, 1, 3, 5).reshape(n * g * g, 3 * Pp * Pp)
+    assert torch.equal(out[:, :588], ref.bfloat16())
+    assert float(out[:, 588:].abs().max()) == 0.0
+
+
+def test_rope(hip):
+    B, S, nh, hd = 2, 50, 3, 128
+    H = nh * hd
+    qkv = rnd(B * S, 3 * H, seed=1)
+    pos = torch.randint(0, 300, (B, S), device=DEV, dtype=torch.int32)
+    cos_t = torch.empty(512, hd // 2, dtype=torch.float32, device=DEV)
+    sin_t = torch.empty_like(cos_t)
+    hip.call("vlr_rope_table", cos_t, sin_t, 512, hd, 10000.0)
+    cos, sin = O.rope_tables(pos.cpu().long(), hd)
+    torch.cuda.synchronize()
+    check(cos_t[pos.long()], cos[..., : hd // 2].to(DEV), 2e-4, "cos table")
+    x = qkv.clone()
+    hip.call("vlr_rope", x, pos, cos_t, sin_t, B * S, H, hd, 3 * H, 512, 0)
+    torch.cuda.synchronize()
+    q = qkv[:, :H].float().reshape(B, S, nh, hd).transpose(1, 2).cpu()
+    k = qkv[:, H:2 * H].float().reshape(B, S, nh, hd).transpose(1, 2).cpu()
+    rq = O.apply_rope(q, cos, sin).transpose(1, 2).reshape(B * S, H)
+    rk = O.apply_rope(k, cos, sin).transpose(1, 2).reshape(B * S, H)
+    check(x[:, :H].cpu(), rq, 8e-3, "rope q")
+    check(x[:, H:2 * H].cpu(), rk, 8e-3, "rope k")
+    assert torch.equal(x[:, 2 * H:], qkv[:, 2 * H:])
+    # backward = inverse rotation: applying it to the rotated tensor restores the input
+    hip.call("vlr_rope", x, pos, cos_t, sin_t, B * S, H, hd, 3 * H, 512, 1)
+    torch.cuda.synchronize()
+    check(x, qkv, 1.5e-2, "rope bwd(fwd(x)) == x")
+
+
+def test_swiglu_gelu_colsum_rows(hip):
+    M, I = 123, 1384
+    gu, dact = rnd(M, 2 * I, seed=1), rnd(M, I, seed=2)
+    act = torch.empty(M, I, dtype=torch.bfloat16, device=DEV)
+    hip.call("vlr_swiglu_fwd", gu, act, M, I)
+    g = gu[:, :I].float().requires_grad_(True)
+    u = gu[:, I:].float().requires_grad_(True)
+    ref = F.silu(g) * u
+    torch.cuda.synchronize()
+    check(act, ref, 8e-3, "swiglu fwd")
+    (ref * dact.float()).sum().backward()
+    gu2 = gu.clone()
+    hip.call("vlr_swiglu_bwd", gu2, dact, M, I)
+    torch.cuda.synchronize()
+    check(gu2[:, :I], g.grad, 8e-3, "swiglu dgate")
+    check(gu2[:, I:], u.grad, 8e-3, "swiglu dup")
+    z, dh = rnd(M, 1024, seed=3), rnd(M, 1024, seed=4)
+    h = torch.empty_like(z)
+    hip.call("vlr_gelu_fwd", z, h, z.numel())
+    zf = z.float().requires_grad_(True)
+    r = F.gelu(zf)
+    (r * dh.float()).sum().backward()
+    dz = torch.empty_like(z)
+    hip.call("vlr_gelu_bwd", z, dh, dz, z.numel())
+    torch.cuda.synchronize()
+    check(h, r, 8e-3, "gelu fwd")
+    check(dz, zf.grad, 8e-3, "gelu bwd")
+    ws = torch.empty(hip.helper("vlr_colsum_workspace_bytes", 1024), dtype=torch.uint8, device=DEV)
+    out = rnd(1024, seed=5)
+    out0 = out.clone()
+    hip.call("vlr_colsum", z, M, 1024, 1024, out, 1, ws)
+    torch.cuda.synchronize()
+    check(out, z.float().sum(0) + out0.float(), 8e-3, "colsum")
+    rows = torch.tensor([5, 0, 77, 122], dtype=torch.int32, device=DEV)
+    dst = torch.empty(4, 1024, dtype=torch.bfloat16, device=DEV)
+    hip.call("vlr_gather_rows", z, rows, dst, 4, 1024)
+    back = torch.zeros_like(z)
+    hip.call("vlr_scatter_rows", dst, rows, back, 4, 1024)
+    v = torch.randn(1024, device=DEV)
+    rd = torch.empty(M, device=DEV)
+    hip.call("vlr_rowdot", z, v, rd, M, 1024)
+    torch.cuda.synchronize()
+    assert torch.equal(dst, z[rows.long()])
+    assert torch.equal(back[rows.long()], z[rows.long()]) and float(back.abs().sum()) == float(z[rows.long()].abs().sum())
+    check(rd, z.float() @ v, 1e-4, "rowdot")
+
+
+# ---------------------------------------------------------------------------------------------------- attention
+def ref_attention(q, k, v, causal, key_mask, scale):
+    """q,k,v [B,nh,S,hd] fp32 -> out, probabilities (eager softmax, HF semantics)."""
+    B, nh, S, hd = q.shape
+    s = (q @ k.transpose(-1, -2)) * scale
+    vis = torch.ones(S, S, dtype=torch.bool, device=q.device)
+    if causal:
+        vis = vis.tril()
+    vis = vis[None, None].expand(B, 1, S, S)
+    if key_mask is not None:
+        vis = vis & (key_mask[:, None, None, :] != 0)
+    s = s.masked_fill(~vis, float("-inf"))
+    return torch.softmax(s, -1) @ v
+
+
+@pytest.mark.parametrize("B,S,nh,hd,causal,masked", [
+    (2, 64, 1, 128, True, False), (2, 200, 2, 128, True, True), (1, 831, 2, 128, True, True),
+    (3, 577, 2, 64, False, False), (2, 100, 3, 64, False, False), (1, 129, 1, 128, False, False)])
+def test_attention_fwd(hip, B, S, nh, hd, causal, masked):
+    H = nh * hd
+    qkv = rnd(B * S, 3 * H, seed=11, scale=1.0)
+    km = None
+    if masked:
+        km = torch.ones(B, S, dtype=torch.int32, device=DEV)
+        km[0, S - 13:] = 0                  # right padding
+        if B > 1:
+            km[1, S - 1:] = 0
+    o = torch.full((B * S, H), float("nan"), dtype=torch.bfloat16, device=DEV)
+    Sp = (S + 63) // 64 * 64
+    lse = torch.zeros(B, nh, Sp, dtype=torch.float32, device=DEV)
+    scale = 1.0 / math.sqrt(hd)
+    hip.call("vlr_attn_fwd", qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, o, H, lse, km, B, S, nh, hd, int(causal), scale)
+    torch.cuda.synchronize()
+    q, k, v = (qkv[:, i * H:(i + 1) * H].float().reshape(B, S, nh, hd).transpose(1, 2) for i in range(3))
+    ref = ref_attention(q, k, v, causal, km, scale).transpose(1, 2).reshape(B * S, H)
+    valid = torch.ones(B * S, dtype=torch.bool, device=DEV) if km is None else (km.reshape(-1) != 0)
+    check(o[valid], ref[valid], 1.2e-2, "attention fwd")
+    assert torch.isfinite(o.float()).all()
+    # lse (log2 domain) against the reference logsumexp
+    s = (q @ k.transpose(-1, -2)) * scale
+    vis = torch.ones(S, S, dtype=torch.bool, device=DEV)
+    if causal:
+        vis = vis.tril()
+    vis = vis[None, None].expand(B, 1, S, S)
+    if km is not None:
+        vis = vis & (km[:, None, None, :] != 0)
+    l2 = torch.logsumexp(s.masked_fill(~vis, float("-inf")), -1) / math.log(2.0)
+    check(lse[:, :, :S], l2, 2e-3, "lse")
+    assert torch.isinf(lse[:, :, S:]).all()
+
+
+def test_attention_left_padding_fully_masked_rows(hip):
+    """leading padded keys (merge 'left padding'): queries that see no key give O = 0 and stay finite."""
+    B, S, nh, hd = 1, 96, 1, 128
+    H = nh * hd
+    qkv = rnd(B * S, 3 * H, seed=5)
+    km = torch.ones(B, S, dtype=torch.int32, device=DEV)
+    km[0, :7] = 0
+    o = torch.empty(B * S, H, dtype=torch.bfloat16, device=DEV)
+    lse = torch.zeros(B, nh, 128, dtype=torch.float32, device=DEV)
+    hip.call("vlr_attn_fwd", qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, o, H, lse, km, B, S, nh, hd, 1, 1 / math.sqrt(hd))
+    torch.cuda.synchronize()
+    assert torch.isfinite(o.float()).all() and float(o[:7].abs().max()) == 0.0
+    q, k, v = (qkv[:, i * H:(i + 1) * H].float().reshape(B, S, nh, hd).transpose(1, 2) for i in range(3))
+    ref = ref_attention(q, k, v, True, km, 1 / math.sqrt(hd)).transpose(1, 2).reshape(B * S, H)
+    check(o[7:], ref[7:], 1.2e-2, "left-padded attention")
+
+
+@pytest.mark.parametrize("B,S,nh,masked", [(1, 64, 1, False), (2, 200, 2, True), (1, 333, 1, True)])
+def test_attention_bwd(hip, B, S, nh, masked):
+    hd = 128
+    H = nh * hd
+    qkv = rnd(B * S, 3 * H, seed=21)
+    do = rnd(B * S, H, seed=22)
+    km = None
+    if masked:
+        km = torch.ones(B, S, dtype=torch.int32, device=DEV)
+        km[0, S - 9:] = 0
+        do[S - 9:S] = 0            # padded positions receive no gradient in the real step
+    scale = 1.0 / math.sqrt(hd)
+    Sp = (S + 63) // 64 * 64
+    o = torch.empty(B * S, H, dtype=torch.bfloat16, device=DEV)
+    lse = torch.zeros(B, nh, Sp, dtype=torch.float32, device=DEV)
+    hip.call("vlr_attn_fwd", qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, o, H, lse, km, B, S, nh, hd, 1, scale)
+    dqkv = torch.full((B * S, 3 * H), float("nan"), dtype=torch.bfloat16, device=DEV)
+    delta = torch.zeros(B, nh, Sp, dtype=torch.float32, device=DEV)
+    hip.call("vlr_attn_bwd", qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, o, do, H, lse, delta, km, dqkv, dqkv[:, H:],
+             dqkv[:, 2 * H:], 3 * H, B, S, nh, hd, 1, scale)
+    torch.cuda.synchronize()
+    x = qkv.float().requires_grad_(True)
+    q, k, v = (x[:, i * H:(i + 1) * H].reshape(B, S, nh, hd).transpose(1, 2) for i in range(3))
+    ref = ref_attention(q, k, v, True, km, scale).transpose(1, 2).reshape(B * S, H)
+    (ref * do.float()).sum().backward()
+    g = x.grad
+    valid = torch.ones(B * S, dtype=torch.bool, device=DEV) if km is None else (km.reshape(-1) != 0)
+    check(dqkv[valid][:, :H], g[valid][:, :H], 2e-2, "dq")
+    check(dqkv[valid][:, H:2 * H], g[valid][:, H:2 * H], 2e-2, "dk")
+    check(dqkv[valid][:, 2 * H:], g[valid][:, 2 * H:], 2e-2, "dv")
+    assert torch.isfinite(dqkv.float()).all()
+    if km is not None:   # padded keys get exactly zero dk / dv
+        assert float(dqkv[~valid][:, H:].abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------- merge
+def test_merge_matches_oracle(hip):
+    H, P, V, image_token, model_pad = 64, 5, 90, 80, 81
+    g = torch.Generator().manual_seed(3)
+    Bh, T = 3, 12
+    ids_h = torch.randint(3, 80, (Bh, T), generator=g)
+    ids_h[:, 0] = 1
+    for b in range(Bh):
+        ids_h[b, 2 + b] = image_token
+    # chosen / rejected halves share the prompt (and the image); ragged right padding with 0
+    ids = torch.cat([ids_h, ids_h.clone()], 0)
+    ids[Bh:, 8:] = torch.randint(3, 80, (Bh, T - 8), generator=g)
+    am = torch.ones_like(ids)
+    ids[1, 10:] = 0
+    am[1, 10:] = 0
+    ids[4, 9:] = 0
+    am[4, 9:] = 0
+    lab = ids.clone()
+    lab[:, :6] = -100
+    lab[am == 0] = -100
+    table = rnd(V, H, seed=1)
+    feats = rnd(Bh * P, H, seed=2)                     # deduplicated: one feature set per distinct image
+    S = T - 1 + P
+    Bn = 2 * Bh
+    src = torch.empty(Bn, S, dtype=torch.int32, device=DEV)
+    omask = torch.empty(Bn, S, dtype=torch.int32, device=DEV)
+    olab = torch.empty(Bn, S, dtype=torch.int64, device=DEV)
+    opos = torch.empty(Bn, S, dtype=torch.int32, device=DEV)
+    imap = torch.empty(Bn, S, dtype=torch.uint8, device=DEV)
+    inv = torch.empty(2, Bh * P, dtype=torch.int32, device=DEV)
+    info = torch.zeros(2, dtype=torch.int32, device=DEV)
+    idd, amd, labd = ids.to(DEV), am.to(DEV), lab.to(DEV)
+    hip.call("vlr_merge_index", idd, amd, labd, Bn, T, S, P, image_token, model_pad, Bh * P, 2, src, omask, olab, opos, imap, inv, info)
+    out = torch.empty(Bn, S, H, dtype=torch.bfloat16, device=DEV)
+    hip.call("vlr_merge_fwd", src, idd, table, feats, out, Bn, T, S, H)
+    torch.cuda.synchronize()
+    f2 = torch.cat([feats, feats], 0).float().cpu().reshape(Bn, P, H)
+    emb = table.float().cpu()[ids]
+    e, m, l, p, mp = O.merge_input_ids_with_image_features(f2, emb, ids, am, lab, image_token, model_pad)
+    assert int(info[0]) == Bn * P
+    assert torch.equal(out.float().cpu(), e)
+    assert torch.equal(omask.cpu().long(), m) and torch.equal(olab.cpu(), l) and torch.equal(opos.cpu().long(), p)
+    assert torch.equal(imap.cpu().bool(), mp)
+    # backward: d_feats sums the two halves, d_table scatter-adds duplicates
+    dm = rnd(Bn, S, H, seed=4)
+    dfe = torch.empty_like(feats)
+    dtab = torch.zeros_like(table)
+    hip.call("vlr_merge_bwd", dm, src, inv, idd, dfe, dtab, Bn, T, S, H, Bh * P, 2)
+    torch.cuda.synchronize()
+    embg = emb.clone().requires_grad_(True)
+    fg = feats.float().cpu().clone().requires_grad_(True)
+    e2, *_ = O.merge_input_ids_with_image_features(torch.cat([fg, fg], 0).reshape(Bn, P, H), embg, ids, am, lab, image_token, model_pad)
+    (e2 * dm.float().cpu()).sum().backward()
+    check(dfe.cpu(), fg.grad, 1e-2, "merge d_feats")
+    tg = torch.zeros(V, H).index_add_(0, ids.reshape(-1), embg.grad.reshape(-1, H))
+    check(dtab.cpu(), tg, 2e-2, "merge d_table")
+    # a wrong image count is reported through info[0]
+    info.zero_()
+    hip.call("vlr_merge_index", idd, amd, labd, Bn, T, S, P, image_token, model_pad, (Bh - 1) * P, 2, src, omask, olab, opos, imap, inv, info)
+    torch.cuda.synchronize()
+    assert int(info[0]) != (Bh - 1) * P * 2
+
+
+# ---------------------------------------------------------------------------------------------------- logps / loss
+@pytest.mark.parametrize("average", [0, 1])
+def test_logps_pipeline(hip, average):
+    Bn, S, V = 4, 37, 264
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn(Bn, S, V, generator=g) * 3
+    labels = torch.randint(0, V, (Bn, S), generator=g)
+    labels[:, :9] = -100
+    labels[1, 30:] = -100
+    labels[3, 20:] = -100
+    ref = O.get_batch_logps(logits, labels, average_log_prob=bool(average))
+    ld, lb = logits.to(DEV), labels.to(DEV)
+    rows = torch.empty(Bn * S, dtype=torch.int32, device=DEV)
+    tgt = torch.empty(Bn * S, dtype=torch.int32, device=DEV)
+    seq_off = torch.empty(Bn + 1, dtype=torch.int32, device=DEV)
+    hip.call("vlr_build_rows", lb, None, Bn, S, -100, rows, tgt, seq_off)
+    torch.cuda.synchronize()
+    R = int(seq_off[-1])
+    mask = labels[:, 1:] != -100
+    assert R == int(mask.sum())
+    exp_rows = torch.nonzero(F.pad(mask, (0, 1)).reshape(-1)).squeeze(1)
+    assert torch.equal(rows[:R].cpu().long(), exp_rows)
+    tok = torch.empty(R, device=DEV)
+    lse = torch.empty(R, device=DEV)
+    hip.call("vlr_logp_rows", ld, rows, tgt, R, V, V, tok, lse)
+    out = torch.empty(Bn, device=DEV)
+    hip.call("vlr_seq_sum", tok, seq_off, Bn, average, out)
+    torch.cuda.synchronize()
+    assert torch.allclose(out.cpu(), ref, rtol=1e-5, atol=1e-4)
+    # backward: d logits
+    lg = logits.clone().requires_grad_(True)
+    dl_up = torch.randn(Bn, generator=g)
+    (O.get_batch_logps(lg, labels, average_log_prob=bool(average)) * dl_up).sum().backward()
+    compact = ld.reshape(-1, V)[rows[:R].long()].contiguous()
+    dlog = torch.empty(R, V, dtype=torch.bfloat16, device=DEV)
+    hip.call("vlr_dlogits_rows", compact, tgt, lse, seq_off, Bn, dl_up.to(DEV), average, R, V, V, dlog, V)
+    torch.cuda.synchronize()
+    check(dlog.cpu(), lg.grad.reshape(-1, V)[exp_rows], 8e-3, "dlogits")
+
+
+def test_ddpo_shared_mask_rows(hip):
+    Bn, S = 4, 20
+    g = torch.Generator().manual_seed(2)
+    labels = torch.randint(3, 30, (Bn, S), generator=g)
+    labels[2] = labels[0]
+    labels[2, 12:15] = torch.tensor([31, 32, 33])
+    labels[:, :6] = -100
+    shared = O.ddpo_shared_mask(labels)
+    rows = torch.empty(Bn * S, dtype=torch.int32, device=DEV)
+    tgt = torch.empty(Bn * S, dtype=torch.int32, device=DEV)
+    seq_off = torch.empty(Bn + 1, dtype=torch.int32, device=DEV)
+    hip.call("vlr_build_rows", labels.to(DEV), shared.to(torch.uint8).to(DEV), Bn, S, -100, rows, tgt, seq_off)
+    torch.cuda.synchronize()
+    keep = (labels[:, 1:] != -100) & shared
+    assert seq_off.cpu().tolist() == [0] + torch.cumsum(keep.sum(-1), 0).tolist()
+
+
+LOSS_IDS = {"sigmoid": 0, "ddpo": 0, "hinge": 1, "ipo": 2, "kto_pair": 3}
+
+
+@pytest.mark.parametrize("loss_type", list(LOSS_IDS))
+@pytest.mark.parametrize("ls,rf", [(0.0, False), (0.2, True)])
+def test_dpo_loss_fwd_bwd(hip, loss_type, ls, rf):
+    n, beta = 6, 0.3
+    g = torch.Generator().manual_seed(7)
+    pc, pr, rc, rr = [(torch.randn(n, generator=g) * 4 - 30) for _ in range(4)]
+    pcg, prg = pc.clone().requires_grad_(True), pr.clone().requires_grad_(True)
+    losses, cr, rw = O.dpo_loss(pcg, prg, rc, rr, beta, ls, loss_type, rf)
+    losses.mean().backward()
+    nl = losses.numel()
+    d = [t.to(DEV) for t in (pc, pr, rc, rr)]
+    out_l = torch.empty(nl, device=DEV)
+    out = [torch.empty(n, device=DEV) for _ in range(4)]
+    mean = torch.empty(1, device=DEV)
+    hip.call("vlr_dpo_loss", *d, n, beta, ls, LOSS_IDS[loss_type], int(rf), out_l, out[0], out[1], out[2], out[3], mean, None)
+    torch.cuda.synchronize()
+    assert torch.allclose(out_l.cpu(), losses.detach(), rtol=2e-5, atol=2e-6)
+    assert torch.allclose(out[0].cpu(), cr, rtol=1e-5, atol=1e-6) and torch.allclose(out[1].cpu(), rw, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(out[2].cpu(), pcg.grad, rtol=2e-4, atol=2e-7), (out[2].cpu(), pcg.grad)
+    assert torch.allclose(out[3].cpu(), prg.grad, rtol=2e-4, atol=2e-7)
+    assert abs(float(mean) - float(losses.mean())) < 2e-5 * abs(float(losses.mean())) + 1e-6
+    # arbitrary upstream gradient
+    up = torch.randn(nl, generator=g)
+    pcg.grad = prg.grad = None
+    (O.dpo_loss(pcg, prg, rc, rr, beta, ls, loss_type, rf)[0] * up).sum().backward()
+    hip.call("vlr_dpo_loss", *d, n, beta, ls, LOSS_IDS[loss_type], int(rf), out_l, out[0], out[1], out[2], out[3], mean, up.to(DEV))
+    torch.cuda.synchronize()
+    assert torch.allclose(out[2].cpu(), pcg.grad, rtol=2e-4, atol=2e-6)
+    assert torch.allclose(out[3].cpu(), prg.grad, rtol=2e-4, atol=2e-6)
+
+
+def test_dpo_loss_unknown_type(hip):
+    t = torch.zeros(2, device=DEV)
+    with pytest.raises(ValueError, match="Unknown loss type"):
+        hip.call("vlr_dpo_loss", t, t, t, t, 2, 0.1, 0.0, 9, 0, t, t, t, t, t, t, None)
+
+
+# ---------------------------------------------------------------------------------------------------- optimizer
+def test_sqnorm_clip_adamw(hip):
+    n = 8 * 3001
+    g = torch.Generator().manual_seed(1)
+    w = torch.randn(n, generator=g)
+    grads = (torch.randn(n, generator=g) * 0.01).bfloat16()
+    ws = torch.empty(hip.helper("vlr_grad_sqnorm_workspace_bytes"), dtype=torch.uint8, device=DEV)
+    out3 = torch.zeros(3, device=DEV)
+    gd = grads.to(DEV)
+    hip.call("vlr_grad_sqnorm", gd, n, 1.0, 1.0, 0.0, ws, out3)
+    torch.cuda.synchronize()
+    total = float(grads.float().norm())
+    assert abs(float(out3[0]) - total) < 1e-4 * total
+    assert abs(float(out3[1]) - min(1.0, 1.0 / (total + 1e-6))) < 1e-5
+    W = {"a.weight": w.clone()}
+    G = {"a.weight": grads.float().clone()}
+    tot = O.clip_grad_norm_(G, 1.0)
+    state = {}
+    master, m, v = w.clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    p16 = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    hp = dict(lr=1e-3, beta1=0.9, beta2=0.98, eps=1e-6, weight_decay=0.05)
+    for step in (1, 2, 3):
+        O.adamw_step(W, G, state, hp["lr"], hp["beta1"], hp["beta2"], hp["eps"], hp["weight_decay"])
+        hip.call("vlr_adamw_step", master, m, v, gd, p16, n, hp["lr"], hp["beta1"], hp["beta2"], hp["eps"], hp["weight_decay"], step, out3)
+    torch.cuda.synchronize()
+    assert float((master.cpu() - W["a.weight"]).abs().max()) < 3e-6
+    assert torch.equal(p16.cpu(), master.cpu().bfloat16())
+    assert abs(float(tot) - total) < 1e-4 * total
+
+
+# ---------------------------------------------------------------------------------------------------- composed layer
+def test_decoder_layer_fwd_bwd_vs_oracle(hip):
+    """One LLaMA layer through vlr_decoder_layer_fwd/bwd against the CPU oracle with bf16 rounding emulated at the
+    same points, and against fp32 autograd for the gradients."""
+    from vlrlhf import _hip as HH
+    B, S, nh, hd, I = 2, 70, 2, 128, 384
+    H = nh * hd
+    M = B * S
+    cfgo = dict(hidden=H, inter=I, layers=1, heads=nh, vocab=8, rms_eps=1e-5)
+    g = torch.Generator().manual_seed(0)
+    W = {}
+    p = "language_model.model.layers.0."
+    for nm, shp in (("self_attn.q_proj", (H, H)), ("self_attn.k_proj", (H, H)), ("self_attn.v_proj", (H, H)),
+                    ("self_attn.o_proj", (H, H)), ("mlp.gate_proj", (I, H)), ("mlp.up_proj", (I, H)), ("mlp.down_proj", (H, I))):
+        W[p + nm + ".weight"] = (torch.randn(*shp, generator=g) * 0.05).bfloat16().float()
+    W[p + "input_layernorm.weight"] = (1 + 0.1 * torch.randn(H, generator=g)).bfloat16().float()
+    W[p + "post_attention_layernorm.weight"] = (1 + 0.1 * torch.randn(H, generator=g)).bfloat16().float()
+    W["language_model.model.norm.weight"] = torch.ones(H)
+    x = (torch.randn(B, S, H, generator=g)).bfloat16().float()
+    am = torch.ones(B, S, dtype=torch.long)
+    am[1, S - 6:] = 0
+    pos = (am.cumsum(-1) - 1).masked_fill(am == 0, 1)
+    dy = torch.randn(B, S, H, generator=g).bfloat16().float()
+    dy[am == 0] = 0
+    # oracle: fp32 autograd of the bf16-emulated forward (rounding is piecewise constant -> straight-through not needed
+    # for the fp32 reference gradient; use the un-rounded forward for gradients)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in W.items()}
+    xg = x.clone().requires_grad_(True)
+    col = []
+    O.llama_hidden(xg, am, pos, leaves, cfgo, emulate_bf16=False, collect=col)
+    (col[0] * dy).sum().backward()
+    col16 = []
+    with torch.no_grad():
+        O.llama_hidden(x, am, pos, W, cfgo, emulate_bf16=True, collect=col16)
+
+    def dv(t, dt=torch.bfloat16):
+        return t.to(dt).to(DEV).contiguous()
+
+    wqkv = dv(torch.cat([W[p + f"self_attn.{n}_proj.weight"] for n in "qkv"], 0))
+    wgu = dv(torch.cat([W[p + "mlp.gate_proj.weight"], W[p + "mlp.up_proj.weight"]], 0))
+    wo, wdown = dv(W[p + "self_attn.o_proj.weight"]), dv(W[p + "mlp.down_proj.weight"])
+    ln1, ln2 = dv(W[p + "input_layernorm.weight"]), dv(W[p + "post_attention_layernorm.weight"])
+    cos_t = torch.empty(256, hd // 2, device=DEV)
+    sin_t = torch.empty_like(cos_t)
+    hip.call("vlr_rope_table", cos_t, sin_t, 256, hd, 10000.0)
+    cfg = HH.LlamaCfg(H, I, nh, hd, 1e-5, 256, cos_t.data_ptr(), sin_t.data_ptr())
+    lw = HH.LayerWeights(*(t.data_ptr() for t in (ln1, wqkv, wo, ln2, wgu, wdown)))
+    Sp = (S + 63) // 64 * 64
+    bufs = dict(xn1=torch.empty(M, H), rstd1=torch.empty(M, dtype=torch.float32), qkv=torch.empty(M, 3 * H), attn=torch.empty(M, H),
+                lse=torch.zeros(B, nh, Sp, dtype=torch.float32), x_mid=torch.empty(M, H), xn2=torch.empty(M, H),
+                rstd2=torch.empty(M, dtype=torch.float32), gu=torch.empty(M, 2 * I), act=torch.empty(M, I), x_out=torch.empty(M, H))
+    bufs = {k: (v.to(DEV) if v.dtype == torch.float32 and k in ("rstd1", "rstd2", "lse") else v.bfloat16().to(DEV)) for k, v in bufs.items()}
+    la = HH.LayerActs(*(bufs[k].data_ptr() for k in ("xn1", "rstd1", "qkv", "attn", "lse", "x_mid", "xn2", "rstd2", "gu", "act", "x_out")))
+    xin = dv(x.reshape(M, H))
+    posd = pos.to(torch.int32).to(DEV)
+    kmd = am.to(torch.int32).to(DEV)
+    hip.call("vlr_decoder_layer_fwd", cfg, lw, la, xin, posd, kmd, B, S)
+    torch.cuda.synchronize()
+    valid = (am.reshape(-1) != 0)
+    check(bufs["x_out"].cpu()[valid], col16[0].reshape(M, H)[valid], 2e-2, "layer fwd vs bf16-emulated oracle")
+    check(bufs["x_out"].cpu()[valid], col[0].detach().reshape(M, H)[valid], 3e-2, "layer fwd vs fp32 oracle")
+    # backward
+    grads = {k: torch.full_like(t, float("nan")) for k, t in dict(ln1=ln1, wqkv=wqkv, wo=wo, ln2=ln2, wgu=wgu, wdown=wdown).items()}
+    lg = HH.LayerGrads(*(grads[k].data_ptr() for k in ("ln1", "wqkv", "wo", "ln2", "wgu", "wdown")))
+    wsb = dict(dact=torch.empty(M, I), dxn=torch.empty(M, H), dattn=torch.empty(M, H), dqkv=torch.empty(M, 3 * H), dx_mid=torch.empty(M, H))
+    wsb = {k: v.bfloat16().to(DEV) for k, v in wsb.items()}
+    delta = torch.zeros(B, nh, Sp, dtype=torch.float32, device=DEV)
+    nws = torch.empty(hip.helper("vlr_rmsnorm_bwd_workspace_bytes", H), dtype=torch.uint8, device=DEV)
+    lws = HH.LayerBwdWs(wsb["dact"].data_ptr(), wsb["dxn"].data_ptr(), wsb["dattn"].data_ptr(), wsb["dqkv"].data_ptr(),
+                        wsb["dx_mid"].data_ptr(), delta.data_ptr(), nws.data_ptr())
+    dxin = torch.empty(M, H, dtype=torch.bfloat16, device=DEV)
+    hip.call("vlr_decoder_layer_bwd", cfg, lw, lg, 0, la, lws, xin, dv(dy.reshape(M, H)), dxin, posd, kmd, B, S)
+    torch.cuda.synchronize()
+    check(dxin.cpu()[valid], xg.grad.reshape(M, H)[valid], 4e-2, "layer dx")
+    gq = torch.cat([leaves[p + f"self_attn.{n}_proj.weight"].grad for n in "qkv"], 0)
+    ggu = torch.cat([leaves[p + "mlp.gate_proj.weight"].grad, leaves[p + "mlp.up_proj.weight"].grad], 0)
+    check(grads["wqkv"].cpu(), gq, 4e-2, "dWqkv")
+    check(grads["wo"].cpu(), leaves[p + "self_attn.o_proj.weight"].grad, 4e-2, "dWo")
+    check(grads["wgu"].cpu(), ggu, 4e-2, "dWgu")
+    check(grads["wdown"].cpu(), leaves[p + "mlp.down_proj.weight"].grad, 4e-2, "dWdown")
+    check(grads["ln1"].cpu(), leaves[p + "input_layernorm.weight"].grad, 4e-2, "dln1")
+    check(grads["ln2"].cpu(), leaves[p + "post_attention_layernorm.weight"].grad, 4e-2, "dln2")

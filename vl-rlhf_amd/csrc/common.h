@@ -1,0 +1,86 @@
+// Shared device/host helpers for the vlr HIP library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+typedef uint16_t bf16_t;  // raw bf16 bits in HBM
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define VLR_OK 0
+#define VLR_ERR_ARG 1
+#define VLR_ERR_HIP 2
+
+void vlr_set_error(const char* fmt, ...);
+int vlr_check_launch(const char* what);
+
+#define VLR_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            vlr_set_error(__VA_ARGS__);        \
+            return VLR_ERR_ARG;                \
+        }                                      \
+    } while (0)
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
+__device__ __forceinline__ float bf16lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf16hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+// round-to-nearest-even pack of two floats (lowers to v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16(f, 0.f) & 0xffffu); }
+
+__device__ __forceinline__ void unpack8(const u32x4& w, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = bf16lo(w[i]);
+        f[2 * i + 1] = bf16hi(w[i]);
+    }
+}
+__device__ __forceinline__ u32x4 pack8(const float* f) {
+    u32x4 w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = pack_bf16(f[2 * i], f[2 * i + 1]);
+    return w;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+// block-wide sum for blockDim.x multiple of 64 (<= 1024); `red` = 16 floats of LDS
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float t = red[0];
+    for (int i = 1; i < nw; ++i) t = fmaxf(t, red[i]);
+    return t;
+}

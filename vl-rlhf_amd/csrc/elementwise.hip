@@ -1,0 +1,491 @@
+// HBM-bound row / elementwise kernels of the DPO step (gfx950).  All bf16 tensors are moved 16 B per lane
+// (8 elements), arithmetic is fp32, reductions are wave shuffles + one LDS hop.  Algorithmic bytes per element are
+// stated per kernel in DESIGN.md; none of these re-read a tensor.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------------------
+// RMSNorm forward: y = w * x * rsqrt(mean(x^2) + eps); one workgroup per row.  (LlamaRMSNorm, fp32 internal)
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                          bf16_t* __restrict__ y, float* __restrict__ rstd_out, int H,
+                                                          float eps) {
+    __shared__ float red[16];
+    const size_t row = blockIdx.x;
+    const bf16_t* xr = x + row * H;
+    float ss = 0.f;
+    for (int c = threadIdx.x * 8; c < H; c += 256 * 8) {
+        float v[8];
+        unpack8(*reinterpret_cast<const u32x4*>(xr + c), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
+    }
+    ss = block_sum(ss, red);
+    const float rstd = rsqrtf(ss / (float)H + eps);
+    if (threadIdx.x == 0 && rstd_out) rstd_out[row] = rstd;
+    for (int c = threadIdx.x * 8; c < H; c += 256 * 8) {
+        float v[8], g[8];
+        unpack8(*reinterpret_cast<const u32x4*>(xr + c), v);
+        unpack8(*reinterpret_cast<const u32x4*>(w + c), g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = g[e] * (v[e] * rstd);
+        *reinterpret_cast<u32x4*>(y + row * H + c) = pack8(v);
+    }
+}
+
+// RMSNorm backward.  dx = rstd * (dy*w - xhat * mean(dy*w*xhat)) (+ dres), dw partial[j] += dy*xhat.
+// Workgroup b walks rows b, b+G, ...; its dw partial goes to dw_part[b][H] (reduced by reduce_partials_kernel).
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                          const bf16_t* __restrict__ w, const float* __restrict__ rstd,
+                                                          const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
+                                                          float* __restrict__ dw_part, int M, int H) {
+    __shared__ float red[16];
+    constexpr int MAXC = 4;  // H <= 256*8*MAXC = 8192
+    float dwacc[MAXC][8];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dwacc[i][e] = 0.f;
+    for (int row = blockIdx.x; row < M; row += gridDim.x) {
+        const size_t off = (size_t)row * H;
+        const float rs = rstd[row];
+        float dot = 0.f;
+        float gx[MAXC][8], xh[MAXC][8];
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = (i * 256 + threadIdx.x) * 8;
+            if (c < H) {
+                float a[8], b[8], g[8];
+                unpack8(*reinterpret_cast<const u32x4*>(dy + off + c), a);
+                unpack8(*reinterpret_cast<const u32x4*>(x + off + c), b);
+                unpack8(*reinterpret_cast<const u32x4*>(w + c), g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    xh[i][e] = b[e] * rs;
+                    gx[i][e] = a[e] * g[e];
+                    dot += gx[i][e] * xh[i][e];
+                    dwacc[i][e] += a[e] * xh[i][e];
+                }
+            }
+        }
+        dot = block_sum(dot, red) / (float)H;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = (i * 256 + threadIdx.x) * 8;
+            if (c < H) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rs * (gx[i][e] - xh[i][e] * dot);
+                if (dres) {
+                    float r[8];
+                    unpack8(*reinterpret_cast<const u32x4*>(dres + off + c), r);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] += r[e];
+                }
+                *reinterpret_cast<u32x4*>(dx + off + c) = pack8(o);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = (i * 256 + threadIdx.x) * 8;
+        if (c < H) {
+            float* d = dw_part + (size_t)blockIdx.x * H + c;
+            *reinterpret_cast<f32x4*>(d) = f32x4{dwacc[i][0], dwacc[i][1], dwacc[i][2], dwacc[i][3]};
+            *reinterpret_cast<f32x4*>(d + 4) = f32x4{dwacc[i][4], dwacc[i][5], dwacc[i][6], dwacc[i][7]};
+        }
+    }
+}
+
+// out[c] (bf16, optional +=) = sum_p part[p][c]
+__global__ void reduce_partials_kernel(const float* __restrict__ part, int P, int C, bf16_t* __restrict__ out,
+                                       int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += part[(size_t)p * C + c];
+    if (accumulate) s += bf16_to_f32(out[c]);
+    out[c] = f32_to_bf16(s);
+}
+
+// column-sum partials of a bf16 matrix X[R][C] (ld): workgroup (bx, by) sums rows by, by+Gy, ... of 512 columns
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* __restrict__ X, int R, int C, int ld,
+                                                             float* __restrict__ part) {
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 2;
+    if (c >= C) return;
+    float s0 = 0.f, s1 = 0.f;
+    for (int r = blockIdx.y; r < R; r += gridDim.y) {
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(X + (size_t)r * ld + c);
+        s0 += bf16lo(w);
+        s1 += bf16hi(w);
+    }
+    part[(size_t)blockIdx.y * C + c] = s0;
+    part[(size_t)blockIdx.y * C + c + 1] = s1;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// LayerNorm forward (CLIP ViT; frozen tower, no backward).  Optional fused "embedding assemble": when pe != null the
+// input row (b, t) is (t == 0 ? cls : pe[b, t-1]) + pos[t]  (CLIPVisionEmbeddings + pre_layrnorm).
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                            const bf16_t* __restrict__ b, bf16_t* __restrict__ y, int D,
+                                                            float eps, const bf16_t* __restrict__ pe,
+                                                            const bf16_t* __restrict__ cls,
+                                                            const bf16_t* __restrict__ pos, int T) {
+    __shared__ float red[16];
+    const size_t row = blockIdx.x;
+    constexpr int MAXC = 2;  // D <= 4096
+    float v[MAXC][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = (i * 256 + threadIdx.x) * 8;
+        if (c < D) {
+            if (pe) {
+                const int bi = (int)(row / T), ti = (int)(row % T);
+                float a[8], p[8];
+                if (ti == 0) unpack8(*reinterpret_cast<const u32x4*>(cls + c), a);
+                else unpack8(*reinterpret_cast<const u32x4*>(pe + ((size_t)bi * (T - 1) + ti - 1) * D + c), a);
+                unpack8(*reinterpret_cast<const u32x4*>(pos + (size_t)ti * D + c), p);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[i][e] = a[e] + p[e];
+            } else {
+                unpack8(*reinterpret_cast<const u32x4*>(x + row * D + c), v[i]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[i][e];
+        }
+    }
+    const float mean = block_sum(s, red) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = (i * 256 + threadIdx.x) * 8;
+        if (c < D) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = v[i][e] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(block_sum(q, red) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = (i * 256 + threadIdx.x) * 8;
+        if (c < D) {
+            float g[8], bb[8], o[8];
+            unpack8(*reinterpret_cast<const u32x4*>(w + c), g);
+            unpack8(*reinterpret_cast<const u32x4*>(b + c), bb);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + bb[e];
+            *reinterpret_cast<u32x4*>(y + row * D + c) = pack8(o);
+        }
+    }
+}
+
+// raw-embedding variant used by tests / hidden_states parity: x_out = assemble (no norm)
+// ------------------------------------------------------------------------------------------------------------
+// RoPE (rotate-half), in place on the q and k thirds of the fused qkv buffer [M][3H].  cos/sin come from a fp32 table
+// [max_pos][hd/2]; sign = +1 forward, -1 backward (transpose of the rotation).
+// ------------------------------------------------------------------------------------------------------------
+__global__ void rope_table_kernel(float* __restrict__ cos_t, float* __restrict__ sin_t, int max_pos, int half,
+                                  float theta) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= max_pos * half) return;
+    const int p = i / half, f = i % half;
+    const float inv = 1.0f / powf(theta, (float)(2 * f) / (float)(2 * half));
+    const float a = (float)p * inv;
+    cos_t[i] = cosf(a);
+    sin_t[i] = sinf(a);
+}
+
+__global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ qkv, const int* __restrict__ pos,
+                                                   const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                   int M, int H, int hd, int ld, float sign, int max_pos) {
+    // one thread = 8 consecutive frequencies of one head of q or k; (H/hd)*2 heads per row, hd/16 threads per head
+    const int tph = hd / 16;
+    const int per_row = (H / hd) * 2 * tph;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long row = gid / per_row;
+    if (row >= M) return;
+    const int r = (int)(gid % per_row);
+    const int head = r / tph, f0 = (r % tph) * 8;   // head in [0, 2*nh): q heads then k heads
+    const int half = hd / 2;
+    int p = pos[row];
+    p = p < 0 ? 0 : (p >= max_pos ? max_pos - 1 : p);
+    bf16_t* base = qkv + (size_t)row * ld + (size_t)head * hd + f0;   // k third follows q third: head*hd spans both
+    float x1[8], x2[8], c[8], s[8];
+    unpack8(*reinterpret_cast<const u32x4*>(base), x1);
+    unpack8(*reinterpret_cast<const u32x4*>(base + half), x2);
+    const float* cp = cos_t + (size_t)p * half + f0;
+    const float* sp = sin_t + (size_t)p * half + f0;
+    *reinterpret_cast<f32x4*>(c) = *reinterpret_cast<const f32x4*>(cp);
+    *reinterpret_cast<f32x4*>(c + 4) = *reinterpret_cast<const f32x4*>(cp + 4);
+    *reinterpret_cast<f32x4*>(s) = *reinterpret_cast<const f32x4*>(sp);
+    *reinterpret_cast<f32x4*>(s + 4) = *reinterpret_cast<const f32x4*>(sp + 4);
+    float o1[8], o2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float sn = sign * s[e];
+        o1[e] = x1[e] * c[e] - x2[e] * sn;
+        o2[e] = x2[e] * c[e] + x1[e] * sn;
+    }
+    *reinterpret_cast<u32x4*>(base) = pack8(o1);
+    *reinterpret_cast<u32x4*>(base + half) = pack8(o2);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// SwiGLU: gu = [gate | up] fused [M][2I]; act = silu(gate) * up.  Backward overwrites gu with [dgate | dup].
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ act,
+                                                         long M, int I) {
+    const long chunks = (long)M * (I / 8);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (long)gridDim.x * 256) {
+        const long row = i / (I / 8);
+        const int c = (int)(i % (I / 8)) * 8;
+        float g[8], u[8], o[8];
+        unpack8(*reinterpret_cast<const u32x4*>(gu + row * 2 * I + c), g);
+        unpack8(*reinterpret_cast<const u32x4*>(gu + row * 2 * I + I + c), u);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = g[e] / (1.f + __expf(-g[e])) * u[e];
+        *reinterpret_cast<u32x4*>(act + row * I + c) = pack8(o);
+    }
+}
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(bf16_t* __restrict__ gu, const bf16_t* __restrict__ dact,
+                                                         long M, int I) {
+    const long chunks = (long)M * (I / 8);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (long)gridDim.x * 256) {
+        const long row = i / (I / 8);
+        const int c = (int)(i % (I / 8)) * 8;
+        float g[8], u[8], d[8], dg[8], du[8];
+        unpack8(*reinterpret_cast<const u32x4*>(gu + row * 2 * I + c), g);
+        unpack8(*reinterpret_cast<const u32x4*>(gu + row * 2 * I + I + c), u);
+        unpack8(*reinterpret_cast<const u32x4*>(dact + row * I + c), d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float sg = 1.f / (1.f + __expf(-g[e]));
+            du[e] = d[e] * g[e] * sg;
+            dg[e] = d[e] * u[e] * sg * (1.f + g[e] * (1.f - sg));
+        }
+        *reinterpret_cast<u32x4*>(gu + row * 2 * I + c) = pack8(dg);
+        *reinterpret_cast<u32x4*>(gu + row * 2 * I + I + c) = pack8(du);
+    }
+}
+
+// GELU (erf) forward / backward for the projector (z kept for backward)
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16_t* __restrict__ z, bf16_t* __restrict__ h, long n8) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        float v[8];
+        unpack8(*reinterpret_cast<const u32x4*>(z + i * 8), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752f));
+        *reinterpret_cast<u32x4*>(h + i * 8) = pack8(v);
+    }
+}
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict__ z, const bf16_t* __restrict__ dh,
+                                                       bf16_t* __restrict__ dz, long n8) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        float v[8], d[8];
+        unpack8(*reinterpret_cast<const u32x4*>(z + i * 8), v);
+        unpack8(*reinterpret_cast<const u32x4*>(dh + i * 8), d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float cdf = 0.5f * (1.f + erff(v[e] * 0.70710678118654752f));
+            const float pdf = 0.3989422804014327f * __expf(-0.5f * v[e] * v[e]);
+            d[e] *= cdf + v[e] * pdf;
+        }
+        *reinterpret_cast<u32x4*>(dz + i * 8) = pack8(d);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// im2col for the CLIP patch embedding: pixel_values fp32 [n][3][S][S] -> patches bf16 [n*g*g][Kp], column order
+// (c, py, px) = Conv2d weight.reshape(D, 3*P*P); columns >= 3*P*P are zero padding up to Kp (multiple of 8).
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ px, bf16_t* __restrict__ out, int n,
+                                                     int S, int P, int Kp) {
+    const int g = S / P;
+    const long total = (long)n * g * g * Kp;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int k = (int)(i % Kp);
+        const long pr = i / Kp;
+        float v = 0.f;
+        if (k < 3 * P * P) {
+            const int c = k / (P * P), py = (k / P) % P, pxx = k % P;
+            const int gi = (int)(pr % (g * g));
+            const long img = pr / (g * g);
+            const int y = (gi / g) * P + py, x = (gi % g) * P + pxx;
+            v = px[((img * 3 + c) * S + y) * S + x];
+        }
+        out[i] = f32_to_bf16(v);
+    }
+}
+
+// generic helpers -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restrict__ src, const int* __restrict__ rows,
+                                                          bf16_t* __restrict__ dst, int R, int H) {
+    const int r = blockIdx.x;
+    const size_t s = (size_t)rows[r] * H;
+    for (int c = threadIdx.x * 8; c < H; c += 256 * 8)
+        *reinterpret_cast<u32x4*>(dst + (size_t)r * H + c) = *reinterpret_cast<const u32x4*>(src + s + c);
+}
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const bf16_t* __restrict__ src, const int* __restrict__ rows,
+                                                           bf16_t* __restrict__ dst, int R, int H) {
+    const int r = blockIdx.x;
+    const size_t d = (size_t)rows[r] * H;
+    for (int c = threadIdx.x * 8; c < H; c += 256 * 8)
+        *reinterpret_cast<u32x4*>(dst + d + c) = *reinterpret_cast<const u32x4*>(src + (size_t)r * H + c);
+}
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = f32_to_bf16(src[i]);
+}
+__global__ __launch_bounds__(256) void bf16_to_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = bf16_to_f32(src[i]);
+}
+// out[r] = sum_c X[r][c] * v[c]   (used for the logits-mean metric: mean_v(h . W_v) = h . mean_v W_v)
+__global__ __launch_bounds__(256) void rowdot_kernel(const bf16_t* __restrict__ X, const float* __restrict__ v,
+                                                     float* __restrict__ out, int H) {
+    __shared__ float red[16];
+    const size_t row = blockIdx.x;
+    float s = 0.f;
+    for (int c = threadIdx.x * 8; c < H; c += 256 * 8) {
+        float a[8];
+        unpack8(*reinterpret_cast<const u32x4*>(X + row * H + c), a);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += a[e] * v[c + e];
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[row] = s;
+}
+
+// ============================================================================================================
+static inline int grid_for(long n, int per_block, int cap = 256 * 16) {
+    long g = (n + per_block - 1) / per_block;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+extern "C" int vlr_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int M, int H, float eps,
+                               hipStream_t st) {
+    VLR_REQUIRE(M > 0 && H > 0 && H % 8 == 0, "vlr_rmsnorm_fwd: bad shape M=%d H=%d", M, H);
+    hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(M), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y,
+                       rstd, H, eps);
+    return vlr_check_launch("vlr_rmsnorm_fwd");
+}
+
+#define VLR_NORM_BWD_BLOCKS 256
+extern "C" int vlr_rmsnorm_bwd_workspace_bytes(int H) { return VLR_NORM_BWD_BLOCKS * H * 4; }
+
+extern "C" int vlr_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres,
+                               void* dx, void* dw, int dw_accumulate, void* workspace, int M, int H, hipStream_t st) {
+    VLR_REQUIRE(M > 0 && H % 8 == 0 && H <= 8192, "vlr_rmsnorm_bwd: bad shape M=%d H=%d (H<=8192)", M, H);
+    VLR_REQUIRE(workspace, "vlr_rmsnorm_bwd: workspace of vlr_rmsnorm_bwd_workspace_bytes(H) required");
+    const int G = M < VLR_NORM_BWD_BLOCKS ? M : VLR_NORM_BWD_BLOCKS;
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(G), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x,
+                       (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, (float*)workspace, M, H);
+    if (dw)
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((H + 255) / 256), dim3(256), 0, st, (const float*)workspace, G, H,
+                           (bf16_t*)dw, dw_accumulate);
+    return vlr_check_launch("vlr_rmsnorm_bwd");
+}
+
+#define VLR_COLSUM_ROWS 64
+extern "C" int vlr_colsum_workspace_bytes(int C) { return VLR_COLSUM_ROWS * C * 4; }
+extern "C" int vlr_colsum(const void* X, int R, int C, int ld, void* out, int accumulate, void* workspace,
+                          hipStream_t st) {
+    VLR_REQUIRE(R > 0 && C > 0 && C % 2 == 0 && ld % 2 == 0 && workspace, "vlr_colsum: bad args R=%d C=%d", R, C);
+    const int gy = R < VLR_COLSUM_ROWS ? R : VLR_COLSUM_ROWS;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((C / 2 + 255) / 256, gy), dim3(256), 0, st, (const bf16_t*)X, R, C, ld,
+                       (float*)workspace);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)workspace, gy, C,
+                       (bf16_t*)out, accumulate);
+    return vlr_check_launch("vlr_colsum");
+}
+
+extern "C" int vlr_layernorm_fwd(const void* x, const void* w, const void* b, void* y, int M, int D, float eps,
+                                 hipStream_t st) {
+    VLR_REQUIRE(M > 0 && D % 8 == 0 && D <= 4096, "vlr_layernorm_fwd: bad shape M=%d D=%d", M, D);
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(M), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)w,
+                       (const bf16_t*)b, (bf16_t*)y, D, eps, (const bf16_t*)nullptr, (const bf16_t*)nullptr,
+                       (const bf16_t*)nullptr, 1);
+    return vlr_check_launch("vlr_layernorm_fwd");
+}
+extern "C" int vlr_vit_embed_ln(const void* patch_embeds, const void* cls, const void* pos, const void* w, const void* b,
+                                void* y, int n_img, int T, int D, float eps, hipStream_t st) {
+    VLR_REQUIRE(n_img > 0 && T > 1 && D % 8 == 0 && D <= 4096, "vlr_vit_embed_ln: bad shape");
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(n_img * T), dim3(256), 0, st, (const bf16_t*)nullptr, (const bf16_t*)w,
+                       (const bf16_t*)b, (bf16_t*)y, D, eps, (const bf16_t*)patch_embeds, (const bf16_t*)cls,
+                       (const bf16_t*)pos, T);
+    return vlr_check_launch("vlr_vit_embed_ln");
+}
+
+extern "C" int vlr_rope_table(float* cos_t, float* sin_t, int max_pos, int head_dim, float theta, hipStream_t st) {
+    VLR_REQUIRE(max_pos > 0 && head_dim % 16 == 0, "vlr_rope_table: bad args");
+    const int n = max_pos * (head_dim / 2);
+    hipLaunchKernelGGL(rope_table_kernel, dim3((n + 255) / 256), dim3(256), 0, st, cos_t, sin_t, max_pos, head_dim / 2, theta);
+    return vlr_check_launch("vlr_rope_table");
+}
+extern "C" int vlr_rope(void* qkv, const int* pos, const float* cos_t, const float* sin_t, int M, int H, int head_dim,
+                        int ld, int max_pos, int backward, hipStream_t st) {
+    VLR_REQUIRE(M > 0 && head_dim % 16 == 0 && H % head_dim == 0 && ld % 8 == 0, "vlr_rope: bad shape");
+    const long threads = (long)M * (H / head_dim) * 2 * (head_dim / 16);
+    hipLaunchKernelGGL(rope_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, (bf16_t*)qkv, pos, cos_t,
+                       sin_t, M, H, head_dim, ld, backward ? -1.f : 1.f, max_pos);
+    return vlr_check_launch("vlr_rope");
+}
+
+extern "C" int vlr_swiglu_fwd(const void* gu, void* act, int M, int I, hipStream_t st) {
+    VLR_REQUIRE(M > 0 && I % 8 == 0, "vlr_swiglu_fwd: bad shape");
+    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid_for((long)M * I / 8, 256)), dim3(256), 0, st, (const bf16_t*)gu,
+                       (bf16_t*)act, (long)M, I);
+    return vlr_check_launch("vlr_swiglu_fwd");
+}
+extern "C" int vlr_swiglu_bwd(void* gu_inout, const void* dact, int M, int I, hipStream_t st) {
+    VLR_REQUIRE(M > 0 && I % 8 == 0, "vlr_swiglu_bwd: bad shape");
+    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for((long)M * I / 8, 256)), dim3(256), 0, st, (bf16_t*)gu_inout,
+                       (const bf16_t*)dact, (long)M, I);
+    return vlr_check_launch("vlr_swiglu_bwd");
+}
+extern "C" int vlr_gelu_fwd(const void* z, void* h, long n, hipStream_t st) {
+    VLR_REQUIRE(n > 0 && n % 8 == 0, "vlr_gelu_fwd: n %% 8");
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, st, (const bf16_t*)z, (bf16_t*)h, n / 8);
+    return vlr_check_launch("vlr_gelu_fwd");
+}
+extern "C" int vlr_gelu_bwd(const void* z, const void* dh, void* dz, long n, hipStream_t st) {
+    VLR_REQUIRE(n > 0 && n % 8 == 0, "vlr_gelu_bwd: n %% 8");
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, st, (const bf16_t*)z, (const bf16_t*)dh,
+                       (bf16_t*)dz, n / 8);
+    return vlr_check_launch("vlr_gelu_bwd");
+}
+extern "C" int vlr_im2col(const float* pixel_values, void* patches, int n_img, int image_size, int patch, int Kp,
+                          hipStream_t st) {
+    VLR_REQUIRE(n_img > 0 && image_size % patch == 0 && Kp >= 3 * patch * patch && Kp % 8 == 0, "vlr_im2col: bad args");
+    const long total = (long)n_img * (image_size / patch) * (image_size / patch) * Kp;
+    hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, pixel_values, (bf16_t*)patches, n_img,
+                       image_size, patch, Kp);
+    return vlr_check_launch("vlr_im2col");
+}
+extern "C" int vlr_gather_rows(const void* src, const int* rows, void* dst, int R, int H, hipStream_t st) {
+    VLR_REQUIRE(R > 0 && H % 8 == 0, "vlr_gather_rows: bad shape");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(R), dim3(256), 0, st, (const bf16_t*)src, rows, (bf16_t*)dst, R, H);
+    return vlr_check_launch("vlr_gather_rows");
+}
+extern "C" int vlr_scatter_rows(const void* src, const int* rows, void* dst, int R, int H, hipStream_t st) {
+    VLR_REQUIRE(R > 0 && H % 8 == 0, "vlr_scatter_rows: bad shape");
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(R), dim3(256), 0, st, (const bf16_t*)src, rows, (bf16_t*)dst, R, H);
+    return vlr_check_launch("vlr_scatter_rows");
+}
+extern "C" int vlr_cast_f32_to_bf16(const float* src, void* dst, long n, hipStream_t st) {
+    VLR_REQUIRE(n > 0, "vlr_cast_f32_to_bf16: n");
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, src, (bf16_t*)dst, n);
+    return vlr_check_launch("vlr_cast_f32_to_bf16");
+}
+extern "C" int vlr_cast_bf16_to_f32(const void* src, float* dst, long n, hipStream_t st) {
+    VLR_REQUIRE(n > 0, "vlr_cast_bf16_to_f32: n");
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, (const bf16_t*)src, dst, n);
+    return vlr_check_launch("vlr_cast_bf16_to_f32");
+}
+extern "C" int vlr_rowdot(const void* X, const float* v, float* out, int M, int H, hipStream_t st) {
+    VLR_REQUIRE(M > 0 && H % 8 == 0, "vlr_rowdot: bad shape");
+    hipLaunchKernelGGL(rowdot_kernel, dim3(M), dim3(256), 0, st, (const bf16_t*)X, v, out, H);
+    return vlr_check_launch("vlr_rowdot");
+}

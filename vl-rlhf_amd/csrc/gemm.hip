@@ -1,0 +1,291 @@
+// bf16 MFMA GEMM for gfx950 (MI355X): C[M,N] = epilogue( sum_k A(m,k) * B(n,k) ).
+//
+// One kernel template covers the three operand layouts the DPO step needs
+//   NT  forward      Y  = X  . W^T      A: [M,K] k-contiguous      B: [N,K] k-contiguous
+//   NN  dgrad        dX = dY . W        A: [M,K] k-contiguous      B: stored [K,N] (k strided)
+//   TN  wgrad        dW = dY^T . X      A: stored [K,M] (k strided) B: stored [K,N] (k strided)
+// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 v_mfma_f32_32x32x16_bf16 tiles.
+// Global -> registers -> LDS staging (k-strided operands are transposed 4x4/8x4 in registers with v_perm so LDS
+// always holds [row][k] with k contiguous), XOR-swizzled 16-byte chunks so every ds_read_b128 lane group hits 16
+// distinct slots, LDS double buffer with the next tile's global loads in flight across the MFMA block, one barrier
+// per K step.  Epilogue goes through LDS (per-wave 64x64 fp32) so bias / activation / residual / accumulate are
+// applied in fp32 and global stores are 16 B per lane along rows.
+// Workgroup -> tile map: XCD-aware (block b runs on XCD b%8; each XCD gets a contiguous run of tiles) and grouped
+// (8 tile-rows x all tile-columns) so co-resident workgroups share A panels and B panels in their XCD's L2.
+#include "common.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+
+enum { ACT_NONE = 0, ACT_QUICK_GELU = 1, ACT_GELU = 2 };
+
+struct GemmParams {
+    const bf16_t* A;
+    const bf16_t* B;
+    void* C;
+    const bf16_t* bias;      // [N] or null
+    const bf16_t* residual;  // [M,N] ld = ldr, or null
+    int M, N, K;
+    int lda, ldb, ldc, ldr;
+    int act;
+    int accumulate;  // C += result (C read in its own dtype)
+    int out_f32;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == ACT_QUICK_GELU) return v / (1.f + __expf(-1.702f * v));
+    if (act == ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+    return v;
+}
+
+__device__ __forceinline__ int swz_off(int row, int chunk) { return row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// ---- k-contiguous operand: 128 rows x 64 k, thread -> (row = t/8 + 32 i, chunk = t%8) ------------------------
+__device__ __forceinline__ void load_kc(const bf16_t* __restrict__ P, int ld, int row0, int nrows, int k0, int K, int t,
+                                        u32x4 (&r)[4]) {
+    const int c = t & 7;
+    const int k = k0 + c * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = row0 + (t >> 3) + 32 * i;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row < nrows && k + 8 <= K) v = *reinterpret_cast<const u32x4*>(P + (size_t)row * ld + k);
+        r[i] = v;
+    }
+}
+__device__ __forceinline__ void store_kc(char* lds, int t, const u32x4 (&r)[4]) {
+    const int c = t & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (t >> 3) + 32 * i;
+        *reinterpret_cast<u32x4*>(lds + swz_off(row, c)) = r[i];
+    }
+}
+// ---- k-strided operand: stored [K][ncols]; tile 64 k x 128 cols; thread -> (k block = t/32, col quad = t%32) ----
+__device__ __forceinline__ void load_ks(const bf16_t* __restrict__ P, int ld, int col0, int ncols, int k0, int K, int t,
+                                        u32x2 (&r)[8]) {
+    const int kb = t >> 5, nq = t & 31;
+    const int col = col0 + nq * 4;
+    const bool cok = col + 4 <= ncols;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = k0 + kb * 8 + j;
+        u32x2 v = {0u, 0u};
+        if (cok && k < K) v = *reinterpret_cast<const u32x2*>(P + (size_t)k * ld + col);
+        r[j] = v;
+    }
+}
+__device__ __forceinline__ void store_ks(char* lds, int t, const u32x2 (&r)[8]) {
+    const int kb = t >> 5, nq = t & 31;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = nq * 4 + i;
+        u32x4 o;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const uint32_t lo = r[2 * p][i >> 1], hi = r[2 * p + 1][i >> 1];
+            o[p] = (i & 1) ? __builtin_amdgcn_perm(hi, lo, 0x07060302u) : __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+        }
+        *reinterpret_cast<u32x4*>(lds + swz_off(row, kb)) = o;
+    }
+}
+
+template <bool A_KS, bool B_KS>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * BK * 2];  // 64 KiB
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- XCD-aware, grouped tile map (bijective for any tile count)
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    int pid;
+    {
+        const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+        const int q = nwg >> 3, rem = nwg & 7;
+        pid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+    }
+    const int GROUP = 8;
+    const int per_group = GROUP * tiles_n;
+    const int gid = pid / per_group;
+    const int first_m = gid * GROUP;
+    const int gsz = min(tiles_m - first_m, GROUP);
+    const int tm = first_m + (pid % per_group) % gsz;
+    const int tn = (pid % per_group) / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    u32x4 ra_c[4], rb_c[4];
+    u32x2 ra_s[8], rb_s[8];
+    const int nt = (p.K + BK - 1) / BK;
+
+    auto gload = [&](int kt) {
+        const int k0 = kt * BK;
+        if constexpr (A_KS) load_ks(p.A, p.lda, m0, p.M, k0, p.K, t, ra_s);
+        else load_kc(p.A, p.lda, m0, p.M, k0, p.K, t, ra_c);
+        if constexpr (B_KS) load_ks(p.B, p.ldb, n0, p.N, k0, p.K, t, rb_s);
+        else load_kc(p.B, p.ldb, n0, p.N, k0, p.K, t, rb_c);
+    };
+    auto lstore = [&](int buf) {
+        char* a = smem + buf * (BM + BN) * BK * 2;
+        char* b = a + BM * BK * 2;
+        if constexpr (A_KS) store_ks(a, t, ra_s);
+        else store_kc(a, t, ra_c);
+        if constexpr (B_KS) store_ks(b, t, rb_s);
+        else store_kc(b, t, rb_c);
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nt) gload(kt + 1);
+        const char* a = smem + cur * (BM + BN) * BK * 2;
+        const char* b = a + BM * BK * 2;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 fa[2], fb[2];
+            const int c = kk * 2 + (lane >> 5);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wm * 64 + i * 32 + (lane & 31);
+                fa[i] = *reinterpret_cast<const bf16x8*>(a + swz_off(row, c));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = wn * 64 + j * 32 + (lane & 31);
+                fb[j] = *reinterpret_cast<const bf16x8*>(b + swz_off(row, c));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nt) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue through LDS: per-wave 64x64 fp32 staging
+    float* stage = reinterpret_cast<float*>(smem) + wave * 64 * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int col = j * 32 + (lane & 31);
+                stage[row * 64 + col] = acc[i][j][r];
+            }
+    __syncthreads();
+    const int gm0 = m0 + wm * 64, gn0 = n0 + wn * 64;
+    if (!p.out_f32) {
+        bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+        const int cq = (lane & 7) * 8;
+        const int gn = gn0 + cq;
+        float bv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+        if (p.bias && gn + 8 <= p.N) unpack8(*reinterpret_cast<const u32x4*>(p.bias + gn), bv);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 8 + (lane >> 3);
+            const int gm = gm0 + row;
+            if (gm < p.M && gn + 8 <= p.N) {
+                float v[8];
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(stage + row * 64 + cq);
+                const f32x4 s1 = *reinterpret_cast<const f32x4*>(stage + row * 64 + cq + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = s0[e];
+                    v[4 + e] = s1[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e] + bv[e], p.act);
+                if (p.residual) {
+                    float rv[8];
+                    unpack8(*reinterpret_cast<const u32x4*>(p.residual + (size_t)gm * p.ldr + gn), rv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += rv[e];
+                }
+                bf16_t* dst = C + (size_t)gm * p.ldc + gn;
+                if (p.accumulate) {
+                    float ov[8];
+                    unpack8(*reinterpret_cast<const u32x4*>(dst), ov);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += ov[e];
+                }
+                *reinterpret_cast<u32x4*>(dst) = pack8(v);
+            }
+        }
+    } else {
+        float* C = reinterpret_cast<float*>(p.C);
+        const int cq = (lane & 15) * 4;
+        const int gn = gn0 + cq;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && gn + 4 <= p.N) {
+            const u32x2 w = *reinterpret_cast<const u32x2*>(p.bias + gn);
+            bv[0] = bf16lo(w[0]); bv[1] = bf16hi(w[0]); bv[2] = bf16lo(w[1]); bv[3] = bf16hi(w[1]);
+        }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int row = it * 4 + (lane >> 4);
+            const int gm = gm0 + row;
+            if (gm < p.M && gn + 4 <= p.N) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * 64 + cq);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e] + bv[e], p.act);
+                if (p.residual) {
+                    const u32x2 w = *reinterpret_cast<const u32x2*>(p.residual + (size_t)gm * p.ldr + gn);
+                    v[0] += bf16lo(w[0]); v[1] += bf16hi(w[0]); v[2] += bf16lo(w[1]); v[3] += bf16hi(w[1]);
+                }
+                float* dst = C + (size_t)gm * p.ldc + gn;
+                if (p.accumulate) {
+                    const f32x4 o = *reinterpret_cast<const f32x4*>(dst);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += o[e];
+                }
+                *reinterpret_cast<f32x4*>(dst) = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+extern "C" int vlr_gemm_bf16(int layout, const void* A, const void* B, void* C, const void* bias, const void* residual,
+                             int M, int N, int K, int lda, int ldb, int ldc, int ldr, int act, int accumulate,
+                             int out_f32, hipStream_t stream) {
+    VLR_REQUIRE(layout >= 0 && layout <= 2, "vlr_gemm_bf16: layout must be 0 (NT), 1 (NN) or 2 (TN), got %d", layout);
+    VLR_REQUIRE(M > 0 && N > 0 && K > 0, "vlr_gemm_bf16: empty problem M=%d N=%d K=%d", M, N, K);
+    VLR_REQUIRE(A && B && C, "vlr_gemm_bf16: null operand");
+    const bool a_ks = layout == 2, b_ks = layout != 0;
+    // 16-byte (k-contiguous) / 8-byte (k-strided) vector loads, 16-byte stores
+    VLR_REQUIRE(a_ks ? (lda % 4 == 0 && M % 4 == 0) : (lda % 8 == 0 && K % 8 == 0),
+                "vlr_gemm_bf16: A alignment (layout %d lda %d M %d K %d)", layout, lda, M, K);
+    VLR_REQUIRE(b_ks ? (ldb % 4 == 0 && N % 4 == 0) : (ldb % 8 == 0 && K % 8 == 0),
+                "vlr_gemm_bf16: B alignment (layout %d ldb %d N %d K %d)", layout, ldb, N, K);
+    VLR_REQUIRE(out_f32 ? (N % 4 == 0 && ldc % 4 == 0) : (N % 8 == 0 && ldc % 8 == 0),
+                "vlr_gemm_bf16: C alignment (N %d ldc %d)", N, ldc);
+    VLR_REQUIRE(!residual || ldr % (out_f32 ? 4 : 8) == 0, "vlr_gemm_bf16: residual ld %d", ldr);
+    GemmParams p;
+    p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
+    p.bias = (const bf16_t*)bias; p.residual = (const bf16_t*)residual;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
+    p.act = act; p.accumulate = accumulate; p.out_f32 = out_f32;
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    if (layout == 0) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), dim3(tiles), dim3(256), 0, stream, p);
+    else if (layout == 1) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), dim3(tiles), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), dim3(tiles), dim3(256), 0, stream, p);
+    return vlr_check_launch("vlr_gemm_bf16");
+}

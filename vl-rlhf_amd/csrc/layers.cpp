@@ -1,0 +1,83 @@
+// Composed passes: one LLaMA decoder layer forward / backward and one CLIP encoder layer forward, sequenced on a
+// single HIP stream from the kernel-level entry points.  Pure host code: no allocation, no synchronisation.
+//
+// Decoder layer (transformers LlamaDecoderLayer; call site /root/reference src/vlrlhf/models/Llava/__init__.py:232):
+//   xn1 = RMSNorm(x) ; qkv = xn1 Wqkv^T ; RoPE(q,k) ; attn = softmax(q k^T / sqrt(d) + causal/pad) v
+//   x_mid = x + attn Wo^T ; xn2 = RMSNorm(x_mid) ; gu = xn2 Wgu^T ; act = silu(g) * u ; x_out = x_mid + act Wdown^T
+// The backward is the exact adjoint, weight gradients written (or accumulated) straight into the flat bf16 gradient
+// buffer views passed in `g` - no autograd graph, no temporaries beyond `ws`.
+#include <math.h>
+
+#include "../../include/vlr.h"
+#include "common.h"
+
+#define CHECK(call)                     \
+    do {                                \
+        int rc_ = (call);               \
+        if (rc_ != VLR_OK) return rc_;  \
+    } while (0)
+
+static inline const char* off(const void* p, size_t elems) { return (const char*)p + elems * 2; }
+static inline char* off(void* p, size_t elems) { return (char*)p + elems * 2; }
+
+extern "C" int vlr_decoder_layer_fwd(const vlr_llama_cfg* cfg, const vlr_layer_weights* w, const vlr_layer_acts* a,
+                                     const void* x_in, const int* pos, const int* key_mask, int batch, int S,
+                                     vlr_stream_t st) {
+    VLR_REQUIRE(cfg && w && a && x_in && pos, "vlr_decoder_layer_fwd: null argument");
+    const int H = cfg->hidden, I = cfg->inter, M = batch * S;
+    VLR_REQUIRE(cfg->heads * cfg->head_dim == H, "vlr_decoder_layer_fwd: heads*head_dim != hidden");
+    CHECK(vlr_rmsnorm_fwd(x_in, w->ln1, a->xn1, a->rstd1, M, H, cfg->rms_eps, st));
+    CHECK(vlr_gemm_bf16(0, a->xn1, w->wqkv, a->qkv, nullptr, nullptr, M, 3 * H, H, H, H, 3 * H, 0, 0, 0, 0, st));
+    CHECK(vlr_rope(a->qkv, pos, cfg->rope_cos, cfg->rope_sin, M, H, cfg->head_dim, 3 * H, cfg->max_pos, 0, st));
+    CHECK(vlr_attn_fwd(a->qkv, off(a->qkv, H), off(a->qkv, 2 * (size_t)H), 3 * H, a->attn, H, a->lse, key_mask, batch, S,
+                       cfg->heads, cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));
+    CHECK(vlr_gemm_bf16(0, a->attn, w->wo, a->x_mid, nullptr, x_in, M, H, H, H, H, H, H, 0, 0, 0, st));
+    CHECK(vlr_rmsnorm_fwd(a->x_mid, w->ln2, a->xn2, a->rstd2, M, H, cfg->rms_eps, st));
+    CHECK(vlr_gemm_bf16(0, a->xn2, w->wgu, a->gu, nullptr, nullptr, M, 2 * I, H, H, H, 2 * I, 0, 0, 0, 0, st));
+    CHECK(vlr_swiglu_fwd(a->gu, a->act, M, I, st));
+    CHECK(vlr_gemm_bf16(0, a->act, w->wdown, a->x_out, nullptr, a->x_mid, M, H, I, I, I, H, H, 0, 0, 0, st));
+    return VLR_OK;
+}
+
+extern "C" int vlr_decoder_layer_bwd(const vlr_llama_cfg* cfg, const vlr_layer_weights* w, const vlr_layer_grads* g,
+                                     int accumulate, const vlr_layer_acts* a, const vlr_layer_bwd_ws* ws,
+                                     const void* x_in, const void* dx_out, void* dx_in, const int* pos,
+                                     const int* key_mask, int batch, int S, vlr_stream_t st) {
+    VLR_REQUIRE(cfg && w && g && a && ws && x_in && dx_out && dx_in && pos, "vlr_decoder_layer_bwd: null argument");
+    const int H = cfg->hidden, I = cfg->inter, M = batch * S;
+    // ---- MLP
+    CHECK(vlr_gemm_bf16(1, dx_out, w->wdown, ws->dact, nullptr, nullptr, M, I, H, H, I, I, 0, 0, 0, 0, st));
+    CHECK(vlr_gemm_bf16(2, dx_out, a->act, g->wdown, nullptr, nullptr, H, I, M, H, I, I, 0, 0, accumulate, 0, st));
+    CHECK(vlr_swiglu_bwd(a->gu, ws->dact, M, I, st));   // gu now holds [dgate | dup]
+    CHECK(vlr_gemm_bf16(1, a->gu, w->wgu, ws->dxn, nullptr, nullptr, M, H, 2 * I, 2 * I, H, H, 0, 0, 0, 0, st));
+    CHECK(vlr_gemm_bf16(2, a->gu, a->xn2, g->wgu, nullptr, nullptr, 2 * I, H, M, 2 * I, H, H, 0, 0, accumulate, 0, st));
+    CHECK(vlr_rmsnorm_bwd(ws->dxn, a->x_mid, w->ln2, a->rstd2, dx_out, ws->dx_mid, g->ln2, accumulate, ws->norm_ws, M, H, st));
+    // ---- attention
+    CHECK(vlr_gemm_bf16(1, ws->dx_mid, w->wo, ws->dattn, nullptr, nullptr, M, H, H, H, H, H, 0, 0, 0, 0, st));
+    CHECK(vlr_gemm_bf16(2, ws->dx_mid, a->attn, g->wo, nullptr, nullptr, H, H, M, H, H, H, 0, 0, accumulate, 0, st));
+    CHECK(vlr_attn_bwd(a->qkv, off(a->qkv, H), off(a->qkv, 2 * (size_t)H), 3 * H, a->attn, ws->dattn, H, a->lse, ws->delta,
+                       key_mask, ws->dqkv, off(ws->dqkv, H), off(ws->dqkv, 2 * (size_t)H), 3 * H, batch, S, cfg->heads,
+                       cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));
+    CHECK(vlr_rope(ws->dqkv, pos, cfg->rope_cos, cfg->rope_sin, M, H, cfg->head_dim, 3 * H, cfg->max_pos, 1, st));
+    CHECK(vlr_gemm_bf16(1, ws->dqkv, w->wqkv, ws->dxn, nullptr, nullptr, M, H, 3 * H, 3 * H, H, H, 0, 0, 0, 0, st));
+    CHECK(vlr_gemm_bf16(2, ws->dqkv, a->xn1, g->wqkv, nullptr, nullptr, 3 * H, H, M, 3 * H, H, H, 0, 0, accumulate, 0, st));
+    CHECK(vlr_rmsnorm_bwd(ws->dxn, x_in, w->ln1, a->rstd1, ws->dx_mid, dx_in, g->ln1, accumulate, ws->norm_ws, M, H, st));
+    return VLR_OK;
+}
+
+// CLIP encoder layer (transformers CLIPEncoderLayer, pre-LN, quick_gelu; call site Llava/__init__.py:178), in place on x
+extern "C" int vlr_vit_layer_fwd(const vlr_vit_cfg* cfg, const vlr_vit_layer_weights* w, const vlr_vit_ws* ws,
+                                 void* x, int n_img, int T, vlr_stream_t st) {
+    VLR_REQUIRE(cfg && w && ws && x, "vlr_vit_layer_fwd: null argument");
+    const int D = cfg->hidden, F = cfg->mlp, M = n_img * T;
+    VLR_REQUIRE(cfg->heads * cfg->head_dim == D, "vlr_vit_layer_fwd: heads*head_dim != hidden");
+    CHECK(vlr_layernorm_fwd(x, w->ln1_w, w->ln1_b, ws->xn, M, D, cfg->ln_eps, st));
+    CHECK(vlr_gemm_bf16(0, ws->xn, w->wqkv, ws->qkv, w->bqkv, nullptr, M, 3 * D, D, D, D, 3 * D, 0, 0, 0, 0, st));
+    CHECK(vlr_attn_fwd(ws->qkv, off(ws->qkv, D), off(ws->qkv, 2 * (size_t)D), 3 * D, ws->attn, D, nullptr, nullptr, n_img, T,
+                       cfg->heads, cfg->head_dim, 0, 1.0f / sqrtf((float)cfg->head_dim), st));
+    CHECK(vlr_gemm_bf16(0, ws->attn, w->wo, x, w->bo, x, M, D, D, D, D, D, D, 0, 0, 0, st));
+    CHECK(vlr_layernorm_fwd(x, w->ln2_w, w->ln2_b, ws->xn, M, D, cfg->ln_eps, st));
+    CHECK(vlr_gemm_bf16(0, ws->xn, w->w1, ws->h, w->b1, nullptr, M, F, D, D, D, F, 0, 1 /*quick_gelu*/, 0, 0, st));
+    CHECK(vlr_gemm_bf16(0, ws->h, w->w2, x, w->b2, x, M, D, F, F, F, D, D, 0, 0, 0, st));
+    return VLR_OK;
+}

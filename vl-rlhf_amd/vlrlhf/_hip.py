@@ -1,0 +1,149 @@
+"""ctypes binding of libvlr_hip.so (include/vlr.h).  The product path has NO fallback: if the library is missing
+or a call fails this module raises - nothing is silently routed to PyTorch or to the CPU oracle."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libvlr_hip.so")
+
+_lib = None
+
+P, I, L, F = C.c_void_p, C.c_int, C.c_long, C.c_float
+
+
+class LlamaCfg(C.Structure):
+    _fields_ = [("hidden", I), ("inter", I), ("heads", I), ("head_dim", I), ("rms_eps", F), ("max_pos", I),
+                ("rope_cos", P), ("rope_sin", P)]
+
+
+class LayerWeights(C.Structure):
+    _fields_ = [(n, P) for n in ("ln1", "wqkv", "wo", "ln2", "wgu", "wdown")]
+
+
+class LayerGrads(C.Structure):
+    _fields_ = [(n, P) for n in ("ln1", "wqkv", "wo", "ln2", "wgu", "wdown")]
+
+
+class LayerActs(C.Structure):
+    _fields_ = [(n, P) for n in ("xn1", "rstd1", "qkv", "attn", "lse", "x_mid", "xn2", "rstd2", "gu", "act", "x_out")]
+
+
+class LayerBwdWs(C.Structure):
+    _fields_ = [(n, P) for n in ("dact", "dxn", "dattn", "dqkv", "dx_mid", "delta", "norm_ws")]
+
+
+class VitCfg(C.Structure):
+    _fields_ = [("hidden", I), ("mlp", I), ("heads", I), ("head_dim", I), ("ln_eps", F)]
+
+
+class VitLayerWeights(C.Structure):
+    _fields_ = [(n, P) for n in ("ln1_w", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ln2_w", "ln2_b", "w1", "b1", "w2", "b2")]
+
+
+class VitWs(C.Structure):
+    _fields_ = [(n, P) for n in ("xn", "qkv", "attn", "h")]
+
+
+# name -> argtypes (every function returns int status, except the *_bytes helpers and vlr_last_error)
+_SIGS = {
+    "vlr_gemm_bf16": [I, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "vlr_rmsnorm_fwd": [P, P, P, P, I, I, F, P],
+    "vlr_rmsnorm_bwd": [P, P, P, P, P, P, P, I, P, I, I, P],
+    "vlr_layernorm_fwd": [P, P, P, P, I, I, F, P],
+    "vlr_vit_embed_ln": [P, P, P, P, P, P, I, I, I, F, P],
+    "vlr_im2col": [P, P, I, I, I, I, P],
+    "vlr_rope_table": [P, P, I, I, F, P],
+    "vlr_rope": [P, P, P, P, I, I, I, I, I, I, P],
+    "vlr_swiglu_fwd": [P, P, I, I, P],
+    "vlr_swiglu_bwd": [P, P, I, I, P],
+    "vlr_gelu_fwd": [P, P, L, P],
+    "vlr_gelu_bwd": [P, P, P, L, P],
+    "vlr_colsum": [P, I, I, I, P, I, P, P],
+    "vlr_gather_rows": [P, P, P, I, I, P],
+    "vlr_scatter_rows": [P, P, P, I, I, P],
+    "vlr_cast_f32_to_bf16": [P, P, L, P],
+    "vlr_cast_bf16_to_f32": [P, P, L, P],
+    "vlr_rowdot": [P, P, P, I, I, P],
+    "vlr_attn_fwd": [P, P, P, I, P, I, P, P, I, I, I, I, I, F, P],
+    "vlr_attn_bwd": [P, P, P, I, P, P, I, P, P, P, P, P, P, I, I, I, I, I, I, F, P],
+    "vlr_merge_index": [P, P, P, I, I, I, I, I, I, I, I, P, P, P, P, P, P, P, P],
+    "vlr_merge_fwd": [P, P, P, P, P, I, I, I, I, P],
+    "vlr_merge_bwd": [P, P, P, P, P, P, I, I, I, I, I, I, P],
+    "vlr_build_rows": [P, P, I, I, I, P, P, P, P],
+    "vlr_logp_rows": [P, P, P, I, I, L, P, P, P],
+    "vlr_dlogits_rows": [P, P, P, P, I, P, I, I, I, L, P, L, P],
+    "vlr_seq_sum": [P, P, I, I, P, P],
+    "vlr_dpo_loss": [P, P, P, P, I, F, F, I, I, P, P, P, P, P, P, P, P],
+    "vlr_grad_sqnorm": [P, L, F, F, F, P, P, P],
+    "vlr_adamw_step": [P, P, P, P, P, L, F, F, F, F, F, I, P, P],
+    "vlr_decoder_layer_fwd": [P, P, P, P, P, P, I, I, P],
+    "vlr_decoder_layer_bwd": [P, P, P, I, P, P, P, P, P, P, P, I, I, P],
+    "vlr_vit_layer_fwd": [P, P, P, P, I, I, P],
+}
+_INT_HELPERS = {
+    "vlr_rmsnorm_bwd_workspace_bytes": [I],
+    "vlr_colsum_workspace_bytes": [I],
+    "vlr_grad_sqnorm_workspace_bytes": [],
+    "vlr_abi_version": [],
+}
+
+
+class VlrError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libvlr_hip.so once.  Raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VlrError(f"{LIB_PATH} not found: build it with `python vl-rlhf_amd/build_hip.py` "
+                           "(the MI355X DPO path has no PyTorch/CPU fallback)")
+        l = C.CDLL(LIB_PATH)
+        l.vlr_last_error.restype = C.c_char_p
+        l.vlr_last_error.argtypes = []
+        for name, sig in _SIGS.items():
+            fn = getattr(l, name)
+            fn.restype = I
+            fn.argtypes = sig
+        for name, sig in _INT_HELPERS.items():
+            fn = getattr(l, name)
+            fn.restype = I
+            fn.argtypes = sig
+        _lib = l
+    return _lib
+
+
+def exported_symbols():
+    return list(_SIGS) + list(_INT_HELPERS) + ["vlr_last_error"]
+
+
+def ptr(t):
+    """device pointer of a tensor (or None)."""
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return t
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Invoke a vlr_* entry point on torch's current stream; argument errors -> ValueError (reference behaviour),
+    launch failures -> VlrError."""
+    l = lib()
+    conv = [ptr(a) if isinstance(a, torch.Tensor) else (C.byref(a) if isinstance(a, C.Structure) else a) for a in args]
+    rc = getattr(l, name)(*conv, stream())
+    if rc != 0:
+        msg = l.vlr_last_error().decode()
+        raise (ValueError if rc == 1 else VlrError)(msg)
+    return rc
+
+
+def helper(name, *args):
+    return getattr(lib(), name)(*args)
