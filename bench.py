@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Benchmark of the north-star metric: preference-pairs/sec of one full LLaVA-1.5-7B DPO optimizer step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = policy forward + backward, reference forward, DPO loss, gradient all-reduce (N>1), clip + AdamW, on a
+synthetic batch already resident in HBM: per rank 4 pairs, 336x336 image, 1024 text tokens each (BASELINE.json
+configs[1]; S = 1599 decoder positions), random N(0,0.02) bf16 weights, policy != reference.  Prints ONE JSON line.
+
+roofline: the dominant kernel is the bf16 MFMA GEMM (gemm_bf16_kernel, all three layouts); `achieved` = its algorithmic
+FLOPs (2*M*N*K per launch) / its summed launch durations, measured with HIP events on the launch stream over the
+timed region.  `step_frac` = pairs/s x 174.87 TFLOP (reference forward inside the step) / 2516.6 TF/s.
+cpu_baseline: the fp32 CPU oracle (oracle/llava_dpo_oracle.py, a port of the reference algorithm) timed on this host's
+cores on a bounded sample - one decoder layer forward+backward at the configs[0] shape - and extrapolated to the full
+step; a reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "vl-rlhf_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2516.6          # 256 CU x 4096 FLOP/clk/CU x 2.4 GHz (MI355X_MICROARCH.md: ~2.5 PF dense)
+TFLOP_PER_PAIR = {"ref_in_step": 174.87, "ref_precomputed": 131.24}
+
+
+def cpu_baseline(budget_s=20.0):
+    """fp32 oracle, one LLaMA-7B decoder layer fwd+bwd at the configs[0] shape (4 pairs, T=256 -> 8 x 831 positions)."""
+    from oracle import llava_dpo_oracle as O       # checker / baseline only
+    torch.manual_seed(0)
+    n_thr = torch.get_num_threads()
+    H, I, nh = 4096, 11008, 32
+    B, S = 8, 831
+    cfg = dict(hidden=H, inter=I, layers=1, heads=nh, vocab=8, rms_eps=1e-5)
+    p = "language_model.model.layers.0."
+    W = {p + f"self_attn.{n}_proj.weight": torch.randn(H, H) * 0.02 for n in "qkvo"}
+    W.update({p + "mlp.gate_proj.weight": torch.randn(I, H) * 0.02, p + "mlp.up_proj.weight": torch.randn(I, H) * 0.02,
+              p + "mlp.down_proj.weight": torch.randn(H, I) * 0.02, p + "input_layernorm.weight": torch.ones(H),
+              p + "post_attention_layernorm.weight": torch.ones(H), "language_model.model.norm.weight": torch.ones(H)})
+    x = torch.randn(B, S, H)
+    am = torch.ones(B, S, dtype=torch.long)
+    pos = torch.arange(S)[None].expand(B, S)
+    t_fwd = t_all = 0.0
+    reps = 0
+    t_start = time.time()
+    while reps < 1 or (time.time() - t_start < budget_s and reps < 3):
+        leaves = {k: v.clone().requires_grad_(True) for k, v in W.items()}
+        t0 = time.time()
+        col = []
+        O.llama_hidden(x, am, pos, leaves, cfg, collect=col)
+        t1 = time.time()
+        col[0].square().mean().backward()
+        t2 = time.time()
+        t_fwd += t1 - t0
+        t_all += t2 - t0
+        reps += 1
+    t_fwd, t_all = t_fwd / reps, t_all / reps
+    # full step ~ 32 layers x (policy fwd+bwd + reference fwd); ViT / lm-head / optimizer (< 6 % of the FLOPs) not sampled
+    step_s = 32 * (t_all + t_fwd)
+    return dict(value=4.0 / step_s, unit="pairs/s", cores=n_thr, kind="port",
+                sample=f"1 of 32 LLaMA-7B decoder layers, fp32 fwd+bwd ({t_all:.2f} s) + ref fwd ({t_fwd:.2f} s) at the "
+                       f"configs[0] shape (4 pairs, T=256, S=831), x32 layers; ViT/lm-head/AdamW not sampled; {reps} rep(s)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=4)
+    ap.add_argument("--text_len", type=int, default=1024)
+    ap.add_argument("--layers", type=int, default=None, help="debug only: fewer decoder layers (line is then marked INVALID)")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_side_stream", action="store_true")
+    ap.add_argument("--precomputed_ref", action="store_true", help="stream precomputed reference log-probs (SURVEY 8f rank 1)")
+    a = ap.parse_args()
+
+    from vlrlhf import _hip
+    from vlrlhf.models.Llava import LlavaDPOTrainer, LlavaForRL
+    from vlrlhf.parallel import GradReducer, init_distributed_from_env
+    from vlrlhf.utils.synthetic import LLAVA_1_5_7B, init_random_model, synthetic_batch
+    from types import SimpleNamespace
+
+    rank, local, world = init_distributed_from_env()
+    assert world == max(1, a.gpus) or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    cfg = dict(LLAVA_1_5_7B)
+    if a.layers:
+        cfg["layers"] = a.layers
+    model = LlavaForRL(cfg)
+    ref = init_random_model(model, seed=0, std=0.02, policy_delta=1e-3)
+    eng = model.engine
+    eng.init_optimizer()
+    if world > 1:
+        eng.reducer = GradReducer(eng.grads, eng.layout.bucket_after)
+    args = SimpleNamespace(gradient_accumulation_steps=1)
+    tr = LlavaDPOTrainer(model, None if a.precomputed_ref else ref, 0.1, 0, "sigmoid", args, None, -100, 0,
+                         precompute_ref_log_probs=a.precomputed_ref)
+    tr.ref_on_side_stream = not a.no_side_stream
+    batch = synthetic_batch(a.pairs, a.text_len, cfg["image_token"], 32000, cfg["image_size"], seed=1234 + rank)
+    batch = tr._prepare_inputs(batch)                      # inputs resident in HBM before the timed region
+    if a.precomputed_ref:
+        with torch.no_grad():
+            rc, rr, _, _ = tr.concatenated_forward(ref, batch)
+        batch["reference_chosen_logps"], batch["reference_rejected_logps"] = rc, rr
+    hp = dict(lr=1e-6, beta1=0.9, beta2=0.98, eps=1e-6, weight_decay=0.0, max_grad_norm=1.0)   # scripts/dpo_llava.sh:35-41
+
+    def step():
+        loss = tr.training_step(model, batch)
+        eng.optimizer_step(grad_scale=1.0 / world, **hp)
+        return loss
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    loss = None
+    for _ in range(a.warmup):
+        loss = step()
+    barrier()
+    _hip.profile_start(["vlr_gemm_bf16"])
+    t0 = time.time()
+    for _ in range(a.steps):
+        loss = step()
+    barrier()
+    dt = time.time() - t0
+    prof = _hip.profile_stop()
+    tmax = torch.tensor([dt], device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    g = prof["vlr_gemm_bf16"]
+    g_ms = sum(ms for ms, _ in g)
+    g_flop = sum(2.0 * ar[1] * ar[2] * ar[3] for _, ar in g)     # args: layout, M, N, K, ...
+    pairs_per_s = world * a.pairs * a.steps / dt
+    per_pair = TFLOP_PER_PAIR["ref_precomputed" if a.precomputed_ref else "ref_in_step"]
+    if rank == 0:
+        achieved = g_flop / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+        line = {
+            "metric": "preference-pairs/sec (chosen+rejected) LLaVA-1.5-7B DPO step", "value": round(pairs_per_s, 4),
+            "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[1]: LLaVA-1.5-7B DPO bf16, 336x336 image, max_length {a.text_len}, "
+                                   f"per-device batch {a.pairs} pairs (S=1599), full fine-tune of LLM+projector, frozen ViT, "
+                                   + ("reference log-probs precomputed" if a.precomputed_ref else "reference forward inside the step"),
+                       "global_batch_pairs": world * a.pairs, "text_len": a.text_len, "parallelism": f"dp{world}",
+                       "layers": cfg["layers"], "loss": float(loss)},
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (NT/NN/TN)", "achieved": round(achieved, 1),
+                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                         "traffic": None, "launches": len(g), "avg_launch_ms": round(g_ms / max(1, len(g)), 4),
+                         "gemm_share_of_step": round(g_ms * 1e-3 / dt, 3),
+                         "step_frac": round(pairs_per_s / world * per_pair / PEAK_BF16_TFLOPS, 4)},
+        }
+        if a.layers:
+            line["INVALID"] = "reduced layer count (debug run)"
+        if not a.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -54,6 +54,7 @@ int vlr_gelu_fwd(const void* z, void* h, long n, vlr_stream_t stream);
 int vlr_gelu_bwd(const void* z, const void* dh, void* dz, long n, vlr_stream_t stream);
 int vlr_colsum_workspace_bytes(int C);
 int vlr_colsum(const void* X, int R, int C, int ld, void* out, int accumulate, void* workspace, vlr_stream_t stream);
+int vlr_colsum_f32(const void* X, int R, int C, int ld, float* out, void* workspace, vlr_stream_t stream);
 int vlr_gather_rows(const void* src, const int* rows, void* dst, int R, int H, vlr_stream_t stream);
 int vlr_scatter_rows(const void* src, const int* rows, void* dst, int R, int H, vlr_stream_t stream);
 int vlr_cast_f32_to_bf16(const float* src, void* dst, long n, vlr_stream_t stream);

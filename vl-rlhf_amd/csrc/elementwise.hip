@@ -107,6 +107,14 @@ __global__ void reduce_partials_kernel(const float* __restrict__ part, int P, in
     out[c] = f32_to_bf16(s);
 }
 
+__global__ void reduce_partials_f32_kernel(const float* __restrict__ part, int P, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += part[(size_t)p * C + c];
+    out[c] = s;
+}
+
 // column-sum partials of a bf16 matrix X[R][C] (ld): workgroup (bx, by) sums rows by, by+Gy, ... of 512 columns
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* __restrict__ X, int R, int C, int ld,
                                                              float* __restrict__ part) {
@@ -399,6 +407,15 @@ extern "C" int vlr_colsum(const void* X, int R, int C, int ld, void* out, int ac
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)workspace, gy, C,
                        (bf16_t*)out, accumulate);
     return vlr_check_launch("vlr_colsum");
+}
+
+extern "C" int vlr_colsum_f32(const void* X, int R, int C, int ld, float* out, void* workspace, hipStream_t st) {
+    VLR_REQUIRE(R > 0 && C > 0 && C % 2 == 0 && ld % 2 == 0 && workspace, "vlr_colsum_f32: bad args R=%d C=%d", R, C);
+    const int gy = R < VLR_COLSUM_ROWS ? R : VLR_COLSUM_ROWS;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((C / 2 + 255) / 256, gy), dim3(256), 0, st, (const bf16_t*)X, R, C, ld,
+                       (float*)workspace);
+    hipLaunchKernelGGL(reduce_partials_f32_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)workspace, gy, C, out);
+    return vlr_check_launch("vlr_colsum_f32");
 }
 
 extern "C" int vlr_layernorm_fwd(const void* x, const void* w, const void* b, void* y, int M, int D, float eps,

@@ -61,6 +61,7 @@ _SIGS = {
     "vlr_gelu_fwd": [P, P, L, P],
     "vlr_gelu_bwd": [P, P, P, L, P],
     "vlr_colsum": [P, I, I, I, P, I, P, P],
+    "vlr_colsum_f32": [P, I, I, I, P, P, P],
     "vlr_gather_rows": [P, P, P, I, I, P],
     "vlr_scatter_rows": [P, P, P, I, I, P],
     "vlr_cast_f32_to_bf16": [P, P, L, P],
@@ -133,12 +134,35 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_prof = None   # {entry point: [(start_event, end_event, args)]} while bench.py times kernels with HIP events
+
+
+def profile_start(names):
+    global _prof
+    _prof = {n: [] for n in names}
+
+
+def profile_stop():
+    """-> {name: [(milliseconds, args), ...]}; call after torch.cuda.synchronize()."""
+    global _prof
+    out = {n: [(s.elapsed_time(e), a) for s, e, a in v] for n, v in (_prof or {}).items()}
+    _prof = None
+    return out
+
+
 def call(name, *args):
     """Invoke a vlr_* entry point on torch's current stream; argument errors -> ValueError (reference behaviour),
     launch failures -> VlrError."""
     l = lib()
     conv = [ptr(a) if isinstance(a, torch.Tensor) else (C.byref(a) if isinstance(a, C.Structure) else a) for a in args]
-    rc = getattr(l, name)(*conv, stream())
+    if _prof is not None and name in _prof:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = getattr(l, name)(*conv, stream())
+        e.record()
+        _prof[name].append((s, e, tuple(a for a in args if isinstance(a, (int, float)))))
+    else:
+        rc = getattr(l, name)(*conv, stream())
     if rc != 0:
         msg = l.vlr_last_error().decode()
         raise (ValueError if rc == 1 else VlrError)(msg)

@@ -1,0 +1,138 @@
+"""DPO entry point - mirror of /root/reference/src/vlrlhf/dpo.py (ScriptArguments :16-56, LoraArguments :59-74,
+TrainingArguments :77-86, main :98-149).  One process per GPU (torchrun / accelerate launch); gradients are reduced
+with RCCL over xGMI by vlrlhf.parallel.GradReducer."""
+import argparse
+import os
+from dataclasses import dataclass, field, fields
+from typing import Optional
+
+
+@dataclass
+class ScriptArguments:
+    beta: Optional[float] = 0.1
+    score_margin: Optional[float] = -1
+    data_path: Optional[str] = None
+    data_ratio: Optional[float] = 1.0
+    image_root: Optional[str] = None
+    dataset_name: Optional[str] = "vlfeedback_paired"
+    model_name_or_path: Optional[str] = "llava-hf/llava-1.5-7b-hf"
+    max_length: Optional[int] = 512
+    max_prompt_length: Optional[int] = 128
+    max_target_length: Optional[int] = 128
+    label_pad_token_id: Optional[int] = -100
+    ignore_bias_buffers: Optional[bool] = False
+    freeze_vision_tower: bool = True
+    loss_type: str = "sigmoid"
+
+
+@dataclass
+class LoraArguments:
+    lora_r: int = 64
+    lora_alpha: int = 16
+    lora_dropout: float = 0.05
+    lora_target_modules: Optional[str] = None
+    lora_bias: str = "none"
+    q_lora: bool = False
+    bits: int = 4
+    modules_to_save: Optional[str] = None
+
+
+@dataclass
+class TrainingArguments:
+    """the subset of transformers.TrainingArguments the DPO scripts set (scripts/dpo_llava.sh:16-61) + the reference's
+    extra fields (:78-86)."""
+    output_dir: str = "output"
+    per_device_train_batch_size: int = 4
+    gradient_accumulation_steps: int = 1
+    learning_rate: float = 1e-6
+    weight_decay: float = 0.0
+    adam_beta1: float = 0.9
+    adam_beta2: float = 0.98
+    adam_epsilon: float = 1e-6
+    max_grad_norm: float = 1.0
+    warmup_ratio: float = 0.03
+    warmup_steps: int = 0
+    lr_scheduler_type: str = "cosine"
+    num_train_epochs: float = 1.0
+    max_steps: int = -1
+    logging_steps: int = 10
+    seed: int = 42
+    bf16: bool = True
+    tf32: bool = True
+    gradient_checkpointing: bool = False
+    use_lora: bool = False
+    use_flash_attention_2: bool = True
+    dataset_num_proc: Optional[int] = 16
+    project_name: Optional[str] = "VL-RLHF"
+    group_name: Optional[str] = "llava-1.5-7b-dpo"
+    resume_from_checkpoint: Optional[bool] = None
+    report_to: str = "none"
+    run_name: str = "dpo"
+    save_strategy: str = "no"
+    save_steps: int = 500
+    save_total_limit: int = 1
+    evaluation_strategy: str = "no"
+    eval_steps: int = 500
+    per_device_eval_batch_size: int = 4
+    dataloader_num_workers: int = 0
+    remove_unused_columns: bool = False
+    local_rank: int = 0
+
+
+def _parse(*classes):
+    p = argparse.ArgumentParser()
+    for c in classes:
+        for f in fields(c):
+            t = f.type if f.type in (int, float, str) else None
+            if f.type in (bool, Optional[bool]):
+                p.add_argument(f"--{f.name}", type=lambda s: str(s).lower() in ("1", "true", "yes"), default=f.default)
+            else:
+                base = {Optional[int]: int, Optional[float]: float, Optional[str]: str}.get(f.type, t or str)
+                p.add_argument(f"--{f.name}", type=base, default=f.default)
+    ns, _ = p.parse_known_args()
+    return [c(**{f.name: getattr(ns, f.name) for f in fields(c)}) for c in classes]
+
+
+def main():
+    from vlrlhf.parallel import GradReducer, init_distributed_from_env
+    from vlrlhf.utils.auto_load import MyAutoDPOCollator, MyAutoDPOTrainer, MyAutoProcessor, auto_load_rlmodel
+    from vlrlhf.utils.data import DATASET_MAP
+    script_args, training_args, lora_args = _parse(ScriptArguments, TrainingArguments, LoraArguments)
+    rank, local, world = init_distributed_from_env()
+    training_args.local_rank = local
+    model, ref_model, lora_config = auto_load_rlmodel(script_args, training_args, lora_args)
+    if world > 1:
+        model.engine.reducer = GradReducer(model.engine.grads, model.engine.layout.bucket_after)
+    processor = MyAutoProcessor.from_pretrained(script_args.model_name_or_path)
+    processor.train()
+    dataset = DATASET_MAP[script_args.dataset_name](script_args)
+    n_eval = max(1, int(len(dataset) * 0.005))
+    import random
+    idx = list(range(len(dataset)))
+    random.Random(42).shuffle(idx)
+    eval_dataset = [dataset[i] for i in idx[:n_eval]]
+    train_dataset = [dataset[i] for i in idx[n_eval:]]
+    train_dataset = train_dataset[: int(len(train_dataset) * script_args.data_ratio)]
+    data_collator = MyAutoDPOCollator(script_args.model_name_or_path, pad_token_id=processor.tokenizer.pad_token_id,
+                                      label_pad_token_id=script_args.label_pad_token_id,
+                                      is_encoder_decoder=model.config.is_encoder_decoder, processor=processor)
+    dpo_trainer = MyAutoDPOTrainer(
+        script_args.model_name_or_path, model=model, args=training_args, beta=script_args.beta,
+        train_dataset=train_dataset, eval_dataset=eval_dataset, processor=processor, max_length=script_args.max_length,
+        max_target_length=script_args.max_target_length, max_prompt_length=script_args.max_prompt_length,
+        generate_during_eval=False, label_pad_token_id=script_args.label_pad_token_id, data_collator=data_collator,
+        peft_config=lora_config, loss_type=script_args.loss_type, ref_model=ref_model,
+        dataset_num_proc=training_args.dataset_num_proc)
+    dpo_trainer.use_dpo_data_collator = True
+    dpo_trainer.train(resume_from_checkpoint=training_args.resume_from_checkpoint)
+    dpo_trainer.save_state()
+    if rank == 0:
+        from safetensors.torch import save_file
+        os.makedirs(training_args.output_dir, exist_ok=True)
+        save_file({k: v.contiguous() for k, v in model.state_dict().items()},
+                  os.path.join(training_args.output_dir, "model.safetensors"))
+        processor.save_pretrained(training_args.output_dir)
+
+
+if __name__ == "__main__":
+    main()

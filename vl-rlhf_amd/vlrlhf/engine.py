@@ -1,0 +1,482 @@
+"""MI355X engine for the LLaVA-1.5 DPO step: owns the flat parameter / gradient / optimizer buffers and the
+activation workspaces, and sequences libvlr_hip.so (include/vlr.h) for the forward, the backward and the optimizer.
+
+PyTorch is used for device memory, streams and the autograd *boundary* only - every FLOP below goes through the C ABI.
+There is no fallback path: without the HIP library (or a GPU) constructing the engine raises.
+
+Replaces, for the DPO hot path, what the reference reaches through
+  LlavaForRL.forward                    /root/reference/src/vlrlhf/models/Llava/__init__.py:111-271
+  VLDPOTrainer.get_batch_logps          /root/reference/src/vlrlhf/base/trainer.py:148-188
+  Trainer.training_step / optimizer     (transformers 4.41.0 + torch AdamW; flags scripts/dpo_llava.sh:35-41)
+"""
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _hip
+
+BF16 = torch.bfloat16
+
+
+def _align(n, a=8):
+    return (n + a - 1) // a * a
+
+
+class ParamLayout:
+    """Flat layout of the TRAINABLE parameters (LLM + projector; the vision tower is frozen, auto_load.py:554-555).
+
+    Weight-decay region first, in the order the backward finishes them (lm_head, layer L-1 .. 0, projector,
+    embed_tokens) so contiguous slices are the DDP buckets; then the no-decay region (norm weights, biases)."""
+
+    def __init__(self, cfg):
+        H, I, V, D, L = cfg["hidden"], cfg["inter"], cfg["vocab"], cfg["vit_hidden"], cfg["layers"]
+        assert H % 8 == 0 and I % 8 == 0 and V % 8 == 0 and D % 8 == 0
+        self.entries = []   # (name, shape, [(hf_name, row0, rows)])
+        e = self.entries
+        lm = "language_model."
+        e.append(("lm_head", (V, H), [(lm + "lm_head.weight", 0, V)]))
+        for l in range(L - 1, -1, -1):
+            p = f"{lm}model.layers.{l}."
+            e.append((f"l{l}.wdown", (H, I), [(p + "mlp.down_proj.weight", 0, H)]))
+            e.append((f"l{l}.wgu", (2 * I, H), [(p + "mlp.gate_proj.weight", 0, I), (p + "mlp.up_proj.weight", I, I)]))
+            e.append((f"l{l}.wo", (H, H), [(p + "self_attn.o_proj.weight", 0, H)]))
+            e.append((f"l{l}.wqkv", (3 * H, H), [(p + "self_attn.q_proj.weight", 0, H), (p + "self_attn.k_proj.weight", H, H),
+                                                 (p + "self_attn.v_proj.weight", 2 * H, H)]))
+        e.append(("proj.w2", (H, H), [("multi_modal_projector.linear_2.weight", 0, H)]))
+        e.append(("proj.w1", (H, D), [("multi_modal_projector.linear_1.weight", 0, H)]))
+        e.append(("embed", (V, H), [(lm + "model.embed_tokens.weight", 0, V)]))
+        self.n_decay_entries = len(e)
+        e.append(("norm", (H,), [(lm + "model.norm.weight", 0, H)]))
+        for l in range(L - 1, -1, -1):
+            p = f"{lm}model.layers.{l}."
+            e.append((f"l{l}.ln2", (H,), [(p + "post_attention_layernorm.weight", 0, H)]))
+            e.append((f"l{l}.ln1", (H,), [(p + "input_layernorm.weight", 0, H)]))
+        e.append(("proj.b2", (H,), [("multi_modal_projector.linear_2.bias", 0, H)]))
+        e.append(("proj.b1", (H,), [("multi_modal_projector.linear_1.bias", 0, H)]))
+        self.offset = {}
+        off = 0
+        for i, (name, shape, _) in enumerate(e):
+            if i == self.n_decay_entries:
+                self.n_decay = off
+            self.offset[name] = off
+            off += _align(int(math.prod(shape)))
+        self.numel = off
+        self.shape = {name: shape for name, shape, _ in e}
+        # DDP buckets = contiguous slices of the flat gradient in backward-completion order
+        self.bucket_after = {}   # event name -> (start, end)
+        self.bucket_after["lm_head"] = (0, self.offset[f"l{L - 1}.wdown"] if L else self.offset["proj.w2"])
+        for l in range(L - 1, -1, -1):
+            end = self.offset[f"l{l - 1}.wdown"] if l > 0 else self.offset["proj.w2"]
+            self.bucket_after[f"layer{l}"] = (self.offset[f"l{l}.wdown"], end)
+        self.bucket_after["tail"] = (self.offset["proj.w2"], self.numel)
+
+    def hf_names(self):
+        for name, shape, parts in self.entries:
+            for hf, r0, rows in parts:
+                yield hf, name, r0, rows
+
+
+class WeightSet:
+    """One set of LLM + projector weights in a flat bf16 buffer, with named 2-D views."""
+
+    def __init__(self, layout: ParamLayout, device, flat: Optional[torch.Tensor] = None):
+        self.layout = layout
+        self.flat = flat if flat is not None else torch.zeros(layout.numel, dtype=BF16, device=device)
+        self.v = {n: self.flat[layout.offset[n]: layout.offset[n] + int(math.prod(s))].view(*s)
+                  for n, s in layout.shape.items()}
+
+    def clone(self):
+        return WeightSet(self.layout, self.flat.device, self.flat.clone())
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict=True):
+        seen = set()
+        for hf, name, r0, rows in self.layout.hf_names():
+            if hf not in sd:
+                if strict:
+                    raise KeyError(f"missing weight {hf}")
+                continue
+            t = sd[hf]
+            dst = self.v[name]
+            if dst.dim() == 1:
+                dst.copy_(t.to(BF16))
+            else:
+                dst[r0:r0 + rows].copy_(t.to(BF16))
+            seen.add(hf)
+        return seen
+
+    def state_dict(self):
+        out = {}
+        for hf, name, r0, rows in self.layout.hf_names():
+            v = self.v[name]
+            out[hf] = v if v.dim() == 1 else v[r0:r0 + rows]
+        return out
+
+
+class VisionWeights:
+    """Frozen CLIP ViT weights, bf16, q|k|v fused, patch-embedding kernel flattened and K-padded to a multiple of 8."""
+
+    def __init__(self, cfg, sd, device, prefix="vision_tower.vision_model."):
+        D, P = cfg["vit_hidden"], cfg["patch_size"]
+        self.Kp = _align(3 * P * P, 8)
+        dv = lambda t: t.to(BF16).to(device).contiguous()  # noqa: E731
+        w = torch.zeros(D, self.Kp)
+        w[:, : 3 * P * P] = sd[prefix + "embeddings.patch_embedding.weight"].float().reshape(D, -1)
+        self.patch_w = dv(w)
+        self.cls = dv(sd[prefix + "embeddings.class_embedding"].reshape(D))
+        self.pos = dv(sd[prefix + "embeddings.position_embedding.weight"])
+        self.pre_w, self.pre_b = dv(sd[prefix + "pre_layrnorm.weight"]), dv(sd[prefix + "pre_layrnorm.bias"])
+        self.layers = []
+        self._keep = []
+        for i in range(cfg["vit_layers"] - 1):        # vision_feature_layer = -2: the last layer is never evaluated
+            p = f"{prefix}encoder.layers.{i}."
+            t = dict(
+                ln1_w=dv(sd[p + "layer_norm1.weight"]), ln1_b=dv(sd[p + "layer_norm1.bias"]),
+                wqkv=dv(torch.cat([sd[p + f"self_attn.{n}_proj.weight"] for n in "qkv"], 0)),
+                bqkv=dv(torch.cat([sd[p + f"self_attn.{n}_proj.bias"] for n in "qkv"], 0)),
+                wo=dv(sd[p + "self_attn.out_proj.weight"]), bo=dv(sd[p + "self_attn.out_proj.bias"]),
+                ln2_w=dv(sd[p + "layer_norm2.weight"]), ln2_b=dv(sd[p + "layer_norm2.bias"]),
+                w1=dv(sd[p + "mlp.fc1.weight"]), b1=dv(sd[p + "mlp.fc1.bias"]),
+                w2=dv(sd[p + "mlp.fc2.weight"]), b2=dv(sd[p + "mlp.fc2.bias"]))
+            self._keep.append(t)
+            self.layers.append(_hip.VitLayerWeights(*(t[k].data_ptr() for k in (
+                "ln1_w", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ln2_w", "ln2_b", "w1", "b1", "w2", "b2"))))
+
+
+class LlavaHipEngine:
+    def __init__(self, cfg: dict, device="cuda", max_positions: int = 4096):
+        if not torch.cuda.is_available():
+            raise _hip.VlrError("LlavaHipEngine needs an MI355X (torch.cuda.is_available() is False); "
+                                "there is no CPU fallback for the DPO hot path")
+        _hip.lib()
+        self.cfg = dict(cfg)
+        self.dev = torch.device(device)
+        c = self.cfg
+        self.H, self.I, self.V, self.L = c["hidden"], c["inter"], c["vocab"], c["layers"]
+        self.nh = c["heads"]
+        self.hd = self.H // self.nh
+        if self.hd != 128:
+            raise ValueError(f"decoder head_dim must be 128 for the gfx950 attention kernels, got {self.hd}")
+        self.D = c["vit_hidden"]
+        self.P = (c["image_size"] // c["patch_size"]) ** 2
+        self.layout = ParamLayout(c)
+        self.max_pos = max_positions
+        self.cos = torch.empty(max_positions, self.hd // 2, dtype=torch.float32, device=self.dev)
+        self.sin = torch.empty_like(self.cos)
+        _hip.call("vlr_rope_table", self.cos, self.sin, max_positions, self.hd, float(c.get("rope_theta", 10000.0)))
+        self.llama_cfg = _hip.LlamaCfg(self.H, self.I, self.nh, self.hd, float(c.get("rms_eps", 1e-5)), max_positions,
+                                       self.cos.data_ptr(), self.sin.data_ptr())
+        self.vit_cfg = _hip.VitCfg(self.D, c["vit_mlp"], c["vit_heads"], self.D // c["vit_heads"],
+                                   float(c.get("vit_ln_eps", 1e-5)))
+        if self.D // c["vit_heads"] != 64:
+            raise ValueError("ViT head_dim must be 64 for the gfx950 attention kernels")
+        self.vision: Optional[VisionWeights] = None
+        self.policy = WeightSet(self.layout, self.dev)
+        self.grads = torch.zeros(self.layout.numel, dtype=BF16, device=self.dev)
+        self.gv = {n: self.grads[self.layout.offset[n]: self.layout.offset[n] + int(math.prod(s))].view(*s)
+                   for n, s in self.layout.shape.items()}
+        self.master = self.m = self.v = None     # fp32 optimizer state, allocated by init_optimizer()
+        self.opt_step = 0
+        self.grad_fresh = True                   # next backward overwrites instead of accumulating
+        self._ws = {}
+        self._vit_cache = None
+        self.reducer = None                      # parallel.GradReducer for DDP
+        self._norm_ws = torch.empty(_hip.helper("vlr_rmsnorm_bwd_workspace_bytes", self.H), dtype=torch.uint8, device=self.dev)
+        self._colsum_ws = torch.empty(_hip.helper("vlr_colsum_workspace_bytes", max(self.H, 8)), dtype=torch.uint8, device=self.dev)
+        self._sq_ws = torch.empty(_hip.helper("vlr_grad_sqnorm_workspace_bytes"), dtype=torch.uint8, device=self.dev)
+        self.norm_out = torch.zeros(3, dtype=torch.float32, device=self.dev)
+
+    # ------------------------------------------------------------------------------------------------ weights
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        self.policy.load_state_dict(sd)
+        self.vision = VisionWeights(self.cfg, sd, self.dev)
+        self._vit_cache = None
+        if self.master is not None:
+            self.init_optimizer()
+
+    def layer_weights(self, ws: WeightSet, l):
+        v = ws.v
+        return _hip.LayerWeights(*(v[f"l{l}.{k}"].data_ptr() for k in ("ln1", "wqkv", "wo", "ln2", "wgu", "wdown")))
+
+    def layer_grads(self, l):
+        return _hip.LayerGrads(*(self.gv[f"l{l}.{k}"].data_ptr() for k in ("ln1", "wqkv", "wo", "ln2", "wgu", "wdown")))
+
+    # ------------------------------------------------------------------------------------------------ workspaces
+    def _buf(self, key, shape, dtype=BF16, zero=False):
+        t = self._ws.get(key)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = (torch.zeros if zero else torch.empty)(*shape, dtype=dtype, device=self.dev)
+            self._ws[key] = t
+        return t
+
+    def _layer_acts(self, tag, l, Bn, S):
+        M, H, I = Bn * S, self.H, self.I
+        Sp = _align(S, 64)
+        k = (tag, l, Bn, S)
+        t = self._ws.get(k)
+        if t is None:
+            t = dict(xn1=torch.empty(M, H, dtype=BF16, device=self.dev), rstd1=torch.empty(M, dtype=torch.float32, device=self.dev),
+                     qkv=torch.empty(M, 3 * H, dtype=BF16, device=self.dev), attn=torch.empty(M, H, dtype=BF16, device=self.dev),
+                     lse=torch.empty(Bn, self.nh, Sp, dtype=torch.float32, device=self.dev),
+                     x_mid=torch.empty(M, H, dtype=BF16, device=self.dev), xn2=torch.empty(M, H, dtype=BF16, device=self.dev),
+                     rstd2=torch.empty(M, dtype=torch.float32, device=self.dev), gu=torch.empty(M, 2 * I, dtype=BF16, device=self.dev),
+                     act=torch.empty(M, I, dtype=BF16, device=self.dev), x_out=torch.empty(M, H, dtype=BF16, device=self.dev))
+            t["struct"] = _hip.LayerActs(*(t[n].data_ptr() for n in ("xn1", "rstd1", "qkv", "attn", "lse", "x_mid", "xn2", "rstd2", "gu", "act", "x_out")))
+            self._ws[k] = t
+        return t
+
+    # ------------------------------------------------------------------------------------------------ vision
+    def vision_features(self, pixel_values: torch.Tensor) -> torch.Tensor:
+        """CLIP ViT hidden_states[-2] without CLS -> [n*P, D] bf16 (frozen tower: cached per pixel_values tensor so the
+        reference pass and the policy pass share one evaluation)."""
+        key = (pixel_values.data_ptr(), tuple(pixel_values.shape), pixel_values._version)
+        if self._vit_cache is not None and self._vit_cache[0] == key:
+            return self._vit_cache[1]
+        c = self.cfg
+        n = pixel_values.shape[0]
+        g = c["image_size"] // c["patch_size"]
+        T = g * g + 1
+        D, F = self.D, c["vit_mlp"]
+        vw = self.vision
+        pv = pixel_values.to(device=self.dev, dtype=torch.float32).contiguous()
+        patches = self._buf(("vit_patches", n), (n * g * g, vw.Kp))
+        _hip.call("vlr_im2col", pv, patches, n, c["image_size"], c["patch_size"], vw.Kp)
+        pe = self._buf(("vit_pe", n), (n * g * g, D))
+        _hip.call("vlr_gemm_bf16", 0, patches, vw.patch_w, pe, None, None, n * g * g, D, vw.Kp, vw.Kp, vw.Kp, D, 0, 0, 0, 0)
+        x = self._buf(("vit_x", n), (n * T, D))
+        _hip.call("vlr_vit_embed_ln", pe, vw.cls, vw.pos, vw.pre_w, vw.pre_b, x, n, T, D, self.vit_cfg.ln_eps)
+        wsb = dict(xn=self._buf(("vit_xn", n), (n * T, D)), qkv=self._buf(("vit_qkv", n), (n * T, 3 * D)),
+                   attn=self._buf(("vit_attn", n), (n * T, D)), h=self._buf(("vit_h", n), (n * T, F)))
+        ws = _hip.VitWs(*(wsb[k].data_ptr() for k in ("xn", "qkv", "attn", "h")))
+        for lw in vw.layers:
+            _hip.call("vlr_vit_layer_fwd", self.vit_cfg, lw, ws, x, n, T)
+        rows = self._ws.get(("vit_rows", n))
+        if rows is None:
+            rows = (torch.arange(n * T, device=self.dev, dtype=torch.int32).view(n, T)[:, 1:]).reshape(-1).contiguous()
+            self._ws[("vit_rows", n)] = rows
+        feat = torch.empty(n * (T - 1), D, dtype=BF16, device=self.dev)
+        _hip.call("vlr_gather_rows", x, rows, feat, n * (T - 1), D)
+        self._vit_cache = (key, feat, pixel_values)
+        return feat
+
+    def projector_fwd(self, ws: WeightSet, vit_feat, tag):
+        R, H, D = vit_feat.shape[0], self.H, self.D
+        z = self._buf((tag, "proj_z", R), (R, H))
+        h = self._buf((tag, "proj_h", R), (R, H))
+        out = self._buf((tag, "proj_out", R), (R, H))
+        _hip.call("vlr_gemm_bf16", 0, vit_feat, ws.v["proj.w1"], z, ws.v["proj.b1"], None, R, H, D, D, D, H, 0, 0, 0, 0)
+        _hip.call("vlr_gelu_fwd", z, h, z.numel())
+        _hip.call("vlr_gemm_bf16", 0, h, ws.v["proj.w2"], out, ws.v["proj.b2"], None, R, H, H, H, H, H, 0, 0, 0, 0)
+        return out, z, h
+
+    # ------------------------------------------------------------------------------------------------ forward
+    def forward_hidden(self, ws: WeightSet, input_ids, attention_mask, labels, pixel_values, image_dup=1, save=False,
+                       tag="ref"):
+        """embed -> ViT -> projector -> merge -> decoder -> final RMSNorm.  Returns a context dict with the final
+        hidden states [Bn*S, H] and the merged labels / mask / positions."""
+        c = self.cfg
+        Bn, T = input_ids.shape
+        ids = input_ids.to(self.dev).contiguous()
+        am = attention_mask.to(self.dev).contiguous()
+        lab = labels.to(self.dev).contiguous() if labels is not None else None
+        n_img = pixel_values.shape[0]
+        if image_dup > 1:
+            assert n_img % image_dup == 0
+            uniq = pixel_values[: n_img // image_dup]
+        else:
+            uniq = pixel_values
+        vit_feat = self.vision_features(uniq)
+        feats, z, h = self.projector_fwd(ws, vit_feat, tag)
+        n_rows = feats.shape[0]
+        P = self.P
+        n_img_tok = (ids == c["image_token"]).sum(-1)
+        S = int(n_img_tok.max()) * (P - 1) + T                       # one small D2H sync (shape of the merged batch)
+        M = Bn * S
+        src = self._buf((tag, "src", Bn, S), (Bn, S), torch.int32)
+        mask = torch.empty(Bn, S, dtype=torch.int32, device=self.dev)
+        mlabels = torch.empty(Bn, S, dtype=torch.int64, device=self.dev)
+        pos = torch.empty(Bn, S, dtype=torch.int32, device=self.dev)
+        img_map = torch.empty(Bn, S, dtype=torch.uint8, device=self.dev)
+        inv = self._buf((tag, "inv", image_dup, n_rows), (image_dup, n_rows), torch.int32)
+        info = torch.zeros(2, dtype=torch.int32, device=self.dev)
+        _hip.call("vlr_merge_index", ids, am, lab, Bn, T, S, P, int(c["image_token"]),
+                  int(c.get("model_pad_token_id", c["image_token"] + 1)), n_rows, image_dup, src, mask, mlabels, pos,
+                  img_map, inv, info)
+        found = int(info[0])
+        if found != n_rows * image_dup:
+            raise ValueError(
+                f"The input provided to the model are wrong. The number of image tokens is {int(n_img_tok.sum())} while"
+                f" the number of image given to the model is {n_img}. This prevents correct indexing and breaks batch"
+                " generation.")
+        x0 = self._buf((tag, "x0", Bn, S), (M, self.H))
+        _hip.call("vlr_merge_fwd", src, ids, ws.v["embed"], feats, x0, Bn, T, S, self.H)
+        x = x0
+        acts = []
+        for l in range(self.L):
+            a = self._layer_acts(tag if save else "scratch", l if save else (l % 2), Bn, S)
+            _hip.call("vlr_decoder_layer_fwd", self.llama_cfg, self.layer_weights(ws, l), a["struct"], x, pos, mask, Bn, S)
+            acts.append(a)
+            x = a["x_out"]
+        hidden = torch.empty(M, self.H, dtype=BF16, device=self.dev)
+        rstd_f = self._buf((tag, "rstd_f", M), (M,), torch.float32)
+        _hip.call("vlr_rmsnorm_fwd", x, ws.v["norm"], hidden, rstd_f, M, self.H, self.llama_cfg.rms_eps)
+        return dict(ws=ws, Bn=Bn, T=T, S=S, M=M, ids=ids, src=src, inv=inv, mask=mask, labels=mlabels, pos=pos,
+                    img_map=img_map.bool(), hidden=hidden, rstd_f=rstd_f, x_last=x, x0=x0, acts=acts if save else None,
+                    vit_feat=vit_feat, feats=feats, proj_z=z, proj_h=h, image_dup=image_dup, n_rows=n_rows, tag=tag)
+
+    # ------------------------------------------------------------------------------------------------ log-probs
+    def logps_forward(self, ctx, labels, shared_mask=None, average=False, label_pad=-100):
+        """get_batch_logps on the lm-head restricted to the response rows (identical result: every other row is
+        multiplied by a zero mask in the reference, base/trainer.py:185-188).  Returns (logps [Bn], lp_ctx)."""
+        Bn, S, M, H, V = ctx["Bn"], ctx["S"], ctx["M"], self.H, self.V
+        ws = ctx["ws"]
+        if tuple(labels.shape) != (Bn, S):
+            raise ValueError("Logits (batch and sequence length dim) and labels must have the same shape.")
+        lab = labels.to(self.dev).contiguous()
+        rows = torch.empty(M, dtype=torch.int32, device=self.dev)
+        tgt = torch.empty(M, dtype=torch.int32, device=self.dev)
+        seq_off = torch.empty(Bn + 1, dtype=torch.int32, device=self.dev)
+        sm = shared_mask.to(device=self.dev, dtype=torch.uint8).contiguous() if shared_mask is not None else None
+        _hip.call("vlr_build_rows", lab, sm, Bn, S, label_pad, rows, tgt, seq_off)
+        R = int(seq_off[-1])                                          # one small D2H sync (row count of the lm-head GEMM)
+        logps = torch.zeros(Bn, dtype=torch.float32, device=self.dev)
+        lp = dict(R=R, rows=rows, tgt=tgt, seq_off=seq_off, average=average, ctx=ctx)
+        if R == 0:
+            return logps, lp
+        hg = torch.empty(R, H, dtype=BF16, device=self.dev)
+        _hip.call("vlr_gather_rows", ctx["hidden"], rows, hg, R, H)
+        logits = self._buf(("logits", R), (R, V), torch.float32)
+        _hip.call("vlr_gemm_bf16", 0, hg, ws.v["lm_head"], logits, None, None, R, V, H, H, H, V, 0, 0, 0, 1)
+        tok = torch.empty(R, dtype=torch.float32, device=self.dev)
+        lse = torch.empty(R, dtype=torch.float32, device=self.dev)
+        _hip.call("vlr_logp_rows", logits, None, tgt, R, V, V, tok, lse)
+        _hip.call("vlr_seq_sum", tok, seq_off, Bn, int(average), logps)
+        lp.update(hg=hg, lse=lse, tok=tok)
+        return logps, lp
+
+    def logits_mean(self, ctx, lo, hi):
+        """mean over [lo:hi] sequences, all positions, all vocabulary entries of the logits = mean_rows(h . sum_v W_v)/V
+        (the `logits/chosen|rejected` metrics of trl's get_batch_loss_metrics, never materialising [B,S,V])."""
+        ws = ctx["ws"]
+        wsum = self._ws.get(("wsum", id(ws), ws.flat._version))
+        if wsum is None:
+            wsum = torch.empty(self.H, dtype=torch.float32, device=self.dev)
+            _hip.call("vlr_colsum_f32", ws.v["lm_head"], self.V, self.H, self.H, wsum, self._colsum_ws)
+            self._ws = {k: v for k, v in self._ws.items() if not (isinstance(k, tuple) and k and k[0] == "wsum")}
+            self._ws[("wsum", id(ws), ws.flat._version)] = wsum
+        S = ctx["S"]
+        rd = torch.empty(ctx["M"], dtype=torch.float32, device=self.dev)
+        _hip.call("vlr_rowdot", ctx["hidden"], wsum, rd, ctx["M"], self.H)
+        return rd[lo * S: hi * S].mean() / self.V
+
+    def materialize_logits(self, ctx, lo=0, hi=None):
+        """Full fp32 logits [hi-lo, S, V] (debug / small shapes / callers that insist on a tensor)."""
+        hi = ctx["Bn"] if hi is None else hi
+        S = ctx["S"]
+        n = (hi - lo) * S
+        out = torch.empty(n, self.V, dtype=torch.float32, device=self.dev)
+        hsl = ctx["hidden"][lo * S: hi * S]
+        _hip.call("vlr_gemm_bf16", 0, hsl, ctx["ws"].v["lm_head"], out, None, None, n, self.V, self.H, self.H, self.H, self.V, 0, 0, 0, 1)
+        return out.view(hi - lo, S, self.V)
+
+    # ------------------------------------------------------------------------------------------------ backward
+    def logps_backward(self, lp, dlogps):
+        """d logps -> d hidden (dense [M,H], zero outside the response rows) and the lm_head weight gradient."""
+        ctx = lp["ctx"]
+        M, H, V, R = ctx["M"], self.H, self.V, lp["R"]
+        acc = int(not self.grad_fresh)
+        dhidden = torch.zeros(M, H, dtype=BF16, device=self.dev)
+        if R == 0:
+            if not acc:
+                self.gv["lm_head"].zero_()
+            return dhidden
+        logits = self._buf(("logits", R), (R, V), torch.float32)
+        # recompute the logits of the response rows if another pass (the reference forward) reused the buffer
+        _hip.call("vlr_gemm_bf16", 0, lp["hg"], ctx["ws"].v["lm_head"], logits, None, None, R, V, H, H, H, V, 0, 0, 0, 1)
+        dl = self._buf(("dlogits", R), (R, V))
+        _hip.call("vlr_dlogits_rows", logits, lp["tgt"], lp["lse"], lp["seq_off"], ctx["Bn"],
+                  dlogps.to(torch.float32).contiguous(), int(lp["average"]), R, V, V, dl, V)
+        dhg = torch.empty(R, H, dtype=BF16, device=self.dev)
+        _hip.call("vlr_gemm_bf16", 1, dl, ctx["ws"].v["lm_head"], dhg, None, None, R, H, V, V, H, H, 0, 0, 0, 0)
+        _hip.call("vlr_gemm_bf16", 2, dl, lp["hg"], self.gv["lm_head"], None, None, V, H, R, V, H, H, 0, 0, acc, 0)
+        _hip.call("vlr_scatter_rows", dhg, lp["rows"], dhidden, R, H)
+        if self.reducer is not None:
+            self.reducer.bucket_ready("lm_head")
+        return dhidden
+
+    def hidden_backward(self, ctx, dhidden):
+        """Backward of forward_hidden(save=True): final norm, decoder layers L-1..0, merge, projector.  Gradients
+        land in the flat bf16 gradient buffer (overwrite when `grad_fresh`, else accumulate)."""
+        assert ctx["acts"] is not None, "forward_hidden(save=True) required"
+        ws = ctx["ws"]
+        Bn, S, M, H, I = ctx["Bn"], ctx["S"], ctx["M"], self.H, self.I
+        acc = int(not self.grad_fresh)
+        Sp = _align(S, 64)
+        dxa = self._buf(("dxa", M), (M, H))
+        dxb = self._buf(("dxb", M), (M, H))
+        _hip.call("vlr_rmsnorm_bwd", dhidden, ctx["x_last"], ws.v["norm"], ctx["rstd_f"], None, dxa, self.gv["norm"], acc,
+                  self._norm_ws, M, H)
+        wsb = dict(dact=self._buf(("dact", M), (M, I)), dxn=self._buf(("dxn", M), (M, H)), dattn=self._buf(("dattn", M), (M, H)),
+                   dqkv=self._buf(("dqkv", M), (M, 3 * H)), dx_mid=self._buf(("dx_mid", M), (M, H)),
+                   delta=self._buf(("delta", Bn, S), (Bn, self.nh, Sp), torch.float32))
+        lws = _hip.LayerBwdWs(wsb["dact"].data_ptr(), wsb["dxn"].data_ptr(), wsb["dattn"].data_ptr(), wsb["dqkv"].data_ptr(),
+                              wsb["dx_mid"].data_ptr(), wsb["delta"].data_ptr(), self._norm_ws.data_ptr())
+        cur, nxt = dxa, dxb
+        for l in range(self.L - 1, -1, -1):
+            a = ctx["acts"][l]
+            x_in = ctx["acts"][l - 1]["x_out"] if l > 0 else ctx["x0"]
+            _hip.call("vlr_decoder_layer_bwd", self.llama_cfg, self.layer_weights(ws, l), self.layer_grads(l), acc,
+                      a["struct"], lws, x_in, cur, nxt, ctx["pos"], ctx["mask"], Bn, S)
+            cur, nxt = nxt, cur
+            if self.reducer is not None:
+                self.reducer.bucket_ready(f"layer{l}")
+        # ---- merge + projector
+        n_rows, dup = ctx["n_rows"], ctx["image_dup"]
+        if not acc:
+            self.gv["embed"].zero_()          # the embedding gradient is scatter-added with atomics
+        dfeats = self._buf(("dfeats", n_rows), (n_rows, H))
+        _hip.call("vlr_merge_bwd", cur, ctx["src"], ctx["inv"], ctx["ids"], dfeats, self.gv["embed"], Bn, ctx["T"], S, H, n_rows, dup)
+        D = self.D
+        _hip.call("vlr_colsum", dfeats, n_rows, H, H, self.gv["proj.b2"], acc, self._colsum_ws)
+        _hip.call("vlr_gemm_bf16", 2, dfeats, ctx["proj_h"], self.gv["proj.w2"], None, None, H, H, n_rows, H, H, H, 0, 0, acc, 0)
+        dh = self._buf(("proj_dh", n_rows), (n_rows, H))
+        _hip.call("vlr_gemm_bf16", 1, dfeats, ws.v["proj.w2"], dh, None, None, n_rows, H, H, H, H, H, 0, 0, 0, 0)
+        dz = self._buf(("proj_dz", n_rows), (n_rows, H))
+        _hip.call("vlr_gelu_bwd", ctx["proj_z"], dh, dz, dz.numel())
+        _hip.call("vlr_colsum", dz, n_rows, H, H, self.gv["proj.b1"], acc, self._colsum_ws)
+        _hip.call("vlr_gemm_bf16", 2, dz, ctx["vit_feat"], self.gv["proj.w1"], None, None, H, D, n_rows, H, D, D, 0, 0, acc, 0)
+        self.grad_fresh = False
+        if self.reducer is not None:
+            self.reducer.bucket_ready("tail")
+
+    # ------------------------------------------------------------------------------------------------ optimizer
+    def init_optimizer(self):
+        """fp32 master copy + Adam moments for the flat parameter buffer (28 B of HBM traffic per parameter and step).
+        The reference leaves the precision policy to DeepSpeed/DDP; fp32 master + fp32 moments is the documented choice."""
+        self.master = self.policy.flat.float()
+        self.m = torch.zeros_like(self.master)
+        self.v = torch.zeros_like(self.master)
+        self.opt_step = 0
+
+    def zero_grad(self):
+        self.grad_fresh = True
+
+    def optimizer_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, grad_scale=1.0):
+        """clip_grad_norm_(max_grad_norm) + AdamW on the flat buffers; no host synchronisation (the clip coefficient
+        stays on the device).  grad_scale multiplies the raw gradients first (1/world_size after a sum all-reduce,
+        1/gradient_accumulation_steps ...).  Returns the device tensor [norm, coef, sum g^2]."""
+        if self.master is None:
+            self.init_optimizer()
+        if self.reducer is not None:
+            self.reducer.wait()
+        n = self.layout.numel
+        _hip.call("vlr_grad_sqnorm", self.grads, n, float(max_grad_norm if max_grad_norm else 0.0), float(grad_scale), 0.0,
+                  self._sq_ws, self.norm_out)
+        self.opt_step += 1
+        nd = self.layout.n_decay
+        for lo, hi, wd in ((0, nd, weight_decay), (nd, n, 0.0)):
+            _hip.call("vlr_adamw_step", self.master[lo:hi], self.m[lo:hi], self.v[lo:hi], self.grads[lo:hi],
+                      self.policy.flat[lo:hi], hi - lo, float(lr), float(beta1), float(beta2), float(eps), float(wd),
+                      self.opt_step, self.norm_out)
+        self.grad_fresh = True
+        return self.norm_out

@@ -1,0 +1,400 @@
+"""LLaVA-1.5 wrapper for the MI355X DPO path - mirror of /root/reference/src/vlrlhf/models/Llava/__init__.py
+(LlavaRLOutputWithPast :22-32, LlavaForRL :35-298, LlavaProcessor :315-432, LlavaDPODataCollatorWithPadding :435-443,
+LlavaDPOTrainer :474, core_mapper :486-499).  `LlavaForRL.forward` keeps the reference call signature and output
+fields; underneath it runs vlrlhf.engine (HIP kernels) and returns a LAZY logits handle so the [2B,S,V] fp32 tensor is
+never written to HBM unless a caller asks for it."""
+import json
+import os
+from dataclasses import dataclass
+from typing import Any, Dict, List, Literal, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from ... import _hip
+from ...base.collator import VLDPODataCollatorWithPadding
+from ...base.processor import VLChatTemplate, VLProcessor
+from ...base.trainer import VLDPOTrainer
+from ...engine import BF16, LlavaHipEngine, WeightSet
+from ...utils.common import flatten_list
+from ..utils import ModelCoreMapper
+
+
+@dataclass
+class LlavaRLOutputWithPast:
+    loss: Optional[torch.Tensor] = None
+    logits: Any = None
+    past_key_values: Optional[List[torch.Tensor]] = None
+    hidden_states: Optional[Tuple[torch.Tensor]] = None
+    attentions: Optional[Tuple[torch.Tensor]] = None
+    image_hidden_states: Optional[Tuple[torch.Tensor]] = None
+    labels: Optional[torch.Tensor] = None
+    image_position_map: Optional[torch.Tensor] = None
+
+    def __getitem__(self, k):
+        return getattr(self, k) if isinstance(k, str) else (self.loss, self.logits)[k]
+
+
+# ----------------------------------------------------------------------------------------------------------
+class _HiddenFn(torch.autograd.Function):
+    """embed -> ViT -> projector -> merge -> 32 decoder layers -> final norm, as ONE autograd node.  Parameter
+    gradients are written by the HIP backward straight into the engine's flat gradient buffer (the .grad of every
+    nn.Parameter is a view of it), so this node returns no tensor gradients."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, input_ids, attention_mask, labels, pixel_values, dup):
+        c = model.engine.forward_hidden(model.weights, input_ids, attention_mask, labels, pixel_values, image_dup=dup,
+                                        save=True, tag="policy")
+        ctx.c, ctx.engine = c, model.engine
+        model._last_ctx = c
+        return c["hidden"]
+
+    @staticmethod
+    def backward(ctx, dhidden):
+        ctx.engine.hidden_backward(ctx.c, dhidden.contiguous())
+        ctx.c = None
+        return (None,) * 7
+
+
+class _LogpsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hidden, engine, c, labels, shared, average, label_pad):
+        logps, lp = engine.logps_forward(c, labels, shared, average, label_pad)
+        ctx.lp, ctx.engine = lp, engine
+        return logps
+
+    @staticmethod
+    def backward(ctx, dlogps):
+        dh = ctx.engine.logps_backward(ctx.lp, dlogps.contiguous())
+        ctx.lp = None
+        return (dh,) + (None,) * 6
+
+
+class LazyLogits:
+    """Stand-in for the [B,S,V] logits of the reference (`output.logits`): supports what the DPO path does with them -
+    `get_batch_logps` (fused lm-head + log-softmax pick on the response rows), batch slicing, `.detach()`, `.mean()`
+    (trl's logits/* metrics) - and `materialize()` for callers that need the tensor."""
+
+    def __init__(self, engine, c, hidden, lo=0, hi=None):
+        self.engine, self.c, self.hidden = engine, c, hidden
+        self.lo, self.hi = lo, (c["Bn"] if hi is None else hi)
+
+    @property
+    def shape(self):
+        return torch.Size((self.hi - self.lo, self.c["S"], self.engine.V))
+
+    @property
+    def dtype(self):
+        return torch.float32
+
+    @property
+    def device(self):
+        return self.engine.dev
+
+    is_cuda = True
+
+    def __getitem__(self, idx):
+        if isinstance(idx, slice):
+            lo, hi, st = idx.indices(self.hi - self.lo)
+            assert st == 1
+            return LazyLogits(self.engine, self.c, self.hidden, self.lo + lo, self.lo + hi)
+        return self.materialize()[idx]
+
+    def detach(self):
+        return LazyLogits(self.engine, self.c, self.hidden.detach(), self.lo, self.hi)
+
+    def float(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def mean(self):
+        return self.engine.logits_mean(self.c, self.lo, self.hi)
+
+    def materialize(self):
+        return self.engine.materialize_logits(self.c, self.lo, self.hi)
+
+    def batch_logps(self, labels, shared, average, label_pad):
+        assert self.lo == 0 and self.hi == self.c["Bn"], "get_batch_logps expects the whole concatenated batch"
+        if self.hidden.requires_grad:
+            return _LogpsFn.apply(self.hidden, self.engine, self.c, labels, shared, bool(average), int(label_pad))
+        logps, _ = self.engine.logps_forward(self.c, labels, shared, bool(average), int(label_pad))
+        return logps
+
+
+class _Config(dict):
+    """attribute + dict access; the handful of HF config fields the reference reads."""
+    __getattr__ = dict.get
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def _cfg_from_hf(hf: dict) -> dict:
+    t, v = hf.get("text_config", {}), hf.get("vision_config", {})
+    hidden = t.get("hidden_size", 4096)
+    return dict(
+        vit_hidden=v.get("hidden_size", 1024), vit_mlp=v.get("intermediate_size", 4096),
+        vit_layers=v.get("num_hidden_layers", 24), vit_heads=v.get("num_attention_heads", 16),
+        image_size=v.get("image_size", 336), patch_size=v.get("patch_size", 14), vit_ln_eps=v.get("layer_norm_eps", 1e-5),
+        hidden=hidden, inter=t.get("intermediate_size", 11008), layers=t.get("num_hidden_layers", 32),
+        heads=t.get("num_attention_heads", 32), vocab=t.get("vocab_size", hf.get("vocab_size", 32064)),
+        rms_eps=t.get("rms_norm_eps", 1e-5), rope_theta=t.get("rope_theta", 10000.0),
+        image_token=hf.get("image_token_index", 32000), model_pad_token_id=hf.get("pad_token_id", 32001),
+        ignore_index=hf.get("ignore_index", -100))
+
+
+class LlavaForRL(nn.Module):
+    def __init__(self, cfg: dict, engine: Optional[LlavaHipEngine] = None, weights: Optional[WeightSet] = None,
+                 trainable: bool = True):
+        super().__init__()
+        self.engine = engine if engine is not None else LlavaHipEngine(cfg)
+        self.weights = weights if weights is not None else self.engine.policy
+        self.config = _Config(cfg)
+        self.config.setdefault("is_encoder_decoder", False)
+        self.config.setdefault("image_token_index", cfg["image_token"])
+        self.config.setdefault("ignore_index", -100)
+        self.config.setdefault("use_cache", False)
+        self.pad_token_id = cfg.get("model_pad_token_id", cfg["image_token"] + 1)
+        self._trainable = trainable and self.weights is self.engine.policy
+        self._params = nn.ParameterDict()
+        self._hf_names = {}
+        if self._trainable:
+            sd = self.weights.state_dict()
+            for i, (hf, v) in enumerate(sd.items()):
+                p = nn.Parameter(v, requires_grad=True)
+                self._params[f"p{i}"] = p
+                self._hf_names[f"_params.p{i}"] = hf
+            gsd = WeightSet(self.engine.layout, self.engine.dev, self.engine.grads).state_dict()
+            for i, hf in enumerate(sd.keys()):
+                self._params[f"p{i}"].grad = gsd[hf]
+        self._anchor = nn.Parameter(torch.zeros(1, device=self.engine.dev), requires_grad=True)
+        self._last_ctx = None
+        self._vision_frozen = True
+
+    # ---- construction ---------------------------------------------------------------------------------
+    @classmethod
+    def from_state_dict(cls, cfg: dict, sd: Dict[str, torch.Tensor], **kw):
+        m = cls(cfg, **kw)
+        m.engine.load_state_dict(sd)
+        return m
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, *args, torch_dtype=None, use_flash_attention_2=None, **kwargs):
+        """reads a transformers==4.41.0 LLaVA checkpoint directory (config.json + *.safetensors)."""
+        from safetensors.torch import load_file
+        path = pretrained_model_name_or_path
+        with open(os.path.join(path, "config.json")) as f:
+            cfg = _cfg_from_hf(json.load(f))
+        m = cls(cfg)
+        sd = {}
+        idx = os.path.join(path, "model.safetensors.index.json")
+        files = sorted(set(json.load(open(idx))["weight_map"].values())) if os.path.exists(idx) else \
+            [f for f in os.listdir(path) if f.endswith(".safetensors")]
+        for fn in files:
+            sd.update(load_file(os.path.join(path, fn)))
+        m.engine.load_state_dict(sd)
+        return m
+
+    def create_reference_model(self):
+        """trl.create_reference_model: a frozen deep copy of the policy weights sharing the engine (and the frozen ViT)."""
+        ref = LlavaForRL(dict(self.engine.cfg), engine=self.engine, weights=self.weights.clone(), trainable=False)
+        ref.eval()
+        return ref
+
+    # ---- reference wrapper API (docs/CustomizedModel.md:7-11; Llava/__init__.py:273-298) ------------------
+    def named_parameters(self, *a, **k):
+        for n, p in super().named_parameters(*a, **k):
+            if n == "_anchor":
+                continue
+            yield self._hf_names.get(n, n), p
+
+    def parameters(self, recurse=True):
+        for _, p in self.named_parameters():
+            yield p
+
+    def state_dict(self, *a, **k):
+        out = dict(self.weights.state_dict())
+        return out
+
+    @property
+    def default_lora_target(self):
+        return ["q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj"]
+
+    def get_vision_tower(self):
+        return self.engine.vision
+
+    def freeze_vision_tower(self):
+        self._vision_frozen = True          # the MI355X path keeps the tower frozen (reference default, auto_load.py:554)
+
+    def prepare_default_generation_kwargs(self, generation_config):
+        generation_config.max_new_tokens = 1024
+        generation_config.do_sample = False
+        return dict(generation_config=generation_config)
+
+    def zero_grad(self, set_to_none: bool = True):
+        self.engine.zero_grad()
+
+    def prefetch_vision(self, img_input_dict):
+        pv = img_input_dict.get("pixel_values")
+        if pv is not None:
+            dup = getattr(pv, "_vlr_dup", 1)
+            self.engine.vision_features(pv[: pv.shape[0] // dup] if dup > 1 else pv)
+
+    def get_input_embeddings(self):
+        return self.weights.v["embed"]
+
+    # ---- forward ----------------------------------------------------------------------------------------
+    def forward(self, input_ids=None, pixel_values=None, attention_mask=None, position_ids=None, past_key_values=None,
+                inputs_embeds=None, vision_feature_layer=None, vision_feature_select_strategy=None, labels=None,
+                use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None):
+        """reference Llava/__init__.py:111-271 on the training path.  Returns `logits` (lazy), the EXPANDED `labels`
+        and `image_position_map`; the reference's internal cross-entropy `loss` (:246-257, unused by DPO) is None."""
+        if inputs_embeds is not None or past_key_values is not None or use_cache:
+            raise NotImplementedError("generation / KV-cache inputs are outside the MI355X DPO training path")
+        if pixel_values is None:
+            raise ValueError("LlavaForRL.forward on the DPO path needs pixel_values")
+        if vision_feature_layer not in (None, -2) or vision_feature_select_strategy not in (None, "default"):
+            raise ValueError(f"Unexpected select feature strategy: {vision_feature_select_strategy}")
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        dup = int(getattr(pixel_values, "_vlr_dup", 1))
+        grad = torch.is_grad_enabled() and self._trainable and self.training
+        if grad:
+            hidden = _HiddenFn.apply(self._anchor, self, input_ids, attention_mask, labels, pixel_values, dup)
+            c = self._last_ctx
+        else:
+            c = self.engine.forward_hidden(self.weights, input_ids, attention_mask, labels, pixel_values, image_dup=dup,
+                                           save=False, tag="policy_ng" if self.weights is self.engine.policy else "ref")
+            hidden = c["hidden"]
+        out_labels = c["labels"] if labels is not None else torch.full_like(c["mask"], -100, dtype=torch.long)
+        return LlavaRLOutputWithPast(loss=None, logits=LazyLogits(self.engine, c, hidden), labels=out_labels,
+                                     image_position_map=c["img_map"])
+
+
+# ----------------------------------------------------------------------------------------------------------
+class LlavaProcessor(VLProcessor):
+    def __init__(self, model_name_or_path=None, tokenizer=None, image_processor=None, **kwargs) -> None:
+        if model_name_or_path is not None:
+            import transformers
+            self.processor = transformers.LlavaProcessor.from_pretrained(model_name_or_path, **kwargs)
+            self._tok, self._ip = self.processor.tokenizer, self.processor.image_processor
+        else:
+            self.processor = None
+            self._tok, self._ip = tokenizer, image_processor
+
+    @property
+    def tokenizer(self):
+        return self._tok
+
+    @property
+    def chat_template(self):
+        return VLChatTemplate(system_begin=None, system_end=None, user_begin="USER: ", user_end="",
+                              assistant_begin="ASSISTANT: ", assistant_end="", image_placeholder="<image>\n")
+
+    @property
+    def image_processor(self):
+        return self._ip
+
+    def save_pretrained(self, output_dir):
+        if self.processor is not None:
+            return self.processor.save_pretrained(output_dir)
+
+    def process_batch_conv(self, sources, system_message=None, add_end_for_empty_value=False):
+        """reference Llava/__init__.py:343-388."""
+        if not isinstance(sources, list) or not isinstance(sources[0], list):
+            raise ValueError("sources must be a batch of conversations, eg. List[List[Dict]]")
+        t = self.chat_template
+        begin = {"user": t.user_begin, "assistant": t.assistant_begin}
+        end = {"user": t.user_end, "assistant": t.assistant_end}
+        raw_texts, b_ids, b_masks, b_labels = [], [], [], []
+        for source in sources:
+            raw, labels, prev = "", [], 0
+            ids, masks = [], []
+            for i, s in enumerate(source):
+                raw += begin[s["from"]] + s["value"] + (end[s["from"]] if s["value"] != "" or add_end_for_empty_value else "")
+                text_tokens = self.tokenizer(s["value"], padding=False, add_special_tokens=(i == 0))
+                cur = self.tokenizer(raw)
+                ids, masks = cur["input_ids"], cur["attention_mask"]
+                ext = len(ids) - prev
+                prev = len(ids)
+                labels.extend([-100] * ext)
+                if s["from"] == "assistant" and len(text_tokens["input_ids"]) != 0:
+                    n = min(ext, len(text_tokens["input_ids"]), len(labels))
+                    labels[-n:] = text_tokens["input_ids"][-n:]
+            labels = [l if m == 1 else -100 for l, m in zip(labels, masks)]
+            assert len(ids) == len(masks) == len(labels), f"input_ids:{len(ids)}, attention_masks:{len(masks)}, labels:{len(labels)}"
+            b_ids.append(ids)
+            b_masks.append(masks)
+            b_labels.append(labels)
+            raw_texts.append(raw)
+        return {"prompt": None, "answer": None,
+                "full": dict(input_ids=b_ids, attention_mask=b_masks, labels=b_labels), "raw_str": raw_texts}
+
+    @staticmethod
+    def format_multimodal_prompt(prompt: str, img_paths=None):
+        if img_paths is None:
+            return prompt
+        if not isinstance(img_paths, list):
+            img_paths = [img_paths]
+        if len(img_paths) == 1 and "<image>" not in prompt:
+            return "<image>\n" + prompt
+        assert prompt.count("<image>") == len(img_paths), \
+            f"The number of given image ({len(img_paths)}) does not match the number of image placeholders in the prompt: {prompt}"
+        return prompt.replace("<image>", "<image>\n")
+
+    @staticmethod
+    def remove_image_placeholder(prompt: str):
+        return prompt.replace("<image>\n", "")
+
+    @staticmethod
+    def is_multimodal_prompt_valid(prompt: str):
+        return "<image>\n" in prompt
+
+    def train(self):
+        self.tokenizer.pad_token = self.tokenizer.unk_token
+
+    def infer(self):
+        self.tokenizer.pad_token = self.tokenizer.bos_token
+
+    def __call__(self, texts=None, convs=None, images_path=None, padding=True, padding_side="left", check_format=True):
+        inputs = super().__call__(texts, convs, images_path, padding, padding_side, check_format)
+        if images_path is not None:
+            inputs["pixel_values"] = load_pixel_values(flatten_list(images_path), self.image_processor)
+        return inputs
+
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def load_pixel_values(items, image_processor=None) -> torch.Tensor:
+    """paths / PIL images -> CLIP-normalised fp32 [n,3,S,S] via the HF CLIPImageProcessor (reference :435-443); items that
+    already are [3,S,S] float tensors (synthetic data) pass through."""
+    if all(isinstance(i, torch.Tensor) for i in items):
+        return torch.stack([i.float() for i in items])
+    from PIL import Image
+    imgs = [Image.open(i).convert("RGB") if isinstance(i, str) else i for i in items]
+    return image_processor(images=imgs, return_tensors="pt")["pixel_values"]
+
+
+@dataclass
+class LlavaDPODataCollatorWithPadding(VLDPODataCollatorWithPadding):
+    def __call__(self, features: List[Dict[str, Any]]) -> Dict[str, Any]:
+        padded = super().__call__(features)
+        ip = self.processor.image_processor if self.processor is not None else None
+        padded["img_input_dict"] = dict(pixel_values=load_pixel_values(padded["img_path"], ip))
+        return padded
+
+
+class LlavaDPOTrainer(VLDPOTrainer):
+    ...
+
+
+core_mapper = ModelCoreMapper(
+    model=LlavaForRL,
+    processor=LlavaProcessor,
+    dpo_collator=LlavaDPODataCollatorWithPadding,
+    dpo_trainer=LlavaDPOTrainer,
+)

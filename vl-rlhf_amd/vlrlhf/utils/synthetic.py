@@ -1,0 +1,91 @@
+"""Synthetic LLaVA-shaped weights and DPO batches on the device (benchmarks / smoke runs: no checkpoints, no network).
+Workload definition: SURVEY.md section 8(d)."""
+import numpy as np
+import torch
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+LLAVA_1_5_7B = dict(vit_hidden=1024, vit_mlp=4096, vit_layers=24, vit_heads=16, image_size=336, patch_size=14,
+                    hidden=4096, inter=11008, layers=32, heads=32, vocab=32064, image_token=32000,
+                    model_pad_token_id=32001, rms_eps=1e-5, rope_theta=10000.0)
+
+
+def vision_state_dict(cfg, device, seed=0, std=0.02, prefix="vision_tower.vision_model."):
+    g = torch.Generator(device=device).manual_seed(seed)
+    D, P, F = cfg["vit_hidden"], cfg["patch_size"], cfg["vit_mlp"]
+    T = (cfg["image_size"] // P) ** 2 + 1
+
+    def rnd(*shape, s=std):
+        return (torch.randn(*shape, generator=g, device=device) * s).to(torch.bfloat16)
+
+    sd = {prefix + "embeddings.class_embedding": rnd(D), prefix + "embeddings.patch_embedding.weight": rnd(D, 3, P, P),
+          prefix + "embeddings.position_embedding.weight": rnd(T, D)}
+    for nm in ("pre_layrnorm", "post_layernorm"):
+        sd[prefix + nm + ".weight"] = (1 + rnd(D, s=0.05).float()).to(torch.bfloat16)
+        sd[prefix + nm + ".bias"] = rnd(D)
+    for i in range(cfg["vit_layers"]):
+        p = f"{prefix}encoder.layers.{i}."
+        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            sd[p + f"self_attn.{nm}.weight"] = rnd(D, D)
+            sd[p + f"self_attn.{nm}.bias"] = rnd(D)
+        for nm in ("layer_norm1", "layer_norm2"):
+            sd[p + nm + ".weight"] = (1 + rnd(D, s=0.05).float()).to(torch.bfloat16)
+            sd[p + nm + ".bias"] = rnd(D)
+        sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"] = rnd(F, D), rnd(F)
+        sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"] = rnd(D, F), rnd(D)
+    return sd
+
+
+def init_random_model(model, seed=0, std=0.02, policy_delta=1e-3):
+    """N(0, std) weights (norm gains 1), written straight into the engine's flat buffers; returns a reference model
+    whose LLM/projector weights differ from the policy by N(0, policy_delta) (avoids the loss == ln 2 degenerate case)."""
+    from ..engine import VisionWeights
+    eng = model.engine
+    g = torch.Generator(device=eng.dev).manual_seed(seed)
+    flat = eng.policy.flat
+    step = 1 << 28
+    for a in range(0, flat.numel(), step):
+        b = min(flat.numel(), a + step)
+        flat[a:b] = (torch.randn(b - a, generator=g, device=eng.dev) * std).to(torch.bfloat16)
+    for name, shape in eng.layout.shape.items():
+        if len(shape) == 1 and (name.endswith("ln1") or name.endswith("ln2") or name == "norm"):
+            eng.policy.v[name].fill_(1.0)
+    eng.vision = VisionWeights(eng.cfg, vision_state_dict(eng.cfg, eng.dev, seed + 1, std), eng.dev)
+    ref = model.create_reference_model()
+    for a in range(0, flat.numel(), step):
+        b = min(flat.numel(), a + step)
+        ref.weights.flat[a:b] = (flat[a:b].float() - torch.randn(b - a, generator=g, device=eng.dev) * policy_delta).to(torch.bfloat16)
+    return ref
+
+
+def synthetic_pixels(n, image_size, seed):
+    g = np.random.Generator(np.random.PCG64(seed))
+    px = g.integers(0, 256, size=(n, 3, image_size, image_size), dtype=np.uint8).astype(np.float32) / 255.0
+    mean = np.array(CLIP_MEAN, dtype=np.float32)[None, :, None, None]
+    std = np.array(CLIP_STD, dtype=np.float32)[None, :, None, None]
+    return torch.from_numpy((px - mean) / std)
+
+
+def synthetic_batch(pairs, text_len, image_token, vocab_hi, image_size, seed, ragged=False, prompt_frac=0.5):
+    """BOS at 0, one <image> at index 4, ids U{3..vocab_hi-1}; first half = prompt shared by chosen and rejected;
+    labels = ids with the prompt -> -100.  ragged: response lengths U{..}, right-padded 0 / -100 / 0."""
+    from ..base.collator import VLDPODataCollatorWithPadding
+    g = np.random.Generator(np.random.PCG64(seed))
+    lp = int(text_len * prompt_frac)
+    rows = []
+    for _ in range(pairs):
+        prompt = g.integers(3, vocab_hi, size=lp).tolist()
+        prompt[0], prompt[4] = 1, image_token
+        lens = [text_len - lp, text_len - lp]
+        if ragged:
+            lens = [int(g.integers(max(2, (text_len - lp) // 8), text_len - lp + 1)) for _ in range(2)]
+        resp = [g.integers(3, vocab_hi, size=n).tolist() for n in lens]
+        rows.append(dict(prompt_input_ids=prompt, prompt_attention_mask=[1] * lp,
+                         chosen_input_ids=prompt + resp[0], chosen_attention_mask=[1] * (lp + lens[0]),
+                         chosen_labels=[-100] * lp + resp[0], rejected_input_ids=prompt + resp[1],
+                         rejected_attention_mask=[1] * (lp + lens[1]), rejected_labels=[-100] * lp + resp[1],
+                         img_path="synthetic"))
+    batch = VLDPODataCollatorWithPadding()(rows)
+    batch["img_input_dict"] = dict(pixel_values=synthetic_pixels(pairs, image_size, seed + 7))
+    return batch
