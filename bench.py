@@ -128,20 +128,22 @@ def main():
     for _ in range(a.warmup):
         loss = step()
     barrier()
-    _hip.profile_start(["vlr_gemm_bf16"])
+    _hip.lib_profile_start()
     t0 = time.time()
     for _ in range(a.steps):
         loss = step()
     barrier()
     dt = time.time() - t0
-    prof = _hip.profile_stop()
+    prof = _hip.lib_profile_stop()
     tmax = torch.tensor([dt], device="cuda")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
-    g = prof["vlr_gemm_bf16"]
-    g_ms = sum(ms for ms, _ in g)
-    g_flop = sum(2.0 * ar[1] * ar[2] * ar[3] for _, ar in g)     # args: layout, M, N, K, ...
+    g_n = sum(prof[k][0] for k in ("gemm_nt", "gemm_nn", "gemm_tn"))
+    g_ms = sum(prof[k][1] for k in ("gemm_nt", "gemm_nn", "gemm_tn"))
+    g_flop = sum(prof[k][2] for k in ("gemm_nt", "gemm_nn", "gemm_tn"))
+    per_kernel = {k: {"launches": n, "ms": round(ms, 2), "tflops": round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else 0.0}
+                  for k, (n, ms, fl) in prof.items()}
     pairs_per_s = world * a.pairs * a.steps / dt
     per_pair = TFLOP_PER_PAIR["ref_precomputed" if a.precomputed_ref else "ref_in_step"]
     if rank == 0:
@@ -158,7 +160,7 @@ def main():
                        "layers": cfg["layers"], "loss": float(loss)},
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (NT/NN/TN)", "achieved": round(achieved, 1),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                         "traffic": None, "launches": len(g), "avg_launch_ms": round(g_ms / max(1, len(g)), 4),
+                         "traffic": None, "launches": g_n, "avg_launch_ms": round(g_ms / max(1, g_n), 4), "per_kernel": per_kernel,
                          "gemm_share_of_step": round(g_ms * 1e-3 / dt, 3),
                          "step_frac": round(pairs_per_s / world * per_pair / PEAK_BF16_TFLOPS, 4)},
         }

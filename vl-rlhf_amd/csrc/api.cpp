@@ -25,3 +25,41 @@ int vlr_check_launch(const char* what) {
 
 extern "C" const char* vlr_last_error(void) { return g_err; }
 extern "C" int vlr_abi_version(void) { return 1; }
+
+// ---- in-library kernel timing (bench.py roofline leg): HIP events on the launch stream around selected kernels -------
+#include <vector>
+struct ProfRec { hipEvent_t a, b; int kernel; double work; };
+static std::vector<ProfRec> g_prof;
+static int g_prof_on = 0;
+
+extern "C" int vlr_prof_enable(int on) {
+    g_prof_on = on;
+    if (on) {
+        for (auto& r : g_prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+        g_prof.clear();
+    }
+    return VLR_OK;
+}
+int vlr_prof_begin(int kernel, double work, hipStream_t st) {
+    if (!g_prof_on) return -1;
+    ProfRec r;
+    r.kernel = kernel; r.work = work;
+    hipEventCreate(&r.a); hipEventCreate(&r.b);
+    hipEventRecord(r.a, st);
+    g_prof.push_back(r);
+    return (int)g_prof.size() - 1;
+}
+void vlr_prof_end(int idx, hipStream_t st) {
+    if (idx >= 0) hipEventRecord(g_prof[idx].b, st);
+}
+// out[kernel*3 + {0,1,2}] = {launches, total ms, total work}; kernels 0..nk-1.  Synchronises on the recorded events.
+extern "C" int vlr_prof_collect(double* out, int nk) {
+    for (int i = 0; i < nk * 3; ++i) out[i] = 0.0;
+    for (auto& r : g_prof) {
+        hipEventSynchronize(r.b);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, r.a, r.b);
+        if (r.kernel < nk) { out[r.kernel * 3] += 1.0; out[r.kernel * 3 + 1] += ms; out[r.kernel * 3 + 2] += r.work; }
+    }
+    return VLR_OK;
+}

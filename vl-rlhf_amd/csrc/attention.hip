@@ -438,12 +438,14 @@ extern "C" int vlr_attn_fwd(const void* q, const void* k, const void* v, int ld,
     const dim3 grid((S + 127) / 128, heads, batch);
     const float sl2 = scale * LOG2E;
     const int Sp = (S + 63) / 64 * 64;   // lse is [batch][heads][Sp]
+    const int pi = vlr_prof_begin(VLR_K_ATTN_FWD, 4.0 * S * S * heads * head_dim * batch * (causal ? 0.5 : 1.0), st);
 #define LAUNCH(D_, C_)                                                                                                  \
     hipLaunchKernelGGL((attn_fwd_kernel<D_, C_>), grid, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,           \
                        (const bf16_t*)v, ld, (bf16_t*)o, ldo, lse, key_mask, S, Sp, sl2)
     if (head_dim == 128) { if (causal) LAUNCH(128, true); else LAUNCH(128, false); }
     else { if (causal) LAUNCH(64, true); else LAUNCH(64, false); }
 #undef LAUNCH
+    vlr_prof_end(pi, st);
     return vlr_check_launch("vlr_attn_fwd");
 }
 
@@ -455,6 +457,7 @@ extern "C" int vlr_attn_bwd(const void* q, const void* k, const void* v, int ld,
     VLR_REQUIRE(head_dim == 128, "vlr_attn_bwd: head_dim must be 128 (the ViT is frozen), got %d", head_dim);
     VLR_REQUIRE(ld % 8 == 0 && ldo % 8 == 0 && ldd % 8 == 0 && delta_ws && lse, "vlr_attn_bwd: strides / workspace");
     const int Sp = (S + 63) / 64 * 64;   // lse and delta_ws are [batch][heads][Sp] floats
+    const int pi = vlr_prof_begin(VLR_K_ATTN_BWD, 10.0 * S * S * heads * head_dim * batch * (causal ? 0.5 : 1.0), st);
     hipLaunchKernelGGL(attn_delta_kernel, dim3(batch * S), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)o, ldo,
                        delta_ws, S, Sp, heads);
     const dim3 grid((S + 127) / 128, heads, batch);
@@ -469,5 +472,6 @@ extern "C" int vlr_attn_bwd(const void* q, const void* k, const void* v, int ld,
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<false>), grid, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,
                            (const bf16_t*)v, ld, (const bf16_t*)dout, ldo, lse, delta_ws, key_mask, (bf16_t*)dk, (bf16_t*)dv, ldd, S, Sp, scale);
     }
+    vlr_prof_end(pi, st);
     return vlr_check_launch("vlr_attn_bwd");
 }

@@ -284,8 +284,10 @@ extern "C" int vlr_gemm_bf16(int layout, const void* A, const void* B, void* C, 
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
     p.act = act; p.accumulate = accumulate; p.out_f32 = out_f32;
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const int pi = vlr_prof_begin(layout, 2.0 * M * N * K, stream);
     if (layout == 0) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), dim3(tiles), dim3(256), 0, stream, p);
     else if (layout == 1) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), dim3(tiles), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), dim3(tiles), dim3(256), 0, stream, p);
+    vlr_prof_end(pi, stream);
     return vlr_check_launch("vlr_gemm_bf16");
 }

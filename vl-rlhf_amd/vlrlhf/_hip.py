@@ -88,6 +88,8 @@ _INT_HELPERS = {
     "vlr_colsum_workspace_bytes": [I],
     "vlr_grad_sqnorm_workspace_bytes": [],
     "vlr_abi_version": [],
+    "vlr_prof_enable": [I],
+    "vlr_prof_collect": [P, I],
 }
 
 
@@ -135,6 +137,21 @@ def stream():
 
 
 _prof = None   # {entry point: [(start_event, end_event, args)]} while bench.py times kernels with HIP events
+
+
+PROF_KERNELS = ["gemm_nt", "gemm_nn", "gemm_tn", "attn_fwd", "attn_bwd"]
+
+
+def lib_profile_start():
+    lib().vlr_prof_enable(1)
+
+
+def lib_profile_stop():
+    """-> {kernel: (launches, total_ms, flops)} from the in-library HIP-event timers (api.cpp)."""
+    buf = (C.c_double * (3 * len(PROF_KERNELS)))()
+    lib().vlr_prof_collect(buf, len(PROF_KERNELS))
+    lib().vlr_prof_enable(0)
+    return {k: (int(buf[3 * i]), buf[3 * i + 1], buf[3 * i + 2]) for i, k in enumerate(PROF_KERNELS)}
 
 
 def profile_start(names):
