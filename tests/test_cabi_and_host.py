@@ -1,0 +1,203 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/vlr.h declares, argument errors are
+reported without a GPU, the host-side mirror (collator, tokenize_row, concatenation, DDPO ids, schedule, flat layout)
+reproduces the reference-generated golden vectors, and the product path refuses to run without the MI355X."""
+import ctypes
+import json
+import os
+import re
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_util import GOLDEN, load_case, t
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from vlrlhf import _hip
+    l = _hip.lib()
+    hdr = open(os.path.join(ROOT, "include", "vlr.h")).read()
+    declared = set(re.findall(r"\b(vlr_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 40
+    for name in sorted(declared):
+        assert hasattr(l, name), f"{name} declared in include/vlr.h but not exported by libvlr_hip.so"
+    for name in _hip.exported_symbols():
+        assert name in declared, f"{name} bound in _hip.py but not declared in include/vlr.h"
+    assert _hip.helper("vlr_abi_version") == 1
+
+
+def test_argument_errors_without_gpu():
+    from vlrlhf import _hip
+    l = _hip.lib()
+    assert l.vlr_gemm_bf16(9, None, None, None, None, None, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, None) == 1
+    assert b"layout" in l.vlr_last_error()
+    assert l.vlr_dpo_loss(None, None, None, None, 4, 0.1, 0.0, 7, 0, None, None, None, None, None, None, None, None) == 1
+    assert b"Unknown loss type" in l.vlr_last_error()
+    assert l.vlr_attn_fwd(None, None, None, 8, None, 8, None, None, 1, 8, 1, 96, 1, 1.0, None) == 1
+    assert b"head_dim" in l.vlr_last_error()
+    assert _hip.helper("vlr_rmsnorm_bwd_workspace_bytes", 4096) == 256 * 4096 * 4
+
+
+def test_product_refuses_to_run_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from vlrlhf import _hip
+    from vlrlhf.engine import LlavaHipEngine
+    from vlrlhf.base.trainer import VLDPOTrainer
+    with pytest.raises(_hip.VlrError):
+        LlavaHipEngine(dict(hidden=128, inter=256, vocab=64, layers=1, heads=1, vit_hidden=64, vit_heads=1, vit_mlp=128,
+                            vit_layers=2, image_size=28, patch_size=14, image_token=60))
+    with pytest.raises(_hip.VlrError):   # CPU logits are rejected, not silently handled by PyTorch
+        VLDPOTrainer.get_batch_logps(torch.zeros(2, 4, 8), torch.zeros(2, 4, dtype=torch.long))
+    with pytest.raises(ValueError):
+        VLDPOTrainer.get_batch_logps(torch.zeros(2, 4, 8), torch.zeros(2, 5, dtype=torch.long))
+
+
+def test_collator_matches_reference_golden():
+    from vlrlhf.base.collator import VLDPODataCollatorWithPadding
+    ka = np.load(os.path.join(GOLDEN, "known_answers.npz"))
+    rows = json.loads(bytes(ka["collator_rows_json"]).decode())
+    got = VLDPODataCollatorWithPadding(pad_token_id=0, label_pad_token_id=-100)(rows)
+    n = 0
+    for k in ka.files:
+        if k.startswith("collator."):
+            exp = torch.from_numpy(ka[k])
+            g = got[k[len("collator."):]]
+            assert torch.equal(g, exp) if exp.dtype == torch.int64 else torch.allclose(g.float(), exp.float()), k
+            n += 1
+    assert n == 10 and got["img_path"] == ["a.jpg", "b.jpg"]
+    for case in ("llava_tiny", "llava_hipsmall"):
+        z, cfg, W, W_ref, batch, rws = load_case(case)
+        got = VLDPODataCollatorWithPadding()(rws)
+        for k, v in batch.items():
+            if isinstance(v, torch.Tensor):
+                assert torch.equal(got[k], v), (case, k)
+
+
+class _Trainer:
+    """VLDPOTrainer without a model (host-side methods only)."""
+    def __new__(cls, **kw):
+        from vlrlhf.base.trainer import VLDPOTrainer
+        tr = VLDPOTrainer.__new__(VLDPOTrainer)
+        tr.__dict__.update(dict(label_pad_token_id=-100, padding_value=0, max_length=512, max_prompt_length=128,
+                                truncation_mode="keep_end", is_encoder_decoder=False, loss_type="sigmoid"), **kw)
+        return tr
+
+
+def test_concatenated_inputs_matches_reference_golden():
+    for case in ("llava_tiny", "llava_hipsmall"):
+        z, cfg, W, W_ref, batch, rows = load_case(case)
+        tr = _Trainer()
+        cb = tr.concatenated_inputs(batch)
+        for k in ("concatenated_input_ids", "concatenated_attention_mask", "concatenated_labels"):
+            assert torch.equal(cb[k], t(z, "cat." + k)), (case, k)
+        pv = cb["concatenated_img_input_dict"]["pixel_values"]
+        n = batch["img_input_dict"]["pixel_values"].shape[0]
+        assert pv.shape[0] == 2 * n and torch.equal(pv[:n], pv[n:]) and pv._vlr_dup == 2
+        assert tr.concatenated_inputs(batch)["concatenated_input_ids"] is cb["concatenated_input_ids"]   # memoised
+    b = dict(batch)
+    b.pop("_vlr_concat")
+    b["img_input_dict"] = dict(paths=["a", "b"], bad=3)
+    with pytest.raises(ValueError, match="Unsupported type"):
+        tr.concatenated_inputs(b)
+
+
+def test_ddpo_ids_match_reference_golden():
+    from vlrlhf.utils.diff_lib import ddpo_shared_mask, get_diff_ids
+    ka = np.load(os.path.join(GOLDEN, "known_answers.npz"))
+    labels = torch.from_numpy(ka["lp.labels"])
+    sh = labels[:, 1:].clone()
+    sh[sh == -100] = 0
+    c, r = get_diff_ids(sh[0].tolist(), sh[2].tolist(), 3)
+    assert c == ka["lp.ddpo_c0"].tolist() and r == ka["lp.ddpo_r0"].tolist()
+    for case in ("llava_tiny", "llava_hipsmall"):
+        z, cfg, W, W_ref, batch, rows = load_case(case)
+        m = ddpo_shared_mask(t(z, "merged_labels"))
+        B = batch["chosen_input_ids"].shape[0]
+        for b in range(B):
+            assert torch.where(m[b])[0].tolist() == z[f"ddpo_chosen_ids_{b}"].tolist()
+            assert torch.where(m[B + b])[0].tolist() == z[f"ddpo_rejected_ids_{b}"].tolist()
+
+
+class FakeTokenizer:
+    """whitespace-free character-bigram tokenizer: deterministic, merges across boundaries like BPE can."""
+    bos_token_id, eos_token_id, pad_token_id, unk_token = 1, 2, 0, "<unk>"
+    bos_token = "<s>"
+
+    def __call__(self, text, add_special_tokens=True, padding=False):
+        ids, i = [], 0
+        while i < len(text):
+            if text.startswith("<image>", i):
+                ids.append(90)
+                i += 7
+            else:
+                ids.append(3 + (ord(text[i]) % 80))
+                i += 1
+        if add_special_tokens:
+            ids = [self.bos_token_id] + ids
+        return {"input_ids": ids, "attention_mask": [1] * len(ids)}
+
+
+def test_tokenize_row_template_and_truncation():
+    from vlrlhf.models.Llava import LlavaProcessor
+    proc = LlavaProcessor(tokenizer=FakeTokenizer())
+    conv = proc.make_single_turn_conv(proc.format_multimodal_prompt("What is this?", "x.jpg"), "")
+    raw = proc.process_batch_conv([conv], add_end_for_empty_value=False)["raw_str"][0]
+    assert raw == "USER: <image>\nWhat is this?ASSISTANT: "          # SURVEY Appendix A.6 (verified on the reference)
+    tr = _Trainer(processor=proc, tokenizer=proc.tokenizer, max_length=60, max_prompt_length=20)
+    row = tr.tokenize_row(dict(prompt="What is this?", chosen="a cat on a mat", rejected="a dog", img_path="x.jpg"))
+    tok = FakeTokenizer()
+    p_ids = [1] + tok(raw, add_special_tokens=False)["input_ids"]
+    c_ids = tok("a cat on a mat", add_special_tokens=False)["input_ids"] + [2]
+    assert row["prompt_input_ids"] == p_ids
+    assert row["chosen_input_ids"] == p_ids + c_ids
+    assert row["chosen_labels"] == [-100] * len(p_ids) + c_ids
+    assert row["rejected_labels"][: len(p_ids)] == [-100] * len(p_ids) and row["rejected_input_ids"][-1] == 2
+    assert row["img_path"] == "x.jpg" and row["chosen_input_ids"].count(90) == 1
+    # prompt too long -> keep_end to max_prompt_length, then answers to max_length - max_prompt_length
+    tr2 = _Trainer(processor=proc, tokenizer=proc.tokenizer, max_length=30, max_prompt_length=12)
+    row2 = tr2.tokenize_row(dict(prompt="What is this?", chosen="x" * 40, rejected="y" * 5, img_path="x.jpg"))
+    assert row2["prompt_input_ids"] == p_ids[-12:]
+    assert len(row2["chosen_input_ids"]) == 12 + 18 and len(row2["rejected_input_ids"]) == 12 + 6
+    tr3 = _Trainer(processor=proc, tokenizer=proc.tokenizer, max_length=30, max_prompt_length=12, truncation_mode="nope")
+    with pytest.raises(ValueError, match="Unknown truncation mode"):
+        tr3.tokenize_row(dict(prompt="What is this?", chosen="x" * 40, rejected="y", img_path="x.jpg"))
+    assert LlavaProcessor.format_multimodal_prompt("a <image> b", ["p"]) == "a <image>\n b"
+    assert LlavaProcessor.remove_image_placeholder("<image>\nhi") == "hi"
+
+
+def test_lr_schedule_and_layout():
+    from vlrlhf.engine import ParamLayout
+    tr = _Trainer(args=SimpleNamespace(learning_rate=1e-5, warmup_ratio=0.1, lr_scheduler_type="cosine"))
+    assert tr.lr_at(0, 100) == 0.0 and abs(tr.lr_at(10, 100) - 1e-5) < 1e-12 and abs(tr.lr_at(55, 100) - 0.5e-5) < 1e-9
+    assert tr.lr_at(100, 100) < 1e-12
+    cfg = dict(hidden=256, inter=512, vocab=320, layers=3, vit_hidden=128)
+    lay = ParamLayout(cfg)
+    spans = sorted(lay.bucket_after.values())
+    assert spans[0][0] == 0 and spans[-1][1] == lay.numel
+    for (a, b), (c, d) in zip(spans, spans[1:]):
+        assert b == c                                   # the DDP buckets tile the flat gradient exactly
+    names = [hf for hf, *_ in lay.hf_names()]
+    assert len(names) == len(set(names)) == 3 * 9 + 7
+    assert lay.n_decay % 8 == 0 and all(o % 8 == 0 for o in lay.offset.values())
+    no_decay = [n for n, o in lay.offset.items() if o >= lay.n_decay]
+    assert all(("ln" in n or n == "norm" or ".b" in n) for n in no_decay)
+
+
+def test_registry_surface():
+    from vlrlhf.models.Llava import core_mapper
+    from vlrlhf.utils.auto_load import MODEL_NICKNAME_MAP, auto_core_mapper
+    assert MODEL_NICKNAME_MAP["LlavaForConditionalGeneration"] == "Llava"
+    assert auto_core_mapper("LlavaForConditionalGeneration") is core_mapper
+    assert core_mapper.dpo_trainer.__mro__[1].__name__ == "VLDPOTrainer"
+    with pytest.raises(NotImplementedError):
+        auto_core_mapper("QWenLMHeadModel")
+    import inspect
+    from vlrlhf.base.trainer import VLDPOTrainer
+    params = list(inspect.signature(VLDPOTrainer.__init__).parameters)[1:]
+    assert params[:13] == ["model", "ref_model", "beta", "label_smoothing", "loss_type", "args", "data_collator",
+                           "label_pad_token_id", "padding_value", "truncation_mode", "train_dataset", "eval_dataset", "processor"]
+    assert len(params) == 32 and params[-1] == "reference_free"
