@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libvlr_hip.so")
-SOURCES = ["api.cpp", "layers.cpp", "gemm.hip", "attention.hip", "elementwise.hip", "dpo_ops.hip"]
+SOURCES = ["api.cpp", "layers.cpp", "gemm.hip", "gemm256.hip", "attention.hip", "elementwise.hip", "dpo_ops.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 
@@ -39,9 +39,17 @@ def build(force=False, verbose=True):
     def cc(src):
         obj = os.path.join(OBJ, src.rsplit(".", 1)[0] + ".o")
         cmd = [hipcc] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if src.endswith(".hip"):
+            cmd.append("-Rpass-analysis=kernel-resource-usage")
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-4000:]}")
+        # a kernel that touches scratch (spill, or a register array the compiler could not keep in VGPRs) is a 10-20x
+        # performance bug on this path: refuse to build it
+        import re
+        for m in re.finditer(r"Function Name: (\S+).*?ScratchSize \[bytes/lane\]: (\d+)", r.stderr, re.S):
+            if int(m.group(2)) > 0:
+                raise RuntimeError(f"{src}: kernel {m.group(1)} uses {m.group(2)} B/lane of scratch")
         return obj
 
     with ThreadPoolExecutor(max_workers=6) as ex:

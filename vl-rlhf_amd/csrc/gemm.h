@@ -1,0 +1,28 @@
+// Shared definitions of the bf16 GEMM kernels (gemm.hip: 128x128 tile, gemm256.hip: 256x256 tile).
+#pragma once
+#include "common.h"
+
+enum { ACT_NONE = 0, ACT_QUICK_GELU = 1, ACT_GELU = 2 };
+
+struct GemmParams {
+    const bf16_t* A;
+    const bf16_t* B;
+    void* C;
+    const bf16_t* bias;      // [N] or null
+    const bf16_t* residual;  // [M,N] ld = ldr, or null
+    int M, N, K;
+    int lda, ldb, ldc, ldr;
+    int act;
+    int accumulate;  // C += result (C read in its own dtype)
+    int out_f32;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == ACT_QUICK_GELU) return v / (1.f + __expf(-1.702f * v));
+    if (act == ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+    return v;
+}
+
+
+// 256x256-tile kernel (gemm256.hip); returns false when the problem does not qualify (caller falls back to 128x128)
+bool vlr_gemm256_try_launch(int layout, const GemmParams& p, hipStream_t stream);

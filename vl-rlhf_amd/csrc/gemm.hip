@@ -12,32 +12,11 @@
 // applied in fp32 and global stores are 16 B per lane along rows.
 // Workgroup -> tile map: XCD-aware (block b runs on XCD b%8; each XCD gets a contiguous run of tiles) and grouped
 // (8 tile-rows x all tile-columns) so co-resident workgroups share A panels and B panels in their XCD's L2.
-#include "common.h"
+#include "gemm.h"
 
 #define BM 128
 #define BN 128
 #define BK 64
-
-enum { ACT_NONE = 0, ACT_QUICK_GELU = 1, ACT_GELU = 2 };
-
-struct GemmParams {
-    const bf16_t* A;
-    const bf16_t* B;
-    void* C;
-    const bf16_t* bias;      // [N] or null
-    const bf16_t* residual;  // [M,N] ld = ldr, or null
-    int M, N, K;
-    int lda, ldb, ldc, ldr;
-    int act;
-    int accumulate;  // C += result (C read in its own dtype)
-    int out_f32;
-};
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == ACT_QUICK_GELU) return v / (1.f + __expf(-1.702f * v));
-    if (act == ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
-    return v;
-}
 
 __device__ __forceinline__ int swz_off(int row, int chunk) { return row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
@@ -285,6 +264,10 @@ extern "C" int vlr_gemm_bf16(int layout, const void* A, const void* B, void* C, 
     p.act = act; p.accumulate = accumulate; p.out_f32 = out_f32;
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const int pi = vlr_prof_begin(layout, 2.0 * M * N * K, stream);
+    if (vlr_gemm256_try_launch(layout, p, stream)) {
+        vlr_prof_end(pi, stream);
+        return vlr_check_launch("vlr_gemm_bf16(256)");
+    }
     if (layout == 0) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), dim3(tiles), dim3(256), 0, stream, p);
     else if (layout == 1) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), dim3(tiles), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), dim3(tiles), dim3(256), 0, stream, p);
