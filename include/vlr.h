@@ -146,6 +146,10 @@ int vlr_decoder_layer_bwd(const vlr_llama_cfg* cfg, const vlr_layer_weights* w, 
                           const void* dx_out, void* dx_in, const int* pos, const int* key_mask, int batch, int S,
                           vlr_stream_t stream);
 
+/* vlr_decoder_layer_bwd runs the weight-gradient GEMMs on a library-owned side stream (VLR_BWD_STREAMS=0 disables);
+ * vlr_layers_join makes `stream` wait for them - call it before anything reads or reduces the weight gradients. */
+int vlr_layers_join(vlr_stream_t stream);
+
 typedef struct {
     int hidden, mlp, heads, head_dim;
     float ln_eps;

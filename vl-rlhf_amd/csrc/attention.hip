@@ -24,48 +24,59 @@ __device__ __forceinline__ int kt_off(int row, int chunk) {   // [64][D] k-conti
 // transposed tile [D][64 cols]: 128-byte rows of 8 chunks; chunk = (16-col block)*2 + g holds cols {4g..4g+3, 8+4g..}
 __device__ __forceinline__ int tt_off(int drow, int chunk) { return drow * 128 + ((chunk ^ ((drow >> 1) & 7)) << 4); }
 
-// stage 64 rows x D (k-contiguous) from global rows [row0, row0+64) of `src` (row stride ld); rows >= nrows -> 0
+// ---- tile staging, split in two so the global loads of tile t+1 fly under the MFMAs of tile t --------------------------
+// A 64-row x D tile is held as 8-byte quads: thread -> (d quad dq = t % (D/4), row quads j = t/(D/4) + JPI*i): rows 4j..4j+3,
+// columns 4dq..4dq+3.  The same registers feed the row-major (k-contiguous, swizzled) image and the transposed image.
 template <int D>
-__device__ __forceinline__ void stage_rows(char* lds, const bf16_t* __restrict__ src, int ld, int row0, int nrows, int t) {
-    constexpr int CPR = D / 8;            // chunks per row
-    constexpr int RPI = 256 / CPR;        // rows per iteration
-    const int c = t % CPR;
-#pragma unroll
-    for (int i = 0; i < 64 / RPI; ++i) {
-        const int row = t / CPR + RPI * i;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (row0 + row < nrows) v = *reinterpret_cast<const u32x4*>(src + (size_t)(row0 + row) * ld + c * 8);
-        *reinterpret_cast<u32x4*>(lds + kt_off<D>(row, c)) = v;
-    }
-}
-// stage the TRANSPOSE of 64 rows x D into [D][64] (permuted 16-col blocks); rows >= nrows -> 0
+struct TileRegs {
+    static constexpr int DQ = D / 4;
+    static constexpr int JPI = 256 / DQ;
+    static constexpr int NI = 16 / JPI;
+    u32x2 r[NI][4];
+};
 template <int D>
-__device__ __forceinline__ void stage_transposed(char* lds, const bf16_t* __restrict__ src, int ld, int row0, int nrows,
-                                                 int t) {
-    constexpr int DQ = D / 4;             // d quads
-    constexpr int JPI = 256 / DQ;         // row-quads per iteration
-    const int dq = t % DQ;
+__device__ __forceinline__ void tile_load(TileRegs<D>& tr, const bf16_t* __restrict__ src, int ld, int row0, int nrows, int t) {
+    const int dq = t % TileRegs<D>::DQ;
 #pragma unroll
-    for (int i = 0; i < 16 / JPI; ++i) {
-        const int j = t / DQ + JPI * i;   // rows 4j..4j+3
-        u32x2 r[4];
+    for (int i = 0; i < TileRegs<D>::NI; ++i) {
+        const int j = t / TileRegs<D>::DQ + TileRegs<D>::JPI * i;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int row = row0 + 4 * j + rr;
             u32x2 v = {0u, 0u};
             if (row < nrows) v = *reinterpret_cast<const u32x2*>(src + (size_t)row * ld + dq * 4);
-            r[rr] = v;
+            tr.r[i][rr] = v;
         }
+    }
+}
+// row-major [64][D] image, 16-byte chunk swizzle (kt_off); each thread writes its 8-byte halves
+template <int D>
+__device__ __forceinline__ void tile_store_rows(const TileRegs<D>& tr, char* lds, int t) {
+    const int dq = t % TileRegs<D>::DQ;
+#pragma unroll
+    for (int i = 0; i < TileRegs<D>::NI; ++i) {
+        const int j = t / TileRegs<D>::DQ + TileRegs<D>::JPI * i;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+            *reinterpret_cast<u32x2*>(lds + kt_off<D>(4 * j + rr, dq >> 1) + (dq & 1) * 8) = tr.r[i][rr];
+    }
+}
+// transposed [D][64] image (permuted 16-col blocks, tt_off): 4x4 register transposes with v_perm
+template <int D>
+__device__ __forceinline__ void tile_store_transposed(const TileRegs<D>& tr, char* lds, int t) {
+    const int dq = t % TileRegs<D>::DQ;
+#pragma unroll
+    for (int i = 0; i < TileRegs<D>::NI; ++i) {
+        const int j = t / TileRegs<D>::DQ + TileRegs<D>::JPI * i;
         const int ks = j >> 2, qi = j & 3;
         const int chunk = ks * 2 + (qi & 1);
 #pragma unroll
         for (int dd = 0; dd < 4; ++dd) {
             const uint32_t sel = (dd & 1) ? 0x07060302u : 0x05040100u;
             u32x2 o;
-            o[0] = __builtin_amdgcn_perm(r[1][dd >> 1], r[0][dd >> 1], sel);
-            o[1] = __builtin_amdgcn_perm(r[3][dd >> 1], r[2][dd >> 1], sel);
-            const int d = dq * 4 + dd;
-            *reinterpret_cast<u32x2*>(lds + tt_off(d, chunk) + (qi >> 1) * 8) = o;
+            o[0] = __builtin_amdgcn_perm(tr.r[i][1][dd >> 1], tr.r[i][0][dd >> 1], sel);
+            o[1] = __builtin_amdgcn_perm(tr.r[i][3][dd >> 1], tr.r[i][2][dd >> 1], sel);
+            *reinterpret_cast<u32x2*>(lds + tt_off(dq * 4 + dd, chunk) + (qi >> 1) * 8) = o;
         }
     }
 }
@@ -111,7 +122,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     const bf16_t* qh = q + tok0 * ld + head * D;
     const bf16_t* kh = k + tok0 * ld + head * D;
     const bf16_t* vh = v + tok0 * ld + head * D;
-    const int qw0 = blockIdx.x * 128 + wave * 32;
+    const int qblk = CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;   // causal: heaviest blocks first
+    const int qw0 = qblk * 128 + wave * 32;
     const int qi = qw0 + (lane & 31);
     const int qrow = qi < S ? qi : S - 1;
 
@@ -127,18 +139,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     float m = -INFINITY, l = 0.f;
 
-    const int q_end = min(S, (int)blockIdx.x * 128 + 128);
+    const int q_end = min(S, qblk * 128 + 128);
     const int nkv = CAUSAL ? (q_end + KV_TILE - 1) / KV_TILE : (S + KV_TILE - 1) / KV_TILE;
+    TileRegs<D> kreg, vreg;
+    tile_load<D>(kreg, kh, ld, 0, S, t);
+    tile_load<D>(vreg, vh, ld, 0, S, t);
     for (int it = 0; it < nkv; ++it) {
         const int k0 = it * KV_TILE;
-        __syncthreads();
-        stage_rows<D>(k_lds, kh, ld, k0, S, t);
-        stage_transposed<D>(vt_lds, vh, ld, k0, S, t);
+        __syncthreads();                                   // every wave is done reading the previous tile
+        tile_store_rows<D>(kreg, k_lds, t);
+        tile_store_transposed<D>(vreg, vt_lds, t);
         if (t < KV_TILE) {
             const int key = k0 + t;
             bias_lds[t] = (key < S && (!kmask || kmask[tok0 + key] != 0)) ? 0.f : -INFINITY;
         }
         __syncthreads();
+        if (it + 1 < nkv) {                                // next tile's global loads fly under this tile's MFMAs
+            tile_load<D>(kreg, kh, ld, k0 + KV_TILE, S, t);
+            tile_load<D>(vreg, vh, ld, k0 + KV_TILE, S, t);
+        }
         if (CAUSAL && k0 > qw0 + 31) continue;   // wave-uniform: whole tile is in this wave's future
 
         f32x16 s[2];
@@ -250,7 +269,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     const bf16_t* kh = k + tok0 * ld + head * D;
     const bf16_t* vh = v + tok0 * ld + head * D;
     const bf16_t* doh = dout + tok0 * ldo + head * D;
-    const int qw0 = blockIdx.x * 128 + wave * 32;
+    const int qblk = CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+    const int qw0 = qblk * 128 + wave * 32;
     const int qi = qw0 + (lane & 31);
     const int qrow = qi < S ? qi : S - 1;
     const float scale_log2 = scale * LOG2E;
@@ -270,19 +290,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    const int q_end = min(S, (int)blockIdx.x * 128 + 128);
+    const int q_end = min(S, qblk * 128 + 128);
     const int nkv = CAUSAL ? (q_end + KV_TILE - 1) / KV_TILE : (S + KV_TILE - 1) / KV_TILE;
+    TileRegs<D> kreg, vreg;
+    tile_load<D>(kreg, kh, ld, 0, S, t);
+    tile_load<D>(vreg, vh, ld, 0, S, t);
     for (int it = 0; it < nkv; ++it) {
         const int k0 = it * KV_TILE;
         __syncthreads();
-        stage_rows<D>(k_lds, kh, ld, k0, S, t);
-        stage_rows<D>(v_lds, vh, ld, k0, S, t);
-        stage_transposed<D>(kt_lds, kh, ld, k0, S, t);
+        tile_store_rows<D>(kreg, k_lds, t);
+        tile_store_transposed<D>(kreg, kt_lds, t);
+        tile_store_rows<D>(vreg, v_lds, t);
         if (t < KV_TILE) {
             const int key = k0 + t;
             bias_lds[t] = (key < S && (!kmask || kmask[tok0 + key] != 0)) ? 0.f : -INFINITY;
         }
         __syncthreads();
+        if (it + 1 < nkv) {
+            tile_load<D>(kreg, kh, ld, k0 + KV_TILE, S, t);
+            tile_load<D>(vreg, vh, ld, k0 + KV_TILE, S, t);
+        }
         if (CAUSAL && k0 > qw0 + 31) continue;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -370,13 +397,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
         for (int r = 0; r < 16; ++r) { adk[i][r] = 0.f; adv[i][r] = 0.f; }
 
     const int q_start = CAUSAL ? ((int)blockIdx.x * 128 / KV_TILE) * KV_TILE : 0;
+    TileRegs<D> qreg, doreg;
+    tile_load<D>(qreg, qh, ld, q_start, S, t);
+    tile_load<D>(doreg, doh, ldo, q_start, S, t);
     for (int q0 = q_start; q0 < S; q0 += KV_TILE) {
         __syncthreads();
-        stage_rows<D>(q_lds, qh, ld, q0, S, t);
-        stage_rows<D>(do_lds, doh, ldo, q0, S, t);
-        stage_transposed<D>(qt_lds, qh, ld, q0, S, t);
-        stage_transposed<D>(dot_lds, doh, ldo, q0, S, t);
+        tile_store_rows<D>(qreg, q_lds, t);
+        tile_store_transposed<D>(qreg, qt_lds, t);
+        tile_store_rows<D>(doreg, do_lds, t);
+        tile_store_transposed<D>(doreg, dot_lds, t);
         __syncthreads();
+        if (q0 + KV_TILE < S) {
+            tile_load<D>(qreg, qh, ld, q0 + KV_TILE, S, t);
+            tile_load<D>(doreg, doh, ldo, q0 + KV_TILE, S, t);
+        }
         if (CAUSAL && q0 + KV_TILE - 1 < kw0) continue;   // every query of the tile precedes this wave's keys
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {

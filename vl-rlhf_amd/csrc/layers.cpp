@@ -11,6 +11,43 @@
 #include "../../include/vlr.h"
 #include "common.h"
 
+// ---- optional second stream for the weight-gradient GEMMs: dgrad (NN) and wgrad (TN) of a layer are independent, and a
+// 256x256-tile GEMM leaves up to 22 % of the chip idle in its last wave of workgroups (800 tiles on 256 CUs); running the
+// wgrad on a side stream lets its workgroups fill those tails.  VLR_BWD_STREAMS=0 disables it.
+#include <stdlib.h>
+static hipStream_t g_side = nullptr;
+static hipEvent_t g_fork = nullptr, g_done[4] = {nullptr, nullptr, nullptr, nullptr};
+static int g_two_streams = -1;
+static bool g_side_used = false;
+
+static bool two_streams() {
+    if (g_two_streams < 0) {
+        const char* e = getenv("VLR_BWD_STREAMS");
+        g_two_streams = (e && e[0] == '0') ? 0 : 1;
+        if (g_two_streams) {
+            if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) g_two_streams = 0;
+            hipEventCreateWithFlags(&g_fork, hipEventDisableTiming);
+            for (int i = 0; i < 4; ++i) hipEventCreateWithFlags(&g_done[i], hipEventDisableTiming);
+        }
+    }
+    return g_two_streams == 1;
+}
+// side stream continues from the current point of `main`
+static hipStream_t fork_side(hipStream_t main) {
+    hipEventRecord(g_fork, main);
+    hipStreamWaitEvent(g_side, g_fork, 0);
+    return g_side;
+}
+static void side_done(int i) { hipEventRecord(g_done[i], g_side); g_side_used = true; }
+static void wait_side(int i, hipStream_t main) { if (g_side_used) hipStreamWaitEvent(main, g_done[i], 0); }
+
+// make `stream` wait for every wgrad GEMM issued on the side stream (call before anything reads the weight gradients)
+extern "C" int vlr_layers_join(vlr_stream_t stream) {
+    if (g_two_streams == 1 && g_side_used)
+        for (int i = 0; i < 4; ++i) hipStreamWaitEvent(stream, g_done[i], 0);
+    return VLR_OK;
+}
+
 #define CHECK(call)                     \
     do {                                \
         int rc_ = (call);               \
@@ -45,22 +82,36 @@ extern "C" int vlr_decoder_layer_bwd(const vlr_llama_cfg* cfg, const vlr_layer_w
                                      const int* key_mask, int batch, int S, vlr_stream_t st) {
     VLR_REQUIRE(cfg && w && g && a && ws && x_in && dx_out && dx_in && pos, "vlr_decoder_layer_bwd: null argument");
     const int H = cfg->hidden, I = cfg->inter, M = batch * S;
+    const bool two = two_streams();
+    hipStream_t sd = st;
     // ---- MLP
+    if (two) { sd = fork_side(st); }
+    CHECK(vlr_gemm_bf16(2, dx_out, a->act, g->wdown, nullptr, nullptr, H, I, M, H, I, I, 0, 0, accumulate, 0, sd));
+    if (two) side_done(0);
     CHECK(vlr_gemm_bf16(1, dx_out, w->wdown, ws->dact, nullptr, nullptr, M, I, H, H, I, I, 0, 0, 0, 0, st));
-    CHECK(vlr_gemm_bf16(2, dx_out, a->act, g->wdown, nullptr, nullptr, H, I, M, H, I, I, 0, 0, accumulate, 0, st));
     CHECK(vlr_swiglu_bwd(a->gu, ws->dact, M, I, st));   // gu now holds [dgate | dup]
+    if (two) { sd = fork_side(st); }
+    CHECK(vlr_gemm_bf16(2, a->gu, a->xn2, g->wgu, nullptr, nullptr, 2 * I, H, M, 2 * I, H, H, 0, 0, accumulate, 0, sd));
+    if (two) side_done(1);
     CHECK(vlr_gemm_bf16(1, a->gu, w->wgu, ws->dxn, nullptr, nullptr, M, H, 2 * I, 2 * I, H, H, 0, 0, 0, 0, st));
-    CHECK(vlr_gemm_bf16(2, a->gu, a->xn2, g->wgu, nullptr, nullptr, 2 * I, H, M, 2 * I, H, H, 0, 0, accumulate, 0, st));
+    if (two) wait_side(2, st);                           // previous layer's dWo GEMM still reads ws->dx_mid
     CHECK(vlr_rmsnorm_bwd(ws->dxn, a->x_mid, w->ln2, a->rstd2, dx_out, ws->dx_mid, g->ln2, accumulate, ws->norm_ws, M, H, st));
     // ---- attention
+    if (two) { sd = fork_side(st); }
+    CHECK(vlr_gemm_bf16(2, ws->dx_mid, a->attn, g->wo, nullptr, nullptr, H, H, M, H, H, H, 0, 0, accumulate, 0, sd));
+    if (two) side_done(2);
     CHECK(vlr_gemm_bf16(1, ws->dx_mid, w->wo, ws->dattn, nullptr, nullptr, M, H, H, H, H, H, 0, 0, 0, 0, st));
-    CHECK(vlr_gemm_bf16(2, ws->dx_mid, a->attn, g->wo, nullptr, nullptr, H, H, M, H, H, H, 0, 0, accumulate, 0, st));
+    if (two) wait_side(3, st);                           // previous layer's dWqkv GEMM still reads ws->dqkv
     CHECK(vlr_attn_bwd(a->qkv, off(a->qkv, H), off(a->qkv, 2 * (size_t)H), 3 * H, a->attn, ws->dattn, H, a->lse, ws->delta,
                        key_mask, ws->dqkv, off(ws->dqkv, H), off(ws->dqkv, 2 * (size_t)H), 3 * H, batch, S, cfg->heads,
                        cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));
     CHECK(vlr_rope(ws->dqkv, pos, cfg->rope_cos, cfg->rope_sin, M, H, cfg->head_dim, 3 * H, cfg->max_pos, 1, st));
+    if (two) { sd = fork_side(st); }
+    CHECK(vlr_gemm_bf16(2, ws->dqkv, a->xn1, g->wqkv, nullptr, nullptr, 3 * H, H, M, 3 * H, H, H, 0, 0, accumulate, 0, sd));
+    if (two) side_done(3);
     CHECK(vlr_gemm_bf16(1, ws->dqkv, w->wqkv, ws->dxn, nullptr, nullptr, M, H, 3 * H, 3 * H, H, H, 0, 0, 0, 0, st));
-    CHECK(vlr_gemm_bf16(2, ws->dqkv, a->xn1, g->wqkv, nullptr, nullptr, 3 * H, H, M, 3 * H, H, H, 0, 0, accumulate, 0, st));
+    if (two) { wait_side(0, st); wait_side(1, st); }     // this layer's dWdown / dWgu read dx_out / gu: done before dx_in (the
+                                                         // buffer the NEXT layer overwrites dx_out with) is produced
     CHECK(vlr_rmsnorm_bwd(ws->dxn, x_in, w->ln1, a->rstd1, ws->dx_mid, dx_in, g->ln1, accumulate, ws->norm_ws, M, H, st));
     return VLR_OK;
 }

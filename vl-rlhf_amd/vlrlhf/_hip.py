@@ -82,6 +82,7 @@ _SIGS = {
     "vlr_decoder_layer_fwd": [P, P, P, P, P, P, I, I, P],
     "vlr_decoder_layer_bwd": [P, P, P, I, P, P, P, P, P, P, P, I, I, P],
     "vlr_vit_layer_fwd": [P, P, P, P, I, I, P],
+    "vlr_layers_join": [P],
 }
 _INT_HELPERS = {
     "vlr_rmsnorm_bwd_workspace_bytes": [I],

@@ -429,7 +429,9 @@ class LlavaHipEngine:
                       a["struct"], lws, x_in, cur, nxt, ctx["pos"], ctx["mask"], Bn, S)
             cur, nxt = nxt, cur
             if self.reducer is not None:
+                _hip.call("vlr_layers_join")          # wgrad GEMMs of this layer run on the library's side stream
                 self.reducer.bucket_ready(f"layer{l}")
+        _hip.call("vlr_layers_join")
         # ---- merge + projector
         n_rows, dup = ctx["n_rows"], ctx["image_dup"]
         if not acc:
