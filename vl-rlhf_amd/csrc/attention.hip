@@ -3,10 +3,16 @@
 //
 // Tiling is built around v_mfma_f32_32x32x16_bf16 with the SWAPPED product S^T = K . Q^T so that a query's row of
 // scores lives in ONE lane pair (l, l^32): softmax statistics are lane-local + one cross-lane exchange, and the
-// bf16 P (or dS) fragment that feeds the second MFMA is built from the accumulator registers in place - the MFMA's
-// k-slot permutation is absorbed by storing the other operand (V^T / K^T / Q^T / dO^T) in LDS in the same permuted
-// order.  K-type tiles are XOR-swizzled 16-byte chunks (conflict-free ds_read_b128); transposed tiles are produced
-// in registers (4x4 v_perm transposes) while staging.
+// bf16 P (or dS) fragment that feeds the second MFMA is packed from the accumulator registers in place.  Every LDS tile
+// is a plain row-major [64 rows][D] image (16-byte chunks XOR-swizzled so that both access patterns below are
+// bank-conflict free):
+//   * "row" fragments  (K for S^T, V for dP^T, Q / dO in the dK,dV kernel): one ds_read_b128 per 32x16 operand;
+//   * "transposed" fragments (V^T for P.V, K^T for dQ, Q^T / dO^T for dK / dV): two ds_read_b64_tr_b16 - the hardware
+//     transposes 4x16 blocks on the way out of LDS, and the two reads are aimed at the row groups {4g..4g+3} and
+//     {8+4g..8+4g+3} so the fragment's k-slot order equals the accumulator layout of the first MFMA.
+// Staging is global -> registers -> LDS with the next tile's loads in flight under the current tile's MFMAs; rows past
+// the end are clamped (their scores are masked), so the hot loop has no divergent load guards.  Masks (causal /
+// key padding / tail) are only applied on tiles that need them (wave-uniform test).
 //
 // Layout: q, k, v are column blocks of one fused [tokens][3H] buffer (row stride ld); token row = b*S + s; head h
 // owns columns [h*D, (h+1)*D).  lse is kept in the log2 domain: L2 = m + log2(l) with scores pre-multiplied by
@@ -16,72 +22,59 @@
 #define KV_TILE 64
 #define LOG2E 1.4426950408889634f
 
-template <int D>
-__device__ __forceinline__ int kt_off(int row, int chunk) {   // [64][D] k-contiguous tile, 16-byte chunk swizzle
-    if constexpr (D == 128) return row * 256 + ((chunk ^ (row & 15)) << 4);
-    else return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
-}
-// transposed tile [D][64 cols]: 128-byte rows of 8 chunks; chunk = (16-col block)*2 + g holds cols {4g..4g+3, 8+4g..}
-__device__ __forceinline__ int tt_off(int drow, int chunk) { return drow * 128 + ((chunk ^ ((drow >> 1) & 7)) << 4); }
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
 
-// ---- tile staging, split in two so the global loads of tile t+1 fly under the MFMAs of tile t --------------------------
-// A 64-row x D tile is held as 8-byte quads: thread -> (d quad dq = t % (D/4), row quads j = t/(D/4) + JPI*i): rows 4j..4j+3,
-// columns 4dq..4dq+3.  The same registers feed the row-major (k-contiguous, swizzled) image and the transposed image.
+// byte offset of 16-byte chunk `chunk` of row `row` in a [64][D] tile
+template <int D>
+__device__ __forceinline__ int tile_off(int row, int chunk) {
+    if constexpr (D == 128) return row * 256 + ((chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
+    else return row * 128 + ((chunk ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3))) << 4);
+}
+
 template <int D>
 struct TileRegs {
-    static constexpr int DQ = D / 4;
-    static constexpr int JPI = 256 / DQ;
-    static constexpr int NI = 16 / JPI;
-    u32x2 r[NI][4];
+    static constexpr int CPR = D / 8;         // 16-byte chunks per row
+    static constexpr int RPI = 256 / CPR;     // rows per pass of the 256 threads
+    static constexpr int NI = 64 / RPI;
+    u32x4 r[NI];
 };
+// global rows [row0, row0+64) x D -> registers (rows past nrows-1 are clamped: finite data, masked by the caller)
 template <int D>
 __device__ __forceinline__ void tile_load(TileRegs<D>& tr, const bf16_t* __restrict__ src, int ld, int row0, int nrows, int t) {
-    const int dq = t % TileRegs<D>::DQ;
+    const int c = t % TileRegs<D>::CPR;
 #pragma unroll
     for (int i = 0; i < TileRegs<D>::NI; ++i) {
-        const int j = t / TileRegs<D>::DQ + TileRegs<D>::JPI * i;
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int row = row0 + 4 * j + rr;
-            u32x2 v = {0u, 0u};
-            if (row < nrows) v = *reinterpret_cast<const u32x2*>(src + (size_t)row * ld + dq * 4);
-            tr.r[i][rr] = v;
-        }
+        int row = row0 + t / TileRegs<D>::CPR + TileRegs<D>::RPI * i;
+        row = row < nrows ? row : nrows - 1;
+        tr.r[i] = *reinterpret_cast<const u32x4*>(src + (size_t)row * ld + c * 8);
     }
 }
-// row-major [64][D] image, 16-byte chunk swizzle (kt_off); each thread writes its 8-byte halves
 template <int D>
-__device__ __forceinline__ void tile_store_rows(const TileRegs<D>& tr, char* lds, int t) {
-    const int dq = t % TileRegs<D>::DQ;
+__device__ __forceinline__ void tile_store(const TileRegs<D>& tr, char* lds, int t) {
+    const int c = t % TileRegs<D>::CPR;
 #pragma unroll
-    for (int i = 0; i < TileRegs<D>::NI; ++i) {
-        const int j = t / TileRegs<D>::DQ + TileRegs<D>::JPI * i;
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
-            *reinterpret_cast<u32x2*>(lds + kt_off<D>(4 * j + rr, dq >> 1) + (dq & 1) * 8) = tr.r[i][rr];
-    }
+    for (int i = 0; i < TileRegs<D>::NI; ++i)
+        *reinterpret_cast<u32x4*>(lds + tile_off<D>(t / TileRegs<D>::CPR + TileRegs<D>::RPI * i, c)) = tr.r[i];
 }
-// transposed [D][64] image (permuted 16-col blocks, tt_off): 4x4 register transposes with v_perm
+// 32 x 16 operand whose 32-index is the tile ROW (rows rbase..rbase+31) and whose k-slots are 16 columns at chunk cchunk
 template <int D>
-__device__ __forceinline__ void tile_store_transposed(const TileRegs<D>& tr, char* lds, int t) {
-    const int dq = t % TileRegs<D>::DQ;
-#pragma unroll
-    for (int i = 0; i < TileRegs<D>::NI; ++i) {
-        const int j = t / TileRegs<D>::DQ + TileRegs<D>::JPI * i;
-        const int ks = j >> 2, qi = j & 3;
-        const int chunk = ks * 2 + (qi & 1);
-#pragma unroll
-        for (int dd = 0; dd < 4; ++dd) {
-            const uint32_t sel = (dd & 1) ? 0x07060302u : 0x05040100u;
-            u32x2 o;
-            o[0] = __builtin_amdgcn_perm(tr.r[i][1][dd >> 1], tr.r[i][0][dd >> 1], sel);
-            o[1] = __builtin_amdgcn_perm(tr.r[i][3][dd >> 1], tr.r[i][2][dd >> 1], sel);
-            *reinterpret_cast<u32x2*>(lds + tt_off(dq * 4 + dd, chunk) + (qi >> 1) * 8) = o;
-        }
-    }
+__device__ __forceinline__ bf16x8 frag_row(const char* tile, int rbase, int cchunk, int lane) {
+    return *reinterpret_cast<const bf16x8*>(tile + tile_off<D>(rbase + (lane & 31), cchunk + (lane >> 5)));
 }
-
-__device__ __forceinline__ int crow(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
+// 32 x 16 operand whose 32-index is the tile COLUMN (cols cbase..cbase+31) and whose k-slots are the 16 rows of block
+// `ks`, in accumulator order: lane group g holds rows {4g..4g+3, 8+4g..8+4g+3}.  ds_read_b64_tr_b16: within a 16-lane
+// group lane p supplies the address of (row p/4, 4 columns at (p%4)*4) and receives column p of that 4 x 16 block.
+template <int D>
+__device__ __forceinline__ bf16x8 frag_tr(const char* tile, int cbase, int ks, int lane) {
+    const int q4 = lane >> 4, pq = lane & 15;
+    const int col = cbase + 16 * (q4 & 1) + (pq & 3) * 4;
+    const int row = ks * 16 + 4 * (q4 >> 1) + (pq >> 2);
+    const int sub = ((col >> 2) & 1) * 8;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + tile_off<D>(row, col >> 3) + sub));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + tile_off<D>(row + 8, col >> 3) + sub));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
 
 __device__ __forceinline__ bf16x8 pack_frag(const f32x16& s, int h) {
     u32x4 w;
@@ -90,7 +83,8 @@ __device__ __forceinline__ bf16x8 pack_frag(const f32x16& s, int h) {
     return __builtin_bit_cast(bf16x8, w);
 }
 
-// write a transposed accumulator tile set acc[db][r] = X^T[d = db*32 + crow(r,g)][row = lane&31] to X[row][d]
+// write a transposed accumulator tile set acc[db][r] = X^T[d = db*32 + crow(r,g)][row = lane&31] to X[row][d],
+// crow(r,g) = (r&3) + 8*(r>>2) + 4*g
 template <int D>
 __device__ __forceinline__ void write_rows(const f32x16* acc, float mul, bf16_t* __restrict__ dst_row, int g) {
 #pragma unroll
@@ -104,6 +98,18 @@ __device__ __forceinline__ void write_rows(const f32x16* acc, float mul, bf16_t*
         }
 }
 
+// key-validity of a 64-key tile -> additive bias row in LDS; returns (block-uniform) whether any key is masked
+__device__ __forceinline__ int stage_bias(float* bias_lds, const int* __restrict__ kmask, size_t tok0, int k0, int S, int t) {
+    int bad = 0;
+    if (t < KV_TILE) {
+        const int key = k0 + t;
+        const bool ok = key < S && (!kmask || kmask[tok0 + key] != 0);
+        bias_lds[t] = ok ? 0.f : -INFINITY;
+        bad = !ok;
+    }
+    return __syncthreads_or(bad);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Forward.  grid (ceil(S/128), heads, batch), 256 threads; wave w owns queries [q0 + 32w, q0 + 32w + 32).
 // ------------------------------------------------------------------------------------------------------------
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
                                                        int S, int Sp, float scale_log2) {
     __shared__ __attribute__((aligned(16))) char smem[KV_TILE * D * 2 * 2 + KV_TILE * 4];
     char* k_lds = smem;
-    char* vt_lds = smem + KV_TILE * D * 2;
+    char* v_lds = smem + KV_TILE * D * 2;
     float* bias_lds = reinterpret_cast<float*>(smem + KV_TILE * D * 4);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 5;
     const int head = blockIdx.y, b = blockIdx.z, nh = gridDim.y;
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     for (int i = 0; i < D / 32; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    float m = -INFINITY, l = 0.f;
+    float m = -INFINITY, l = 0.f;      // m in the scaled log2 domain
 
     const int q_end = min(S, qblk * 128 + 128);
     const int nkv = CAUSAL ? (q_end + KV_TILE - 1) / KV_TILE : (S + KV_TILE - 1) / KV_TILE;
@@ -147,18 +153,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     for (int it = 0; it < nkv; ++it) {
         const int k0 = it * KV_TILE;
         __syncthreads();                                   // every wave is done reading the previous tile
-        tile_store_rows<D>(kreg, k_lds, t);
-        tile_store_transposed<D>(vreg, vt_lds, t);
-        if (t < KV_TILE) {
-            const int key = k0 + t;
-            bias_lds[t] = (key < S && (!kmask || kmask[tok0 + key] != 0)) ? 0.f : -INFINITY;
-        }
-        __syncthreads();
+        tile_store<D>(kreg, k_lds, t);
+        tile_store<D>(vreg, v_lds, t);
+        const int masked_keys = stage_bias(bias_lds, kmask, tok0, k0, S, t);   // barrier inside
         if (it + 1 < nkv) {                                // next tile's global loads fly under this tile's MFMAs
             tile_load<D>(kreg, kh, ld, k0 + KV_TILE, S, t);
             tile_load<D>(vreg, vh, ld, k0 + KV_TILE, S, t);
         }
-        if (CAUSAL && k0 > qw0 + 31) continue;   // wave-uniform: whole tile is in this wave's future
+        if (CAUSAL && k0 > qw0 + 31) continue;             // wave-uniform: whole tile is in this wave's future
 
         f32x16 s[2];
 #pragma unroll
@@ -166,55 +168,56 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
 #pragma unroll
-            for (int st = 0; st < D / 16; ++st) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(k_lds + kt_off<D>(kb * 32 + (lane & 31), 2 * st + g));
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s[kb], 0, 0, 0);
-            }
+            for (int st = 0; st < D / 16; ++st)
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(k_lds, kb * 32, 2 * st, lane), qf[st], s[kb], 0, 0, 0);
         }
-        float mloc = -INFINITY;
+        // masks only where a tile needs them: diagonal tiles (causal) and tiles holding padded / out-of-range keys
+        if ((CAUSAL && k0 + KV_TILE - 1 > qw0) || masked_keys) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(bias_lds + kb * 32 + 8 * rq + 4 * g);
+                for (int rq = 0; rq < 4; ++rq) {
+                    const f32x4 bb = *reinterpret_cast<const f32x4*>(bias_lds + kb * 32 + 8 * rq + 4 * g);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * rq + e;
-                    const int key = k0 + kb * 32 + crow(r, g);
-                    float val = s[kb][r] * scale_log2 + bb[e];
-                    if (CAUSAL && key > qi) val = -INFINITY;
-                    s[kb][r] = val;
-                    mloc = fmaxf(mloc, val);
+                    for (int e = 0; e < 4; ++e) {
+                        const int key = k0 + kb * 32 + 8 * rq + 4 * g + e;
+                        if (bb[e] != 0.f || (CAUSAL && key > qi)) s[kb][4 * rq + e] = -INFINITY;
+                    }
                 }
-            }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-        const float m_new = fmaxf(m, mloc);
+        }
+        float mx = s[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m, mx * scale_log2);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = exp2f(m - m_use);
+        const float alpha = __builtin_amdgcn_exp2f(m - m_use);
         float rs = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = exp2f(s[kb][r] - m_use);
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], scale_log2, -m_use));
                 s[kb][r] = p;
                 rs += p;
             }
         rs += __shfl_xor(rs, 32);
         l = l * alpha + rs;
         m = m_new;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {   // the running max moved for some query of this wave
 #pragma unroll
-        for (int i = 0; i < D / 32; ++i)
+            for (int i = 0; i < D / 32; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
+                for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const bf16x8 pf = pack_frag(s[ks >> 1], ks & 1);
 #pragma unroll
-            for (int db = 0; db < D / 32; ++db) {
-                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vt_lds + tt_off(db * 32 + (lane & 31), ks * 2 + g));
-                acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, acc[db], 0, 0, 0);
-            }
+            for (int db = 0; db < D / 32; ++db)
+                acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(v_lds, db * 32, ks, lane), pf, acc[db], 0, 0, 0);
         }
     }
     if (qi < S) {
@@ -257,11 +260,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
                                                           const int* __restrict__ kmask, bf16_t* __restrict__ dq, int lddq,
                                                           int S, int Sp, float scale) {
     constexpr int D = 128;
-    __shared__ __attribute__((aligned(16))) char smem[KV_TILE * D * 2 * 3 + KV_TILE * 4];
+    __shared__ __attribute__((aligned(16))) char smem[KV_TILE * D * 2 * 2 + KV_TILE * 4];
     char* k_lds = smem;
     char* v_lds = smem + KV_TILE * D * 2;
-    char* kt_lds = smem + KV_TILE * D * 4;
-    float* bias_lds = reinterpret_cast<float*>(smem + KV_TILE * D * 6);
+    float* bias_lds = reinterpret_cast<float*>(smem + KV_TILE * D * 4);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 5;
     const int head = blockIdx.y, b = blockIdx.z, nh = gridDim.y;
     const size_t tok0 = (size_t)b * S;
@@ -298,19 +300,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     for (int it = 0; it < nkv; ++it) {
         const int k0 = it * KV_TILE;
         __syncthreads();
-        tile_store_rows<D>(kreg, k_lds, t);
-        tile_store_transposed<D>(kreg, kt_lds, t);
-        tile_store_rows<D>(vreg, v_lds, t);
-        if (t < KV_TILE) {
-            const int key = k0 + t;
-            bias_lds[t] = (key < S && (!kmask || kmask[tok0 + key] != 0)) ? 0.f : -INFINITY;
-        }
-        __syncthreads();
+        tile_store<D>(kreg, k_lds, t);
+        tile_store<D>(vreg, v_lds, t);
+        const int masked_keys = stage_bias(bias_lds, kmask, tok0, k0, S, t);
         if (it + 1 < nkv) {
             tile_load<D>(kreg, kh, ld, k0 + KV_TILE, S, t);
             tile_load<D>(vreg, vh, ld, k0 + KV_TILE, S, t);
         }
         if (CAUSAL && k0 > qw0 + 31) continue;
+        const bool need_mask = (CAUSAL && k0 + KV_TILE - 1 > qw0) || masked_keys;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             f32x16 s, dp;
@@ -318,34 +316,32 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
             for (int st = 0; st < 8; ++st) {
-                const int off = kt_off<D>(kb * 32 + (lane & 31), 2 * st + g);
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(k_lds + off);
-                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(v_lds + off);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[st], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(k_lds, kb * 32, 2 * st, lane), qf[st], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(v_lds, kb * 32, 2 * st, lane), dof[st], dp, 0, 0, 0);
+            }
+            if (need_mask) {
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const f32x4 bb = *reinterpret_cast<const f32x4*>(bias_lds + kb * 32 + 8 * rq + 4 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int key = k0 + kb * 32 + 8 * rq + 4 * g + e;
+                        if (bb[e] != 0.f || (CAUSAL && key > qi)) s[4 * rq + e] = -INFINITY;
+                    }
+                }
             }
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(bias_lds + kb * 32 + 8 * rq + 4 * g);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * rq + e;
-                    const int key = k0 + kb * 32 + crow(r, g);
-                    float val = s[r] * scale_log2 + bb[e];
-                    if (CAUSAL && key > qi) val = -INFINITY;
-                    const float p = exp2f(val - L2);
-                    s[r] = p > 0.f ? p * (dp[r] - dl) * scale : 0.f;
-                }
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], scale_log2, -L2));   // masked / L2=+inf -> 0
+                s[r] = p * (dp[r] - dl) * scale;
             }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const bf16x8 dsf = pack_frag(s, h);
                 const int ks = kb * 2 + h;
 #pragma unroll
-                for (int db = 0; db < 4; ++db) {
-                    const bf16x8 ktf = *reinterpret_cast<const bf16x8*>(kt_lds + tt_off(db * 32 + (lane & 31), ks * 2 + g));
-                    acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf, acc[db], 0, 0, 0);
-                }
+                for (int db = 0; db < 4; ++db)
+                    acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(k_lds, db * 32, ks, lane), dsf, acc[db], 0, 0, 0);
             }
         }
     }
@@ -364,11 +360,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
                                                            const int* __restrict__ kmask, bf16_t* __restrict__ dk,
                                                            bf16_t* __restrict__ dv, int lddkv, int S, int Sp, float scale) {
     constexpr int D = 128;
-    __shared__ __attribute__((aligned(16))) char smem[KV_TILE * D * 2 * 4];
+    __shared__ __attribute__((aligned(16))) char smem[KV_TILE * D * 2 * 2];
     char* q_lds = smem;
     char* do_lds = smem + KV_TILE * D * 2;
-    char* qt_lds = smem + KV_TILE * D * 4;
-    char* dot_lds = smem + KV_TILE * D * 6;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 5;
     const int head = blockIdx.y, b = blockIdx.z, nh = gridDim.y;
     const size_t tok0 = (size_t)b * S;
@@ -382,6 +376,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
     const int ki = kw0 + (lane & 31);
     const int krow = ki < S ? ki : S - 1;
     const bool key_ok = ki < S && (!kmask || kmask[tok0 + krow] != 0);
+    const bool any_bad_key = __builtin_amdgcn_ballot_w64(!key_ok) != 0;
     const float scale_log2 = scale * LOG2E;
 
     bf16x8 kf[8], vf[8];
@@ -402,16 +397,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
     tile_load<D>(doreg, doh, ldo, q_start, S, t);
     for (int q0 = q_start; q0 < S; q0 += KV_TILE) {
         __syncthreads();
-        tile_store_rows<D>(qreg, q_lds, t);
-        tile_store_transposed<D>(qreg, qt_lds, t);
-        tile_store_rows<D>(doreg, do_lds, t);
-        tile_store_transposed<D>(doreg, dot_lds, t);
+        tile_store<D>(qreg, q_lds, t);
+        tile_store<D>(doreg, do_lds, t);
         __syncthreads();
         if (q0 + KV_TILE < S) {
             tile_load<D>(qreg, qh, ld, q0 + KV_TILE, S, t);
             tile_load<D>(doreg, doh, ldo, q0 + KV_TILE, S, t);
         }
         if (CAUSAL && q0 + KV_TILE - 1 < kw0) continue;   // every query of the tile precedes this wave's keys
+        const bool need_mask = (CAUSAL && q0 < kw0 + 31) || any_bad_key;   // wave-uniform
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             f32x16 s, dp;
@@ -419,11 +413,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
             for (int st = 0; st < 8; ++st) {
-                const int off = kt_off<D>(qb * 32 + (lane & 31), 2 * st + g);
-                const bf16x8 qfr = *reinterpret_cast<const bf16x8*>(q_lds + off);
-                const bf16x8 dofr = *reinterpret_cast<const bf16x8*>(do_lds + off);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kf[st], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dofr, vf[st], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(q_lds, qb * 32, 2 * st, lane), kf[st], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(do_lds, qb * 32, 2 * st, lane), vf[st], dp, 0, 0, 0);
             }
             f32x16 p;
 #pragma unroll
@@ -433,9 +424,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * rq + e;
-                    const int qq = q0 + qb * 32 + crow(r, g);
-                    float pv = exp2f(s[r] * scale_log2 - l2[e]);
-                    if (!key_ok || (CAUSAL && ki > qq)) pv = 0.f;
+                    float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], scale_log2, -l2[e]));   // l2 = +inf past S -> 0
+                    if (need_mask) {
+                        const int qq = q0 + qb * 32 + 8 * rq + 4 * g + e;
+                        if (!key_ok || (CAUSAL && ki > qq)) pv = 0.f;
+                    }
                     p[r] = pv;
                     s[r] = pv > 0.f ? pv * (dp[r] - dl[e]) * scale : 0.f;
                 }
@@ -447,11 +440,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
                 const int ks = qb * 2 + h;
 #pragma unroll
                 for (int db = 0; db < 4; ++db) {
-                    const int off = tt_off(db * 32 + (lane & 31), ks * 2 + g);
-                    const bf16x8 dotf = *reinterpret_cast<const bf16x8*>(dot_lds + off);
-                    const bf16x8 qtf = *reinterpret_cast<const bf16x8*>(qt_lds + off);
-                    adv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf, pf, adv[db], 0, 0, 0);
-                    adk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf, adk[db], 0, 0, 0);
+                    adv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(do_lds, db * 32, ks, lane), pf, adv[db], 0, 0, 0);
+                    adk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(q_lds, db * 32, ks, lane), dsf, adk[db], 0, 0, 0);
                 }
             }
         }
