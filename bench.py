@@ -139,9 +139,21 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
+    # HBM traffic of the dominant kernel: PMC passes cannot run inside the timed region; the committed rocprofv3 --pmc
+    # result (profiles/r01_pmc_hbm_traffic_bench.*) is quoted when present
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_bench.json")
+    if os.path.exists(tf):
+        traffic = round(json.load(open(tf))["gemm_hbm_bytes_per_launch"])
     g_n = sum(prof[k][0] for k in ("gemm_nt", "gemm_nn", "gemm_tn"))
     g_ms = sum(prof[k][1] for k in ("gemm_nt", "gemm_nn", "gemm_tn"))
     g_flop = sum(prof[k][2] for k in ("gemm_nt", "gemm_nn", "gemm_tn"))
+    g_bytes = 0.0   # algorithmic elements moved (A + B + C once) summed over the decoder GEMMs of the timed steps
+    H_, I_, M_ = cfg["hidden"], cfg["inter"], 2 * a.pairs * (a.text_len - 1 + 576)
+    per_shape = cfg["layers"] * a.steps * ((1 if a.precomputed_ref else 2) + 2)   # fwd (policy [+ ref]) + dgrad + wgrad
+    g_dec = 4 * per_shape
+    for m_, n_, k_ in ((M_, 3 * H_, H_), (M_, H_, H_), (M_, 2 * I_, H_), (M_, H_, I_)):
+        g_bytes += per_shape * (m_ * k_ + n_ * k_ + m_ * n_)
     per_kernel = {k: {"launches": n, "ms": round(ms, 2), "tflops": round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else 0.0}
                   for k, (n, ms, fl) in prof.items()}
     pairs_per_s = world * a.pairs * a.steps / dt
@@ -160,7 +172,8 @@ def main():
                        "layers": cfg["layers"], "loss": float(loss)},
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (NT/NN/TN)", "achieved": round(achieved, 1),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                         "traffic": None, "launches": g_n, "avg_launch_ms": round(g_ms / max(1, g_n), 4), "per_kernel": per_kernel,
+                         "traffic": traffic, "traffic_unit": "bytes/launch (2*FETCH_SIZE+WRITE_SIZE, rocprofv3 --pmc, offline pass)",
+                         "algorithmic_bytes_per_launch": round(2.0 * g_bytes / max(1, g_dec)), "launches": g_n, "avg_launch_ms": round(g_ms / max(1, g_n), 4), "per_kernel": per_kernel,
                          "gemm_share_of_step": round(g_ms * 1e-3 / dt, 3),
                          "step_frac": round(pairs_per_s / world * per_pair / PEAK_BF16_TFLOPS, 4)},
         }
