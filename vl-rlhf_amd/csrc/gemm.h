@@ -15,6 +15,7 @@ struct GemmParams {
     int act;
     int accumulate;  // C += result (C read in its own dtype)
     int out_f32;
+    int flags;       // tuning experiments (VLR_GEMM_FLAGS), 0 in production
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {

@@ -12,6 +12,8 @@
 // applied in fp32 and global stores are 16 B per lane along rows.
 // Workgroup -> tile map: XCD-aware (block b runs on XCD b%8; each XCD gets a contiguous run of tiles) and grouped
 // (8 tile-rows x all tile-columns) so co-resident workgroups share A panels and B panels in their XCD's L2.
+#include <stdlib.h>
+
 #include "gemm.h"
 
 #define BM 128
@@ -262,8 +264,48 @@ extern "C" int vlr_gemm_bf16(int layout, const void* A, const void* B, void* C, 
     p.bias = (const bf16_t*)bias; p.residual = (const bf16_t*)residual;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
     p.act = act; p.accumulate = accumulate; p.out_f32 = out_f32;
-    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    static int gflags = -1;
+    if (gflags < 0) { const char* e = getenv("VLR_GEMM_FLAGS"); gflags = e ? atoi(e) : 0; }
+    p.flags = gflags;
     const int pi = vlr_prof_begin(layout, 2.0 * M * N * K, stream);
+    // ---- wave quantisation: a 256x256-tile grid of T tiles runs ceil(T/256) rounds on the 256 CUs; when the last round is
+    // nearly empty (e.g. 12792 x 4096 -> 800 tiles = 3.125 rounds) the last tile-rows are peeled off and run as 128x128
+    // tiles (2 workgroups per CU) so the big-tile part is a whole number of rounds.  VLR_GEMM_SPLIT=0 disables.
+    static int split_on = -1;
+    if (split_on < 0) { const char* e = getenv("VLR_GEMM_SPLIT"); split_on = (e && e[0] == '0') ? 0 : 1; }
+    const int tm256 = (M + 255) / 256, tn256 = (N + 255) / 256;
+    int peel = 0;
+    if (split_on && (long)tm256 * tn256 >= 512) {
+        const int full = tm256 * tn256;
+        const double base = (double)((full + 255) / 256);
+        double best = base;
+        for (int r = 1; r <= 3 && tm256 - r >= 2; ++r) {
+            const int t1 = (tm256 - r) * tn256;
+            const int rem_rows = M - (tm256 - r) * 256;
+            const long t128 = (long)((rem_rows + 127) / 128) * ((N + 127) / 128);
+            const double est = (double)((t1 + 255) / 256) + 0.7 * (double)((t128 + 511) / 512);
+            if (est < best - 0.05) { best = est; peel = r; }
+        }
+    }
+    if (peel) {
+        const int M1 = (tm256 - peel) * 256;
+        GemmParams p1 = p, p2 = p;
+        p1.M = M1;
+        p2.M = M - M1;
+        const size_t esz = out_f32 ? 4 : 2;
+        p2.A = layout == 2 ? p.A + M1 : p.A + (size_t)M1 * lda;
+        p2.C = (char*)p.C + (size_t)M1 * ldc * esz;
+        if (p.residual) p2.residual = p.residual + (size_t)M1 * ldr;
+        if (vlr_gemm256_try_launch(layout, p1, stream)) {
+            const int t2 = ((p2.M + BM - 1) / BM) * ((N + BN - 1) / BN);
+            if (layout == 0) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), dim3(t2), dim3(256), 0, stream, p2);
+            else if (layout == 1) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), dim3(t2), dim3(256), 0, stream, p2);
+            else hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), dim3(t2), dim3(256), 0, stream, p2);
+            vlr_prof_end(pi, stream);
+            return vlr_check_launch("vlr_gemm_bf16(256+128)");
+        }
+    }
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     if (vlr_gemm256_try_launch(layout, p, stream)) {
         vlr_prof_end(pi, stream);
         return vlr_check_launch("vlr_gemm_bf16(256)");

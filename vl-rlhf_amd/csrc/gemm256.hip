@@ -344,6 +344,21 @@ __device__ __forceinline__ void dma_piece32(const bf16_t* __restrict__ P, int ld
     const bf16_t* g = (k + 8 <= K) ? P + (size_t)grow * ld + k : zero16;
     __builtin_amdgcn_global_load_lds((gvoid_t*)g, (lvoid_t*)(lds + R * (SK * 2)), 16, 0, 0);
 }
+// k-contiguous operand, FULL-LINE variant: the vector-memory pipeline is the bottleneck of this kernel and it pays per
+// 128-byte line, so a 64-byte row (K tile of 32) costs as much as a whole line.  The k-contiguous operand is therefore kept
+// in two DOUBLE stages of [256 rows][64 k] (128-byte rows = two consecutive K tiles side by side); one DMA instruction
+// brings 8 rows x 128 B, and a double tile is fetched every second K tile.  Same LDS footprint as 4 single stages.
+__device__ __forceinline__ void dma_piece64(const bf16_t* __restrict__ P, int ld, int row0, int nrows, int k0, int K,
+                                            const bf16_t* __restrict__ zero16, char* lds, int wave, int lane, int i) {
+    const int R = (wave * 4 + i) * 8;
+    const int r = R + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    int grow = row0 + r;
+    grow = grow < nrows ? grow : nrows - 1;
+    const int k = k0 + c * 8;
+    const bf16_t* g = (k + 8 <= K) ? P + (size_t)grow * ld + k : zero16;
+    __builtin_amdgcn_global_load_lds((gvoid_t*)g, (lvoid_t*)(lds + R * 128), 16, 0, 0);
+}
 // k-strided operand (stored [K][ncols]): LDS image [32 k][256 cols] (512-byte rows), 2 k-rows per wave instruction.  The
 // 16-byte chunks of row r are XOR-permuted by (r&3)<<2 on the SOURCE side so that the ds_read_b64_tr_b16 of a 32-lane
 // half (4 k-rows x 64 B) touches 16 distinct chunks of a 256-byte bank row.  k >= K -> zeros; columns clamped in range.
@@ -416,56 +431,79 @@ __global__ __launch_bounds__(512) void gemm256s_kernel(GemmParams p, const bf16_
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nt = (p.K + SK - 1) / SK;
-    auto dma_tile = [&](int kt) {
-        char* a = smem + (kt & (NSTAGE - 1)) * SSTAGE;
-        char* b = a + TM * SK * 2;
-        const int k0 = kt * SK;
+    char* const a_base = smem;                       // 64 KiB per operand
+    char* const b_base = smem + NSTAGE * TM * SK * 2;
+    // byte offset of the LDS region holding K tile kt of an operand
+    auto a_region = [&](int kt) { return a_base + (A_KS ? (kt & 3) * (TM * SK * 2) : ((kt >> 1) & 1) * (TM * SK * 4)); };
+    auto b_region = [&](int kt) { return b_base + (B_KS ? (kt & 3) * (TN * SK * 2) : ((kt >> 1) & 1) * (TN * SK * 4)); };
+    // issue the DMA owed in the LOAD phase of tile kt: k-strided operands fetch tile kt+2 every phase, k-contiguous
+    // operands fetch the double tile (kt+2, kt+3) on even kt
+    auto dma_for = [&](int kt) {
+        const int k0 = (kt + 2) * SK;
+        if constexpr (A_KS) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if constexpr (A_KS) dma_piece32_ks(p.A, p.lda, m0, p.M, k0, p.K, zero16, a, wave, lane, i);
-            else dma_piece32(p.A, p.lda, m0, p.M, k0, p.K, zero16, a, wave, lane, i);
+            for (int i = 0; i < 2; ++i) dma_piece32_ks(p.A, p.lda, m0, p.M, k0, p.K, zero16, a_region(kt + 2), wave, lane, i);
+        } else if ((kt & 1) == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dma_piece64(p.A, p.lda, m0, p.M, k0, p.K, zero16, a_region(kt + 2), wave, lane, i);
         }
+        if constexpr (B_KS) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if constexpr (B_KS) dma_piece32_ks(p.B, p.ldb, n0, p.N, k0, p.K, zero16, b, wave, lane, i);
-            else dma_piece32(p.B, p.ldb, n0, p.N, k0, p.K, zero16, b, wave, lane, i);
+            for (int i = 0; i < 2; ++i) dma_piece32_ks(p.B, p.ldb, n0, p.N, k0, p.K, zero16, b_region(kt + 2), wave, lane, i);
+        } else if ((kt & 1) == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dma_piece64(p.B, p.ldb, n0, p.N, k0, p.K, zero16, b_region(kt + 2), wave, lane, i);
         }
     };
     // prologue: tiles 0 and 1 resident before anyone reads
-    dma_tile(0);
-    if (nt > 1) dma_tile(1);
+    dma_for(-2);                                     // K tiles 0 (and 1 for k-contiguous operands)
+    dma_for(-1);                                     // K tile 1 of k-strided operands
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     RAW_BARRIER();
     if (grp == 1) RAW_BARRIER();          // waves 4-7 run one phase behind waves 0-3
 
     bf16x8 fa[2][4], fb[2][2];
     for (int kt = 0; kt < nt; ++kt) {
-        const char* a = smem + (kt & (NSTAGE - 1)) * SSTAGE;
-        const char* b = a + TM * SK * 2;
+        const char* a = a_region(kt);
+        const char* b = b_region(kt);
         // ---------------- LOAD phase: all 12 fragment reads of tile kt (the MATH phase is register-only), then the DMA
+        if (!(p.flags & 16) || kt == 0)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int c = kk * 2 + (lane >> 5);
+            const int c64 = (kt & 1) * 4 + c;        // chunk inside a 128-byte double-stage row
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if constexpr (A_KS) fa[kk][i] = frag_ks(a, wm * 128 + i * 32, kk, lane);
-                else fa[kk][i] = *reinterpret_cast<const bf16x8*>(a + swz32(wm * 128 + i * 32 + (lane & 31), c));
+                else fa[kk][i] = *reinterpret_cast<const bf16x8*>(a + swz256(wm * 128 + i * 32 + (lane & 31), c64));
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 if constexpr (B_KS) fb[kk][j] = frag_ks(b, wn * 64 + j * 32, kk, lane);
-                else fb[kk][j] = *reinterpret_cast<const bf16x8*>(b + swz32(wn * 64 + j * 32 + (lane & 31), c));
+                else fb[kk][j] = *reinterpret_cast<const bf16x8*>(b + swz256(wn * 64 + j * 32 + (lane & 31), c64));
             }
         }
+        // everything issued BEFORE this phase must have landed by the barrier below (it is first read two phases later);
+        // what this phase issues stays in flight: counted vmcnt = number of pieces issued here
         if (kt + 2 < nt) {
-            dma_tile(kt + 2);
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // everything but the tile just issued has landed
+            if (!(p.flags & 8)) dma_for(kt);
+            constexpr int N_KS = (A_KS ? 2 : 0) + (B_KS ? 2 : 0);
+            constexpr int N_KC = (A_KS ? 0 : 4) + (B_KS ? 0 : 4);
+            if ((kt & 1) == 0) {
+                if constexpr (N_KS + N_KC == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if constexpr (N_KS + N_KC == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                if constexpr (N_KS == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if constexpr (N_KS == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            }
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         RAW_BARRIER();
         // ---------------- MATH phase
-        __builtin_amdgcn_s_setprio(1);
+        if (!(p.flags & 1)) __builtin_amdgcn_s_setprio(1);
 #define MMS(s_, i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s_][i], fb[s_][j], acc[i][j], 0, 0, 0)
         MMS(0, 0, 0); MMS(0, 0, 1); MMS(0, 1, 0); MMS(0, 1, 1); MMS(0, 2, 0); MMS(0, 2, 1); MMS(0, 3, 0); MMS(0, 3, 1);
         MMS(1, 0, 0); MMS(1, 0, 1); MMS(1, 1, 0); MMS(1, 1, 1); MMS(1, 2, 0); MMS(1, 2, 1); MMS(1, 3, 0); MMS(1, 3, 1);

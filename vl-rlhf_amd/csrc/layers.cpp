@@ -11,9 +11,10 @@
 #include "../../include/vlr.h"
 #include "common.h"
 
-// ---- optional second stream for the weight-gradient GEMMs: dgrad (NN) and wgrad (TN) of a layer are independent, and a
-// 256x256-tile GEMM leaves up to 22 % of the chip idle in its last wave of workgroups (800 tiles on 256 CUs); running the
-// wgrad on a side stream lets its workgroups fill those tails.  VLR_BWD_STREAMS=0 disables it.
+// ---- optional second stream for the weight-gradient GEMMs: dgrad (NN) and wgrad (TN) of a layer are independent, so the
+// wgrad can run on a side stream and fill the dgrad's last, partly empty wave of workgroups.  Measured (profiles/): +1.5 %
+// with the first 256-tile kernel, -2 % once the GEMM dispatcher peels the ragged tile rows itself (gemm.hip) - two
+// 128 KiB-LDS kernels only time-share the CUs.  Off by default; VLR_BWD_STREAMS=1 enables it.
 #include <stdlib.h>
 static hipStream_t g_side = nullptr;
 static hipEvent_t g_fork = nullptr, g_done[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -23,7 +24,7 @@ static bool g_side_used = false;
 static bool two_streams() {
     if (g_two_streams < 0) {
         const char* e = getenv("VLR_BWD_STREAMS");
-        g_two_streams = (e && e[0] == '0') ? 0 : 1;
+        g_two_streams = (e && e[0] == '1') ? 1 : 0;
         if (g_two_streams) {
             if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) g_two_streams = 0;
             hipEventCreateWithFlags(&g_fork, hipEventDisableTiming);
