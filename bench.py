@@ -100,7 +100,7 @@ def main():
     eng = model.engine
     eng.init_optimizer()
     if world > 1:
-        eng.reducer = GradReducer(eng.grads, eng.layout.bucket_after)
+        eng.make_reducer()
     args = SimpleNamespace(gradient_accumulation_steps=1)
     tr = LlavaDPOTrainer(model, None if a.precomputed_ref else ref, 0.1, 0, "sigmoid", args, None, -100, 0,
                          precompute_ref_log_probs=a.precomputed_ref)

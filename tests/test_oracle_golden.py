@@ -187,3 +187,33 @@ def test_bf16_emulation_close_to_fp32():
         l32, _ = O.compute_loss(W, W_ref, cfg, batch, cfg["beta"])
         l16, _ = O.compute_loss(W, W_ref, cfg, batch, cfg["beta"], emulate_bf16=True)
     assert abs(float(l32) - float(l16)) < 0.05
+
+
+# ---------------------------------------------------------------------------------------------------- LoRA restatement
+def test_lora_forward_equals_merged_base_forward():
+    """peft identity: base(x) + s*B(A(x)) == (W + s*B A) x.  Pins the LoRA restatement to the golden-pinned base path."""
+    z, cfg, W, W_ref, batch, rows = load_case("llava_hipsmall")
+    lora = O.random_lora(cfg, r=8, alpha=16, seed=3, b_std=0.05)
+    with torch.no_grad():
+        l_a, m_a = O.compute_loss(W, W, cfg, batch, cfg["beta"], lora=lora)
+        l_m, m_m = O.compute_loss(O.lora_merged_weights(W, lora, cfg), W, cfg, batch, cfg["beta"])
+        l_0, _ = O.compute_loss(W, W, cfg, batch, cfg["beta"])
+    assert abs(float(l_a) - float(l_m)) < 1e-5 * max(1.0, abs(float(l_m)))
+    assert abs(float(l_a) - float(l_0)) > 1e-4          # the adapters do change the loss
+    for k in m_a:
+        assert abs(float(m_a[k]) - float(m_m[k])) < 2e-4 * max(1.0, abs(float(m_m[k]))), k
+    # B = 0 (peft init): policy == reference, loss = ln 2
+    l_i, _ = O.compute_loss(W, W, cfg, batch, cfg["beta"], lora=O.random_lora(cfg, 8, 16, seed=1))
+    assert abs(float(l_i) - 0.6931472) < 1e-6
+
+
+def test_dropout_mask_restatement():
+    m1 = O.dropout_mask(1234, 1 << 16, 0.05)
+    m2 = O.dropout_mask(1234, 1 << 16, 0.05)
+    m3 = O.dropout_mask(1235, 1 << 16, 0.05)
+    assert torch.equal(m1, m2) and not torch.equal(m1, m3)
+    assert abs(float(m1.float().mean()) - 0.95) < 5e-3
+    assert abs(float((m1 & m3).float().mean()) - 0.95 * 0.95) < 8e-3           # independent streams
+    assert int(O.dropout_mask(7, 64, 0.0).sum()) == 64
+    # prefix property: the mask of element i does not depend on n
+    assert torch.equal(O.dropout_mask(9, 4096, 0.3)[:512], O.dropout_mask(9, 512, 0.3))

@@ -107,6 +107,15 @@ __global__ void reduce_partials_kernel(const float* __restrict__ part, int P, in
     out[c] = f32_to_bf16(s);
 }
 
+// stage 1 of a two-stage reduction: out[y][c] = sum of part[p][c] for p = y, y + gridDim.y, ...
+__global__ void reduce_partials_stage_kernel(const float* __restrict__ part, int P, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int p = blockIdx.y; p < P; p += gridDim.y) s += part[(size_t)p * C + c];
+    out[(size_t)blockIdx.y * C + c] = s;
+}
+
 __global__ void reduce_partials_f32_kernel(const float* __restrict__ part, int P, int C, float* __restrict__ out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
@@ -307,6 +316,58 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// counter-based dropout (LoRA lora_dropout, peft lora.Linear: result += lora_B(lora_A(dropout(x))) * scaling).
+// Group g of 8 consecutive elements draws two 64-bit words r_j = mix64(key ^ (2g+j)), key = mix64(seed); element e keeps
+// iff its 16-bit lane (r_{e/4} >> 16*(e%4)) & 0xffff >= thr, thr = round(p * 65536).  Stateless, so the backward
+// regenerates the mask from (seed, index) instead of storing it.  oracle/llava_dpo_oracle.py:dropout_mask restates it.
+// ------------------------------------------------------------------------------------------------------------
+__host__ __device__ inline uint64_t vlr_mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ uint32_t dropout_keep8(uint64_t key, long g, uint32_t thr) {
+    const uint64_t r0 = vlr_mix64(key ^ (uint64_t)(2 * g)), r1 = vlr_mix64(key ^ (uint64_t)(2 * g + 1));
+    uint32_t keep = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        keep |= (uint32_t)(((r0 >> (16 * e)) & 0xffffu) >= thr) << e;
+        keep |= (uint32_t)(((r1 >> (16 * e)) & 0xffffu) >= thr) << (4 + e);
+    }
+    return keep;
+}
+// out = mask * x * scale ; or, with ADD, out += mask * x * scale
+template <bool ADD>
+__global__ __launch_bounds__(256) void dropout_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, long n8,
+                                                      uint64_t key, uint32_t thr, float scale) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        float v[8];
+        unpack8(*reinterpret_cast<const u32x4*>(x + i * 8), v);
+        const uint32_t keep = dropout_keep8(key, i, thr);
+        if (ADD) {
+            float o[8];
+            unpack8(*reinterpret_cast<const u32x4*>(out + i * 8), o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = o[e] + ((keep >> e) & 1 ? v[e] * scale : 0.f);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (keep >> e) & 1 ? v[e] * scale : 0.f;
+        }
+        *reinterpret_cast<u32x4*>(out + i * 8) = pack8(v);
+    }
+}
+__global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ mask, long n8, uint64_t key, uint32_t thr) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const uint32_t keep = dropout_keep8(key, i, thr);
+        uint64_t w = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w |= (uint64_t)((keep >> e) & 1) << (8 * e);
+        *reinterpret_cast<uint64_t*>(mask + i * 8) = w;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // im2col for the CLIP patch embedding: pixel_values fp32 [n][3][S][S] -> patches bf16 [n*g*g][Kp], column order
 // (c, py, px) = Conv2d weight.reshape(D, 3*P*P); columns >= 3*P*P are zero padding up to Kp (multiple of 8).
 // ------------------------------------------------------------------------------------------------------------
@@ -380,8 +441,11 @@ extern "C" int vlr_rmsnorm_fwd(const void* x, const void* w, void* y, float* rst
     return vlr_check_launch("vlr_rmsnorm_fwd");
 }
 
-#define VLR_NORM_BWD_BLOCKS 256
-extern "C" int vlr_rmsnorm_bwd_workspace_bytes(int H) { return VLR_NORM_BWD_BLOCKS * H * 4; }
+// 1024 workgroups (4 per CU) keep enough loads in flight for an HBM-bound pass; their dw partials are reduced in two
+// deterministic stages (1024 -> 16 -> 1)
+#define VLR_NORM_BWD_BLOCKS 1024
+#define VLR_NORM_BWD_STAGE2 16
+extern "C" int vlr_rmsnorm_bwd_workspace_bytes(int H) { return (VLR_NORM_BWD_BLOCKS + VLR_NORM_BWD_STAGE2) * H * 4; }
 
 extern "C" int vlr_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres,
                                void* dx, void* dw, int dw_accumulate, void* workspace, int M, int H, hipStream_t st) {
@@ -390,9 +454,13 @@ extern "C" int vlr_rmsnorm_bwd(const void* dy, const void* x, const void* w, con
     const int G = M < VLR_NORM_BWD_BLOCKS ? M : VLR_NORM_BWD_BLOCKS;
     hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(G), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x,
                        (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, (float*)workspace, M, H);
-    if (dw)
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((H + 255) / 256), dim3(256), 0, st, (const float*)workspace, G, H,
+    if (dw) {
+        float* part2 = (float*)workspace + (size_t)VLR_NORM_BWD_BLOCKS * H;
+        const int S2 = G < VLR_NORM_BWD_STAGE2 ? 1 : VLR_NORM_BWD_STAGE2;
+        hipLaunchKernelGGL(reduce_partials_stage_kernel, dim3((H + 255) / 256, S2), dim3(256), 0, st, (const float*)workspace, G, H, part2);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((H + 255) / 256), dim3(256), 0, st, (const float*)part2, S2, H,
                            (bf16_t*)dw, dw_accumulate);
+    }
     return vlr_check_launch("vlr_rmsnorm_bwd");
 }
 
@@ -472,6 +540,24 @@ extern "C" int vlr_gelu_bwd(const void* z, const void* dh, void* dz, long n, hip
     hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, st, (const bf16_t*)z, (const bf16_t*)dh,
                        (bf16_t*)dz, n / 8);
     return vlr_check_launch("vlr_gelu_bwd");
+}
+static inline uint32_t dropout_thr(float p) { return (uint32_t)(p * 65536.0f + 0.5f); }
+extern "C" int vlr_dropout(const void* x, void* out, long n, float p, uint64_t seed, float alpha, int add, hipStream_t st) {
+    VLR_REQUIRE(n > 0 && n % 8 == 0 && p >= 0.f && p < 1.f, "vlr_dropout: n %% 8 == 0 and 0 <= p < 1 required (n=%ld p=%g)", n, (double)p);
+    const float scale = alpha / (1.f - p);
+    if (add)
+        hipLaunchKernelGGL(dropout_kernel<true>, dim3(grid_for(n / 8, 256)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)out, n / 8,
+                           vlr_mix64(seed), dropout_thr(p), scale);
+    else
+        hipLaunchKernelGGL(dropout_kernel<false>, dim3(grid_for(n / 8, 256)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)out, n / 8,
+                           vlr_mix64(seed), dropout_thr(p), scale);
+    return vlr_check_launch("vlr_dropout");
+}
+extern "C" int vlr_dropout_mask(void* mask_u8, long n, float p, uint64_t seed, hipStream_t st) {
+    VLR_REQUIRE(n > 0 && n % 8 == 0 && p >= 0.f && p < 1.f, "vlr_dropout_mask: n %% 8 == 0 and 0 <= p < 1 required");
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, st, (uint8_t*)mask_u8, n / 8, vlr_mix64(seed),
+                       dropout_thr(p));
+    return vlr_check_launch("vlr_dropout_mask");
 }
 extern "C" int vlr_im2col(const float* pixel_values, void* patches, int n_img, int image_size, int patch, int Kp,
                           hipStream_t st) {

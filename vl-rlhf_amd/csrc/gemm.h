@@ -16,6 +16,7 @@ struct GemmParams {
     int accumulate;  // C += result (C read in its own dtype)
     int out_f32;
     int flags;       // tuning experiments (VLR_GEMM_FLAGS), 0 in production
+    float alpha;     // v = act(alpha * acc + bias) + residual (+ C)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
                     v[4 + e] = s1[e];
                 }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e] + bv[e], p.act);
+                for (int e = 0; e < 8; ++e) v[e] = apply_act(p.alpha * v[e] + bv[e], p.act);
                 if (p.residual) {
                     float rv[8];
                     unpack8(*reinterpret_cast<const u32x4*>(p.residual + (size_t)gm * p.ldr + gn), rv);
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
             if (gm < p.M && gn + 4 <= p.N) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * 64 + cq);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e] + bv[e], p.act);
+                for (int e = 0; e < 4; ++e) v[e] = apply_act(p.alpha * v[e] + bv[e], p.act);
                 if (p.residual) {
                     const u32x2 w = *reinterpret_cast<const u32x2*>(p.residual + (size_t)gm * p.ldr + gn);
                     v[0] += bf16lo(w[0]); v[1] += bf16hi(w[0]); v[2] += bf16lo(w[1]); v[3] += bf16hi(w[1]);
@@ -244,9 +244,25 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+static int gemm_impl(int layout, const void* A, const void* B, void* C, const void* bias, const void* residual, int M, int N,
+                     int K, int lda, int ldb, int ldc, int ldr, int act, int accumulate, int out_f32, float alpha,
+                     hipStream_t stream);
+
 extern "C" int vlr_gemm_bf16(int layout, const void* A, const void* B, void* C, const void* bias, const void* residual,
                              int M, int N, int K, int lda, int ldb, int ldc, int ldr, int act, int accumulate,
                              int out_f32, hipStream_t stream) {
+    return gemm_impl(layout, A, B, C, bias, residual, M, N, K, lda, ldb, ldc, ldr, act, accumulate, out_f32, 1.0f, stream);
+}
+// same, with the accumulator scaled by alpha before the epilogue (LoRA merge: W_eff = W + (alpha/r) B A)
+extern "C" int vlr_gemm_bf16_scaled(int layout, const void* A, const void* B, void* C, const void* bias,
+                                    const void* residual, int M, int N, int K, int lda, int ldb, int ldc, int ldr, int act,
+                                    int accumulate, int out_f32, float alpha, hipStream_t stream) {
+    return gemm_impl(layout, A, B, C, bias, residual, M, N, K, lda, ldb, ldc, ldr, act, accumulate, out_f32, alpha, stream);
+}
+
+static int gemm_impl(int layout, const void* A, const void* B, void* C, const void* bias, const void* residual, int M, int N,
+                     int K, int lda, int ldb, int ldc, int ldr, int act, int accumulate, int out_f32, float alpha,
+                     hipStream_t stream) {
     VLR_REQUIRE(layout >= 0 && layout <= 2, "vlr_gemm_bf16: layout must be 0 (NT), 1 (NN) or 2 (TN), got %d", layout);
     VLR_REQUIRE(M > 0 && N > 0 && K > 0, "vlr_gemm_bf16: empty problem M=%d N=%d K=%d", M, N, K);
     VLR_REQUIRE(A && B && C, "vlr_gemm_bf16: null operand");
@@ -267,6 +283,7 @@ extern "C" int vlr_gemm_bf16(int layout, const void* A, const void* B, void* C, 
     static int gflags = -1;
     if (gflags < 0) { const char* e = getenv("VLR_GEMM_FLAGS"); gflags = e ? atoi(e) : 0; }
     p.flags = gflags;
+    p.alpha = alpha;
     const int pi = vlr_prof_begin(layout, 2.0 * M * N * K, stream);
     // ---- wave quantisation: a 256x256-tile grid of T tiles runs ceil(T/256) rounds on the 256 CUs; when the last round is
     // nearly empty (e.g. 12792 x 4096 -> 800 tiles = 3.125 rounds) the last tile-rows are peeled off and run as 128x128

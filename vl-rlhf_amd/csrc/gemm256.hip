@@ -260,7 +260,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v[e] = s0[e]; v[4 + e] = s1[e]; }
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e] + bv[e], p.act);
+                    for (int e = 0; e < 8; ++e) v[e] = apply_act(p.alpha * v[e] + bv[e], p.act);
                     if (p.residual) {
                         float rv[8];
                         unpack8(*reinterpret_cast<const u32x4*>(p.residual + (size_t)gm * p.ldr + gn), rv);
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                 if (gm < p.M && gn + 4 <= p.N) {
                     f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * 64 + cq);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e] + bv[e], p.act);
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act(p.alpha * v[e] + bv[e], p.act);
                     if (p.residual) {
                         const u32x2 w = *reinterpret_cast<const u32x2*>(p.residual + (size_t)gm * p.ldr + gn);
                         v[0] += bf16lo(w[0]); v[1] += bf16hi(w[0]); v[2] += bf16lo(w[1]); v[3] += bf16hi(w[1]);
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(512) void gemm256s_kernel(GemmParams p, const bf16_
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v[e] = s0[e]; v[4 + e] = s1[e]; }
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e] + bv[e], p.act);
+                    for (int e = 0; e < 8; ++e) v[e] = apply_act(p.alpha * v[e] + bv[e], p.act);
                     if (p.residual) {
                         float rv[8];
                         unpack8(*reinterpret_cast<const u32x4*>(p.residual + (size_t)gm * p.ldr + gn), rv);
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(512) void gemm256s_kernel(GemmParams p, const bf16_
                 if (gm < p.M && gn + 4 <= p.N) {
                     f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * 64 + cq);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e] + bv[e], p.act);
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act(p.alpha * v[e] + bv[e], p.act);
                     if (p.residual) {
                         const u32x2 w = *reinterpret_cast<const u32x2*>(p.residual + (size_t)gm * p.ldr + gn);
                         v[0] += bf16lo(w[0]); v[1] += bf16hi(w[0]); v[2] += bf16lo(w[1]); v[3] += bf16hi(w[1]);

@@ -117,6 +117,123 @@ extern "C" int vlr_decoder_layer_bwd(const vlr_llama_cfg* cfg, const vlr_layer_w
     return VLR_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// LoRA (peft lora.Linear.forward: result = base(x) + lora_B(lora_A(dropout(x))) * scaling) on the seven decoder linears,
+// un-merged so that lora_dropout works and the frozen base weights double as the reference model (adapter disabled).
+// One fused linear group = n sub-targets sharing the input x [M][in]; y/dy [M][n*out]; A [n*r][in]; B [n*out][r];
+// u = dropout_t(x) A_t^T is kept for the backward ([M][7r] per layer: qkv | o | gate,up | down).
+// Dropout target t of a layer uses seed + t (t = 0..6 in q,k,v,o,gate,up,down order).
+// ---------------------------------------------------------------------------------------------------------------------
+static int lora_group_fwd(int n, int r, int in, int out, const void* x, void* y, int ldy, const void* A, const void* B, void* u,
+                          int ldu, float scale, float p, uint64_t seed, void* ws_xd, int M, hipStream_t st) {
+    if (p > 0.f) {
+        for (int t = 0; t < n; ++t) {
+            CHECK(vlr_dropout(x, ws_xd, (long)M * in, p, seed + t, 1.f, 0, st));
+            CHECK(vlr_gemm_bf16(0, ws_xd, off(A, (size_t)t * r * in), off(u, (size_t)t * r), nullptr, nullptr, M, r, in, in, in, ldu, 0, 0, 0, 0, st));
+        }
+    } else {
+        CHECK(vlr_gemm_bf16(0, x, A, u, nullptr, nullptr, M, n * r, in, in, in, ldu, 0, 0, 0, 0, st));
+    }
+    for (int t = 0; t < n; ++t)
+        CHECK(vlr_gemm_bf16_scaled(0, off(u, (size_t)t * r), off(B, (size_t)t * out * r), off(y, (size_t)t * out), nullptr, nullptr, M, out, r,
+                                   ldu, r, ldy, 0, 0, 1, 0, scale, st));
+    return VLR_OK;
+}
+
+// dx [M][in] already holds dy W; adds the adapter path and writes the adapter gradients
+static int lora_group_bwd(int n, int r, int in, int out, const void* x, const void* dy, int lddy, const void* A, const void* B,
+                          void* dA, void* dB, const void* u, int ldu, void* v, void* dx, float scale, float p, uint64_t seed,
+                          void* ws_xd, int accumulate, int M, hipStream_t st) {
+    const int nr = n * r;
+    for (int t = 0; t < n; ++t) {
+        const void* dyt = off(dy, (size_t)t * out);
+        CHECK(vlr_gemm_bf16_scaled(2, dyt, off(u, (size_t)t * r), off(dB, (size_t)t * out * r), nullptr, nullptr, out, r, M, lddy, ldu, r,
+                                   0, 0, accumulate, 0, scale, st));                                                // dB_t = s dy_t^T u_t
+        CHECK(vlr_gemm_bf16(1, dyt, off(B, (size_t)t * out * r), off(v, (size_t)t * r), nullptr, nullptr, M, r, out, lddy, r, nr,
+                            0, 0, 0, 0, st));                                                                       // v_t = dy_t B_t
+    }
+    if (p > 0.f) {
+        for (int t = 0; t < n; ++t) {
+            CHECK(vlr_dropout(x, ws_xd, (long)M * in, p, seed + t, 1.f, 0, st));
+            CHECK(vlr_gemm_bf16_scaled(2, off(v, (size_t)t * r), ws_xd, off(dA, (size_t)t * r * in), nullptr, nullptr, r, in, M, nr, in, in,
+                                       0, 0, accumulate, 0, scale, st));                                            // dA_t = s v_t^T drop_t(x)
+            CHECK(vlr_gemm_bf16(1, off(v, (size_t)t * r), off(A, (size_t)t * r * in), ws_xd, nullptr, nullptr, M, in, r, nr, in, in,
+                                0, 0, 0, 0, st));
+            CHECK(vlr_dropout(ws_xd, dx, (long)M * in, p, seed + t, scale, 1, st));                                  // dx += s mask_t (v_t A_t)/(1-p)
+        }
+    } else {
+        CHECK(vlr_gemm_bf16_scaled(2, v, x, dA, nullptr, nullptr, nr, in, M, nr, in, in, 0, 0, accumulate, 0, scale, st));  // dA = s v^T x
+        CHECK(vlr_gemm_bf16_scaled(1, v, A, dx, nullptr, nullptr, M, in, nr, nr, in, in, 0, 0, 1, 0, scale, st));     // dx += s v A
+    }
+    return VLR_OK;
+}
+
+static int lora_check(const char* who, const vlr_lora_weights* lw, const void* ws_xd) {
+    VLR_REQUIRE(lw->r > 0 && lw->r % 8 == 0, "%s: LoRA rank must be a positive multiple of 8, got %d", who, lw->r);
+    VLR_REQUIRE(lw->dropout >= 0.f && lw->dropout < 1.f, "%s: lora_dropout must be in [0,1), got %g", who, (double)lw->dropout);
+    VLR_REQUIRE(lw->dropout == 0.f || ws_xd, "%s: lora_dropout > 0 needs the ws_xd scratch buffer", who);
+    VLR_REQUIRE(lw->a_qkv && lw->b_qkv && lw->a_o && lw->b_o && lw->a_gu && lw->b_gu && lw->a_down && lw->b_down, "%s: null adapter pointer", who);
+    return VLR_OK;
+}
+
+extern "C" int vlr_decoder_layer_fwd_lora(const vlr_llama_cfg* cfg, const vlr_layer_weights* w, const vlr_lora_weights* lw,
+                                          const vlr_layer_acts* a, void* u, void* ws_xd, uint64_t seed, const void* x_in,
+                                          const int* pos, const int* key_mask, int batch, int S, vlr_stream_t st) {
+    VLR_REQUIRE(cfg && w && lw && a && u && x_in && pos, "vlr_decoder_layer_fwd_lora: null argument");
+    CHECK(lora_check("vlr_decoder_layer_fwd_lora", lw, ws_xd));
+    const int H = cfg->hidden, I = cfg->inter, M = batch * S, r = lw->r, ldu = 7 * r;
+    const float sc = lw->scale, p = lw->dropout;
+    VLR_REQUIRE(cfg->heads * cfg->head_dim == H, "vlr_decoder_layer_fwd_lora: heads*head_dim != hidden");
+    CHECK(vlr_rmsnorm_fwd(x_in, w->ln1, a->xn1, a->rstd1, M, H, cfg->rms_eps, st));
+    CHECK(vlr_gemm_bf16(0, a->xn1, w->wqkv, a->qkv, nullptr, nullptr, M, 3 * H, H, H, H, 3 * H, 0, 0, 0, 0, st));
+    CHECK(lora_group_fwd(3, r, H, H, a->xn1, a->qkv, 3 * H, lw->a_qkv, lw->b_qkv, u, ldu, sc, p, seed + 0, ws_xd, M, st));
+    CHECK(vlr_rope(a->qkv, pos, cfg->rope_cos, cfg->rope_sin, M, H, cfg->head_dim, 3 * H, cfg->max_pos, 0, st));
+    CHECK(vlr_attn_fwd(a->qkv, off(a->qkv, H), off(a->qkv, 2 * (size_t)H), 3 * H, a->attn, H, a->lse, key_mask, batch, S,
+                       cfg->heads, cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));
+    CHECK(vlr_gemm_bf16(0, a->attn, w->wo, a->x_mid, nullptr, x_in, M, H, H, H, H, H, H, 0, 0, 0, st));
+    CHECK(lora_group_fwd(1, r, H, H, a->attn, a->x_mid, H, lw->a_o, lw->b_o, off(u, 3 * (size_t)r), ldu, sc, p, seed + 3, ws_xd, M, st));
+    CHECK(vlr_rmsnorm_fwd(a->x_mid, w->ln2, a->xn2, a->rstd2, M, H, cfg->rms_eps, st));
+    CHECK(vlr_gemm_bf16(0, a->xn2, w->wgu, a->gu, nullptr, nullptr, M, 2 * I, H, H, H, 2 * I, 0, 0, 0, 0, st));
+    CHECK(lora_group_fwd(2, r, H, I, a->xn2, a->gu, 2 * I, lw->a_gu, lw->b_gu, off(u, 4 * (size_t)r), ldu, sc, p, seed + 4, ws_xd, M, st));
+    CHECK(vlr_swiglu_fwd(a->gu, a->act, M, I, st));
+    CHECK(vlr_gemm_bf16(0, a->act, w->wdown, a->x_out, nullptr, a->x_mid, M, H, I, I, I, H, H, 0, 0, 0, st));
+    CHECK(lora_group_fwd(1, r, I, H, a->act, a->x_out, H, lw->a_down, lw->b_down, off(u, 6 * (size_t)r), ldu, sc, p, seed + 6, ws_xd, M, st));
+    return VLR_OK;
+}
+
+extern "C" int vlr_decoder_layer_bwd_lora(const vlr_llama_cfg* cfg, const vlr_layer_weights* w, const vlr_lora_weights* lw,
+                                          const vlr_lora_grads* lg, int accumulate, const vlr_layer_acts* a, const void* u,
+                                          const vlr_layer_bwd_ws* ws, void* ws_v, void* ws_xd, uint64_t seed, const void* x_in,
+                                          const void* dx_out, void* dx_in, const int* pos, const int* key_mask, int batch,
+                                          int S, vlr_stream_t st) {
+    VLR_REQUIRE(cfg && w && lw && lg && a && u && ws && ws_v && x_in && dx_out && dx_in && pos, "vlr_decoder_layer_bwd_lora: null argument");
+    CHECK(lora_check("vlr_decoder_layer_bwd_lora", lw, ws_xd));
+    const int H = cfg->hidden, I = cfg->inter, M = batch * S, r = lw->r, ldu = 7 * r;
+    const float sc = lw->scale, p = lw->dropout;
+    // ---- MLP
+    CHECK(vlr_gemm_bf16(1, dx_out, w->wdown, ws->dact, nullptr, nullptr, M, I, H, H, I, I, 0, 0, 0, 0, st));
+    CHECK(lora_group_bwd(1, r, I, H, a->act, dx_out, H, lw->a_down, lw->b_down, lg->a_down, lg->b_down, off(u, 6 * (size_t)r), ldu, ws_v,
+                         ws->dact, sc, p, seed + 6, ws_xd, accumulate, M, st));
+    CHECK(vlr_swiglu_bwd(a->gu, ws->dact, M, I, st));   // gu now holds [dgate | dup]
+    CHECK(vlr_gemm_bf16(1, a->gu, w->wgu, ws->dxn, nullptr, nullptr, M, H, 2 * I, 2 * I, H, H, 0, 0, 0, 0, st));
+    CHECK(lora_group_bwd(2, r, H, I, a->xn2, a->gu, 2 * I, lw->a_gu, lw->b_gu, lg->a_gu, lg->b_gu, off(u, 4 * (size_t)r), ldu, ws_v,
+                         ws->dxn, sc, p, seed + 4, ws_xd, accumulate, M, st));
+    CHECK(vlr_rmsnorm_bwd(ws->dxn, a->x_mid, w->ln2, a->rstd2, dx_out, ws->dx_mid, nullptr, 0, ws->norm_ws, M, H, st));
+    // ---- attention
+    CHECK(vlr_gemm_bf16(1, ws->dx_mid, w->wo, ws->dattn, nullptr, nullptr, M, H, H, H, H, H, 0, 0, 0, 0, st));
+    CHECK(lora_group_bwd(1, r, H, H, a->attn, ws->dx_mid, H, lw->a_o, lw->b_o, lg->a_o, lg->b_o, off(u, 3 * (size_t)r), ldu, ws_v,
+                         ws->dattn, sc, p, seed + 3, ws_xd, accumulate, M, st));
+    CHECK(vlr_attn_bwd(a->qkv, off(a->qkv, H), off(a->qkv, 2 * (size_t)H), 3 * H, a->attn, ws->dattn, H, a->lse, ws->delta,
+                       key_mask, ws->dqkv, off(ws->dqkv, H), off(ws->dqkv, 2 * (size_t)H), 3 * H, batch, S, cfg->heads,
+                       cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));
+    CHECK(vlr_rope(ws->dqkv, pos, cfg->rope_cos, cfg->rope_sin, M, H, cfg->head_dim, 3 * H, cfg->max_pos, 1, st));
+    CHECK(vlr_gemm_bf16(1, ws->dqkv, w->wqkv, ws->dxn, nullptr, nullptr, M, H, 3 * H, 3 * H, H, H, 0, 0, 0, 0, st));
+    CHECK(lora_group_bwd(3, r, H, H, a->xn1, ws->dqkv, 3 * H, lw->a_qkv, lw->b_qkv, lg->a_qkv, lg->b_qkv, u, ldu, ws_v, ws->dxn, sc, p,
+                         seed + 0, ws_xd, accumulate, M, st));
+    CHECK(vlr_rmsnorm_bwd(ws->dxn, x_in, w->ln1, a->rstd1, ws->dx_mid, dx_in, nullptr, 0, ws->norm_ws, M, H, st));
+    return VLR_OK;
+}
+
 // CLIP encoder layer (transformers CLIPEncoderLayer, pre-LN, quick_gelu; call site Llava/__init__.py:178), in place on x
 extern "C" int vlr_vit_layer_fwd(const vlr_vit_cfg* cfg, const vlr_vit_layer_weights* w, const vlr_vit_ws* ws,
                                  void* x, int n_img, int T, vlr_stream_t st) {

@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "libvlr_hip.so")
 
 _lib = None
 
-P, I, L, F = C.c_void_p, C.c_int, C.c_long, C.c_float
+P, I, L, F, U64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint64
 
 
 class LlamaCfg(C.Structure):
@@ -34,6 +34,14 @@ class LayerBwdWs(C.Structure):
     _fields_ = [(n, P) for n in ("dact", "dxn", "dattn", "dqkv", "dx_mid", "delta", "norm_ws")]
 
 
+class LoraWeights(C.Structure):
+    _fields_ = [("r", I), ("scale", F), ("dropout", F)] + [(n, P) for n in ("a_qkv", "b_qkv", "a_o", "b_o", "a_gu", "b_gu", "a_down", "b_down")]
+
+
+class LoraGrads(C.Structure):
+    _fields_ = [(n, P) for n in ("a_qkv", "b_qkv", "a_o", "b_o", "a_gu", "b_gu", "a_down", "b_down")]
+
+
 class VitCfg(C.Structure):
     _fields_ = [("hidden", I), ("mlp", I), ("heads", I), ("head_dim", I), ("ln_eps", F)]
 
@@ -49,6 +57,7 @@ class VitWs(C.Structure):
 # name -> argtypes (every function returns int status, except the *_bytes helpers and vlr_last_error)
 _SIGS = {
     "vlr_gemm_bf16": [I, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "vlr_gemm_bf16_scaled": [I, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, F, P],
     "vlr_rmsnorm_fwd": [P, P, P, P, I, I, F, P],
     "vlr_rmsnorm_bwd": [P, P, P, P, P, P, P, I, P, I, I, P],
     "vlr_layernorm_fwd": [P, P, P, P, I, I, F, P],
@@ -82,6 +91,10 @@ _SIGS = {
     "vlr_decoder_layer_fwd": [P, P, P, P, P, P, I, I, P],
     "vlr_decoder_layer_bwd": [P, P, P, I, P, P, P, P, P, P, P, I, I, P],
     "vlr_vit_layer_fwd": [P, P, P, P, I, I, P],
+    "vlr_decoder_layer_fwd_lora": [P, P, P, P, P, P, U64, P, P, P, I, I, P],
+    "vlr_decoder_layer_bwd_lora": [P, P, P, P, I, P, P, P, P, P, U64, P, P, P, P, P, I, I, P],
+    "vlr_dropout": [P, P, L, F, U64, F, I, P],
+    "vlr_dropout_mask": [P, L, F, U64, P],
     "vlr_layers_join": [P],
 }
 _INT_HELPERS = {

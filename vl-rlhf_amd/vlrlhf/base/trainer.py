@@ -7,6 +7,7 @@ Same names, argument order and error behaviour; the arithmetic (model forward/ba
 runs in libvlr_hip.so through `vlrlhf.engine` - there is no PyTorch/CPU fallback.  What is deliberately NOT
 reproduced: the per-micro-step `torch.cuda.empty_cache(); gc.collect()` (reference :306-307), ZeRO/DeepSpeed, wandb.
 """
+import contextlib
 import math
 import random
 from collections import defaultdict
@@ -134,10 +135,15 @@ class VLDPOTrainer:
         reference_free: bool = False,
     ):
         # argument order = reference base/trainer.py:34-68 (MyAutoDPOTrainer passes them positionally)
-        if peft_config is not None:
-            raise NotImplementedError("LoRA/PEFT is the next row of SURVEY.md 8(f); this round implements full fine-tuning")
         if model is None:
             raise ValueError("VLDPOTrainer needs a model")
+        if peft_config is not None:
+            # trl==0.8.1 DPOTrainer.__init__: model = get_peft_model(model, peft_config); with a peft policy and no
+            # ref_model the reference pass runs the policy with its adapters disabled (null_ref_context)
+            if not hasattr(model, "apply_lora"):
+                raise ValueError("peft_config given but the model wrapper has no apply_lora()")
+            model.apply_lora(peft_config)
+        self.is_peft_model = bool(getattr(model, "is_peft_model", False))
         self.processor = processor
         self.tokenizer = processor.tokenizer if processor is not None else None
         self.model = model
@@ -166,7 +172,7 @@ class VLDPOTrainer:
         self.log_history: List[dict] = []
         self.accelerator = _Accelerator(model)
         # trl: ref_model None and no peft -> frozen deep copy of the policy
-        if ref_model is None and not reference_free and not precompute_ref_log_probs:
+        if ref_model is None and not reference_free and not precompute_ref_log_probs and not self.is_peft_model:
             ref_model = model.create_reference_model() if hasattr(model, "create_reference_model") else None
         self.ref_model = ref_model
         self.data_collator = data_collator
@@ -363,20 +369,29 @@ class VLDPOTrainer:
             dev = self.accelerator.device
             return batch["reference_chosen_logps"].to(dev).float(), batch["reference_rejected_logps"].to(dev).float()
         if self.ref_model is None:
-            raise ValueError("no reference model and no precomputed reference log-probs in the batch")
+            if not self.is_peft_model:
+                raise ValueError("no reference model and no precomputed reference log-probs in the batch")
+            with torch.no_grad(), self.null_ref_context():
+                rc, rr, _, _ = self.concatenated_forward(self.model, batch)
+            return rc, rr
         with torch.no_grad():
             rc, rr, _, _ = self.concatenated_forward(self.ref_model, batch)
         return rc, rr
+
+    def null_ref_context(self):
+        """trl==0.8.1 DPOTrainer.null_ref_context: the peft policy with its adapters disabled is the reference model."""
+        return self.model.disable_adapter() if self.is_peft_model else contextlib.nullcontext()
 
     def get_batch_loss_metrics(self, model, batch, train_eval: Literal["train", "eval"] = "train"):
         """trl==0.8.1 DPOTrainer.get_batch_loss_metrics.  The reference forward is issued on a side HIP stream ahead of
         the policy forward (it is frozen and shares only the cached vision features), then joined before the loss."""
         main = torch.cuda.current_stream()
-        use_side = (self.ref_on_side_stream and self.ref_model is not None and "reference_chosen_logps" not in batch)
+        ref_owner = self.ref_model if self.ref_model is not None else (self.model if self.is_peft_model else None)
+        use_side = (self.ref_on_side_stream and ref_owner is not None and "reference_chosen_logps" not in batch)
         if use_side:
             cb = self.concatenated_inputs(batch, False, self.label_pad_token_id, self.padding_value, self.accelerator.device)
-            if "concatenated_img_input_dict" in cb and hasattr(self.ref_model, "prefetch_vision"):
-                self.ref_model.prefetch_vision(cb["concatenated_img_input_dict"])
+            if "concatenated_img_input_dict" in cb and hasattr(ref_owner, "prefetch_vision"):
+                ref_owner.prefetch_vision(cb["concatenated_img_input_dict"])
             if self._ref_stream is None:
                 self._ref_stream = torch.cuda.Stream()
             self._ref_stream.wait_stream(main)

@@ -102,7 +102,7 @@ def main():
     training_args.local_rank = local
     model, ref_model, lora_config = auto_load_rlmodel(script_args, training_args, lora_args)
     if world > 1:
-        model.engine.reducer = GradReducer(model.engine.grads, model.engine.layout.bucket_after)
+        model.engine.make_reducer()
     processor = MyAutoProcessor.from_pretrained(script_args.model_name_or_path)
     processor.train()
     dataset = DATASET_MAP[script_args.dataset_name](script_args)

@@ -77,6 +77,47 @@ class ParamLayout:
                 yield hf, name, r0, rows
 
 
+LORA_KEYS = ("a_qkv", "b_qkv", "a_o", "b_o", "a_gu", "b_gu", "a_down", "b_down")
+# (group, peft module path, sub-target names in stacking order)
+LORA_GROUPS = (("qkv", "self_attn", ("q_proj", "k_proj", "v_proj")), ("o", "self_attn", ("o_proj",)),
+               ("gu", "mlp", ("gate_proj", "up_proj")), ("down", "mlp", ("down_proj",)))
+LORA_TARGETS = tuple(t for _, _, ts in LORA_GROUPS for t in ts)
+
+
+class LoraLayout:
+    """Flat bf16 layout of the peft adapters on the seven decoder linears (LlavaForRL.default_lora_target,
+    /root/reference src/vlrlhf/models/Llava/__init__.py:273-286).  Per layer: a_qkv [3r,H] | b_qkv [3H,r] | a_o [r,H] |
+    b_o [H,r] | a_gu [2r,H] | b_gu [2I,r] | a_down [r,I] | b_down [H,r]; sub-targets of a fused group are stacked rows,
+    matching vlr_lora_weights (include/vlr.h)."""
+
+    def __init__(self, cfg, r):
+        H, I, L = cfg["hidden"], cfg["inter"], cfg["layers"]
+        self.r, self.L = r, L
+        per = dict(a_qkv=(3 * r, H), b_qkv=(3 * H, r), a_o=(r, H), b_o=(H, r), a_gu=(2 * r, H), b_gu=(2 * I, r),
+                   a_down=(r, I), b_down=(H, r))
+        self.offset, self.shape = {}, {}
+        o = 0
+        for l in range(L):
+            for k in LORA_KEYS:
+                self.offset[f"l{l}.{k}"] = o
+                self.shape[f"l{l}.{k}"] = per[k]
+                o += _align(per[k][0] * per[k][1])
+        self.numel = o
+        self.out_dim = dict(q_proj=H, k_proj=H, v_proj=H, o_proj=H, gate_proj=I, up_proj=I, down_proj=H)
+
+    def hf_names(self, prefix="base_model.model.language_model.model.layers."):
+        """peft adapter-file name -> (flat key, row_lo, row_hi)"""
+        out = {}
+        r = self.r
+        for l in range(self.L):
+            for g, mod, ts in LORA_GROUPS:
+                for i, t in enumerate(ts):
+                    od = self.out_dim[t]
+                    out[f"{prefix}{l}.{mod}.{t}.lora_A.weight"] = (f"l{l}.a_{g}", i * r, (i + 1) * r)
+                    out[f"{prefix}{l}.{mod}.{t}.lora_B.weight"] = (f"l{l}.b_{g}", i * od, (i + 1) * od)
+        return out
+
+
 class WeightSet:
     """One set of LLM + projector weights in a flat bf16 buffer, with named 2-D views."""
 
@@ -181,6 +222,9 @@ class LlavaHipEngine:
         self._ws = {}
         self._vit_cache = None
         self.reducer = None                      # parallel.GradReducer for DDP
+        self.lora = None                         # dict(r, scale, dropout) once enable_lora() ran
+        self.lora_active = True                  # False inside LlavaForRL.disable_adapter() (reference pass)
+        self.training = True                     # lora_dropout only in training mode
         self._norm_ws = torch.empty(_hip.helper("vlr_rmsnorm_bwd_workspace_bytes", self.H), dtype=torch.uint8, device=self.dev)
         self._colsum_ws = torch.empty(_hip.helper("vlr_colsum_workspace_bytes", max(self.H, 8)), dtype=torch.uint8, device=self.dev)
         self._sq_ws = torch.empty(_hip.helper("vlr_grad_sqnorm_workspace_bytes"), dtype=torch.uint8, device=self.dev)
@@ -200,6 +244,78 @@ class LlavaHipEngine:
 
     def layer_grads(self, l):
         return _hip.LayerGrads(*(self.gv[f"l{l}.{k}"].data_ptr() for k in ("ln1", "wqkv", "wo", "ln2", "wgu", "wdown")))
+
+    # ------------------------------------------------------------------------------------------------ LoRA
+    def enable_lora(self, r: int, alpha: float, dropout: float = 0.0, seed: int = 0):
+        """peft get_peft_model(LoraConfig(r, lora_alpha, lora_dropout, target_modules=default_lora_target, bias='none')):
+        base weights frozen, A ~ kaiming_uniform(a=sqrt(5)) = U(-1/sqrt(in), 1/sqrt(in)), B = 0.  From here on the only
+        trainable parameters (gradients, optimizer state, DDP bucket) are the adapters."""
+        if r <= 0 or r % 8:
+            raise ValueError(f"lora_r must be a positive multiple of 8 for the gfx950 GEMM tiles, got {r}")
+        if not 0.0 <= dropout < 1.0:
+            raise ValueError(f"lora_dropout must be in [0, 1), got {dropout}")
+        self.lora = dict(r=int(r), scale=float(alpha) / r, dropout=float(dropout), alpha=float(alpha))
+        self.lora_layout = LoraLayout(self.cfg, r)
+        n = self.lora_layout.numel
+        self.lora_flat = torch.zeros(n, dtype=BF16, device=self.dev)
+        self.lora_grads = torch.zeros(n, dtype=BF16, device=self.dev)
+        view = lambda flat: {k: flat[o: o + int(math.prod(self.lora_layout.shape[k]))].view(*self.lora_layout.shape[k])
+                             for k, o in self.lora_layout.offset.items()}
+        self.lv, self.lgv = view(self.lora_flat), view(self.lora_grads)
+        gen = torch.Generator(device=self.dev)
+        gen.manual_seed(seed)
+        for k, t in self.lv.items():
+            if ".a_" in k:
+                bound = 1.0 / math.sqrt(t.shape[1])
+                t.copy_((torch.rand(t.shape, generator=gen, device=self.dev) * 2 - 1) * bound)
+        self.lora_seed = int(seed)
+        self._lora_calls = 0
+        self.grads = None                         # full-parameter gradient / optimizer buffers are not needed any more
+        self.gv = None
+        self.master = self.m = self.v = None
+        self.opt_step = 0
+        self.grad_fresh = True
+
+    def lora_state_dict(self):
+        """adapter tensors under their peft adapter-file names (adapter_model.safetensors layout)"""
+        return {n: self.lv[k][lo:hi].clone() for n, (k, lo, hi) in self.lora_layout.hf_names().items()}
+
+    def load_lora_state_dict(self, sd):
+        names = self.lora_layout.hf_names()
+        norm = {k.replace(".default.weight", ".weight"): v for k, v in sd.items()}
+        missing = [n for n in names if n not in norm]
+        if missing:
+            raise KeyError(f"missing LoRA tensors: {missing[:4]}{'...' if len(missing) > 4 else ''}")
+        for n, (k, lo, hi) in names.items():
+            t = norm[n]
+            if tuple(t.shape) != tuple(self.lv[k][lo:hi].shape):
+                raise ValueError(f"shape mismatch for {n}: {tuple(t.shape)} vs {tuple(self.lv[k][lo:hi].shape)}")
+            self.lv[k][lo:hi].copy_(t)
+        if self.master is not None:
+            self.init_optimizer()
+
+    def _lora_structs(self, l, train):
+        lo = self.lora
+        p = lo["dropout"] if (train and self.training) else 0.0
+        w = _hip.LoraWeights(lo["r"], lo["scale"], p, *(self.lv[f"l{l}.{k}"].data_ptr() for k in LORA_KEYS))
+        g = _hip.LoraGrads(*(self.lgv[f"l{l}.{k}"].data_ptr() for k in LORA_KEYS))
+        return w, g
+
+    def merged_weights(self) -> WeightSet:
+        """W + (alpha/r) B A for every adapted linear (peft merge_and_unload): a new WeightSet for export / inference."""
+        ws = self.policy.clone()
+        r, sc = self.lora["r"], self.lora["scale"]
+        for l in range(self.L):
+            for g in ("qkv", "o", "gu", "down"):
+                W = ws.v[f"l{l}.w{g}"]
+                A, B = self.lv[f"l{l}.a_{g}"], self.lv[f"l{l}.b_{g}"]
+                n = A.shape[0] // r
+                out, inn = W.shape[0] // n, W.shape[1]
+                for t in range(n):
+                    Wt = W[t * out:(t + 1) * out]
+                    _hip.call("vlr_gemm_bf16_scaled", 1, B[t * out:(t + 1) * out], A[t * r:(t + 1) * r], Wt, None, Wt,
+                              out, inn, r, r, inn, inn, inn, 0, 0, 0, sc)
+        return ws
 
     # ------------------------------------------------------------------------------------------------ workspaces
     def _buf(self, key, shape, dtype=BF16, zero=False):
@@ -312,9 +428,23 @@ class LlavaHipEngine:
         _hip.call("vlr_merge_fwd", src, ids, ws.v["embed"], feats, x0, Bn, T, S, self.H)
         x = x0
         acts = []
+        use_lora = self.lora is not None and self.lora_active and ws is self.policy
+        lora_seed = None
+        if use_lora:
+            r = self.lora["r"]
+            self._lora_calls += 1
+            lora_seed = (self.lora_seed << 40) + (self._lora_calls << 16)        # + 8*layer + target inside the library
+            xd = self._buf(("lora_xd", M), (M, max(self.H, self.I))) if (self.lora["dropout"] > 0 and self.training) else None
         for l in range(self.L):
             a = self._layer_acts(tag if save else "scratch", l if save else (l % 2), Bn, S)
-            _hip.call("vlr_decoder_layer_fwd", self.llama_cfg, self.layer_weights(ws, l), a["struct"], x, pos, mask, Bn, S)
+            if use_lora:
+                if "u" not in a or a["u"].shape[1] != 7 * r:
+                    a["u"] = torch.empty(M, 7 * r, dtype=BF16, device=self.dev)
+                lw, _ = self._lora_structs(l, train=True)
+                _hip.call("vlr_decoder_layer_fwd_lora", self.llama_cfg, self.layer_weights(ws, l), lw, a["struct"], a["u"], xd,
+                          lora_seed + 8 * l, x, pos, mask, Bn, S)
+            else:
+                _hip.call("vlr_decoder_layer_fwd", self.llama_cfg, self.layer_weights(ws, l), a["struct"], x, pos, mask, Bn, S)
             acts.append(a)
             x = a["x_out"]
         hidden = torch.empty(M, self.H, dtype=BF16, device=self.dev)
@@ -322,7 +452,8 @@ class LlavaHipEngine:
         _hip.call("vlr_rmsnorm_fwd", x, ws.v["norm"], hidden, rstd_f, M, self.H, self.llama_cfg.rms_eps)
         return dict(ws=ws, Bn=Bn, T=T, S=S, M=M, ids=ids, src=src, inv=inv, mask=mask, labels=mlabels, pos=pos,
                     img_map=img_map.bool(), hidden=hidden, rstd_f=rstd_f, x_last=x, x0=x0, acts=acts if save else None,
-                    vit_feat=vit_feat, feats=feats, proj_z=z, proj_h=h, image_dup=image_dup, n_rows=n_rows, tag=tag)
+                    vit_feat=vit_feat, feats=feats, proj_z=z, proj_h=h, image_dup=image_dup, n_rows=n_rows, tag=tag,
+                    lora_seed=lora_seed)
 
     # ------------------------------------------------------------------------------------------------ log-probs
     def logps_forward(self, ctx, labels, shared_mask=None, average=False, label_pad=-100):
@@ -387,7 +518,7 @@ class LlavaHipEngine:
         acc = int(not self.grad_fresh)
         dhidden = torch.zeros(M, H, dtype=BF16, device=self.dev)
         if R == 0:
-            if not acc:
+            if not acc and self.lora is None:
                 self.gv["lm_head"].zero_()
             return dhidden
         logits = self._buf(("logits", R), (R, V), torch.float32)
@@ -398,9 +529,10 @@ class LlavaHipEngine:
                   dlogps.to(torch.float32).contiguous(), int(lp["average"]), R, V, V, dl, V)
         dhg = torch.empty(R, H, dtype=BF16, device=self.dev)
         _hip.call("vlr_gemm_bf16", 1, dl, ctx["ws"].v["lm_head"], dhg, None, None, R, H, V, V, H, H, 0, 0, 0, 0)
-        _hip.call("vlr_gemm_bf16", 2, dl, lp["hg"], self.gv["lm_head"], None, None, V, H, R, V, H, H, 0, 0, acc, 0)
+        if self.lora is None:                 # under LoRA the lm_head is frozen (not a target module)
+            _hip.call("vlr_gemm_bf16", 2, dl, lp["hg"], self.gv["lm_head"], None, None, V, H, R, V, H, H, 0, 0, acc, 0)
         _hip.call("vlr_scatter_rows", dhg, lp["rows"], dhidden, R, H)
-        if self.reducer is not None:
+        if self.reducer is not None and self.lora is None:
             self.reducer.bucket_ready("lm_head")
         return dhidden
 
@@ -414,6 +546,8 @@ class LlavaHipEngine:
         Sp = _align(S, 64)
         dxa = self._buf(("dxa", M), (M, H))
         dxb = self._buf(("dxb", M), (M, H))
+        if self.lora is not None:
+            return self._hidden_backward_lora(ctx, dhidden, dxa, dxb)
         _hip.call("vlr_rmsnorm_bwd", dhidden, ctx["x_last"], ws.v["norm"], ctx["rstd_f"], None, dxa, self.gv["norm"], acc,
                   self._norm_ws, M, H)
         wsb = dict(dact=self._buf(("dact", M), (M, I)), dxn=self._buf(("dxn", M), (M, H)), dattn=self._buf(("dattn", M), (M, H)),
@@ -451,11 +585,51 @@ class LlavaHipEngine:
         if self.reducer is not None:
             self.reducer.bucket_ready("tail")
 
+    def _hidden_backward_lora(self, ctx, dhidden, dxa, dxb):
+        """LoRA backward: data gradients through the frozen decoder + adapter gradients only; nothing below the first
+        decoder layer is trainable (embedding, projector and vision tower are not target modules), so it stops there."""
+        if ctx.get("lora_seed") is None:
+            raise RuntimeError("backward through a pass that ran with the adapters disabled")
+        ws = ctx["ws"]
+        Bn, S, M, H, I = ctx["Bn"], ctx["S"], ctx["M"], self.H, self.I
+        acc = int(not self.grad_fresh)
+        Sp = _align(S, 64)
+        r = self.lora["r"]
+        _hip.call("vlr_rmsnorm_bwd", dhidden, ctx["x_last"], ws.v["norm"], ctx["rstd_f"], None, dxa, None, 0, self._norm_ws, M, H)
+        wsb = dict(dact=self._buf(("dact", M), (M, I)), dxn=self._buf(("dxn", M), (M, H)), dattn=self._buf(("dattn", M), (M, H)),
+                   dqkv=self._buf(("dqkv", M), (M, 3 * H)), dx_mid=self._buf(("dx_mid", M), (M, H)),
+                   delta=self._buf(("delta", Bn, S), (Bn, self.nh, Sp), torch.float32))
+        lws = _hip.LayerBwdWs(wsb["dact"].data_ptr(), wsb["dxn"].data_ptr(), wsb["dattn"].data_ptr(), wsb["dqkv"].data_ptr(),
+                              wsb["dx_mid"].data_ptr(), wsb["delta"].data_ptr(), self._norm_ws.data_ptr())
+        ws_v = self._buf(("lora_v", M), (M, 3 * r))
+        xd = self._buf(("lora_xd", M), (M, max(H, I))) if (self.lora["dropout"] > 0 and self.training) else None
+        cur, nxt = dxa, dxb
+        for l in range(self.L - 1, -1, -1):
+            a = ctx["acts"][l]
+            x_in = ctx["acts"][l - 1]["x_out"] if l > 0 else ctx["x0"]
+            lw, lg = self._lora_structs(l, train=True)
+            _hip.call("vlr_decoder_layer_bwd_lora", self.llama_cfg, self.layer_weights(ws, l), lw, lg, acc, a["struct"], a["u"],
+                      lws, ws_v, xd, ctx["lora_seed"] + 8 * l, x_in, cur, nxt, ctx["pos"], ctx["mask"], Bn, S)
+            cur, nxt = nxt, cur
+        self.grad_fresh = False
+        if self.reducer is not None:
+            self.reducer.bucket_ready("lora")
+
+    def make_reducer(self, group=None):
+        """DDP gradient reducer over the trainable flat gradient buffer (full fine-tuning: one bucket per decoder layer in
+        backward order; LoRA: the adapters are small, one bucket when the backward is done)."""
+        from .parallel import GradReducer
+        if self.lora is not None:
+            self.reducer = GradReducer(self.lora_grads, {"lora": (0, self.lora_layout.numel)}, group=group)
+        else:
+            self.reducer = GradReducer(self.grads, self.layout.bucket_after, group=group)
+        return self.reducer
+
     # ------------------------------------------------------------------------------------------------ optimizer
     def init_optimizer(self):
         """fp32 master copy + Adam moments for the flat parameter buffer (28 B of HBM traffic per parameter and step).
         The reference leaves the precision policy to DeepSpeed/DDP; fp32 master + fp32 moments is the documented choice."""
-        self.master = self.policy.flat.float()
+        self.master = (self.lora_flat if self.lora is not None else self.policy.flat).float()
         self.m = torch.zeros_like(self.master)
         self.v = torch.zeros_like(self.master)
         self.opt_step = 0
@@ -471,6 +645,16 @@ class LlavaHipEngine:
             self.init_optimizer()
         if self.reducer is not None:
             self.reducer.wait()
+        if self.lora is not None:
+            # HF's decay grouping puts every lora_A / lora_B weight in the decay group.
+            n = self.lora_layout.numel
+            _hip.call("vlr_grad_sqnorm", self.lora_grads, n, float(max_grad_norm if max_grad_norm else 0.0),
+                      float(grad_scale), 0.0, self._sq_ws, self.norm_out)
+            self.opt_step += 1
+            _hip.call("vlr_adamw_step", self.master, self.m, self.v, self.lora_grads, self.lora_flat, n, float(lr),
+                      float(beta1), float(beta2), float(eps), float(weight_decay), self.opt_step, self.norm_out)
+            self.grad_fresh = True
+            return self.norm_out
         n = self.layout.numel
         _hip.call("vlr_grad_sqnorm", self.grads, n, float(max_grad_norm if max_grad_norm else 0.0), float(grad_scale), 0.0,
                   self._sq_ws, self.norm_out)

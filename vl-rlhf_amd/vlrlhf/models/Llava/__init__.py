@@ -3,6 +3,7 @@
 LlavaDPOTrainer :474, core_mapper :486-499).  `LlavaForRL.forward` keeps the reference call signature and output
 fields; underneath it runs vlrlhf.engine (HIP kernels) and returns a LAZY logits handle so the [2B,S,V] fp32 tensor is
 never written to HBM unless a caller asks for it."""
+import contextlib
 import json
 import os
 from dataclasses import dataclass
@@ -196,6 +197,68 @@ class LlavaForRL(nn.Module):
             sd.update(load_file(os.path.join(path, fn)))
         m.engine.load_state_dict(sd)
         return m
+
+    # ---- LoRA (peft) ---------------------------------------------------------------------------------------
+    def apply_lora(self, peft_config):
+        """peft.get_peft_model(self, LoraConfig(...)) as the reference's trainer applies it (trl DPOTrainer.__init__ with
+        peft_config from utils/auto_load.py:559-571): freezes the base weights, adds adapters on default_lora_target,
+        and leaves only lora_A / lora_B trainable.  `peft_config` is a LoraConfig-like object or a dict."""
+        get = (lambda k, d=None: peft_config.get(k, d)) if isinstance(peft_config, dict) else (lambda k, d=None: getattr(peft_config, k, d))
+        targets = get("target_modules")
+        if targets in (None, "auto"):
+            targets = self.default_lora_target
+        if isinstance(targets, str):
+            targets = targets.split(",")
+        if sorted(targets) != sorted(self.default_lora_target):
+            raise NotImplementedError(f"LoRA target_modules {sorted(targets)}: the MI355X path adapts exactly the decoder "
+                                      f"linears {self.default_lora_target} (LlavaForRL.default_lora_target)")
+        if get("bias", "none") != "none":
+            raise NotImplementedError("lora_bias other than 'none' is not supported on the MI355X path")
+        if get("modules_to_save"):
+            raise NotImplementedError("modules_to_save is not supported on the MI355X path")
+        if not self._trainable:
+            raise ValueError("apply_lora needs the trainable policy model")
+        self.engine.enable_lora(int(get("r", 64)), float(get("lora_alpha", 16)), float(get("lora_dropout", 0.0) or 0.0),
+                                seed=int(get("seed", 0) or 0))
+        self.engine.training = self.training
+        self._params = nn.ParameterDict()
+        self._hf_names = {}
+        names = self.engine.lora_layout.hf_names()
+        for i, (hf, (k, lo, hi)) in enumerate(names.items()):
+            p = nn.Parameter(self.engine.lv[k][lo:hi], requires_grad=True)
+            p.grad = self.engine.lgv[k][lo:hi]
+            self._params[f"p{i}"] = p
+            self._hf_names[f"_params.p{i}"] = hf.replace(".weight", ".default.weight")
+        self.peft_config = {"default": peft_config}
+        return self
+
+    @property
+    def is_peft_model(self):
+        return self.engine.lora is not None and self._trainable
+
+    @contextlib.contextmanager
+    def disable_adapter(self):
+        """peft PeftModel.disable_adapter(): inside, forwards use the frozen base weights only - trl's null_ref_context
+        turns the policy into its own reference model this way."""
+        prev = self.engine.lora_active
+        self.engine.lora_active = False
+        try:
+            yield
+        finally:
+            self.engine.lora_active = prev
+
+    def lora_state_dict(self):
+        return self.engine.lora_state_dict()
+
+    def merge_and_unload(self):
+        """state dict of the base model with the adapters folded in (peft merge_and_unload)"""
+        return self.engine.merged_weights().state_dict()
+
+    def train(self, mode: bool = True):
+        super().train(mode)
+        if self._trainable:
+            self.engine.training = bool(mode)     # lora_dropout is active in training mode only
+        return self
 
     def create_reference_model(self):
         """trl.create_reference_model: a frozen deep copy of the policy weights sharing the engine (and the frozen ViT)."""
