@@ -81,11 +81,12 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_side_stream", action="store_true")
     ap.add_argument("--precomputed_ref", action="store_true", help="stream precomputed reference log-probs (SURVEY 8f rank 1)")
+    ap.add_argument("--lora", action="store_true", help="variant: LoRA DPO of scripts/ddpo_llava.sh (r=128, alpha=256, dropout 0.05)")
     a = ap.parse_args()
 
     from vlrlhf import _hip
     from vlrlhf.models.Llava import LlavaDPOTrainer, LlavaForRL
-    from vlrlhf.parallel import GradReducer, init_distributed_from_env
+    from vlrlhf.parallel import init_distributed_from_env
     from vlrlhf.utils.synthetic import LLAVA_1_5_7B, init_random_model, synthetic_batch
     from types import SimpleNamespace
 
@@ -98,12 +99,20 @@ def main():
     model = LlavaForRL(cfg)
     ref = init_random_model(model, seed=0, std=0.02, policy_delta=1e-3)
     eng = model.engine
+    args = SimpleNamespace(gradient_accumulation_steps=1)
+    if a.lora:
+        del ref
+        tr = LlavaDPOTrainer(model, None, 0.1, 0, "sigmoid", args, None, -100, 0,
+                             peft_config=dict(r=128, lora_alpha=256, lora_dropout=0.05, target_modules="auto", bias="none", seed=rank))
+        for k, t_ in eng.lv.items():             # peft initialises B = 0; random B so the adapter GEMMs do real arithmetic
+            if ".b_" in k:
+                t_.normal_(0.0, 1e-3)
+    else:
+        tr = LlavaDPOTrainer(model, None if a.precomputed_ref else ref, 0.1, 0, "sigmoid", args, None, -100, 0,
+                             precompute_ref_log_probs=a.precomputed_ref)
     eng.init_optimizer()
     if world > 1:
         eng.make_reducer()
-    args = SimpleNamespace(gradient_accumulation_steps=1)
-    tr = LlavaDPOTrainer(model, None if a.precomputed_ref else ref, 0.1, 0, "sigmoid", args, None, -100, 0,
-                         precompute_ref_log_probs=a.precomputed_ref)
     tr.ref_on_side_stream = not a.no_side_stream
     batch = synthetic_batch(a.pairs, a.text_len, cfg["image_token"], 32000, cfg["image_size"], seed=1234 + rank)
     batch = tr._prepare_inputs(batch)                      # inputs resident in HBM before the timed region
@@ -179,6 +188,11 @@ def main():
         }
         if a.layers:
             line["INVALID"] = "reduced layer count (debug run)"
+        if a.lora:
+            line["config"]["workload"] = line["config"]["workload"].replace(
+                "full fine-tune of LLM+projector", "LoRA r=128 alpha=256 dropout=0.05 on the 7 decoder linears (scripts/ddpo_llava.sh), frozen base")
+            line["config"]["variant"] = "lora (not the headline configuration)"
+            line["roofline"]["step_frac"] = None
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

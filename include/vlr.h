@@ -43,6 +43,10 @@ int vlr_gemm_bf16(int layout, const void* A, const void* B, void* C, const void*
 int vlr_gemm_bf16_scaled(int layout, const void* A, const void* B, void* C, const void* bias, const void* residual, int M,
                          int N, int K, int lda, int ldb, int ldc, int ldr, int act, int accumulate, int out_f32,
                          float alpha, vlr_stream_t stream);
+/* Optional fp32 scratch for split-K (TN layout only: few output tiles, reduction over all tokens - the LoRA adapter
+ * gradients).  Without it such problems run un-split.  The buffer is shared by every split-K launch of the process, so
+ * TN GEMMs must stay on ONE stream while it is registered (the backward is single-stream).  (NULL, 0) unregisters. */
+int vlr_gemm_set_splitk_workspace(void* workspace, long bytes);
 
 /* ---- normalisation / activations (transformers LlamaRMSNorm, CLIP LayerNorm, SwiGLU, GELU; call sites
  *      Llava/__init__.py:178-191,232) ------------------------------------------------------------------------- */

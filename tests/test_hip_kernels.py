@@ -618,3 +618,32 @@ def test_decoder_layer_fwd_bwd_vs_oracle(hip):
     check(grads["wdown"].cpu(), leaves[p + "mlp.down_proj.weight"].grad, 4e-2, "dWdown")
     check(grads["ln1"].cpu(), leaves[p + "input_layernorm.weight"].grad, 4e-2, "dln1")
     check(grads["ln2"].cpu(), leaves[p + "post_attention_layernorm.weight"].grad, 4e-2, "dln2")
+
+
+@pytest.mark.parametrize("shape", [(4096, 128, 12792), (384, 4096, 12792), (128, 11008, 6000), (256, 64, 2048)])
+def test_gemm_tn_split_k(hip, shape):
+    """weight-gradient-shaped skinny problems (LoRA dB / dA): few output tiles, reduction over all tokens -> split-K."""
+    M, N, K = shape
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    assert hip.helper("vlr_gemm_set_splitk_workspace", ws.data_ptr(), ws.numel()) == 0
+    try:
+        a = rnd(K, M, seed=1, scale=0.5)          # TN: A stored [K][M], B stored [K][N]
+        b = rnd(K, N, seed=2, scale=0.5)
+        ref = a.float().t() @ b.float()
+        c = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        hip.call("vlr_gemm_bf16", 2, a, b, c, None, None, M, N, K, M, N, N, 0, 0, 0, 0)
+        check(c, ref, 8e-3, f"split-K {shape}")
+        c0 = rnd(M, N, seed=3)
+        c1 = c0.clone()
+        hip.call("vlr_gemm_bf16_scaled", 2, a, b, c1, None, None, M, N, K, M, N, N, 0, 0, 1, 0, 0.25)
+        check(c1, c0.float() + 0.25 * ref, 8e-3, f"split-K accumulate+alpha {shape}")
+        cf = torch.empty(M, N, dtype=torch.float32, device=DEV)
+        hip.call("vlr_gemm_bf16", 2, a, b, cf, None, None, M, N, K, M, N, N, 0, 0, 0, 1)
+        check(cf, ref, 2e-3, f"split-K fp32 out {shape}")
+        # the un-split kernel gives the same answer
+        assert hip.helper("vlr_gemm_set_splitk_workspace", None, 0) == 0
+        c2 = torch.empty_like(c)
+        hip.call("vlr_gemm_bf16", 2, a, b, c2, None, None, M, N, K, M, N, N, 0, 0, 0, 0)
+        check(c2, c, 4e-3, "split vs un-split")
+    finally:
+        hip.helper("vlr_gemm_set_splitk_workspace", None, 0)

@@ -17,6 +17,9 @@ struct GemmParams {
     int out_f32;
     int flags;       // tuning experiments (VLR_GEMM_FLAGS), 0 in production
     float alpha;     // v = act(alpha * acc + bias) + residual (+ C)
+    int splitk;      // > 1: blockIdx.y = K-slice z of kchunk elements, raw alpha*acc -> part[z][M][N] fp32 (128x128 kernel only)
+    int kchunk;
+    float* part;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -28,3 +31,5 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 // 256x256-tile kernel (gemm256.hip); returns false when the problem does not qualify (caller falls back to 128x128)
 bool vlr_gemm256_try_launch(int layout, const GemmParams& p, hipStream_t stream);
+// 256x256 tile, eight-phase schedule (gemm256p.hip); tried first by vlr_gemm256_try_launch
+bool vlr_gemm256p_try_launch(int layout, const GemmParams& p, hipStream_t stream);

@@ -78,6 +78,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    if (p.splitk > 1) {   // split-K slice: this workgroup reduces k in [z*kchunk, (z+1)*kchunk) into its own fp32 partial
+        const int z = blockIdx.y, k0 = z * p.kchunk;
+        p.A += A_KS ? (size_t)k0 * p.lda : (size_t)k0;
+        p.B += B_KS ? (size_t)k0 * p.ldb : (size_t)k0;
+        p.K = min(p.kchunk, p.K - k0);
+        p.C = p.part + (size_t)z * p.M * p.N;
+        p.ldc = p.N; p.out_f32 = 1; p.bias = nullptr; p.residual = nullptr; p.accumulate = 0; p.act = 0;
+    }
 
     // ---- XCD-aware, grouped tile map (bijective for any tile count)
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
@@ -244,6 +252,44 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// split-K epilogue: C = sum_z part[z] (+ C), 4 columns per thread
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, int M, int N, void* Cv,
+                                                            int ldc, int out_f32, int accumulate) {
+    const long n4 = (long)M * N / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(part + i * 4);
+        for (int z = 1; z < splits; ++z) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(part + (size_t)z * M * N + i * 4);
+            v += w;
+        }
+        const long m = (i * 4) / N, n = (i * 4) % N;
+        if (out_f32) {
+            float* dst = reinterpret_cast<float*>(Cv) + m * ldc + n;
+            if (accumulate) v += *reinterpret_cast<const f32x4*>(dst);
+            *reinterpret_cast<f32x4*>(dst) = v;
+        } else {
+            bf16_t* dst = reinterpret_cast<bf16_t*>(Cv) + m * ldc + n;
+            if (accumulate) {
+                const u32x2 o = *reinterpret_cast<const u32x2*>(dst);
+                v[0] += bf16lo(o[0]); v[1] += bf16hi(o[0]); v[2] += bf16lo(o[1]); v[3] += bf16hi(o[1]);
+            }
+            u32x2 w;
+            w[0] = pack_bf16(v[0], v[1]);
+            w[1] = pack_bf16(v[2], v[3]);
+            *reinterpret_cast<u32x2*>(dst) = w;
+        }
+    }
+}
+
+static float* g_splitk_ws = nullptr;
+static long g_splitk_bytes = 0;
+extern "C" int vlr_gemm_set_splitk_workspace(void* ws, long bytes) {
+    VLR_REQUIRE((ws && bytes > 0) || (!ws && bytes == 0), "vlr_gemm_set_splitk_workspace: (ptr, bytes) or (NULL, 0)");
+    g_splitk_ws = (float*)ws;
+    g_splitk_bytes = bytes;
+    return VLR_OK;
+}
+
 static int gemm_impl(int layout, const void* A, const void* B, void* C, const void* bias, const void* residual, int M, int N,
                      int K, int lda, int ldb, int ldc, int ldr, int act, int accumulate, int out_f32, float alpha,
                      hipStream_t stream);
@@ -284,7 +330,33 @@ static int gemm_impl(int layout, const void* A, const void* B, void* C, const vo
     if (gflags < 0) { const char* e = getenv("VLR_GEMM_FLAGS"); gflags = e ? atoi(e) : 0; }
     p.flags = gflags;
     p.alpha = alpha;
+    p.splitk = 1; p.kchunk = 0; p.part = nullptr;
     const int pi = vlr_prof_begin(layout, 2.0 * M * N * K, stream);
+    // ---- split-K for weight-gradient-shaped (TN) problems whose output is a handful of tiles but whose reduction runs
+    // over all tokens (LoRA dB = dy^T u [out x r], dA = v^T x [r x in]): 32..96 workgroups would leave most CUs idle.
+    if (layout == 2 && g_splitk_ws && !bias && !residual && act == ACT_NONE) {
+        const int tiles128 = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+        if (tiles128 < 128 && K >= 2048) {
+            int splits = 512 / tiles128;
+            if (splits > 16) splits = 16;
+            if (splits > K / 256) splits = K / 256;
+            const long per = (long)M * N * 4;
+            if ((long)splits * per > g_splitk_bytes) splits = (int)(g_splitk_bytes / per);
+            if (splits > 1) {
+                const int kchunk = (((K + splits - 1) / splits) + 31) / 32 * 32;
+                splits = (K + kchunk - 1) / kchunk;
+                p.splitk = splits; p.kchunk = kchunk; p.part = g_splitk_ws;
+                hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), dim3(tiles128, splits), dim3(256), 0, stream, p);
+                const long n4 = (long)M * N / 4;
+                int rg = (int)((n4 + 255) / 256);
+                if (rg > 2048) rg = 2048;
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, stream, g_splitk_ws, splits, M, N, C, ldc, out_f32,
+                                   accumulate);
+                vlr_prof_end(pi, stream);
+                return vlr_check_launch("vlr_gemm_bf16(split-K)");
+            }
+        }
+    }
     // ---- wave quantisation: a 256x256-tile grid of T tiles runs ceil(T/256) rounds on the 256 CUs; when the last round is
     // nearly empty (e.g. 12792 x 4096 -> 800 tiles = 3.125 rounds) the last tile-rows are peeled off and run as 128x128
     // tiles (2 workgroups per CU) so the big-tile part is a whole number of rounds.  VLR_GEMM_SPLIT=0 disables.

@@ -615,6 +615,7 @@ bool vlr_gemm256_try_launch(int layout, const GemmParams& p, hipStream_t stream)
         }
     }
     if (!g_gemm256_mode) return false;
+    if (vlr_gemm256p_try_launch(layout, p, stream)) return true;
     const int tiles = ((p.M + TM - 1) / TM) * ((p.N + TN - 1) / TN);
     if (tiles < 192) return false;                       // too few workgroups for 256 CUs: the 128x128 kernel fills better
     // LDS-DMA cannot zero-fill a K tail: K-contiguous operands need K % 64 == 0 (true for every decoder GEMM)

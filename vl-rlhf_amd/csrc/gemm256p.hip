@@ -1,0 +1,387 @@
+// 256x256x64-tile bf16 MFMA GEMM, eight-phase schedule: the large-shape path of vlr_gemm_bf16 for all three layouts.
+//
+// The two-phase staggered kernel (gemm256.hip) is bound by the ISSUE of the LDS-DMA: one global_load_lds blocks its in-order
+// wave for ~100 cycles, and a LOAD phase that carries 4-8 of them next to 12 fragment reads takes longer than the 16 MFMAs
+// of its partner wave.  Here the same work is cut finer, after the guide's 256^2 8-phase template:
+//   * K tile 64; LDS = 2 buffers x {A-lo, A-hi, B-lo, B-hi} half tiles of 128 rows x 64 k (16 KiB each) = 128 KiB;
+//   * 8 waves = 2 (wr) x 4 (wc).  A wave owns the rows {wr*64..+64} of BOTH A halves and the columns {wc*32..+32} of BOTH
+//     B halves, i.e. four 64x32 quadrants (A0|A1) x (B0|B1) of the 256x256 tile, 32 accumulator tiles of 16x16;
+//   * per K tile four phases, each = {fragment ds_reads; ONE half tile of LDS-DMA (2 instructions per wave); barrier;
+//     16 v_mfma_f32_16x16x32_bf16 (one quadrant x K=64, 8 independent accumulators: a 32x32x16 quadrant has only two and
+//     its dependent chain left the matrix pipe idle - 1.31 PF with everything else ablated); barrier}.  Fragment reads per
+//     phase: 12 (B0, A0) / 4 (B1) / 8 (A1) / 0;
+//   * half tiles become free in the order B-lo, A-lo (last read in phase 1), B-hi (phase 2), A-hi (phase 3) and are re-staged
+//     for tile t+2 in phases 2, 3, 4 and phase 1 of tile t+1; the only vector-memory wait is a COUNTED vmcnt(6) in phase 4:
+//     three half tiles stay in flight across barriers, everything tile t+1 needs has landed;
+//   * waves 4-7 (wr = 1) run one barrier behind waves 0-3, so on every SIMD one wave is in its MFMA section while its partner
+//     issues reads and DMA; s_setprio(1) around the MFMAs lets the arbiter prefer the former.
+// Ordering rules (guide, "Read a staged buffer one phase AFTER the wait that retires it"): RAW - the phase-4 wait precedes that
+// phase's first barrier, the reads start in the next phase; WAR - a half is re-staged two phases after its last read, or one
+// phase after when an lgkmcnt before the reading phase's first barrier retired the reads (B-lo: the four B reads are issued
+// first in phase 1 and retired by lgkmcnt(8)).
+// K-contiguous operands: LDS image [128 rows][128 B], 16-byte chunk c of row r stored at c ^ ((r>>1)&7) (XOR on the per-lane
+// SOURCE address of the DMA, same XOR on the ds_read_b128).  K-strided operands (stored [K][cols]): LDS image [64 k][256 B],
+// chunk c of k-row r stored at c ^ (((r&3)<<2) | (((r>>3)&1)<<1)), fragments by two ds_read_b64_tr_b16.  M/N edges: rows/columns clamped on the
+// source side, never stored.  K tail: chunks beyond K read a 16-byte zero buffer.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "gemm.h"
+
+#define PT 256
+#define PK 64
+#define HALF_BYTES (128 * PK * 2)    // 16 KiB
+#define BUF_BYTES (4 * HALF_BYTES)   // A-lo | A-hi | B-lo | B-hi
+#define P_LDS_BYTES (2 * BUF_BYTES)  // 128 KiB
+
+typedef __attribute__((address_space(1))) const void gvoid_t;
+typedef __attribute__((address_space(3))) void lvoid_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+
+// One LDS-DMA wave instruction (64 lanes x 16 B -> LDS [m0 + lane*16]) issued through inline asm ON PURPOSE: when hipcc sees
+// the builtin it tracks an outstanding "LDS store through VMEM" and puts s_waitcnt vmcnt(0) in front of every
+// ds_read_b64_tr_b16 that follows (observed in the ISA of the builtin version: the DMA queue was drained every phase).
+// Hidden from the compiler, the only vector-memory waits are the counted ones written in the K loop.
+__device__ __forceinline__ void lds_dma16(const bf16_t* g, char* lds) {
+    const uint32_t l = (uint32_t)(uintptr_t)(lvoid_t*)lds;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l) : "memory", "m0");
+}
+// ---- LDS-DMA of one half tile, 2 wave instructions (1 KiB each) per wave
+// k-contiguous operand P[rows][ld]: instruction = 8 rows x 128 B
+__device__ __forceinline__ void stage_kc(const bf16_t* __restrict__ P, int ld, int row0, int nrows, int k0, int K,
+                                         const bf16_t* __restrict__ zero16, char* half, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int R = (wave + 8 * i) * 8;
+        const int r = R + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        int grow = row0 + r;
+        grow = grow < nrows ? grow : nrows - 1;
+        const int k = k0 + c * 8;
+        const bf16_t* g = (k + 8 <= K) ? P + (size_t)grow * ld + k : zero16;
+        lds_dma16(g, half + R * 128);
+    }
+}
+// k-strided operand P[K][ld] (columns contiguous): instruction = 4 k-rows x 256 B
+__device__ __forceinline__ void stage_ks(const bf16_t* __restrict__ P, int ld, int col0, int ncols, int k0, int K,
+                                         const bf16_t* __restrict__ zero16, char* half, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int R = (wave + 8 * i) * 4;
+        const int r = R + (lane >> 4);
+        const int chunk = (lane & 15) ^ (((r & 3) << 2) | (((r >> 3) & 1) << 1));
+        int col = col0 + chunk * 8;
+        col = col + 8 <= ncols ? col : ncols - 8;
+        const int k = k0 + r;
+        const bf16_t* g = (k < K) ? P + (size_t)k * ld + col : zero16;
+        lds_dma16(g, half + R * 256);
+    }
+}
+// ---- MFMA operand fragments for v_mfma_f32_16x16x32_bf16 (16 rows x 32 k of slice s; lane l: row l&15, k (l>>4)*8..+8)
+__device__ __forceinline__ bf16x8 pfrag_kc(const char* half, int rbase, int s, int lane) {
+    const int row = rbase + (lane & 15);
+    const int chunk = s * 4 + (lane >> 4);
+    return *reinterpret_cast<const bf16x8*>(half + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+}
+// k-strided half [64 k][128 cols]: within a 16-lane group g lane p supplies the address of (k-row p/4, 4 columns at (p%4)*4)
+// and receives column p of that 4 x 16 block; two reads (k-rows +0..3, +4..7 of the group's 8).  A 32-lane half of the
+// instruction covers k-rows {b..b+3} and {b+8..b+11} x 32 B: the swizzle spreads them over 8 distinct 32-byte segments.
+__device__ __forceinline__ bf16x8 pfrag_ks(const char* half, int cbase, int s, int lane) {
+    const int g = lane >> 4, pq = lane & 15;
+    const int krow = s * 32 + g * 8 + (pq >> 2);
+    const int col = cbase + (pq & 3) * 4;
+    const int swz = ((krow & 3) << 2) | (((krow >> 3) & 1) << 1);
+    const int off = krow * 256 + (((col >> 3) ^ swz) << 4) + ((col >> 2) & 1) * 8;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(half + off));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(half + off + 4 * 256));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+#define PFENCE() __builtin_amdgcn_sched_barrier(0)
+#define PBAR()                               \
+    do {                                     \
+        __builtin_amdgcn_sched_barrier(0);   \
+        __builtin_amdgcn_s_barrier();        \
+        asm volatile("" ::: "memory");       \
+        __builtin_amdgcn_sched_barrier(0);   \
+    } while (0)
+#define PWAIT_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
+#define PWAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+template <bool A_KS, bool B_KS, int ABL = 0>
+__global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_t* __restrict__ zero16) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // P_LDS_BYTES
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    // consume the kernel arguments here: otherwise the s_load of `zero16` is first waited for (lgkmcnt(0)) inside the K loop,
+    // in front of the phase-1 DMA, and drains the 12 fragment reads every iteration
+    asm volatile("" ::"s"(zero16), "s"(p.A), "s"(p.B), "s"(p.K), "s"(p.M), "s"(p.N), "s"(p.lda), "s"(p.ldb));
+
+    // ---- XCD-aware, grouped tile map (bijective for any tile count)
+    const int tiles_m = (p.M + PT - 1) / PT, tiles_n = (p.N + PT - 1) / PT;
+    const int nwg = tiles_m * tiles_n;
+    int pid;
+    {
+        const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+        const int q = nwg >> 3, rem = nwg & 7;
+        pid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+    }
+    const int GROUP = 8;
+    const int per_group = GROUP * tiles_n;
+    const int gid = pid / per_group;
+    const int first_m = gid * GROUP;
+    const int gsz = min(tiles_m - first_m, GROUP);
+    const int tm = first_m + (pid % per_group) % gsz;
+    const int tn = (pid % per_group) / gsz;
+    const int m0 = tm * PT, n0 = tn * PT;
+
+    f32x4 acc[2][4][2][2];   // [A half a][16-row tile i][B half b][16-col tile j]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[a][i][b][j][r] = 0.f;
+
+    const int nt = (p.K + PK - 1) / PK;
+    // half h of K tile `tile`: 0 A-lo, 1 A-hi, 2 B-lo, 3 B-hi
+    // diagnostics (template ABL via VLR_GEMM_ABLATE, NT only, timing only - results are wrong): 1 no DMA in the K loop,
+    // 2 no fragment reads after the first K tile, 4 no barriers in the K loop
+    constexpr bool abl_dma = ABL & 1, abl_rd = ABL & 2, abl_bar = ABL & 4;
+    bool in_loop = false;
+    auto stage = [&](int tile, auto hc) {
+        constexpr int h = decltype(hc)::value;
+        if (tile >= nt || (abl_dma && in_loop)) return;
+        char* dst = smem + (tile & 1) * BUF_BYTES + h * HALF_BYTES;
+        const int k0 = tile * PK;
+        if constexpr (h < 2) {
+            if constexpr (A_KS) stage_ks(p.A, p.lda, m0 + h * 128, p.M, k0, p.K, zero16, dst, wave, lane);
+            else stage_kc(p.A, p.lda, m0 + h * 128, p.M, k0, p.K, zero16, dst, wave, lane);
+        } else {
+            if constexpr (B_KS) stage_ks(p.B, p.ldb, n0 + (h - 2) * 128, p.N, k0, p.K, zero16, dst, wave, lane);
+            else stage_kc(p.B, p.ldb, n0 + (h - 2) * 128, p.N, k0, p.K, zero16, dst, wave, lane);
+        }
+    };
+    using H_ALO = std::integral_constant<int, 0>;
+    using H_AHI = std::integral_constant<int, 1>;
+    using H_BLO = std::integral_constant<int, 2>;
+    using H_BHI = std::integral_constant<int, 3>;
+
+    // ---- prologue: K tile 0 resident, the first three halves of tile 1 in flight
+    stage(0, H_BLO{}); stage(0, H_ALO{}); stage(0, H_BHI{}); stage(0, H_AHI{});
+    stage(1, H_BLO{}); stage(1, H_ALO{}); stage(1, H_BHI{});
+    if (nt >= 2) PWAIT_VM(6); else PWAIT_VM(0);
+    PBAR();
+    if (wr == 1) PBAR();          // waves 4-7 run one barrier behind waves 0-3
+
+    bf16x8 fa0[4][2], fa1[4][2], fb0[2][2], fb1[2][2];   // [16-row/col tile][k slice of 32]
+    auto rdA = [&](const char* half, bf16x8 (&f)[4][2]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if constexpr (A_KS) f[i][ks] = pfrag_ks(half, wr * 64 + i * 16, ks, lane);
+                else f[i][ks] = pfrag_kc(half, wr * 64 + i * 16, ks, lane);
+            }
+    };
+    auto rdB = [&](const char* half, bf16x8 (&f)[2][2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if constexpr (B_KS) f[j][ks] = pfrag_ks(half, wc * 32 + j * 16, ks, lane);
+                else f[j][ks] = pfrag_kc(half, wc * 32 + j * 16, ks, lane);
+            }
+    };
+#define PMFMA(A_, B_, a_, b_)                                                                                            \
+    do {                                                                                                                 \
+        __builtin_amdgcn_s_setprio(1);                                                                                   \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                    \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                    \
+            acc[a_][i][b_][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_[i][ks], B_[j][ks], acc[a_][i][b_][j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                                   \
+    } while (0)
+
+#define LBAR() do { if (!abl_bar) PBAR(); } while (0)
+    in_loop = true;
+    for (int kt = 0; kt < nt; ++kt) {
+        const char* buf = smem + (kt & 1) * BUF_BYTES;
+        const bool rd = !abl_rd || kt == 0;
+        // ---------------- phase 1: B0 (4 reads, retired first), A0 (8 reads); stage A-hi of tile kt+1
+        if (rd) rdB(buf + 2 * HALF_BYTES, fb0);
+        PFENCE();
+        if (rd) rdA(buf, fa0);
+        PFENCE();
+        stage(kt + 1, H_AHI{});
+        PFENCE();
+        if constexpr (A_KS) PWAIT_LGKM(15);   // 16 A reads (two per fragment); the counter holds 15: the B reads are retired
+        else PWAIT_LGKM(8);
+        LBAR();
+        PMFMA(fa0, fb0, 0, 0);
+        LBAR();
+        // ---------------- phase 2: B1; stage B-lo of tile kt+2
+        if (rd) rdB(buf + 3 * HALF_BYTES, fb1);
+        PFENCE();
+        stage(kt + 2, H_BLO{});
+        LBAR();
+        PMFMA(fa0, fb1, 0, 1);
+        LBAR();
+        // ---------------- phase 3: A1; stage A-lo of tile kt+2
+        if (rd) rdA(buf + HALF_BYTES, fa1);
+        PFENCE();
+        stage(kt + 2, H_ALO{});
+        LBAR();
+        PMFMA(fa1, fb1, 1, 1);
+        LBAR();
+        // ---------------- phase 4: no reads; stage B-hi of tile kt+2; the counted wait that makes tile kt+1 resident
+        stage(kt + 2, H_BHI{});
+        PFENCE();
+        if (kt + 2 < nt) PWAIT_VM(6); else PWAIT_VM(0);
+        LBAR();
+        PMFMA(fa1, fb0, 1, 0);
+        LBAR();
+    }
+#undef PMFMA
+    if (wr == 0) PBAR();          // balance the extra barrier of waves 4-7
+    __syncthreads();
+
+    // ---- epilogue: one 64x32 quadrant at a time through a wave-private LDS patch (8 KiB), 16-byte global accesses
+    constexpr int PS = 36;   // patch row stride in floats: +4 rows = 144 floats = 16 banks -> conflict-free 16x16 tile writes
+    float* patch = reinterpret_cast<float*>(smem) + wave * (64 * PS);
+    auto quadrant = [&](auto ac, auto bc) {
+        constexpr int a = decltype(ac)::value, b = decltype(bc)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    patch[(i * 16 + 4 * (lane >> 4) + r) * PS + j * 16 + (lane & 15)] = acc[a][i][b][j][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int gm0 = m0 + a * 128 + wr * 64, gn0 = n0 + b * 128 + wc * 32;
+        if (!p.out_f32) {
+            bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+            const int cq = (lane & 3) * 8;
+            const int gn = gn0 + cq;
+            float bv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+            if (p.bias && gn + 8 <= p.N) unpack8(*reinterpret_cast<const u32x4*>(p.bias + gn), bv);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 16 + (lane >> 2);
+                const int gm = gm0 + row;
+                if (gm < p.M && gn + 8 <= p.N) {
+                    float v[8];
+                    const f32x4 s0 = *reinterpret_cast<const f32x4*>(patch + row * PS + cq);
+                    const f32x4 s1 = *reinterpret_cast<const f32x4*>(patch + row * PS + cq + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = s0[e]; v[4 + e] = s1[e]; }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = apply_act(p.alpha * v[e] + bv[e], p.act);
+                    if (p.residual) {
+                        float rv[8];
+                        unpack8(*reinterpret_cast<const u32x4*>(p.residual + (size_t)gm * p.ldr + gn), rv);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+                    }
+                    bf16_t* dst = C + (size_t)gm * p.ldc + gn;
+                    if (p.accumulate) {
+                        float ov[8];
+                        unpack8(*reinterpret_cast<const u32x4*>(dst), ov);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += ov[e];
+                    }
+                    *reinterpret_cast<u32x4*>(dst) = pack8(v);
+                }
+            }
+        } else {
+            float* C = reinterpret_cast<float*>(p.C);
+            const int cq = (lane & 7) * 4;
+            const int gn = gn0 + cq;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias && gn + 4 <= p.N) {
+                const u32x2 w = *reinterpret_cast<const u32x2*>(p.bias + gn);
+                bv[0] = bf16lo(w[0]); bv[1] = bf16hi(w[0]); bv[2] = bf16lo(w[1]); bv[3] = bf16hi(w[1]);
+            }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 8 + (lane >> 3);
+                const int gm = gm0 + row;
+                if (gm < p.M && gn + 4 <= p.N) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(patch + row * PS + cq);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act(p.alpha * v[e] + bv[e], p.act);
+                    if (p.residual) {
+                        const u32x2 w = *reinterpret_cast<const u32x2*>(p.residual + (size_t)gm * p.ldr + gn);
+                        v[0] += bf16lo(w[0]); v[1] += bf16hi(w[0]); v[2] += bf16lo(w[1]); v[3] += bf16hi(w[1]);
+                    }
+                    float* dst = C + (size_t)gm * p.ldc + gn;
+                    if (p.accumulate) {
+                        const f32x4 o = *reinterpret_cast<const f32x4*>(dst);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += o[e];
+                    }
+                    *reinterpret_cast<f32x4*>(dst) = v;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    quadrant(I0{}, I0{});
+    quadrant(I0{}, I1{});
+    quadrant(I1{}, I0{});
+    quadrant(I1{}, I1{});
+}
+
+// returns false when the problem does not qualify (caller falls back to the staggered / 128x128 kernels)
+bool vlr_gemm256p_try_launch(int layout, const GemmParams& p, hipStream_t stream) {
+    static int mode = -1;
+    static bf16_t* zero16 = nullptr;
+    if (mode < 0) {
+        const char* e = getenv("VLR_GEMM_8PHASE");
+        mode = e ? atoi(e) : 7;            // bit 0 NT, bit 1 NN, bit 2 TN
+        if (mode) {
+            hipFuncSetAttribute((const void*)gemm256p_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES);
+            hipFuncSetAttribute((const void*)gemm256p_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES);
+            hipFuncSetAttribute((const void*)gemm256p_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES);
+            if (hipMalloc((void**)&zero16, 256) != hipSuccess || hipMemset(zero16, 0, 256) != hipSuccess) mode = 0;
+        }
+    }
+    if (!((mode >> layout) & 1)) return false;
+    const int tiles = ((p.M + PT - 1) / PT) * ((p.N + PT - 1) / PT);
+    if (tiles < 192) return false;
+    // 16-byte DMA source alignment: k-contiguous operands need ld % 8 and K % 8 (checked by the caller), k-strided
+    // operands ld % 8 and at least 8 columns; pointers 16-byte aligned
+    const bool a_ks = layout == 2, b_ks = layout != 0;
+    if (((uintptr_t)p.A | (uintptr_t)p.B) & 15) return false;
+    if (a_ks && (p.lda % 8 != 0 || p.M % 8 != 0)) return false;
+    if (b_ks && (p.ldb % 8 != 0 || p.N % 8 != 0)) return false;
+    if (!a_ks && p.lda % 8 != 0) return false;
+    if (!b_ks && p.ldb % 8 != 0) return false;
+    static int abl = -1;
+    if (abl < 0) { const char* e = getenv("VLR_GEMM_ABLATE"); abl = e ? atoi(e) : 0; }
+    if (layout == 0 && abl) {
+#define PABL(n) case n: hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, n>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES); \
+        hipLaunchKernelGGL((gemm256p_kernel<false, false, n>), dim3(tiles), dim3(512), P_LDS_BYTES, stream, p, (const bf16_t*)zero16); return true;
+        switch (abl) { PABL(1) PABL(2) PABL(3) PABL(4) PABL(5) PABL(6) PABL(7) default: break; }
+#undef PABL
+    }
+    if (layout == 0) hipLaunchKernelGGL((gemm256p_kernel<false, false>), dim3(tiles), dim3(512), P_LDS_BYTES, stream, p, (const bf16_t*)zero16);
+    else if (layout == 1) hipLaunchKernelGGL((gemm256p_kernel<false, true>), dim3(tiles), dim3(512), P_LDS_BYTES, stream, p, (const bf16_t*)zero16);
+    else hipLaunchKernelGGL((gemm256p_kernel<true, true>), dim3(tiles), dim3(512), P_LDS_BYTES, stream, p, (const bf16_t*)zero16);
+    return true;
+}

@@ -104,6 +104,7 @@ _INT_HELPERS = {
     "vlr_abi_version": [],
     "vlr_prof_enable": [I],
     "vlr_prof_collect": [P, I],
+    "vlr_gemm_set_splitk_workspace": [P, L],
 }
 
 

@@ -94,15 +94,13 @@ def _parse(*classes):
 
 
 def main():
-    from vlrlhf.parallel import GradReducer, init_distributed_from_env
+    from vlrlhf.parallel import init_distributed_from_env
     from vlrlhf.utils.auto_load import MyAutoDPOCollator, MyAutoDPOTrainer, MyAutoProcessor, auto_load_rlmodel
     from vlrlhf.utils.data import DATASET_MAP
     script_args, training_args, lora_args = _parse(ScriptArguments, TrainingArguments, LoraArguments)
     rank, local, world = init_distributed_from_env()
     training_args.local_rank = local
     model, ref_model, lora_config = auto_load_rlmodel(script_args, training_args, lora_args)
-    if world > 1:
-        model.engine.make_reducer()
     processor = MyAutoProcessor.from_pretrained(script_args.model_name_or_path)
     processor.train()
     dataset = DATASET_MAP[script_args.dataset_name](script_args)
@@ -124,13 +122,23 @@ def main():
         peft_config=lora_config, loss_type=script_args.loss_type, ref_model=ref_model,
         dataset_num_proc=training_args.dataset_num_proc)
     dpo_trainer.use_dpo_data_collator = True
+    if world > 1:
+        model.engine.make_reducer()           # after the trainer: with peft_config only the adapters are reduced
     dpo_trainer.train(resume_from_checkpoint=training_args.resume_from_checkpoint)
     dpo_trainer.save_state()
     if rank == 0:
         from safetensors.torch import save_file
         os.makedirs(training_args.output_dir, exist_ok=True)
-        save_file({k: v.contiguous() for k, v in model.state_dict().items()},
-                  os.path.join(training_args.output_dir, "model.safetensors"))
+        if training_args.use_lora:
+            # reference utils/common.py:97-98 (get_peft_state_maybe_zero_3): only the adapter tensors, peft file layout
+            import json
+            save_file({k: v.contiguous() for k, v in model.lora_state_dict().items()},
+                      os.path.join(training_args.output_dir, "adapter_model.safetensors"))
+            with open(os.path.join(training_args.output_dir, "adapter_config.json"), "w") as f:
+                json.dump(dict(lora_config, peft_type="LORA", base_model_name_or_path=script_args.model_name_or_path), f, indent=1)
+        else:
+            save_file({k: v.contiguous() for k, v in model.state_dict().items()},
+                      os.path.join(training_args.output_dir, "model.safetensors"))
         processor.save_pretrained(training_args.output_dir)
 
 

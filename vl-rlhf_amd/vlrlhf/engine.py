@@ -270,6 +270,9 @@ class LlavaHipEngine:
                 t.copy_((torch.rand(t.shape, generator=gen, device=self.dev) * 2 - 1) * bound)
         self.lora_seed = int(seed)
         self._lora_calls = 0
+        # split-K scratch for the adapter-gradient GEMMs ([out x r] / [r x in] outputs reduced over all tokens)
+        self._splitk_ws = torch.empty(64 << 20, dtype=torch.uint8, device=self.dev)
+        _hip.helper("vlr_gemm_set_splitk_workspace", self._splitk_ws.data_ptr(), self._splitk_ws.numel())
         self.grads = None                         # full-parameter gradient / optimizer buffers are not needed any more
         self.gv = None
         self.master = self.m = self.v = None

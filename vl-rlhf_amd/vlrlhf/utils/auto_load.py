@@ -52,12 +52,24 @@ class MyAutoDPOTrainer:
 
 
 def auto_load_rlmodel(script_args, training_args, lora_args):
-    """-> (model, ref_model=None, lora_config=None); vision tower frozen (reference :554-555)."""
-    if getattr(training_args, "use_lora", False):
-        raise NotImplementedError("LoRA is SURVEY.md 8(f) rank 2; this round trains the full LLM + projector")
+    """-> (model, ref_model=None, lora_config); vision tower frozen (reference :554-555).  With use_lora the LoraConfig of
+    reference :559-571 is returned as a plain dict (peft itself is not needed: the trainer hands it to
+    LlavaForRL.apply_lora); q_lora (GPTQ, reference :520-548) is not on the MI355X path."""
+    if getattr(training_args, "use_lora", False) and getattr(lora_args, "q_lora", False):
+        raise NotImplementedError("q_lora (GPTQ 4-bit base weights) is outside the MI355X DPO path")
     model = MyAutoModel.from_pretrained(script_args.model_name_or_path)
     if getattr(script_args, "freeze_vision_tower", True):
         model.freeze_vision_tower()
     model.config.label_pad_token_id = script_args.label_pad_token_id
     model.config.use_cache = False
-    return model, None, None
+    lora_config = None
+    if getattr(training_args, "use_lora", False):
+        targets = lora_args.lora_target_modules
+        if targets in (None, "auto"):
+            targets = model.default_lora_target
+        elif isinstance(targets, str):
+            targets = targets.split(",")
+        lora_config = dict(r=lora_args.lora_r, lora_alpha=lora_args.lora_alpha, lora_dropout=lora_args.lora_dropout,
+                           target_modules=list(targets), bias=lora_args.lora_bias, task_type="CAUSAL_LM",
+                           modules_to_save=lora_args.modules_to_save, seed=int(getattr(training_args, "seed", 0)))
+    return model, None, lora_config
