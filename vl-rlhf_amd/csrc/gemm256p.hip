@@ -48,7 +48,32 @@ __device__ __forceinline__ void lds_dma16(const bf16_t* g, char* lds) {
     const uint32_t l = (uint32_t)(uintptr_t)(lvoid_t*)lds;
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l) : "memory", "m0");
 }
-// ---- LDS-DMA of one half tile, 2 wave instructions (1 KiB each) per wave
+// fast form: uniform 64-bit base in SGPRs + per-lane 32-bit byte offset (loop invariant), no per-piece vector arithmetic
+__device__ __forceinline__ void lds_dma16_s(const char* sbase, uint32_t voff, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+}
+// per-lane byte offsets of the two pieces this wave stages for one half tile, relative to the K tile's base address
+__device__ __forceinline__ void piece_off_kc(int ld, int row0, int nrows, int wave, int lane, uint32_t (&off)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (wave + 8 * i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        int grow = row0 + r;
+        grow = grow < nrows ? grow : nrows - 1;
+        off[i] = (uint32_t)(((size_t)grow * ld + c * 8) * 2);
+    }
+}
+__device__ __forceinline__ void piece_off_ks(int ld, int col0, int ncols, int wave, int lane, uint32_t (&off)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (wave + 8 * i) * 4 + (lane >> 4);
+        const int chunk = (lane & 15) ^ (((r & 3) << 2) | (((r >> 3) & 1) << 1));
+        int col = col0 + chunk * 8;
+        col = col + 8 <= ncols ? col : ncols - 8;
+        off[i] = (uint32_t)(((size_t)r * ld + col) * 2);
+    }
+}
+// ---- LDS-DMA of one half tile, 2 wave instructions (1 KiB each) per wave (general form: K tail -> zeros)
 // k-contiguous operand P[rows][ld]: instruction = 8 rows x 128 B
 __device__ __forceinline__ void stage_kc(const bf16_t* __restrict__ P, int ld, int row0, int nrows, int k0, int K,
                                          const bf16_t* __restrict__ zero16, char* half, int wave, int lane) {
@@ -157,17 +182,46 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     // 2 no fragment reads after the first K tile, 4 no barriers in the K loop
     constexpr bool abl_dma = ABL & 1, abl_rd = ABL & 2, abl_bar = ABL & 4;
     bool in_loop = false;
-    auto stage = [&](int tile, auto hc) {
+    // loop-invariant per-lane source offsets (bytes) of this wave's two pieces of each half, and the per-K-tile base step
+    uint32_t offA[2][2], offB[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if constexpr (A_KS) piece_off_ks(p.lda, m0 + h * 128, p.M, wave, lane, offA[h]);
+        else piece_off_kc(p.lda, m0 + h * 128, p.M, wave, lane, offA[h]);
+        if constexpr (B_KS) piece_off_ks(p.ldb, n0 + h * 128, p.N, wave, lane, offB[h]);
+        else piece_off_kc(p.ldb, n0 + h * 128, p.N, wave, lane, offB[h]);
+    }
+    const size_t stepA = A_KS ? (size_t)PK * p.lda * 2 : (size_t)PK * 2;
+    const size_t stepB = B_KS ? (size_t)PK * p.ldb * 2 : (size_t)PK * 2;
+    const bool ktail = (p.K % PK) != 0;          // only the last K tile can be partial: it takes the general (zero-filling) path
+    const uint32_t lds_wave = (uint32_t)(uintptr_t)(lvoid_t*)smem + wave * 1024;
+    // fastc = true: the caller guarantees tile < nt and that the tile is a full one (steady-state loop): no checks at all
+    auto stage = [&](int tile, auto hc, auto fastc) {
         constexpr int h = decltype(hc)::value;
-        if (tile >= nt || (abl_dma && in_loop)) return;
-        char* dst = smem + (tile & 1) * BUF_BYTES + h * HALF_BYTES;
-        const int k0 = tile * PK;
+        constexpr bool fast = decltype(fastc)::value;
+        if constexpr (abl_dma) { if (in_loop) return; }
+        if constexpr (!fast) { if (tile >= nt) return; }
+        if (!fast && ktail && tile == nt - 1) {
+            char* dst = smem + (tile & 1) * BUF_BYTES + h * HALF_BYTES;
+            const int k0 = tile * PK;
+            if constexpr (h < 2) {
+                if constexpr (A_KS) stage_ks(p.A, p.lda, m0 + h * 128, p.M, k0, p.K, zero16, dst, wave, lane);
+                else stage_kc(p.A, p.lda, m0 + h * 128, p.M, k0, p.K, zero16, dst, wave, lane);
+            } else {
+                if constexpr (B_KS) stage_ks(p.B, p.ldb, n0 + (h - 2) * 128, p.N, k0, p.K, zero16, dst, wave, lane);
+                else stage_kc(p.B, p.ldb, n0 + (h - 2) * 128, p.N, k0, p.K, zero16, dst, wave, lane);
+            }
+            return;
+        }
+        const uint32_t dst = lds_wave + (tile & 1) * BUF_BYTES + h * HALF_BYTES;
         if constexpr (h < 2) {
-            if constexpr (A_KS) stage_ks(p.A, p.lda, m0 + h * 128, p.M, k0, p.K, zero16, dst, wave, lane);
-            else stage_kc(p.A, p.lda, m0 + h * 128, p.M, k0, p.K, zero16, dst, wave, lane);
+            const char* base = (const char*)p.A + (size_t)tile * stepA;
+            lds_dma16_s(base, offA[h][0], dst);
+            lds_dma16_s(base, offA[h][1], dst + 8192);
         } else {
-            if constexpr (B_KS) stage_ks(p.B, p.ldb, n0 + (h - 2) * 128, p.N, k0, p.K, zero16, dst, wave, lane);
-            else stage_kc(p.B, p.ldb, n0 + (h - 2) * 128, p.N, k0, p.K, zero16, dst, wave, lane);
+            const char* base = (const char*)p.B + (size_t)tile * stepB;
+            lds_dma16_s(base, offB[h - 2][0], dst);
+            lds_dma16_s(base, offB[h - 2][1], dst + 8192);
         }
     };
     using H_ALO = std::integral_constant<int, 0>;
@@ -176,31 +230,82 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     using H_BHI = std::integral_constant<int, 3>;
 
     // ---- prologue: K tile 0 resident, the first three halves of tile 1 in flight
-    stage(0, H_BLO{}); stage(0, H_ALO{}); stage(0, H_BHI{}); stage(0, H_AHI{});
-    stage(1, H_BLO{}); stage(1, H_ALO{}); stage(1, H_BHI{});
+    using SLOW = std::false_type;
+    using FAST = std::true_type;
+    stage(0, H_BLO{}, SLOW{}); stage(0, H_ALO{}, SLOW{}); stage(0, H_BHI{}, SLOW{}); stage(0, H_AHI{}, SLOW{});
+    stage(1, H_BLO{}, SLOW{}); stage(1, H_ALO{}, SLOW{}); stage(1, H_BHI{}, SLOW{});
     if (nt >= 2) PWAIT_VM(6); else PWAIT_VM(0);
     PBAR();
     if (wr == 1) PBAR();          // waves 4-7 run one barrier behind waves 0-3
 
     bf16x8 fa0[4][2], fa1[4][2], fb0[2][2], fb1[2][2];   // [16-row/col tile][k slice of 32]
-    auto rdA = [&](const char* half, bf16x8 (&f)[4][2]) {
+    // Per-lane LDS read pointers into the CURRENT buffer's A-lo / B-lo half, loop carried and flipped by +-BUF_BYTES per K tile,
+    // so that every fragment read is `pointer + compile-time offset` (half, tile, slice): no address arithmetic in the phases.
+    //   k-contiguous: one pointer per k slice (the swizzled chunk differs by an XOR, the 16-row tiles by +2048 B);
+    //   k-strided:    one pointer per 16-column tile (XOR in the chunk index), the k slices / row quads by +8192 / +1024 B.
+    constexpr int NPA = A_KS ? 4 : 2, NPB = 2;
+    const char* pa[NPA];
+    const char* pb[NPB];
+    {
+        const int g = lane >> 4, pq = lane & 15;
+        if constexpr (A_KS) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int krow = g * 8 + (pq >> 2), col = wr * 64 + i * 16 + (pq & 3) * 4;
+                const int swz = ((krow & 3) << 2) | (((krow >> 3) & 1) << 1);
+                pa[i] = smem + krow * 256 + (((col >> 3) ^ swz) << 4) + ((col >> 2) & 1) * 8;
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int row = wr * 64 + pq;
+                pa[ks] = smem + row * 128 + (((ks * 4 + g) ^ ((row >> 1) & 7)) << 4);
+            }
+        }
+        if constexpr (B_KS) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int krow = g * 8 + (pq >> 2), col = wc * 32 + j * 16 + (pq & 3) * 4;
+                const int swz = ((krow & 3) << 2) | (((krow >> 3) & 1) << 1);
+                pb[j] = smem + 2 * HALF_BYTES + krow * 256 + (((col >> 3) ^ swz) << 4) + ((col >> 2) & 1) * 8;
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int row = wc * 32 + pq;
+                pb[ks] = smem + 2 * HALF_BYTES + row * 128 + (((ks * 4 + g) ^ ((row >> 1) & 7)) << 4);
+            }
+        }
+    }
+    int flip = BUF_BYTES;
+    auto tr2 = [&](const char* q) {
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)q);
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(q + 4 * 256));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    // hi = 0: the -lo half, 1: the -hi half of the current buffer
+    auto rdA = [&](auto hic, bf16x8 (&f)[4][2]) {
+        constexpr int ho = decltype(hic)::value * HALF_BYTES;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                if constexpr (A_KS) f[i][ks] = pfrag_ks(half, wr * 64 + i * 16, ks, lane);
-                else f[i][ks] = pfrag_kc(half, wr * 64 + i * 16, ks, lane);
+                if constexpr (A_KS) f[i][ks] = tr2(pa[i] + ho + ks * 8192);
+                else f[i][ks] = *reinterpret_cast<const bf16x8*>(pa[ks] + ho + i * 2048);
             }
     };
-    auto rdB = [&](const char* half, bf16x8 (&f)[2][2]) {
+    auto rdB = [&](auto hic, bf16x8 (&f)[2][2]) {
+        constexpr int ho = decltype(hic)::value * HALF_BYTES;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                if constexpr (B_KS) f[j][ks] = pfrag_ks(half, wc * 32 + j * 16, ks, lane);
-                else f[j][ks] = pfrag_kc(half, wc * 32 + j * 16, ks, lane);
+                if constexpr (B_KS) f[j][ks] = tr2(pb[j] + ho + ks * 8192);
+                else f[j][ks] = *reinterpret_cast<const bf16x8*>(pb[ks] + ho + j * 2048);
             }
     };
+    using LO = std::integral_constant<int, 0>;
+    using HI = std::integral_constant<int, 1>;
 #define PMFMA(A_, B_, a_, b_)                                                                                            \
     do {                                                                                                                 \
         __builtin_amdgcn_s_setprio(1);                                                                                   \
@@ -213,15 +318,14 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
 
 #define LBAR() do { if (!abl_bar) PBAR(); } while (0)
     in_loop = true;
-    for (int kt = 0; kt < nt; ++kt) {
-        const char* buf = smem + (kt & 1) * BUF_BYTES;
+    auto ktile = [&](int kt, auto fastc) {
         const bool rd = !abl_rd || kt == 0;
         // ---------------- phase 1: B0 (4 reads, retired first), A0 (8 reads); stage A-hi of tile kt+1
-        if (rd) rdB(buf + 2 * HALF_BYTES, fb0);
+        if (rd) rdB(LO{}, fb0);
         PFENCE();
-        if (rd) rdA(buf, fa0);
+        if (rd) rdA(LO{}, fa0);
         PFENCE();
-        stage(kt + 1, H_AHI{});
+        stage(kt + 1, H_AHI{}, fastc);
         PFENCE();
         if constexpr (A_KS) PWAIT_LGKM(15);   // 16 A reads (two per fragment); the counter holds 15: the B reads are retired
         else PWAIT_LGKM(8);
@@ -229,27 +333,37 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
         PMFMA(fa0, fb0, 0, 0);
         LBAR();
         // ---------------- phase 2: B1; stage B-lo of tile kt+2
-        if (rd) rdB(buf + 3 * HALF_BYTES, fb1);
+        if (rd) rdB(HI{}, fb1);
         PFENCE();
-        stage(kt + 2, H_BLO{});
+        stage(kt + 2, H_BLO{}, fastc);
         LBAR();
         PMFMA(fa0, fb1, 0, 1);
         LBAR();
         // ---------------- phase 3: A1; stage A-lo of tile kt+2
-        if (rd) rdA(buf + HALF_BYTES, fa1);
+        if (rd) rdA(HI{}, fa1);
         PFENCE();
-        stage(kt + 2, H_ALO{});
+        stage(kt + 2, H_ALO{}, fastc);
         LBAR();
         PMFMA(fa1, fb1, 1, 1);
         LBAR();
         // ---------------- phase 4: no reads; stage B-hi of tile kt+2; the counted wait that makes tile kt+1 resident
-        stage(kt + 2, H_BHI{});
+        stage(kt + 2, H_BHI{}, fastc);
         PFENCE();
-        if (kt + 2 < nt) PWAIT_VM(6); else PWAIT_VM(0);
+        if (decltype(fastc)::value || kt + 2 < nt) PWAIT_VM(6); else PWAIT_VM(0);
         LBAR();
         PMFMA(fa1, fb0, 1, 0);
         LBAR();
-    }
+#pragma unroll
+        for (int q = 0; q < NPA; ++q) pa[q] += flip;
+#pragma unroll
+        for (int q = 0; q < NPB; ++q) pb[q] += flip;
+        flip = -flip;
+    };
+    // steady state: every staged tile (kt+1, kt+2) exists and is full -> no checks, no K-tail path in the hot loop
+    const int n_fast = nt - 2 - (ktail ? 1 : 0);
+    int kt = 0;
+    for (; kt < n_fast; ++kt) ktile(kt, FAST{});
+    for (; kt < nt; ++kt) ktile(kt, SLOW{});
 #undef PMFMA
     if (wr == 0) PBAR();          // balance the extra barrier of waves 4-7
     __syncthreads();
@@ -377,7 +491,7 @@ bool vlr_gemm256p_try_launch(int layout, const GemmParams& p, hipStream_t stream
     if (layout == 0 && abl) {
 #define PABL(n) case n: hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, n>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES); \
         hipLaunchKernelGGL((gemm256p_kernel<false, false, n>), dim3(tiles), dim3(512), P_LDS_BYTES, stream, p, (const bf16_t*)zero16); return true;
-        switch (abl) { PABL(1) PABL(2) PABL(3) PABL(4) PABL(5) PABL(6) PABL(7) default: break; }
+        switch (abl) { PABL(1) PABL(3) PABL(4) PABL(5) PABL(7) default: break; }   // 2 and 6 spill
 #undef PABL
     }
     if (layout == 0) hipLaunchKernelGGL((gemm256p_kernel<false, false>), dim3(tiles), dim3(512), P_LDS_BYTES, stream, p, (const bf16_t*)zero16);
