@@ -43,9 +43,11 @@ int vlr_gemm_bf16(int layout, const void* A, const void* B, void* C, const void*
 int vlr_gemm_bf16_scaled(int layout, const void* A, const void* B, void* C, const void* bias, const void* residual, int M,
                          int N, int K, int lda, int ldb, int ldc, int ldr, int act, int accumulate, int out_f32,
                          float alpha, vlr_stream_t stream);
-/* Optional fp32 scratch for split-K (TN layout only: few output tiles, reduction over all tokens - the LoRA adapter
- * gradients).  Without it such problems run un-split.  The buffer is shared by every split-K launch of the process, so
- * TN GEMMs must stay on ONE stream while it is registered (the backward is single-stream).  (NULL, 0) unregisters. */
+/* Optional fp32 scratch for split-K: problems with few output tiles and a long reduction (the LoRA adapter gradients;
+ * the ragged last tile rows of the decoder GEMMs) are split along K into fp32 partials and reduced by a second kernel
+ * that applies the epilogue.  Without it they run un-split.  The buffer is cut in two slots handed to the first two
+ * distinct streams that launch such a GEMM (policy pass + reference pass on a side stream); further streams run
+ * un-split.  64 MiB per slot covers the 7B shapes.  (NULL, 0) unregisters. */
 int vlr_gemm_set_splitk_workspace(void* workspace, long bytes);
 
 /* ---- normalisation / activations (transformers LlamaRMSNorm, CLIP LayerNorm, SwiGLU, GELU; call sites

@@ -646,4 +646,23 @@ def test_gemm_tn_split_k(hip, shape):
         hip.call("vlr_gemm_bf16", 2, a, b, c2, None, None, M, N, K, M, N, N, 0, 0, 0, 0)
         check(c2, c, 4e-3, "split vs un-split")
     finally:
-        hip.helper("vlr_gemm_set_splitk_workspace", None, 0)
+        hip.ensure_splitk_workspace(force=True)
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+def test_gemm_peeled_rows_split_k(hip, layout):
+    """12792 rows = 48 full 256-row tile rows (three whole rounds of 256x256 tiles) + 504 peeled rows that run as 128x128
+    tiles split along K, reduced by the kernel that applies bias / residual / accumulate."""
+    hip.ensure_splitk_workspace(force=True)
+    M, N, K = 12792, 4096, 4352
+    a = rnd(M, K, seed=1, scale=0.5)
+    b = rnd(N, K, seed=2, scale=0.5)
+    bias = rnd(N, seed=3)
+    res = rnd(M, N, seed=4)
+    c0 = rnd(M, N, seed=5)
+    ref = a.float() @ b.float().t() * 0.5 + bias.float() + res.float() + c0.float()
+    Bm = b if layout == 0 else b.t().contiguous()
+    c = c0.clone()
+    hip.call("vlr_gemm_bf16_scaled", layout, a, Bm, c, bias, res, M, N, K, K, K if layout == 0 else N, N, N, 0, 1, 0, 0.5)
+    check(c, ref, 8e-3, f"peel + split-K layout {layout}")
+    check(c[-504:], ref[-504:], 8e-3, "peeled rows")

@@ -17,6 +17,8 @@
 // Layout: q, k, v are column blocks of one fused [tokens][3H] buffer (row stride ld); token row = b*S + s; head h
 // owns columns [h*D, (h+1)*D).  lse is kept in the log2 domain: L2 = m + log2(l) with scores pre-multiplied by
 // scale*log2(e), so P = exp2(s*scale*log2e - L2).  Fully masked query rows give O = 0, L2 = +inf (P == 0 in bwd).
+#include <stdlib.h>
+
 #include "common.h"
 
 #define KV_TILE 64
@@ -225,6 +227,169 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         write_rows<D>(acc, inv, o + (tok0 + qi) * (size_t)ldo + head * D, g);
     }
     // lse rows are padded to Sp (multiple of 64) and the tail holds +inf so the backward's P is exactly 0 there
+    if (lse && g == 0 && qi < Sp) lse[((size_t)b * nh + head) * Sp + qi] = (qi < S && l > 0.f) ? m + log2f(l) : INFINITY;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Forward, LDS-DMA version.  Same tiling and arithmetic as attn_fwd_kernel; what changes is how K / V tiles reach LDS and
+// how many waves share a SIMD:
+//   * K and V tiles are double buffered in LDS and fetched by LDS-DMA (global_load_lds_dwordx4, one 1-KiB piece = 1024/(2D)
+//     rows per wave instruction, 16-byte chunks permuted on the SOURCE side so that the lane-linear LDS image equals
+//     tile_off<D>); no staging registers, no ds_write, ONE barrier per tile: {vmcnt(0); barrier; issue tile t+1; compute t};
+//   * key validity is turned into one 64-bit mask per KV tile in the prologue (no per-tile bias row / block-wide OR);
+//   * <= 128 VGPR + 128 AGPR per wave and 64.5 KiB LDS per block -> TWO blocks per CU: a wave's softmax (VALU) runs under
+//     the MFMAs of the wave it shares the SIMD with.
+// The DMA is issued through inline asm so that hipcc does not put s_waitcnt vmcnt(0) before the transposing LDS reads.
+// ------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void attn_lvoid_t;
+__device__ __forceinline__ void attn_dma16(const bf16_t* sbase, uint32_t voff, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+}
+#define ATTN_MAX_TILES 128   // S <= 8192
+template <int D>
+struct AttnFwd2 {
+    static constexpr int TILE_BYTES = KV_TILE * D * 2;
+    static constexpr int LDS_BYTES = 4 * TILE_BYTES + ATTN_MAX_TILES * 8;
+    static constexpr int RPP = 1024 / (2 * D);          // rows per DMA piece
+    static constexpr int NPIECE = KV_TILE / RPP / 4;    // pieces per wave and tile (4 waves)
+};
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                           const bf16_t* __restrict__ v, int ld, bf16_t* __restrict__ o,
+                                                           int ldo, float* __restrict__ lse, const int* __restrict__ kmask,
+                                                           int S, int Sp, float scale_log2) {
+    using CF = AttnFwd2<D>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][K tile | V tile] | tile masks
+    unsigned long long* tilemask = reinterpret_cast<unsigned long long*>(smem + 4 * CF::TILE_BYTES);
+    const int t = threadIdx.x, lane = t & 63, g = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int head = blockIdx.y, b = blockIdx.z, nh = gridDim.y;
+    const size_t tok0 = (size_t)b * S;
+    const bf16_t* qh = q + tok0 * ld + head * D;
+    const bf16_t* kh = k + tok0 * ld + head * D;
+    const bf16_t* vh = v + tok0 * ld + head * D;
+    const int qblk = CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;   // causal: heaviest blocks first
+    const int qw0 = qblk * 128 + wave * 32;
+    const int qi = qw0 + (lane & 31);
+    const int qrow = qi < S ? qi : S - 1;
+    const int q_end = min(S, qblk * 128 + 128);
+    const int nkv = CAUSAL ? (q_end + KV_TILE - 1) / KV_TILE : (S + KV_TILE - 1) / KV_TILE;
+
+    // DMA geometry: piece pc = wave + 4*i covers tile rows [pc*RPP, (pc+1)*RPP); lane -> (row, LDS chunk position)
+    constexpr int CPR = D / 8;
+    const int prow = lane / CPR, ppos = lane % CPR;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(attn_lvoid_t*)smem;
+    auto issue_tile = [&](int it) {
+        const int k0 = it * KV_TILE;
+        const uint32_t dst = lds0 + (it & 1) * 2 * CF::TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < CF::NPIECE; ++i) {
+            const int pc = wave + 4 * i;
+            const int r = pc * CF::RPP + prow;                      // row inside the tile
+            // LDS position ppos of row r holds chunk c with tile_off(r, c) == r*rowbytes + ppos*16
+            const int swz = (tile_off<D>(r, 0) - r * (D * 2)) >> 4;
+            const int c = ppos ^ swz;
+            int row = k0 + r;
+            row = row < S ? row : S - 1;
+            const uint32_t off = (uint32_t)(((size_t)row * ld + c * 8) * 2);
+            attn_dma16(kh, off, dst + pc * 1024);
+            attn_dma16(vh, off, dst + CF::TILE_BYTES + pc * 1024);
+        }
+    };
+    issue_tile(0);
+
+    // key-validity masks, one 64-bit word per KV tile (bit = key is masked)
+    for (int tl = wave; tl < nkv; tl += 4) {
+        const int key = tl * KV_TILE + lane;
+        const bool ok = key < S && (!kmask || kmask[tok0 + key] != 0);
+        const unsigned long long bad = __builtin_amdgcn_ballot_w64(!ok);
+        if (lane == 0) tilemask[tl] = bad;
+    }
+
+    bf16x8 qf[D / 16];
+#pragma unroll
+    for (int st = 0; st < D / 16; ++st)
+        qf[st] = *reinterpret_cast<const bf16x8*>(qh + (size_t)qrow * ld + 16 * st + 8 * g);
+
+    f32x16 acc[D / 32];
+#pragma unroll
+    for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float m = -INFINITY, l = 0.f;      // m in the scaled log2 domain
+
+    for (int it = 0; it < nkv; ++it) {
+        const int k0 = it * KV_TILE;
+        // tile `it` has landed (own pieces: vmcnt, everybody's: barrier) and nobody still reads the other buffer
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (it + 1 < nkv) issue_tile(it + 1);
+        if (CAUSAL && k0 > qw0 + 31) continue;             // wave-uniform: whole tile is in this wave's future
+        const char* k_lds = smem + (it & 1) * 2 * CF::TILE_BYTES;
+        const char* v_lds = k_lds + CF::TILE_BYTES;
+
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+            for (int st = 0; st < D / 16; ++st)
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(k_lds, kb * 32, 2 * st, lane), qf[st], s[kb], 0, 0, 0);
+        }
+        // masks only where a tile needs them: diagonal tiles (causal) and tiles holding padded / out-of-range keys
+        const unsigned long long mk = tilemask[it];
+        if ((CAUSAL && k0 + KV_TILE - 1 > qw0) || mk != 0ull) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kk = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                    if (((mk >> kk) & 1ull) || (CAUSAL && k0 + kk > qi)) s[kb][r] = -INFINITY;
+                }
+        }
+        float mx = s[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m, mx * scale_log2);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m - m_use);
+        float rs = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pp = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], scale_log2, -m_use));
+                s[kb][r] = pp;
+                rs += pp;
+            }
+        rs += __shfl_xor(rs, 32);
+        l = l * alpha + rs;
+        m = m_new;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {   // the running max moved for some query of this wave
+#pragma unroll
+            for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 pf = pack_frag(s[ks >> 1], ks & 1);
+#pragma unroll
+            for (int db = 0; db < D / 32; ++db)
+                acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(v_lds, db * 32, ks, lane), pf, acc[db], 0, 0, 0);
+        }
+    }
+    if (qi < S) {
+        const float inv = l > 0.f ? 1.f / l : 0.f;
+        write_rows<D>(acc, inv, o + (tok0 + qi) * (size_t)ldo + head * D, g);
+    }
     if (lse && g == 0 && qi < Sp) lse[((size_t)b * nh + head) * Sp + qi] = (qi < S && l > 0.f) ? m + log2f(l) : INFINITY;
 }
 
@@ -452,6 +617,231 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Backward kernels, LDS-DMA versions (same arithmetic as attn_bwd_dq_kernel / attn_bwd_dkv_kernel; tiles double buffered in
+// LDS and fetched by LDS-DMA, one barrier per tile, key masks as 64-bit words - see attn_fwd2_kernel).
+// ------------------------------------------------------------------------------------------------------------
+// LDS-DMA of one [64][128] tile whose rows are rows [row0, row0+64) (clamped to nrows-1) of src (row stride ld)
+__device__ __forceinline__ void attn_issue_tile128(const bf16_t* src, int ld, int row0, int nrows, uint32_t dst, int wave, int lane) {
+    const int prow = lane >> 4, ppos = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pc = wave + 4 * i;
+        const int r = pc * 4 + prow;
+        const int c = ppos ^ (((r & 3) << 2) | ((r >> 2) & 3));      // tile_off<128>
+        int row = row0 + r;
+        row = row < nrows ? row : nrows - 1;
+        attn_dma16(src, (uint32_t)(((size_t)row * ld + c * 8) * 2), dst + pc * 1024);
+    }
+}
+#define ATTN_TILE_BARRIER()                               \
+    do {                                                  \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+        __builtin_amdgcn_sched_barrier(0);                \
+        __builtin_amdgcn_s_barrier();                     \
+        asm volatile("" ::: "memory");                    \
+        __builtin_amdgcn_sched_barrier(0);                \
+    } while (0)
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, CAUSAL ? 2 : 1) void attn_bwd_dq2_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                              const bf16_t* __restrict__ v, int ld,
+                                                              const bf16_t* __restrict__ dout, int ldo,
+                                                              const float* __restrict__ lse, const float* __restrict__ delta,
+                                                              const int* __restrict__ kmask, bf16_t* __restrict__ dq, int lddq,
+                                                              int S, int Sp, float scale) {
+    constexpr int D = 128, TB = KV_TILE * D * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K | V] | tile masks
+    unsigned long long* tilemask = reinterpret_cast<unsigned long long*>(smem + 4 * TB);
+    const int t = threadIdx.x, lane = t & 63, g = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int head = blockIdx.y, b = blockIdx.z, nh = gridDim.y;
+    const size_t tok0 = (size_t)b * S;
+    const bf16_t* qh = q + tok0 * ld + head * D;
+    const bf16_t* kh = k + tok0 * ld + head * D;
+    const bf16_t* vh = v + tok0 * ld + head * D;
+    const bf16_t* doh = dout + tok0 * ldo + head * D;
+    const int qblk = CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+    const int qw0 = qblk * 128 + wave * 32;
+    const int qi = qw0 + (lane & 31);
+    const int qrow = qi < S ? qi : S - 1;
+    const float scale_log2 = scale * LOG2E;
+    const int q_end = min(S, qblk * 128 + 128);
+    const int nkv = CAUSAL ? (q_end + KV_TILE - 1) / KV_TILE : (S + KV_TILE - 1) / KV_TILE;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(attn_lvoid_t*)smem;
+    auto issue = [&](int it) {
+        const uint32_t dst = lds0 + (it & 1) * 2 * TB;
+        attn_issue_tile128(kh, ld, it * KV_TILE, S, dst, wave, lane);
+        attn_issue_tile128(vh, ld, it * KV_TILE, S, dst + TB, wave, lane);
+    };
+    issue(0);
+    for (int tl = wave; tl < nkv; tl += 4) {
+        const int key = tl * KV_TILE + lane;
+        const bool ok = key < S && (!kmask || kmask[tok0 + key] != 0);
+        const unsigned long long bad = __builtin_amdgcn_ballot_w64(!ok);
+        if (lane == 0) tilemask[tl] = bad;
+    }
+
+    bf16x8 qf[8], dof[8];
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+        qf[st] = *reinterpret_cast<const bf16x8*>(qh + (size_t)qrow * ld + 16 * st + 8 * g);
+        dof[st] = *reinterpret_cast<const bf16x8*>(doh + (size_t)qrow * ldo + 16 * st + 8 * g);
+    }
+    const float L2 = qi < S ? lse[((size_t)b * nh + head) * Sp + qrow] : INFINITY;
+    const float dl = delta[((size_t)b * nh + head) * Sp + qrow];
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    for (int it = 0; it < nkv; ++it) {
+        const int k0 = it * KV_TILE;
+        ATTN_TILE_BARRIER();
+        if (it + 1 < nkv) issue(it + 1);
+        if (CAUSAL && k0 > qw0 + 31) continue;
+        const char* k_lds = smem + (it & 1) * 2 * TB;
+        const char* v_lds = k_lds + TB;
+        const unsigned long long mk = tilemask[it];
+        const bool need_mask = (CAUSAL && k0 + KV_TILE - 1 > qw0) || mk != 0ull;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(k_lds, kb * 32, 2 * st, lane), qf[st], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(v_lds, kb * 32, 2 * st, lane), dof[st], dp, 0, 0, 0);
+            }
+            if (need_mask) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kk = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                    if (((mk >> kk) & 1ull) || (CAUSAL && k0 + kk > qi)) s[r] = -INFINITY;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pp = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], scale_log2, -L2));   // masked / L2=+inf -> 0
+                s[r] = pp * (dp[r] - dl) * scale;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const bf16x8 dsf = pack_frag(s, h);
+                const int ks = kb * 2 + h;
+#pragma unroll
+                for (int db = 0; db < 4; ++db)
+                    acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(k_lds, db * 32, ks, lane), dsf, acc[db], 0, 0, 0);
+            }
+        }
+    }
+    if (qi < S) write_rows<D>(acc, 1.f, dq + (tok0 + qi) * (size_t)lddq + head * D, g);
+}
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                            const bf16_t* __restrict__ v, int ld,
+                                                            const bf16_t* __restrict__ dout, int ldo,
+                                                            const float* __restrict__ lse, const float* __restrict__ delta,
+                                                            const int* __restrict__ kmask, bf16_t* __restrict__ dk,
+                                                            bf16_t* __restrict__ dv, int lddkv, int S, int Sp, float scale) {
+    constexpr int D = 128, TB = KV_TILE * D * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][Q | dO]
+    const int t = threadIdx.x, lane = t & 63, g = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int head = blockIdx.y, b = blockIdx.z, nh = gridDim.y;
+    const size_t tok0 = (size_t)b * S;
+    const bf16_t* qh = q + tok0 * ld + head * D;
+    const bf16_t* kh = k + tok0 * ld + head * D;
+    const bf16_t* vh = v + tok0 * ld + head * D;
+    const bf16_t* doh = dout + tok0 * ldo + head * D;
+    const float* lse_h = lse + ((size_t)b * nh + head) * Sp;   // rows padded to Sp: 16-byte aligned, tail = +inf
+    const float* dl_h = delta + ((size_t)b * nh + head) * Sp;
+    const int kw0 = blockIdx.x * 128 + wave * 32;
+    const int ki = kw0 + (lane & 31);
+    const int krow = ki < S ? ki : S - 1;
+    const bool key_ok = ki < S && (!kmask || kmask[tok0 + krow] != 0);
+    const bool any_bad_key = __builtin_amdgcn_ballot_w64(!key_ok) != 0;
+    const float scale_log2 = scale * LOG2E;
+    const int q_start = CAUSAL ? ((int)blockIdx.x * 128 / KV_TILE) * KV_TILE : 0;
+    const int nq = (S - q_start + KV_TILE - 1) / KV_TILE;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(attn_lvoid_t*)smem;
+    auto issue = [&](int it) {
+        const uint32_t dst = lds0 + (it & 1) * 2 * TB;
+        attn_issue_tile128(qh, ld, q_start + it * KV_TILE, S, dst, wave, lane);
+        attn_issue_tile128(doh, ldo, q_start + it * KV_TILE, S, dst + TB, wave, lane);
+    };
+    issue(0);
+
+    bf16x8 kf[8], vf[8];
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+        kf[st] = *reinterpret_cast<const bf16x8*>(kh + (size_t)krow * ld + 16 * st + 8 * g);
+        vf[st] = *reinterpret_cast<const bf16x8*>(vh + (size_t)krow * ld + 16 * st + 8 * g);
+    }
+    f32x16 adk[4], adv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { adk[i][r] = 0.f; adv[i][r] = 0.f; }
+
+    for (int it = 0; it < nq; ++it) {
+        const int q0 = q_start + it * KV_TILE;
+        ATTN_TILE_BARRIER();
+        if (it + 1 < nq) issue(it + 1);
+        if (CAUSAL && q0 + KV_TILE - 1 < kw0) continue;   // every query of the tile precedes this wave's keys
+        const char* q_lds = smem + (it & 1) * 2 * TB;
+        const char* do_lds = q_lds + TB;
+        const bool need_mask = (CAUSAL && q0 < kw0 + 31) || any_bad_key;   // wave-uniform
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(q_lds, qb * 32, 2 * st, lane), kf[st], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(do_lds, qb * 32, 2 * st, lane), vf[st], dp, 0, 0, 0);
+            }
+            f32x16 pm;
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const f32x4 l2 = *reinterpret_cast<const f32x4*>(lse_h + q0 + qb * 32 + 8 * rq + 4 * g);
+                const f32x4 dl = *reinterpret_cast<const f32x4*>(dl_h + q0 + qb * 32 + 8 * rq + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * rq + e;
+                    float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], scale_log2, -l2[e]));   // l2 = +inf past S -> 0
+                    if (need_mask) {
+                        const int qq = q0 + qb * 32 + 8 * rq + 4 * g + e;
+                        if (!key_ok || (CAUSAL && ki > qq)) pv = 0.f;
+                    }
+                    pm[r] = pv;
+                    s[r] = pv > 0.f ? pv * (dp[r] - dl[e]) * scale : 0.f;
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const bf16x8 pf = pack_frag(pm, h);
+                const bf16x8 dsf = pack_frag(s, h);
+                const int ks = qb * 2 + h;
+#pragma unroll
+                for (int db = 0; db < 4; ++db) {
+                    adv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(do_lds, db * 32, ks, lane), pf, adv[db], 0, 0, 0);
+                    adk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(q_lds, db * 32, ks, lane), dsf, adk[db], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (ki < S) {
+        write_rows<D>(adk, 1.f, dk + (tok0 + ki) * (size_t)lddkv + head * D, g);
+        write_rows<D>(adv, 1.f, dv + (tok0 + ki) * (size_t)lddkv + head * D, g);
+    }
+}
+
 // ============================================================================================================
 extern "C" int vlr_attn_fwd(const void* q, const void* k, const void* v, int ld, void* o, int ldo, float* lse,
                             const int* key_mask, int batch, int S, int heads, int head_dim, int causal, float scale,
@@ -466,8 +856,26 @@ extern "C" int vlr_attn_fwd(const void* q, const void* k, const void* v, int ld,
 #define LAUNCH(D_, C_)                                                                                                  \
     hipLaunchKernelGGL((attn_fwd_kernel<D_, C_>), grid, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,           \
                        (const bf16_t*)v, ld, (bf16_t*)o, ldo, lse, key_mask, S, Sp, sl2)
-    if (head_dim == 128) { if (causal) LAUNCH(128, true); else LAUNCH(128, false); }
-    else { if (causal) LAUNCH(64, true); else LAUNCH(64, false); }
+    static int fwd2 = -1;
+    if (fwd2 < 0) {
+        const char* e = getenv("VLR_ATTN_DMA");
+        fwd2 = (e && e[0] == '0') ? 0 : 1;
+        hipFuncSetAttribute((const void*)attn_fwd2_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, AttnFwd2<128>::LDS_BYTES);
+        hipFuncSetAttribute((const void*)attn_fwd2_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, AttnFwd2<128>::LDS_BYTES);
+        hipFuncSetAttribute((const void*)attn_fwd2_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, AttnFwd2<64>::LDS_BYTES);
+        hipFuncSetAttribute((const void*)attn_fwd2_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, AttnFwd2<64>::LDS_BYTES);
+    }
+#define LAUNCH2(D_, C_)                                                                                                 \
+    hipLaunchKernelGGL((attn_fwd2_kernel<D_, C_>), grid, dim3(256), AttnFwd2<D_>::LDS_BYTES, st, (const bf16_t*)q,       \
+                       (const bf16_t*)k, (const bf16_t*)v, ld, (bf16_t*)o, ldo, lse, key_mask, S, Sp, sl2)
+    if (fwd2 && S <= ATTN_MAX_TILES * KV_TILE) {
+        if (head_dim == 128) { if (causal) LAUNCH2(128, true); else LAUNCH2(128, false); }
+        else { if (causal) LAUNCH2(64, true); else LAUNCH2(64, false); }
+    } else {
+        if (head_dim == 128) { if (causal) LAUNCH(128, true); else LAUNCH(128, false); }
+        else { if (causal) LAUNCH(64, true); else LAUNCH(64, false); }
+    }
+#undef LAUNCH2
 #undef LAUNCH
     vlr_prof_end(pi, st);
     return vlr_check_launch("vlr_attn_fwd");
@@ -485,7 +893,29 @@ extern "C" int vlr_attn_bwd(const void* q, const void* k, const void* v, int ld,
     hipLaunchKernelGGL(attn_delta_kernel, dim3(batch * S), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)o, ldo,
                        delta_ws, S, Sp, heads);
     const dim3 grid((S + 127) / 128, heads, batch);
-    if (causal) {
+    static int dma = -1;
+    constexpr int LDS_DQ = 4 * KV_TILE * 128 * 2 + ATTN_MAX_TILES * 8, LDS_DKV = 4 * KV_TILE * 128 * 2;
+    if (dma < 0) {
+        const char* e = getenv("VLR_ATTN_DMA");
+        dma = (e && e[0] == '0') ? 0 : 1;
+        hipFuncSetAttribute((const void*)attn_bwd_dq2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ);
+        hipFuncSetAttribute((const void*)attn_bwd_dq2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ);
+        hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DKV);
+        hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DKV);
+    }
+    if (dma && S <= ATTN_MAX_TILES * KV_TILE) {
+        if (causal) {
+            hipLaunchKernelGGL((attn_bwd_dq2_kernel<true>), grid, dim3(256), LDS_DQ, st, (const bf16_t*)q, (const bf16_t*)k,
+                               (const bf16_t*)v, ld, (const bf16_t*)dout, ldo, lse, delta_ws, key_mask, (bf16_t*)dq, ldd, S, Sp, scale);
+            hipLaunchKernelGGL((attn_bwd_dkv2_kernel<true>), grid, dim3(256), LDS_DKV, st, (const bf16_t*)q, (const bf16_t*)k,
+                               (const bf16_t*)v, ld, (const bf16_t*)dout, ldo, lse, delta_ws, key_mask, (bf16_t*)dk, (bf16_t*)dv, ldd, S, Sp, scale);
+        } else {
+            hipLaunchKernelGGL((attn_bwd_dq2_kernel<false>), grid, dim3(256), LDS_DQ, st, (const bf16_t*)q, (const bf16_t*)k,
+                               (const bf16_t*)v, ld, (const bf16_t*)dout, ldo, lse, delta_ws, key_mask, (bf16_t*)dq, ldd, S, Sp, scale);
+            hipLaunchKernelGGL((attn_bwd_dkv2_kernel<false>), grid, dim3(256), LDS_DKV, st, (const bf16_t*)q, (const bf16_t*)k,
+                               (const bf16_t*)v, ld, (const bf16_t*)dout, ldo, lse, delta_ws, key_mask, (bf16_t*)dk, (bf16_t*)dv, ldd, S, Sp, scale);
+        }
+    } else if (causal) {
         hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), grid, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,
                            (const bf16_t*)v, ld, (const bf16_t*)dout, ldo, lse, delta_ws, key_mask, (bf16_t*)dq, ldd, S, Sp, scale);
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), grid, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,

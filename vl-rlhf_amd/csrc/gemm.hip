@@ -252,9 +252,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// split-K epilogue: C = sum_z part[z] (+ C), 4 columns per thread
+// split-K epilogue: C = act(sum_z part[z] + bias) + residual (+ C), 4 columns per thread (the partials carry alpha already)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, int M, int N, void* Cv,
-                                                            int ldc, int out_f32, int accumulate) {
+                                                            int ldc, int out_f32, int accumulate,
+                                                            const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual,
+                                                            int ldr, int act) {
     const long n4 = (long)M * N / 4;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         f32x4 v = *reinterpret_cast<const f32x4*>(part + i * 4);
@@ -263,6 +265,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
             v += w;
         }
         const long m = (i * 4) / N, n = (i * 4) % N;
+        if (bias) {
+            const u32x2 w = *reinterpret_cast<const u32x2*>(bias + n);
+            v[0] += bf16lo(w[0]); v[1] += bf16hi(w[0]); v[2] += bf16lo(w[1]); v[3] += bf16hi(w[1]);
+        }
+        if (act != ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act);
+        }
+        if (residual) {
+            const u32x2 w = *reinterpret_cast<const u32x2*>(residual + m * ldr + n);
+            v[0] += bf16lo(w[0]); v[1] += bf16hi(w[0]); v[2] += bf16lo(w[1]); v[3] += bf16hi(w[1]);
+        }
         if (out_f32) {
             float* dst = reinterpret_cast<float*>(Cv) + m * ldc + n;
             if (accumulate) v += *reinterpret_cast<const f32x4*>(dst);
@@ -281,13 +295,56 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+// The registered scratch is cut in two slots, one per stream (the DPO step runs the frozen reference forward on a side
+// stream next to the policy forward): the first two distinct streams that ask get a slot each, any further stream runs
+// un-split.  Re-registering forgets the stream assignment.
 static float* g_splitk_ws = nullptr;
-static long g_splitk_bytes = 0;
+static long g_splitk_bytes = 0;          // bytes per slot
+static hipStream_t g_splitk_stream[2] = {nullptr, nullptr};
+static int g_splitk_nstream = 0;
 extern "C" int vlr_gemm_set_splitk_workspace(void* ws, long bytes) {
     VLR_REQUIRE((ws && bytes > 0) || (!ws && bytes == 0), "vlr_gemm_set_splitk_workspace: (ptr, bytes) or (NULL, 0)");
     g_splitk_ws = (float*)ws;
-    g_splitk_bytes = bytes;
+    g_splitk_bytes = (bytes / 2) & ~255L;
+    g_splitk_nstream = 0;
     return VLR_OK;
+}
+static float* splitk_slot(hipStream_t st) {
+    if (!g_splitk_ws) return nullptr;
+    for (int i = 0; i < g_splitk_nstream; ++i)
+        if (g_splitk_stream[i] == st) return (float*)((char*)g_splitk_ws + (size_t)i * g_splitk_bytes);
+    if (g_splitk_nstream < 2) {
+        g_splitk_stream[g_splitk_nstream] = st;
+        return (float*)((char*)g_splitk_ws + (size_t)(g_splitk_nstream++) * g_splitk_bytes);
+    }
+    return nullptr;
+}
+// split-K launch of the 128x128 kernel: few output tiles, long reduction.  Returns false when it does not apply.
+static bool launch_splitk128(int layout, GemmParams p, hipStream_t stream, int min_k) {
+    if (p.N % 4 != 0 || p.K < min_k) return false;
+    const int tiles128 = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    if (tiles128 >= 256) return false;
+    int splits = 512 / tiles128;
+    if (splits > 16) splits = 16;
+    if (splits > p.K / 256) splits = p.K / 256;
+    if (splits < 2) return false;
+    float* ws = splitk_slot(stream);
+    if (!ws) return false;
+    const long per = (long)p.M * p.N * 4;
+    if ((long)splits * per > g_splitk_bytes) splits = (int)(g_splitk_bytes / per);
+    if (splits < 2) return false;
+    const int kchunk = (((p.K + splits - 1) / splits) + 31) / 32 * 32;
+    splits = (p.K + kchunk - 1) / kchunk;
+    p.splitk = splits; p.kchunk = kchunk; p.part = ws;
+    if (layout == 0) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), dim3(tiles128, splits), dim3(256), 0, stream, p);
+    else if (layout == 1) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), dim3(tiles128, splits), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), dim3(tiles128, splits), dim3(256), 0, stream, p);
+    const long n4 = (long)p.M * p.N / 4;
+    int rg = (int)((n4 + 255) / 256);
+    if (rg > 2048) rg = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, stream, ws, splits, p.M, p.N, p.C, p.ldc, p.out_f32,
+                       p.accumulate, p.bias, p.residual, p.ldr, p.act);
+    return true;
 }
 
 static int gemm_impl(int layout, const void* A, const void* B, void* C, const void* bias, const void* residual, int M, int N,
@@ -332,30 +389,11 @@ static int gemm_impl(int layout, const void* A, const void* B, void* C, const vo
     p.alpha = alpha;
     p.splitk = 1; p.kchunk = 0; p.part = nullptr;
     const int pi = vlr_prof_begin(layout, 2.0 * M * N * K, stream);
-    // ---- split-K for weight-gradient-shaped (TN) problems whose output is a handful of tiles but whose reduction runs
-    // over all tokens (LoRA dB = dy^T u [out x r], dA = v^T x [r x in]): 32..96 workgroups would leave most CUs idle.
-    if (layout == 2 && g_splitk_ws && !bias && !residual && act == ACT_NONE) {
-        const int tiles128 = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-        if (tiles128 < 128 && K >= 2048) {
-            int splits = 512 / tiles128;
-            if (splits > 16) splits = 16;
-            if (splits > K / 256) splits = K / 256;
-            const long per = (long)M * N * 4;
-            if ((long)splits * per > g_splitk_bytes) splits = (int)(g_splitk_bytes / per);
-            if (splits > 1) {
-                const int kchunk = (((K + splits - 1) / splits) + 31) / 32 * 32;
-                splits = (K + kchunk - 1) / kchunk;
-                p.splitk = splits; p.kchunk = kchunk; p.part = g_splitk_ws;
-                hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), dim3(tiles128, splits), dim3(256), 0, stream, p);
-                const long n4 = (long)M * N / 4;
-                int rg = (int)((n4 + 255) / 256);
-                if (rg > 2048) rg = 2048;
-                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, stream, g_splitk_ws, splits, M, N, C, ldc, out_f32,
-                                   accumulate);
-                vlr_prof_end(pi, stream);
-                return vlr_check_launch("vlr_gemm_bf16(split-K)");
-            }
-        }
+    // ---- split-K for problems whose output is a handful of tiles but whose reduction is long: the LoRA adapter gradients
+    // (TN: dB = dy^T u [out x r], dA = v^T x [r x in], reduction over all tokens) - 32..96 workgroups would leave most CUs idle
+    if (layout == 2 && launch_splitk128(layout, p, stream, 2048)) {
+        vlr_prof_end(pi, stream);
+        return vlr_check_launch("vlr_gemm_bf16(split-K)");
     }
     // ---- wave quantisation: a 256x256-tile grid of T tiles runs ceil(T/256) rounds on the 256 CUs; when the last round is
     // nearly empty (e.g. 12792 x 4096 -> 800 tiles = 3.125 rounds) the last tile-rows are peeled off and run as 128x128
@@ -387,6 +425,12 @@ static int gemm_impl(int layout, const void* A, const void* B, void* C, const vo
         if (p.residual) p2.residual = p.residual + (size_t)M1 * ldr;
         if (vlr_gemm256_try_launch(layout, p1, stream)) {
             const int t2 = ((p2.M + BM - 1) / BM) * ((N + BN - 1) / BN);
+            // the peeled rows are few tiles with the full reduction depth (e.g. 504 x 4096 x 22016 = 128 tiles x 688 k-steps):
+            // split them along K so that they fill the chip
+            if (launch_splitk128(layout, p2, stream, 4096)) {
+                vlr_prof_end(pi, stream);
+                return vlr_check_launch("vlr_gemm_bf16(256+128 split-K)");
+            }
             if (layout == 0) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), dim3(t2), dim3(256), 0, stream, p2);
             else if (layout == 1) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), dim3(t2), dim3(256), 0, stream, p2);
             else hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), dim3(t2), dim3(256), 0, stream, p2);

@@ -201,5 +201,22 @@ def call(name, *args):
     return rc
 
 
+_splitk_ws = None
+
+
+def ensure_splitk_workspace(device="cuda", force=False):
+    """process-wide fp32 scratch of the GEMM dispatcher's split-K path (include/vlr.h: two 64 MiB slots, one per stream);
+    allocated once and never freed, so the pointer registered in the library cannot dangle."""
+    global _splitk_ws
+    if _splitk_ws is None:
+        _splitk_ws = torch.empty(128 << 20, dtype=torch.uint8, device=device)
+        force = True
+    if force:
+        rc = lib().vlr_gemm_set_splitk_workspace(_splitk_ws.data_ptr(), _splitk_ws.numel())
+        if rc != 0:
+            raise VlrError(lib().vlr_last_error().decode())
+    return _splitk_ws
+
+
 def helper(name, *args):
     return getattr(lib(), name)(*args)

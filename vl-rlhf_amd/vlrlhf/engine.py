@@ -229,6 +229,8 @@ class LlavaHipEngine:
         self._colsum_ws = torch.empty(_hip.helper("vlr_colsum_workspace_bytes", max(self.H, 8)), dtype=torch.uint8, device=self.dev)
         self._sq_ws = torch.empty(_hip.helper("vlr_grad_sqnorm_workspace_bytes"), dtype=torch.uint8, device=self.dev)
         self.norm_out = torch.zeros(3, dtype=torch.float32, device=self.dev)
+        # split-K scratch of the GEMM dispatcher (ragged last tile rows, LoRA adapter gradients): two 64 MiB slots (main + side stream)
+        _hip.ensure_splitk_workspace(self.dev)
 
     # ------------------------------------------------------------------------------------------------ weights
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
@@ -270,9 +272,7 @@ class LlavaHipEngine:
                 t.copy_((torch.rand(t.shape, generator=gen, device=self.dev) * 2 - 1) * bound)
         self.lora_seed = int(seed)
         self._lora_calls = 0
-        # split-K scratch for the adapter-gradient GEMMs ([out x r] / [r x in] outputs reduced over all tokens)
-        self._splitk_ws = torch.empty(64 << 20, dtype=torch.uint8, device=self.dev)
-        _hip.helper("vlr_gemm_set_splitk_workspace", self._splitk_ws.data_ptr(), self._splitk_ws.numel())
+
         self.grads = None                         # full-parameter gradient / optimizer buffers are not needed any more
         self.gv = None
         self.master = self.m = self.v = None
