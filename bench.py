@@ -149,9 +149,9 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
     # HBM traffic of the dominant kernel: PMC passes cannot run inside the timed region; the committed rocprofv3 --pmc
-    # result (profiles/r01_pmc_hbm_traffic_bench.*) is quoted when present
+    # result (profiles/r01_pmc_hbm_traffic_8phase.*, tools/pmc_traffic.sh) is quoted when present
     traffic = None
-    tf = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_bench.json")
+    tf = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_8phase.json")
     if os.path.exists(tf):
         traffic = round(json.load(open(tf))["gemm_hbm_bytes_per_launch"])
     g_n = sum(prof[k][0] for k in ("gemm_nt", "gemm_nn", "gemm_tn"))
@@ -179,9 +179,9 @@ def main():
                                    + ("reference log-probs precomputed" if a.precomputed_ref else "reference forward inside the step"),
                        "global_batch_pairs": world * a.pairs, "text_len": a.text_len, "parallelism": f"dp{world}",
                        "layers": cfg["layers"], "loss": float(loss)},
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (NT/NN/TN)", "achieved": round(achieved, 1),
+            "roofline": {"bound": "mfma", "kernel": "gemm256p_kernel<A_KS,B_KS> (8-phase 256x256x64 bf16 GEMM: NT/NN/TN)", "achieved": round(achieved, 1),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                         "traffic": traffic, "traffic_unit": "bytes/launch (2*FETCH_SIZE+WRITE_SIZE, rocprofv3 --pmc, offline pass)",
+                         "traffic": traffic, "traffic_unit": "bytes/launch leaving L2 (2*FETCH_SIZE+WRITE_SIZE, rocprofv3 --pmc, offline pass; A+B of a decoder GEMM fit the 256 MB Infinity Cache, so most of the re-reads never reach HBM)",
                          "algorithmic_bytes_per_launch": round(2.0 * g_bytes / max(1, g_dec)), "launches": g_n, "avg_launch_ms": round(g_ms / max(1, g_n), 4), "per_kernel": per_kernel,
                          "gemm_share_of_step": round(g_ms * 1e-3 / dt, 3),
                          "step_frac": round(pairs_per_s / world * per_pair / PEAK_BF16_TFLOPS, 4)},
