@@ -423,3 +423,28 @@ def test_lora_init_is_reference_and_merge(gpu):
         LlavaForRL.from_state_dict(cfg, W).apply_lora(dict(PEFT, target_modules=["q_proj", "v_proj"]))
     with pytest.raises(ValueError):
         LlavaForRL.from_state_dict(cfg, W).apply_lora(dict(PEFT, r=6))
+
+
+def test_precompute_ref_log_probs_prepass(gpu):
+    """trl's precompute_ref_log_probs: one no-grad pass stores the reference log-probs on the dataset rows; the training
+    steps then run without a reference forward and see the same loss as with a live reference model."""
+    from vlrlhf.models.Llava import LlavaDPODataCollatorWithPadding, LlavaDPOTrainer, LlavaForRL
+    z, cfg, W, W_ref, batch, rows = load_case("llava_hipsmall")
+    px = t(z, "batch.pixel_values")
+    ds = [dict(r, img_path=px[i]) for i, r in enumerate(rows)]
+    model = LlavaForRL.from_state_dict(cfg, W)
+    o = cfg["optim"]
+    args = SimpleNamespace(gradient_accumulation_steps=1, per_device_train_batch_size=2, learning_rate=o["lr"], adam_beta1=o["beta1"],
+                           adam_beta2=o["beta2"], adam_epsilon=o["eps"], weight_decay=o["weight_decay"], max_grad_norm=o["max_grad_norm"],
+                           seed=0, max_steps=2, logging_steps=1, lr_scheduler_type="constant")
+    coll = LlavaDPODataCollatorWithPadding(pad_token_id=0, label_pad_token_id=-100)
+    tr = LlavaDPOTrainer(model, None, cfg["beta"], 0, "sigmoid", args, coll, -100, 0, "keep_end", ds, None, None,
+                         precompute_ref_log_probs=True)
+    assert tr.ref_model is None
+    tr.train()
+    got = torch.tensor([[r["reference_chosen_logps"] for r in tr.train_dataset], [r["reference_rejected_logps"] for r in tr.train_dataset]])
+    exp = t(z, "policy_logps").view(2, -1)             # the policy's initial weights are the reference
+    assert float((got - exp).abs().max()) < TOL_LOGPS_FP32
+    # first logged loss: policy == reference -> ln 2 (up to the bf16 noise between two evaluations of the same weights)
+    assert abs(tr.log_history[0]["loss"] - math.log(2.0)) < 2e-3, tr.log_history[0]
+    assert len(tr.log_history) == 2 and all(math.isfinite(h["loss"]) for h in tr.log_history)

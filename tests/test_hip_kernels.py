@@ -41,7 +41,9 @@ def check(a, b, tol, what=""):
 # ---------------------------------------------------------------------------------------------------- GEMM
 GEMM_SHAPES = [(256, 256, 128), (128, 128, 64), (200, 136, 72), (1000, 512, 320), (96, 1032, 256), (2048, 4096, 1024),
                # >= 192 tiles of 256x256: the LDS-DMA 256-tile kernel (ragged M/N edges, K = one / odd number of tiles)
-               (4096, 3072, 256), (4000, 3336, 192), (3592, 4104, 64), (12792, 4096, 320)]
+               (4096, 3072, 256), (4000, 3336, 192), (3592, 4104, 64), (12792, 4096, 320),
+               # K tail of the k-contiguous operands (K % 64 = 8): the last K tile takes the zero-filling DMA path
+               (4096, 3072, 328)]
 
 
 @pytest.mark.parametrize("layout", [0, 1, 2])

@@ -164,6 +164,8 @@ class VLDPOTrainer:
             raise NotImplementedError("encoder-decoder models are not on the MI355X DPO path")
         self.generate_during_eval = generate_during_eval
         self.precompute_ref_log_probs = precompute_ref_log_probs
+        self._precomputed_train_ref_log_probs = False
+        self._precomputed_eval_ref_log_probs = False
         self.reference_free = reference_free
         self.dataset_num_proc = dataset_num_proc
         self.callbacks = list(callbacks or [])
@@ -463,6 +465,40 @@ class VLDPOTrainer:
         loss.backward()
         return loss.detach() / ga
 
+    # ------------------------------------------------------------------------------------------ reference pre-pass
+    def compute_reference_log_probs(self, padded_batch: Dict) -> Tuple[torch.Tensor, torch.Tensor]:
+        """trl==0.8.1 DPOTrainer.compute_reference_log_probs: reference log-probs of one collated batch, no grad.  Without
+        a ref_model the policy itself is the reference (its adapters disabled if it is a peft model): the pre-pass runs
+        before the first optimizer step, so these are the initial weights."""
+        with torch.no_grad():
+            if self.ref_model is None:
+                with self.null_ref_context():
+                    was_training = self.model.training
+                    self.model.eval()
+                    rc, rr, _, _ = self.concatenated_forward(self.model, padded_batch)
+                    self.model.train(was_training)
+            else:
+                rc, rr, _, _ = self.concatenated_forward(self.ref_model, padded_batch)
+        return rc, rr
+
+    def precompute_reference_log_probs(self, dataset, batch_size: Optional[int] = None):
+        """trl==0.8.1 get_train_dataloader / get_eval_dataloader with precompute_ref_log_probs=True: one no-grad pass over
+        the tokenised dataset, the two log-probs are stored on every row as `reference_chosen_logps` /
+        `reference_rejected_logps`; the collator turns them into float tensors and the training step then skips the
+        reference forward (21 % of the step at the 7B configuration).  Every rank walks the whole dataset, as in trl."""
+        if dataset is None or not len(dataset) or "reference_chosen_logps" in dataset[0]:
+            return dataset
+        bs = int(batch_size or getattr(self.args, "per_device_eval_batch_size", None) or
+                 getattr(self.args, "per_device_train_batch_size", 4))
+        for i in range(0, len(dataset), bs):
+            rows = dataset[i:i + bs]
+            batch = self._prepare_inputs(self.data_collator(rows))
+            rc, rr = self.compute_reference_log_probs(batch)
+            rc, rr = rc.float().cpu().tolist(), rr.float().cpu().tolist()
+            for r, c, j in zip(rows, rc, rr):
+                r["reference_chosen_logps"], r["reference_rejected_logps"] = c, j
+        return dataset
+
     def get_train_batches(self, epoch: int):
         bs = int(getattr(self.args, "per_device_train_batch_size", 4))
         world, rank = _world(), _rank()
@@ -497,6 +533,9 @@ class VLDPOTrainer:
         epochs = float(getattr(a, "num_train_epochs", 1.0))
         total = max_steps if max_steps > 0 else int(math.ceil(per_epoch * epochs))
         logging_steps = max(1, int(getattr(a, "logging_steps", 10) or 10))
+        if self.precompute_ref_log_probs and not self._precomputed_train_ref_log_probs:
+            self.precompute_reference_log_probs(self.train_dataset)
+            self._precomputed_train_ref_log_probs = True
         eng.init_optimizer() if eng.master is None else None
         eng.zero_grad()
         step, micro, ep = 0, 0, 0
