@@ -668,3 +668,20 @@ def test_gemm_peeled_rows_split_k(hip, layout):
     hip.call("vlr_gemm_bf16_scaled", layout, a, Bm, c, bias, res, M, N, K, K, K if layout == 0 else N, N, N, 0, 1, 0, 0.5)
     check(c, ref, 8e-3, f"peel + split-K layout {layout}")
     check(c[-504:], ref[-504:], 8e-3, "peeled rows")
+
+
+@pytest.mark.parametrize("shape", [(3592, 3336, 192), (4344, 4352, 256)])
+@pytest.mark.parametrize("layout", [0, 2])
+def test_gemm_accumulate_odd_tile_counts(hip, layout, shape):
+    """210 tiles (one per workgroup) and 289 tiles (persistent workgroups, 289 % 8 = 1): every tile is computed exactly once -
+    a tile visited twice would show up as a doubled accumulate."""
+    M, N, K = shape
+    a = rnd(M, K, seed=1, scale=0.5)
+    b = rnd(N, K, seed=2, scale=0.5)
+    c0 = rnd(M, N, seed=3)
+    ref = c0.float() + a.float() @ b.float().t()
+    A = a if layout != 2 else a.t().contiguous()
+    Bm = b if layout == 0 else b.t().contiguous()
+    c = c0.clone()
+    hip.call("vlr_gemm_bf16", layout, A, Bm, c, None, None, M, N, K, K if layout != 2 else M, K if layout == 0 else N, N, 0, 0, 1, 0)
+    check(c, ref, 8e-3, f"accumulate {shape} layout {layout}")

@@ -33,7 +33,8 @@
 #define PK 64
 #define HALF_BYTES (128 * PK * 2)    // 16 KiB
 #define BUF_BYTES (4 * HALF_BYTES)   // A-lo | A-hi | B-lo | B-hi
-#define P_LDS_BYTES (2 * BUF_BYTES)  // 128 KiB
+#define C_STRIDE 528                 // bytes per row of the bf16 C image (256 cols + 16 B pad: conflict-free 8-byte writes)
+#define P_LDS_BYTES (256 * C_STRIDE)  // 132 KiB: the two K-tile buffers (128 KiB) / the epilogue's C image
 
 typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
@@ -139,20 +140,31 @@ template <bool A_KS, bool B_KS, int ABL = 0>
 __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_t* __restrict__ zero16) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // P_LDS_BYTES
     const int t = threadIdx.x;
-    const int lane = t & 63;
+    const int lane0 = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     // consume the kernel arguments here: otherwise the s_load of `zero16` is first waited for (lgkmcnt(0)) inside the K loop,
     // in front of the phase-1 DMA, and drains the 12 fragment reads every iteration
     asm volatile("" ::"s"(zero16), "s"(p.A), "s"(p.B), "s"(p.K), "s"(p.M), "s"(p.N), "s"(p.lda), "s"(p.ldb));
 
-    // ---- XCD-aware, grouped tile map (bijective for any tile count)
+    // ---- persistent workgroups: the grid is min(#tiles, #CUs) and every workgroup walks the tiles of ITS XCD (block b sits on
+    // XCD b % 8) in steps of gridDim/8.  A finished tile's global stores drain while the next tile's first K tiles are
+    // fetched; a workgroup that ends instead holds its CU (LDS) until the stores have landed and the next one starts cold:
+    // 10-12 us per tile, measured (K sweep: 0.23 ms of fixed cost per 2304-tile launch).
     const int tiles_m = (p.M + PT - 1) / PT, tiles_n = (p.N + PT - 1) / PT;
     const int nwg = tiles_m * tiles_n;
+    for (int titer = 0;; ++titer) {
+    // per-tile opaque copy of the lane id: keeps hipcc from hoisting every lane-derived address out of the tile loop (it did,
+    // and spilled 100-200 bytes per lane into the K loop)
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
     int pid;
     {
-        const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+        // gridDim == nwg: one tile per workgroup (any count); gridDim < nwg: persistent, gridDim is a multiple of 8
+        if (titer > 0 && (int)gridDim.x >= nwg) break;
+        const int b = blockIdx.x, xcd = b & 7, idx = (b >> 3) + titer * ((int)gridDim.x >> 3);
         const int q = nwg >> 3, rem = nwg & 7;
+        if (idx >= q + (xcd < rem ? 1 : 0)) break;
         pid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
     }
     const int GROUP = 8;
@@ -234,7 +246,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     using FAST = std::true_type;
     stage(0, H_BLO{}, SLOW{}); stage(0, H_ALO{}, SLOW{}); stage(0, H_BHI{}, SLOW{}); stage(0, H_AHI{}, SLOW{});
     stage(1, H_BLO{}, SLOW{}); stage(1, H_ALO{}, SLOW{}); stage(1, H_BHI{}, SLOW{});
-    if (nt >= 2) PWAIT_VM(6); else PWAIT_VM(0);
+    // (from the second tile on the previous tile's stores are still in flight and vmcnt counts them too: wait for everything)
+    if (titer == 0 && nt >= 2) PWAIT_VM(6); else PWAIT_VM(0);
     PBAR();
     if (wr == 1) PBAR();          // waves 4-7 run one barrier behind waves 0-3
 
@@ -312,7 +325,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                 \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                    \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                    \
-            acc[a_][i][b_][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_[i][ks], B_[j][ks], acc[a_][i][b_][j], 0, 0, 0); \
+            acc[a_][i][b_][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B_[j][ks], A_[i][ks], acc[a_][i][b_][j], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                                                   \
     } while (0)
 
@@ -368,8 +381,69 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     if (wr == 0) PBAR();          // balance the extra barrier of waves 4-7
     __syncthreads();
 
-    // ---- epilogue: one 64x32 quadrant at a time through a wave-private LDS patch (8 KiB), 16-byte global accesses
-    constexpr int PS = 36;   // patch row stride in floats: +4 rows = 144 floats = 16 banks -> conflict-free 16x16 tile writes
+    // ---- epilogue.  The MFMAs were issued as (B fragment, A fragment), i.e. they accumulated C^T tiles: lane l of a 16x16
+    // tile holds C[m = l&15][n = 4*(l>>4) .. +3] - four CONSECUTIVE columns of one row.
+    const int lm = lane & 15, lq = lane >> 4;
+    const bool skip_epilogue = (ABL & 8) && p.alpha != 12345.f;   // diagnostics: no epilogue (keeps the accumulators live)
+    if (skip_epilogue) {
+    } else if (!p.out_f32) {
+        // bf16 output: every wave applies the fp32 epilogue to its quadrants (alpha, bias, activation, residual, accumulate:
+        // 8-byte global reads), rounds ONCE and writes 8-byte pieces of a bf16 image of the whole 256x256 C tile in LDS; after a
+        // barrier the block copies the image out as full 512-byte rows (two rows per wave instruction, 16 B per lane).
+        // (The per-quadrant version wrote 64-byte row pieces straight from each wave: 12 us per tile, measured by ablation.)
+        const bf16_t* Cold = reinterpret_cast<const bf16_t*>(p.C);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int tn_ = b * 128 + wc * 32 + j * 16 + 4 * lq;      // column inside the tile
+                    const int gn = n0 + tn_;
+                    const bool nok = gn + 4 <= p.N;
+                    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (p.bias && nok) {
+                        const u32x2 w = *reinterpret_cast<const u32x2*>(p.bias + gn);
+                        bv[0] = bf16lo(w[0]); bv[1] = bf16hi(w[0]); bv[2] = bf16lo(w[1]); bv[3] = bf16hi(w[1]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int tm_ = a * 128 + wr * 64 + i * 16 + lm;      // row inside the tile
+                        const int gm = m0 + tm_;
+                        f32x4 v = acc[a][i][b][j];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = apply_act(p.alpha * v[e] + bv[e], p.act);
+                        if (gm < p.M && nok) {
+                            if (p.residual) {
+                                const u32x2 w = *reinterpret_cast<const u32x2*>(p.residual + (size_t)gm * p.ldr + gn);
+                                v[0] += bf16lo(w[0]); v[1] += bf16hi(w[0]); v[2] += bf16lo(w[1]); v[3] += bf16hi(w[1]);
+                            }
+                            if (p.accumulate) {
+                                const u32x2 w = *reinterpret_cast<const u32x2*>(Cold + (size_t)gm * p.ldc + gn);
+                                v[0] += bf16lo(w[0]); v[1] += bf16hi(w[0]); v[2] += bf16lo(w[1]); v[3] += bf16hi(w[1]);
+                            }
+                        }
+                        u32x2 o;
+                        o[0] = pack_bf16(v[0], v[1]);
+                        o[1] = pack_bf16(v[2], v[3]);
+                        *reinterpret_cast<u32x2*>(smem + tm_ * C_STRIDE + tn_ * 2) = o;
+                    }
+                }
+            }
+        __syncthreads();
+        bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+        const int cch = lane & 31;                     // 16-byte chunk of the 512-byte row
+        const int gn = n0 + cch * 8;
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int row = it * 16 + wave * 2 + (lane >> 5);
+            const int gm = m0 + row;
+            if (gm < p.M && gn + 8 <= p.N)
+                *reinterpret_cast<u32x4*>(C + (size_t)gm * p.ldc + gn) = *reinterpret_cast<const u32x4*>(smem + row * C_STRIDE + cch * 16);
+        }
+    } else {
+    // fp32 output (lm-head logits): one 64x32 quadrant at a time through a wave-private fp32 patch, 16-byte global accesses
+    constexpr int PS = 36;   // patch row stride in floats
     float* patch = reinterpret_cast<float*>(smem) + wave * (64 * PS);
     auto quadrant = [&](auto ac, auto bc) {
         constexpr int a = decltype(ac)::value, b = decltype(bc)::value;
@@ -377,77 +451,37 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    patch[(i * 16 + 4 * (lane >> 4) + r) * PS + j * 16 + (lane & 15)] = acc[a][i][b][j][r];
+                *reinterpret_cast<f32x4*>(patch + (i * 16 + lm) * PS + j * 16 + 4 * lq) = acc[a][i][b][j];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const int gm0 = m0 + a * 128 + wr * 64, gn0 = n0 + b * 128 + wc * 32;
-        if (!p.out_f32) {
-            bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
-            const int cq = (lane & 3) * 8;
-            const int gn = gn0 + cq;
-            float bv[8];
+        float* C = reinterpret_cast<float*>(p.C);
+        const int cq = (lane & 7) * 4;
+        const int gn = gn0 + cq;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && gn + 4 <= p.N) {
+            const u32x2 w = *reinterpret_cast<const u32x2*>(p.bias + gn);
+            bv[0] = bf16lo(w[0]); bv[1] = bf16hi(w[0]); bv[2] = bf16lo(w[1]); bv[3] = bf16hi(w[1]);
+        }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) bv[e] = 0.f;
-            if (p.bias && gn + 8 <= p.N) unpack8(*reinterpret_cast<const u32x4*>(p.bias + gn), bv);
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 8 + (lane >> 3);
+            const int gm = gm0 + row;
+            if (gm < p.M && gn + 4 <= p.N) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(patch + row * PS + cq);
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int row = it * 16 + (lane >> 2);
-                const int gm = gm0 + row;
-                if (gm < p.M && gn + 8 <= p.N) {
-                    float v[8];
-                    const f32x4 s0 = *reinterpret_cast<const f32x4*>(patch + row * PS + cq);
-                    const f32x4 s1 = *reinterpret_cast<const f32x4*>(patch + row * PS + cq + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] = s0[e]; v[4 + e] = s1[e]; }
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = apply_act(p.alpha * v[e] + bv[e], p.act);
-                    if (p.residual) {
-                        float rv[8];
-                        unpack8(*reinterpret_cast<const u32x4*>(p.residual + (size_t)gm * p.ldr + gn), rv);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += rv[e];
-                    }
-                    bf16_t* dst = C + (size_t)gm * p.ldc + gn;
-                    if (p.accumulate) {
-                        float ov[8];
-                        unpack8(*reinterpret_cast<const u32x4*>(dst), ov);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += ov[e];
-                    }
-                    *reinterpret_cast<u32x4*>(dst) = pack8(v);
+                for (int e = 0; e < 4; ++e) v[e] = apply_act(p.alpha * v[e] + bv[e], p.act);
+                if (p.residual) {
+                    const u32x2 w = *reinterpret_cast<const u32x2*>(p.residual + (size_t)gm * p.ldr + gn);
+                    v[0] += bf16lo(w[0]); v[1] += bf16hi(w[0]); v[2] += bf16lo(w[1]); v[3] += bf16hi(w[1]);
                 }
-            }
-        } else {
-            float* C = reinterpret_cast<float*>(p.C);
-            const int cq = (lane & 7) * 4;
-            const int gn = gn0 + cq;
-            float bv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias && gn + 4 <= p.N) {
-                const u32x2 w = *reinterpret_cast<const u32x2*>(p.bias + gn);
-                bv[0] = bf16lo(w[0]); bv[1] = bf16hi(w[0]); bv[2] = bf16lo(w[1]); bv[3] = bf16hi(w[1]);
-            }
+                float* dst = C + (size_t)gm * p.ldc + gn;
+                if (p.accumulate) {
+                    const f32x4 o = *reinterpret_cast<const f32x4*>(dst);
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int row = it * 8 + (lane >> 3);
-                const int gm = gm0 + row;
-                if (gm < p.M && gn + 4 <= p.N) {
-                    f32x4 v = *reinterpret_cast<const f32x4*>(patch + row * PS + cq);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = apply_act(p.alpha * v[e] + bv[e], p.act);
-                    if (p.residual) {
-                        const u32x2 w = *reinterpret_cast<const u32x2*>(p.residual + (size_t)gm * p.ldr + gn);
-                        v[0] += bf16lo(w[0]); v[1] += bf16hi(w[0]); v[2] += bf16lo(w[1]); v[3] += bf16hi(w[1]);
-                    }
-                    float* dst = C + (size_t)gm * p.ldc + gn;
-                    if (p.accumulate) {
-                        const f32x4 o = *reinterpret_cast<const f32x4*>(dst);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += o[e];
-                    }
-                    *reinterpret_cast<f32x4*>(dst) = v;
+                    for (int e = 0; e < 4; ++e) v[e] += o[e];
                 }
+                *reinterpret_cast<f32x4*>(dst) = v;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -459,6 +493,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     quadrant(I0{}, I1{});
     quadrant(I1{}, I0{});
     quadrant(I1{}, I1{});
+    }
+    __syncthreads();              // every wave is done with the LDS image / patches before the next tile's DMA lands
+    }   // persistent tile loop
 }
 
 // returns false when the problem does not qualify (caller falls back to the staggered / 128x128 kernels)
@@ -476,8 +513,18 @@ bool vlr_gemm256p_try_launch(int layout, const GemmParams& p, hipStream_t stream
         }
     }
     if (!((mode >> layout) & 1)) return false;
-    const int tiles = ((p.M + PT - 1) / PT) * ((p.N + PT - 1) / PT);
-    if (tiles < 192) return false;
+    const int ntiles = ((p.M + PT - 1) / PT) * ((p.N + PT - 1) / PT);
+    if (ntiles < 192) return false;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+        n_cu &= ~7;                     // whole XCD octets (256 on MI355X)
+        const char* e = getenv("VLR_GEMM_PERSIST");
+        if (e && e[0] == '0') n_cu = 1 << 30;
+    }
+    const int tiles = ntiles < n_cu ? ntiles : n_cu;   // grid size: persistent workgroups when there are more tiles than CUs
     // 16-byte DMA source alignment: k-contiguous operands need ld % 8 and K % 8 (checked by the caller), k-strided
     // operands ld % 8 and at least 8 columns; pointers 16-byte aligned
     const bool a_ks = layout == 2, b_ks = layout != 0;
@@ -491,7 +538,7 @@ bool vlr_gemm256p_try_launch(int layout, const GemmParams& p, hipStream_t stream
     if (layout == 0 && abl) {
 #define PABL(n) case n: hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, n>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES); \
         hipLaunchKernelGGL((gemm256p_kernel<false, false, n>), dim3(tiles), dim3(512), P_LDS_BYTES, stream, p, (const bf16_t*)zero16); return true;
-        switch (abl) { PABL(1) PABL(3) PABL(4) PABL(5) PABL(7) default: break; }   // 2 and 6 spill
+        switch (abl) { PABL(1) PABL(4) PABL(5) PABL(8) default: break; }   // 2, 3, 6, 7 (no fragment reads) spill; 8 = no epilogue
 #undef PABL
     }
     if (layout == 0) hipLaunchKernelGGL((gemm256p_kernel<false, false>), dim3(tiles), dim3(512), P_LDS_BYTES, stream, p, (const bf16_t*)zero16);
