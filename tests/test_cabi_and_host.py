@@ -201,3 +201,40 @@ def test_registry_surface():
     assert params[:13] == ["model", "ref_model", "beta", "label_smoothing", "loss_type", "args", "data_collator",
                            "label_pad_token_id", "padding_value", "truncation_mode", "train_dataset", "eval_dataset", "processor"]
     assert len(params) == 32 and params[-1] == "reference_free"
+
+
+def test_prefetch_loader_order_depth_and_errors():
+    """input pipeline: background collation keeps order, runs at most `depth` batches ahead, surfaces
+    collator exceptions on the consuming thread and stops its thread when the consumer stops early."""
+    import threading
+    import time
+    from vlrlhf.base.loader import PrefetchLoader
+    made = []
+
+    def rows():
+        for i in range(6):
+            yield [dict(i=i)]
+
+    def collate(r):
+        made.append(r[0]["i"])
+        return dict(x=torch.full((2,), r[0]["i"]), meta=[r[0]["i"]], img_input_dict=dict(pixel_values=torch.zeros(1, 3, 2, 2)))
+
+    out = []
+    for b in PrefetchLoader(rows, collate, None, depth=2):
+        time.sleep(0.02)
+        out.append(int(b["x"][0]))
+        assert len(made) <= len(out) + 3            # queue (2) + the one being collated
+    assert out == list(range(6))
+
+    def bad(r):
+        if r[0]["i"] == 2:
+            raise ValueError("boom")
+        return dict(x=torch.zeros(1))
+    with pytest.raises(ValueError, match="boom"):
+        list(PrefetchLoader(rows, bad, None, depth=2))
+    n0 = threading.active_count()
+    it = iter(PrefetchLoader(rows, collate, None, depth=1))
+    next(it)
+    it.close()
+    time.sleep(0.3)
+    assert threading.active_count() <= n0

@@ -499,14 +499,25 @@ class VLDPOTrainer:
                 r["reference_chosen_logps"], r["reference_rejected_logps"] = c, j
         return dataset
 
-    def get_train_batches(self, epoch: int):
+    def _train_row_batches(self, epoch: int):
         bs = int(getattr(self.args, "per_device_train_batch_size", 4))
         world, rank = _world(), _rank()
         idx = list(range(len(self.train_dataset)))
         random.Random(int(getattr(self.args, "seed", 42)) + epoch).shuffle(idx)
         idx = idx[rank::world]                               # DistributedSampler semantics (ddp.yaml: MULTI_GPU)
         for i in range(0, len(idx) - bs + 1, bs):
-            yield self.data_collator([self.train_dataset[j] for j in idx[i:i + bs]])
+            yield [self.train_dataset[j] for j in idx[i:i + bs]]
+
+    def get_train_batches(self, epoch: int):
+        """collated batches of one epoch.  The collator (image decode + CLIP preprocess) runs `dataloader_prefetch` batches
+        ahead on a background thread and the H2D copy goes through a copy stream (base/loader.py); 0 = collate inline."""
+        depth = int(getattr(self.args, "dataloader_prefetch", 2) or 0)
+        if depth <= 0:
+            for rows in self._train_row_batches(epoch):
+                yield self.data_collator(rows)
+            return
+        from .loader import PrefetchLoader
+        yield from PrefetchLoader(lambda: self._train_row_batches(epoch), self.data_collator, self.accelerator.device, depth)
 
     def lr_at(self, step: int, total: int) -> float:
         """transformers get_scheduler('cosine' | 'linear' | 'constant') with warmup_ratio / warmup_steps."""
