@@ -1,6 +1,8 @@
 // Integer / scalar side of the DPO hot path (gfx950): image-text merge index + gather/scatter, response-row
 // compaction, per-token log-prob from logits, sequence sums, the DPO loss (all five reference loss types) and the
 // flat-buffer optimizer (grad norm, clip coefficient, fused AdamW).
+#include <stdlib.h>
+
 #include "common.h"
 
 #define IGNORE_INDEX (-100)
@@ -88,6 +90,114 @@ __global__ void merge_index_kernel(const long* __restrict__ ids, const long* __r
     }
     atomicAdd(&info[0], k);   // host compares with n_feat_rows * dup (reference :90-94 raises ValueError)
     (void)total_slots;
+}
+
+// Block-parallel version of the same map: one 256-thread workgroup per batch row, the three serial walks (token -> new
+// position, free position -> image-slot rank, mask -> position id) become chunked block scans.  Bit-identical outputs
+// (tests/test_hip_kernels.py compares both with the golden merge); the serial kernel above stays as the Bn > 64 path.
+__device__ __forceinline__ int block_exclusive_scan256(int v, int* sh, int* total) {
+    const int t = threadIdx.x;
+    __syncthreads();
+    sh[t] = v;
+    __syncthreads();
+#pragma unroll
+    for (int o = 1; o < 256; o <<= 1) {
+        const int add = t >= o ? sh[t - o] : 0;
+        __syncthreads();
+        sh[t] += add;
+        __syncthreads();
+    }
+    const int incl = sh[t];
+    *total = sh[255];
+    return incl - v;
+}
+__global__ __launch_bounds__(256) void merge_index_block_kernel(const long* __restrict__ ids, const long* __restrict__ amask,
+                                                                const long* __restrict__ labels, int Bn, int T, int S, int P,
+                                                                int image_token, int pad_token, int n_feat_rows, int dup,
+                                                                int* __restrict__ src, int* __restrict__ out_mask,
+                                                                long* __restrict__ out_labels, int* __restrict__ out_pos,
+                                                                unsigned char* __restrict__ img_map, int* __restrict__ inv_map,
+                                                                int* __restrict__ info) {
+    __shared__ int sh[256];
+    __shared__ int s_cnt[64];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int not_left = 0;
+    if (t < Bn) not_left = ids[(size_t)t * T + T - 1] == pad_token;          // reference :39
+    const int s_left = !__syncthreads_or(not_left);
+    for (int i = wave; i < Bn; i += 4) {                                      // image tokens per row
+        int c = 0;
+        for (int k = lane; k < T; k += 64) c += ids[(size_t)i * T + k] == image_token;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+        if (lane == 0) s_cnt[i] = c;
+    }
+    __syncthreads();
+    int slot_base = 0;
+    for (int i = 0; i < b; ++i) {
+        const int pad_i = S - 1 - (T - 1 + s_cnt[i] * (P - 1));
+        slot_base += (S - (T - s_cnt[i])) - pad_i;
+    }
+    const int nimg = s_cnt[b];
+    const int nb_pad = S - 1 - (T - 1 + nimg * (P - 1));
+    const int shift = s_left ? nb_pad : 0;
+    int* srow = src + (size_t)b * S;
+    int* mrow = out_mask + (size_t)b * S;
+    long* lrow = out_labels + (size_t)b * S;
+    unsigned char* irow = img_map + (size_t)b * S;
+    for (int k = t; k < S; k += 256) {
+        srow[k] = SRC_ZERO;
+        mrow[k] = 0;
+        lrow[k] = IGNORE_INDEX;
+        irow[k] = 0;
+    }
+    // pass 1: text tokens -> new positions (np = inclusive prefix of {P for <image>, 1 otherwise} - 1)
+    const int ct = (T + 255) / 256, t0 = min(T, t * ct), t1 = min(T, t0 + ct);
+    int inc = 0, tot;
+    for (int k = t0; k < t1; ++k) inc += ids[(size_t)b * T + k] == image_token ? P : 1;
+    int np = block_exclusive_scan256(inc, sh, &tot) - 1;        // also the barrier after the row initialisation
+    for (int k = t0; k < t1; ++k) {
+        const long id = ids[(size_t)b * T + k];
+        np += (id == image_token) ? P : 1;
+        if (id != image_token) {
+            const int d = np + shift;
+            srow[d] = (id == pad_token) ? SRC_ZERO + 1 : k;      // SRC_ZERO+1: written-but-zeroed (reference step 6)
+            mrow[d] = (int)amask[(size_t)b * T + k];
+            lrow[d] = labels ? labels[(size_t)b * T + k] : IGNORE_INDEX;
+        }
+    }
+    __syncthreads();
+    // pass 2: free positions with rank >= nb_pad are image slots, filled in order
+    const int cs = (S + 255) / 256, s0 = min(S, t * cs), s1 = min(S, s0 + cs);
+    int nfree = 0;
+    for (int k = s0; k < s1; ++k) nfree += srow[k] == SRC_ZERO;
+    int total_free;
+    int rank = block_exclusive_scan256(nfree, sh, &total_free);
+    for (int k = s0; k < s1; ++k) {
+        const int v = srow[k];
+        if (v == SRC_ZERO) {
+            if (rank >= nb_pad) {
+                const int g = slot_base + (rank - nb_pad);       // global rank over the whole (2B) batch
+                const int f = g % n_feat_rows;                    // duplicated images share one feature row
+                srow[k] = -(f + 1);
+                if (g / n_feat_rows < dup) inv_map[(size_t)(g / n_feat_rows) * n_feat_rows + f] = b * S + k;
+                mrow[k] = 1;
+                irow[k] = 1;
+            }
+            ++rank;
+        } else if (v == SRC_ZERO + 1) {
+            srow[k] = SRC_ZERO;
+        }
+    }
+    if (t == 0) atomicAdd(&info[0], max(0, total_free - max(nb_pad, 0)));   // host compares with n_feat_rows * dup
+    __syncthreads();
+    // position ids = cumsum(mask) - 1, 1 where masked (reference :98)
+    int nm = 0, tm;
+    for (int k = s0; k < s1; ++k) nm += mrow[k] != 0;
+    int c = block_exclusive_scan256(nm, sh, &tm);
+    for (int k = s0; k < s1; ++k) {
+        c += mrow[k] != 0;
+        out_pos[(size_t)b * S + k] = mrow[k] ? c - 1 : 1;
+    }
 }
 
 // embeds[b][s][:] = embed_tokens[ids[b][t]] | image_features[f] | 0
@@ -384,8 +494,14 @@ extern "C" int vlr_merge_index(const long* input_ids, const long* attention_mask
     VLR_REQUIRE(n_feat_rows > 0 && dup >= 1, "vlr_merge_index: n_feat_rows/dup");
     hipMemsetAsync(inv_map, 0xff, (size_t)dup * n_feat_rows * sizeof(int), st);
     hipMemsetAsync(info, 0, 2 * sizeof(int), st);
-    hipLaunchKernelGGL(merge_index_kernel, dim3(1), dim3(1024), 0, st, input_ids, attention_mask, labels, Bn, T, S, P,
-                       image_token, pad_token, n_feat_rows, dup, src, out_mask, out_labels, out_pos, img_map, inv_map, info);
+    static int serial = -1;
+    if (serial < 0) { const char* e = getenv("VLR_MERGE_SERIAL"); serial = (e && e[0] == '1') ? 1 : 0; }
+    if (Bn <= 64 && !serial)
+        hipLaunchKernelGGL(merge_index_block_kernel, dim3(Bn), dim3(256), 0, st, input_ids, attention_mask, labels, Bn, T, S, P,
+                           image_token, pad_token, n_feat_rows, dup, src, out_mask, out_labels, out_pos, img_map, inv_map, info);
+    else
+        hipLaunchKernelGGL(merge_index_kernel, dim3(1), dim3(1024), 0, st, input_ids, attention_mask, labels, Bn, T, S, P,
+                           image_token, pad_token, n_feat_rows, dup, src, out_mask, out_labels, out_pos, img_map, inv_map, info);
     return vlr_check_launch("vlr_merge_index");
 }
 extern "C" int vlr_merge_fwd(const int* src, const long* input_ids, const void* embed_table, const void* feats,
