@@ -1,0 +1,23 @@
+#!/bin/bash
+# PMC profile of the decoder attention kernels (tools/attn_time.py)
+cd /root/repo
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_ACTIVE_INST_MISC"; do
+  tag=$(echo $set | cut -d' ' -f1)
+  rocprofv3 --pmc $set --kernel-trace -d gpurun_out/apmc_$tag -o r -f csv -- python tools/attn_time.py 3 > gpurun_out/apmc_$tag.log 2>&1
+  python - <<PY
+import csv,glob,collections
+fs=glob.glob("gpurun_out/apmc_$tag/**/*counter_collection.csv",recursive=True)
+acc=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.Counter()
+for f in fs:
+    for r in csv.DictReader(open(f)):
+        k=r["Kernel_Name"][:40]
+        acc[k][r["Counter_Name"]]+=float(r["Counter_Value"]); n[(k,r["Counter_Name"])]+=1
+for k,d in acc.items():
+    if "attn" not in k: continue
+    print(k)
+    for c,v in d.items(): print("   %-34s %.4g per launch"%(c, v/max(1,n[(k,c)])))
+PY
+done
