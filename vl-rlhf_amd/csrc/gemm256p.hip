@@ -136,7 +136,10 @@ __device__ __forceinline__ bf16x8 pfrag_ks(const char* half, int cbase, int s, i
 #define PWAIT_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
 #define PWAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-template <bool A_KS, bool B_KS, int ABL = 0>
+// CONT = true: continuous pipeline across the output tiles of a persistent workgroup (plain bf16 epilogue only): the last K tiles
+// of tile i stage the first K tiles of tile i+1 (same slots, same counted wait), the epilogue stores straight from the
+// accumulator registers (8 bytes per lane, no LDS, no barrier) and the K loop of tile i+1 starts with its data resident.
+template <bool A_KS, bool B_KS, int ABL = 0, bool CONT = false>
 __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_t* __restrict__ zero16) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // P_LDS_BYTES
     const int t = threadIdx.x;
@@ -153,28 +156,33 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     // 10-12 us per tile, measured (K sweep: 0.23 ms of fixed cost per 2304-tile launch).
     const int tiles_m = (p.M + PT - 1) / PT, tiles_n = (p.N + PT - 1) / PT;
     const int nwg = tiles_m * tiles_n;
+    // tile `titer` of this workgroup -> (m0, n0); false when the workgroup has no such tile
+    auto tile_coords = [&](int titer, int& m0_, int& n0_) -> bool {
+        // gridDim == nwg: one tile per workgroup (any count); gridDim < nwg: persistent, gridDim is a multiple of 8
+        if (titer > 0 && (int)gridDim.x >= nwg) return false;
+        const int b = blockIdx.x, xcd = b & 7, idx = (b >> 3) + titer * ((int)gridDim.x >> 3);
+        const int q = nwg >> 3, rem = nwg & 7;
+        if (idx >= q + (xcd < rem ? 1 : 0)) return false;
+        const int pid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+        const int GROUP = 8;
+        const int per_group = GROUP * tiles_n;
+        const int gid = pid / per_group;
+        const int first_m = gid * GROUP;
+        const int gsz = min(tiles_m - first_m, GROUP);
+        m0_ = (first_m + (pid % per_group) % gsz) * PT;
+        n0_ = ((pid % per_group) / gsz) * PT;
+        return true;
+    };
+    int parb = 0;                 // CONT: buffer parity of the current tile's K tile 0 (K tiles keep alternating across tiles)
     for (int titer = 0;; ++titer) {
     // per-tile opaque copy of the lane id: keeps hipcc from hoisting every lane-derived address out of the tile loop (it did,
     // and spilled 100-200 bytes per lane into the K loop)
     int lane = lane0;
     asm volatile("" : "+v"(lane));
-    int pid;
-    {
-        // gridDim == nwg: one tile per workgroup (any count); gridDim < nwg: persistent, gridDim is a multiple of 8
-        if (titer > 0 && (int)gridDim.x >= nwg) break;
-        const int b = blockIdx.x, xcd = b & 7, idx = (b >> 3) + titer * ((int)gridDim.x >> 3);
-        const int q = nwg >> 3, rem = nwg & 7;
-        if (idx >= q + (xcd < rem ? 1 : 0)) break;
-        pid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
-    }
-    const int GROUP = 8;
-    const int per_group = GROUP * tiles_n;
-    const int gid = pid / per_group;
-    const int first_m = gid * GROUP;
-    const int gsz = min(tiles_m - first_m, GROUP);
-    const int tm = first_m + (pid % per_group) % gsz;
-    const int tn = (pid % per_group) / gsz;
-    const int m0 = tm * PT, n0 = tn * PT;
+    int m0, n0, m0n = 0, n0n = 0;
+    if (!tile_coords(titer, m0, n0)) break;
+    const bool has_next = CONT && tile_coords(titer + 1, m0n, n0n);
+    const bool first = !CONT || titer == 0;
 
     f32x4 acc[2][4][2][2];   // [A half a][16-row tile i][B half b][16-col tile j]
 #pragma unroll
@@ -212,9 +220,25 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
         constexpr int h = decltype(hc)::value;
         constexpr bool fast = decltype(fastc)::value;
         if constexpr (abl_dma) { if (in_loop) return; }
-        if constexpr (!fast) { if (tile >= nt) return; }
+        if constexpr (!fast) {
+            if (tile >= nt) {
+                if constexpr (CONT) {      // the K loop runs on into the next output tile: its K tile (tile - nt), general path
+                    if (!has_next) return;
+                    char* dst = smem + ((tile + parb) & 1) * BUF_BYTES + h * HALF_BYTES;
+                    const int k0 = (tile - nt) * PK;
+                    if constexpr (h < 2) {
+                        if constexpr (A_KS) stage_ks(p.A, p.lda, m0n + h * 128, p.M, k0, p.K, zero16, dst, wave, lane);
+                        else stage_kc(p.A, p.lda, m0n + h * 128, p.M, k0, p.K, zero16, dst, wave, lane);
+                    } else {
+                        if constexpr (B_KS) stage_ks(p.B, p.ldb, n0n + (h - 2) * 128, p.N, k0, p.K, zero16, dst, wave, lane);
+                        else stage_kc(p.B, p.ldb, n0n + (h - 2) * 128, p.N, k0, p.K, zero16, dst, wave, lane);
+                    }
+                }
+                return;
+            }
+        }
         if (!fast && ktail && tile == nt - 1) {
-            char* dst = smem + (tile & 1) * BUF_BYTES + h * HALF_BYTES;
+            char* dst = smem + ((tile + parb) & 1) * BUF_BYTES + h * HALF_BYTES;
             const int k0 = tile * PK;
             if constexpr (h < 2) {
                 if constexpr (A_KS) stage_ks(p.A, p.lda, m0 + h * 128, p.M, k0, p.K, zero16, dst, wave, lane);
@@ -225,7 +249,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
             }
             return;
         }
-        const uint32_t dst = lds_wave + (tile & 1) * BUF_BYTES + h * HALF_BYTES;
+        const uint32_t dst = lds_wave + ((tile + parb) & 1) * BUF_BYTES + h * HALF_BYTES;
         if constexpr (h < 2) {
             const char* base = (const char*)p.A + (size_t)tile * stepA;
             lds_dma16_s(base, offA[h][0], dst);
@@ -244,12 +268,14 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     // ---- prologue: K tile 0 resident, the first three halves of tile 1 in flight
     using SLOW = std::false_type;
     using FAST = std::true_type;
-    stage(0, H_BLO{}, SLOW{}); stage(0, H_ALO{}, SLOW{}); stage(0, H_BHI{}, SLOW{}); stage(0, H_AHI{}, SLOW{});
-    stage(1, H_BLO{}, SLOW{}); stage(1, H_ALO{}, SLOW{}); stage(1, H_BHI{}, SLOW{});
-    // (from the second tile on the previous tile's stores are still in flight and vmcnt counts them too: wait for everything)
-    if (titer == 0 && nt >= 2) PWAIT_VM(6); else PWAIT_VM(0);
-    PBAR();
-    if (wr == 1) PBAR();          // waves 4-7 run one barrier behind waves 0-3
+    if (first) {
+        stage(0, H_BLO{}, SLOW{}); stage(0, H_ALO{}, SLOW{}); stage(0, H_BHI{}, SLOW{}); stage(0, H_AHI{}, SLOW{});
+        stage(1, H_BLO{}, SLOW{}); stage(1, H_ALO{}, SLOW{}); stage(1, H_BHI{}, SLOW{});
+        // (from the second tile on the previous tile's stores are still in flight and vmcnt counts them too: wait for everything)
+        if (titer == 0 && nt >= 2) PWAIT_VM(6); else PWAIT_VM(0);
+        PBAR();
+        if (wr == 1) PBAR();      // waves 4-7 run one barrier behind waves 0-3
+    }
 
     bf16x8 fa0[4][2], fa1[4][2], fb0[2][2], fb1[2][2];   // [16-row/col tile][k slice of 32]
     // Per-lane LDS read pointers into the CURRENT buffer's A-lo / B-lo half, loop carried and flipped by +-BUF_BYTES per K tile,
@@ -291,6 +317,13 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
         }
     }
     int flip = BUF_BYTES;
+    if (CONT && parb) {           // this tile's K tile 0 sits in buffer 1
+#pragma unroll
+        for (int q = 0; q < NPA; ++q) pa[q] += BUF_BYTES;
+#pragma unroll
+        for (int q = 0; q < NPB; ++q) pb[q] += BUF_BYTES;
+        flip = -BUF_BYTES;
+    }
     auto tr2 = [&](const char* q) {
         const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)q);
         const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(q + 4 * 256));
@@ -362,7 +395,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
         // ---------------- phase 4: no reads; stage B-hi of tile kt+2; the counted wait that makes tile kt+1 resident
         stage(kt + 2, H_BHI{}, fastc);
         PFENCE();
-        if (decltype(fastc)::value || kt + 2 < nt) PWAIT_VM(6); else PWAIT_VM(0);
+        if (decltype(fastc)::value || kt + 2 < nt || (CONT && has_next)) PWAIT_VM(6); else PWAIT_VM(0);
         LBAR();
         PMFMA(fa1, fb0, 1, 0);
         LBAR();
@@ -378,6 +411,34 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     for (; kt < n_fast; ++kt) ktile(kt, FAST{});
     for (; kt < nt; ++kt) ktile(kt, SLOW{});
 #undef PMFMA
+    if constexpr (CONT) {
+        // plain bf16 epilogue straight from the registers: lane (lm, lq) of tile (i, j) holds C[row lm][cols 4 lq .. +3]
+        bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+        const int lm_ = lane & 15, lq_ = lane >> 4;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int gm = m0 + a * 128 + wr * 64 + i * 16 + lm_;
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int gn = n0 + b * 128 + wc * 32 + j * 16 + 4 * lq_;
+                        const f32x4 v = acc[a][i][b][j];
+                        u32x2 o;
+                        o[0] = pack_bf16(p.alpha * v[0], p.alpha * v[1]);
+                        o[1] = pack_bf16(p.alpha * v[2], p.alpha * v[3]);
+                        if (gm < p.M && gn + 4 <= p.N) *reinterpret_cast<u32x2*>(C + (size_t)gm * p.ldc + gn) = o;
+                    }
+            }
+        parb = (parb + nt) & 1;
+        if (!has_next) {
+            if (wr == 0) PBAR();  // balance the extra barrier of waves 4-7
+            break;
+        }
+        continue;
+    }
     if (wr == 0) PBAR();          // balance the extra barrier of waves 4-7
     __syncthreads();
 
@@ -509,6 +570,9 @@ bool vlr_gemm256p_try_launch(int layout, const GemmParams& p, hipStream_t stream
             hipFuncSetAttribute((const void*)gemm256p_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES);
             hipFuncSetAttribute((const void*)gemm256p_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES);
             hipFuncSetAttribute((const void*)gemm256p_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES);
+            hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+            hipFuncSetAttribute((const void*)gemm256p_kernel<false, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+            hipFuncSetAttribute((const void*)gemm256p_kernel<true, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
             if (hipMalloc((void**)&zero16, 256) != hipSuccess || hipMemset(zero16, 0, 256) != hipSuccess) mode = 0;
         }
     }
@@ -540,6 +604,15 @@ bool vlr_gemm256p_try_launch(int layout, const GemmParams& p, hipStream_t stream
         hipLaunchKernelGGL((gemm256p_kernel<false, false, n>), dim3(tiles), dim3(512), P_LDS_BYTES, stream, p, (const bf16_t*)zero16); return true;
         switch (abl) { PABL(1) PABL(4) PABL(5) PABL(8) default: break; }   // 2, 3, 6, 7 (no fragment reads) spill; 8 = no epilogue
 #undef PABL
+    }
+    // continuous pipeline across tiles: persistent launch, plain bf16 epilogue (C = alpha * A B), at least 4 K tiles
+    static int cont = -1;
+    if (cont < 0) { const char* e = getenv("VLR_GEMM_CONT"); cont = (e && e[0] == '0') ? 0 : 1; }
+    if (cont && ntiles > tiles && !p.bias && !p.residual && !p.accumulate && !p.out_f32 && p.act == ACT_NONE && p.K >= 4 * PK && p.ldc % 4 == 0) {
+        if (layout == 0) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true>), dim3(tiles), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
+        else if (layout == 1) hipLaunchKernelGGL((gemm256p_kernel<false, true, 0, true>), dim3(tiles), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
+        else hipLaunchKernelGGL((gemm256p_kernel<true, true, 0, true>), dim3(tiles), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
+        return true;
     }
     if (layout == 0) hipLaunchKernelGGL((gemm256p_kernel<false, false>), dim3(tiles), dim3(512), P_LDS_BYTES, stream, p, (const bf16_t*)zero16);
     else if (layout == 1) hipLaunchKernelGGL((gemm256p_kernel<false, true>), dim3(tiles), dim3(512), P_LDS_BYTES, stream, p, (const bf16_t*)zero16);
