@@ -154,9 +154,10 @@ def main():
     tf = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_8phase.json")
     if os.path.exists(tf):
         traffic = round(json.load(open(tf))["gemm_hbm_bytes_per_launch"])
-    g_n = sum(prof[k][0] for k in ("gemm_nt", "gemm_nn", "gemm_tn"))
-    g_ms = sum(prof[k][1] for k in ("gemm_nt", "gemm_nn", "gemm_tn"))
-    g_flop = sum(prof[k][2] for k in ("gemm_nt", "gemm_nn", "gemm_tn"))
+    # roofline of the DOMINANT kernel: the 8-phase 256x256 GEMM alone (its launches are timed under their own id; the
+    # gemm_nt/nn/tn entries of per_kernel are whole vlr_gemm_bf16 calls incl. peeled rows and split-K reduces)
+    g_n, g_ms, g_flop = prof["gemm256p"]
+    all_ms = sum(prof[k][1] for k in ("gemm_nt", "gemm_nn", "gemm_tn"))
     g_bytes = 0.0   # algorithmic elements moved (A + B + C once) summed over the decoder GEMMs of the timed steps
     H_, I_, M_ = cfg["hidden"], cfg["inter"], 2 * a.pairs * (a.text_len - 1 + 576)
     per_shape = cfg["layers"] * a.steps * ((1 if a.precomputed_ref else 2) + 2)   # fwd (policy [+ ref]) + dgrad + wgrad
@@ -183,7 +184,7 @@ def main():
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                          "traffic": traffic, "traffic_unit": "bytes/launch leaving L2 (2*FETCH_SIZE+WRITE_SIZE, rocprofv3 --pmc, offline pass; A+B of a decoder GEMM fit the 256 MB Infinity Cache, so most of the re-reads never reach HBM)",
                          "algorithmic_bytes_per_launch": round(2.0 * g_bytes / max(1, g_dec)), "launches": g_n, "avg_launch_ms": round(g_ms / max(1, g_n), 4), "per_kernel": per_kernel,
-                         "gemm_share_of_step": round(g_ms * 1e-3 / dt, 3),
+                         "kernel_share_of_step": round(g_ms * 1e-3 / dt, 3), "all_gemm_share_of_step": round(all_ms * 1e-3 / dt, 3),
                          "step_frac": round(pairs_per_s / world * per_pair / PEAK_BF16_TFLOPS, 4)},
         }
         if a.layers:

@@ -24,7 +24,7 @@ typedef struct ihipStream_t* vlr_stream_t; /* == hipStream_t */
 const char* vlr_last_error(void);
 int vlr_abi_version(void);
 /* in-library kernel timing (HIP events on the launch stream): kernels 0 gemm NT, 1 gemm NN, 2 gemm TN, 3 attention fwd,
- * 4 attention bwd.  vlr_prof_collect fills out[k*3 + {0,1,2}] = {launches, total ms, algorithmic FLOPs}. */
+ * 4 attention bwd, 5 the 256x256 eight-phase GEMM kernel alone (the sub-launches of 0-2).  vlr_prof_collect fills out[k*3 + {0,1,2}] = {launches, total ms, algorithmic FLOPs}. */
 int vlr_prof_enable(int on);
 int vlr_prof_collect(double* out_host, int n_kernels);
 

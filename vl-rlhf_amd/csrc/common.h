@@ -21,7 +21,7 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 void vlr_set_error(const char* fmt, ...);
 int vlr_check_launch(const char* what);
 // kernel ids for the in-library profiler (api.cpp)
-enum { VLR_K_GEMM_NT = 0, VLR_K_GEMM_NN = 1, VLR_K_GEMM_TN = 2, VLR_K_ATTN_FWD = 3, VLR_K_ATTN_BWD = 4, VLR_K_COUNT = 5 };
+enum { VLR_K_GEMM_NT = 0, VLR_K_GEMM_NN = 1, VLR_K_GEMM_TN = 2, VLR_K_ATTN_FWD = 3, VLR_K_ATTN_BWD = 4, VLR_K_GEMM256P = 5, VLR_K_COUNT = 6 };
 int vlr_prof_begin(int kernel, double work, hipStream_t st);
 void vlr_prof_end(int idx, hipStream_t st);
 

@@ -154,7 +154,7 @@ def stream():
 _prof = None   # {entry point: [(start_event, end_event, args)]} while bench.py times kernels with HIP events
 
 
-PROF_KERNELS = ["gemm_nt", "gemm_nn", "gemm_tn", "attn_fwd", "attn_bwd"]
+PROF_KERNELS = ["gemm_nt", "gemm_nn", "gemm_tn", "attn_fwd", "attn_bwd", "gemm256p"]
 
 
 def lib_profile_start():
