@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--no_side_stream", action="store_true")
     ap.add_argument("--precomputed_ref", action="store_true", help="stream precomputed reference log-probs (SURVEY 8f rank 1)")
     ap.add_argument("--lora", action="store_true", help="variant: LoRA DPO of scripts/ddpo_llava.sh (r=128, alpha=256, dropout 0.05)")
+    ap.add_argument("--lora_dropout", type=float, default=0.05)
     a = ap.parse_args()
 
     from vlrlhf import _hip
@@ -103,7 +104,7 @@ def main():
     if a.lora:
         del ref
         tr = LlavaDPOTrainer(model, None, 0.1, 0, "sigmoid", args, None, -100, 0,
-                             peft_config=dict(r=128, lora_alpha=256, lora_dropout=0.05, target_modules="auto", bias="none", seed=rank))
+                             peft_config=dict(r=128, lora_alpha=256, lora_dropout=a.lora_dropout, target_modules="auto", bias="none", seed=rank))
         for k, t_ in eng.lv.items():             # peft initialises B = 0; random B so the adapter GEMMs do real arithmetic
             if ".b_" in k:
                 t_.normal_(0.0, 1e-3)
