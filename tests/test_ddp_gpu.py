@@ -49,7 +49,7 @@ def _step(cfg, W, W_ref, batch, world):
     o = cfg["optim"]
     eng.optimizer_step(o["lr"], o["beta1"], o["beta2"], o["eps"], o["weight_decay"], o["max_grad_norm"], grad_scale=1.0 / world)
     torch.cuda.synchronize()
-    return float(loss), eng.policy.flat.float().cpu(), eng.grads.float().cpu(), float(eng.norm_out[0])
+    return float(loss), eng.policy.flat.float().cpu(), eng.grads.float().cpu(), eng.grad_norm()
 
 
 def _worker(rank, world, port, q):

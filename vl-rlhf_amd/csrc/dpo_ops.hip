@@ -236,20 +236,61 @@ __global__ __launch_bounds__(256) void merge_bwd_feats_kernel(const bf16_t* __re
         *reinterpret_cast<u32x4*>(dfeats + (size_t)f * H + c) = pack8(a);
     }
 }
-// d_embed_tokens[id] += d_merged[pos]  (packed bf16 atomics: duplicate ids are the common case - shared prompts)
+// d_embed_tokens[id] += sum over the positions holding token `id` of d_merged[pos]  - DETERMINISTIC: the workgroup of the FIRST
+// position of an id gathers every later position with the same id in position order, accumulates in fp32 and writes the row
+// once (read-modify-write, no atomics: each table row has exactly one writer).  The earlier version scatter-added with packed
+// bf16 atomics; their arrival order changed the rounding from run to run, and after three AdamW steps on random weights the
+// 7B loss differed by 5 % between two runs of the same binary (tools/determinism.py).
 __global__ __launch_bounds__(256) void merge_bwd_embed_kernel(const bf16_t* __restrict__ dmerged,
                                                               const int* __restrict__ src, const long* __restrict__ ids,
-                                                              bf16_t* __restrict__ dtable, int T, int S, int H) {
-    const size_t pos = blockIdx.x;
+                                                              bf16_t* __restrict__ dtable, int T, int S, int H, int npos) {
+    __shared__ int s_hit[256];
+    const int pos = blockIdx.x, t = threadIdx.x;
     const int sv = src[pos];
-    if (sv < 0) return;
-    const int b = (int)(pos / S);
-    bf16_t* dst = dtable + (size_t)ids[(size_t)b * T + sv] * H;
-    typedef __attribute__((ext_vector_type(2))) short s16x2;
-    for (int c = threadIdx.x * 2; c < H; c += 256 * 2) {
-        const uint32_t w = *reinterpret_cast<const uint32_t*>(dmerged + pos * H + c);
-        __builtin_amdgcn_global_atomic_fadd_v2bf16((__attribute__((address_space(1))) s16x2*)(dst + c),
-                                                   __builtin_bit_cast(s16x2, w));
+    if (sv < 0) return;                                    // image feature row or zero row: no embedding behind it
+    const long id = ids[(size_t)(pos / S) * T + sv];
+    auto id_at = [&](int q) -> long {
+        const int sq = src[q];
+        return sq < 0 ? -1 : ids[(size_t)(q / S) * T + sq];
+    };
+    int earlier = 0;
+    for (int q = t; q < pos; q += 256) earlier |= id_at(q) == id;
+    if (__syncthreads_or(earlier)) return;                 // an earlier position owns this id
+    constexpr int NB = 4;                                  // thread t owns columns [8*(t + 256 k), +8), k < NB: H <= 8192
+    float acc[NB][8];
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[k][e] = 0.f;
+    for (int q0 = pos; q0 < npos; q0 += 256) {             // every thread takes part in the barriers, whatever H is
+        __syncthreads();
+        s_hit[t] = (q0 + t < npos) && id_at(q0 + t) == id;
+        __syncthreads();
+        for (int h = 0; h < 256; ++h) {
+            if (!s_hit[h]) continue;                       // uniform: every thread walks the hits in position order
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int c0 = (t + 256 * k) * 8;
+                if (c0 < H) {
+                    float v[8];
+                    unpack8(*reinterpret_cast<const u32x4*>(dmerged + (size_t)(q0 + h) * H + c0), v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[k][e] += v[e];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int c0 = (t + 256 * k) * 8;
+        if (c0 < H) {
+            bf16_t* dst = dtable + (size_t)id * H + c0;
+            float o[8];
+            unpack8(*reinterpret_cast<const u32x4*>(dst), o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += acc[k][e];
+            *reinterpret_cast<u32x4*>(dst) = pack8(o);
+        }
     }
 }
 
@@ -514,13 +555,13 @@ extern "C" int vlr_merge_fwd(const int* src, const long* input_ids, const void* 
 extern "C" int vlr_merge_bwd(const void* dmerged, const int* src, const int* inv_map, const long* input_ids,
                              void* dfeats, void* dembed_table, int Bn, int T, int S, int H, int n_feat_rows, int dup,
                              hipStream_t st) {
-    VLR_REQUIRE(Bn > 0 && H % 8 == 0, "vlr_merge_bwd: bad shape");
+    VLR_REQUIRE(Bn > 0 && H % 8 == 0 && H <= 8192, "vlr_merge_bwd: bad shape (H %% 8 == 0, H <= 8192)");
     if (dfeats)
         hipLaunchKernelGGL(merge_bwd_feats_kernel, dim3(n_feat_rows), dim3(256), 0, st, (const bf16_t*)dmerged, inv_map,
                            (bf16_t*)dfeats, n_feat_rows, dup, H);
     if (dembed_table)
         hipLaunchKernelGGL(merge_bwd_embed_kernel, dim3(Bn * S), dim3(256), 0, st, (const bf16_t*)dmerged, src, input_ids,
-                           (bf16_t*)dembed_table, T, S, H);
+                           (bf16_t*)dembed_table, T, S, H, Bn * S);
     return vlr_check_launch("vlr_merge_bwd");
 }
 extern "C" int vlr_build_rows(const long* labels, const unsigned char* shared_mask, int Bn, int S, int label_pad,

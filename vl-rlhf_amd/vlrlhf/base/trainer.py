@@ -567,7 +567,7 @@ class VLDPOTrainer:
                 if step % logging_steps == 0 or step >= total:
                     n_opt = max(1, len(window) // ga)
                     self.log({"loss": float(torch.stack(window).sum()) / n_opt, "learning_rate": lr,
-                              "grad_norm": float(eng.norm_out[0]), "epoch": ep + (micro / ga) / per_epoch})
+                              "grad_norm": eng.grad_norm(), "epoch": ep + (micro / ga) / per_epoch})
                     window = []
                 if step >= total:
                     break

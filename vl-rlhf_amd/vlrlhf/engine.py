@@ -10,6 +10,7 @@ Replaces, for the DPO hot path, what the reference reaches through
   Trainer.training_step / optimizer     (transformers 4.41.0 + torch AdamW; flags scripts/dpo_llava.sh:35-41)
 """
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -229,6 +230,11 @@ class LlavaHipEngine:
         self._colsum_ws = torch.empty(_hip.helper("vlr_colsum_workspace_bytes", max(self.H, 8)), dtype=torch.uint8, device=self.dev)
         self._sq_ws = torch.empty(_hip.helper("vlr_grad_sqnorm_workspace_bytes"), dtype=torch.uint8, device=self.dev)
         self.norm_out = torch.zeros(3, dtype=torch.float32, device=self.dev)
+        # Optional (VLR_ASYNC_OPT=1): clip + AdamW (HBM-bound, 32 ms) on their own stream so that they overlap the next step's
+        # FROZEN reference forward; the policy forward waits for the `_opt_done` event.  Measured on MI355X: no gain (650.7 /
+        # 652.6 ms without vs 648.5 / 653.1 ms with) - the two kernels do not co-schedule - so it is off by default.
+        self._opt_stream = torch.cuda.Stream(self.dev) if os.environ.get("VLR_ASYNC_OPT", "0") == "1" else None
+        self._opt_done = None
         # split-K scratch of the GEMM dispatcher (ragged last tile rows, LoRA adapter gradients): two 64 MiB slots (main + side stream)
         _hip.ensure_splitk_workspace(self.dev)
 
@@ -394,6 +400,8 @@ class LlavaHipEngine:
         """embed -> ViT -> projector -> merge -> decoder -> final RMSNorm.  Returns a context dict with the final
         hidden states [Bn*S, H] and the merged labels / mask / positions."""
         c = self.cfg
+        if ws is self.policy:
+            self.wait_optimizer()
         Bn, T = input_ids.shape
         ids = input_ids.to(self.dev).contiguous()
         am = attention_mask.to(self.dev).contiguous()
@@ -640,7 +648,34 @@ class LlavaHipEngine:
     def zero_grad(self):
         self.grad_fresh = True
 
+    def wait_optimizer(self):
+        """make the current stream wait for the last optimizer step (no host synchronisation)"""
+        if self._opt_done is not None:
+            torch.cuda.current_stream(self.dev).wait_event(self._opt_done)
+
+    def grad_norm(self) -> float:
+        """total gradient norm of the last optimizer step (host value; synchronises on the optimizer stream)"""
+        if self._opt_done is not None:
+            self._opt_done.synchronize()
+        return float(self.norm_out[0])
+
     def optimizer_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, grad_scale=1.0):
+        """clip + AdamW, issued on the optimizer stream behind everything queued on the caller's stream so far."""
+        if self.master is None:
+            self.init_optimizer()
+        if self.reducer is not None:
+            self.reducer.wait()
+        if self._opt_stream is None:
+            return self._optimizer_step(lr, beta1, beta2, eps, weight_decay, max_grad_norm, grad_scale)
+        main = torch.cuda.current_stream(self.dev)
+        self._opt_stream.wait_stream(main)
+        with torch.cuda.stream(self._opt_stream):
+            out = self._optimizer_step(lr, beta1, beta2, eps, weight_decay, max_grad_norm, grad_scale)
+            self._opt_done = torch.cuda.Event()
+            self._opt_done.record(self._opt_stream)
+        return out
+
+    def _optimizer_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, grad_scale=1.0):
         """clip_grad_norm_(max_grad_norm) + AdamW on the flat buffers; no host synchronisation (the clip coefficient
         stays on the device).  grad_scale multiplies the raw gradients first (1/world_size after a sum all-reduce,
         1/gradient_accumulation_steps ...).  Returns the device tensor [norm, coef, sum g^2]."""

@@ -248,6 +248,7 @@ class LlavaForRL(nn.Module):
             self.engine.lora_active = prev
 
     def lora_state_dict(self):
+        self.engine.wait_optimizer()
         return self.engine.lora_state_dict()
 
     def merge_and_unload(self):
@@ -278,6 +279,7 @@ class LlavaForRL(nn.Module):
             yield p
 
     def state_dict(self, *a, **k):
+        self.engine.wait_optimizer()
         out = dict(self.weights.state_dict())
         return out
 
