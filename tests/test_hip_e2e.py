@@ -448,3 +448,26 @@ def test_precompute_ref_log_probs_prepass(gpu):
     # first logged loss: policy == reference -> ln 2 (up to the bf16 noise between two evaluations of the same weights)
     assert abs(tr.log_history[0]["loss"] - math.log(2.0)) < 2e-3, tr.log_history[0]
     assert len(tr.log_history) == 2 and all(math.isfinite(h["loss"]) for h in tr.log_history)
+
+
+def test_step_is_bit_reproducible(gpu):
+    """two evaluations of the same step give bit-identical loss and gradients - including the embedding gradient, whose
+    duplicate-token contributions are summed in position order (no atomics anywhere on the path)."""
+    z, cfg, W, W_ref, batch, rows = load_case("llava_hipsmall")
+    # repeat tokens inside and across the sequences so that many positions share an embedding row
+    b2 = dict(batch)
+    for side in ("chosen", "rejected"):
+        ids = batch[f"{side}_input_ids"].clone()
+        ids[:, 8:14] = ids[:, 2:3]
+        b2[f"{side}_input_ids"] = ids
+    outs = []
+    for rep in range(2):
+        model, ref = build(cfg, W, W_ref)
+        tr = make_trainer(model, ref, cfg)
+        loss = tr.training_step(model, b2)
+        torch.cuda.synchronize()
+        outs.append((float(loss), model.engine.grads.clone()))
+    assert outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1], outs[1][1])
+    emb = dict(model.named_parameters())["language_model.model.embed_tokens.weight"].grad
+    assert float(emb.float().abs().sum()) > 0
