@@ -1,4 +1,4 @@
-// Shared definitions of the bf16 GEMM kernels (gemm.hip: 128x128 tile, gemm256.hip: 256x256 tile).
+// Shared definitions of the bf16 GEMM kernels (gemm.hip: 128x128 tile, gemm256p.hip: 256x256 tile).
 #pragma once
 #include "common.h"
 
@@ -29,7 +29,6 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 }
 
 
-// 256x256-tile kernel (gemm256.hip); returns false when the problem does not qualify (caller falls back to 128x128)
-bool vlr_gemm256_try_launch(int layout, const GemmParams& p, hipStream_t stream);
-// 256x256 tile, eight-phase schedule (gemm256p.hip); tried first by vlr_gemm256_try_launch
+// 256x256 tile, eight-phase schedule (gemm256p.hip); returns false when the problem does not qualify (fewer than 192 tiles,
+// unaligned operands, VLR_GEMM_8PHASE=0): the caller falls back to the 128x128 kernel
 bool vlr_gemm256p_try_launch(int layout, const GemmParams& p, hipStream_t stream);

@@ -423,7 +423,7 @@ static int gemm_impl(int layout, const void* A, const void* B, void* C, const vo
         p2.A = layout == 2 ? p.A + M1 : p.A + (size_t)M1 * lda;
         p2.C = (char*)p.C + (size_t)M1 * ldc * esz;
         if (p.residual) p2.residual = p.residual + (size_t)M1 * ldr;
-        if (vlr_gemm256_try_launch(layout, p1, stream)) {
+        if (vlr_gemm256p_try_launch(layout, p1, stream)) {
             const int t2 = ((p2.M + BM - 1) / BM) * ((N + BN - 1) / BN);
             // the peeled rows are few tiles with the full reduction depth (e.g. 504 x 4096 x 22016 = 128 tiles x 688 k-steps):
             // split them along K so that they fill the chip
@@ -439,7 +439,7 @@ static int gemm_impl(int layout, const void* A, const void* B, void* C, const vo
         }
     }
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    if (vlr_gemm256_try_launch(layout, p, stream)) {
+    if (vlr_gemm256p_try_launch(layout, p, stream)) {
         vlr_prof_end(pi, stream);
         return vlr_check_launch("vlr_gemm_bf16(256)");
     }

@@ -1,6 +1,6 @@
 // 256x256x64-tile bf16 MFMA GEMM, eight-phase schedule: the large-shape path of vlr_gemm_bf16 for all three layouts.
 //
-// The two-phase staggered kernel (gemm256.hip) is bound by the ISSUE of the LDS-DMA: one global_load_lds blocks its in-order
+// Its predecessor, a two-phase staggered kernel (r01 history), was bound by the ISSUE of the LDS-DMA: one global_load_lds blocks its in-order
 // wave for ~100 cycles, and a LOAD phase that carries 4-8 of them next to 12 fragment reads takes longer than the 16 MFMAs
 // of its partner wave.  Here the same work is cut finer, after the guide's 256^2 8-phase template:
 //   * K tile 64; LDS = 2 buffers x {A-lo, A-hi, B-lo, B-hi} half tiles of 128 rows x 64 k (16 KiB each) = 128 KiB;
