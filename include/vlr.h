@@ -163,7 +163,8 @@ int vlr_decoder_layer_bwd(const vlr_llama_cfg* cfg, const vlr_layer_weights* w, 
  * un-merged: lora_dropout works and the frozen base weights serve as the reference model (adapter disabled, trl
  * null_ref_context).  Sub-targets of a fused group are stacked: A_*: [n*r][in], B_*: [n*out][r].
  * u [M][7r] (columns qkv | o | gate,up | down) = dropout_t(x) A_t^T, written by the forward and read by the backward.
- * ws_v: scratch [M][3r]; ws_xd: scratch [M][inter], required when dropout > 0.  Dropout target t of the layer draws its
+ * ws_v: scratch [M][3r]; ws_xd (dropout > 0): [M][6*hidden + inter] PER LAYER - the forward stores the seven dropped inputs
+ * drop_t(x) there (q,k,v | o | gate,up | down), the backward reads them for dA and then reuses the space as scratch.  Dropout target t of the layer draws its
  * mask from vlr_dropout(seed + t), t = 0..6 in q,k,v,o,gate,up,down order. */
 typedef struct {
     int r;

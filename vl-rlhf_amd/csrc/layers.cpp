@@ -128,8 +128,9 @@ static int lora_group_fwd(int n, int r, int in, int out, const void* x, void* y,
                           int ldu, float scale, float p, uint64_t seed, void* ws_xd, int M, hipStream_t st) {
     if (p > 0.f) {
         for (int t = 0; t < n; ++t) {
-            CHECK(vlr_dropout(x, ws_xd, (long)M * in, p, seed + t, 1.f, 0, st));
-            CHECK(vlr_gemm_bf16(0, ws_xd, off(A, (size_t)t * r * in), off(u, (size_t)t * r), nullptr, nullptr, M, r, in, in, in, ldu, 0, 0, 0, 0, st));
+            void* xd_t = off(ws_xd, (size_t)t * M * in);          // kept for the backward (dA_t = s v_t^T drop_t(x))
+            CHECK(vlr_dropout(x, xd_t, (long)M * in, p, seed + t, 1.f, 0, st));
+            CHECK(vlr_gemm_bf16(0, xd_t, off(A, (size_t)t * r * in), off(u, (size_t)t * r), nullptr, nullptr, M, r, in, in, in, ldu, 0, 0, 0, 0, st));
         }
     } else {
         CHECK(vlr_gemm_bf16(0, x, A, u, nullptr, nullptr, M, n * r, in, in, in, ldu, 0, 0, 0, 0, st));
@@ -154,12 +155,12 @@ static int lora_group_bwd(int n, int r, int in, int out, const void* x, const vo
     }
     if (p > 0.f) {
         for (int t = 0; t < n; ++t) {
-            CHECK(vlr_dropout(x, ws_xd, (long)M * in, p, seed + t, 1.f, 0, st));
-            CHECK(vlr_gemm_bf16_scaled(2, off(v, (size_t)t * r), ws_xd, off(dA, (size_t)t * r * in), nullptr, nullptr, r, in, M, nr, in, in,
+            void* xd_t = off(ws_xd, (size_t)t * M * in);          // drop_t(x) saved by the forward; dead after dA_t -> reused as scratch
+            CHECK(vlr_gemm_bf16_scaled(2, off(v, (size_t)t * r), xd_t, off(dA, (size_t)t * r * in), nullptr, nullptr, r, in, M, nr, in, in,
                                        0, 0, accumulate, 0, scale, st));                                            // dA_t = s v_t^T drop_t(x)
-            CHECK(vlr_gemm_bf16(1, off(v, (size_t)t * r), off(A, (size_t)t * r * in), ws_xd, nullptr, nullptr, M, in, r, nr, in, in,
+            CHECK(vlr_gemm_bf16(1, off(v, (size_t)t * r), off(A, (size_t)t * r * in), xd_t, nullptr, nullptr, M, in, r, nr, in, in,
                                 0, 0, 0, 0, st));
-            CHECK(vlr_dropout(ws_xd, dx, (long)M * in, p, seed + t, scale, 1, st));                                  // dx += s mask_t (v_t A_t)/(1-p)
+            CHECK(vlr_dropout(xd_t, dx, (long)M * in, p, seed + t, scale, 1, st));                                   // dx += s mask_t (v_t A_t)/(1-p)
         }
     } else {
         CHECK(vlr_gemm_bf16_scaled(2, v, x, dA, nullptr, nullptr, nr, in, M, nr, in, in, 0, 0, accumulate, 0, scale, st));  // dA = s v^T x
@@ -171,7 +172,7 @@ static int lora_group_bwd(int n, int r, int in, int out, const void* x, const vo
 static int lora_check(const char* who, const vlr_lora_weights* lw, const void* ws_xd) {
     VLR_REQUIRE(lw->r > 0 && lw->r % 8 == 0, "%s: LoRA rank must be a positive multiple of 8, got %d", who, lw->r);
     VLR_REQUIRE(lw->dropout >= 0.f && lw->dropout < 1.f, "%s: lora_dropout must be in [0,1), got %g", who, (double)lw->dropout);
-    VLR_REQUIRE(lw->dropout == 0.f || ws_xd, "%s: lora_dropout > 0 needs the ws_xd scratch buffer", who);
+    VLR_REQUIRE(lw->dropout == 0.f || ws_xd, "%s: lora_dropout > 0 needs the xd buffer [M][6*hidden + inter]", who);
     VLR_REQUIRE(lw->a_qkv && lw->b_qkv && lw->a_o && lw->b_o && lw->a_gu && lw->b_gu && lw->a_down && lw->b_down, "%s: null adapter pointer", who);
     return VLR_OK;
 }
@@ -183,21 +184,22 @@ extern "C" int vlr_decoder_layer_fwd_lora(const vlr_llama_cfg* cfg, const vlr_la
     CHECK(lora_check("vlr_decoder_layer_fwd_lora", lw, ws_xd));
     const int H = cfg->hidden, I = cfg->inter, M = batch * S, r = lw->r, ldu = 7 * r;
     const float sc = lw->scale, p = lw->dropout;
+#define XD(seg) (ws_xd ? (void*)off(ws_xd, (size_t)(seg) * M * H) : nullptr)   // segment base in units of M*H elements
     VLR_REQUIRE(cfg->heads * cfg->head_dim == H, "vlr_decoder_layer_fwd_lora: heads*head_dim != hidden");
     CHECK(vlr_rmsnorm_fwd(x_in, w->ln1, a->xn1, a->rstd1, M, H, cfg->rms_eps, st));
     CHECK(vlr_gemm_bf16(0, a->xn1, w->wqkv, a->qkv, nullptr, nullptr, M, 3 * H, H, H, H, 3 * H, 0, 0, 0, 0, st));
-    CHECK(lora_group_fwd(3, r, H, H, a->xn1, a->qkv, 3 * H, lw->a_qkv, lw->b_qkv, u, ldu, sc, p, seed + 0, ws_xd, M, st));
+    CHECK(lora_group_fwd(3, r, H, H, a->xn1, a->qkv, 3 * H, lw->a_qkv, lw->b_qkv, u, ldu, sc, p, seed + 0, ws_xd, M, st));   // xd segments: q,k,v | o | gate,up | down
     CHECK(vlr_rope(a->qkv, pos, cfg->rope_cos, cfg->rope_sin, M, H, cfg->head_dim, 3 * H, cfg->max_pos, 0, st));
     CHECK(vlr_attn_fwd(a->qkv, off(a->qkv, H), off(a->qkv, 2 * (size_t)H), 3 * H, a->attn, H, a->lse, key_mask, batch, S,
                        cfg->heads, cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));
     CHECK(vlr_gemm_bf16(0, a->attn, w->wo, a->x_mid, nullptr, x_in, M, H, H, H, H, H, H, 0, 0, 0, st));
-    CHECK(lora_group_fwd(1, r, H, H, a->attn, a->x_mid, H, lw->a_o, lw->b_o, off(u, 3 * (size_t)r), ldu, sc, p, seed + 3, ws_xd, M, st));
+    CHECK(lora_group_fwd(1, r, H, H, a->attn, a->x_mid, H, lw->a_o, lw->b_o, off(u, 3 * (size_t)r), ldu, sc, p, seed + 3, XD(3), M, st));
     CHECK(vlr_rmsnorm_fwd(a->x_mid, w->ln2, a->xn2, a->rstd2, M, H, cfg->rms_eps, st));
     CHECK(vlr_gemm_bf16(0, a->xn2, w->wgu, a->gu, nullptr, nullptr, M, 2 * I, H, H, H, 2 * I, 0, 0, 0, 0, st));
-    CHECK(lora_group_fwd(2, r, H, I, a->xn2, a->gu, 2 * I, lw->a_gu, lw->b_gu, off(u, 4 * (size_t)r), ldu, sc, p, seed + 4, ws_xd, M, st));
+    CHECK(lora_group_fwd(2, r, H, I, a->xn2, a->gu, 2 * I, lw->a_gu, lw->b_gu, off(u, 4 * (size_t)r), ldu, sc, p, seed + 4, XD(4), M, st));
     CHECK(vlr_swiglu_fwd(a->gu, a->act, M, I, st));
     CHECK(vlr_gemm_bf16(0, a->act, w->wdown, a->x_out, nullptr, a->x_mid, M, H, I, I, I, H, H, 0, 0, 0, st));
-    CHECK(lora_group_fwd(1, r, I, H, a->act, a->x_out, H, lw->a_down, lw->b_down, off(u, 6 * (size_t)r), ldu, sc, p, seed + 6, ws_xd, M, st));
+    CHECK(lora_group_fwd(1, r, I, H, a->act, a->x_out, H, lw->a_down, lw->b_down, off(u, 6 * (size_t)r), ldu, sc, p, seed + 6, XD(6), M, st));
     return VLR_OK;
 }
 
@@ -210,19 +212,20 @@ extern "C" int vlr_decoder_layer_bwd_lora(const vlr_llama_cfg* cfg, const vlr_la
     CHECK(lora_check("vlr_decoder_layer_bwd_lora", lw, ws_xd));
     const int H = cfg->hidden, I = cfg->inter, M = batch * S, r = lw->r, ldu = 7 * r;
     const float sc = lw->scale, p = lw->dropout;
+#define XD(seg) (ws_xd ? (void*)off(ws_xd, (size_t)(seg) * M * H) : nullptr)   // segment base in units of M*H elements
     // ---- MLP
     CHECK(vlr_gemm_bf16(1, dx_out, w->wdown, ws->dact, nullptr, nullptr, M, I, H, H, I, I, 0, 0, 0, 0, st));
     CHECK(lora_group_bwd(1, r, I, H, a->act, dx_out, H, lw->a_down, lw->b_down, lg->a_down, lg->b_down, off(u, 6 * (size_t)r), ldu, ws_v,
-                         ws->dact, sc, p, seed + 6, ws_xd, accumulate, M, st));
+                         ws->dact, sc, p, seed + 6, XD(6), accumulate, M, st));
     CHECK(vlr_swiglu_bwd(a->gu, ws->dact, M, I, st));   // gu now holds [dgate | dup]
     CHECK(vlr_gemm_bf16(1, a->gu, w->wgu, ws->dxn, nullptr, nullptr, M, H, 2 * I, 2 * I, H, H, 0, 0, 0, 0, st));
     CHECK(lora_group_bwd(2, r, H, I, a->xn2, a->gu, 2 * I, lw->a_gu, lw->b_gu, lg->a_gu, lg->b_gu, off(u, 4 * (size_t)r), ldu, ws_v,
-                         ws->dxn, sc, p, seed + 4, ws_xd, accumulate, M, st));
+                         ws->dxn, sc, p, seed + 4, XD(4), accumulate, M, st));
     CHECK(vlr_rmsnorm_bwd(ws->dxn, a->x_mid, w->ln2, a->rstd2, dx_out, ws->dx_mid, nullptr, 0, ws->norm_ws, M, H, st));
     // ---- attention
     CHECK(vlr_gemm_bf16(1, ws->dx_mid, w->wo, ws->dattn, nullptr, nullptr, M, H, H, H, H, H, 0, 0, 0, 0, st));
     CHECK(lora_group_bwd(1, r, H, H, a->attn, ws->dx_mid, H, lw->a_o, lw->b_o, lg->a_o, lg->b_o, off(u, 3 * (size_t)r), ldu, ws_v,
-                         ws->dattn, sc, p, seed + 3, ws_xd, accumulate, M, st));
+                         ws->dattn, sc, p, seed + 3, XD(3), accumulate, M, st));
     CHECK(vlr_attn_bwd(a->qkv, off(a->qkv, H), off(a->qkv, 2 * (size_t)H), 3 * H, a->attn, ws->dattn, H, a->lse, ws->delta,
                        key_mask, ws->dqkv, off(ws->dqkv, H), off(ws->dqkv, 2 * (size_t)H), 3 * H, batch, S, cfg->heads,
                        cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));

@@ -445,13 +445,18 @@ class LlavaHipEngine:
             r = self.lora["r"]
             self._lora_calls += 1
             lora_seed = (self.lora_seed << 40) + (self._lora_calls << 16)        # + 8*layer + target inside the library
-            xd = self._buf(("lora_xd", M), (M, max(self.H, self.I))) if (self.lora["dropout"] > 0 and self.training) else None
+            drop = self.lora["dropout"] > 0 and self.training
         for l in range(self.L):
             a = self._layer_acts(tag if save else "scratch", l if save else (l % 2), Bn, S)
             if use_lora:
                 if "u" not in a or a["u"].shape[1] != 7 * r:
                     a["u"] = torch.empty(M, 7 * r, dtype=BF16, device=self.dev)
                 lw, _ = self._lora_structs(l, train=True)
+                xd = None
+                if drop:                                   # dropped inputs of the seven targets, kept per layer for the backward
+                    if "xd" not in a:
+                        a["xd"] = torch.empty(M, 6 * self.H + self.I, dtype=BF16, device=self.dev)
+                    xd = a["xd"]
                 _hip.call("vlr_decoder_layer_fwd_lora", self.llama_cfg, self.layer_weights(ws, l), lw, a["struct"], a["u"], xd,
                           lora_seed + 8 * l, x, pos, mask, Bn, S)
             else:
@@ -613,14 +618,14 @@ class LlavaHipEngine:
         lws = _hip.LayerBwdWs(wsb["dact"].data_ptr(), wsb["dxn"].data_ptr(), wsb["dattn"].data_ptr(), wsb["dqkv"].data_ptr(),
                               wsb["dx_mid"].data_ptr(), wsb["delta"].data_ptr(), self._norm_ws.data_ptr())
         ws_v = self._buf(("lora_v", M), (M, 3 * r))
-        xd = self._buf(("lora_xd", M), (M, max(H, I))) if (self.lora["dropout"] > 0 and self.training) else None
+        drop = self.lora["dropout"] > 0 and self.training
         cur, nxt = dxa, dxb
         for l in range(self.L - 1, -1, -1):
             a = ctx["acts"][l]
             x_in = ctx["acts"][l - 1]["x_out"] if l > 0 else ctx["x0"]
             lw, lg = self._lora_structs(l, train=True)
             _hip.call("vlr_decoder_layer_bwd_lora", self.llama_cfg, self.layer_weights(ws, l), lw, lg, acc, a["struct"], a["u"],
-                      lws, ws_v, xd, ctx["lora_seed"] + 8 * l, x_in, cur, nxt, ctx["pos"], ctx["mask"], Bn, S)
+                      lws, ws_v, a["xd"] if drop else None, ctx["lora_seed"] + 8 * l, x_in, cur, nxt, ctx["pos"], ctx["mask"], Bn, S)
             cur, nxt = nxt, cur
         self.grad_fresh = False
         if self.reducer is not None:
