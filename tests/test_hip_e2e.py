@@ -471,3 +471,49 @@ def test_step_is_bit_reproducible(gpu):
     assert torch.equal(outs[0][1], outs[1][1])
     emb = dict(model.named_parameters())["language_model.model.embed_tokens.weight"].grad
     assert float(emb.float().abs().sum()) > 0
+
+
+def test_training_trajectory_tracks_oracle(gpu):
+    """four optimizer steps on the same batch with a large learning rate (the loss must MOVE): the HIP trajectory follows the
+    oracle trajectory computed the way the HIP path stores things - fp32 master weights updated by the restated clip + AdamW,
+    forward / backward on their bf16 rounding with bf16-rounded activations.  (Adam's first steps are sign-like, so tiny
+    gradient elements flip between any two arithmetic paths: the per-step tolerance is 3e-2 on a 0.69 -> 0.15 trajectory.)"""
+    z, cfg, W, W_ref, batch, rows = load_case("llava_hipsmall")
+    o = dict(cfg["optim"], lr=2e-4)
+    model, ref = build(cfg, W, W_ref)
+    tr = make_trainer(model, ref, cfg)
+    eng = model.engine
+    eng.init_optimizer()
+    hip_losses = []
+    for _ in range(4):
+        eng.zero_grad()
+        hip_losses.append(float(tr.training_step(model, batch)))
+        eng.optimizer_step(o["lr"], o["beta1"], o["beta2"], o["eps"], o["weight_decay"], o["max_grad_norm"])
+    torch.cuda.synchronize()
+    names = O.trainable_names(W)
+    master = {k: v.bfloat16().float() for k, v in W.items()}           # the engine's master copy starts from the bf16 weights
+    Wr16 = {k: v.bfloat16().float() for k, v in W_ref.items()}
+    state, ora_losses = {}, []
+    for _ in range(4):
+        leaves = {k: master[k].bfloat16().float().requires_grad_(True) for k in names}
+        Wp = {k: v.bfloat16().float() for k, v in master.items()}
+        Wp.update(leaves)
+        loss, _ = O.compute_loss(Wp, Wr16, cfg, batch, cfg["beta"], emulate_bf16=True)
+        loss.backward()
+        grads = {k: leaves[k].grad for k in names if leaves[k].grad is not None}
+        O.clip_grad_norm_(grads, o["max_grad_norm"])
+        with torch.no_grad():
+            O.adamw_step(master, grads, state, o["lr"], o["beta1"], o["beta2"], o["eps"], o["weight_decay"])
+        ora_losses.append(float(loss))
+    assert ora_losses[0] - ora_losses[-1] > 0.3, ora_losses             # the trajectory does move
+    assert all(a > b for a, b in zip(hip_losses, hip_losses[1:])), hip_losses
+    for h, r in zip(hip_losses, ora_losses):
+        assert abs(h - r) < 3e-2, (hip_losses, ora_losses)
+    new = model.state_dict()
+    num = den = dot = 0.0
+    for k in names:
+        dh = new[k].float().cpu() - W[k].bfloat16().float()
+        dr = master[k] - W[k].bfloat16().float()
+        num += float((dh * dh).sum()); den += float((dr * dr).sum()); dot += float((dh * dr).sum())
+    cos = dot / math.sqrt(num * den)
+    assert cos > 0.9 and 0.8 < math.sqrt(num / den) < 1.25, (cos, math.sqrt(num / den))
