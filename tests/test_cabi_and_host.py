@@ -238,3 +238,39 @@ def test_prefetch_loader_order_depth_and_errors():
     it.close()
     time.sleep(0.3)
     assert threading.active_count() <= n0
+
+
+def test_ctypes_signatures_match_the_header():
+    """every prototype of include/vlr.h has the same number (and pointer / integer / float kind) of parameters as its
+    ctypes binding in vlrlhf/_hip.py - a shifted argument would otherwise only show up as garbage on the GPU."""
+    import ctypes as C
+    from vlrlhf import _hip
+    hdr = open(os.path.join(ROOT, "include", "vlr.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    protos = dict(re.findall(r"\b(?:int|const char\*)\s+(vlr_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S))
+
+    def kind(param):
+        p = " ".join(param.split())
+        if p in ("void", ""):
+            return None
+        if "*" in p or "vlr_stream_t" in p:
+            return "p"
+        if re.search(r"\b(float|double)\b", p):
+            return "f"
+        return "i"
+
+    def ckind(ct):
+        if ct in (C.c_void_p, C.c_char_p):
+            return "p"
+        if ct in (C.c_float, C.c_double):
+            return "f"
+        return "i"
+
+    checked = 0
+    for name, sig in list(_hip._SIGS.items()) + list(_hip._INT_HELPERS.items()):
+        assert name in protos, name
+        want = [k for k in (kind(x) for x in protos[name].split(",")) if k]
+        have = [ckind(c) for c in sig]                       # the stream is the last entry of every _SIGS signature
+        assert have == want, f"{name}: header {want} vs ctypes {have}"
+        checked += 1
+    assert checked >= 45
