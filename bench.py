@@ -7,9 +7,10 @@ One "step" = policy forward + backward, reference forward, DPO loss, gradient al
 synthetic batch already resident in HBM: per rank 4 pairs, 336x336 image, 1024 text tokens each (BASELINE.json
 configs[1]; S = 1599 decoder positions), random N(0,0.02) bf16 weights, policy != reference.  Prints ONE JSON line.
 
-roofline: the dominant kernel is the bf16 MFMA GEMM (gemm_bf16_kernel, all three layouts); `achieved` = its algorithmic
-FLOPs (2*M*N*K per launch) / its summed launch durations, measured with HIP events on the launch stream over the
-timed region.  `step_frac` = pairs/s x 174.87 TFLOP (reference forward inside the step) / 2516.6 TF/s.
+roofline: the dominant kernel is the 8-phase 256x256x64 bf16 MFMA GEMM (gemm256p_kernel, all three layouts: 518 launches
+and ~75 % of the step); `achieved` = its algorithmic FLOPs (2*M*N*K per launch) / its summed launch durations, measured
+with HIP events on the launch stream inside the timed region (in-library profiler, kernel id 5); `per_kernel` lists the
+whole vlr_gemm_bf16 calls per layout (incl. peeled rows / split-K reduces) and the attention kernels.  `step_frac` = pairs/s x 174.87 TFLOP (reference forward inside the step) / 2516.6 TF/s.
 cpu_baseline: the fp32 CPU oracle (oracle/llava_dpo_oracle.py, a port of the reference algorithm) timed on this host's
 cores on a bounded sample - one decoder layer forward+backward at the configs[0] shape - and extrapolated to the full
 step; a reported baseline, not the target.
