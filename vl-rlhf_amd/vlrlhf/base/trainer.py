@@ -553,6 +553,8 @@ class VLDPOTrainer:
         window = []           # device scalars; only read back at logging time (no per-step host sync)
         while step < total:
             for batch in self.get_train_batches(ep):
+                if eng.reducer is not None:        # DDP no_sync: reduce only with the last micro-batch of an accumulation window
+                    eng.reducer.enabled = (micro + 1) % ga == 0
                 window.append(self.training_step(self.model, batch))
                 micro += 1
                 if micro % ga:
