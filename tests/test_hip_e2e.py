@@ -517,3 +517,22 @@ def test_training_trajectory_tracks_oracle(gpu):
         num += float((dh * dh).sum()); den += float((dr * dr).sum()); dot += float((dh * dr).sum())
     cos = dot / math.sqrt(num * den)
     assert cos > 0.9 and 0.8 < math.sqrt(num / den) < 1.25, (cos, math.sqrt(num / den))
+
+
+def test_evaluate_reports_eval_metrics(gpu):
+    """HF-style evaluation on the DPO objective: eval_loss + the eight eval_ metrics, no gradients, policy untouched."""
+    from vlrlhf.models.Llava import LlavaDPODataCollatorWithPadding, LlavaDPOTrainer
+    z, cfg, W, W_ref, batch, rows = load_case("llava_hipsmall")
+    px = t(z, "batch.pixel_values")
+    ds = [dict(r, img_path=px[i]) for i, r in enumerate(rows)]
+    model, ref = build(cfg, W, W_ref)
+    args = SimpleNamespace(gradient_accumulation_steps=1, per_device_train_batch_size=2, per_device_eval_batch_size=2, seed=0)
+    tr = LlavaDPOTrainer(model, ref, cfg["beta"], 0, "sigmoid", args, LlavaDPODataCollatorWithPadding(pad_token_id=0, label_pad_token_id=-100),
+                         -100, 0, "keep_end", None, ds, None)
+    before = model.engine.policy.flat.clone()
+    out = tr.evaluate()
+    assert abs(out["eval_loss"] - float(z["loss_mean_sigmoid"])) < TOL_LOSS_FP32
+    for k in ("rewards/chosen", "rewards/rejected", "rewards/accuracies", "rewards/margins", "logps/chosen", "logps/rejected",
+              "logits/chosen", "logits/rejected"):
+        assert f"eval_{k}" in out, k
+    assert torch.equal(before, model.engine.policy.flat) and model.training

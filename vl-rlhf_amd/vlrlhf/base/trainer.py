@@ -465,6 +465,38 @@ class VLDPOTrainer:
         loss.backward()
         return loss.detach() / ga
 
+    # ------------------------------------------------------------------------------------------ evaluation
+    def prediction_step(self, model, inputs, prediction_loss_only: bool = True, ignore_keys=None):
+        """trl==0.8.1 DPOTrainer.prediction_step: no-grad loss + metrics of one batch, stored under the eval_ prefix;
+        returns (loss, logits, labels) with logits = [eval_logits/chosen, eval_logits/rejected] as trl does."""
+        with torch.no_grad():
+            loss, metrics = self.get_batch_loss_metrics(model, self._prepare_inputs(inputs), train_eval="eval")
+        self.store_metrics(metrics, train_eval="eval")
+        if prediction_loss_only:
+            return loss.detach(), None, None
+        logits = torch.stack([metrics["eval_logits/chosen"], metrics["eval_logits/rejected"]]).mean(dim=0, keepdim=True)
+        return loss.detach(), logits, torch.zeros(logits.shape[0], device=logits.device)
+
+    def evaluate(self, eval_dataset=None, metric_key_prefix: str = "eval") -> Dict[str, float]:
+        """HF Trainer.evaluate on the DPO objective: mean eval loss + the eight eval_ metrics over the (rank-sharded) eval set."""
+        ds = eval_dataset if eval_dataset is not None else self.eval_dataset
+        if not ds:
+            return {}
+        if self.precompute_ref_log_probs and not self._precomputed_eval_ref_log_probs and eval_dataset is None:
+            self.precompute_reference_log_probs(ds)
+            self._precomputed_eval_ref_log_probs = True
+        bs = int(getattr(self.args, "per_device_eval_batch_size", None) or getattr(self.args, "per_device_train_batch_size", 4))
+        rows = list(ds)[_rank()::_world()]
+        was_training = self.model.training
+        self.model.eval()
+        losses = []
+        for i in range(0, len(rows), bs):
+            loss, _, _ = self.prediction_step(self.model, self.data_collator(rows[i:i + bs]))
+            losses.append(loss)
+        self.model.train(was_training)
+        out = {f"{metric_key_prefix}_loss": float(torch.stack(losses).mean()) if losses else float("nan")}
+        return self.log(out)
+
     # ------------------------------------------------------------------------------------------ reference pre-pass
     def compute_reference_log_probs(self, padded_batch: Dict) -> Tuple[torch.Tensor, torch.Tensor]:
         """trl==0.8.1 DPOTrainer.compute_reference_log_probs: reference log-probs of one collated batch, no grad.  Without
@@ -571,6 +603,9 @@ class VLDPOTrainer:
                     self.log({"loss": float(torch.stack(window).sum()) / n_opt, "learning_rate": lr,
                               "grad_norm": eng.grad_norm(), "epoch": ep + (micro / ga) / per_epoch})
                     window = []
+                ev = str(getattr(a, "evaluation_strategy", "no")).split(".")[-1].lower()
+                if ev == "steps" and self.eval_dataset and step % max(1, int(getattr(a, "eval_steps", None) or logging_steps)) == 0:
+                    self.evaluate()
                 if step >= total:
                     break
             ep += 1
