@@ -19,7 +19,7 @@ def _free_port():
 
 
 def _worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")   # CPU test: never a second device
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path[:0] = [root, os.path.join(root, "vl-rlhf_amd")]
@@ -85,13 +85,18 @@ def test_grad_reducer_two_ranks_gloo():
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q), daemon=True) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=240) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    try:
+        res = [q.get(timeout=240) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:                      # a rank stuck in a collective must not outlive the test
+            if p.is_alive():
+                p.terminate()
     for rank, ok1, err in res:
         assert ok1, f"rank {rank}: bucketed all-reduce mismatch"
         assert err < 2e-5, f"rank {rank}: DDP gradient differs from the single-rank gradient ({err})"

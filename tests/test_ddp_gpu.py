@@ -77,12 +77,17 @@ def test_two_rank_step_equals_one_rank_full_batch():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q), daemon=True) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
-    for p in procs:
-        p.join(timeout=60)
+    try:
+        res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+        for p in procs:
+            p.join(timeout=60)
+    finally:
+        for p in procs:                      # a rank stuck in a collective must not outlive the test
+            if p.is_alive():
+                p.terminate()
     for r in res:
         assert r[5] is None, r[5]
     z, cfg, W, W_ref, batch, rows = load_case("llava_hipsmall")
