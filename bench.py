@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Benchmark of the north-star metric: preference-pairs/sec of one full LLaVA-1.5-7B DPO optimizer step on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W        (N>1 without a launcher: re-executes itself under
+                                                          torch.distributed.run, one rank per GPU, backend nccl = RCCL)
 
 One "step" = policy forward + backward, reference forward, DPO loss, gradient all-reduce (N>1), clip + AdamW, on a
 synthetic batch already resident in HBM: per rank 4 pairs, 336x336 image, 1024 text tokens each (BASELINE.json
@@ -12,8 +13,12 @@ and ~75 % of the step); `achieved` = its algorithmic FLOPs (2*M*N*K per launch) 
 with HIP events on the launch stream inside the timed region (in-library profiler, kernel id 5); `per_kernel` lists the
 whole vlr_gemm_bf16 calls per layout (incl. peeled rows / split-K reduces) and the attention kernels.  `step_frac` = pairs/s x 174.87 TFLOP (reference forward inside the step) / 2516.6 TF/s.
 cpu_baseline: the fp32 CPU oracle (oracle/llava_dpo_oracle.py, a port of the reference algorithm) timed on this host's
-cores on a bounded sample - one decoder layer forward+backward at the configs[0] shape - and extrapolated to the full
-step; a reported baseline, not the target.
+cores on a bounded sample of the configs[0] step - one decoder layer fwd+bwd (+ reference fwd), the lm-head + log-prob
+fwd+bwd on all positions, one ViT layer, AdamW on one layer's parameters - each scaled by how often the full step runs
+it; a reported baseline, not the target.
+The timed steps rotate over four resident batches with lr = 2e-8 so that the loss stays in the non-saturated regime
+(the arithmetic of every kernel, AdamW included, does not depend on lr); `loss_first_step` / `loss_last_step` are printed
+and must be finite.
 """
 import argparse
 import json
@@ -30,15 +35,18 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2516.6          # 256 CU x 4096 FLOP/clk/CU x 2.4 GHz (MI355X_MICROARCH.md: ~2.5 PF dense)
+PROFILE_FILE = "profiles/r02_rocprofv3_kernel_stats_bench.txt"   # rocprofv3 --kernel-trace --stats of this command; `frac` can be recomputed from it
 TFLOP_PER_PAIR = {"ref_in_step": 174.87, "ref_precomputed": 131.24}
 
 
-def cpu_baseline(budget_s=20.0):
-    """fp32 oracle, one LLaMA-7B decoder layer fwd+bwd at the configs[0] shape (4 pairs, T=256 -> 8 x 831 positions)."""
+def cpu_baseline(budget_s=30.0):
+    """fp32 oracle on a bounded sample of the configs[0] step (4 pairs, T=256 -> 8 sequences x 831 positions, LLaMA-7B
+    widths): every distinct piece of the step is timed once and multiplied by its count in the full step."""
     from oracle import llava_dpo_oracle as O       # checker / baseline only
+    import torch.nn.functional as F
     torch.manual_seed(0)
     n_thr = torch.get_num_threads()
-    H, I, nh = 4096, 11008, 32
+    H, I, nh, V = 4096, 11008, 32, 32064
     B, S = 8, 831
     cfg = dict(hidden=H, inter=I, layers=1, heads=nh, vocab=8, rms_eps=1e-5)
     p = "language_model.model.layers.0."
@@ -49,26 +57,76 @@ def cpu_baseline(budget_s=20.0):
     x = torch.randn(B, S, H)
     am = torch.ones(B, S, dtype=torch.long)
     pos = torch.arange(S)[None].expand(B, S)
-    t_fwd = t_all = 0.0
-    reps = 0
     t_start = time.time()
-    while reps < 1 or (time.time() - t_start < budget_s and reps < 3):
-        leaves = {k: v.clone().requires_grad_(True) for k, v in W.items()}
-        t0 = time.time()
-        col = []
-        O.llama_hidden(x, am, pos, leaves, cfg, collect=col)
-        t1 = time.time()
-        col[0].square().mean().backward()
-        t2 = time.time()
-        t_fwd += t1 - t0
-        t_all += t2 - t0
-        reps += 1
-    t_fwd, t_all = t_fwd / reps, t_all / reps
-    # full step ~ 32 layers x (policy fwd+bwd + reference fwd); ViT / lm-head / optimizer (< 6 % of the FLOPs) not sampled
-    step_s = 32 * (t_all + t_fwd)
+    # (1) one decoder layer: policy fwd+bwd, reference fwd
+    leaves = {k: v.clone().requires_grad_(True) for k, v in W.items()}
+    t0 = time.time()
+    col = []
+    O.llama_hidden(x, am, pos, leaves, cfg, collect=col)
+    t_fwd = time.time() - t0
+    col[0].square().mean().backward()
+    t_layer = time.time() - t0
+    del leaves, col
+    # (2) lm-head + get_batch_logps on all positions (the reference materialises [2B,S,V] fp32), fwd + bwd, and once more fwd for the reference model
+    wl = (torch.randn(V, H) * 0.02).requires_grad_(True)
+    hid = torch.randn(B, S, H, requires_grad=True)
+    labels = torch.randint(0, V, (B, S))
+    labels[:, : S - 128] = -100
+    t0 = time.time()
+    lp = O.get_batch_logps(hid @ wl.t(), labels)
+    t_head_f = time.time() - t0
+    lp.sum().backward()
+    t_head = time.time() - t0
+    del lp, hid
+    # (3) AdamW on one decoder layer's 202 M parameters (fp32 state)
+    n_layer = 4 * H * H + 3 * H * I
+    st = {}
+    Wp = {"w": torch.zeros(n_layer)}
+    t0 = time.time()
+    O.adamw_step(Wp, {"w": torch.ones(n_layer)}, st, 1e-6, step=1)
+    t_adam = time.time() - t0
+    del Wp, st
+    # (4) one CLIP ViT-L/14-336 layer on the 4 distinct images (the oracle dedupes like the HIP path)
+    vcfg = dict(vit_hidden=1024, vit_mlp=4096, vit_layers=2, vit_heads=16, image_size=336, patch_size=14)
+    Wv = O.random_weights(dict(vcfg, hidden=8, inter=8, vocab=8, layers=0, heads=1), seed=0)
+    px = torch.randn(4, 3, 336, 336)
+    t0 = time.time()
+    with torch.no_grad():
+        O.clip_vit_features(px, Wv, vcfg)
+    t_vit = time.time() - t0
+    n_params = 32 * n_layer + 2 * V * H
+    step_s = 32 * (t_layer + t_fwd) + (t_head + t_head_f) + 23 * t_vit + t_adam * n_params / n_layer
     return dict(value=4.0 / step_s, unit="pairs/s", cores=n_thr, kind="port",
-                sample=f"1 of 32 LLaMA-7B decoder layers, fp32 fwd+bwd ({t_all:.2f} s) + ref fwd ({t_fwd:.2f} s) at the "
-                       f"configs[0] shape (4 pairs, T=256, S=831), x32 layers; ViT/lm-head/AdamW not sampled; {reps} rep(s)")
+                sample=f"configs[0] shape (4 pairs, T=256, S=831), fp32, {time.time() - t_start:.0f} s of CPU work: one LLaMA-7B decoder layer "
+                       f"fwd+bwd {t_layer:.2f} s and reference fwd {t_fwd:.2f} s (x32); lm-head + log-probs over all 8x831 positions "
+                       f"fwd+bwd {t_head:.2f} s + reference fwd {t_head_f:.2f} s (x1); one ViT layer on 4 images {t_vit:.2f} s (x23); AdamW on "
+                       f"one layer's {n_layer / 1e6:.0f} M parameters {t_adam:.2f} s (x{n_params / n_layer:.1f}); "
+                       f"extrapolated full step {step_s:.0f} s")
+
+
+def dry_run_launch(a):
+    """CPU-only skeleton of the multi-rank bench (tests/test_bench_launch.py): process group from the launcher's env, the
+    barrier / max-over-ranks timing, the metric all-reduce and the ONE JSON line - with a no-op step."""
+    from vlrlhf.parallel import all_reduce_mean_scalars, init_distributed_from_env
+    rank, local, world = init_distributed_from_env("gloo")
+    if world > 1:
+        dist.barrier()
+    t0 = time.time()
+    for _ in range(a.steps):
+        time.sleep(0.001)
+    if world > 1:
+        dist.barrier()
+    tmax = torch.tensor([time.time() - t0])
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    mean_rank = all_reduce_mean_scalars([float(rank)])[0]
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run (launcher path only)", "value": 0.0, "unit": "pairs/s", "n_gpus": world, "steps": a.steps,
+                          "warmup": a.warmup, "ms_per_step": round(float(tmax) / max(1, a.steps) * 1e3, 3), "rccl_ranks": world,
+                          "mean_rank": mean_rank, "INVALID": "dry run"}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -84,7 +142,16 @@ def main():
     ap.add_argument("--precomputed_ref", action="store_true", help="stream precomputed reference log-probs (SURVEY 8f rank 1)")
     ap.add_argument("--lora", action="store_true", help="variant: LoRA DPO of scripts/ddpo_llava.sh (r=128, alpha=256, dropout 0.05)")
     ap.add_argument("--lora_dropout", type=float, default=0.05)
+    ap.add_argument("--dry_run_launch", action="store_true", help="CPU test of the self-launch path: no model, gloo, no-op steps")
+    ap.add_argument("--lr", type=float, default=2e-8, help="learning rate of the timed steps (kernel arithmetic does not depend on it)")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: become one (one process per GPU on 127.0.0.1, like `accelerate launch` with accelerate_config/ddp.yaml)
+        from vlrlhf.parallel import relaunch_under_torchrun
+        sys.exit(relaunch_under_torchrun(os.path.abspath(__file__), sys.argv[1:], a.gpus))
+    if a.dry_run_launch:
+        return dry_run_launch(a)
 
     from vlrlhf import _hip
     from vlrlhf.models.Llava import LlavaDPOTrainer, LlavaForRL
@@ -93,7 +160,7 @@ def main():
     from types import SimpleNamespace
 
     rank, local, world = init_distributed_from_env()
-    assert world == max(1, a.gpus) or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    assert world == max(1, a.gpus), f"--gpus {a.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     cfg = dict(LLAVA_1_5_7B)
     if a.layers:
@@ -113,20 +180,24 @@ def main():
         tr = LlavaDPOTrainer(model, None if a.precomputed_ref else ref, 0.1, 0, "sigmoid", args, None, -100, 0,
                              precompute_ref_log_probs=a.precomputed_ref)
     eng.init_optimizer()
-    if world > 1:
-        eng.make_reducer()
+    reducer = eng.make_reducer() if world > 1 else None
     tr.ref_on_side_stream = not a.no_side_stream
-    batch = synthetic_batch(a.pairs, a.text_len, cfg["image_token"], 32000, cfg["image_size"], seed=1234 + rank)
-    batch = tr._prepare_inputs(batch)                      # inputs resident in HBM before the timed region
-    if a.precomputed_ref:
-        with torch.no_grad():
-            rc, rr, _, _ = tr.concatenated_forward(ref, batch)
-        batch["reference_chosen_logps"], batch["reference_rejected_logps"] = rc, rr
-    hp = dict(lr=1e-6, beta1=0.9, beta2=0.98, eps=1e-6, weight_decay=0.0, max_grad_norm=1.0)   # scripts/dpo_llava.sh:35-41
+    # four resident batches per rank (seeds 1234 + rank + 1000*i), rotated: inputs are in HBM before the timed region
+    batches = []
+    for i in range(4):
+        b_ = tr._prepare_inputs(synthetic_batch(a.pairs, a.text_len, cfg["image_token"], 32000, cfg["image_size"], seed=1234 + rank + 1000 * i))
+        if a.precomputed_ref:
+            with torch.no_grad():
+                rc, rr, _, _ = tr.concatenated_forward(ref, b_)
+            b_["reference_chosen_logps"], b_["reference_rejected_logps"] = rc, rr
+        batches.append(b_)
+    hp = dict(lr=a.lr, beta1=0.9, beta2=0.98, eps=1e-6, weight_decay=0.0, max_grad_norm=1.0)   # scripts/dpo_llava.sh:35-41 (lr: see docstring)
+    n_step = [0]
 
     def step():
-        loss = tr.training_step(model, batch)
+        loss = tr.training_step(model, batches[n_step[0] % len(batches)])
         eng.optimizer_step(grad_scale=1.0 / world, **hp)
+        n_step[0] += 1
         return loss
 
     def barrier():
@@ -135,8 +206,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    loss = None
-    for _ in range(a.warmup):
+    loss = loss_first = step() if a.warmup > 0 else None
+    for _ in range(a.warmup - 1):
         loss = step()
     barrier()
     _hip.lib_profile_start()
@@ -150,6 +221,26 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
+    loss_last = float(loss)
+    loss_first = float(loss_first) if loss_first is not None else loss_last
+    import math
+    assert math.isfinite(loss_first) and math.isfinite(loss_last), (loss_first, loss_last)
+    assert torch.isfinite(eng.norm_out).all(), "non-finite gradient norm in the timed region"
+    # exposed communication: the same steps with the gradient exchange switched off (ranks diverge afterwards - timing only)
+    exposed_ms = None
+    if reducer is not None:
+        reducer.enabled = False
+        step()
+        barrier()
+        t1 = time.time()
+        k2 = max(2, a.steps // 2)
+        for _ in range(k2):
+            step()
+        barrier()
+        t2 = torch.tensor([(time.time() - t1) / k2], device="cuda")
+        dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        exposed_ms = round((dt / a.steps - float(t2)) * 1e3, 2)
+        reducer.enabled = True
     # HBM traffic of the dominant kernel: PMC passes cannot run inside the timed region; the committed rocprofv3 --pmc
     # result (profiles/r01_pmc_hbm_traffic_8phase.*, tools/pmc_traffic.sh) is quoted when present
     traffic = None
@@ -181,11 +272,18 @@ def main():
                                    f"per-device batch {a.pairs} pairs (S=1599), full fine-tune of LLM+projector, frozen ViT, "
                                    + ("reference log-probs precomputed" if a.precomputed_ref else "reference forward inside the step"),
                        "global_batch_pairs": world * a.pairs, "text_len": a.text_len, "parallelism": f"dp{world}",
-                       "layers": cfg["layers"], "loss": float(loss)},
+                       "layers": cfg["layers"], "lr": a.lr, "resident_batches": len(batches), "loss_first_step": loss_first,
+                       "loss_last_step": loss_last, "grad_norm_last_step": float(eng.norm_out[0])},
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "comm": {"transport": reducer.transport if reducer is not None else None,
+                     "library": (reducer.transport_note if reducer is not None and reducer.transport == "native" else
+                                 ("torch.distributed backend " + dist.get_backend()) if world > 1 else None),
+                     "exposed_ms_per_step": exposed_ms, "bytes_per_step": 2 * (eng.lora_layout.numel if a.lora else eng.layout.numel)},
             "roofline": {"bound": "mfma", "kernel": "gemm256p_kernel<A_KS,B_KS> (8-phase 256x256x64 bf16 GEMM: NT/NN/TN)", "achieved": round(achieved, 1),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                          "traffic": traffic, "traffic_unit": "bytes/launch leaving L2 (2*FETCH_SIZE+WRITE_SIZE, rocprofv3 --pmc, offline pass; A+B of a decoder GEMM fit the 256 MB Infinity Cache, so most of the re-reads never reach HBM)",
                          "algorithmic_bytes_per_launch": round(2.0 * g_bytes / max(1, g_dec)), "launches": g_n, "avg_launch_ms": round(g_ms / max(1, g_n), 4), "per_kernel": per_kernel,
+                         "profile_file": PROFILE_FILE,
                          "kernel_share_of_step": round(g_ms * 1e-3 / dt, 3), "all_gemm_share_of_step": round(all_ms * 1e-3 / dt, 3),
                          "step_frac": round(pairs_per_s / world * per_pair / PEAK_BF16_TFLOPS, 4)},
         }

@@ -207,6 +207,20 @@ typedef struct { void* xn; void* qkv; void* attn; void* h; } vlr_vit_ws;   /* [M
 int vlr_vit_layer_fwd(const vlr_vit_cfg* cfg, const vlr_vit_layer_weights* w, const vlr_vit_ws* ws, void* x_inout,
                       int n_img, int T, vlr_stream_t stream);
 
+/* ---- data-parallel gradient exchange on RCCL over xGMI (replaces accelerate MULTI_GPU / torch DDP's NCCL all-reduce:
+ *      /root/reference accelerate_config/ddp.yaml:1-14; the reference itself never calls a collective).  One process per
+ *      GPU, one communicator per process.  RCCL is dlopen'ed at run time (the copy already mapped into the process,
+ *      else librccl.so.1; override with VLR_RCCL_LIB).  vlr_comm_unique_id fills `vlr_comm_unique_id_bytes()` HOST
+ *      bytes on rank 0; the launcher carries them to every rank; vlr_comm_init blocks until all `world` ranks called
+ *      it.  vlr_allreduce_bucket: in-place SUM over one contiguous slice of the flat gradient buffer, enqueued on
+ *      `stream` (dtype 0 = bf16, 1 = fp32); 1/world is folded into the optimizer's gradient scale. */
+int vlr_comm_unique_id_bytes(void);
+const char* vlr_comm_library(void);   /* path of the RCCL library in use ("" + vlr_last_error() when none loads) */
+int vlr_comm_unique_id(void* id_host);
+int vlr_comm_init(const void* id_host, int rank, int world, void** comm_out);
+int vlr_comm_destroy(void* comm);
+int vlr_allreduce_bucket(void* comm, void* buf, long n, int dtype, vlr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

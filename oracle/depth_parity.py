@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Full-depth (LLaVA-1.5-7B, 32 decoder layers) runs of the CPU oracle.  TEST INFRASTRUCTURE - NOT THE PRODUCT.
+
+    python oracle/depth_parity.py small      # 1 pair, T = 128 (S = 703), ragged: fp32 + bf16 error budget
+    python oracle/depth_parity.py configs0   # BASELINE.json configs[0]: 4 pairs, T = 256 (S = 831): fp32 + bf16-emulated
+
+The weights are the machine-independent hashed weights of oracle.llava_dpo_oracle.HashedWeights (reference = seed 0,
+policy = reference + 1e-3 * n'), so the GPU test regenerates the SAME 7B model on the MI355X from (seed, name) alone and
+compares its loss / log-probs with the numbers written here (tests/golden/llava7b_depth32_<case>.json) - the CPU side
+of the comparison takes minutes to hours on host cores and therefore runs offline, here, once.
+
+Error budget (`small`): the fp32 oracle (weights are bf16-representable in every variant, like a bf16 checkpoint run in
+fp32) against variants that round ONE group of tensors to bf16, showing which rounding points of a bf16 pipeline move
+the DPO loss by more than north_star's rtol = 1e-3.  Written to profiles/r02_bf16_error_budget.txt.
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from oracle import llava_dpo_oracle as O  # noqa: E402
+
+CASES = {
+    "small": dict(pairs=1, text_len=128, seed=11, ragged=True),
+    "configs0": dict(pairs=4, text_len=256, seed=12, ragged=True),
+}
+ALL = frozenset(("w", "vit", "x0", "xn", "qkv", "rope", "p", "attn", "resid", "gu", "act", "hidden"))
+MFMA_OPERANDS = frozenset(("w", "xn", "rope", "p", "attn", "act", "hidden"))      # what any bf16-MFMA pipeline must round
+VARIANTS = [
+    ("fp32", False, "reference-exact arithmetic (bf16-representable weights)"),
+    ("bf16_emulated", True, "every tensor the HIP path stores as bf16 (the oracle's emulate_bf16=True mode)"),
+    ("all+p", ALL, "the above + softmax probabilities rounded before P.V"),
+    ("only_hidden", frozenset(("hidden",)), "final-norm output (A operand of the lm-head GEMM) only"),
+    ("only_resid", frozenset(("resid", "x0")), "residual stream only"),
+    ("only_gemm_out", frozenset(("qkv", "gu")), "q/k/v and gate/up GEMM outputs only (storage choice)"),
+    ("only_vit", frozenset(("vit",)), "vision tower + projector only"),
+    ("mfma_operands", MFMA_OPERANDS, "only the operands of the MFMAs (xn, rope'd q/k, P, attn, act, hidden): floor of ANY bf16-MFMA path"),
+    ("mfma_operands-hidden", MFMA_OPERANDS - {"hidden"}, "the floor if the lm-head consumed an unrounded hidden state"),
+]
+
+
+def run(case, variants, cfg, log):
+    spec = CASES[case]
+    batch = O.synthetic_batch(spec["pairs"], spec["text_len"], cfg["image_token"], 32000, cfg["image_size"], spec["seed"],
+                              ragged=spec["ragged"])
+    Wr = O.HashedWeights(cfg, seed=0, cache=True)
+    Wp = O.HashedWeights(cfg, seed=0, delta=1e-3, seed_delta=1, cache=True)
+    out = {}
+    for name, emu, what in variants:
+        t0 = time.time()
+        with torch.no_grad():
+            pc, pr, _, _ = O.concatenated_forward(Wp, cfg, batch, "sigmoid", emu)
+            rc, rr, _, _ = O.concatenated_forward(Wr, cfg, batch, "sigmoid", emu)
+            losses, cr, rj = O.dpo_loss(pc, pr, rc, rr, 0.1)
+        out[name] = dict(loss=float(losses.mean()), policy_chosen_logps=pc.tolist(), policy_rejected_logps=pr.tolist(),
+                         reference_chosen_logps=rc.tolist(), reference_rejected_logps=rr.tolist(), what=what)
+        log(f"{case} {name}: loss {out[name]['loss']:.7f}  pc {pc.tolist()} pr {pr.tolist()} rc {rc.tolist()} rr {rr.tolist()}"
+            f"  [{time.time() - t0:.0f} s]")
+    return spec, out
+
+
+def main():
+    case = sys.argv[1] if len(sys.argv) > 1 else "small"
+    layers = int(os.environ.get("VLR_DEPTH_LAYERS", "32"))
+    cfg = dict(O.LLAVA_1_5_7B, layers=layers)
+    variants = VARIANTS if case == "small" else VARIANTS[:2]
+    if os.environ.get("VLR_DEPTH_VARIANTS"):
+        keep = os.environ["VLR_DEPTH_VARIANTS"].split(",")
+        variants = [v for v in VARIANTS if v[0] in keep]
+    logf = open(os.path.join(ROOT, "gpurun_out", f"depth_parity_{case}_L{layers}.log"), "a") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else None
+
+    def log(s):
+        print(s, flush=True)
+        if logf:
+            logf.write(s + "\n")
+            logf.flush()
+
+    spec, out = run(case, variants, cfg, log)
+    tag = f"llava7b_depth{layers}_{case}"
+    # a checksum of the generated weights so the GPU side can prove it rebuilt the same model
+    W = O.HashedWeights(cfg, seed=0, delta=1e-3, seed_delta=1)
+    probe = {k: W[k].double().sum().item() for k in ("language_model.model.layers.0.self_attn.q_proj.weight",
+                                                     f"language_model.model.layers.{layers - 1}.mlp.down_proj.weight",
+                                                     "language_model.model.norm.weight")}
+    with open(os.path.join(ROOT, "tests", "golden", tag + ".json"), "w") as f:
+        json.dump(dict(case=case, spec=spec, layers=layers, cfg="LLAVA_1_5_7B", weights="HashedWeights(seed=0) reference; policy delta=1e-3 seed_delta=1",
+                       beta=0.1, weight_probe=probe, results=out), f, indent=1)
+    if case == "small" and len(out) > 2:
+        ref = out["fp32"]["loss"]
+        lines = [f"bf16 error budget of the DPO loss, LLaVA-1.5-7B widths, {layers} decoder layers, {spec['pairs']} pair(s), T={spec['text_len']} "
+                 f"(S={spec['text_len'] - 1 + 576}), beta 0.1, sigmoid; CPU oracle (oracle/depth_parity.py)",
+                 f"{'variant':24s} {'loss':>11s} {'|d| vs fp32':>12s} {'rel':>9s}   max |d logp|   what is rounded to bf16"]
+        for name, r in out.items():
+            d = abs(r["loss"] - ref)
+            dl = max(abs(a - b) for k in ("policy_chosen_logps", "policy_rejected_logps", "reference_chosen_logps", "reference_rejected_logps")
+                     for a, b in zip(r[k], out["fp32"][k]))
+            lines.append(f"{name:24s} {r['loss']:11.7f} {d:12.3e} {d / abs(ref):9.2e}   {dl:12.4f}   {r['what']}")
+        with open(os.path.join(ROOT, "profiles", f"r02_bf16_error_budget_L{layers}.txt"), "w") as f:
+            f.write("\n".join(lines) + "\n")
+        log("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()

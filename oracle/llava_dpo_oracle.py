@@ -37,7 +37,13 @@ CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 
 
-def _rt(x, on):
+def _rt(x, on, tag=None):
+    """bf16 round trip.  `on`: False (fp32, reference-exact), True (every tensor the HIP path stores as bf16), or a set of
+    rounding-point tags (error-budget runs, oracle/depth_parity.py): only tensors whose tag is in the set are rounded.
+    Tags of the decoder: x0 xn qkv rope p attn resid gu act hidden; "w" weights; "vit" the whole vision tower +
+    projector.  "p" (softmax probabilities, the A operand of the P.V MFMA) is rounded only when named explicitly."""
+    if isinstance(on, (set, frozenset)):
+        on = tag in on
     return x.to(torch.bfloat16).to(torch.float32) if on else x
 
 
@@ -112,7 +118,7 @@ def clip_vit_features(pixel_values, W: Dict[str, torch.Tensor], cfg: dict, emula
                       prefix="vision_tower.vision_model."):
     """hidden_states[-2] of the CLIP ViT with the CLS token dropped (Llava/__init__.py:178-183).  Pre-LN encoder:
     x += out_proj(attn(LN1(x))); x += fc2(quick_gelu(fc1(LN2(x)))).  Only layers 0..L-2 are evaluated."""
-    r = lambda t: _rt(t, emulate_bf16)  # noqa: E731
+    r = lambda t: _rt(t, emulate_bf16, "vit")  # noqa: E731
     B = pixel_values.shape[0]
     D, P, nh = cfg["vit_hidden"], cfg["patch_size"], cfg["vit_heads"]
     g = cfg["image_size"] // P
@@ -144,7 +150,7 @@ def clip_vit_features(pixel_values, W: Dict[str, torch.Tensor], cfg: dict, emula
 
 def projector(feat, W, emulate_bf16=False, prefix="multi_modal_projector."):
     """Linear -> GELU(erf) -> Linear (transformers LlavaMultiModalProjector; call site Llava/__init__.py:191)."""
-    r = lambda t: _rt(t, emulate_bf16)  # noqa: E731
+    r = lambda t: _rt(t, emulate_bf16, "vit")  # noqa: E731
     h = r(F.gelu(r(feat) @ r(W[prefix + "linear_1.weight"]).t() + W[prefix + "linear_1.bias"]))
     return r(h @ r(W[prefix + "linear_2.weight"]).t() + W[prefix + "linear_2.bias"])
 
@@ -310,46 +316,53 @@ def random_lora(cfg, r, alpha, seed=0, b_std=0.0, dropout=0.0):
 
 def llama_hidden(embeds, attention_mask, position_ids, W, cfg, emulate_bf16=False,
                  prefix="language_model.model.", collect=None, lora=None):
-    """All decoder layers + final RMSNorm -> hidden [B,S,H] (what lm_head consumes)."""
-    r = lambda t: _rt(t, emulate_bf16)  # noqa: E731
+    """All decoder layers + final RMSNorm -> hidden [B,S,H] (what lm_head consumes).  `kv_heads` < heads = grouped-query
+    attention (Mistral / InternLM2): k, v have kv_heads heads, each shared by heads/kv_heads query heads."""
+    r = lambda t, tag=None: _rt(t, emulate_bf16, tag)  # noqa: E731
     B, S, H = embeds.shape
     nh = cfg["heads"]
-    hd = H // nh
+    nkv = cfg.get("kv_heads", nh)
+    hd = cfg.get("head_dim", H // nh)
     eps = cfg.get("rms_eps", 1e-5)
     cos, sin = rope_tables(position_ids, hd, cfg.get("rope_theta", 10000.0))
     bias = causal_padding_bias(attention_mask)
-    x = r(embeds)
+    x = r(embeds, "x0")
     for i in range(cfg["layers"]):
         p = f"{prefix}layers.{i}."
-        h = r(rms_norm(x, W[p + "input_layernorm.weight"], eps))
-        q = r(h @ r(W[p + "self_attn.q_proj.weight"]).t())
-        k = r(h @ r(W[p + "self_attn.k_proj.weight"]).t())
-        v = r(h @ r(W[p + "self_attn.v_proj.weight"]).t())
+        h = r(rms_norm(x, W[p + "input_layernorm.weight"], eps), "xn")
+        q = r(h @ r(W[p + "self_attn.q_proj.weight"], "w").t(), "qkv")
+        k = r(h @ r(W[p + "self_attn.k_proj.weight"], "w").t(), "qkv")
+        v = r(h @ r(W[p + "self_attn.v_proj.weight"], "w").t(), "qkv")
         if lora is not None:
-            q, k, v = (r(y + lora_delta(h, lora, i, t, r)) for y, t in ((q, "q_proj"), (k, "k_proj"), (v, "v_proj")))
-        q, k, v = (t.reshape(B, S, nh, hd).transpose(1, 2) for t in (q, k, v))
-        q, k = r(apply_rope(q, cos, sin)), r(apply_rope(k, cos, sin))
+            q, k, v = (r(y + lora_delta(h, lora, i, t, r), "qkv") for y, t in ((q, "q_proj"), (k, "k_proj"), (v, "v_proj")))
+        q = q.reshape(B, S, nh, hd).transpose(1, 2)
+        k, v = (t.reshape(B, S, nkv, hd).transpose(1, 2) for t in (k, v))
+        q, k = r(apply_rope(q, cos, sin), "rope"), r(apply_rope(k, cos, sin), "rope")
+        if nkv != nh:
+            k, v = (t.repeat_interleave(nh // nkv, dim=1) for t in (k, v))
         att = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(hd) + bias, dim=-1)
-        a = r((att @ v).transpose(1, 2).reshape(B, S, H))
-        x = r(x + a @ r(W[p + "self_attn.o_proj.weight"]).t())
+        if isinstance(emulate_bf16, (set, frozenset)):
+            att = r(att, "p")
+        a = r((att @ v).transpose(1, 2).reshape(B, S, nh * hd), "attn")
+        x = r(x + a @ r(W[p + "self_attn.o_proj.weight"], "w").t(), "resid")
         if lora is not None:
-            x = r(x + lora_delta(a, lora, i, "o_proj", r))
-        h = r(rms_norm(x, W[p + "post_attention_layernorm.weight"], eps))
-        gate = r(h @ r(W[p + "mlp.gate_proj.weight"]).t())
-        up = r(h @ r(W[p + "mlp.up_proj.weight"]).t())
+            x = r(x + lora_delta(a, lora, i, "o_proj", r), "resid")
+        h = r(rms_norm(x, W[p + "post_attention_layernorm.weight"], eps), "xn")
+        gate = r(h @ r(W[p + "mlp.gate_proj.weight"], "w").t(), "gu")
+        up = r(h @ r(W[p + "mlp.up_proj.weight"], "w").t(), "gu")
         if lora is not None:
-            gate, up = r(gate + lora_delta(h, lora, i, "gate_proj", r)), r(up + lora_delta(h, lora, i, "up_proj", r))
-        act = r(F.silu(gate) * up)
-        x = r(x + act @ r(W[p + "mlp.down_proj.weight"]).t())
+            gate, up = r(gate + lora_delta(h, lora, i, "gate_proj", r), "gu"), r(up + lora_delta(h, lora, i, "up_proj", r), "gu")
+        act = r(F.silu(gate) * up, "act")
+        x = r(x + act @ r(W[p + "mlp.down_proj.weight"], "w").t(), "resid")
         if lora is not None:
-            x = r(x + lora_delta(act, lora, i, "down_proj", r))
+            x = r(x + lora_delta(act, lora, i, "down_proj", r), "resid")
         if collect is not None:
             collect.append(x)
-    return r(rms_norm(x, W[prefix + "norm.weight"], eps))
+    return r(rms_norm(x, W[prefix + "norm.weight"], eps), "hidden")
 
 
 def lm_logits(hidden, W, emulate_bf16=False, key="language_model.lm_head.weight"):
-    return hidden @ _rt(W[key], emulate_bf16).t()
+    return hidden @ _rt(W[key], emulate_bf16, "w").t()
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -443,7 +456,7 @@ def llava_forward(W, cfg, input_ids, attention_mask, labels, pixel_values, emula
     -> projector -> merge -> decoder -> logits.  Returns (logits fp32, merged labels, aux).
     `dedupe_images`: the concatenated batch carries every image twice (trainer.py:138-142); the ViT is frozen and
     deterministic so it is evaluated once per distinct image and the features are repeated - identical result."""
-    emb = _rt(W["language_model.model.embed_tokens.weight"], emulate_bf16)[input_ids]
+    emb = _rt(W["language_model.model.embed_tokens.weight"][input_ids], emulate_bf16, "w")
     n = pixel_values.shape[0]
     if dedupe_images and n % 2 == 0 and torch.equal(pixel_values[: n // 2], pixel_values[n // 2:]):
         feat = clip_vit_features(pixel_values[: n // 2], W, cfg, emulate_bf16)
@@ -631,6 +644,127 @@ def random_weights(cfg, seed=0, std=0.02, dtype=torch.float32):
     W[lp + "norm.weight"] = 1 + rnd(H, s=0.05)
     W["language_model.lm_head.weight"] = rnd(V, H)
     return W
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Machine-independent synthetic weights for full-size parity (tests/test_hip_depth.py, oracle/depth_parity.py).
+# Integer hash -> Irwin-Hall(4) "normal" -> one fp32 multiply -> bf16: every step is exact or a single correctly
+# rounded operation, so a CPU here and the GPU there produce bit-identical tensors from (seed, name) alone - 7B
+# weights never have to be stored or shipped.  Restated on the product side in vlrlhf/utils/synthetic.py;
+# tests/test_oracle_golden.py checks the two agree bit for bit.
+# ----------------------------------------------------------------------------------------------------------
+def _hash32_np(x, key):
+    import numpy as np
+    x ^= np.uint32(key)
+    x *= np.uint32(0x45D9F3B)           # uint32 arithmetic wraps by definition
+    x ^= x >> np.uint32(16)
+    x *= np.uint32(0x45D9F3B)
+    x ^= x >> np.uint32(16)
+    return x
+
+
+def name_key(seed: int, name: str):
+    import hashlib
+    d = hashlib.sha256(f"{seed}:{name}".encode()).digest()
+    return int.from_bytes(d[:4], "little"), int.from_bytes(d[4:8], "little")
+
+
+def hashed_normal(n: int, seed: int, name: str, device="cpu"):
+    """~N(0,1) fp32 [n] (sum of four 16-bit uniforms, +-3.46 sigma), a pure function of (seed, name, index):
+    h1 = hash32(i ^ k1), h2 = hash32((i + 0x9E3779B9 mod 2^32) ^ k2), u = sum of their four 16-bit halves."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    k1, k2 = name_key(seed, name)
+    out = np.empty(n, np.float32)
+    step = 1 << 20
+
+    def chunk(a):
+        b = min(n, a + step)
+        i = np.arange(a, b, dtype=np.uint32)
+        h2 = _hash32_np(i + np.uint32(0x9E3779B9), k2)
+        h1 = _hash32_np(i, k1)
+        u = h1 & np.uint32(0xFFFF)
+        u += h1 >> np.uint32(16)
+        u += h2 & np.uint32(0xFFFF)
+        u += h2 >> np.uint32(16)
+        out[a:b] = (u.astype(np.int32) - 131070).astype(np.float32) * np.float32(1.0 / 37837.227)   # sqrt(4 * 65536^2 / 12)
+
+    with ThreadPoolExecutor(max(1, torch.get_num_threads())) as ex:
+        list(ex.map(chunk, range(0, n, step)))
+    return torch.from_numpy(out)
+
+
+def hashed_tensor(shape, seed, name, std=0.02, gain=False, device="cpu"):
+    """bf16-representable fp32 tensor: std * n (weights) or 1 + 0.05 * n (norm gains)."""
+    n = hashed_normal(int(math.prod(shape)), seed, name, device).view(*shape)
+    t = (n * 0.05 + 1.0) if gain else n * std
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+class HashedWeights:
+    """Lazy mapping name -> fp32 tensor with transformers==4.41.0 LLaVA checkpoint names; nothing is stored.
+    `delta` > 0: value = bf16(base(seed) + delta * n(seed_delta)) - a policy that differs from the reference `base`."""
+
+    def __init__(self, cfg, seed=0, std=0.02, delta=0.0, seed_delta=1, device="cpu", cache=False):
+        self.cfg, self.seed, self.std, self.delta, self.seed_delta, self.device = cfg, seed, std, delta, seed_delta, device
+        self._cache = {} if cache else None          # bf16 copies (2 B / parameter) for multi-pass runs
+        D, P, H, I, V = cfg["vit_hidden"], cfg["patch_size"], cfg["hidden"], cfg["inter"], cfg["vocab"]
+        nkv = cfg.get("kv_heads", cfg["heads"])
+        hd = cfg.get("head_dim", H // cfg["heads"])
+        ntok = (cfg["image_size"] // P) ** 2 + 1
+        sh = {}
+        vp = "vision_tower.vision_model."
+        sh[vp + "embeddings.class_embedding"] = (D,)
+        sh[vp + "embeddings.patch_embedding.weight"] = (D, 3, P, P)
+        sh[vp + "embeddings.position_embedding.weight"] = (ntok, D)
+        for nm in ("pre_layrnorm", "post_layernorm"):
+            sh[vp + nm + ".weight"], sh[vp + nm + ".bias"] = (D,), (D,)
+        for i in range(cfg["vit_layers"]):
+            p = f"{vp}encoder.layers.{i}."
+            for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                sh[p + f"self_attn.{nm}.weight"], sh[p + f"self_attn.{nm}.bias"] = (D, D), (D,)
+            for nm in ("layer_norm1", "layer_norm2"):
+                sh[p + nm + ".weight"], sh[p + nm + ".bias"] = (D,), (D,)
+            sh[p + "mlp.fc1.weight"], sh[p + "mlp.fc1.bias"] = (cfg["vit_mlp"], D), (cfg["vit_mlp"],)
+            sh[p + "mlp.fc2.weight"], sh[p + "mlp.fc2.bias"] = (D, cfg["vit_mlp"]), (D,)
+        sh["multi_modal_projector.linear_1.weight"], sh["multi_modal_projector.linear_1.bias"] = (H, D), (H,)
+        sh["multi_modal_projector.linear_2.weight"], sh["multi_modal_projector.linear_2.bias"] = (H, H), (H,)
+        lp = "language_model.model."
+        sh[lp + "embed_tokens.weight"] = (V, H)
+        for i in range(cfg["layers"]):
+            p = f"{lp}layers.{i}."
+            sh[p + "self_attn.q_proj.weight"], sh[p + "self_attn.o_proj.weight"] = (cfg["heads"] * hd, H), (H, cfg["heads"] * hd)
+            sh[p + "self_attn.k_proj.weight"], sh[p + "self_attn.v_proj.weight"] = (nkv * hd, H), (nkv * hd, H)
+            sh[p + "mlp.gate_proj.weight"], sh[p + "mlp.up_proj.weight"], sh[p + "mlp.down_proj.weight"] = (I, H), (I, H), (H, I)
+            sh[p + "input_layernorm.weight"], sh[p + "post_attention_layernorm.weight"] = (H,), (H,)
+        sh[lp + "norm.weight"] = (H,)
+        sh["language_model.lm_head.weight"] = (V, H)
+        self.shapes = sh
+
+    def keys(self):
+        return self.shapes.keys()
+
+    def __contains__(self, k):
+        return k in self.shapes
+
+    def __iter__(self):
+        return iter(self.shapes)
+
+    def __getitem__(self, name):
+        if self._cache is not None and name in self._cache:
+            return self._cache[name].to(torch.float32)
+        t = self._make(name)
+        if self._cache is not None:
+            self._cache[name] = t.to(torch.bfloat16)
+        return t
+
+    def _make(self, name):
+        shape = self.shapes[name]
+        gain = name.endswith("norm.weight") or name.endswith("norm1.weight") or name.endswith("norm2.weight") or name.endswith("layrnorm.weight")
+        t = hashed_tensor(shape, self.seed, name, self.std, gain, self.device)
+        if self.delta > 0 and not name.startswith("vision_tower."):
+            t = (t + hashed_normal(t.numel(), self.seed_delta, name, self.device).view(*shape) * self.delta).to(torch.bfloat16).to(torch.float32)
+        return t
 
 
 LLAVA_1_5_7B = dict(vit_hidden=1024, vit_mlp=4096, vit_layers=24, vit_heads=16, image_size=336, patch_size=14,

@@ -75,6 +75,19 @@ def _worker(rank, world, port, q):
     local /= world
     full = grads_of(batch)
     err = float((local - full).abs().max()) / float(full.abs().max())
+    # (3) the <= 9 logged scalars are averaged over the ranks with one all-reduce (trainer.log)
+    from vlrlhf.parallel import all_reduce_mean_scalars
+    from vlrlhf.base.trainer import VLDPOTrainer, _Accelerator, _State
+    from collections import defaultdict
+    got = all_reduce_mean_scalars([float(rank), torch.tensor(2.0 * rank + 1.0)])
+    ok1 = ok1 and got == [0.5, 2.0] and red.transport == "torch"
+    tr = VLDPOTrainer.__new__(VLDPOTrainer)
+    tr.__dict__.update(_stored_metrics={"train": defaultdict(list), "eval": defaultdict(list)}, state=_State(), log_history=[],
+                       args=None, accelerator=_Accelerator(None))
+    tr.store_metrics({"rewards/chosen": torch.tensor(1.0 + rank), "rewards/margins": 0.25 * rank})
+    tr.store_metrics({"rewards/chosen": torch.tensor(3.0 + rank), "rewards/margins": 0.25 * rank})
+    logs = tr.log({"loss": 10.0 * (rank + 1)})
+    ok1 = ok1 and abs(logs["rewards/chosen"] - 2.5) < 1e-6 and abs(logs["rewards/margins"] - 0.125) < 1e-6 and abs(logs["loss"] - 15.0) < 1e-6
     q.put((rank, ok1, err))
     dist.barrier()
     dist.destroy_process_group()

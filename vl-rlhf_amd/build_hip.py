@@ -15,8 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libvlr_hip.so")
-SOURCES = ["api.cpp", "layers.cpp", "gemm.hip", "gemm256p.hip", "attention.hip", "elementwise.hip", "dpo_ops.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+SOURCES = ["api.cpp", "layers.cpp", "comm.cpp", "gemm.hip", "gemm256p.hip", "attention.hip", "elementwise.hip", "dpo_ops.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-I/opt/rocm/include"]
 
 
 def _digest():
@@ -54,7 +54,7 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=6) as ex:
         objs = list(ex.map(cc, SOURCES))
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, capture_output=True, text=True)
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
     with open(stamp, "w") as f:

@@ -96,6 +96,7 @@ _SIGS = {
     "vlr_dropout": [P, P, L, F, U64, F, I, P],
     "vlr_dropout_mask": [P, L, F, U64, P],
     "vlr_layers_join": [P],
+    "vlr_allreduce_bucket": [P, P, L, I, P],
 }
 _INT_HELPERS = {
     "vlr_rmsnorm_bwd_workspace_bytes": [I],
@@ -105,6 +106,10 @@ _INT_HELPERS = {
     "vlr_prof_enable": [I],
     "vlr_prof_collect": [P, I],
     "vlr_gemm_set_splitk_workspace": [P, L],
+    "vlr_comm_unique_id_bytes": [],
+    "vlr_comm_unique_id": [P],
+    "vlr_comm_init": [P, I, I, P],
+    "vlr_comm_destroy": [P],
 }
 
 
@@ -122,6 +127,8 @@ def lib():
         l = C.CDLL(LIB_PATH)
         l.vlr_last_error.restype = C.c_char_p
         l.vlr_last_error.argtypes = []
+        l.vlr_comm_library.restype = C.c_char_p
+        l.vlr_comm_library.argtypes = []
         for name, sig in _SIGS.items():
             fn = getattr(l, name)
             fn.restype = I
@@ -135,7 +142,7 @@ def lib():
 
 
 def exported_symbols():
-    return list(_SIGS) + list(_INT_HELPERS) + ["vlr_last_error"]
+    return list(_SIGS) + list(_INT_HELPERS) + ["vlr_last_error", "vlr_comm_library"]
 
 
 def ptr(t):

@@ -433,10 +433,22 @@ class VLDPOTrainer:
             self._stored_metrics[train_eval][k].append(v)
 
     def log(self, logs: Dict[str, float]):
+        """trl DPOTrainer.log + HF Trainer.log: the stored metrics are averaged over the micro-steps since the last log and -
+        like the loss HF reports (`_nested_gather(tr_loss).mean()`) - over the data-parallel ranks, with ONE all-reduce of
+        the <= 9 scalars.  Every rank must call log() at the same steps (they do: same step counter)."""
+        from ..parallel import all_reduce_mean_scalars
         train_eval = "train" if "loss" in logs else "eval"
-        for k, vals in self._stored_metrics[train_eval].items():
-            logs[k] = float(torch.stack([torch.as_tensor(v, dtype=torch.float32).cpu() for v in vals]).mean())
+        keys, vals = [], []
+        for k, v in self._stored_metrics[train_eval].items():
+            keys.append(k)
+            vals.append(torch.stack([torch.as_tensor(x, dtype=torch.float32, device=self.accelerator.device) for x in v]).mean())
+        for k in ("loss", "eval_loss"):
+            if k in logs:
+                keys.append(k)
+                vals.append(float(logs[k]))
         self._stored_metrics[train_eval].clear()
+        if keys:
+            logs.update(zip(keys, all_reduce_mean_scalars(vals, device=self.accelerator.device if _world() > 1 and _backend() == "nccl" else None)))
         logs = dict(logs, step=self.state.global_step)
         self.log_history.append(logs)
         if getattr(self.args, "local_rank", 0) in (0, -1) and _rank() == 0:
@@ -643,3 +655,8 @@ def _world():
 def _rank():
     import torch.distributed as dist
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def _backend():
+    import torch.distributed as dist
+    return dist.get_backend() if dist.is_available() and dist.is_initialized() else None

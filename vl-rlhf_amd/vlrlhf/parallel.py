@@ -1,13 +1,94 @@
 """Data-parallel gradient reduction for one-process-per-GPU DPO (the only mode the path keeps: accelerate_config/ddp.yaml,
-MULTI_GPU).  `torch.distributed` backend "nccl" is RCCL on ROCm; xGMI is a point-to-point full mesh, so the flat bf16
-gradient is reduced in a few LARGE contiguous buckets (one decoder layer = ~0.4 GB at 7B) instead of DDP's 25 MB ones,
-each issued on a dedicated communication stream the moment the HIP backward has finished writing it (reverse layer
-order) and overlapped with the remaining backward.  SUM all-reduce; the 1/world_size is folded into the optimizer's
-gradient scale, so no extra pass over the gradients.  On CPU tensors (gloo tests) the same code runs synchronously."""
+MULTI_GPU).  xGMI is a point-to-point full mesh, so the flat bf16 gradient is reduced in a few LARGE contiguous buckets
+(one decoder layer = ~0.4 GB at 7B) instead of DDP's 25 MB ones, each issued on a dedicated communication stream the moment
+the HIP backward has finished writing it (reverse layer order) and overlapped with the remaining backward.  SUM
+all-reduce; the 1/world_size is folded into the optimizer's gradient scale, so no extra pass over the gradients.
+
+Two transports for the same buckets:
+  * "native"  - vlr_allreduce_bucket of libvlr_hip.so (include/vlr.h): RCCL called straight from the C ABI on our comm
+                stream; the unique id travels through torch.distributed once at start-up.  It is verified with a known
+                all-reduce before it is trusted; if RCCL cannot be loaded / initialised the reducer says so and uses
+  * "torch"   - torch.distributed all_reduce (backend "nccl" IS RCCL on ROCm; "gloo" for the CPU tests).
+VLR_COMM=native|torch forces one of them (native then raises instead of falling back)."""
+import ctypes as C
+import os
+import subprocess
+import sys
 from typing import Dict, Optional, Tuple
 
 import torch
 import torch.distributed as dist
+
+
+class NativeComm:
+    """RCCL communicator owned by libvlr_hip.so (one per process)."""
+
+    def __init__(self, group=None):
+        from . import _hip
+        self._hip = _hip
+        l = _hip.lib()
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        nbytes = _hip.helper("vlr_comm_unique_id_bytes")
+        dev = torch.device("cuda", torch.cuda.current_device())
+        idt = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        if self.rank == 0:
+            buf = (C.c_ubyte * nbytes)()
+            if l.vlr_comm_unique_id(buf) != 0:
+                raise _hip.VlrError(l.vlr_last_error().decode())
+            idt.copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
+        dist.broadcast(idt, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        host = (C.c_ubyte * nbytes).from_buffer_copy(bytes(idt.cpu().numpy().tobytes()))
+        comm = C.c_void_p()
+        if l.vlr_comm_init(host, self.rank, self.world, C.byref(comm)) != 0:
+            raise _hip.VlrError(l.vlr_last_error().decode())
+        self.comm = comm
+        self.library = l.vlr_comm_library().decode()
+        # trust, but verify: sum of (rank + 1) over the ranks, in both dtypes the reducer uses
+        for dt, code in ((torch.bfloat16, 0), (torch.float32, 1)):
+            t = torch.full((1024,), float(self.rank + 1), dtype=dt, device=dev)
+            self.all_reduce_(t, torch.cuda.current_stream())
+            torch.cuda.current_stream().synchronize()
+            want = self.world * (self.world + 1) / 2
+            if not bool((t.float() == want).all()):
+                raise _hip.VlrError(f"vlr_allreduce_bucket self-check failed: got {float(t[0])}, expected {want}")
+
+    def all_reduce_(self, t: torch.Tensor, stream):
+        code = {torch.bfloat16: 0, torch.float32: 1}[t.dtype]
+        l = self._hip.lib()
+        if l.vlr_allreduce_bucket(self.comm, t.data_ptr(), t.numel(), code, stream.cuda_stream) != 0:
+            raise self._hip.VlrError(l.vlr_last_error().decode())
+
+    def close(self):
+        if self.comm:
+            self._hip.lib().vlr_comm_destroy(self.comm)
+            self.comm = None
+
+
+def make_transport(group=None, cuda=True):
+    """-> (NativeComm | None, name, note).  CPU tensors (gloo tests) always use torch.distributed."""
+    want = os.environ.get("VLR_COMM", "auto").lower()
+    if not cuda or not dist.is_initialized() or dist.get_world_size(group) == 1 or want == "torch":
+        return None, "torch", ""
+    if dist.get_backend(group) != "nccl":       # e.g. gloo ranks sharing one GPU in the tests: RCCL refuses duplicate devices
+        return None, "torch", f"process group backend is {dist.get_backend(group)}"
+    ok, note, comm = 1, "", None
+    try:
+        comm = NativeComm(group)
+    except Exception as e:          # noqa: BLE001 - any failure of the native transport is reported, not swallowed
+        if want == "native":
+            raise
+        ok, note = 0, f"{type(e).__name__}: {e}"
+    # every rank must take the same path
+    flag = torch.tensor([ok], device="cuda")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag) == 0:
+        if comm is not None:
+            comm.close()
+        if dist.get_rank(group) == 0:
+            print(f"[vlrlhf.parallel] native RCCL transport unavailable ({note or 'another rank failed'}); "
+                  "using torch.distributed all_reduce", file=sys.stderr, flush=True)
+        return None, "torch", note or "another rank failed"
+    return comm, "native", comm.library
 
 
 class GradReducer:
@@ -20,7 +101,9 @@ class GradReducer:
         self.max_elems = max_bucket_elems
         self.enabled = True           # set False on non-final gradient-accumulation micro-steps (DDP no_sync)
         self._pending = []
+        self._issued = False
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.native, self.transport, self.transport_note = make_transport(group, self.cuda)
 
     def bucket_ready(self, name: str):
         if not self.enabled or self.world == 1:
@@ -32,6 +115,11 @@ class GradReducer:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.stream.wait_event(ev)
+            self._issued = True
+            if self.native is not None:
+                for a in range(lo, hi, self.max_elems):
+                    self.native.all_reduce_(self.grads[a:min(hi, a + self.max_elems)], self.stream)
+                return
             with torch.cuda.stream(self.stream):
                 for a in range(lo, hi, self.max_elems):
                     self._pending.append(dist.all_reduce(self.grads[a:min(hi, a + self.max_elems)], op=dist.ReduceOp.SUM,
@@ -46,16 +134,30 @@ class GradReducer:
         self.wait()
 
     def wait(self):
-        if self.cuda and self._pending:
+        if self.cuda and self._issued:
             for w in self._pending:
                 w.wait()
             torch.cuda.current_stream().wait_stream(self.stream)
         self._pending = []
+        self._issued = False
+
+
+def all_reduce_mean_scalars(values, device=None, group=None):
+    """ONE all-reduce for the <= 9 logged scalars (loss + the eight DPO metrics): HF Trainer reports the loss averaged
+    over the data-parallel ranks (`_nested_gather(tr_loss).mean()`); the metrics get the same treatment.  `values` is a
+    list of floats / 0-d tensors; returns a list of floats.  No-op (local values) without a process group."""
+    vals = [v.detach().float().reshape(()) if isinstance(v, torch.Tensor) else torch.tensor(float(v)) for v in values]
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return [float(v) for v in vals]
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    t = torch.stack([v.to(device) for v in vals])
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return (t / dist.get_world_size(group)).tolist()
 
 
 def init_distributed_from_env(backend: Optional[str] = None):
     """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher (torchrun / accelerate launch)."""
-    import os
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world <= 1:
         return 0, 0, 1
@@ -65,3 +167,22 @@ def init_distributed_from_env(backend: Optional[str] = None):
     if not dist.is_initialized():
         dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank, world_size=world)
     return rank, local, world
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def relaunch_under_torchrun(script: str, argv, nproc: int, env=None) -> int:
+    """`python script --gpus N` without a launcher: re-run it as N ranks of one node (one per GPU) under
+    torch.distributed.run on 127.0.0.1 - what accelerate launch does for the reference (accelerate_config/ddp.yaml:
+    MULTI_GPU, num_machines 1, num_processes 8).  Returns the launcher's exit code; rank 0's stdout passes through."""
+    e = dict(os.environ if env is None else env)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # the host driver only supports dmabuf IPC (RCCL needs it)
+    e.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, nproc))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), script] + list(argv)
+    return subprocess.call(cmd, env=e)

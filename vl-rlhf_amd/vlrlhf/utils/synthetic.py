@@ -11,6 +11,79 @@ LLAVA_1_5_7B = dict(vit_hidden=1024, vit_mlp=4096, vit_layers=24, vit_heads=16, 
                     model_pad_token_id=32001, rms_eps=1e-5, rope_theta=10000.0)
 
 
+_M32 = 0xFFFFFFFF
+
+
+def _hash32(x, key):
+    x = (x ^ key) & _M32
+    x = (x * 0x45D9F3B) & _M32          # operands < 2^32 and < 2^27: the int64 product cannot overflow
+    x = x ^ (x >> 16)
+    x = (x * 0x45D9F3B) & _M32
+    return x ^ (x >> 16)
+
+
+def hashed_normal(n, seed, name, device):
+    """~N(0,1) fp32 [n] as a pure integer function of (seed, name, index): sum of the four 16-bit halves of two 32-bit
+    hashes (Irwin-Hall, +-3.46 sigma), then ONE fp32 multiply.  Bit-identical on any device, so full-size (7B) parity
+    runs regenerate their weights where they are needed instead of shipping them."""
+    import hashlib
+    d = hashlib.sha256(f"{seed}:{name}".encode()).digest()
+    k1, k2 = int.from_bytes(d[:4], "little"), int.from_bytes(d[4:8], "little")
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    step = 1 << 26
+    for a in range(0, n, step):
+        i = torch.arange(a, min(n, a + step), dtype=torch.int64, device=device)
+        h1, h2 = _hash32(i, k1), _hash32((i + 0x9E3779B9) & _M32, k2)
+        u = (h1 & 0xFFFF) + (h1 >> 16) + (h2 & 0xFFFF) + (h2 >> 16)
+        out[a:a + step] = (u - 131070).to(torch.float32) * (1.0 / 37837.227)
+    return out
+
+
+def init_hashed_model(model, seed=0, std=0.02, policy_delta=1e-3, seed_delta=1):
+    """Weights named by their HF checkpoint keys and drawn by hashed_normal: reference = bf16(std * n) (norm gains
+    1 + 0.05 n), policy = bf16(reference + policy_delta * n').  Returns the reference model."""
+    from ..engine import VisionWeights
+    eng = model.engine
+    dev = eng.dev
+
+    def draw(name, shape, delta):
+        numel = 1
+        for s_ in shape:
+            numel *= s_
+        n = hashed_normal(numel, seed, name, dev).view(*shape)
+        gain = name.endswith(("norm.weight", "norm1.weight", "norm2.weight", "layrnorm.weight"))
+        t = ((n * 0.05 + 1.0) if gain else n * std).to(torch.bfloat16)
+        if delta > 0 and not name.startswith("vision_tower."):
+            t = (t.float() + hashed_normal(numel, seed_delta, name, dev).view(*shape) * delta).to(torch.bfloat16)
+        return t
+
+    ref = model.create_reference_model()
+    for ws, delta in ((ref.weights, 0.0), (eng.policy, policy_delta)):
+        for hf, name, r0, rows in eng.layout.hf_names():
+            dst = ws.v[name]
+            if dst.dim() == 1:
+                dst.copy_(draw(hf, tuple(dst.shape), delta))
+            else:
+                dst[r0:r0 + rows].copy_(draw(hf, (rows, dst.shape[1]), delta))
+    c = eng.cfg
+    D, P, F = c["vit_hidden"], c["patch_size"], c["vit_mlp"]
+    T = (c["image_size"] // P) ** 2 + 1
+    vp = "vision_tower.vision_model."
+    sh = {vp + "embeddings.class_embedding": (D,), vp + "embeddings.patch_embedding.weight": (D, 3, P, P),
+          vp + "embeddings.position_embedding.weight": (T, D), vp + "pre_layrnorm.weight": (D,), vp + "pre_layrnorm.bias": (D,)}
+    for i in range(c["vit_layers"] - 1):
+        p = f"{vp}encoder.layers.{i}."
+        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            sh[p + f"self_attn.{nm}.weight"], sh[p + f"self_attn.{nm}.bias"] = (D, D), (D,)
+        for nm in ("layer_norm1", "layer_norm2"):
+            sh[p + nm + ".weight"], sh[p + nm + ".bias"] = (D,), (D,)
+        sh[p + "mlp.fc1.weight"], sh[p + "mlp.fc1.bias"] = (F, D), (F,)
+        sh[p + "mlp.fc2.weight"], sh[p + "mlp.fc2.bias"] = (D, F), (D,)
+    eng.vision = VisionWeights(c, {k: draw(k, s_, 0.0) for k, s_ in sh.items()}, dev)
+    eng._vit_cache = None
+    return ref
+
+
 def vision_state_dict(cfg, device, seed=0, std=0.02, prefix="vision_tower.vision_model."):
     g = torch.Generator(device=device).manual_seed(seed)
     D, P, F = cfg["vit_hidden"], cfg["patch_size"], cfg["vit_mlp"]
