@@ -44,6 +44,21 @@ VARIANTS = [
 ]
 
 
+PROBE_FEATURES = 32
+
+
+class _Probe:
+    """list-like `collect` sink of llama_hidden: keeps, per decoder layer, x_out[sequence 0 and the last sequence,
+    positions {0, S//2, S-1}, first 32 features] - enough to tell a mis-wired layer from bf16 noise, small enough to commit."""
+
+    def __init__(self):
+        self.rows = []
+
+    def append(self, x):
+        S = x.shape[1]
+        self.rows.append(x[[0, -1]][:, [0, S // 2, S - 1], :PROBE_FEATURES].reshape(-1).tolist())
+
+
 def run(case, variants, cfg, log):
     spec = CASES[case]
     batch = O.synthetic_batch(spec["pairs"], spec["text_len"], cfg["image_token"], 32000, cfg["image_size"], spec["seed"],
@@ -53,12 +68,15 @@ def run(case, variants, cfg, log):
     out = {}
     for name, emu, what in variants:
         t0 = time.time()
+        col = _Probe() if name in ("fp32", "bf16_emulated") else None
         with torch.no_grad():
-            pc, pr, _, _ = O.concatenated_forward(Wp, cfg, batch, "sigmoid", emu)
+            pc, pr, _, _ = O.concatenated_forward(Wp, cfg, batch, "sigmoid", emu, collect=col)
             rc, rr, _, _ = O.concatenated_forward(Wr, cfg, batch, "sigmoid", emu)
             losses, cr, rj = O.dpo_loss(pc, pr, rc, rr, 0.1)
         out[name] = dict(loss=float(losses.mean()), policy_chosen_logps=pc.tolist(), policy_rejected_logps=pr.tolist(),
                          reference_chosen_logps=rc.tolist(), reference_rejected_logps=rr.tolist(), what=what)
+        if col is not None:
+            out[name]["layer_probe"] = col.rows     # residual stream after every decoder layer of the POLICY pass (see _Probe)
         log(f"{case} {name}: loss {out[name]['loss']:.7f}  pc {pc.tolist()} pr {pr.tolist()} rc {rc.tolist()} rr {rr.tolist()}"
             f"  [{time.time() - t0:.0f} s]")
     return spec, out
@@ -87,9 +105,14 @@ def main():
     probe = {k: W[k].double().sum().item() for k in ("language_model.model.layers.0.self_attn.q_proj.weight",
                                                      f"language_model.model.layers.{layers - 1}.mlp.down_proj.weight",
                                                      "language_model.model.norm.weight")}
-    with open(os.path.join(ROOT, "tests", "golden", tag + ".json"), "w") as f:
+    gpath = os.path.join(ROOT, "tests", "golden", tag + ".json")
+    if os.path.exists(gpath):          # partial re-runs (VLR_DEPTH_VARIANTS) update the file
+        old = json.load(open(gpath))["results"]
+        old.update(out)
+        out = old
+    with open(gpath, "w") as f:
         json.dump(dict(case=case, spec=spec, layers=layers, cfg="LLAVA_1_5_7B", weights="HashedWeights(seed=0) reference; policy delta=1e-3 seed_delta=1",
-                       beta=0.1, weight_probe=probe, results=out), f, indent=1)
+                       beta=0.1, weight_probe=probe, results=out), f)
     if case == "small" and len(out) > 2:
         ref = out["fp32"]["loss"]
         lines = [f"bf16 error budget of the DPO loss, LLaVA-1.5-7B widths, {layers} decoder layers, {spec['pairs']} pair(s), T={spec['text_len']} "

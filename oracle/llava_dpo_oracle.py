@@ -451,7 +451,7 @@ def dpo_loss(policy_chosen_logps, policy_rejected_logps, reference_chosen_logps,
 # Whole model / whole step
 # ----------------------------------------------------------------------------------------------------------
 def llava_forward(W, cfg, input_ids, attention_mask, labels, pixel_values, emulate_bf16=False,
-                  dedupe_images=True, return_hidden=False, lora=None):
+                  dedupe_images=True, return_hidden=False, lora=None, collect=None):
     """src/vlrlhf/models/Llava/__init__.py:111-271 on the training path: embed -> ViT(hidden_states[-2], no CLS)
     -> projector -> merge -> decoder -> logits.  Returns (logits fp32, merged labels, aux).
     `dedupe_images`: the concatenated batch carries every image twice (trainer.py:138-142); the ViT is frozen and
@@ -467,20 +467,20 @@ def llava_forward(W, cfg, input_ids, attention_mask, labels, pixel_values, emula
         img = projector(feat, W, emulate_bf16)
     merged, mask, mlabels, pos, img_map = merge_input_ids_with_image_features(
         img, emb, input_ids, attention_mask, labels, cfg["image_token"], cfg.get("model_pad_token_id", cfg["image_token"] + 1))
-    hidden = llama_hidden(merged, mask, pos, W, cfg, emulate_bf16, lora=lora)
+    hidden = llama_hidden(merged, mask, pos, W, cfg, emulate_bf16, lora=lora, collect=collect)
     aux = dict(vit_feat=feat, image_features=img, merged=merged, mask=mask, pos=pos, img_map=img_map, hidden=hidden)
     if return_hidden:
         return hidden, mlabels, aux
     return lm_logits(hidden, W, emulate_bf16), mlabels, aux
 
 
-def concatenated_forward(W, cfg, batch, loss_type="sigmoid", emulate_bf16=False, lora=None):
+def concatenated_forward(W, cfg, batch, loss_type="sigmoid", emulate_bf16=False, lora=None, collect=None):
     """src/vlrlhf/base/trainer.py:190-242 -> (chosen_logps, rejected_logps, chosen_logits, rejected_logits)."""
     cb = concatenated_inputs(batch)
     n = batch["chosen_labels"].shape[0]
     logits, labels, _ = llava_forward(W, cfg, cb["concatenated_input_ids"], cb["concatenated_attention_mask"],
                                       cb["concatenated_labels"], cb["concatenated_img_input_dict"]["pixel_values"],
-                                      emulate_bf16, lora=lora)
+                                      emulate_bf16, lora=lora, collect=collect)
     lp = get_batch_logps(logits, labels, mask_shared_tokens=(loss_type == "ddpo"))
     return lp[:n], lp[n:], logits[:n], logits[n:]
 

@@ -424,6 +424,32 @@ def gen_known_answers():
     print(f"[golden] known answers -> {path} ({os.path.getsize(path) / 1e3:.1f} kB)")
 
 
+def gen_processor_answers():
+    """The reference's OWN LlavaProcessor (src/vlrlhf/models/Llava/__init__.py:315-432) + VLProcessor base
+    (base/processor.py:11-164) run on the committed tiny real tokenizer (tests/golden/tiny_llava_processor, a
+    LlamaTokenizerFast with BOS and cross-boundary merges): the prompt string VLDPOTrainer.tokenize_row hands to trl
+    (base/trainer.py:105-118) and the token / label lists of process_batch_conv.  -> tests/golden/processor_answers.json"""
+    from vlrlhf.models.Llava import LlavaProcessor
+    proc = LlavaProcessor(os.path.join(OUT_DIR, "tiny_llava_processor"))
+    proc.train()
+    rows = [dict(prompt="What is shown in this picture?", chosen="A small brown dog is running.", rejected="Two people sitting at a table.", img_path="a.jpg"),
+            dict(prompt="<image>Is there a cat in the photo?", chosen="No, there is no cat.", rejected="Yes.", img_path=["b.jpg"]),
+            dict(prompt="How many apples are on the table", chosen="three apples", rejected="There are three apples and one orange on the table.", img_path="c.jpg")]
+    out = dict(pad_token_id=proc.tokenizer.pad_token_id, unk_token_id=proc.tokenizer.unk_token_id, rows=[])
+    for r in rows:
+        prompt = proc.format_multimodal_prompt(r["prompt"], r["img_path"])
+        conv = proc.make_single_turn_conv(prompt, "")
+        pr = proc.process_batch_conv([conv], system_message=None, add_end_for_empty_value=False)
+        full = proc.process_batch_conv([proc.make_single_turn_conv(prompt, r["chosen"])])
+        out["rows"].append(dict(row=r, formatted_prompt=prompt, conv=conv, prompt_raw_str=pr["raw_str"][0],
+                                prompt_full=pr["full"], chosen_full=full["full"], chosen_raw_str=full["raw_str"][0],
+                                valid=proc.is_multimodal_prompt_valid(prompt), stripped=proc.remove_image_placeholder(prompt)))
+    path = os.path.join(OUT_DIR, "processor_answers.json")
+    with open(path, "w") as f:
+        json.dump(out, f)
+    print(f"[golden] processor answers -> {path}")
+
+
 OPT = dict(lr=1e-3, beta1=0.9, beta2=0.98, eps=1e-6, weight_decay=0.05, max_grad_norm=1.0)
 
 CASES = {
@@ -443,6 +469,10 @@ CASES = {
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
+    if sys.argv[1:] == ["processor"]:        # adds the processor fixture without regenerating the tensor fixtures
+        gen_processor_answers()
+        sys.exit(0)
     gen_known_answers()
+    gen_processor_answers()
     for i, (name, cfg) in enumerate(CASES.items()):
         gen_case(name, cfg, seed=1000 + 17 * i)

@@ -25,3 +25,38 @@ def load_case(name):
 
 def t(z, k):
     return torch.from_numpy(z[k])
+
+
+TINY_PROCESSOR = os.path.join(GOLDEN, "tiny_llava_processor")
+# a checkpoint-shaped tiny LLaVA whose vocabulary matches tests/golden/tiny_llava_processor (385 tokens -> 392)
+TINY_CKPT_CFG = dict(vit_hidden=128, vit_mlp=256, vit_layers=3, vit_heads=2, image_size=28, patch_size=14, hidden=256, inter=512,
+                     layers=2, heads=2, vocab=392, image_token=383, model_pad_token_id=384)
+
+
+def write_tiny_checkpoint(path, cfg=None, seed=5, std=0.05):
+    """transformers==4.41.0-layout LLaVA checkpoint directory (config.json + model.safetensors + the tiny processor files)
+    with random weights: what `--model_name_or_path` points at.  Returns (cfg, state_dict)."""
+    import shutil
+    import sys
+    from safetensors.torch import save_file
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from oracle import llava_dpo_oracle as O
+    cfg = dict(cfg or TINY_CKPT_CFG)
+    os.makedirs(path, exist_ok=True)
+    W = {k: v.to(torch.bfloat16) for k, v in O.random_weights(cfg, seed=seed, std=std).items()}
+    save_file({k: v.contiguous() for k, v in W.items()}, os.path.join(path, "model.safetensors"))
+    hf = dict(architectures=["LlavaForConditionalGeneration"], model_type="llava", image_token_index=cfg["image_token"],
+              pad_token_id=cfg["model_pad_token_id"], ignore_index=-100, vocab_size=cfg["vocab"],
+              text_config=dict(model_type="llama", hidden_size=cfg["hidden"], intermediate_size=cfg["inter"],
+                               num_hidden_layers=cfg["layers"], num_attention_heads=cfg["heads"], vocab_size=cfg["vocab"],
+                               rms_norm_eps=1e-5, rope_theta=10000.0),
+              vision_config=dict(model_type="clip_vision_model", hidden_size=cfg["vit_hidden"], intermediate_size=cfg["vit_mlp"],
+                                 num_hidden_layers=cfg["vit_layers"], num_attention_heads=cfg["vit_heads"],
+                                 image_size=cfg["image_size"], patch_size=cfg["patch_size"], layer_norm_eps=1e-5))
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump(hf, f)
+    for fn in os.listdir(TINY_PROCESSOR):
+        shutil.copy(os.path.join(TINY_PROCESSOR, fn), os.path.join(path, fn))
+    return cfg, W

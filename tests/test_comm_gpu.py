@@ -1,0 +1,45 @@
+"""vlr_comm_* / vlr_allreduce_bucket (include/vlr.h): RCCL reached from the C ABI.  One MI355X is all a test box has, and RCCL
+refuses two ranks on one device, so this covers what a single rank can: the library resolves and loads RCCL, creates a
+communicator from a unique id, and an in-place SUM all-reduce over a 1-rank world returns the data unchanged, on a side
+stream, for both dtypes; argument errors come back as status codes.  The multi-rank wiring (id broadcast, self-check,
+fallback) is exercised with world_size 2 on CPU/gloo in tests/test_ddp_gloo.py and by the driver's scaling bench."""
+import ctypes as C
+
+import pytest
+import torch
+
+
+def test_comm_entry_points_report_argument_errors_without_gpu():
+    from vlrlhf import _hip
+    l = _hip.lib()
+    assert _hip.helper("vlr_comm_unique_id_bytes") == 128
+    assert l.vlr_comm_unique_id(None) == 1 and b"null" in l.vlr_last_error()
+    assert l.vlr_comm_init(None, 0, 1, None) == 1
+    buf = (C.c_ubyte * 128)()
+    comm = C.c_void_p()
+    assert l.vlr_comm_init(buf, 3, 2, C.byref(comm)) == 1 and b"outside world" in l.vlr_last_error()
+    assert l.vlr_allreduce_bucket(None, None, 8, 0, None) == 1 and b"communicator" in l.vlr_last_error()
+    assert l.vlr_comm_destroy(None) == 0
+
+
+@pytest.mark.gpu
+def test_single_rank_allreduce_through_the_c_abi():
+    from vlrlhf import _hip
+    l = _hip.lib()
+    lib_path = l.vlr_comm_library().decode()
+    assert "rccl" in lib_path, l.vlr_last_error()
+    buf = (C.c_ubyte * 128)()
+    assert l.vlr_comm_unique_id(buf) == 0, l.vlr_last_error()
+    comm = C.c_void_p()
+    assert l.vlr_comm_init(buf, 0, 1, C.byref(comm)) == 0, l.vlr_last_error()
+    side = torch.cuda.Stream()
+    for dt, code in ((torch.bfloat16, 0), (torch.float32, 1)):
+        x = torch.randn(1 << 20, device="cuda").to(dt)
+        want = x.clone()
+        side.wait_stream(torch.cuda.current_stream())
+        assert l.vlr_allreduce_bucket(comm, x.data_ptr(), x.numel(), code, side.cuda_stream) == 0, l.vlr_last_error()
+        side.synchronize()
+        assert torch.equal(x, want)
+    assert l.vlr_allreduce_bucket(comm, x.data_ptr(), 8, 5, None) == 1 and b"dtype" in l.vlr_last_error()
+    assert l.vlr_comm_destroy(comm) == 0
+    print(f"[comm] RCCL library in use: {lib_path}")

@@ -1,0 +1,142 @@
+"""FULL-DEPTH parity of the HIP path: LLaVA-1.5-7B widths, all 32 decoder layers, policy != reference, against numbers the
+fp32 CPU oracle produced offline (oracle/depth_parity.py -> tests/golden/llava7b_depth*_*.json; hours of host-core work,
+so it is NOT re-run here).  Both sides build the same 7B model from (seed, tensor name) with the machine-independent
+hashed weights (oracle.HashedWeights <-> vlrlhf.utils.synthetic.init_hashed_model), nothing is shipped.
+
+What is compared, per case:
+  * the residual stream after EVERY decoder layer at probe positions (a layer wired to the wrong weights / offsets in the
+    flat parameter buffer changes it completely; bf16 rounding moves it by a few per cent at depth 32);
+  * the four per-sequence log-prob sums and the DPO loss, against the fp32 oracle AND its bf16-emulating mode.
+Tolerances are the measured bf16 budget (profiles/r02_bf16_error_budget_L32.txt): the oracle's own bf16 emulation sits
+1.2e-2 from fp32 in the loss at depth 32, so rtol 1e-3 against an fp32 reference is not reachable by any bf16 pipeline; the
+assertion is that the HIP path is no further from fp32 than ~2x that emulation."""
+import json
+import math
+import os
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+from tests.golden_util import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+PROBE_FEATURES = 32
+
+
+def _golden(tag):
+    return json.load(open(os.path.join(GOLDEN, tag + ".json")))
+
+
+def _build(layers):
+    from vlrlhf.models.Llava import LlavaDPOTrainer, LlavaForRL
+    from vlrlhf.utils.synthetic import LLAVA_1_5_7B, init_hashed_model
+    cfg = dict(LLAVA_1_5_7B, layers=layers)
+    model = LlavaForRL(cfg)
+    ref = init_hashed_model(model, seed=0, std=0.02, policy_delta=1e-3, seed_delta=1)
+    tr = LlavaDPOTrainer(model, ref, 0.1, 0, "sigmoid", SimpleNamespace(gradient_accumulation_steps=1), None, -100, 0)
+    tr.ref_on_side_stream = False
+    return cfg, model, ref, tr
+
+
+def _check_weights(model, g):
+    sd = model.state_dict()
+    for k, want in g["weight_probe"].items():
+        got = float(sd[k].double().sum())
+        assert abs(got - want) <= 1e-9 * max(1.0, abs(want)), f"{k}: the GPU rebuilt different weights ({got} vs {want})"
+
+
+def _run_case(cfg, model, ref, tr, g):
+    from vlrlhf.utils.synthetic import synthetic_batch
+    sp = g["spec"]
+    batch = tr._prepare_inputs(synthetic_batch(sp["pairs"], sp["text_len"], cfg["image_token"], 32000, cfg["image_size"], sp["seed"],
+                                               ragged=sp["ragged"]))
+    model.train()
+    pc, pr, _, _ = tr.concatenated_forward(model, batch)          # grad mode: keeps every layer's activations
+    c = model._last_ctx
+    S, Bn = c["S"], c["Bn"]
+    rows = torch.tensor([b * S + p for b in (0, Bn - 1) for p in (0, S // 2, S - 1)], device="cuda")
+    probe = [a["x_out"][rows][:, :PROBE_FEATURES].float().reshape(-1).cpu() for a in c["acts"]]
+    with torch.no_grad():
+        rc, rr, _, _ = tr.concatenated_forward(ref, batch)
+    losses, _, _ = tr.dpo_loss(pc.detach(), pr.detach(), rc, rr)
+    torch.cuda.synchronize()
+    got = dict(loss=float(losses.mean()), policy_chosen_logps=pc.tolist(), policy_rejected_logps=pr.tolist(),
+               reference_chosen_logps=rc.tolist(), reference_rejected_logps=rr.tolist())
+    return got, probe
+
+
+def _compare(got, probe, g, label):
+    f32, emu = g["results"]["fp32"], g["results"]["bf16_emulated"]
+    L = g["layers"]
+    # ---- per-layer residual stream
+    worst = 0.0
+    for l in range(L):
+        want = torch.tensor(f32["layer_probe"][l])
+        rel = float((probe[l] - want).norm() / want.norm())
+        emu_rel = float((torch.tensor(emu["layer_probe"][l]) - want).norm() / want.norm())
+        worst = max(worst, rel)
+        assert rel < max(0.03, 3.0 * emu_rel), f"{label}: layer {l} residual stream is {rel:.3f} (relative) from the fp32 oracle (bf16 emulation: {emu_rel:.3f})"
+    # ---- log-probs and loss
+    keys = ("policy_chosen_logps", "policy_rejected_logps", "reference_chosen_logps", "reference_rejected_logps")
+    d_f32 = max(abs(a - b) for k in keys for a, b in zip(got[k], f32[k]))
+    d_emu = max(abs(a - b) for k in keys for a, b in zip(got[k], emu[k]))
+    e_f32 = max(abs(a - b) for k in keys for a, b in zip(emu[k], f32[k]))
+    l_f32, l_emu, le_f32 = abs(got["loss"] - f32["loss"]), abs(got["loss"] - emu["loss"]), abs(emu["loss"] - f32["loss"])
+    print(f"[depth {label}] loss HIP {got['loss']:.6f} fp32 {f32['loss']:.6f} bf16-emulated {emu['loss']:.6f} | |HIP-fp32| {l_f32:.2e} "
+          f"|HIP-emu| {l_emu:.2e} |emu-fp32| {le_f32:.2e} | max |d logp| HIP-fp32 {d_f32:.3f} HIP-emu {d_emu:.3f} emu-fp32 {e_f32:.3f} | "
+          f"worst layer residual rel err {worst:.4f}")
+    assert math.isfinite(got["loss"])
+    assert d_f32 < max(0.25, 2.5 * e_f32), (d_f32, e_f32)
+    assert l_f32 < max(5e-3, 2.5 * le_f32), (l_f32, le_f32)
+    return dict(loss=got["loss"], d_loss_fp32=l_f32, d_loss_emu=l_emu, d_logp_fp32=d_f32, worst_layer_rel=worst)
+
+
+def test_depth2_true_widths_vs_fp32_oracle():
+    g = _golden("llava7b_depth2_small")
+    cfg, model, ref, tr = _build(2)
+    _check_weights(model, g)
+    got, probe = _run_case(cfg, model, ref, tr, g)
+    _compare(got, probe, g, "L2 small")
+    del model, ref, tr
+    torch.cuda.empty_cache()
+
+
+@pytest.fixture(scope="module")
+def full32():
+    if torch.cuda.mem_get_info()[1] < 200 * (1 << 30):
+        pytest.skip("needs a 288 GB device")
+    cfg, model, ref, tr = _build(32)
+    yield cfg, model, ref, tr
+    del model, ref, tr
+    torch.cuda.empty_cache()
+
+
+def test_depth32_small_batch_vs_fp32_oracle(full32):
+    """1 pair, T = 128 (S = 703), ragged - VERDICT r01 item 1(a)."""
+    cfg, model, ref, tr = full32
+    g = _golden("llava7b_depth32_small")
+    _check_weights(model, g)
+    got, probe = _run_case(cfg, model, ref, tr, g)
+    _compare(got, probe, g, "L32 small")
+
+
+def test_depth32_configs0_shape_vs_fp32_oracle(full32):
+    """BASELINE.json configs[0] on the HIP path: 4 pairs, T = 256 (S = 831), all 32 layers, against the CPU fp32 reference run."""
+    cfg, model, ref, tr = full32
+    g = _golden("llava7b_depth32_configs0")
+    got, probe = _run_case(cfg, model, ref, tr, g)
+    _compare(got, probe, g, "L32 configs[0]")
+    # and the step itself at this shape: backward + clip + AdamW run, gradient norm finite and non-zero
+    from vlrlhf.utils.synthetic import synthetic_batch
+    sp = g["spec"]
+    batch = tr._prepare_inputs(synthetic_batch(sp["pairs"], sp["text_len"], cfg["image_token"], 32000, cfg["image_size"], sp["seed"], ragged=sp["ragged"]))
+    model.engine.init_optimizer()
+    model.engine.zero_grad()
+    loss = tr.training_step(model, batch)
+    model.engine.optimizer_step(1e-6, 0.9, 0.98, 1e-6, 0.0, 1.0)
+    torch.cuda.synchronize()
+    assert abs(float(loss) - got["loss"]) < 1e-6
+    n = model.engine.grad_norm()
+    assert math.isfinite(n) and n > 1e-4

@@ -217,3 +217,26 @@ def test_dropout_mask_restatement():
     assert int(O.dropout_mask(7, 64, 0.0).sum()) == 64
     # prefix property: the mask of element i does not depend on n
     assert torch.equal(O.dropout_mask(9, 4096, 0.3)[:512], O.dropout_mask(9, 512, 0.3))
+
+
+def test_hashed_weights_are_machine_independent_and_match_the_product_generator():
+    """oracle.hashed_normal (numpy uint32) == vlrlhf.utils.synthetic.hashed_normal (torch int64, any device), bit for bit;
+    known values pin the function itself; the synthetic batch builders of both sides agree."""
+    from oracle import llava_dpo_oracle as O
+    from vlrlhf.utils import synthetic as S
+    for n, seed, name in ((1, 0, "a"), (1000003, 5, "language_model.model.layers.3.mlp.gate_proj.weight"), ((1 << 20) + 7, 1, "x")):
+        a, b = O.hashed_normal(n, seed, name), S.hashed_normal(n, seed, name, "cpu")
+        assert torch.equal(a, b)
+    x = O.hashed_normal(4, 5, "language_model.x")
+    assert [round(v, 4) for v in x.tolist()] == [-1.3347, -0.5576, -0.144, 0.4453]
+    big = O.hashed_normal(1 << 20, 0, "stats")
+    assert abs(float(big.mean())) < 5e-3 and abs(float(big.std()) - 1.0) < 5e-3
+    W = O.HashedWeights(dict(O.LLAVA_1_5_7B, layers=1), seed=0, delta=1e-3)
+    g = W["language_model.model.layers.0.input_layernorm.weight"]
+    assert g.shape == (4096,) and abs(float(g.mean()) - 1.0) < 5e-3 and torch.equal(g, g.bfloat16().float())
+    bo = O.synthetic_batch(2, 48, 32000, 32000, 28, 11, ragged=True)
+    bp = S.synthetic_batch(2, 48, 32000, 32000, 28, 11, ragged=True)
+    for k, v in bo.items():
+        if isinstance(v, torch.Tensor):
+            assert torch.equal(v, bp[k]), k
+    assert torch.equal(bo["img_input_dict"]["pixel_values"], bp["img_input_dict"]["pixel_values"])

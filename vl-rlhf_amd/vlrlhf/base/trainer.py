@@ -544,24 +544,41 @@ class VLDPOTrainer:
         return dataset
 
     def _train_row_batches(self, epoch: int):
+        """One epoch of this rank's row batches.  torch DistributedSampler semantics (accelerate MULTI_GPU, ddp.yaml): the
+        shuffled index list is padded by wrapping to a multiple of the world size so that EVERY rank gets the same number
+        of batches (unequal counts would dead-lock the gradient all-reduce), then strided by rank.  HF's default
+        dataloader_drop_last=False: the final partial batch is kept."""
         bs = int(getattr(self.args, "per_device_train_batch_size", 4))
         world, rank = _world(), _rank()
         idx = list(range(len(self.train_dataset)))
         random.Random(int(getattr(self.args, "seed", 42)) + epoch).shuffle(idx)
-        idx = idx[rank::world]                               # DistributedSampler semantics (ddp.yaml: MULTI_GPU)
-        for i in range(0, len(idx) - bs + 1, bs):
-            yield [self.train_dataset[j] for j in idx[i:i + bs]]
+        if world > 1 and len(idx) % world:
+            idx += idx[: world - len(idx) % world]
+        idx = idx[rank::world]
+        drop_last = bool(getattr(self.args, "dataloader_drop_last", False))
+        for i in range(0, len(idx), bs):
+            rows = idx[i:i + bs]
+            if len(rows) < bs and drop_last:
+                break
+            yield [self.train_dataset[j] for j in rows]
 
-    def get_train_batches(self, epoch: int):
+    def _batches_per_epoch(self) -> int:
+        bs = int(getattr(self.args, "per_device_train_batch_size", 4))
+        n = -(-len(self.train_dataset) // _world())
+        return n // bs if getattr(self.args, "dataloader_drop_last", False) else -(-n // bs)
+
+    def get_train_batches(self, epoch: int, skip: int = 0):
         """collated batches of one epoch.  The collator (image decode + CLIP preprocess) runs `dataloader_prefetch` batches
         ahead on a background thread and the H2D copy goes through a copy stream (base/loader.py); 0 = collate inline."""
+        import itertools
         depth = int(getattr(self.args, "dataloader_prefetch", 2) or 0)
+        rows_iter = lambda: itertools.islice(self._train_row_batches(epoch), skip, None)   # noqa: E731  (resume: skip consumed batches un-collated)
         if depth <= 0:
-            for rows in self._train_row_batches(epoch):
+            for rows in rows_iter():
                 yield self.data_collator(rows)
             return
         from .loader import PrefetchLoader
-        yield from PrefetchLoader(lambda: self._train_row_batches(epoch), self.data_collator, self.accelerator.device, depth)
+        yield from PrefetchLoader(rows_iter, self.data_collator, self.accelerator.device, depth)
 
     def lr_at(self, step: int, total: int) -> float:
         """transformers get_scheduler('cosine' | 'linear' | 'constant') with warmup_ratio / warmup_steps."""
@@ -578,25 +595,107 @@ class VLDPOTrainer:
             return base
         return base * max(0.0, 1.0 - prog)
 
+    # ------------------------------------------------------------------------------------------ checkpoints
+    def _checkpoint_dirs(self):
+        import os
+        import re
+        out_dir = str(getattr(self.args, "output_dir", "output"))
+        if not os.path.isdir(out_dir):
+            return []
+        found = [(int(m.group(1)), os.path.join(out_dir, d)) for d in os.listdir(out_dir)
+                 if (m := re.fullmatch(r"checkpoint-(\d+)", d)) and os.path.isfile(os.path.join(out_dir, d, "trainer_state.json"))]
+        return [p for _, p in sorted(found)]
+
+    def save_checkpoint(self, step: int, micro: int, epoch: int, window_len: int = 0):
+        """HF Trainer._save_checkpoint for this path: `output_dir/checkpoint-<step>/` with the weights (adapters under LoRA),
+        the optimizer state (fp32 master / m / v + step), trainer_state.json (step counters, log history) and the python RNG;
+        rotated to `save_total_limit`.  Rank 0 writes (every rank holds identical state under DDP)."""
+        import json
+        import os
+        import shutil
+        from safetensors.torch import save_file
+        if _rank() != 0:
+            return None
+        eng = self.model.engine
+        path = os.path.join(str(getattr(self.args, "output_dir", "output")), f"checkpoint-{step}")
+        tmp = path + ".tmp"
+        shutil.rmtree(tmp, ignore_errors=True)
+        os.makedirs(tmp)
+        if self.is_peft_model:
+            self.model.save_adapter(tmp)
+        else:
+            self.model.save_pretrained(tmp)
+        st = eng.optimizer_state()
+        if st is not None:
+            for k in ("master", "m", "v"):          # one file per buffer: 27 GB each at 7B full fine-tuning
+                save_file({k: st[k].detach().cpu()}, os.path.join(tmp, f"optimizer_{k}.safetensors"))
+        with open(os.path.join(tmp, "trainer_state.json"), "w") as f:
+            json.dump(dict(global_step=step, micro_step=micro, epoch=epoch, opt_step=eng.opt_step, log_history=self.log_history,
+                           world_size=_world(), lora_calls=getattr(eng, "_lora_calls", 0)), f, indent=1)
+        shutil.rmtree(path, ignore_errors=True)
+        os.replace(tmp, path)                        # a checkpoint directory is either complete or absent
+        limit = int(getattr(self.args, "save_total_limit", 0) or 0)
+        if limit > 0:
+            for old in self._checkpoint_dirs()[:-limit]:
+                shutil.rmtree(old, ignore_errors=True)
+        return path
+
+    def load_checkpoint(self, path: str) -> dict:
+        import json
+        import os
+        from safetensors.torch import load_file
+        eng = self.model.engine
+        with open(os.path.join(path, "trainer_state.json")) as f:
+            state = json.load(f)
+        if self.is_peft_model:
+            self.model.load_adapter(path)
+        else:
+            sd = {}
+            for fn in sorted(os.listdir(path)):
+                if fn.startswith("model") and fn.endswith(".safetensors"):
+                    sd.update(load_file(os.path.join(path, fn)))
+            eng.policy.load_state_dict(sd)
+        if os.path.isfile(os.path.join(path, "optimizer_master.safetensors")):
+            bufs = {k: load_file(os.path.join(path, f"optimizer_{k}.safetensors"))[k] for k in ("master", "m", "v")}
+            eng.load_optimizer_state(bufs["master"], bufs["m"], bufs["v"], state["opt_step"])
+        if hasattr(eng, "_lora_calls"):
+            eng._lora_calls = int(state.get("lora_calls", 0))
+        self.log_history = list(state.get("log_history", []))
+        return state
+
     def train(self, resume_from_checkpoint=None):
         a = self.args
         eng = self.model.engine
         ga = max(1, int(getattr(a, "gradient_accumulation_steps", 1) or 1))
-        bs = int(getattr(a, "per_device_train_batch_size", 4))
-        per_epoch = max(1, (len(self.train_dataset) // _world() // bs) // ga)
+        n_batches = self._batches_per_epoch()
+        if n_batches == 0:
+            raise ValueError(f"the training set ({len(self.train_dataset)} rows over {_world()} rank(s)) yields no batch of "
+                             f"per_device_train_batch_size={getattr(a, 'per_device_train_batch_size', 4)} with dataloader_drop_last")
+        per_epoch = max(1, n_batches // ga)
         max_steps = int(getattr(a, "max_steps", -1) or -1)
         epochs = float(getattr(a, "num_train_epochs", 1.0))
         total = max_steps if max_steps > 0 else int(math.ceil(per_epoch * epochs))
         logging_steps = max(1, int(getattr(a, "logging_steps", 10) or 10))
+        save_strategy = str(getattr(a, "save_strategy", "no")).split(".")[-1].lower()
+        save_steps = max(1, int(getattr(a, "save_steps", 500) or 500))
         if self.precompute_ref_log_probs and not self._precomputed_train_ref_log_probs:
             self.precompute_reference_log_probs(self.train_dataset)
             self._precomputed_train_ref_log_probs = True
         eng.init_optimizer() if eng.master is None else None
         eng.zero_grad()
         step, micro, ep = 0, 0, 0
+        skip = 0              # micro-batches of the resumed epoch that were already consumed
+        if resume_from_checkpoint:
+            ckpt = resume_from_checkpoint if isinstance(resume_from_checkpoint, str) else (self._checkpoint_dirs() or [None])[-1]
+            if ckpt is None:
+                raise ValueError(f"resume_from_checkpoint: no checkpoint-* directory under {getattr(a, 'output_dir', 'output')}")
+            st = self.load_checkpoint(ckpt)
+            step, micro = int(st["global_step"]), int(st["micro_step"])
+            ep, skip = divmod(micro, n_batches)
+            self.state.global_step = step
         window = []           # device scalars; only read back at logging time (no per-step host sync)
         while step < total:
-            for batch in self.get_train_batches(ep):
+            for batch in self.get_train_batches(ep, skip=skip):
                 if eng.reducer is not None:        # DDP no_sync: reduce only with the last micro-batch of an accumulation window
                     eng.reducer.enabled = (micro + 1) % ga == 0
                 window.append(self.training_step(self.model, batch))
@@ -613,18 +712,31 @@ class VLDPOTrainer:
                 if step % logging_steps == 0 or step >= total:
                     n_opt = max(1, len(window) // ga)
                     self.log({"loss": float(torch.stack(window).sum()) / n_opt, "learning_rate": lr,
-                              "grad_norm": eng.grad_norm(), "epoch": ep + (micro / ga) / per_epoch})
+                              "grad_norm": eng.grad_norm(), "epoch": micro / ga / per_epoch})
                     window = []
                 ev = str(getattr(a, "evaluation_strategy", "no")).split(".")[-1].lower()
                 if ev == "steps" and self.eval_dataset and step % max(1, int(getattr(a, "eval_steps", None) or logging_steps)) == 0:
                     self.evaluate()
+                if save_strategy == "steps" and step % save_steps == 0:
+                    self.save_checkpoint(step, micro, ep)
                 if step >= total:
                     break
+            if save_strategy == "epoch" and step < total:
+                self.save_checkpoint(step, micro, ep)
             ep += 1
+            skip = 0
         return self.state
 
     def save_state(self):
-        pass
+        """HF Trainer.save_state: trainer_state.json (step counter + log history) in output_dir, rank 0."""
+        import json
+        import os
+        if _rank() != 0:
+            return
+        out_dir = str(getattr(self.args, "output_dir", "output"))
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "trainer_state.json"), "w") as f:
+            json.dump(dict(global_step=self.state.global_step, log_history=self.log_history), f, indent=1)
 
     def add_callback(self, cb):
         self.callbacks.append(cb)

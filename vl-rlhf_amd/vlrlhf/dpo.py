@@ -23,6 +23,9 @@ class ScriptArguments:
     ignore_bias_buffers: Optional[bool] = False
     freeze_vision_tower: bool = True
     loss_type: str = "sigmoid"
+    # not in the reference: shape of the `--dataset_name synthetic` rows (benchmarks / tests; no network for the hub datasets)
+    synthetic_rows: int = 64
+    synthetic_image_size: int = 336
 
 
 @dataclass
@@ -72,14 +75,17 @@ class TrainingArguments:
     save_steps: int = 500
     save_total_limit: int = 1
     evaluation_strategy: str = "no"
+    eval_strategy: Optional[str] = None      # newer transformers spelling (scripts/dpo_llava.sh passes --eval_strategy steps)
     eval_steps: int = 500
     per_device_eval_batch_size: int = 4
     dataloader_num_workers: int = 0
+    dataloader_drop_last: bool = False
+    dataloader_prefetch: int = 2             # batches collated ahead on the background thread (base/loader.py); 0 = inline
     remove_unused_columns: bool = False
     local_rank: int = 0
 
 
-def _parse(*classes):
+def _parse(*classes, argv=None):
     p = argparse.ArgumentParser()
     for c in classes:
         for f in fields(c):
@@ -89,15 +95,24 @@ def _parse(*classes):
             else:
                 base = {Optional[int]: int, Optional[float]: float, Optional[str]: str}.get(f.type, t or str)
                 p.add_argument(f"--{f.name}", type=base, default=f.default)
-    ns, _ = p.parse_known_args()
-    return [c(**{f.name: getattr(ns, f.name) for f in fields(c)}) for c in classes]
+    ns, unknown = p.parse_known_args(argv)
+    if unknown:
+        # HF's parser would raise; the reference scripts pass flags of subsystems that do not exist here (wandb, deepspeed,
+        # gradient checkpointing knobs ...): say which ones are being ignored instead of swallowing them
+        import sys
+        print(f"[vlrlhf.dpo] WARNING: ignoring unsupported arguments: {' '.join(unknown)}", file=sys.stderr, flush=True)
+    out = [c(**{f.name: getattr(ns, f.name) for f in fields(c)}) for c in classes]
+    for o in out:
+        if isinstance(o, TrainingArguments) and o.eval_strategy:
+            o.evaluation_strategy = o.eval_strategy
+    return out
 
 
-def main():
+def main(argv=None):
     from vlrlhf.parallel import init_distributed_from_env
     from vlrlhf.utils.auto_load import MyAutoDPOCollator, MyAutoDPOTrainer, MyAutoProcessor, auto_load_rlmodel
     from vlrlhf.utils.data import DATASET_MAP
-    script_args, training_args, lora_args = _parse(ScriptArguments, TrainingArguments, LoraArguments)
+    script_args, training_args, lora_args = _parse(ScriptArguments, TrainingArguments, LoraArguments, argv=argv)
     rank, local, world = init_distributed_from_env()
     training_args.local_rank = local
     model, ref_model, lora_config = auto_load_rlmodel(script_args, training_args, lora_args)
@@ -127,19 +142,13 @@ def main():
     dpo_trainer.train(resume_from_checkpoint=training_args.resume_from_checkpoint)
     dpo_trainer.save_state()
     if rank == 0:
-        from safetensors.torch import save_file
-        os.makedirs(training_args.output_dir, exist_ok=True)
+        # reference dpo.py:140-149: adapters only under LoRA (utils/common.py:97-98), else trainer.save_model -> the whole model
         if training_args.use_lora:
-            # reference utils/common.py:97-98 (get_peft_state_maybe_zero_3): only the adapter tensors, peft file layout
-            import json
-            save_file({k: v.contiguous() for k, v in model.lora_state_dict().items()},
-                      os.path.join(training_args.output_dir, "adapter_model.safetensors"))
-            with open(os.path.join(training_args.output_dir, "adapter_config.json"), "w") as f:
-                json.dump(dict(lora_config, peft_type="LORA", base_model_name_or_path=script_args.model_name_or_path), f, indent=1)
+            model.save_adapter(training_args.output_dir, base_model_name_or_path=script_args.model_name_or_path)
         else:
-            save_file({k: v.contiguous() for k, v in model.state_dict().items()},
-                      os.path.join(training_args.output_dir, "model.safetensors"))
+            model.save_pretrained(training_args.output_dir)
         processor.save_pretrained(training_args.output_dir)
+    return dpo_trainer
 
 
 if __name__ == "__main__":

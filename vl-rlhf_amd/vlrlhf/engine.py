@@ -125,6 +125,7 @@ class WeightSet:
     def __init__(self, layout: ParamLayout, device, flat: Optional[torch.Tensor] = None):
         self.layout = layout
         self.flat = flat if flat is not None else torch.zeros(layout.numel, dtype=BF16, device=device)
+        self.version = 0          # bumped by load_state_dict (caches derived from the weights key on it)
         self.v = {n: self.flat[layout.offset[n]: layout.offset[n] + int(math.prod(s))].view(*s)
                   for n, s in layout.shape.items()}
 
@@ -132,6 +133,7 @@ class WeightSet:
         return WeightSet(self.layout, self.flat.device, self.flat.clone())
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict=True):
+        self.version += 1
         seen = set()
         for hf, name, r0, rows in self.layout.hf_names():
             if hf not in sd:
@@ -219,6 +221,8 @@ class LlavaHipEngine:
                    for n, s in self.layout.shape.items()}
         self.master = self.m = self.v = None     # fp32 optimizer state, allocated by init_optimizer()
         self.opt_step = 0
+        self._weights_version = 0                # bumped whenever weights are (re)loaded: keys caches derived from them
+        self.vision_sd = {}
         self.grad_fresh = True                   # next backward overwrites instead of accumulating
         self._ws = {}
         self._vit_cache = None
@@ -242,7 +246,11 @@ class LlavaHipEngine:
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
         self.policy.load_state_dict(sd)
         self.vision = VisionWeights(self.cfg, sd, self.dev)
+        # the frozen tower's ORIGINAL tensors (bf16, ~0.6 GB for CLIP-L): save_pretrained writes them back so that the
+        # output directory reloads (reference trainer._save writes the whole model)
+        self.vision_sd = {k: v.detach().to(device=self.dev, dtype=BF16) for k, v in sd.items() if k.startswith("vision_tower.")}
         self._vit_cache = None
+        self._weights_version += 1
         if self.master is not None:
             self.init_optimizer()
 
@@ -447,7 +455,7 @@ class LlavaHipEngine:
             lora_seed = (self.lora_seed << 40) + (self._lora_calls << 16)        # + 8*layer + target inside the library
             drop = self.lora["dropout"] > 0 and self.training
         for l in range(self.L):
-            a = self._layer_acts(tag if save else "scratch", l if save else (l % 2), Bn, S)
+            a = self._layer_acts(tag if save else tag + "/scratch", l if save else (l % 2), Bn, S)   # scratch per pass tag (side stream)
             if use_lora:
                 if "u" not in a or a["u"].shape[1] != 7 * r:
                     a["u"] = torch.empty(M, 7 * r, dtype=BF16, device=self.dev)
@@ -492,7 +500,7 @@ class LlavaHipEngine:
             return logps, lp
         hg = torch.empty(R, H, dtype=BF16, device=self.dev)
         _hip.call("vlr_gather_rows", ctx["hidden"], rows, hg, R, H)
-        logits = self._buf(("logits", R), (R, V), torch.float32)
+        logits = self._buf(("logits", ctx["tag"], R), (R, V), torch.float32)    # per pass: the reference pass runs on a side stream
         _hip.call("vlr_gemm_bf16", 0, hg, ws.v["lm_head"], logits, None, None, R, V, H, H, H, V, 0, 0, 0, 1)
         tok = torch.empty(R, dtype=torch.float32, device=self.dev)
         lse = torch.empty(R, dtype=torch.float32, device=self.dev)
@@ -505,12 +513,15 @@ class LlavaHipEngine:
         """mean over [lo:hi] sequences, all positions, all vocabulary entries of the logits = mean_rows(h . sum_v W_v)/V
         (the `logits/chosen|rejected` metrics of trl's get_batch_loss_metrics, never materialising [B,S,V])."""
         ws = ctx["ws"]
-        wsum = self._ws.get(("wsum", id(ws), ws.flat._version))
+        # keyed on the optimizer step / load counter: vlr_adamw_step writes the weights through raw pointers, so torch's
+        # tensor version counter never moves
+        key = ("wsum", id(ws), self.opt_step if ws is self.policy else -1, (self._weights_version, ws.version))
+        wsum = self._ws.get(key)
         if wsum is None:
             wsum = torch.empty(self.H, dtype=torch.float32, device=self.dev)
             _hip.call("vlr_colsum_f32", ws.v["lm_head"], self.V, self.H, self.H, wsum, self._colsum_ws)
-            self._ws = {k: v for k, v in self._ws.items() if not (isinstance(k, tuple) and k and k[0] == "wsum")}
-            self._ws[("wsum", id(ws), ws.flat._version)] = wsum
+            self._ws = {k: v for k, v in self._ws.items() if not (isinstance(k, tuple) and len(k) == 4 and k[0] == "wsum" and k[1] == id(ws))}
+            self._ws[key] = wsum
         S = ctx["S"]
         rd = torch.empty(ctx["M"], dtype=torch.float32, device=self.dev)
         _hip.call("vlr_rowdot", ctx["hidden"], wsum, rd, ctx["M"], self.H)
@@ -537,8 +548,8 @@ class LlavaHipEngine:
             if not acc and self.lora is None:
                 self.gv["lm_head"].zero_()
             return dhidden
-        logits = self._buf(("logits", R), (R, V), torch.float32)
-        # recompute the logits of the response rows if another pass (the reference forward) reused the buffer
+        logits = self._buf(("logits", ctx["tag"], R), (R, V), torch.float32)
+        # recompute the logits of the response rows: a later forward of the same pass tag may have reused the buffer
         _hip.call("vlr_gemm_bf16", 0, lp["hg"], ctx["ws"].v["lm_head"], logits, None, None, R, V, H, H, H, V, 0, 0, 0, 1)
         dl = self._buf(("dlogits", R), (R, V))
         _hip.call("vlr_dlogits_rows", logits, lp["tgt"], lp["lse"], lp["seq_off"], ctx["Bn"],
@@ -649,6 +660,25 @@ class LlavaHipEngine:
         self.m = torch.zeros_like(self.master)
         self.v = torch.zeros_like(self.master)
         self.opt_step = 0
+
+    def optimizer_state(self):
+        """fp32 master / m / v + step counter (what torch.optim.AdamW.state_dict() carries), for checkpoints."""
+        if self.master is None:
+            return None
+        self.wait_optimizer()
+        return dict(master=self.master, m=self.m, v=self.v, opt_step=self.opt_step)
+
+    def load_optimizer_state(self, master, m, v, opt_step):
+        if self.master is None:
+            self.init_optimizer()
+        for dst, src in ((self.master, master), (self.m, m), (self.v, v)):
+            if dst.numel() != src.numel():
+                raise ValueError(f"optimizer state has {src.numel()} elements, the trainable buffer {dst.numel()}")
+            dst.copy_(src.to(self.dev))
+        self.opt_step = int(opt_step)
+        # the bf16 working copy is the rounding of the master weights
+        (self.lora_flat if self.lora is not None else self.policy.flat).copy_(self.master)
+        self._weights_version += 1
 
     def zero_grad(self):
         self.grad_fresh = True

@@ -146,6 +146,21 @@ def _cfg_from_hf(hf: dict) -> dict:
         ignore_index=hf.get("ignore_index", -100))
 
 
+def _hf_from_cfg(c: dict) -> dict:
+    """config.json (transformers==4.41.0 LlavaConfig layout) for a model that was not loaded from a checkpoint."""
+    return dict(
+        architectures=["LlavaForConditionalGeneration"], model_type="llava", image_token_index=c["image_token"],
+        pad_token_id=c.get("model_pad_token_id", c["image_token"] + 1), ignore_index=c.get("ignore_index", -100),
+        projector_hidden_act="gelu", vision_feature_layer=-2, vision_feature_select_strategy="default",
+        vocab_size=c["vocab"], torch_dtype="bfloat16",
+        text_config=dict(model_type="llama", hidden_size=c["hidden"], intermediate_size=c["inter"], num_hidden_layers=c["layers"],
+                         num_attention_heads=c["heads"], num_key_value_heads=c.get("kv_heads", c["heads"]), vocab_size=c["vocab"],
+                         rms_norm_eps=c.get("rms_eps", 1e-5), rope_theta=c.get("rope_theta", 10000.0)),
+        vision_config=dict(model_type="clip_vision_model", hidden_size=c["vit_hidden"], intermediate_size=c["vit_mlp"],
+                           num_hidden_layers=c["vit_layers"], num_attention_heads=c["vit_heads"], image_size=c["image_size"],
+                           patch_size=c["patch_size"], layer_norm_eps=c.get("vit_ln_eps", 1e-5)))
+
+
 class LlavaForRL(nn.Module):
     def __init__(self, cfg: dict, engine: Optional[LlavaHipEngine] = None, weights: Optional[WeightSet] = None,
                  trainable: bool = True):
@@ -189,6 +204,8 @@ class LlavaForRL(nn.Module):
         with open(os.path.join(path, "config.json")) as f:
             cfg = _cfg_from_hf(json.load(f))
         m = cls(cfg)
+        with open(os.path.join(path, "config.json")) as f:
+            m.hf_config = json.load(f)
         sd = {}
         idx = os.path.join(path, "model.safetensors.index.json")
         files = sorted(set(json.load(open(idx))["weight_map"].values())) if os.path.exists(idx) else \
@@ -197,6 +214,55 @@ class LlavaForRL(nn.Module):
             sd.update(load_file(os.path.join(path, fn)))
         m.engine.load_state_dict(sd)
         return m
+
+    def save_pretrained(self, output_dir, max_shard_bytes: int = 5 << 30, state_dict=None):
+        """Writes a directory `from_pretrained` (and transformers) can load: config.json + sharded safetensors of the WHOLE
+        model - language model, projector and the frozen vision tower's original tensors (reference: HF Trainer._save ->
+        model.save_pretrained).  `state_dict`: alternative LLM/projector tensors (e.g. merge_and_unload())."""
+        from safetensors.torch import save_file
+        os.makedirs(output_dir, exist_ok=True)
+        hf = dict(getattr(self, "hf_config", None) or _hf_from_cfg(self.engine.cfg))
+        hf.setdefault("architectures", ["LlavaForConditionalGeneration"])
+        with open(os.path.join(output_dir, "config.json"), "w") as f:
+            json.dump(hf, f, indent=1)
+        sd = dict(state_dict if state_dict is not None else self.state_dict())
+        sd.update(self.engine.vision_sd)
+        shards, cur, size = [], {}, 0
+        for k, v in sd.items():
+            nb = v.numel() * v.element_size()
+            if cur and size + nb > max_shard_bytes:
+                shards.append(cur)
+                cur, size = {}, 0
+            cur[k] = v
+            size += nb
+        shards.append(cur)
+        if len(shards) == 1:
+            save_file({k: v.detach().contiguous().cpu() for k, v in shards[0].items()}, os.path.join(output_dir, "model.safetensors"))
+            return
+        wmap = {}
+        for i, sh in enumerate(shards):
+            fn = f"model-{i + 1:05d}-of-{len(shards):05d}.safetensors"
+            save_file({k: v.detach().contiguous().cpu() for k, v in sh.items()}, os.path.join(output_dir, fn))
+            wmap.update({k: fn for k in sh})
+        with open(os.path.join(output_dir, "model.safetensors.index.json"), "w") as f:
+            json.dump(dict(metadata=dict(total_size=sum(v.numel() * v.element_size() for v in sd.values())), weight_map=wmap), f, indent=1)
+
+    def save_adapter(self, output_dir, base_model_name_or_path=None):
+        """peft PeftModel.save_pretrained layout: adapter_model.safetensors + adapter_config.json holding LoraConfig fields only
+        (reference utils/common.py:97-98 saves exactly the adapter tensors)."""
+        from safetensors.torch import save_file
+        os.makedirs(output_dir, exist_ok=True)
+        save_file({k: v.contiguous().cpu() for k, v in self.lora_state_dict().items()}, os.path.join(output_dir, "adapter_model.safetensors"))
+        lo = self.engine.lora
+        cfg = dict(peft_type="LORA", task_type="CAUSAL_LM", base_model_name_or_path=base_model_name_or_path, r=lo["r"],
+                   lora_alpha=lo["alpha"], lora_dropout=lo["dropout"], target_modules=list(self.default_lora_target), bias="none",
+                   fan_in_fan_out=False, inference_mode=True, modules_to_save=None, init_lora_weights=True)
+        with open(os.path.join(output_dir, "adapter_config.json"), "w") as f:
+            json.dump(cfg, f, indent=1)
+
+    def load_adapter(self, path):
+        from safetensors.torch import load_file
+        self.engine.load_lora_state_dict(load_file(os.path.join(path, "adapter_model.safetensors")))
 
     # ---- LoRA (peft) ---------------------------------------------------------------------------------------
     def apply_lora(self, peft_config):
