@@ -49,6 +49,17 @@ int vlr_gemm_bf16_scaled(int layout, const void* A, const void* B, void* C, cons
  * distinct streams that launch such a GEMM (policy pass + reference pass on a side stream); further streams run
  * un-split.  64 MiB per slot covers the 7B shapes.  (NULL, 0) unregisters. */
 int vlr_gemm_set_splitk_workspace(void* workspace, long bytes);
+/* Fused forward projections of the decoder layer (transformers LlamaMLP / LlamaAttention; call site
+ * src/vlrlhf/models/Llava/__init__.py:232).  The elementwise op that follows the projection runs on the fp32 accumulators
+ * in the GEMM epilogue - one rounding to bf16 instead of two and no extra pass over the tensor.
+ *  vlr_gemm_swiglu  : gu [M][2I] = x [M][K] . wgu[2I][K]^T (gate | up), act [M][I] = silu(gate) * up; store_gu = 0 skips writing
+ *                     gu where the fused kernel runs (no-grad passes; gu must still be a valid scratch buffer).
+ *  vlr_gemm_qkv_rope: qkv [M][N] = x . wqkv[N][K]^T with rotate-half RoPE by pos[row] on the first rope_cols columns (the q and k
+ *                     heads; head_dim 128 takes the fused path, other sizes the plain GEMM + vlr_rope). */
+int vlr_gemm_swiglu(const void* x, const void* wgu, void* gu, void* act, int M, int I, int K, int ldx, int store_gu,
+                    vlr_stream_t stream);
+int vlr_gemm_qkv_rope(const void* x, const void* wqkv, void* qkv, const int* pos, const float* cos_t, const float* sin_t, int M,
+                      int N, int rope_cols, int K, int ldx, int head_dim, int max_pos, vlr_stream_t stream);
 
 /* ---- normalisation / activations (transformers LlamaRMSNorm, CLIP LayerNorm, SwiGLU, GELU; call sites
  *      Llava/__init__.py:178-191,232) ------------------------------------------------------------------------- */
@@ -152,6 +163,10 @@ typedef struct {  /* scratch shared by all layers in the backward */
 int vlr_decoder_layer_fwd(const vlr_llama_cfg* cfg, const vlr_layer_weights* w, const vlr_layer_acts* a,
                           const void* x_in, const int* pos, const int* key_mask, int batch, int S,
                           vlr_stream_t stream);
+/* keep_for_backward = 0: a no-grad pass (reference model, evaluation) - tensors only the backward reads are not written */
+int vlr_decoder_layer_fwd_ex(const vlr_llama_cfg* cfg, const vlr_layer_weights* w, const vlr_layer_acts* a,
+                             const void* x_in, const int* pos, const int* key_mask, int batch, int S,
+                             int keep_for_backward, vlr_stream_t stream);
 int vlr_decoder_layer_bwd(const vlr_llama_cfg* cfg, const vlr_layer_weights* w, const vlr_layer_grads* g,
                           int accumulate, const vlr_layer_acts* a, const vlr_layer_bwd_ws* ws, const void* x_in,
                           const void* dx_out, void* dx_in, const int* pos, const int* key_mask, int batch, int S,

@@ -685,3 +685,58 @@ def test_gemm_accumulate_odd_tile_counts(hip, layout, shape):
     c = c0.clone()
     hip.call("vlr_gemm_bf16", layout, A, Bm, c, None, None, M, N, K, K if layout != 2 else M, K if layout == 0 else N, N, 0, 0, 1, 0)
     check(c, ref, 8e-3, f"accumulate {shape} layout {layout}")
+
+
+# ---------------------------------------------------------------------------------------------------- fused epilogues
+@pytest.mark.parametrize("shape", [(4104, 2176, 512), (4352, 2184, 320), (12792, 2048, 256), (300, 256, 128)])
+@pytest.mark.parametrize("store_gu", [1, 0])
+def test_gemm_swiglu_fused(hip, shape, store_gu):
+    """vlr_gemm_swiglu: act = silu(x Wg^T) * (x Wu^T) from the fp32 accumulators; shapes with > 256 workgroup tiles take the
+    fused 256-tile kernel (ragged M, I not a multiple of 128, a peeled tail), the last one the plain GEMM + SwiGLU kernel."""
+    M, I, K = shape
+    x = rnd(M, K, seed=1)
+    w = rnd(2 * I, K, scale=0.05, seed=2)
+    gu_ref = x.float() @ w.float().t()
+    act_ref = F.silu(gu_ref[:, :I]) * gu_ref[:, I:]
+    gu = torch.full((M, 2 * I), float("nan"), dtype=torch.bfloat16, device=DEV)
+    act = torch.full((M, I), float("nan"), dtype=torch.bfloat16, device=DEV)
+    hip.call("vlr_gemm_swiglu", x, w, gu, act, M, I, K, K, store_gu)
+    torch.cuda.synchronize()
+    check(act, act_ref, 8e-3, f"swiglu act {shape}")
+    if store_gu:
+        check(gu, gu_ref, 8e-3, f"swiglu gate|up {shape}")
+    # the unfused path (plain GEMM, then the SwiGLU kernel on the rounded gate|up) agrees to bf16 rounding
+    gu2 = torch.empty_like(gu)
+    act2 = torch.empty_like(act)
+    hip.call("vlr_gemm_bf16", 0, x, w, gu2, None, None, M, 2 * I, K, K, K, 2 * I, 0, 0, 0, 0)
+    hip.call("vlr_swiglu_fwd", gu2, act2, M, I)
+    torch.cuda.synchronize()
+    check(act, act2, 1.6e-2, f"fused vs unfused {shape}")
+
+
+@pytest.mark.parametrize("shape", [(4104, 512, 12, 12), (6400, 320, 16, 4), (12792, 256, 8, 8), (300, 128, 2, 2)])
+def test_gemm_qkv_rope_fused(hip, shape):
+    """vlr_gemm_qkv_rope: q|k|v projection with rotate-half RoPE in the epilogue (q and k heads only; grouped-query layouts have
+    fewer k/v heads), against the fp32 reference rotation of the fp32 product."""
+    M, K, nh, nkv = shape
+    hd = 128
+    N, rope_cols = (nh + 2 * nkv) * hd, (nh + nkv) * hd
+    max_pos = 700
+    x = rnd(M, K, seed=3)
+    w = rnd(N, K, scale=0.05, seed=4)
+    g = torch.Generator().manual_seed(5)
+    pos = torch.randint(0, max_pos, (M,), generator=g, dtype=torch.int32).to(DEV)
+    cos = torch.empty(max_pos, hd // 2, dtype=torch.float32, device=DEV)
+    sin = torch.empty_like(cos)
+    hip.call("vlr_rope_table", cos, sin, max_pos, hd, 10000.0)
+    y = (x.float() @ w.float().t())
+    ref = y.clone()
+    heads = y[:, :rope_cols].view(M, nh + nkv, hd)
+    c, s_ = cos[pos.long()][:, None, :], sin[pos.long()][:, None, :]
+    x1, x2 = heads[..., : hd // 2], heads[..., hd // 2:]
+    ref[:, :rope_cols] = torch.cat([x1 * c - x2 * s_, x2 * c + x1 * s_], -1).reshape(M, rope_cols)
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    hip.call("vlr_gemm_qkv_rope", x, w, out, pos, cos, sin, M, N, rope_cols, K, K, hd, max_pos)
+    torch.cuda.synchronize()
+    check(out, ref, 8e-3, f"qkv rope {shape}")
+    assert torch.isfinite(out.float()).all()

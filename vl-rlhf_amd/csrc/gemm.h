@@ -20,6 +20,22 @@ struct GemmParams {
     int splitk;      // > 1: blockIdx.y = K-slice z of kchunk elements, raw alpha*acc -> part[z][M][N] fp32 (128x128 kernel only)
     int kchunk;
     float* part;
+    // ---- fused epilogues of the 256x256 continuous-pipeline kernel (gemm256p.hip, NT only); fuse = 0 for a plain GEMM
+    //  1 SwiGLU : B = [gate | up] weights [2I][K], N = 2I.  A workgroup computes gate columns [n0, n0+128) and the MATCHING up
+    //             columns (its B-hi half tile is fetched from row I + n0), writes act = silu(gate) * up to C2 [M][ldc2] and,
+    //             when store_c, gate | up to C [M][ldc] (the backward needs them; the no-grad reference pass does not).
+    //  2 RoPE   : B = [q | k | v] weights, head_dim 128.  The B-lo / B-hi half tiles hold the first / second 64 features of the
+    //             tile's two heads, so a lane owns both members of every rotate-half pair; columns < rope_cols are rotated by
+    //             pos[row] in fp32 before the single rounding to bf16, the rest (v) pass through.
+    int fuse;
+    int store_c;
+    void* C2;
+    int ldc2;
+    const int* pos;
+    const float* rope_cos;   // [max_pos][64]
+    const float* rope_sin;
+    int max_pos;
+    int rope_cols;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -32,3 +48,6 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // 256x256 tile, eight-phase schedule (gemm256p.hip); returns false when the problem does not qualify (fewer than 192 tiles,
 // unaligned operands, VLR_GEMM_8PHASE=0): the caller falls back to the 128x128 kernel
 bool vlr_gemm256p_try_launch(int layout, const GemmParams& p, hipStream_t stream);
+// fused-epilogue variants (p.fuse = 1 | 2, layout NT): false when the shape does not qualify for the persistent
+// continuous-pipeline kernel - the caller then runs the plain GEMM followed by the elementwise kernel
+bool vlr_gemm256p_fused_try_launch(const GemmParams& p, hipStream_t stream);

@@ -351,6 +351,26 @@ static int gemm_impl(int layout, const void* A, const void* B, void* C, const vo
                      int K, int lda, int ldb, int ldc, int ldr, int act, int accumulate, int out_f32, float alpha,
                      hipStream_t stream);
 
+// wave quantisation (see gemm_impl): how many of the last 256-row tile rows to peel off so that the 256x256-tile part is a
+// whole number of rounds on the 256 CUs; tn = workgroup tiles per tile row
+static int choose_peel(int M, int N, int tn) {
+    const int tm256 = (M + 255) / 256;
+    int peel = 0;
+    if ((long)tm256 * tn >= 512) {
+        const int full = tm256 * tn;
+        const double base = (double)((full + 255) / 256);
+        double best = base;
+        for (int r = 1; r <= 3 && tm256 - r >= 2; ++r) {
+            const int t1 = (tm256 - r) * tn;
+            const int rem_rows = M - (tm256 - r) * 256;
+            const long t128 = (long)((rem_rows + 127) / 128) * ((N + 127) / 128);
+            const double est = (double)((t1 + 255) / 256) + 0.7 * (double)((t128 + 511) / 512);
+            if (est < best - 0.05) { best = est; peel = r; }
+        }
+    }
+    return peel;
+}
+
 extern "C" int vlr_gemm_bf16(int layout, const void* A, const void* B, void* C, const void* bias, const void* residual,
                              int M, int N, int K, int lda, int ldb, int ldc, int ldr, int act, int accumulate,
                              int out_f32, hipStream_t stream) {
@@ -388,6 +408,7 @@ static int gemm_impl(int layout, const void* A, const void* B, void* C, const vo
     p.flags = gflags;
     p.alpha = alpha;
     p.splitk = 1; p.kchunk = 0; p.part = nullptr;
+    p.fuse = 0; p.store_c = 1; p.C2 = nullptr; p.ldc2 = 0; p.pos = nullptr; p.rope_cos = p.rope_sin = nullptr; p.max_pos = 0; p.rope_cols = 0;
     const int pi = vlr_prof_begin(layout, 2.0 * M * N * K, stream);
     // ---- split-K for problems whose output is a handful of tiles but whose reduction is long: the LoRA adapter gradients
     // (TN: dB = dy^T u [out x r], dA = v^T x [r x in], reduction over all tokens) - 32..96 workgroups would leave most CUs idle
@@ -401,19 +422,7 @@ static int gemm_impl(int layout, const void* A, const void* B, void* C, const vo
     static int split_on = -1;
     if (split_on < 0) { const char* e = getenv("VLR_GEMM_SPLIT"); split_on = (e && e[0] == '0') ? 0 : 1; }
     const int tm256 = (M + 255) / 256, tn256 = (N + 255) / 256;
-    int peel = 0;
-    if (split_on && (long)tm256 * tn256 >= 512) {
-        const int full = tm256 * tn256;
-        const double base = (double)((full + 255) / 256);
-        double best = base;
-        for (int r = 1; r <= 3 && tm256 - r >= 2; ++r) {
-            const int t1 = (tm256 - r) * tn256;
-            const int rem_rows = M - (tm256 - r) * 256;
-            const long t128 = (long)((rem_rows + 127) / 128) * ((N + 127) / 128);
-            const double est = (double)((t1 + 255) / 256) + 0.7 * (double)((t128 + 511) / 512);
-            if (est < best - 0.05) { best = est; peel = r; }
-        }
-    }
+    const int peel = split_on ? choose_peel(M, N, tn256) : 0;
     if (peel) {
         const int M1 = (tm256 - peel) * 256;
         GemmParams p1 = p, p2 = p;
@@ -448,4 +457,78 @@ static int gemm_impl(int layout, const void* A, const void* B, void* C, const vo
     else hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), dim3(tiles), dim3(256), 0, stream, p);
     vlr_prof_end(pi, stream);
     return vlr_check_launch("vlr_gemm_bf16");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused forward GEMMs of the decoder layer (include/vlr.h): the elementwise op that follows the projection is applied to the
+// fp32 accumulators in the epilogue of the 256x256 continuous-pipeline kernel - one rounding instead of two, and no separate
+// pass over the [M][2I] / [M][3H] tensor.  Rows the persistent kernel does not cover (peeled tile rows, small problems) go
+// through the plain GEMM + the elementwise kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int vlr_swiglu_fwd(const void* gu, void* act, int M, int I, hipStream_t st);
+extern "C" int vlr_rope(void* qkv, const int* pos, const float* cos_t, const float* sin_t, int M, int H, int head_dim, int ld,
+                        int max_pos, int backward, hipStream_t st);
+
+static GemmParams fused_params(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc) {
+    GemmParams p;
+    p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.bias = nullptr; p.residual = nullptr;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = 0;
+    p.act = 0; p.accumulate = 0; p.out_f32 = 0; p.flags = 0; p.alpha = 1.f; p.splitk = 1; p.kchunk = 0; p.part = nullptr;
+    p.fuse = 0; p.store_c = 1; p.C2 = nullptr; p.ldc2 = 0; p.pos = nullptr; p.rope_cos = p.rope_sin = nullptr; p.max_pos = 0; p.rope_cols = 0;
+    return p;
+}
+
+extern "C" int vlr_gemm_swiglu(const void* x, const void* wgu, void* gu, void* act, int M, int I, int K, int ldx, int store_gu,
+                               hipStream_t stream) {
+    VLR_REQUIRE(x && wgu && gu && act, "vlr_gemm_swiglu: null operand");
+    VLR_REQUIRE(M > 0 && I > 0 && K > 0 && I % 8 == 0 && K % 8 == 0 && ldx % 8 == 0, "vlr_gemm_swiglu: bad shape M=%d I=%d K=%d ldx=%d", M, I, K, ldx);
+    const int tn = (I + 127) / 128;
+    const int peel = choose_peel(M, 2 * I, tn);
+    const int tm256 = (M + 255) / 256;
+    const int M1 = peel ? (tm256 - peel) * 256 : M;
+    GemmParams p = fused_params(x, wgu, gu, M1, 2 * I, K, ldx, K, 2 * I);
+    p.fuse = 1; p.store_c = store_gu; p.C2 = act; p.ldc2 = I;
+    int done = 0;
+    if (vlr_gemm256p_fused_try_launch(p, stream)) {
+        int rc = vlr_check_launch("vlr_gemm_swiglu(fused)");
+        if (rc != VLR_OK) return rc;
+        done = M1;
+    }
+    if (done < M) {       // remaining rows: plain GEMM + SwiGLU kernel
+        const bf16_t* xa = (const bf16_t*)x + (size_t)done * ldx;
+        bf16_t* gur = (bf16_t*)gu + (size_t)done * 2 * I;
+        int rc = gemm_impl(0, xa, wgu, gur, nullptr, nullptr, M - done, 2 * I, K, ldx, K, 2 * I, 0, 0, 0, 0, 1.0f, stream);
+        if (rc != VLR_OK) return rc;
+        return vlr_swiglu_fwd(gur, (bf16_t*)act + (size_t)done * I, M - done, I, stream);
+    }
+    return VLR_OK;
+}
+
+extern "C" int vlr_gemm_qkv_rope(const void* x, const void* wqkv, void* qkv, const int* pos, const float* cos_t, const float* sin_t,
+                                 int M, int N, int rope_cols, int K, int ldx, int head_dim, int max_pos, hipStream_t stream) {
+    VLR_REQUIRE(x && wqkv && qkv && pos && cos_t && sin_t, "vlr_gemm_qkv_rope: null operand");
+    VLR_REQUIRE(M > 0 && N > 0 && K > 0 && N % 8 == 0 && K % 8 == 0 && ldx % 8 == 0, "vlr_gemm_qkv_rope: bad shape M=%d N=%d K=%d", M, N, K);
+    VLR_REQUIRE(head_dim % 16 == 0 && rope_cols % head_dim == 0 && rope_cols <= N, "vlr_gemm_qkv_rope: rope_cols %d / head_dim %d / N %d", rope_cols, head_dim, N);
+    int done = 0;
+    if (head_dim == 128) {
+        const int tn = (N + 255) / 256;
+        const int peel = choose_peel(M, N, tn);
+        const int tm256 = (M + 255) / 256;
+        const int M1 = peel ? (tm256 - peel) * 256 : M;
+        GemmParams p = fused_params(x, wqkv, qkv, M1, N, K, ldx, K, N);
+        p.fuse = 2; p.pos = pos; p.rope_cos = cos_t; p.rope_sin = sin_t; p.max_pos = max_pos; p.rope_cols = rope_cols;
+        if (vlr_gemm256p_fused_try_launch(p, stream)) {
+            int rc = vlr_check_launch("vlr_gemm_qkv_rope(fused)");
+            if (rc != VLR_OK) return rc;
+            done = M1;
+        }
+    }
+    if (done < M) {
+        bf16_t* qr = (bf16_t*)qkv + (size_t)done * N;
+        int rc = gemm_impl(0, (const bf16_t*)x + (size_t)done * ldx, wqkv, qr, nullptr, nullptr, M - done, N, K, ldx, K, N, 0, 0, 0, 0, 1.0f, stream);
+        if (rc != VLR_OK) return rc;
+        // the q and k column blocks are rope_cols / head_dim consecutive heads
+        return vlr_rope(qr, pos + done, cos_t, sin_t, M - done, rope_cols / 2, head_dim, N, max_pos, 0, stream);
+    }
+    return VLR_OK;
 }

@@ -64,6 +64,43 @@ __device__ __forceinline__ void piece_off_kc(int ld, int row0, int nrows, int wa
         off[i] = (uint32_t)(((size_t)grow * ld + c * 8) * 2);
     }
 }
+// B-operand row of local row r (0..127) of half tile h for the fused-epilogue variants (GemmParams::fuse); FUSE 0 = plain
+template <int FUSE>
+__device__ __forceinline__ int b_src_row(int n0, int h, int r, int N) {
+    if constexpr (FUSE == 1) {            // SwiGLU: lo = gate rows [n0, n0+128), hi = up rows I + [n0, n0+128)
+        const int I = N >> 1;
+        int c = n0 + r;
+        c = c < I ? c : I - 1;
+        return h * I + c;
+    } else if constexpr (FUSE == 2) {     // RoPE: lo = features 0..63 of the tile's two heads, hi = features 64..127
+        return n0 + (r >> 6) * 128 + h * 64 + (r & 63);
+    } else {
+        const int g = n0 + h * 128 + r;
+        return g < N ? g : N - 1;
+    }
+}
+template <int FUSE>
+__device__ __forceinline__ void piece_off_kc_b(int ld, int n0, int h, int N, int wave, int lane, uint32_t (&off)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (wave + 8 * i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        off[i] = (uint32_t)(((size_t)b_src_row<FUSE>(n0, h, r, N) * ld + c * 8) * 2);
+    }
+}
+template <int FUSE>
+__device__ __forceinline__ void stage_kc_b(const bf16_t* __restrict__ P, int ld, int n0, int h, int N, int k0, int K,
+                                           const bf16_t* __restrict__ zero16, char* half, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int R = (wave + 8 * i) * 8;
+        const int r = R + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const int k = k0 + c * 8;
+        const bf16_t* g = (k + 8 <= K) ? P + (size_t)b_src_row<FUSE>(n0, h, r, N) * ld + k : zero16;
+        lds_dma16(g, half + R * 128);
+    }
+}
 __device__ __forceinline__ void piece_off_ks(int ld, int col0, int ncols, int wave, int lane, uint32_t (&off)[2]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -139,8 +176,10 @@ __device__ __forceinline__ bf16x8 pfrag_ks(const char* half, int cbase, int s, i
 // CONT = true: continuous pipeline across the output tiles of a persistent workgroup (plain bf16 epilogue only): the last K tiles
 // of tile i stage the first K tiles of tile i+1 (same slots, same counted wait), the epilogue stores straight from the
 // accumulator registers (8 bytes per lane, no LDS, no barrier) and the K loop of tile i+1 starts with its data resident.
-template <bool A_KS, bool B_KS, int ABL = 0, bool CONT = false>
+template <bool A_KS, bool B_KS, int ABL = 0, bool CONT = false, int FUSE = 0>
 __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_t* __restrict__ zero16) {
+    static_assert(FUSE == 0 || (CONT && !A_KS && !B_KS), "fused epilogues: NT layout, continuous pipeline only");
+    constexpr int NW = FUSE == 1 ? 128 : PT;      // output columns (of the gate half, for SwiGLU) per workgroup tile
     extern __shared__ __attribute__((aligned(16))) char smem[];   // P_LDS_BYTES
     const int t = threadIdx.x;
     const int lane0 = t & 63;
@@ -154,7 +193,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     // XCD b % 8) in steps of gridDim/8.  A finished tile's global stores drain while the next tile's first K tiles are
     // fetched; a workgroup that ends instead holds its CU (LDS) until the stores have landed and the next one starts cold:
     // 10-12 us per tile, measured (K sweep: 0.23 ms of fixed cost per 2304-tile launch).
-    const int tiles_m = (p.M + PT - 1) / PT, tiles_n = (p.N + PT - 1) / PT;
+    const int tiles_m = (p.M + PT - 1) / PT, tiles_n = FUSE == 1 ? ((p.N >> 1) + NW - 1) / NW : (p.N + PT - 1) / PT;
     const int nwg = tiles_m * tiles_n;
     // tile `titer` of this workgroup -> (m0, n0); false when the workgroup has no such tile
     auto tile_coords = [&](int titer, int& m0_, int& n0_) -> bool {
@@ -170,7 +209,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
         const int first_m = gid * GROUP;
         const int gsz = min(tiles_m - first_m, GROUP);
         m0_ = (first_m + (pid % per_group) % gsz) * PT;
-        n0_ = ((pid % per_group) / gsz) * PT;
+        n0_ = ((pid % per_group) / gsz) * NW;
         return true;
     };
     int parb = 0;                 // CONT: buffer parity of the current tile's K tile 0 (K tiles keep alternating across tiles)
@@ -209,7 +248,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
         if constexpr (A_KS) piece_off_ks(p.lda, m0 + h * 128, p.M, wave, lane, offA[h]);
         else piece_off_kc(p.lda, m0 + h * 128, p.M, wave, lane, offA[h]);
         if constexpr (B_KS) piece_off_ks(p.ldb, n0 + h * 128, p.N, wave, lane, offB[h]);
-        else piece_off_kc(p.ldb, n0 + h * 128, p.N, wave, lane, offB[h]);
+        else piece_off_kc_b<FUSE>(p.ldb, n0, h, p.N, wave, lane, offB[h]);
     }
     const size_t stepA = A_KS ? (size_t)PK * p.lda * 2 : (size_t)PK * 2;
     const size_t stepB = B_KS ? (size_t)PK * p.ldb * 2 : (size_t)PK * 2;
@@ -231,7 +270,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                         else stage_kc(p.A, p.lda, m0n + h * 128, p.M, k0, p.K, zero16, dst, wave, lane);
                     } else {
                         if constexpr (B_KS) stage_ks(p.B, p.ldb, n0n + (h - 2) * 128, p.N, k0, p.K, zero16, dst, wave, lane);
-                        else stage_kc(p.B, p.ldb, n0n + (h - 2) * 128, p.N, k0, p.K, zero16, dst, wave, lane);
+                        else stage_kc_b<FUSE>(p.B, p.ldb, n0n, h - 2, p.N, k0, p.K, zero16, dst, wave, lane);
                     }
                 }
                 return;
@@ -245,7 +284,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                 else stage_kc(p.A, p.lda, m0 + h * 128, p.M, k0, p.K, zero16, dst, wave, lane);
             } else {
                 if constexpr (B_KS) stage_ks(p.B, p.ldb, n0 + (h - 2) * 128, p.N, k0, p.K, zero16, dst, wave, lane);
-                else stage_kc(p.B, p.ldb, n0 + (h - 2) * 128, p.N, k0, p.K, zero16, dst, wave, lane);
+                else stage_kc_b<FUSE>(p.B, p.ldb, n0, h - 2, p.N, k0, p.K, zero16, dst, wave, lane);
             }
             return;
         }
@@ -411,7 +450,78 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     for (; kt < n_fast; ++kt) ktile(kt, FAST{});
     for (; kt < nt; ++kt) ktile(kt, SLOW{});
 #undef PMFMA
-    if constexpr (CONT) {
+    if constexpr (CONT && FUSE == 1) {
+        // SwiGLU epilogue: acc[a][i][0][j] = gate, acc[a][i][1][j] = the matching up columns; act = silu(gate) * up from the fp32
+        // accumulators (one rounding), gate | up stored for the backward only when asked
+        bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+        bf16_t* C2 = reinterpret_cast<bf16_t*>(p.C2);
+        const int I = p.N >> 1;
+        const int lm_ = lane & 15, lq_ = lane >> 4;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int gm = m0 + a * 128 + wr * 64 + i * 16 + lm_;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int gn = n0 + wc * 32 + j * 16 + 4 * lq_;
+                    const f32x4 g = acc[a][i][0][j], u = acc[a][i][1][j];
+                    f32x4 h;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h[e] = g[e] / (1.f + __expf(-g[e])) * u[e];
+                    if (gm < p.M && gn + 4 <= I) {
+                        u32x2 o;
+                        if (p.store_c) {
+                            o[0] = pack_bf16(g[0], g[1]); o[1] = pack_bf16(g[2], g[3]);
+                            *reinterpret_cast<u32x2*>(C + (size_t)gm * p.ldc + gn) = o;
+                            o[0] = pack_bf16(u[0], u[1]); o[1] = pack_bf16(u[2], u[3]);
+                            *reinterpret_cast<u32x2*>(C + (size_t)gm * p.ldc + I + gn) = o;
+                        }
+                        o[0] = pack_bf16(h[0], h[1]); o[1] = pack_bf16(h[2], h[3]);
+                        *reinterpret_cast<u32x2*>(C2 + (size_t)gm * p.ldc2 + gn) = o;
+                    }
+                }
+            }
+    } else if constexpr (CONT && FUSE == 2) {
+        // RoPE epilogue: acc[a][i][0][j] / acc[a][i][1][j] = features d / d + 64 of one head (rotate-half partners)
+        bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+        const int lm_ = lane & 15, lq_ = lane >> 4;
+        const bool rot = n0 < p.rope_cols;            // q and k tiles; v tiles pass through
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int gm = m0 + a * 128 + wr * 64 + i * 16 + lm_;
+                int ps = 0;
+                if (rot && gm < p.M) {
+                    ps = p.pos[gm];
+                    ps = ps < 0 ? 0 : (ps >= p.max_pos ? p.max_pos - 1 : ps);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int c = wc * 32 + j * 16 + 4 * lq_;          // column of the 128-wide half: head c >> 6, feature c & 63
+                    const int gn = n0 + (c >> 6) * 128 + (c & 63);
+                    f32x4 x1 = acc[a][i][0][j], x2 = acc[a][i][1][j];
+                    if (rot) {
+                        const f32x4 cs = *reinterpret_cast<const f32x4*>(p.rope_cos + (size_t)ps * 64 + (c & 63));
+                        const f32x4 sn = *reinterpret_cast<const f32x4*>(p.rope_sin + (size_t)ps * 64 + (c & 63));
+                        const f32x4 y1 = x1, y2 = x2;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            x1[e] = y1[e] * cs[e] - y2[e] * sn[e];
+                            x2[e] = y2[e] * cs[e] + y1[e] * sn[e];
+                        }
+                    }
+                    if (gm < p.M) {
+                        u32x2 o;
+                        o[0] = pack_bf16(x1[0], x1[1]); o[1] = pack_bf16(x1[2], x1[3]);
+                        *reinterpret_cast<u32x2*>(C + (size_t)gm * p.ldc + gn) = o;
+                        o[0] = pack_bf16(x2[0], x2[1]); o[1] = pack_bf16(x2[2], x2[3]);
+                        *reinterpret_cast<u32x2*>(C + (size_t)gm * p.ldc + gn + 64) = o;
+                    }
+                }
+            }
+    } else if constexpr (CONT) {
         // plain bf16 epilogue straight from the registers: lane (lm, lq) of tile (i, j) holds C[row lm][cols 4 lq .. +3]
         bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
         const int lm_ = lane & 15, lq_ = lane >> 4;
@@ -432,6 +542,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                         if (gm < p.M && gn + 4 <= p.N) *reinterpret_cast<u32x2*>(C + (size_t)gm * p.ldc + gn) = o;
                     }
             }
+    }
+    if constexpr (CONT) {
         parb = (parb + nt) & 1;
         if (!has_next) {
             if (wr == 0) PBAR();  // balance the extra barrier of waves 4-7
@@ -557,6 +669,52 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     }
     __syncthreads();              // every wave is done with the LDS image / patches before the next tile's DMA lands
     }   // persistent tile loop
+}
+
+static int gemm256p_n_cu() {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+        n_cu &= ~7;                     // whole XCD octets (256 on MI355X)
+    }
+    return n_cu;
+}
+static bf16_t* gemm256p_zero16() {
+    static bf16_t* z = nullptr;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        if (hipMalloc((void**)&z, 256) != hipSuccess || hipMemset(z, 0, 256) != hipSuccess) z = nullptr;
+    }
+    return z;
+}
+
+bool vlr_gemm256p_fused_try_launch(const GemmParams& p, hipStream_t stream) {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("VLR_GEMM_FUSE");
+        on = e ? atoi(e) : 3;               // bit 0 SwiGLU, bit 1 RoPE
+        hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, 0, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+        hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, 0, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+    }
+    if (p.fuse < 1 || p.fuse > 2 || !((on >> (p.fuse - 1)) & 1)) return false;
+    bf16_t* zero16 = gemm256p_zero16();
+    if (!zero16) return false;
+    const int n_cu = gemm256p_n_cu();
+    const int tiles_m = (p.M + PT - 1) / PT;
+    const int tiles_n = p.fuse == 1 ? ((p.N >> 1) + 127) / 128 : p.N / PT;
+    const int ntiles = tiles_m * tiles_n;
+    if (ntiles <= n_cu || p.K < 4 * PK) return false;                      // persistent continuous pipeline only
+    if (p.fuse == 2 && (p.N % PT != 0 || p.rope_cols % PT != 0)) return false;
+    if (p.fuse == 1 && ((p.N >> 1) % 8 != 0 || p.ldc2 % 4 != 0)) return false;
+    if ((((uintptr_t)p.A | (uintptr_t)p.B) & 15) || p.lda % 8 != 0 || p.ldb % 8 != 0 || p.ldc % 4 != 0) return false;
+    const int pi = vlr_prof_begin(VLR_K_GEMM256P, 2.0 * p.M * p.N * p.K, stream);
+    if (p.fuse == 1) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 1>), dim3(n_cu), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
+    else hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 2>), dim3(n_cu), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
+    vlr_prof_end(pi, stream);
+    return true;
 }
 
 // returns false when the problem does not qualify (caller falls back to the staggered / 128x128 kernels)

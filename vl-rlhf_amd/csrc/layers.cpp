@@ -58,23 +58,31 @@ extern "C" int vlr_layers_join(vlr_stream_t stream) {
 static inline const char* off(const void* p, size_t elems) { return (const char*)p + elems * 2; }
 static inline char* off(void* p, size_t elems) { return (char*)p + elems * 2; }
 
-extern "C" int vlr_decoder_layer_fwd(const vlr_llama_cfg* cfg, const vlr_layer_weights* w, const vlr_layer_acts* a,
-                                     const void* x_in, const int* pos, const int* key_mask, int batch, int S,
-                                     vlr_stream_t st) {
+// keep_for_backward = 0 (no-grad reference / evaluation pass): tensors only the backward reads (gate | up) are not written
+extern "C" int vlr_decoder_layer_fwd_ex(const vlr_llama_cfg* cfg, const vlr_layer_weights* w, const vlr_layer_acts* a,
+                                        const void* x_in, const int* pos, const int* key_mask, int batch, int S,
+                                        int keep_for_backward, vlr_stream_t st) {
     VLR_REQUIRE(cfg && w && a && x_in && pos, "vlr_decoder_layer_fwd: null argument");
     const int H = cfg->hidden, I = cfg->inter, M = batch * S;
     VLR_REQUIRE(cfg->heads * cfg->head_dim == H, "vlr_decoder_layer_fwd: heads*head_dim != hidden");
     CHECK(vlr_rmsnorm_fwd(x_in, w->ln1, a->xn1, a->rstd1, M, H, cfg->rms_eps, st));
-    CHECK(vlr_gemm_bf16(0, a->xn1, w->wqkv, a->qkv, nullptr, nullptr, M, 3 * H, H, H, H, 3 * H, 0, 0, 0, 0, st));
-    CHECK(vlr_rope(a->qkv, pos, cfg->rope_cos, cfg->rope_sin, M, H, cfg->head_dim, 3 * H, cfg->max_pos, 0, st));
+    // q|k|v projection with RoPE applied to the fp32 accumulators in the GEMM epilogue (plain GEMM + rope kernel for the rows /
+    // shapes the persistent kernel does not take)
+    CHECK(vlr_gemm_qkv_rope(a->xn1, w->wqkv, a->qkv, pos, cfg->rope_cos, cfg->rope_sin, M, 3 * H, 2 * H, H, H, cfg->head_dim,
+                            cfg->max_pos, st));
     CHECK(vlr_attn_fwd(a->qkv, off(a->qkv, H), off(a->qkv, 2 * (size_t)H), 3 * H, a->attn, H, a->lse, key_mask, batch, S,
                        cfg->heads, cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));
     CHECK(vlr_gemm_bf16(0, a->attn, w->wo, a->x_mid, nullptr, x_in, M, H, H, H, H, H, H, 0, 0, 0, st));
     CHECK(vlr_rmsnorm_fwd(a->x_mid, w->ln2, a->xn2, a->rstd2, M, H, cfg->rms_eps, st));
-    CHECK(vlr_gemm_bf16(0, a->xn2, w->wgu, a->gu, nullptr, nullptr, M, 2 * I, H, H, H, 2 * I, 0, 0, 0, 0, st));
-    CHECK(vlr_swiglu_fwd(a->gu, a->act, M, I, st));
+    // gate|up projection with act = silu(gate) * up computed in the epilogue
+    CHECK(vlr_gemm_swiglu(a->xn2, w->wgu, a->gu, a->act, M, I, H, H, keep_for_backward, st));
     CHECK(vlr_gemm_bf16(0, a->act, w->wdown, a->x_out, nullptr, a->x_mid, M, H, I, I, I, H, H, 0, 0, 0, st));
     return VLR_OK;
+}
+extern "C" int vlr_decoder_layer_fwd(const vlr_llama_cfg* cfg, const vlr_layer_weights* w, const vlr_layer_acts* a,
+                                     const void* x_in, const int* pos, const int* key_mask, int batch, int S,
+                                     vlr_stream_t st) {
+    return vlr_decoder_layer_fwd_ex(cfg, w, a, x_in, pos, key_mask, batch, S, 1, st);
 }
 
 extern "C" int vlr_decoder_layer_bwd(const vlr_llama_cfg* cfg, const vlr_layer_weights* w, const vlr_layer_grads* g,

@@ -89,6 +89,9 @@ _SIGS = {
     "vlr_grad_sqnorm": [P, L, F, F, F, P, P, P],
     "vlr_adamw_step": [P, P, P, P, P, L, F, F, F, F, F, I, P, P],
     "vlr_decoder_layer_fwd": [P, P, P, P, P, P, I, I, P],
+    "vlr_decoder_layer_fwd_ex": [P, P, P, P, P, P, I, I, I, P],
+    "vlr_gemm_swiglu": [P, P, P, P, I, I, I, I, I, P],
+    "vlr_gemm_qkv_rope": [P, P, P, P, P, P, I, I, I, I, I, I, I, P],
     "vlr_decoder_layer_bwd": [P, P, P, I, P, P, P, P, P, P, P, I, I, P],
     "vlr_vit_layer_fwd": [P, P, P, P, I, I, P],
     "vlr_decoder_layer_fwd_lora": [P, P, P, P, P, P, U64, P, P, P, I, I, P],

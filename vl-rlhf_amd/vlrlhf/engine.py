@@ -468,7 +468,8 @@ class LlavaHipEngine:
                 _hip.call("vlr_decoder_layer_fwd_lora", self.llama_cfg, self.layer_weights(ws, l), lw, a["struct"], a["u"], xd,
                           lora_seed + 8 * l, x, pos, mask, Bn, S)
             else:
-                _hip.call("vlr_decoder_layer_fwd", self.llama_cfg, self.layer_weights(ws, l), a["struct"], x, pos, mask, Bn, S)
+                _hip.call("vlr_decoder_layer_fwd_ex", self.llama_cfg, self.layer_weights(ws, l), a["struct"], x, pos, mask, Bn, S,
+                          int(save))
             acts.append(a)
             x = a["x_out"]
         hidden = torch.empty(M, self.H, dtype=BF16, device=self.dev)
