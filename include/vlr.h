@@ -98,6 +98,16 @@ int vlr_attn_bwd(const void* q, const void* k, const void* v, int ld, const void
                  const float* lse, float* delta_ws, const int* key_mask, void* dq, void* dk, void* dv, int ldd,
                  int batch, int S, int heads, int head_dim, int causal, float scale, vlr_stream_t stream);
 
+/* grouped-query attention (Mistral / InternLM2: kv_heads < heads; k, v column blocks hold kv_heads heads, query head h reads
+ * K/V head h / (heads / kv_heads); dk, dv are summed over the group's query heads in a fixed order - no atomics).
+ * vlr_attn_fwd / vlr_attn_bwd are the kv_heads == heads case. */
+int vlr_attn_fwd_gqa(const void* q, const void* k, const void* v, int ld, void* o, int ldo, float* lse,
+                     const int* key_mask, int batch, int S, int heads, int kv_heads, int head_dim, int causal, float scale,
+                     vlr_stream_t stream);
+int vlr_attn_bwd_gqa(const void* q, const void* k, const void* v, int ld, const void* o, const void* dout, int ldo,
+                     const float* lse, float* delta_ws, const int* key_mask, void* dq, void* dk, void* dv, int ldd,
+                     int batch, int S, int heads, int kv_heads, int head_dim, int causal, float scale, vlr_stream_t stream);
+
 /* ---- image/text merge (LlavaForRL._merge_input_ids_with_image_features, Llava/__init__.py:36-109) ---------------
  * info[0] receives the number of image slots found; the caller compares it with n_feat_rows*dup and raises the
  * reference's ValueError (:90-94) on mismatch.  `dup` = how many batch halves share one feature table (the

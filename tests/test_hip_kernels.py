@@ -740,3 +740,43 @@ def test_gemm_qkv_rope_fused(hip, shape):
     torch.cuda.synchronize()
     check(out, ref, 8e-3, f"qkv rope {shape}")
     assert torch.isfinite(out.float()).all()
+
+
+# ---------------------------------------------------------------------------------------------------- grouped-query attention
+@pytest.mark.parametrize("B,S,nh,nkv,masked", [(2, 200, 4, 2, True), (1, 333, 8, 2, True), (3, 130, 4, 1, False), (9, 70, 2, 1, False)])
+def test_attention_gqa_fwd_bwd(hip, B, S, nh, nkv, masked):
+    """vlr_attn_fwd_gqa / vlr_attn_bwd_gqa (Mistral 32/8-style head sharing) against eager attention with repeated K/V heads;
+    batch * kv_heads not a multiple of 8 exercises the padding workgroups of the XCD-aware block map."""
+    hd = 128
+    Hq, Hkv = nh * hd, nkv * hd
+    N = Hq + 2 * Hkv
+    qkv = rnd(B * S, N, seed=31)
+    do = rnd(B * S, Hq, seed=32)
+    km = None
+    if masked:
+        km = torch.ones(B, S, dtype=torch.int32, device=DEV)
+        km[0, S - 9:] = 0
+        do[S - 9:S] = 0
+    scale = 1.0 / math.sqrt(hd)
+    Sp = (S + 63) // 64 * 64
+    o = torch.full((B * S, Hq), float("nan"), dtype=torch.bfloat16, device=DEV)
+    lse = torch.zeros(B, nh, Sp, dtype=torch.float32, device=DEV)
+    hip.call("vlr_attn_fwd_gqa", qkv, qkv[:, Hq:], qkv[:, Hq + Hkv:], N, o, Hq, lse, km, B, S, nh, nkv, hd, 1, scale)
+    dqkv = torch.full((B * S, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    delta = torch.zeros(B, nh, Sp, dtype=torch.float32, device=DEV)
+    hip.call("vlr_attn_bwd_gqa", qkv, qkv[:, Hq:], qkv[:, Hq + Hkv:], N, o, do, Hq, lse, delta, km, dqkv, dqkv[:, Hq:],
+             dqkv[:, Hq + Hkv:], N, B, S, nh, nkv, hd, 1, scale)
+    torch.cuda.synchronize()
+    x = qkv.float().requires_grad_(True)
+    q = x[:, :Hq].reshape(B, S, nh, hd).transpose(1, 2)
+    k = x[:, Hq:Hq + Hkv].reshape(B, S, nkv, hd).transpose(1, 2).repeat_interleave(nh // nkv, dim=1)
+    v = x[:, Hq + Hkv:].reshape(B, S, nkv, hd).transpose(1, 2).repeat_interleave(nh // nkv, dim=1)
+    ref = ref_attention(q, k, v, True, km, scale).transpose(1, 2).reshape(B * S, Hq)
+    (ref * do.float()).sum().backward()
+    g = x.grad
+    valid = torch.ones(B * S, dtype=torch.bool, device=DEV) if km is None else (km.reshape(-1) != 0)
+    check(o[valid], ref[valid], 1.2e-2, "gqa fwd")
+    check(dqkv[valid][:, :Hq], g[valid][:, :Hq], 2e-2, "gqa dq")
+    check(dqkv[valid][:, Hq:Hq + Hkv], g[valid][:, Hq:Hq + Hkv], 2e-2, "gqa dk")
+    check(dqkv[valid][:, Hq + Hkv:], g[valid][:, Hq + Hkv:], 2e-2, "gqa dv")
+    assert torch.isfinite(dqkv.float()).all() and torch.isfinite(o.float()).all()

@@ -241,6 +241,38 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 //     the MFMAs of the wave it shares the SIMD with.
 // The DMA is issued through inline asm so that hipcc does not put s_waitcnt vmcnt(0) before the transposing LDS reads.
 // ------------------------------------------------------------------------------------------------------------
+// Workgroup -> (batch, head, 128-row block) map of the LDS-DMA kernels.  Workgroup L runs on XCD L % 8 (round-robin dispatch)
+// and every XCD has its own L2, so ALL blocks that stream the same K/V (the nblk row blocks of one head, and under
+// grouped-query attention the `group` query heads that share a K/V head) are given to ONE XCD, consecutively: the K/V (or
+// Q/dO) panels are then fetched into one L2 once instead of into eight (the (x = block, y = head, z = batch) grid spread the
+// blocks of a head over all XCDs: 3.5x the algorithmic HBM traffic, measured, profiles/r01_pmc_hbm_traffic_*).
+struct AttnGrid {
+    int heads, kv_heads, group, nblk, n_kvp;   // n_kvp = batch * kv_heads
+    __host__ __device__ int per_kvp(bool loop_members) const { return loop_members ? nblk : group * nblk; }
+    __host__ int grid(bool loop_members) const { return 8 * ((n_kvp + 7) / 8) * per_kvp(loop_members); }
+    // member-major inside a K/V head; returns false for the padding workgroups of the last XCD round
+    __device__ __forceinline__ bool decode(int L, int& head, int& kvhead, int& b, int& slot) const {
+        const int xcd = L & 7, s = L >> 3, per = group * nblk;
+        const int kvp = (s / per) * 8 + xcd;
+        if (kvp >= n_kvp) return false;
+        const int rem = s % per;
+        b = kvp / kv_heads;
+        kvhead = kvp % kv_heads;
+        head = kvhead * group + rem / nblk;
+        slot = rem % nblk;
+        return true;
+    }
+    // one workgroup per (K/V head, key block): the kernel loops over the group's query heads itself
+    __device__ __forceinline__ bool decode_kv(int L, int& kvhead, int& b, int& slot) const {
+        const int xcd = L & 7, s = L >> 3;
+        const int kvp = (s / nblk) * 8 + xcd;
+        if (kvp >= n_kvp) return false;
+        b = kvp / kv_heads;
+        kvhead = kvp % kv_heads;
+        slot = s % nblk;
+        return true;
+    }
+};
 typedef __attribute__((address_space(3))) void attn_lvoid_t;
 __device__ __forceinline__ void attn_dma16(const bf16_t* sbase, uint32_t voff, uint32_t lds_addr) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
@@ -257,18 +289,20 @@ template <int D, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                            const bf16_t* __restrict__ v, int ld, bf16_t* __restrict__ o,
                                                            int ldo, float* __restrict__ lse, const int* __restrict__ kmask,
-                                                           int S, int Sp, float scale_log2) {
+                                                           int S, int Sp, float scale_log2, AttnGrid ag) {
     using CF = AttnFwd2<D>;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][K tile | V tile] | tile masks
     unsigned long long* tilemask = reinterpret_cast<unsigned long long*>(smem + 4 * CF::TILE_BYTES);
     const int t = threadIdx.x, lane = t & 63, g = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int head = blockIdx.y, b = blockIdx.z, nh = gridDim.y;
+    int head, kvhead, b, qslot;
+    if (!ag.decode(blockIdx.x, head, kvhead, b, qslot)) return;
+    const int nh = ag.heads;
     const size_t tok0 = (size_t)b * S;
     const bf16_t* qh = q + tok0 * ld + head * D;
-    const bf16_t* kh = k + tok0 * ld + head * D;
-    const bf16_t* vh = v + tok0 * ld + head * D;
-    const int qblk = CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;   // causal: heaviest blocks first
+    const bf16_t* kh = k + tok0 * ld + kvhead * D;
+    const bf16_t* vh = v + tok0 * ld + kvhead * D;
+    const int qblk = CAUSAL ? ag.nblk - 1 - qslot : qslot;   // causal: heaviest blocks first
     const int qw0 = qblk * 128 + wave * 32;
     const int qi = qw0 + (lane & 31);
     const int qrow = qi < S ? qi : S - 1;
@@ -649,19 +683,21 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 1) void attn_bwd_dq2_kernel(const
                                                               const bf16_t* __restrict__ dout, int ldo,
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
                                                               const int* __restrict__ kmask, bf16_t* __restrict__ dq, int lddq,
-                                                              int S, int Sp, float scale) {
+                                                              int S, int Sp, float scale, AttnGrid ag) {
     constexpr int D = 128, TB = KV_TILE * D * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K | V] | tile masks
     unsigned long long* tilemask = reinterpret_cast<unsigned long long*>(smem + 4 * TB);
     const int t = threadIdx.x, lane = t & 63, g = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int head = blockIdx.y, b = blockIdx.z, nh = gridDim.y;
+    int head, kvhead, b, qslot;
+    if (!ag.decode(blockIdx.x, head, kvhead, b, qslot)) return;
+    const int nh = ag.heads;
     const size_t tok0 = (size_t)b * S;
     const bf16_t* qh = q + tok0 * ld + head * D;
-    const bf16_t* kh = k + tok0 * ld + head * D;
-    const bf16_t* vh = v + tok0 * ld + head * D;
+    const bf16_t* kh = k + tok0 * ld + kvhead * D;
+    const bf16_t* vh = v + tok0 * ld + kvhead * D;
     const bf16_t* doh = dout + tok0 * ldo + head * D;
-    const int qblk = CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+    const int qblk = CAUSAL ? ag.nblk - 1 - qslot : qslot;
     const int qw0 = qblk * 128 + wave * 32;
     const int qi = qw0 + (lane & 31);
     const int qrow = qi < S ? qi : S - 1;
@@ -747,32 +783,33 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(const bf16_t* __rest
                                                             const bf16_t* __restrict__ dout, int ldo,
                                                             const float* __restrict__ lse, const float* __restrict__ delta,
                                                             const int* __restrict__ kmask, bf16_t* __restrict__ dk,
-                                                            bf16_t* __restrict__ dv, int lddkv, int S, int Sp, float scale) {
+                                                            bf16_t* __restrict__ dv, int lddkv, int S, int Sp, float scale,
+                                                            AttnGrid ag) {
     constexpr int D = 128, TB = KV_TILE * D * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][Q | dO]
     const int t = threadIdx.x, lane = t & 63, g = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int head = blockIdx.y, b = blockIdx.z, nh = gridDim.y;
+    int kvhead, b, kblk;
+    if (!ag.decode_kv(blockIdx.x, kvhead, b, kblk)) return;
+    const int nh = ag.heads, group = ag.group;
     const size_t tok0 = (size_t)b * S;
-    const bf16_t* qh = q + tok0 * ld + head * D;
-    const bf16_t* kh = k + tok0 * ld + head * D;
-    const bf16_t* vh = v + tok0 * ld + head * D;
-    const bf16_t* doh = dout + tok0 * ldo + head * D;
-    const float* lse_h = lse + ((size_t)b * nh + head) * Sp;   // rows padded to Sp: 16-byte aligned, tail = +inf
-    const float* dl_h = delta + ((size_t)b * nh + head) * Sp;
-    const int kw0 = blockIdx.x * 128 + wave * 32;
+    const bf16_t* kh = k + tok0 * ld + kvhead * D;
+    const bf16_t* vh = v + tok0 * ld + kvhead * D;
+    const int kw0 = kblk * 128 + wave * 32;
     const int ki = kw0 + (lane & 31);
     const int krow = ki < S ? ki : S - 1;
     const bool key_ok = ki < S && (!kmask || kmask[tok0 + krow] != 0);
     const bool any_bad_key = __builtin_amdgcn_ballot_w64(!key_ok) != 0;
     const float scale_log2 = scale * LOG2E;
-    const int q_start = CAUSAL ? ((int)blockIdx.x * 128 / KV_TILE) * KV_TILE : 0;
+    const int q_start = CAUSAL ? (kblk * 128 / KV_TILE) * KV_TILE : 0;
     const int nq = (S - q_start + KV_TILE - 1) / KV_TILE;
+    const int nit = nq * group;        // grouped-query attention: the `group` query heads of this K/V head, one after the other
     const uint32_t lds0 = (uint32_t)(uintptr_t)(attn_lvoid_t*)smem;
-    auto issue = [&](int it) {
-        const uint32_t dst = lds0 + (it & 1) * 2 * TB;
-        attn_issue_tile128(qh, ld, q_start + it * KV_TILE, S, dst, wave, lane);
-        attn_issue_tile128(doh, ldo, q_start + it * KV_TILE, S, dst + TB, wave, lane);
+    auto issue = [&](int j) {
+        const int head = kvhead * group + j / nq, it = j % nq;
+        const uint32_t dst = lds0 + (j & 1) * 2 * TB;
+        attn_issue_tile128(q + tok0 * ld + head * D, ld, q_start + it * KV_TILE, S, dst, wave, lane);
+        attn_issue_tile128(dout + tok0 * ldo + head * D, ldo, q_start + it * KV_TILE, S, dst + TB, wave, lane);
     };
     issue(0);
 
@@ -788,12 +825,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(const bf16_t* __rest
 #pragma unroll
         for (int r = 0; r < 16; ++r) { adk[i][r] = 0.f; adv[i][r] = 0.f; }
 
-    for (int it = 0; it < nq; ++it) {
-        const int q0 = q_start + it * KV_TILE;
+    for (int j = 0; j < nit; ++j) {
+        const int head = kvhead * group + j / nq;
+        const int q0 = q_start + (j % nq) * KV_TILE;
+        const float* lse_h = lse + ((size_t)b * nh + head) * Sp;   // rows padded to Sp: 16-byte aligned, tail = +inf
+        const float* dl_h = delta + ((size_t)b * nh + head) * Sp;
         ATTN_TILE_BARRIER();
-        if (it + 1 < nq) issue(it + 1);
+        if (j + 1 < nit) issue(j + 1);
         if (CAUSAL && q0 + KV_TILE - 1 < kw0) continue;   // every query of the tile precedes this wave's keys
-        const char* q_lds = smem + (it & 1) * 2 * TB;
+        const char* q_lds = smem + (j & 1) * 2 * TB;
         const char* do_lds = q_lds + TB;
         const bool need_mask = (CAUSAL && q0 < kw0 + 31) || any_bad_key;   // wave-uniform
 #pragma unroll
@@ -837,18 +877,30 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(const bf16_t* __rest
         }
     }
     if (ki < S) {
-        write_rows<D>(adk, 1.f, dk + (tok0 + ki) * (size_t)lddkv + head * D, g);
-        write_rows<D>(adv, 1.f, dv + (tok0 + ki) * (size_t)lddkv + head * D, g);
+        write_rows<D>(adk, 1.f, dk + (tok0 + ki) * (size_t)lddkv + kvhead * D, g);
+        write_rows<D>(adv, 1.f, dv + (tok0 + ki) * (size_t)lddkv + kvhead * D, g);
     }
 }
 
 // ============================================================================================================
-extern "C" int vlr_attn_fwd(const void* q, const void* k, const void* v, int ld, void* o, int ldo, float* lse,
-                            const int* key_mask, int batch, int S, int heads, int head_dim, int causal, float scale,
-                            hipStream_t st) {
+static int attn_dma_on() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("VLR_ATTN_DMA");
+        on = (e && e[0] == '0') ? 0 : 1;
+    }
+    return on;
+}
+
+extern "C" int vlr_attn_fwd_gqa(const void* q, const void* k, const void* v, int ld, void* o, int ldo, float* lse,
+                                const int* key_mask, int batch, int S, int heads, int kv_heads, int head_dim, int causal,
+                                float scale, hipStream_t st) {
     VLR_REQUIRE(batch > 0 && S > 0 && heads > 0, "vlr_attn_fwd: bad shape");
+    VLR_REQUIRE(kv_heads > 0 && heads % kv_heads == 0, "vlr_attn_fwd: heads %d is not a multiple of kv_heads %d", heads, kv_heads);
     VLR_REQUIRE(head_dim == 128 || head_dim == 64, "vlr_attn_fwd: head_dim must be 64 or 128, got %d", head_dim);
     VLR_REQUIRE(ld % 8 == 0 && ldo % 8 == 0, "vlr_attn_fwd: row strides must be multiples of 8 elements");
+    const bool dma = attn_dma_on() && S <= ATTN_MAX_TILES * KV_TILE;
+    VLR_REQUIRE(dma || heads == kv_heads, "vlr_attn_fwd: grouped-query attention needs the LDS-DMA kernels (S <= %d, VLR_ATTN_DMA != 0)", ATTN_MAX_TILES * KV_TILE);
     const dim3 grid((S + 127) / 128, heads, batch);
     const float sl2 = scale * LOG2E;
     const int Sp = (S + 63) / 64 * 64;   // lse is [batch][heads][Sp]
@@ -856,19 +908,20 @@ extern "C" int vlr_attn_fwd(const void* q, const void* k, const void* v, int ld,
 #define LAUNCH(D_, C_)                                                                                                  \
     hipLaunchKernelGGL((attn_fwd_kernel<D_, C_>), grid, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,           \
                        (const bf16_t*)v, ld, (bf16_t*)o, ldo, lse, key_mask, S, Sp, sl2)
-    static int fwd2 = -1;
-    if (fwd2 < 0) {
-        const char* e = getenv("VLR_ATTN_DMA");
-        fwd2 = (e && e[0] == '0') ? 0 : 1;
+    static bool attr = false;
+    if (!attr) {
+        attr = true;
         hipFuncSetAttribute((const void*)attn_fwd2_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, AttnFwd2<128>::LDS_BYTES);
         hipFuncSetAttribute((const void*)attn_fwd2_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, AttnFwd2<128>::LDS_BYTES);
         hipFuncSetAttribute((const void*)attn_fwd2_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, AttnFwd2<64>::LDS_BYTES);
         hipFuncSetAttribute((const void*)attn_fwd2_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, AttnFwd2<64>::LDS_BYTES);
     }
+    AttnGrid ag;
+    ag.heads = heads; ag.kv_heads = kv_heads; ag.group = heads / kv_heads; ag.nblk = (S + 127) / 128; ag.n_kvp = batch * kv_heads;
 #define LAUNCH2(D_, C_)                                                                                                 \
-    hipLaunchKernelGGL((attn_fwd2_kernel<D_, C_>), grid, dim3(256), AttnFwd2<D_>::LDS_BYTES, st, (const bf16_t*)q,       \
-                       (const bf16_t*)k, (const bf16_t*)v, ld, (bf16_t*)o, ldo, lse, key_mask, S, Sp, sl2)
-    if (fwd2 && S <= ATTN_MAX_TILES * KV_TILE) {
+    hipLaunchKernelGGL((attn_fwd2_kernel<D_, C_>), dim3(ag.grid(false)), dim3(256), AttnFwd2<D_>::LDS_BYTES, st, (const bf16_t*)q, \
+                       (const bf16_t*)k, (const bf16_t*)v, ld, (bf16_t*)o, ldo, lse, key_mask, S, Sp, sl2, ag)
+    if (dma) {
         if (head_dim == 128) { if (causal) LAUNCH2(128, true); else LAUNCH2(128, false); }
         else { if (causal) LAUNCH2(64, true); else LAUNCH2(64, false); }
     } else {
@@ -880,40 +933,49 @@ extern "C" int vlr_attn_fwd(const void* q, const void* k, const void* v, int ld,
     vlr_prof_end(pi, st);
     return vlr_check_launch("vlr_attn_fwd");
 }
-
-extern "C" int vlr_attn_bwd(const void* q, const void* k, const void* v, int ld, const void* o, const void* dout,
-                            int ldo, const float* lse, float* delta_ws, const int* key_mask, void* dq, void* dk,
-                            void* dv, int ldd, int batch, int S, int heads, int head_dim, int causal, float scale,
+extern "C" int vlr_attn_fwd(const void* q, const void* k, const void* v, int ld, void* o, int ldo, float* lse,
+                            const int* key_mask, int batch, int S, int heads, int head_dim, int causal, float scale,
                             hipStream_t st) {
+    return vlr_attn_fwd_gqa(q, k, v, ld, o, ldo, lse, key_mask, batch, S, heads, heads, head_dim, causal, scale, st);
+}
+
+extern "C" int vlr_attn_bwd_gqa(const void* q, const void* k, const void* v, int ld, const void* o, const void* dout,
+                                int ldo, const float* lse, float* delta_ws, const int* key_mask, void* dq, void* dk,
+                                void* dv, int ldd, int batch, int S, int heads, int kv_heads, int head_dim, int causal,
+                                float scale, hipStream_t st) {
     VLR_REQUIRE(batch > 0 && S > 0 && heads > 0, "vlr_attn_bwd: bad shape");
+    VLR_REQUIRE(kv_heads > 0 && heads % kv_heads == 0, "vlr_attn_bwd: heads %d is not a multiple of kv_heads %d", heads, kv_heads);
     VLR_REQUIRE(head_dim == 128, "vlr_attn_bwd: head_dim must be 128 (the ViT is frozen), got %d", head_dim);
     VLR_REQUIRE(ld % 8 == 0 && ldo % 8 == 0 && ldd % 8 == 0 && delta_ws && lse, "vlr_attn_bwd: strides / workspace");
+    const bool dma = attn_dma_on() && S <= ATTN_MAX_TILES * KV_TILE;
+    VLR_REQUIRE(dma || heads == kv_heads, "vlr_attn_bwd: grouped-query attention needs the LDS-DMA kernels (S <= %d, VLR_ATTN_DMA != 0)", ATTN_MAX_TILES * KV_TILE);
     const int Sp = (S + 63) / 64 * 64;   // lse and delta_ws are [batch][heads][Sp] floats
     const int pi = vlr_prof_begin(VLR_K_ATTN_BWD, 10.0 * S * S * heads * head_dim * batch * (causal ? 0.5 : 1.0), st);
     hipLaunchKernelGGL(attn_delta_kernel, dim3(batch * S), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)o, ldo,
                        delta_ws, S, Sp, heads);
     const dim3 grid((S + 127) / 128, heads, batch);
-    static int dma = -1;
     constexpr int LDS_DQ = 4 * KV_TILE * 128 * 2 + ATTN_MAX_TILES * 8, LDS_DKV = 4 * KV_TILE * 128 * 2;
-    if (dma < 0) {
-        const char* e = getenv("VLR_ATTN_DMA");
-        dma = (e && e[0] == '0') ? 0 : 1;
+    static bool attr = false;
+    if (!attr) {
+        attr = true;
         hipFuncSetAttribute((const void*)attn_bwd_dq2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ);
         hipFuncSetAttribute((const void*)attn_bwd_dq2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ);
         hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DKV);
         hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DKV);
     }
-    if (dma && S <= ATTN_MAX_TILES * KV_TILE) {
+    AttnGrid ag;
+    ag.heads = heads; ag.kv_heads = kv_heads; ag.group = heads / kv_heads; ag.nblk = (S + 127) / 128; ag.n_kvp = batch * kv_heads;
+    if (dma) {
         if (causal) {
-            hipLaunchKernelGGL((attn_bwd_dq2_kernel<true>), grid, dim3(256), LDS_DQ, st, (const bf16_t*)q, (const bf16_t*)k,
-                               (const bf16_t*)v, ld, (const bf16_t*)dout, ldo, lse, delta_ws, key_mask, (bf16_t*)dq, ldd, S, Sp, scale);
-            hipLaunchKernelGGL((attn_bwd_dkv2_kernel<true>), grid, dim3(256), LDS_DKV, st, (const bf16_t*)q, (const bf16_t*)k,
-                               (const bf16_t*)v, ld, (const bf16_t*)dout, ldo, lse, delta_ws, key_mask, (bf16_t*)dk, (bf16_t*)dv, ldd, S, Sp, scale);
+            hipLaunchKernelGGL((attn_bwd_dq2_kernel<true>), dim3(ag.grid(false)), dim3(256), LDS_DQ, st, (const bf16_t*)q, (const bf16_t*)k,
+                               (const bf16_t*)v, ld, (const bf16_t*)dout, ldo, lse, delta_ws, key_mask, (bf16_t*)dq, ldd, S, Sp, scale, ag);
+            hipLaunchKernelGGL((attn_bwd_dkv2_kernel<true>), dim3(ag.grid(true)), dim3(256), LDS_DKV, st, (const bf16_t*)q, (const bf16_t*)k,
+                               (const bf16_t*)v, ld, (const bf16_t*)dout, ldo, lse, delta_ws, key_mask, (bf16_t*)dk, (bf16_t*)dv, ldd, S, Sp, scale, ag);
         } else {
-            hipLaunchKernelGGL((attn_bwd_dq2_kernel<false>), grid, dim3(256), LDS_DQ, st, (const bf16_t*)q, (const bf16_t*)k,
-                               (const bf16_t*)v, ld, (const bf16_t*)dout, ldo, lse, delta_ws, key_mask, (bf16_t*)dq, ldd, S, Sp, scale);
-            hipLaunchKernelGGL((attn_bwd_dkv2_kernel<false>), grid, dim3(256), LDS_DKV, st, (const bf16_t*)q, (const bf16_t*)k,
-                               (const bf16_t*)v, ld, (const bf16_t*)dout, ldo, lse, delta_ws, key_mask, (bf16_t*)dk, (bf16_t*)dv, ldd, S, Sp, scale);
+            hipLaunchKernelGGL((attn_bwd_dq2_kernel<false>), dim3(ag.grid(false)), dim3(256), LDS_DQ, st, (const bf16_t*)q, (const bf16_t*)k,
+                               (const bf16_t*)v, ld, (const bf16_t*)dout, ldo, lse, delta_ws, key_mask, (bf16_t*)dq, ldd, S, Sp, scale, ag);
+            hipLaunchKernelGGL((attn_bwd_dkv2_kernel<false>), dim3(ag.grid(true)), dim3(256), LDS_DKV, st, (const bf16_t*)q, (const bf16_t*)k,
+                               (const bf16_t*)v, ld, (const bf16_t*)dout, ldo, lse, delta_ws, key_mask, (bf16_t*)dk, (bf16_t*)dv, ldd, S, Sp, scale, ag);
         }
     } else if (causal) {
         hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), grid, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,
@@ -928,4 +990,11 @@ extern "C" int vlr_attn_bwd(const void* q, const void* k, const void* v, int ld,
     }
     vlr_prof_end(pi, st);
     return vlr_check_launch("vlr_attn_bwd");
+}
+extern "C" int vlr_attn_bwd(const void* q, const void* k, const void* v, int ld, const void* o, const void* dout,
+                            int ldo, const float* lse, float* delta_ws, const int* key_mask, void* dq, void* dk,
+                            void* dv, int ldd, int batch, int S, int heads, int head_dim, int causal, float scale,
+                            hipStream_t st) {
+    return vlr_attn_bwd_gqa(q, k, v, ld, o, dout, ldo, lse, delta_ws, key_mask, dq, dk, dv, ldd, batch, S, heads, heads, head_dim,
+                            causal, scale, st);
 }

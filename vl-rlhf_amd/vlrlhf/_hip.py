@@ -78,6 +78,8 @@ _SIGS = {
     "vlr_rowdot": [P, P, P, I, I, P],
     "vlr_attn_fwd": [P, P, P, I, P, I, P, P, I, I, I, I, I, F, P],
     "vlr_attn_bwd": [P, P, P, I, P, P, I, P, P, P, P, P, P, I, I, I, I, I, I, F, P],
+    "vlr_attn_fwd_gqa": [P, P, P, I, P, I, P, P, I, I, I, I, I, I, F, P],
+    "vlr_attn_bwd_gqa": [P, P, P, I, P, P, I, P, P, P, P, P, P, I, I, I, I, I, I, I, F, P],
     "vlr_merge_index": [P, P, P, I, I, I, I, I, I, I, I, P, P, P, P, P, P, P, P],
     "vlr_merge_fwd": [P, P, P, P, P, I, I, I, I, P],
     "vlr_merge_bwd": [P, P, P, P, P, P, I, I, I, I, I, I, P],
