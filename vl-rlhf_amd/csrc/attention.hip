@@ -277,6 +277,15 @@ typedef __attribute__((address_space(3))) void attn_lvoid_t;
 __device__ __forceinline__ void attn_dma16(const bf16_t* sbase, uint32_t voff, uint32_t lds_addr) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
 }
+// 4 bytes per lane -> LDS [m0 + lane*4]: one wave instruction moves 64 consecutive floats (per-tile lse / delta rows)
+__device__ __forceinline__ void attn_dma4(const float* sbase, uint32_t voff, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+}
+// Retire the prologue's global loads of loop-invariant fragments HERE.  hipcc places the s_waitcnt vmcnt(N) for a loaded register at
+// its first use - inside the tile loop - and cannot see the LDS-DMA instructions (inline asm) issued there: vmcnt retires in
+// order, so that wait also drained the NEXT tile's DMA in the middle of the current tile's MFMAs, every iteration (found in
+// the r01 ISA: vmcnt(7)..vmcnt(0) between the QK^T MFMAs; the double buffering never overlapped anything).
+#define ATTN_RETIRE(frag) asm volatile("" : "+v"(frag))
 #define ATTN_MAX_TILES 128   // S <= 8192
 template <int D>
 struct AttnFwd2 {
@@ -351,6 +360,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     float m = -INFINITY, l = 0.f;      // m in the scaled log2 domain
+#pragma unroll
+    for (int st = 0; st < D / 16; ++st) ATTN_RETIRE(qf[st]);
 
     for (int it = 0; it < nkv; ++it) {
         const int k0 = it * KV_TILE;
@@ -724,14 +735,18 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 1) void attn_bwd_dq2_kernel(const
         qf[st] = *reinterpret_cast<const bf16x8*>(qh + (size_t)qrow * ld + 16 * st + 8 * g);
         dof[st] = *reinterpret_cast<const bf16x8*>(doh + (size_t)qrow * ldo + 16 * st + 8 * g);
     }
-    const float L2 = qi < S ? lse[((size_t)b * nh + head) * Sp + qrow] : INFINITY;
-    const float dl = delta[((size_t)b * nh + head) * Sp + qrow];
+    float L2 = qi < S ? lse[((size_t)b * nh + head) * Sp + qrow] : INFINITY;
+    float dl = delta[((size_t)b * nh + head) * Sp + qrow];
 
     f32x16 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+    for (int st = 0; st < 8; ++st) { ATTN_RETIRE(qf[st]); ATTN_RETIRE(dof[st]); }
+    ATTN_RETIRE(L2);
+    ATTN_RETIRE(dl);
 
     for (int it = 0; it < nkv; ++it) {
         const int k0 = it * KV_TILE;
@@ -786,7 +801,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(const bf16_t* __rest
                                                             bf16_t* __restrict__ dv, int lddkv, int S, int Sp, float scale,
                                                             AttnGrid ag) {
     constexpr int D = 128, TB = KV_TILE * D * 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][Q | dO]
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][Q | dO] | [2][lse 64 f32 | delta 64 f32]
     const int t = threadIdx.x, lane = t & 63, g = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     int kvhead, b, kblk;
@@ -810,6 +825,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(const bf16_t* __rest
         const uint32_t dst = lds0 + (j & 1) * 2 * TB;
         attn_issue_tile128(q + tok0 * ld + head * D, ld, q_start + it * KV_TILE, S, dst, wave, lane);
         attn_issue_tile128(dout + tok0 * ldo + head * D, ldo, q_start + it * KV_TILE, S, dst + TB, wave, lane);
+        // the tile's 64 lse / delta values ride the same DMA queue (rows are padded to Sp: always in range) - a global load in
+        // the loop would make the compiler wait vmcnt(0), i.e. for the next tile's DMA as well
+        if (wave < 2) {
+            const float* src = (wave == 0 ? lse : delta) + ((size_t)b * nh + head) * Sp + q_start + it * KV_TILE;
+            attn_dma4(src, (uint32_t)lane * 4u, lds0 + 4 * TB + (j & 1) * 512 + wave * 256);
+        }
     };
     issue(0);
 
@@ -825,11 +846,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(const bf16_t* __rest
 #pragma unroll
         for (int r = 0; r < 16; ++r) { adk[i][r] = 0.f; adv[i][r] = 0.f; }
 
+#pragma unroll
+    for (int st = 0; st < 8; ++st) { ATTN_RETIRE(kf[st]); ATTN_RETIRE(vf[st]); }
+
     for (int j = 0; j < nit; ++j) {
-        const int head = kvhead * group + j / nq;
         const int q0 = q_start + (j % nq) * KV_TILE;
-        const float* lse_h = lse + ((size_t)b * nh + head) * Sp;   // rows padded to Sp: 16-byte aligned, tail = +inf
-        const float* dl_h = delta + ((size_t)b * nh + head) * Sp;
+        const float* lse_t = reinterpret_cast<const float*>(smem + 4 * TB + (j & 1) * 512);   // this tile's 64 lse | 64 delta (tail = +inf)
+        const float* dl_t = lse_t + 64;
         ATTN_TILE_BARRIER();
         if (j + 1 < nit) issue(j + 1);
         if (CAUSAL && q0 + KV_TILE - 1 < kw0) continue;   // every query of the tile precedes this wave's keys
@@ -849,8 +872,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(const bf16_t* __rest
             f32x16 pm;
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
-                const f32x4 l2 = *reinterpret_cast<const f32x4*>(lse_h + q0 + qb * 32 + 8 * rq + 4 * g);
-                const f32x4 dl = *reinterpret_cast<const f32x4*>(dl_h + q0 + qb * 32 + 8 * rq + 4 * g);
+                const f32x4 l2 = *reinterpret_cast<const f32x4*>(lse_t + qb * 32 + 8 * rq + 4 * g);
+                const f32x4 dl = *reinterpret_cast<const f32x4*>(dl_t + qb * 32 + 8 * rq + 4 * g);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * rq + e;
@@ -954,7 +977,7 @@ extern "C" int vlr_attn_bwd_gqa(const void* q, const void* k, const void* v, int
     hipLaunchKernelGGL(attn_delta_kernel, dim3(batch * S), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)o, ldo,
                        delta_ws, S, Sp, heads);
     const dim3 grid((S + 127) / 128, heads, batch);
-    constexpr int LDS_DQ = 4 * KV_TILE * 128 * 2 + ATTN_MAX_TILES * 8, LDS_DKV = 4 * KV_TILE * 128 * 2;
+    constexpr int LDS_DQ = 4 * KV_TILE * 128 * 2 + ATTN_MAX_TILES * 8, LDS_DKV = 4 * KV_TILE * 128 * 2 + 1024;
     static bool attr = false;
     if (!attr) {
         attr = true;
