@@ -474,13 +474,156 @@ def llava_forward(W, cfg, input_ids, attention_mask, labels, pixel_values, emula
     return lm_logits(hidden, W, emulate_bf16), mlabels, aux
 
 
+# ----------------------------------------------------------------------------------------------------------
+# LLaVA-Next (anyres tiles + Mistral GQA): the deltas of src/vlrlhf/models/LlavaNext/__init__.py on the DPO path
+# ----------------------------------------------------------------------------------------------------------
+def select_best_resolution(original_size, possible_resolutions):
+    """transformers image_processing_utils.select_best_resolution (used by image_size_to_num_patches /
+    get_anyres_image_grid_shape; call sites LlavaNext/__init__.py:216-222 and HF pack_image_features): the (height, width) of
+    the pinpoint that keeps the most of the image and then wastes the least."""
+    oh, ow = original_size
+    best, max_eff, min_waste = None, 0, float("inf")
+    for h, w in possible_resolutions:
+        scale = min(w / ow, h / oh)
+        dw, dh = int(ow * scale), int(oh * scale)
+        eff = min(dw * dh, ow * oh)
+        waste = w * h - eff
+        if eff > max_eff or (eff == max_eff and waste < min_waste):
+            best, max_eff, min_waste = (h, w), eff, waste
+    return best
+
+
+def anyres_num_patches(image_size, pinpoints, tile):
+    """HF image_size_to_num_patches: tiles of the best resolution + the base image"""
+    h, w = select_best_resolution(tuple(int(x) for x in image_size), pinpoints)
+    return len(range(0, h, tile)) * len(range(0, w, tile)) + 1
+
+
+def pack_image_features(image_features, image_sizes, newline, cfg):
+    """HF LlavaNext pack_image_features ("spatial_unpad"; call site LlavaNext/__init__.py:255-259): per image
+    [base | tiles laid out on their grid, un-padded to the original aspect ratio, one `image_newline` column per row]."""
+    g = cfg["image_size"] // cfg["patch_size"]
+    out, lens = [], []
+    for feat, size in zip(image_features, image_sizes):
+        if feat.shape[0] > 1:
+            base, tiles = feat[0], feat[1:]
+            bh, bw = select_best_resolution(tuple(int(x) for x in size), cfg["image_grid_pinpoints"])
+            nph, npw = bh // cfg["image_size"], bw // cfg["image_size"]
+            t = tiles.view(nph, npw, g, g, -1).permute(4, 0, 2, 1, 3).reshape(tiles.shape[-1], nph * g, npw * g)
+            oh, ow = (int(x) for x in size)
+            ch, cw = t.shape[1:]
+            if ow / oh > cw / ch:
+                nh_ = int(round(oh * (cw / ow), 7))
+                pad = (ch - nh_) // 2
+                t = t[:, pad: ch - pad, :]
+            else:
+                nw_ = int(round(ow * (ch / oh), 7))
+                pad = (cw - nw_) // 2
+                t = t[:, :, pad: cw - pad]
+            t = torch.cat((t, newline[:, None, None].expand(-1, t.shape[1], 1).to(t.dtype)), dim=-1)
+            f = torch.cat((base, t.flatten(1, 2).transpose(0, 1)), dim=0)
+        else:
+            f = torch.cat((feat[0], newline[None].to(feat.dtype)), dim=0)
+        out.append(f)
+        lens.append(f.shape[0])
+    return out, torch.tensor(lens, dtype=torch.long)
+
+
+def llavanext_merge(image_features, feature_lens, inputs_embeds, input_ids, attention_mask, labels, image_token_index,
+                    padding_side="left", ignore_index=IGNORE_INDEX):
+    """src/vlrlhf/models/LlavaNext/__init__.py:38-171 restated position-wise.  Differences from the LLaVA-1.5 merge: every
+    `<image>` expands to ITS OWN feature_lens[i] slots; padding is recognised from the attention mask (:57-71: zeros on the
+    left -> rows end-aligned, zeros on the right -> start-aligned, neither -> `padding_side`); padded text tokens are not
+    copied at all; the image slots of a row are exactly the free slots inside its [valid length] window (:141-150).
+    Returns (embeds, mask, position_ids, labels, image_to_overwrite) in the reference's order (:171)."""
+    B, T = input_ids.shape
+    H = inputs_embeds.shape[-1]
+    if int(feature_lens.sum()) != image_features.shape[0]:
+        raise ValueError(f"feature_lens={feature_lens} / {int(feature_lens.sum())} != image_features.shape={tuple(image_features.shape)}")
+    lpad, rpad = bool((attention_mask[:, 0] == 0).any()), bool((attention_mask[:, -1] == 0).any())
+    left = True
+    if B > 1:
+        if lpad and not rpad:
+            left = True
+        elif rpad and not lpad:
+            left = False
+        elif not lpad and not rpad:
+            left = padding_side == "left"
+        else:
+            raise ValueError(f"both side of attention_mask has zero, invalid. {attention_mask}")
+    is_img = input_ids == image_token_index
+    n_img_row = is_img.sum(-1)
+    if int(is_img.sum()) != feature_lens.shape[0]:
+        raise ValueError(f"Number of image tokens in input_ids ({int(is_img.sum())}) different from num_images ({feature_lens.shape[0]}).")
+    per_row = torch.split(feature_lens, n_img_row.tolist())
+    seq_len = (attention_mask == 1).long().sum(-1) - n_img_row + torch.tensor([int(x.sum()) for x in per_row])
+    S = int(seq_len.max())
+    step = torch.ones(B, T, dtype=torch.long)
+    step[is_img] = feature_lens
+    new_pos = torch.cumsum(step, -1) - 1
+    if left:
+        new_pos = new_pos + (S - 1 - new_pos[:, -1:])
+    out = torch.zeros(B, S, H, dtype=inputs_embeds.dtype)
+    out_mask = torch.zeros(B, S, dtype=attention_mask.dtype)
+    out_labels = torch.full((B, S), ignore_index, dtype=torch.long)
+    bi, ti = torch.where((~is_img) & (attention_mask == 1))
+    dst = new_pos[bi, ti]
+    out[bi, dst] = inputs_embeds[bi, ti]
+    out_mask[bi, dst] = attention_mask[bi, ti]
+    if labels is not None:
+        out_labels[bi, dst] = labels[bi, ti]
+    free = torch.ones(B, S, dtype=torch.bool)
+    free[bi, dst] = False
+    idx = torch.arange(S)[None].expand(B, S)
+    free &= ((S - idx) <= seq_len[:, None]) if left else (idx < seq_len[:, None])
+    if int(free.sum()) != image_features.shape[0]:
+        raise ValueError(f"image_to_overwrite.sum()={int(free.sum())} != num_image_features={image_features.shape[0]} The input provided to "
+                         "the model are wrong. This prevents correct indexing and breaks batch generation.")
+    out[free] = image_features.to(out.dtype)
+    out_mask = out_mask | free.to(out_mask.dtype)
+    position_ids = (out_mask.cumsum(-1) - 1).masked_fill(out_mask == 0, 1)
+    return out, out_mask, position_ids, (out_labels if labels is not None else None), free
+
+
+def llavanext_forward(W, cfg, input_ids, attention_mask, labels, pixel_values, image_sizes, emulate_bf16=False,
+                      dedupe_images=True, collect=None):
+    """LlavaNextForRL.forward on the training path (LlavaNext/__init__.py:205-265, 306-316): embeddings with `<image>` ids
+    mapped to 0 (:209-211), ViT on the first num_patches tiles of every image, projector, pack, merge, Mistral decoder
+    (grouped-query attention: cfg['kv_heads']).  pixel_values [n_img, max_patches, 3, s, s], image_sizes [n_img, 2]."""
+    ids0 = input_ids.clone()
+    ids0[input_ids == cfg["image_token"]] = 0
+    emb = _rt(W["language_model.model.embed_tokens.weight"][ids0], emulate_bf16, "w")
+    n = pixel_values.shape[0]
+    dup = dedupe_images and n % 2 == 0 and torch.equal(pixel_values[: n // 2], pixel_values[n // 2:]) and torch.equal(image_sizes[: n // 2], image_sizes[n // 2:])
+    nu = n // 2 if dup else n
+    npatch = [anyres_num_patches(sz, cfg["image_grid_pinpoints"], cfg["image_size"]) for sz in image_sizes[:nu]]
+    pv = torch.cat([x[:k] for x, k in zip(pixel_values[:nu], npatch)], dim=0)
+    feat = clip_vit_features(pv, W, cfg, emulate_bf16)
+    img = projector(feat, W, emulate_bf16)
+    packed, lens = pack_image_features(torch.split(img, npatch, dim=0), image_sizes[:nu], _rt(W["image_newline"], emulate_bf16, "w"), cfg)
+    packed = torch.cat(packed, dim=0)
+    if dup:
+        packed, lens = torch.cat([packed, packed], 0), torch.cat([lens, lens], 0)
+    merged, mask, pos, mlabels, img_map = llavanext_merge(packed, lens, emb, input_ids, attention_mask, labels, cfg["image_token"],
+                                                          cfg.get("padding_side", "left"))
+    hidden = llama_hidden(merged, mask, pos, W, cfg, emulate_bf16, collect=collect)
+    aux = dict(vit_feat=feat, projected=img, packed=packed, feature_lens=lens, merged=merged, mask=mask, pos=pos, img_map=img_map,
+               hidden=hidden, num_patches=npatch)
+    return lm_logits(hidden, W, emulate_bf16), mlabels, aux
+
+
 def concatenated_forward(W, cfg, batch, loss_type="sigmoid", emulate_bf16=False, lora=None, collect=None):
     """src/vlrlhf/base/trainer.py:190-242 -> (chosen_logps, rejected_logps, chosen_logits, rejected_logits)."""
     cb = concatenated_inputs(batch)
     n = batch["chosen_labels"].shape[0]
-    logits, labels, _ = llava_forward(W, cfg, cb["concatenated_input_ids"], cb["concatenated_attention_mask"],
-                                      cb["concatenated_labels"], cb["concatenated_img_input_dict"]["pixel_values"],
-                                      emulate_bf16, lora=lora, collect=collect)
+    if cfg.get("image_grid_pinpoints"):      # LLaVA-Next
+        logits, labels, _ = llavanext_forward(W, cfg, cb["concatenated_input_ids"], cb["concatenated_attention_mask"],
+                                              cb["concatenated_labels"], cb["concatenated_img_input_dict"]["pixel_values"],
+                                              cb["concatenated_img_input_dict"]["image_sizes"], emulate_bf16, collect=collect)
+    else:
+        logits, labels, _ = llava_forward(W, cfg, cb["concatenated_input_ids"], cb["concatenated_attention_mask"],
+                                          cb["concatenated_labels"], cb["concatenated_img_input_dict"]["pixel_values"],
+                                          emulate_bf16, lora=lora, collect=collect)
     lp = get_batch_logps(logits, labels, mask_shared_tokens=(loss_type == "ddpo"))
     return lp[:n], lp[n:], logits[:n], logits[n:]
 

@@ -12,12 +12,17 @@ def load_case(name):
     z = np.load(os.path.join(GOLDEN, f"{name}.npz"))
     cfg = json.loads(bytes(z["config_json"]).decode())
     W = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w.")}
+    W.update({k[4:]: torch.from_numpy(z[k]).view(torch.bfloat16).float() for k in z.files if k.startswith("w16.")})   # bf16 bit patterns
     W_ref = dict(W)
     for k in z.files:
         if k.startswith("ref_w."):
             W_ref[k[6:]] = torch.from_numpy(z[k])
+        elif k.startswith("ref_w16."):
+            W_ref[k[8:]] = torch.from_numpy(z[k]).view(torch.bfloat16).float()
     batch = {k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("batch.") and k != "batch.pixel_values"}
     batch["img_input_dict"] = dict(pixel_values=torch.from_numpy(z["batch.pixel_values"]))
+    if "batch.image_sizes" in z.files:
+        batch["img_input_dict"]["image_sizes"] = torch.from_numpy(z["batch.image_sizes"])
     batch["img_path"] = ["synthetic"] * batch["chosen_input_ids"].shape[0]
     rows = json.loads(bytes(z["rows_json"]).decode())
     return z, cfg, W, W_ref, batch, rows

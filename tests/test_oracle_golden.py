@@ -240,3 +240,54 @@ def test_hashed_weights_are_machine_independent_and_match_the_product_generator(
         if isinstance(v, torch.Tensor):
             assert torch.equal(v, bp[k]), k
     assert torch.equal(bo["img_input_dict"]["pixel_values"], bp["img_input_dict"]["pixel_values"])
+
+
+def test_llavanext_oracle_matches_reference_golden():
+    """the LLaVA-Next restatement (anyres pack, variable-length merge, grouped-query decoder) against
+    tests/golden/llavanext_small.npz = the reference's own merge / get_batch_logps / dpo_loss composed with HF CLIP, pack_image_features
+    and MistralForCausalLM (oracle/make_golden_llavanext.py)."""
+    from oracle import llava_dpo_oracle as O
+    from tests.golden_util import load_case, t
+    z, cfg, W, W_ref, batch, rows = load_case("llavanext_small")
+    # merge known answers (right / left padding, two images in one row)
+    for tag in ("right", "left", "nopad_two_images"):
+        g = lambda k: t(z, f"mg.{tag}.{k}")   # noqa: E731
+        emb, m, pos, lab, imap = O.llavanext_merge(g("feats"), g("fl"), g("emb"), g("ids"), g("am"), g("lab"), 180, "left")
+        assert torch.equal(m, g("out_mask")) and torch.equal(pos, g("out_pos")) and torch.equal(lab, g("out_labels")), tag
+        assert torch.equal(imap, g("out_map")) and torch.equal(emb, g("out_emb")), tag
+    assert [O.anyres_num_patches(s, cfg["image_grid_pinpoints"], cfg["image_size"]) for s in cfg["image_sizes"]] == z["num_patches"].tolist()[:2]
+    cb = O.concatenated_inputs(batch)
+    assert torch.equal(cb["concatenated_img_input_dict"]["image_sizes"], torch.cat([batch["img_input_dict"]["image_sizes"]] * 2))
+    with torch.no_grad():
+        logits, labels, aux = O.llavanext_forward(W, cfg, cb["concatenated_input_ids"], cb["concatenated_attention_mask"], cb["concatenated_labels"],
+                                                  cb["concatenated_img_input_dict"]["pixel_values"], cb["concatenated_img_input_dict"]["image_sizes"])
+    B = batch["chosen_input_ids"].shape[0]
+    assert aux["feature_lens"].tolist() == z["feature_lens"].tolist()
+    assert torch.equal(labels, t(z, "merged_labels")) and torch.equal(aux["mask"], t(z, "merged_mask"))
+    assert torch.equal(aux["pos"], t(z, "merged_pos")) and torch.equal(aux["img_map"], t(z, "image_position_map"))
+    F = int(aux["feature_lens"][:B].sum())
+
+    def close(a, b, tol, what):
+        e = float((a - b).abs().max()) / (float(b.abs().max()) + 1e-12)
+        assert e < tol, f"{what}: {e:.2e}"
+    close(aux["vit_feat"], t(z, "vit_feat"), 3e-5, "vit")
+    close(aux["packed"][:F], t(z, "packed_features"), 3e-5, "packed features")
+    close(aux["merged"], t(z, "merged_embeds"), 3e-5, "merged")
+    close(logits, t(z, "logits"), 5e-5, "logits")
+    lp = O.get_batch_logps(logits, labels)
+    lpd = O.get_batch_logps(logits, labels, mask_shared_tokens=True)
+    close(lp, t(z, "policy_logps"), 2e-5, "logps")
+    close(lpd, t(z, "policy_logps_ddpo"), 2e-5, "ddpo logps")
+    # the DDPO training loss and its gradients (GQA backward through autograd of the restatement)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in W.items() if not k.startswith("vision_tower.")}
+    Wp = dict(W)
+    Wp.update(leaves)
+    loss, _ = O.compute_loss(Wp, W_ref, cfg, batch, cfg["beta"], loss_type="ddpo")
+    assert abs(float(loss) - float(z["loss_mean_ddpo"])) < 2e-5
+    loss.backward()
+    n = 0
+    for k in z.files:
+        if k.startswith("grad."):
+            close(leaves[k[5:]].grad, t(z, k), 2e-3, k)
+            n += 1
+    assert n >= 10
