@@ -74,6 +74,9 @@ int vlr_im2col(const float* pixel_values, void* patches, int n_img, int image_si
 int vlr_rope_table(float* cos_t, float* sin_t, int max_pos, int head_dim, float theta, vlr_stream_t stream);
 int vlr_rope(void* qkv, const int* pos, const float* cos_t, const float* sin_t, int M, int H, int head_dim, int ld,
              int max_pos, int backward, vlr_stream_t stream);
+/* same on the first n_heads heads of every row (q heads followed by the k heads; grouped-query layouts have fewer k heads) */
+int vlr_rope_heads(void* qkv, const int* pos, const float* cos_t, const float* sin_t, int M, int n_heads, int head_dim, int ld,
+                   int max_pos, int backward, vlr_stream_t stream);
 int vlr_swiglu_fwd(const void* gate_up, void* act, int M, int I, vlr_stream_t stream);
 int vlr_swiglu_bwd(void* gate_up_inout, const void* dact, int M, int I, vlr_stream_t stream);
 int vlr_gelu_fwd(const void* z, void* h, long n, vlr_stream_t stream);
@@ -155,7 +158,10 @@ typedef struct {
     int max_pos;            /* rows of the rope tables */
     const float* rope_cos;  /* [max_pos][head_dim/2] */
     const float* rope_sin;
+    int kv_heads;           /* grouped-query attention (Mistral, InternLM2): K/V heads, a divisor of heads; 0 = heads */
 } vlr_llama_cfg;
+/* Shapes with Nq = heads*head_dim, Nkv = kv_heads*head_dim: wqkv [Nq + 2 Nkv][hidden] (q | k | v rows), wo [hidden][Nq],
+ * qkv / dqkv activations [M][Nq + 2 Nkv], attn / dattn [M][Nq].  hidden == Nq for LLaMA / Mistral. */
 typedef struct {  /* bf16 weights of one decoder layer; q|k|v and gate|up are stored fused */
     const void* ln1; const void* wqkv; const void* wo; const void* ln2; const void* wgu; const void* wdown;
 } vlr_layer_weights;

@@ -1,0 +1,120 @@
+"""LLaVA-Next (anyres tiles, variable-length merge, Mistral grouped-query decoder) on the MI355X against
+tests/golden/llavanext_small.npz - the reference's own LlavaNext merge / get_batch_logps / dpo_loss composed with HF CLIP,
+pack_image_features and MistralForCausalLM (oracle/make_golden_llavanext.py) - and against the CPU oracle's bf16 emulation.
+BASELINE.json configs[3] names DDPO (dense per-token beta) on this model: the training-step check uses loss_type ddpo."""
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import llava_dpo_oracle as O  # noqa: E402  (checker only)
+from tests.golden_util import load_case, t  # noqa: E402
+from tests.test_hip_e2e import TOL_LOGPS_FP32, TOL_LOSS_BF16, TOL_LOSS_FP32, cosine, relmax  # noqa: E402
+
+
+def build():
+    from vlrlhf.models.LlavaNext import LlavaNextDPOTrainer, LlavaNextForRL
+    z, cfg, W, W_ref, batch, rows = load_case("llavanext_small")
+    model = LlavaNextForRL.from_state_dict(cfg, W)
+    ref = model.create_reference_model()
+    ref.weights.load_state_dict(W_ref)
+    mk = lambda lt: LlavaNextDPOTrainer(model, ref, cfg["beta"], 0, lt, SimpleNamespace(gradient_accumulation_steps=1), None, -100, 0)   # noqa: E731
+    return z, cfg, W, W_ref, batch, model, ref, mk
+
+
+def test_llavanext_forward_matches_golden():
+    z, cfg, W, W_ref, batch, model, ref, mk = build()
+    tr = mk("sigmoid")
+    cb = tr.concatenated_inputs(batch, device=torch.device("cuda"))
+    assert cb["concatenated_img_input_dict"]["image_sizes"].shape == (4, 2)
+    model.eval()
+    with torch.no_grad():
+        out = model(input_ids=cb["concatenated_input_ids"], attention_mask=cb["concatenated_attention_mask"],
+                    labels=cb["concatenated_labels"], use_cache=False, **cb["concatenated_img_input_dict"])
+    c = out.logits.c
+    # integer side: bit-exact with the reference merge on the reference's pack lengths
+    assert c["pack"]["feature_lens"].tolist() == z["feature_lens"].tolist()[:2]
+    assert torch.equal(out.labels.cpu(), t(z, "merged_labels")) and torch.equal(out.image_position_map.cpu(), t(z, "image_position_map"))
+    assert torch.equal(c["mask"].cpu().long(), t(z, "merged_mask")) and torch.equal(c["pos"].cpu().long(), t(z, "merged_pos"))
+    # floating side
+    assert relmax(c["vit_feat"].reshape(-1, 4, cfg["vit_hidden"]), t(z, "vit_feat")) < 3e-2
+    assert relmax(c["feats"], t(z, "packed_features")) < 3e-2
+    valid = t(z, "merged_mask").bool()
+    x0 = c["x0"].float().cpu().reshape(4, c["S"], -1)
+    assert relmax(x0[valid], t(z, "merged_embeds")[valid]) < 1e-2
+    assert float(x0[~valid].abs().max()) == 0.0                      # padded positions hold zeros
+    logits = out.logits.materialize().cpu()
+    assert relmax(logits[valid], t(z, "logits")[valid]) < 4e-2
+    lp = tr.get_batch_logps(out.logits, out.labels)
+    assert float((lp.cpu() - t(z, "policy_logps")).abs().max()) < TOL_LOGPS_FP32
+    lpd = tr.get_batch_logps(out.logits, out.labels, mask_shared_tokens=True)
+    assert float((lpd.cpu() - t(z, "policy_logps_ddpo")).abs().max()) < TOL_LOGPS_FP32
+    with torch.no_grad():
+        rc, rr, _, _ = tr.concatenated_forward(ref, batch)
+    assert float((torch.cat([rc, rr]).cpu() - t(z, "ref_logps")).abs().max()) < TOL_LOGPS_FP32
+    # errors of the reference forward
+    with pytest.raises(ValueError, match="image_sizes"):
+        model(input_ids=cb["concatenated_input_ids"], attention_mask=cb["concatenated_attention_mask"], labels=cb["concatenated_labels"],
+              pixel_values=cb["concatenated_img_input_dict"]["pixel_values"])
+    bad = cb["concatenated_input_ids"].clone()
+    bad[0, 3] = cfg["image_token"]                                   # one more <image> id than images
+    with pytest.raises(ValueError, match="Number of image tokens"):
+        model(input_ids=bad, attention_mask=cb["concatenated_attention_mask"], labels=cb["concatenated_labels"], **cb["concatenated_img_input_dict"])
+
+
+@pytest.mark.parametrize("loss_type", ["sigmoid", "ddpo", "ipo"])
+def test_llavanext_losses_match_golden(loss_type):
+    z, cfg, W, W_ref, batch, model, ref, mk = build()
+    tr = mk(loss_type)
+    model.eval()
+    with torch.no_grad():
+        pc, pr, _, _ = tr.concatenated_forward(model, batch)
+        rc, rr, _, _ = tr.concatenated_forward(ref, batch)
+    losses, cr, rw = tr.dpo_loss(pc, pr, rc, rr)
+    exp = t(z, f"loss_{loss_type}")
+    tol = 6e-2 * float(exp.abs().max()) + 2e-2 if loss_type == "ipo" else 1.2e-2
+    assert float((losses.cpu() - exp).abs().max()) < tol, (losses.cpu(), exp)
+    assert float((cr.cpu() - t(z, f"chosen_rewards_{loss_type}")).abs().max()) < 2.5e-2
+
+
+def test_llavanext_ddpo_train_step_matches_golden_and_oracle():
+    z, cfg, W, W_ref, batch, model, ref, mk = build()
+    tr = mk("ddpo")
+    eng = model.engine
+    eng.init_optimizer()
+    loss = tr.training_step(model, batch)
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(z["loss_mean_ddpo"])) < TOL_LOSS_FP32, (float(loss), float(z["loss_mean_ddpo"]))
+    with torch.no_grad():
+        l16, _ = O.compute_loss(W, W_ref, cfg, batch, cfg["beta"], loss_type="ddpo", emulate_bf16=True)
+    assert abs(float(loss) - float(l16)) < TOL_LOSS_BF16, (float(loss), float(l16))
+    # gradients: the anyres un-pack (image_newline column sum, projector rows), the GQA backward (k/v summed over the group) ...
+    g = {n: p.grad for n, p in model.named_parameters()}
+    n = 0
+    for k in z.files:
+        if not k.startswith("grad."):
+            continue
+        name = k[5:]
+        assert name in g, name
+        cs = cosine(g[name], t(z, k))
+        assert cs > 0.99, f"{name}: cosine {cs:.4f}"
+        assert abs(float(g[name].float().norm()) / float(t(z, k).norm()) - 1.0) < 6e-2, name
+        n += 1
+    assert n >= 10 and "image_newline" in g
+    eng.optimizer_step(lr=1e-3, beta1=0.9, beta2=0.98, eps=1e-6, weight_decay=0.0, max_grad_norm=1.0)
+    assert abs(eng.grad_norm() / float(z["grad_norm"]) - 1.0) < 4e-2
+    # a second, different step still runs (workspaces keyed by shape)
+    loss2 = tr.training_step(model, batch)
+    assert torch.isfinite(loss2) and float(loss2) < float(loss)
+
+
+def test_llavanext_save_and_reload(tmp_path):
+    from vlrlhf.models.LlavaNext import LlavaNextForRL
+    from vlrlhf.utils.auto_load import MyAutoModel
+    z, cfg, W, W_ref, batch, model, ref, mk = build()
+    model.save_pretrained(str(tmp_path))
+    m2 = MyAutoModel.from_pretrained(str(tmp_path))
+    assert isinstance(m2, LlavaNextForRL) and m2.engine.nkv == 1 and m2.engine.anyres
+    assert torch.equal(m2.engine.policy.flat, model.engine.policy.flat)

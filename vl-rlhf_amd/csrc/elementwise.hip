@@ -218,10 +218,11 @@ __global__ void rope_table_kernel(float* __restrict__ cos_t, float* __restrict__
 
 __global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ qkv, const int* __restrict__ pos,
                                                    const float* __restrict__ cos_t, const float* __restrict__ sin_t,
-                                                   int M, int H, int hd, int ld, float sign, int max_pos) {
-    // one thread = 8 consecutive frequencies of one head of q or k; (H/hd)*2 heads per row, hd/16 threads per head
+                                                   int M, int n_heads, int hd, int ld, float sign, int max_pos) {
+    // one thread = 8 consecutive frequencies of one head of q or k; n_heads rotated heads per row (q heads then k heads),
+    // hd/16 threads per head
     const int tph = hd / 16;
-    const int per_row = (H / hd) * 2 * tph;
+    const int per_row = n_heads * tph;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long row = gid / per_row;
     if (row >= M) return;
@@ -509,13 +510,19 @@ extern "C" int vlr_rope_table(float* cos_t, float* sin_t, int max_pos, int head_
     hipLaunchKernelGGL(rope_table_kernel, dim3((n + 255) / 256), dim3(256), 0, st, cos_t, sin_t, max_pos, head_dim / 2, theta);
     return vlr_check_launch("vlr_rope_table");
 }
+// rotate the first n_heads heads (head_dim columns each: the q heads followed by the k heads) of every row of qkv [M][ld]
+extern "C" int vlr_rope_heads(void* qkv, const int* pos, const float* cos_t, const float* sin_t, int M, int n_heads, int head_dim,
+                              int ld, int max_pos, int backward, hipStream_t st) {
+    VLR_REQUIRE(M > 0 && n_heads > 0 && head_dim % 16 == 0 && ld % 8 == 0 && n_heads * head_dim <= ld, "vlr_rope: bad shape");
+    const long threads = (long)M * n_heads * (head_dim / 16);
+    hipLaunchKernelGGL(rope_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, (bf16_t*)qkv, pos, cos_t,
+                       sin_t, M, n_heads, head_dim, ld, backward ? -1.f : 1.f, max_pos);
+    return vlr_check_launch("vlr_rope");
+}
 extern "C" int vlr_rope(void* qkv, const int* pos, const float* cos_t, const float* sin_t, int M, int H, int head_dim,
                         int ld, int max_pos, int backward, hipStream_t st) {
-    VLR_REQUIRE(M > 0 && head_dim % 16 == 0 && H % head_dim == 0 && ld % 8 == 0, "vlr_rope: bad shape");
-    const long threads = (long)M * (H / head_dim) * 2 * (head_dim / 16);
-    hipLaunchKernelGGL(rope_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, (bf16_t*)qkv, pos, cos_t,
-                       sin_t, M, H, head_dim, ld, backward ? -1.f : 1.f, max_pos);
-    return vlr_check_launch("vlr_rope");
+    VLR_REQUIRE(head_dim > 0 && H % head_dim == 0, "vlr_rope: bad shape");
+    return vlr_rope_heads(qkv, pos, cos_t, sin_t, M, 2 * (H / head_dim), head_dim, ld, max_pos, backward, st);
 }
 
 extern "C" int vlr_swiglu_fwd(const void* gu, void* act, int M, int I, hipStream_t st) {

@@ -466,8 +466,8 @@ static int gemm_impl(int layout, const void* A, const void* B, void* C, const vo
 // through the plain GEMM + the elementwise kernel.
 // ---------------------------------------------------------------------------------------------------------------------
 extern "C" int vlr_swiglu_fwd(const void* gu, void* act, int M, int I, hipStream_t st);
-extern "C" int vlr_rope(void* qkv, const int* pos, const float* cos_t, const float* sin_t, int M, int H, int head_dim, int ld,
-                        int max_pos, int backward, hipStream_t st);
+extern "C" int vlr_rope_heads(void* qkv, const int* pos, const float* cos_t, const float* sin_t, int M, int n_heads, int head_dim,
+                              int ld, int max_pos, int backward, hipStream_t st);
 
 static GemmParams fused_params(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc) {
     GemmParams p;
@@ -528,7 +528,7 @@ extern "C" int vlr_gemm_qkv_rope(const void* x, const void* wqkv, void* qkv, con
         int rc = gemm_impl(0, (const bf16_t*)x + (size_t)done * ldx, wqkv, qr, nullptr, nullptr, M - done, N, K, ldx, K, N, 0, 0, 0, 0, 1.0f, stream);
         if (rc != VLR_OK) return rc;
         // the q and k column blocks are rope_cols / head_dim consecutive heads
-        return vlr_rope(qr, pos + done, cos_t, sin_t, M - done, rope_cols / 2, head_dim, N, max_pos, 0, stream);
+        return vlr_rope_heads(qr, pos + done, cos_t, sin_t, M - done, rope_cols / head_dim, head_dim, N, max_pos, 0, stream);
     }
     return VLR_OK;
 }

@@ -64,15 +64,17 @@ extern "C" int vlr_decoder_layer_fwd_ex(const vlr_llama_cfg* cfg, const vlr_laye
                                         int keep_for_backward, vlr_stream_t st) {
     VLR_REQUIRE(cfg && w && a && x_in && pos, "vlr_decoder_layer_fwd: null argument");
     const int H = cfg->hidden, I = cfg->inter, M = batch * S;
-    VLR_REQUIRE(cfg->heads * cfg->head_dim == H, "vlr_decoder_layer_fwd: heads*head_dim != hidden");
+    const int kvh = cfg->kv_heads > 0 ? cfg->kv_heads : cfg->heads;
+    VLR_REQUIRE(cfg->heads % kvh == 0, "vlr_decoder_layer_fwd: heads %d is not a multiple of kv_heads %d", cfg->heads, kvh);
+    const int Nq = cfg->heads * cfg->head_dim, Nkv = kvh * cfg->head_dim, N = Nq + 2 * Nkv;
     CHECK(vlr_rmsnorm_fwd(x_in, w->ln1, a->xn1, a->rstd1, M, H, cfg->rms_eps, st));
     // q|k|v projection with RoPE applied to the fp32 accumulators in the GEMM epilogue (plain GEMM + rope kernel for the rows /
     // shapes the persistent kernel does not take)
-    CHECK(vlr_gemm_qkv_rope(a->xn1, w->wqkv, a->qkv, pos, cfg->rope_cos, cfg->rope_sin, M, 3 * H, 2 * H, H, H, cfg->head_dim,
+    CHECK(vlr_gemm_qkv_rope(a->xn1, w->wqkv, a->qkv, pos, cfg->rope_cos, cfg->rope_sin, M, N, Nq + Nkv, H, H, cfg->head_dim,
                             cfg->max_pos, st));
-    CHECK(vlr_attn_fwd(a->qkv, off(a->qkv, H), off(a->qkv, 2 * (size_t)H), 3 * H, a->attn, H, a->lse, key_mask, batch, S,
-                       cfg->heads, cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));
-    CHECK(vlr_gemm_bf16(0, a->attn, w->wo, a->x_mid, nullptr, x_in, M, H, H, H, H, H, H, 0, 0, 0, st));
+    CHECK(vlr_attn_fwd_gqa(a->qkv, off(a->qkv, Nq), off(a->qkv, (size_t)Nq + Nkv), N, a->attn, Nq, a->lse, key_mask, batch, S,
+                           cfg->heads, kvh, cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));
+    CHECK(vlr_gemm_bf16(0, a->attn, w->wo, a->x_mid, nullptr, x_in, M, H, Nq, Nq, Nq, H, H, 0, 0, 0, st));
     CHECK(vlr_rmsnorm_fwd(a->x_mid, w->ln2, a->xn2, a->rstd2, M, H, cfg->rms_eps, st));
     // gate|up projection with act = silu(gate) * up computed in the epilogue
     CHECK(vlr_gemm_swiglu(a->xn2, w->wgu, a->gu, a->act, M, I, H, H, keep_for_backward, st));
@@ -91,6 +93,8 @@ extern "C" int vlr_decoder_layer_bwd(const vlr_llama_cfg* cfg, const vlr_layer_w
                                      const int* key_mask, int batch, int S, vlr_stream_t st) {
     VLR_REQUIRE(cfg && w && g && a && ws && x_in && dx_out && dx_in && pos, "vlr_decoder_layer_bwd: null argument");
     const int H = cfg->hidden, I = cfg->inter, M = batch * S;
+    const int kvh = cfg->kv_heads > 0 ? cfg->kv_heads : cfg->heads;
+    const int Nq = cfg->heads * cfg->head_dim, Nkv = kvh * cfg->head_dim, N = Nq + 2 * Nkv;
     const bool two = two_streams();
     hipStream_t sd = st;
     // ---- MLP
@@ -107,18 +111,19 @@ extern "C" int vlr_decoder_layer_bwd(const vlr_llama_cfg* cfg, const vlr_layer_w
     CHECK(vlr_rmsnorm_bwd(ws->dxn, a->x_mid, w->ln2, a->rstd2, dx_out, ws->dx_mid, g->ln2, accumulate, ws->norm_ws, M, H, st));
     // ---- attention
     if (two) { sd = fork_side(st); }
-    CHECK(vlr_gemm_bf16(2, ws->dx_mid, a->attn, g->wo, nullptr, nullptr, H, H, M, H, H, H, 0, 0, accumulate, 0, sd));
+    CHECK(vlr_gemm_bf16(2, ws->dx_mid, a->attn, g->wo, nullptr, nullptr, H, Nq, M, H, Nq, Nq, 0, 0, accumulate, 0, sd));
     if (two) side_done(2);
-    CHECK(vlr_gemm_bf16(1, ws->dx_mid, w->wo, ws->dattn, nullptr, nullptr, M, H, H, H, H, H, 0, 0, 0, 0, st));
+    CHECK(vlr_gemm_bf16(1, ws->dx_mid, w->wo, ws->dattn, nullptr, nullptr, M, Nq, H, H, Nq, Nq, 0, 0, 0, 0, st));
     if (two) wait_side(3, st);                           // previous layer's dWqkv GEMM still reads ws->dqkv
-    CHECK(vlr_attn_bwd(a->qkv, off(a->qkv, H), off(a->qkv, 2 * (size_t)H), 3 * H, a->attn, ws->dattn, H, a->lse, ws->delta,
-                       key_mask, ws->dqkv, off(ws->dqkv, H), off(ws->dqkv, 2 * (size_t)H), 3 * H, batch, S, cfg->heads,
-                       cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));
-    CHECK(vlr_rope(ws->dqkv, pos, cfg->rope_cos, cfg->rope_sin, M, H, cfg->head_dim, 3 * H, cfg->max_pos, 1, st));
+    CHECK(vlr_attn_bwd_gqa(a->qkv, off(a->qkv, Nq), off(a->qkv, (size_t)Nq + Nkv), N, a->attn, ws->dattn, Nq, a->lse, ws->delta,
+                           key_mask, ws->dqkv, off(ws->dqkv, Nq), off(ws->dqkv, (size_t)Nq + Nkv), N, batch, S, cfg->heads, kvh,
+                           cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));
+    // transpose of the rotation on the q and k column blocks ((Nq + Nkv) / head_dim consecutive heads)
+    CHECK(vlr_rope_heads(ws->dqkv, pos, cfg->rope_cos, cfg->rope_sin, M, cfg->heads + kvh, cfg->head_dim, N, cfg->max_pos, 1, st));
     if (two) { sd = fork_side(st); }
-    CHECK(vlr_gemm_bf16(2, ws->dqkv, a->xn1, g->wqkv, nullptr, nullptr, 3 * H, H, M, 3 * H, H, H, 0, 0, accumulate, 0, sd));
+    CHECK(vlr_gemm_bf16(2, ws->dqkv, a->xn1, g->wqkv, nullptr, nullptr, N, H, M, N, H, H, 0, 0, accumulate, 0, sd));
     if (two) side_done(3);
-    CHECK(vlr_gemm_bf16(1, ws->dqkv, w->wqkv, ws->dxn, nullptr, nullptr, M, H, 3 * H, 3 * H, H, H, 0, 0, 0, 0, st));
+    CHECK(vlr_gemm_bf16(1, ws->dqkv, w->wqkv, ws->dxn, nullptr, nullptr, M, H, N, N, H, H, 0, 0, 0, 0, st));
     if (two) { wait_side(0, st); wait_side(1, st); }     // this layer's dWdown / dWgu read dx_out / gu: done before dx_in (the
                                                          // buffer the NEXT layer overwrites dx_out with) is produced
     CHECK(vlr_rmsnorm_bwd(ws->dxn, x_in, w->ln1, a->rstd1, ws->dx_mid, dx_in, g->ln1, accumulate, ws->norm_ws, M, H, st));
@@ -190,6 +195,7 @@ extern "C" int vlr_decoder_layer_fwd_lora(const vlr_llama_cfg* cfg, const vlr_la
                                           const int* pos, const int* key_mask, int batch, int S, vlr_stream_t st) {
     VLR_REQUIRE(cfg && w && lw && a && u && x_in && pos, "vlr_decoder_layer_fwd_lora: null argument");
     CHECK(lora_check("vlr_decoder_layer_fwd_lora", lw, ws_xd));
+    VLR_REQUIRE(cfg->kv_heads == 0 || cfg->kv_heads == cfg->heads, "vlr_decoder_layer_fwd_lora: grouped-query attention is not supported by the LoRA path yet");
     const int H = cfg->hidden, I = cfg->inter, M = batch * S, r = lw->r, ldu = 7 * r;
     const float sc = lw->scale, p = lw->dropout;
 #define XD(seg) (ws_xd ? (void*)off(ws_xd, (size_t)(seg) * M * H) : nullptr)   // segment base in units of M*H elements
@@ -218,6 +224,7 @@ extern "C" int vlr_decoder_layer_bwd_lora(const vlr_llama_cfg* cfg, const vlr_la
                                           int S, vlr_stream_t st) {
     VLR_REQUIRE(cfg && w && lw && lg && a && u && ws && ws_v && x_in && dx_out && dx_in && pos, "vlr_decoder_layer_bwd_lora: null argument");
     CHECK(lora_check("vlr_decoder_layer_bwd_lora", lw, ws_xd));
+    VLR_REQUIRE(cfg->kv_heads == 0 || cfg->kv_heads == cfg->heads, "vlr_decoder_layer_bwd_lora: grouped-query attention is not supported by the LoRA path yet");
     const int H = cfg->hidden, I = cfg->inter, M = batch * S, r = lw->r, ldu = 7 * r;
     const float sc = lw->scale, p = lw->dropout;
 #define XD(seg) (ws_xd ? (void*)off(ws_xd, (size_t)(seg) * M * H) : nullptr)   // segment base in units of M*H elements

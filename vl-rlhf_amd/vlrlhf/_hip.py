@@ -15,7 +15,7 @@ P, I, L, F, U64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint64
 
 class LlamaCfg(C.Structure):
     _fields_ = [("hidden", I), ("inter", I), ("heads", I), ("head_dim", I), ("rms_eps", F), ("max_pos", I),
-                ("rope_cos", P), ("rope_sin", P)]
+                ("rope_cos", P), ("rope_sin", P), ("kv_heads", I)]
 
 
 class LayerWeights(C.Structure):
@@ -65,6 +65,7 @@ _SIGS = {
     "vlr_im2col": [P, P, I, I, I, I, P],
     "vlr_rope_table": [P, P, I, I, F, P],
     "vlr_rope": [P, P, P, P, I, I, I, I, I, I, P],
+    "vlr_rope_heads": [P, P, P, P, I, I, I, I, I, I, P],
     "vlr_swiglu_fwd": [P, P, I, I, P],
     "vlr_swiglu_bwd": [P, P, I, I, P],
     "vlr_gelu_fwd": [P, P, L, P],

@@ -33,6 +33,10 @@ class ParamLayout:
     def __init__(self, cfg):
         H, I, V, D, L = cfg["hidden"], cfg["inter"], cfg["vocab"], cfg["vit_hidden"], cfg["layers"]
         assert H % 8 == 0 and I % 8 == 0 and V % 8 == 0 and D % 8 == 0
+        nh = cfg.get("heads") or 1
+        nkv = cfg.get("kv_heads") or nh                       # grouped-query attention (Mistral, InternLM2)
+        hd = cfg.get("head_dim") or H // nh
+        Nq, Nkv = nh * hd, nkv * hd
         self.entries = []   # (name, shape, [(hf_name, row0, rows)])
         e = self.entries
         lm = "language_model."
@@ -41,11 +45,13 @@ class ParamLayout:
             p = f"{lm}model.layers.{l}."
             e.append((f"l{l}.wdown", (H, I), [(p + "mlp.down_proj.weight", 0, H)]))
             e.append((f"l{l}.wgu", (2 * I, H), [(p + "mlp.gate_proj.weight", 0, I), (p + "mlp.up_proj.weight", I, I)]))
-            e.append((f"l{l}.wo", (H, H), [(p + "self_attn.o_proj.weight", 0, H)]))
-            e.append((f"l{l}.wqkv", (3 * H, H), [(p + "self_attn.q_proj.weight", 0, H), (p + "self_attn.k_proj.weight", H, H),
-                                                 (p + "self_attn.v_proj.weight", 2 * H, H)]))
+            e.append((f"l{l}.wo", (H, Nq), [(p + "self_attn.o_proj.weight", 0, H)]))
+            e.append((f"l{l}.wqkv", (Nq + 2 * Nkv, H), [(p + "self_attn.q_proj.weight", 0, Nq), (p + "self_attn.k_proj.weight", Nq, Nkv),
+                                                        (p + "self_attn.v_proj.weight", Nq + Nkv, Nkv)]))
         e.append(("proj.w2", (H, H), [("multi_modal_projector.linear_2.weight", 0, H)]))
         e.append(("proj.w1", (H, D), [("multi_modal_projector.linear_1.weight", 0, H)]))
+        if cfg.get("image_grid_pinpoints"):                   # LLaVA-Next: the row appended to every line of the un-padded tile grid
+            e.append(("image_newline", (H,), [("image_newline", 0, H)]))
         e.append(("embed", (V, H), [(lm + "model.embed_tokens.weight", 0, V)]))
         self.n_decay_entries = len(e)
         e.append(("norm", (H,), [(lm + "model.norm.weight", 0, H)]))
@@ -198,9 +204,15 @@ class LlavaHipEngine:
         c = self.cfg
         self.H, self.I, self.V, self.L = c["hidden"], c["inter"], c["vocab"], c["layers"]
         self.nh = c["heads"]
-        self.hd = self.H // self.nh
+        self.nkv = c.get("kv_heads") or self.nh
+        self.hd = c.get("head_dim") or self.H // self.nh
         if self.hd != 128:
             raise ValueError(f"decoder head_dim must be 128 for the gfx950 attention kernels, got {self.hd}")
+        if self.nh % self.nkv:
+            raise ValueError(f"heads ({self.nh}) must be a multiple of kv_heads ({self.nkv})")
+        self.Nq, self.Nkv = self.nh * self.hd, self.nkv * self.hd
+        self.Nqkv = self.Nq + 2 * self.Nkv
+        self.anyres = bool(c.get("image_grid_pinpoints"))      # LLaVA-Next tiles
         self.D = c["vit_hidden"]
         self.P = (c["image_size"] // c["patch_size"]) ** 2
         self.layout = ParamLayout(c)
@@ -209,7 +221,7 @@ class LlavaHipEngine:
         self.sin = torch.empty_like(self.cos)
         _hip.call("vlr_rope_table", self.cos, self.sin, max_positions, self.hd, float(c.get("rope_theta", 10000.0)))
         self.llama_cfg = _hip.LlamaCfg(self.H, self.I, self.nh, self.hd, float(c.get("rms_eps", 1e-5)), max_positions,
-                                       self.cos.data_ptr(), self.sin.data_ptr())
+                                       self.cos.data_ptr(), self.sin.data_ptr(), self.nkv)
         self.vit_cfg = _hip.VitCfg(self.D, c["vit_mlp"], c["vit_heads"], self.D // c["vit_heads"],
                                    float(c.get("vit_ln_eps", 1e-5)))
         if self.D // c["vit_heads"] != 64:
@@ -268,6 +280,8 @@ class LlavaHipEngine:
         trainable parameters (gradients, optimizer state, DDP bucket) are the adapters."""
         if r <= 0 or r % 8:
             raise ValueError(f"lora_r must be a positive multiple of 8 for the gfx950 GEMM tiles, got {r}")
+        if self.nkv != self.nh or self.anyres:
+            raise NotImplementedError("LoRA on grouped-query / LLaVA-Next models is not on the MI355X path yet (full fine-tuning is)")
         if not 0.0 <= dropout < 1.0:
             raise ValueError(f"lora_dropout must be in [0, 1), got {dropout}")
         self.lora = dict(r=int(r), scale=float(alpha) / r, dropout=float(dropout), alpha=float(alpha))
@@ -349,7 +363,7 @@ class LlavaHipEngine:
         t = self._ws.get(k)
         if t is None:
             t = dict(xn1=torch.empty(M, H, dtype=BF16, device=self.dev), rstd1=torch.empty(M, dtype=torch.float32, device=self.dev),
-                     qkv=torch.empty(M, 3 * H, dtype=BF16, device=self.dev), attn=torch.empty(M, H, dtype=BF16, device=self.dev),
+                     qkv=torch.empty(M, self.Nqkv, dtype=BF16, device=self.dev), attn=torch.empty(M, self.Nq, dtype=BF16, device=self.dev),
                      lse=torch.empty(Bn, self.nh, Sp, dtype=torch.float32, device=self.dev),
                      x_mid=torch.empty(M, H, dtype=BF16, device=self.dev), xn2=torch.empty(M, H, dtype=BF16, device=self.dev),
                      rstd2=torch.empty(M, dtype=torch.float32, device=self.dev), gu=torch.empty(M, 2 * I, dtype=BF16, device=self.dev),
@@ -359,12 +373,16 @@ class LlavaHipEngine:
         return t
 
     # ------------------------------------------------------------------------------------------------ vision
-    def vision_features(self, pixel_values: torch.Tensor) -> torch.Tensor:
+    def vision_features(self, pixel_values: torch.Tensor, key=None) -> torch.Tensor:
         """CLIP ViT hidden_states[-2] without CLS -> [n*P, D] bf16 (frozen tower: cached per pixel_values tensor so the
-        reference pass and the policy pass share one evaluation)."""
-        key = (pixel_values.data_ptr(), tuple(pixel_values.shape), pixel_values._version)
+        reference pass and the policy pass share one evaluation).  `pixel_values` may be a callable producing the [n,3,s,s]
+        tensor (LLaVA-Next selects the evaluated tiles of a padded 5-D batch) - it is only called on a cache miss."""
+        if key is None:
+            key = (pixel_values.data_ptr(), tuple(pixel_values.shape), pixel_values._version)
         if self._vit_cache is not None and self._vit_cache[0] == key:
             return self._vit_cache[1]
+        if callable(pixel_values):
+            pixel_values = pixel_values()
         c = self.cfg
         n = pixel_values.shape[0]
         g = c["image_size"] // c["patch_size"]
@@ -392,11 +410,11 @@ class LlavaHipEngine:
         self._vit_cache = (key, feat, pixel_values)
         return feat
 
-    def projector_fwd(self, ws: WeightSet, vit_feat, tag):
+    def projector_fwd(self, ws: WeightSet, vit_feat, tag, extra_rows=0):
         R, H, D = vit_feat.shape[0], self.H, self.D
         z = self._buf((tag, "proj_z", R), (R, H))
         h = self._buf((tag, "proj_h", R), (R, H))
-        out = self._buf((tag, "proj_out", R), (R, H))
+        out = self._buf((tag, "proj_out", R, extra_rows), (R + extra_rows, H))    # LLaVA-Next appends the image_newline row
         _hip.call("vlr_gemm_bf16", 0, vit_feat, ws.v["proj.w1"], z, ws.v["proj.b1"], None, R, H, D, D, D, H, 0, 0, 0, 0)
         _hip.call("vlr_gelu_fwd", z, h, z.numel())
         _hip.call("vlr_gemm_bf16", 0, h, ws.v["proj.w2"], out, ws.v["proj.b2"], None, R, H, H, H, H, H, 0, 0, 0, 0)
@@ -404,7 +422,7 @@ class LlavaHipEngine:
 
     # ------------------------------------------------------------------------------------------------ forward
     def forward_hidden(self, ws: WeightSet, input_ids, attention_mask, labels, pixel_values, image_dup=1, save=False,
-                       tag="ref"):
+                       tag="ref", image_sizes=None):
         """embed -> ViT -> projector -> merge -> decoder -> final RMSNorm.  Returns a context dict with the final
         hidden states [Bn*S, H] and the merged labels / mask / positions."""
         c = self.cfg
@@ -420,29 +438,73 @@ class LlavaHipEngine:
             uniq = pixel_values[: n_img // image_dup]
         else:
             uniq = pixel_values
-        vit_feat = self.vision_features(uniq)
-        feats, z, h = self.projector_fwd(ws, vit_feat, tag)
-        n_rows = feats.shape[0]
-        P = self.P
-        n_img_tok = (ids == c["image_token"]).sum(-1)
-        S = int(n_img_tok.max()) * (P - 1) + T                       # one small D2H sync (shape of the merged batch)
-        M = Bn * S
-        src = self._buf((tag, "src", Bn, S), (Bn, S), torch.int32)
-        mask = torch.empty(Bn, S, dtype=torch.int32, device=self.dev)
-        mlabels = torch.empty(Bn, S, dtype=torch.int64, device=self.dev)
-        pos = torch.empty(Bn, S, dtype=torch.int32, device=self.dev)
-        img_map = torch.empty(Bn, S, dtype=torch.uint8, device=self.dev)
-        inv = self._buf((tag, "inv", image_dup, n_rows), (image_dup, n_rows), torch.int32)
-        info = torch.zeros(2, dtype=torch.int32, device=self.dev)
-        _hip.call("vlr_merge_index", ids, am, lab, Bn, T, S, P, int(c["image_token"]),
-                  int(c.get("model_pad_token_id", c["image_token"] + 1)), n_rows, image_dup, src, mask, mlabels, pos,
-                  img_map, inv, info)
-        found = int(info[0])
-        if found != n_rows * image_dup:
-            raise ValueError(
-                f"The input provided to the model are wrong. The number of image tokens is {int(n_img_tok.sum())} while"
-                f" the number of image given to the model is {n_img}. This prevents correct indexing and breaks batch"
-                " generation.")
+        pack = None
+        if self.anyres:
+            # ---- LLaVA-Next (reference LlavaNext/__init__.py:205-265): tiles -> ViT -> projector -> anyres pack (row gather)
+            from .models.LlavaNext import anyres as AR
+            if image_sizes is None:
+                raise ValueError("LLaVA-Next forward needs image_sizes")
+            sizes = [tuple(int(v) for v in sz) for sz in (image_sizes.tolist() if isinstance(image_sizes, torch.Tensor) else image_sizes)]
+            if len(sizes) != n_img:
+                raise ValueError(f"{len(sizes)} image_sizes for {n_img} images")
+            usz = sizes[: n_img // image_dup]
+            npatch = [AR.image_size_to_num_patches(sz, c["image_grid_pinpoints"], c["image_size"]) for sz in usz]
+            if uniq.dim() == 5:
+                if max(npatch) > uniq.shape[1]:
+                    raise ValueError(f"pixel_values holds {uniq.shape[1]} tiles per image, image_sizes need {max(npatch)}")
+                flat = lambda: torch.cat([uniq[i, :k] for i, k in enumerate(npatch)], dim=0)   # noqa: E731
+            elif uniq.dim() == 4:
+                flat = lambda: uniq                                                              # noqa: E731
+            else:
+                raise ValueError(f"pixel_values of shape {tuple(pixel_values.shape)}, expect to be of 4 or 5 dimensions")
+            vit_feat = self.vision_features(flat, key=(pixel_values.data_ptr(), tuple(pixel_values.shape), pixel_values._version, tuple(usz)))
+            n_rows = vit_feat.shape[0]
+            if n_rows != sum(npatch) * self.P:
+                raise ValueError(f"{n_rows // self.P} image tiles given, image_sizes need {sum(npatch)}")
+            ext, z, h = self.projector_fwd(ws, vit_feat, tag, extra_rows=1)
+            ext[n_rows].copy_(ws.v["image_newline"])
+            pidx, lens, nl_pos = AR.pack_index(usz, npatch, c["image_grid_pinpoints"], c["image_size"], c["patch_size"])
+            F = int(pidx.shape[0])
+            pidx_d = torch.from_numpy(pidx).to(self.dev)
+            feats = self._buf((tag, "packed", F), (F, self.H))
+            _hip.call("vlr_gather_rows", ext, pidx_d, feats, F, self.H)
+            mi = AR.merge_index(ids.cpu().numpy(), am.cpu().numpy(), lab.cpu().numpy() if lab is not None else None,
+                                list(lens) * image_dup, int(c["image_token"]), c.get("padding_side", "left"), dup=image_dup)
+            S = mi["S"]
+            M = Bn * S
+            src = torch.from_numpy(mi["src"]).to(self.dev)
+            mask = torch.from_numpy(mi["mask"]).to(self.dev)
+            mlabels = torch.from_numpy(mi["labels"]).to(self.dev)
+            pos = torch.from_numpy(mi["pos"]).to(self.dev)
+            img_map = torch.from_numpy(mi["img_map"]).to(self.dev)
+            inv = torch.from_numpy(mi["inv"]).to(self.dev)
+            pack = dict(idx=pidx_d, nl=torch.from_numpy(nl_pos).to(self.dev), F=F, rows=n_rows, feature_lens=lens)
+            n_feat = F
+        else:
+            vit_feat = self.vision_features(uniq)
+            feats, z, h = self.projector_fwd(ws, vit_feat, tag)
+            n_rows = feats.shape[0]
+            n_feat = n_rows
+            P = self.P
+            n_img_tok = (ids == c["image_token"]).sum(-1)
+            S = int(n_img_tok.max()) * (P - 1) + T                       # one small D2H sync (shape of the merged batch)
+            M = Bn * S
+            src = self._buf((tag, "src", Bn, S), (Bn, S), torch.int32)
+            mask = torch.empty(Bn, S, dtype=torch.int32, device=self.dev)
+            mlabels = torch.empty(Bn, S, dtype=torch.int64, device=self.dev)
+            pos = torch.empty(Bn, S, dtype=torch.int32, device=self.dev)
+            img_map = torch.empty(Bn, S, dtype=torch.uint8, device=self.dev)
+            inv = self._buf((tag, "inv", image_dup, n_rows), (image_dup, n_rows), torch.int32)
+            info = torch.zeros(2, dtype=torch.int32, device=self.dev)
+            _hip.call("vlr_merge_index", ids, am, lab, Bn, T, S, P, int(c["image_token"]),
+                      int(c.get("model_pad_token_id", c["image_token"] + 1)), n_rows, image_dup, src, mask, mlabels, pos,
+                      img_map, inv, info)
+            found = int(info[0])
+            if found != n_rows * image_dup:
+                raise ValueError(
+                    f"The input provided to the model are wrong. The number of image tokens is {int(n_img_tok.sum())} while"
+                    f" the number of image given to the model is {n_img}. This prevents correct indexing and breaks batch"
+                    " generation.")
         x0 = self._buf((tag, "x0", Bn, S), (M, self.H))
         _hip.call("vlr_merge_fwd", src, ids, ws.v["embed"], feats, x0, Bn, T, S, self.H)
         x = x0
@@ -477,8 +539,8 @@ class LlavaHipEngine:
         _hip.call("vlr_rmsnorm_fwd", x, ws.v["norm"], hidden, rstd_f, M, self.H, self.llama_cfg.rms_eps)
         return dict(ws=ws, Bn=Bn, T=T, S=S, M=M, ids=ids, src=src, inv=inv, mask=mask, labels=mlabels, pos=pos,
                     img_map=img_map.bool(), hidden=hidden, rstd_f=rstd_f, x_last=x, x0=x0, acts=acts if save else None,
-                    vit_feat=vit_feat, feats=feats, proj_z=z, proj_h=h, image_dup=image_dup, n_rows=n_rows, tag=tag,
-                    lora_seed=lora_seed)
+                    vit_feat=vit_feat, feats=feats, proj_z=z, proj_h=h, image_dup=image_dup, n_rows=n_rows, n_feat=n_feat,
+                    pack=pack, tag=tag, lora_seed=lora_seed)
 
     # ------------------------------------------------------------------------------------------------ log-probs
     def logps_forward(self, ctx, labels, shared_mask=None, average=False, label_pad=-100):
@@ -578,8 +640,8 @@ class LlavaHipEngine:
             return self._hidden_backward_lora(ctx, dhidden, dxa, dxb)
         _hip.call("vlr_rmsnorm_bwd", dhidden, ctx["x_last"], ws.v["norm"], ctx["rstd_f"], None, dxa, self.gv["norm"], acc,
                   self._norm_ws, M, H)
-        wsb = dict(dact=self._buf(("dact", M), (M, I)), dxn=self._buf(("dxn", M), (M, H)), dattn=self._buf(("dattn", M), (M, H)),
-                   dqkv=self._buf(("dqkv", M), (M, 3 * H)), dx_mid=self._buf(("dx_mid", M), (M, H)),
+        wsb = dict(dact=self._buf(("dact", M), (M, I)), dxn=self._buf(("dxn", M), (M, H)), dattn=self._buf(("dattn", M), (M, self.Nq)),
+                   dqkv=self._buf(("dqkv", M), (M, self.Nqkv)), dx_mid=self._buf(("dx_mid", M), (M, H)),
                    delta=self._buf(("delta", Bn, S), (Bn, self.nh, Sp), torch.float32))
         lws = _hip.LayerBwdWs(wsb["dact"].data_ptr(), wsb["dxn"].data_ptr(), wsb["dattn"].data_ptr(), wsb["dqkv"].data_ptr(),
                               wsb["dx_mid"].data_ptr(), wsb["delta"].data_ptr(), self._norm_ws.data_ptr())
@@ -597,9 +659,25 @@ class LlavaHipEngine:
         # ---- merge + projector
         n_rows, dup = ctx["n_rows"], ctx["image_dup"]
         if not acc:
-            self.gv["embed"].zero_()          # the embedding gradient is scatter-added with atomics
-        dfeats = self._buf(("dfeats", n_rows), (n_rows, H))
-        _hip.call("vlr_merge_bwd", cur, ctx["src"], ctx["inv"], ctx["ids"], dfeats, self.gv["embed"], Bn, ctx["T"], S, H, n_rows, dup)
+            self.gv["embed"].zero_()          # rows of tokens that do not occur keep a zero gradient
+        if ctx["pack"] is None:
+            dfeats = self._buf(("dfeats", n_rows), (n_rows, H))
+            _hip.call("vlr_merge_bwd", cur, ctx["src"], ctx["inv"], ctx["ids"], dfeats, self.gv["embed"], Bn, ctx["T"], S, H, n_rows, dup)
+        else:
+            # LLaVA-Next: gradient of the packed rows, then un-pack: every projector row feeds at most one packed row (tiles the
+            # un-padding dropped get zero), the image_newline row feeds one packed row per grid line -> fixed-order column sum
+            pk = ctx["pack"]
+            F = pk["F"]
+            dpacked = self._buf(("dpacked", F), (F, H))
+            _hip.call("vlr_merge_bwd", cur, ctx["src"], ctx["inv"], ctx["ids"], dpacked, self.gv["embed"], Bn, ctx["T"], S, H, F, dup)
+            dext = self._buf(("dfeats_ext", n_rows), (n_rows + 1, H))
+            dext.zero_()
+            _hip.call("vlr_scatter_rows", dpacked, pk["idx"], dext, F, H)
+            n_nl = int(pk["nl"].shape[0])
+            dnl = self._buf(("dnewline", n_nl), (n_nl, H))
+            _hip.call("vlr_gather_rows", dpacked, pk["nl"], dnl, n_nl, H)
+            _hip.call("vlr_colsum", dnl, n_nl, H, H, self.gv["image_newline"], acc, self._colsum_ws)
+            dfeats = dext[:n_rows]
         D = self.D
         _hip.call("vlr_colsum", dfeats, n_rows, H, H, self.gv["proj.b2"], acc, self._colsum_ws)
         _hip.call("vlr_gemm_bf16", 2, dfeats, ctx["proj_h"], self.gv["proj.w2"], None, None, H, H, n_rows, H, H, H, 0, 0, acc, 0)

@@ -43,9 +43,9 @@ class _HiddenFn(torch.autograd.Function):
     nn.Parameter is a view of it), so this node returns no tensor gradients."""
 
     @staticmethod
-    def forward(ctx, anchor, model, input_ids, attention_mask, labels, pixel_values, dup):
+    def forward(ctx, anchor, model, input_ids, attention_mask, labels, pixel_values, dup, image_sizes=None):
         c = model.engine.forward_hidden(model.weights, input_ids, attention_mask, labels, pixel_values, image_dup=dup,
-                                        save=True, tag="policy")
+                                        save=True, tag="policy", image_sizes=image_sizes)
         ctx.c, ctx.engine = c, model.engine
         model._last_ctx = c
         return c["hidden"]
@@ -54,7 +54,7 @@ class _HiddenFn(torch.autograd.Function):
     def backward(ctx, dhidden):
         ctx.engine.hidden_backward(ctx.c, dhidden.contiguous())
         ctx.c = None
-        return (None,) * 7
+        return (None,) * 8
 
 
 class _LogpsFn(torch.autograd.Function):
@@ -135,7 +135,13 @@ class _Config(dict):
 def _cfg_from_hf(hf: dict) -> dict:
     t, v = hf.get("text_config", {}), hf.get("vision_config", {})
     hidden = t.get("hidden_size", 4096)
+    extra = {}
+    if t.get("num_key_value_heads") and t["num_key_value_heads"] != t.get("num_attention_heads", 32):
+        extra["kv_heads"] = t["num_key_value_heads"]
+    if hf.get("image_grid_pinpoints"):
+        extra["image_grid_pinpoints"] = [list(p) for p in hf["image_grid_pinpoints"]]
     return dict(
+        **extra,
         vit_hidden=v.get("hidden_size", 1024), vit_mlp=v.get("intermediate_size", 4096),
         vit_layers=v.get("num_hidden_layers", 24), vit_heads=v.get("num_attention_heads", 16),
         image_size=v.get("image_size", 336), patch_size=v.get("patch_size", 14), vit_ln_eps=v.get("layer_norm_eps", 1e-5),
@@ -147,13 +153,16 @@ def _cfg_from_hf(hf: dict) -> dict:
 
 
 def _hf_from_cfg(c: dict) -> dict:
-    """config.json (transformers==4.41.0 LlavaConfig layout) for a model that was not loaded from a checkpoint."""
+    """config.json (transformers==4.41.0 LlavaConfig / LlavaNextConfig layout) for a model that was not loaded from a checkpoint."""
+    nxt = bool(c.get("image_grid_pinpoints"))
     return dict(
-        architectures=["LlavaForConditionalGeneration"], model_type="llava", image_token_index=c["image_token"],
+        **({"image_grid_pinpoints": c["image_grid_pinpoints"]} if nxt else {}),
+        architectures=["LlavaNextForConditionalGeneration" if nxt else "LlavaForConditionalGeneration"],
+        model_type="llava_next" if nxt else "llava", image_token_index=c["image_token"],
         pad_token_id=c.get("model_pad_token_id", c["image_token"] + 1), ignore_index=c.get("ignore_index", -100),
         projector_hidden_act="gelu", vision_feature_layer=-2, vision_feature_select_strategy="default",
         vocab_size=c["vocab"], torch_dtype="bfloat16",
-        text_config=dict(model_type="llama", hidden_size=c["hidden"], intermediate_size=c["inter"], num_hidden_layers=c["layers"],
+        text_config=dict(model_type="mistral" if nxt and c.get("kv_heads") else "llama", hidden_size=c["hidden"], intermediate_size=c["inter"], num_hidden_layers=c["layers"],
                          num_attention_heads=c["heads"], num_key_value_heads=c.get("kv_heads", c["heads"]), vocab_size=c["vocab"],
                          rms_norm_eps=c.get("rms_eps", 1e-5), rope_theta=c.get("rope_theta", 10000.0)),
         vision_config=dict(model_type="clip_vision_model", hidden_size=c["vit_hidden"], intermediate_size=c["vit_mlp"],
@@ -379,7 +388,7 @@ class LlavaForRL(nn.Module):
     # ---- forward ----------------------------------------------------------------------------------------
     def forward(self, input_ids=None, pixel_values=None, attention_mask=None, position_ids=None, past_key_values=None,
                 inputs_embeds=None, vision_feature_layer=None, vision_feature_select_strategy=None, labels=None,
-                use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None):
+                use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None, image_sizes=None):
         """reference Llava/__init__.py:111-271 on the training path.  Returns `logits` (lazy), the EXPANDED `labels`
         and `image_position_map`; the reference's internal cross-entropy `loss` (:246-257, unused by DPO) is None."""
         if inputs_embeds is not None or past_key_values is not None or use_cache:
@@ -392,12 +401,15 @@ class LlavaForRL(nn.Module):
             attention_mask = torch.ones_like(input_ids)
         dup = int(getattr(pixel_values, "_vlr_dup", 1))
         grad = torch.is_grad_enabled() and self._trainable and self.training
+        if self.engine.anyres and image_sizes is None:
+            raise ValueError("LLaVA-Next forward needs image_sizes (reference LlavaNext/__init__.py:216-222)")
         if grad:
-            hidden = _HiddenFn.apply(self._anchor, self, input_ids, attention_mask, labels, pixel_values, dup)
+            hidden = _HiddenFn.apply(self._anchor, self, input_ids, attention_mask, labels, pixel_values, dup, image_sizes)
             c = self._last_ctx
         else:
             c = self.engine.forward_hidden(self.weights, input_ids, attention_mask, labels, pixel_values, image_dup=dup,
-                                           save=False, tag="policy_ng" if self.weights is self.engine.policy else "ref")
+                                           save=False, tag="policy_ng" if self.weights is self.engine.policy else "ref",
+                                           image_sizes=image_sizes)
             hidden = c["hidden"]
         out_labels = c["labels"] if labels is not None else torch.full_like(c["mask"], -100, dtype=torch.long)
         return LlavaRLOutputWithPast(loss=None, logits=LazyLogits(self.engine, c, hidden), labels=out_labels,

@@ -11,9 +11,10 @@ MODEL_NICKNAME_MAP = {
     "InternLMXComposer2ForCausalLM": "InternLMXC2",
     "InstructBlipForConditionalGeneration": "InstructBlip",
     "LlavaForRL": "Llava",
+    "LlavaNextForRL": "LlavaNext",
 }
 FLASH_ATTN_MODELS = ["LlavaForConditionalGeneration", "LlavaNextForConditionalGeneration", "LlavaForRL"]
-IMPLEMENTED = ["Llava"]
+IMPLEMENTED = ["Llava", "LlavaNext"]
 
 
 def _architecture(model_name_or_path):
