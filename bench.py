@@ -39,6 +39,24 @@ PROFILE_FILE = "profiles/r02_rocprofv3_kernel_stats_bench.txt"   # rocprofv3 --k
 TFLOP_PER_PAIR = {"ref_in_step": 174.87, "ref_precomputed": 131.24}
 
 
+def tflop_per_pair(cfg, S, tiles_per_image=1, ref_in_step=True):
+    """BASELINE.md section 3 counting rules for any decoder of this family (2 FLOP/MAC, causal attention at half, lm-head on all
+    positions, backward = 2x forward, frozen ViT once per image tile, reference forward 1x when it runs inside the step);
+    reproduces 174.87 / 131.24 for LLaVA-1.5-7B at S = 1599."""
+    H, I, V, L = cfg["hidden"], cfg["inter"], cfg["vocab"], cfg["layers"]
+    nh = cfg["heads"]
+    nkv = cfg.get("kv_heads") or nh
+    hd = H // nh
+    Nq, Nkv = nh * hd, nkv * hd
+    dense = 2 * (L * (H * (Nq + 2 * Nkv) + Nq * H + 3 * H * I) + V * H)
+    attn = L * 4 * Nq * (S + 1) / 2
+    fwd = 2 * S * (dense + attn)
+    D, F, T = cfg["vit_hidden"], cfg["vit_mlp"], (cfg["image_size"] // cfg["patch_size"]) ** 2 + 1
+    vit = (cfg["vit_layers"] - 1) * (2 * T * (4 * D * D + 2 * D * F) + 4 * T * T * D) * tiles_per_image
+    proj = 2 * (T - 1) * (D * H + H * H) * tiles_per_image
+    return ((4 if ref_in_step else 3) * fwd + vit + 3 * proj) / 1e12
+
+
 def cpu_baseline(budget_s=30.0):
     """fp32 oracle on a bounded sample of the configs[0] step (4 pairs, T=256 -> 8 sequences x 831 positions, LLaMA-7B
     widths): every distinct piece of the step is timed once and multiplied by its count in the full step."""
@@ -142,6 +160,9 @@ def main():
     ap.add_argument("--precomputed_ref", action="store_true", help="stream precomputed reference log-probs (SURVEY 8f rank 1)")
     ap.add_argument("--lora", action="store_true", help="variant: LoRA DPO of scripts/ddpo_llava.sh (r=128, alpha=256, dropout 0.05)")
     ap.add_argument("--lora_dropout", type=float, default=0.05)
+    ap.add_argument("--model", default="llava", choices=["llava", "llava_next"],
+                    help="llava_next: variant on BASELINE.json configs[3] (LLaVA-Next-Mistral-7B, anyres 672x672 image, DDPO); not the headline line")
+    ap.add_argument("--loss_type", default=None)
     ap.add_argument("--dry_run_launch", action="store_true", help="CPU test of the self-launch path: no model, gloo, no-op steps")
     ap.add_argument("--lr", type=float, default=2e-8, help="learning rate of the timed steps (kernel arithmetic does not depend on it)")
     a = ap.parse_args()
@@ -163,6 +184,13 @@ def main():
     assert world == max(1, a.gpus), f"--gpus {a.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     cfg = dict(LLAVA_1_5_7B)
+    Trainer = LlavaDPOTrainer
+    nxt = a.model == "llava_next"
+    if nxt:
+        from vlrlhf.models.LlavaNext import LLAVA_NEXT_MISTRAL_7B, LlavaNextDPOTrainer, LlavaNextForRL
+        from vlrlhf.utils.synthetic import synthetic_batch_anyres
+        cfg, LlavaForRL, Trainer = dict(LLAVA_NEXT_MISTRAL_7B), LlavaNextForRL, LlavaNextDPOTrainer
+    loss_type = a.loss_type or ("ddpo" if nxt else "sigmoid")
     if a.layers:
         cfg["layers"] = a.layers
     model = LlavaForRL(cfg)
@@ -171,21 +199,22 @@ def main():
     args = SimpleNamespace(gradient_accumulation_steps=1)
     if a.lora:
         del ref
-        tr = LlavaDPOTrainer(model, None, 0.1, 0, "sigmoid", args, None, -100, 0,
+        tr = Trainer(model, None, 0.1, 0, loss_type, args, None, -100, 0,
                              peft_config=dict(r=128, lora_alpha=256, lora_dropout=a.lora_dropout, target_modules="auto", bias="none", seed=rank))
         for k, t_ in eng.lv.items():             # peft initialises B = 0; random B so the adapter GEMMs do real arithmetic
             if ".b_" in k:
                 t_.normal_(0.0, 1e-3)
     else:
-        tr = LlavaDPOTrainer(model, None if a.precomputed_ref else ref, 0.1, 0, "sigmoid", args, None, -100, 0,
-                             precompute_ref_log_probs=a.precomputed_ref)
+        tr = Trainer(model, None if a.precomputed_ref else ref, 0.1, 0, loss_type, args, None, -100, 0,
+                     precompute_ref_log_probs=a.precomputed_ref)
     eng.init_optimizer()
     reducer = eng.make_reducer() if world > 1 else None
     tr.ref_on_side_stream = not a.no_side_stream
     # four resident batches per rank (seeds 1234 + rank + 1000*i), rotated: inputs are in HBM before the timed region
     batches = []
     for i in range(4):
-        b_ = tr._prepare_inputs(synthetic_batch(a.pairs, a.text_len, cfg["image_token"], 32000, cfg["image_size"], seed=1234 + rank + 1000 * i))
+        mk = synthetic_batch_anyres if nxt else synthetic_batch
+        b_ = tr._prepare_inputs(mk(a.pairs, a.text_len, cfg["image_token"], 32000, cfg["image_size"], seed=1234 + rank + 1000 * i))
         if a.precomputed_ref:
             with torch.no_grad():
                 rc, rr, _, _ = tr.concatenated_forward(ref, b_)
@@ -252,15 +281,20 @@ def main():
     g_n, g_ms, g_flop = prof["gemm256p"]
     all_ms = sum(prof[k][1] for k in ("gemm_nt", "gemm_nn", "gemm_tn"))
     g_bytes = 0.0   # algorithmic elements moved (A + B + C once) summed over the decoder GEMMs of the timed steps
-    H_, I_, M_ = cfg["hidden"], cfg["inter"], 2 * a.pairs * (a.text_len - 1 + 576)
+    S_dec = int(tr.model._last_ctx["S"])            # decoder length of the last policy pass (1599 at configs[1])
+    H_, I_, M_ = cfg["hidden"], cfg["inter"], 2 * a.pairs * S_dec
     per_shape = cfg["layers"] * a.steps * ((1 if a.precomputed_ref else 2) + 2)   # fwd (policy [+ ref]) + dgrad + wgrad
     g_dec = 4 * per_shape
-    for m_, n_, k_ in ((M_, 3 * H_, H_), (M_, H_, H_), (M_, 2 * I_, H_), (M_, H_, I_)):
+    Nqkv_ = eng.Nqkv
+    for m_, n_, k_ in ((M_, Nqkv_, H_), (M_, H_, eng.Nq), (M_, 2 * I_, H_), (M_, H_, I_)):
         g_bytes += per_shape * (m_ * k_ + n_ * k_ + m_ * n_)
     per_kernel = {k: {"launches": n, "ms": round(ms, 2), "tflops": round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else 0.0}
                   for k, (n, ms, fl) in prof.items()}
     pairs_per_s = world * a.pairs * a.steps / dt
     per_pair = TFLOP_PER_PAIR["ref_precomputed" if a.precomputed_ref else "ref_in_step"]
+    if nxt:
+        n_tiles = int(batches[0]["img_input_dict"]["pixel_values"].shape[1])
+        per_pair = tflop_per_pair(cfg, S_dec, n_tiles, not a.precomputed_ref)
     if rank == 0:
         achieved = g_flop / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
         line = {
@@ -289,6 +323,13 @@ def main():
         }
         if a.layers:
             line["INVALID"] = "reduced layer count (debug run)"
+        if nxt:
+            line["metric"] = "preference-pairs/sec (chosen+rejected) LLaVA-Next-Mistral-7B DPO step"
+            line["config"]["workload"] = (f"variant on BASELINE.json configs[3]: LLaVA-Next-Mistral-7B {loss_type.upper()} bf16, anyres 672x672 image "
+                                          f"({n_tiles} tiles -> 2928 image features), max_length {a.text_len}, per-device batch {a.pairs} pairs (S={S_dec}), "
+                                          "full fine-tune of LLM+projector+image_newline, frozen ViT, reference forward inside the step")
+            line["config"]["variant"] = "llava_next (not the headline configuration)"
+            line["config"]["tflop_per_pair"] = round(per_pair, 2)
         if a.lora:
             line["config"]["workload"] = line["config"]["workload"].replace(
                 "full fine-tune of LLM+projector", "LoRA r=128 alpha=256 dropout=0.05 on the 7 decoder linears (scripts/ddpo_llava.sh), frozen base")

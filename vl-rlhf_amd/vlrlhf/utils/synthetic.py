@@ -162,3 +162,16 @@ def synthetic_batch(pairs, text_len, image_token, vocab_hi, image_size, seed, ra
     batch = VLDPODataCollatorWithPadding()(rows)
     batch["img_input_dict"] = dict(pixel_values=synthetic_pixels(pairs, image_size, seed + 7))
     return batch
+
+
+def synthetic_batch_anyres(pairs, text_len, image_token, vocab_hi, image_size, seed, image_hw=(672, 672), grid_pinpoints=None,
+                           ragged=False, prompt_frac=0.5):
+    """LLaVA-Next variant of synthetic_batch: the same token recipe, every image of original size `image_hw` (height, width) given
+    as its anyres tiles [pairs, tiles, 3, s, s] + image_sizes [pairs, 2] (672x672 -> base + 2x2 tiles = 5, 2928 features)."""
+    from ..models.LlavaNext import LLAVA_NEXT_MISTRAL_7B, anyres
+    batch = synthetic_batch(pairs, text_len, image_token, vocab_hi, image_size, seed, ragged=ragged, prompt_frac=prompt_frac)
+    pins = grid_pinpoints or LLAVA_NEXT_MISTRAL_7B["image_grid_pinpoints"]
+    n = anyres.image_size_to_num_patches(image_hw, pins, image_size)
+    tiles = torch.stack([synthetic_pixels(n, image_size, seed + 11 + i) for i in range(pairs)])
+    batch["img_input_dict"] = dict(pixel_values=tiles, image_sizes=torch.tensor([list(image_hw)] * pairs, dtype=torch.long))
+    return batch
