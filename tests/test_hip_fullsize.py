@@ -107,7 +107,8 @@ def test_llava_next_mistral_7b_full_size_properties():
     loss = tr.training_step(model, batch)
     torch.cuda.synchronize()
     c = model._last_ctx
-    assert c["S"] == 255 + 2928 and c["pack"]["feature_lens"].tolist() == [2928, 2928]
+    longest = int(max(batch["chosen_attention_mask"].sum(-1).max(), batch["rejected_attention_mask"].sum(-1).max()))
+    assert c["S"] == longest - 1 + 2928 and c["pack"]["feature_lens"].tolist() == [2928, 2928]
     assert abs(float(loss) - math.log(2.0)) < 1e-6, float(loss)
     model.engine.optimizer_step(1e-6, 0.9, 0.98, 1e-6, 0.0, 1.0)
     norm = model.engine.grad_norm()
