@@ -416,6 +416,13 @@ static int gemm_impl(int layout, const void* A, const void* B, void* C, const vo
         vlr_prof_end(pi, stream);
         return vlr_check_launch("vlr_gemm_bf16(split-K)");
     }
+    // ---- tall-and-skinny forward / dgrad products (LoRA: u = x A^T and v = dy B with r = 128 output columns): [12792 x 128] is
+    // 100 tiles of 128x128 - 39 % of the CUs - each with the full reduction; split along K they fill the chip
+    // (profiles/r02_steady_state_kernel_breakdown_lora_before.txt: 85 ms/step in 1185 such launches)
+    if (layout != 2 && N <= 512 && M >= 2048 && ((M + BM - 1) / BM) * ((N + BN - 1) / BN) < 200 && launch_splitk128(layout, p, stream, 2048)) {
+        vlr_prof_end(pi, stream);
+        return vlr_check_launch("vlr_gemm_bf16(skinny split-K)");
+    }
     // ---- wave quantisation: a 256x256-tile grid of T tiles runs ceil(T/256) rounds on the 256 CUs; when the last round is
     // nearly empty (e.g. 12792 x 4096 -> 800 tiles = 3.125 rounds) the last tile-rows are peeled off and run as 128x128
     // tiles (2 workgroups per CU) so the big-tile part is a whole number of rounds.  VLR_GEMM_SPLIT=0 disables.

@@ -292,14 +292,20 @@ class VLDPOTrainer:
         frozen vision tower is evaluated once per distinct image (results identical), and the result is memoised on
         the batch so the policy pass and the reference pass share the same device tensors."""
         cache = batch.get("_vlr_concat") if isinstance(batch, dict) else None
-        if cache is not None:
-            return dict(cache)
+        src_ids = tuple(id(batch.get(k)) for k in ("chosen_input_ids", "rejected_input_ids", "chosen_labels", "rejected_labels",
+                                                    "chosen_attention_mask", "rejected_attention_mask", "img_input_dict"))
+        if cache is not None and cache.get("_vlr_src") == src_ids:     # a dict(batch) copy with replaced tensors must not hit
+            return {k: v for k, v in cache.items() if k != "_vlr_src"}
         out = {}
         n = max(batch["chosen_input_ids"].shape[1], batch["rejected_input_ids"].shape[1])
         for field, pad in (("input_ids", padding_value), ("attention_mask", 0), ("labels", label_pad_token_id)):
             parts = [pad_to_length(batch[f"{s}_{field}"], n, pad) for s in ("chosen", "rejected")]
             t = torch.cat(parts, dim=0)
             out[f"concatenated_{field}"] = t.to(device) if device is not None else t
+        # integer facts about THIS batch that every pass over it needs on the host (merged length, lm-head row count, DDPO
+        # mask ...): the first pass computes them (one D2H each), later passes - the policy pass after the reference pass, the
+        # next visit of a resident batch - read them here instead of stalling the device again
+        out["concatenated_input_ids"]._vlr_meta = {}
         if "img_input_dict" in batch:
             d = {}
             for k, v in batch["img_input_dict"].items():
@@ -314,7 +320,7 @@ class VLDPOTrainer:
                     raise ValueError(f"Unsupported type {type(v)} for concatenation.")
             out["concatenated_img_input_dict"] = d
         if isinstance(batch, dict):
-            batch["_vlr_concat"] = dict(out)
+            batch["_vlr_concat"] = dict(out, _vlr_src=src_ids)
         return out
 
     @staticmethod
@@ -329,7 +335,12 @@ class VLDPOTrainer:
         shared = None
         if mask_shared_tokens:
             assert labels.shape[0] % 2 == 0
-            shared = ddpo_shared_mask(labels, label_pad_token_id, min_match_size=3)
+            meta = getattr(labels, "_vlr_meta", None)
+            shared = meta.get("ddpo_mask") if meta is not None else None
+            if shared is None:
+                shared = ddpo_shared_mask(labels, label_pad_token_id, min_match_size=3)
+                if meta is not None:
+                    meta["ddpo_mask"] = shared.to(labels.device) if labels.is_cuda else shared
         if hasattr(logits, "batch_logps"):
             return logits.batch_logps(labels, shared, average_log_prob, label_pad_token_id)
         if not logits.is_cuda:

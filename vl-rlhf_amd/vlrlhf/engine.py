@@ -429,6 +429,7 @@ class LlavaHipEngine:
         if ws is self.policy:
             self.wait_optimizer()
         Bn, T = input_ids.shape
+        meta = getattr(input_ids, "_vlr_meta", None)      # per-batch cache of host-side integers (None: always recompute)
         ids = input_ids.to(self.dev).contiguous()
         am = attention_mask.to(self.dev).contiguous()
         lab = labels.to(self.dev).contiguous() if labels is not None else None
@@ -463,22 +464,25 @@ class LlavaHipEngine:
                 raise ValueError(f"{n_rows // self.P} image tiles given, image_sizes need {sum(npatch)}")
             ext, z, h = self.projector_fwd(ws, vit_feat, tag, extra_rows=1)
             ext[n_rows].copy_(ws.v["image_newline"])
-            pidx, lens, nl_pos = AR.pack_index(usz, npatch, c["image_grid_pinpoints"], c["image_size"], c["patch_size"])
-            F = int(pidx.shape[0])
-            pidx_d = torch.from_numpy(pidx).to(self.dev)
+            cached = meta.get("anyres") if meta is not None else None
+            if cached is None:
+                pidx, lens, nl_pos = AR.pack_index(usz, npatch, c["image_grid_pinpoints"], c["image_size"], c["patch_size"])
+                mi = AR.merge_index(ids.cpu().numpy(), am.cpu().numpy(), lab.cpu().numpy() if lab is not None else None,
+                                    list(lens) * image_dup, int(c["image_token"]), c.get("padding_side", "left"), dup=image_dup)
+                dv = lambda a_: torch.from_numpy(a_).to(self.dev)    # noqa: E731
+                cached = dict(S=mi["S"], src=dv(mi["src"]), mask=dv(mi["mask"]), labels=dv(mi["labels"]), pos=dv(mi["pos"]),
+                              img_map=dv(mi["img_map"]), inv=dv(mi["inv"]),
+                              pack=dict(idx=dv(pidx), nl=dv(nl_pos), F=int(pidx.shape[0]), rows=n_rows, feature_lens=lens))
+                if meta is not None:
+                    meta["anyres"] = cached
+            pack = cached["pack"]
+            F = pack["F"]
             feats = self._buf((tag, "packed", F), (F, self.H))
-            _hip.call("vlr_gather_rows", ext, pidx_d, feats, F, self.H)
-            mi = AR.merge_index(ids.cpu().numpy(), am.cpu().numpy(), lab.cpu().numpy() if lab is not None else None,
-                                list(lens) * image_dup, int(c["image_token"]), c.get("padding_side", "left"), dup=image_dup)
-            S = mi["S"]
+            _hip.call("vlr_gather_rows", ext, pack["idx"], feats, F, self.H)
+            S = cached["S"]
             M = Bn * S
-            src = torch.from_numpy(mi["src"]).to(self.dev)
-            mask = torch.from_numpy(mi["mask"]).to(self.dev)
-            mlabels = torch.from_numpy(mi["labels"]).to(self.dev)
-            pos = torch.from_numpy(mi["pos"]).to(self.dev)
-            img_map = torch.from_numpy(mi["img_map"]).to(self.dev)
-            inv = torch.from_numpy(mi["inv"]).to(self.dev)
-            pack = dict(idx=pidx_d, nl=torch.from_numpy(nl_pos).to(self.dev), F=F, rows=n_rows, feature_lens=lens)
+            src, mask, pos, img_map, inv = cached["src"], cached["mask"], cached["pos"], cached["img_map"], cached["inv"]
+            mlabels = cached["labels"].clone()                 # handed out as `output.labels`: every pass gets its own tensor
             n_feat = F
         else:
             vit_feat = self.vision_features(uniq)
@@ -487,7 +491,10 @@ class LlavaHipEngine:
             n_feat = n_rows
             P = self.P
             n_img_tok = (ids == c["image_token"]).sum(-1)
-            S = int(n_img_tok.max()) * (P - 1) + T                       # one small D2H sync (shape of the merged batch)
+            if meta is not None and "S" in meta:
+                S = meta["S"]
+            else:
+                S = int(n_img_tok.max()) * (P - 1) + T                   # one small D2H sync (shape of the merged batch)
             M = Bn * S
             src = self._buf((tag, "src", Bn, S), (Bn, S), torch.int32)
             mask = torch.empty(Bn, S, dtype=torch.int32, device=self.dev)
@@ -499,7 +506,9 @@ class LlavaHipEngine:
             _hip.call("vlr_merge_index", ids, am, lab, Bn, T, S, P, int(c["image_token"]),
                       int(c.get("model_pad_token_id", c["image_token"] + 1)), n_rows, image_dup, src, mask, mlabels, pos,
                       img_map, inv, info)
-            found = int(info[0])
+            found = n_rows * image_dup if (meta is not None and meta.get("merge_ok")) else int(info[0])   # checked once per batch
+            if meta is not None:
+                meta["S"], meta["merge_ok"] = S, found == n_rows * image_dup
             if found != n_rows * image_dup:
                 raise ValueError(
                     f"The input provided to the model are wrong. The number of image tokens is {int(n_img_tok.sum())} while"
@@ -540,7 +549,7 @@ class LlavaHipEngine:
         return dict(ws=ws, Bn=Bn, T=T, S=S, M=M, ids=ids, src=src, inv=inv, mask=mask, labels=mlabels, pos=pos,
                     img_map=img_map.bool(), hidden=hidden, rstd_f=rstd_f, x_last=x, x0=x0, acts=acts if save else None,
                     vit_feat=vit_feat, feats=feats, proj_z=z, proj_h=h, image_dup=image_dup, n_rows=n_rows, n_feat=n_feat,
-                    pack=pack, tag=tag, lora_seed=lora_seed)
+                    pack=pack, tag=tag, lora_seed=lora_seed, meta=meta)
 
     # ------------------------------------------------------------------------------------------------ log-probs
     def logps_forward(self, ctx, labels, shared_mask=None, average=False, label_pad=-100):
@@ -556,7 +565,13 @@ class LlavaHipEngine:
         seq_off = torch.empty(Bn + 1, dtype=torch.int32, device=self.dev)
         sm = shared_mask.to(device=self.dev, dtype=torch.uint8).contiguous() if shared_mask is not None else None
         _hip.call("vlr_build_rows", lab, sm, Bn, S, label_pad, rows, tgt, seq_off)
-        R = int(seq_off[-1])                                          # one small D2H sync (row count of the lm-head GEMM)
+        meta, rkey = ctx.get("meta"), ("R", sm is not None, int(label_pad))
+        if meta is not None and rkey in meta:
+            R = meta[rkey]
+        else:
+            R = int(seq_off[-1])                                      # one small D2H sync (row count of the lm-head GEMM)
+            if meta is not None:
+                meta[rkey] = R
         logps = torch.zeros(Bn, dtype=torch.float32, device=self.dev)
         lp = dict(R=R, rows=rows, tgt=tgt, seq_off=seq_off, average=average, ctx=ctx)
         if R == 0:

@@ -412,6 +412,8 @@ class LlavaForRL(nn.Module):
                                            image_sizes=image_sizes)
             hidden = c["hidden"]
         out_labels = c["labels"] if labels is not None else torch.full_like(c["mask"], -100, dtype=torch.long)
+        if c.get("meta") is not None:
+            out_labels._vlr_meta = c["meta"]          # per-batch host-side facts (trainer.concatenated_inputs)
         return LlavaRLOutputWithPast(loss=None, logits=LazyLogits(self.engine, c, hidden), labels=out_labels,
                                      image_position_map=c["img_map"])
 
