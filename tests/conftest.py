@@ -18,3 +18,19 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _release_gpu_memory_between_modules():
+    """the full-size modules hold 150-280 GB each (7B weights + optimizer state + activations): collect reference cycles
+    (nn.Module <-> engine <-> autograd context) and return the blocks to the driver before the next module allocates"""
+    yield
+    import gc
+    gc.collect()
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+    except Exception:
+        pass

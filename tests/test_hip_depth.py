@@ -100,6 +100,8 @@ def test_depth2_true_widths_vs_fp32_oracle():
     got, probe = _run_case(cfg, model, ref, tr, g)
     _compare(got, probe, g, "L2 small")
     del model, ref, tr
+    import gc
+    gc.collect()
     torch.cuda.empty_cache()
 
 
@@ -110,6 +112,8 @@ def full32():
     cfg, model, ref, tr = _build(32)
     yield cfg, model, ref, tr
     del model, ref, tr
+    import gc
+    gc.collect()
     torch.cuda.empty_cache()
 
 

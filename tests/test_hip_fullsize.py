@@ -25,6 +25,8 @@ def full():
     batch = tr._prepare_inputs(synthetic_batch(4, 1024, cfg["image_token"], 32000, cfg["image_size"], seed=7, ragged=True))
     yield model, ref, tr, batch, cfg
     del model, ref, tr
+    import gc
+    gc.collect()
     torch.cuda.empty_cache()
 
 
