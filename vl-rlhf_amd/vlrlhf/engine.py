@@ -410,6 +410,35 @@ class LlavaHipEngine:
         self._vit_cache = (key, feat, pixel_values)
         return feat
 
+    def anyres_vision_features(self, pixel_values, image_sizes, image_dup=1):
+        """LLaVA-Next: the first num_patches(image_size) tiles of every DISTINCT image through the frozen ViT (cached like
+        vision_features).  -> (features [tiles*P, D], sizes of the distinct images, tiles per image)"""
+        from .models.LlavaNext import anyres as AR
+        c = self.cfg
+        if image_sizes is None:
+            raise ValueError("LLaVA-Next forward needs image_sizes")
+        n_img = pixel_values.shape[0]
+        if n_img % image_dup:
+            raise ValueError(f"{n_img} images cannot be {image_dup} identical halves")
+        sizes = [tuple(int(v) for v in sz) for sz in (image_sizes.tolist() if isinstance(image_sizes, torch.Tensor) else image_sizes)]
+        if len(sizes) != n_img:
+            raise ValueError(f"{len(sizes)} image_sizes for {n_img} images")
+        uniq = pixel_values[: n_img // image_dup]
+        usz = sizes[: n_img // image_dup]
+        npatch = [AR.image_size_to_num_patches(sz, c["image_grid_pinpoints"], c["image_size"]) for sz in usz]
+        if uniq.dim() == 5:
+            if max(npatch) > uniq.shape[1]:
+                raise ValueError(f"pixel_values holds {uniq.shape[1]} tiles per image, image_sizes need {max(npatch)}")
+            flat = lambda: torch.cat([uniq[i, :k] for i, k in enumerate(npatch)], dim=0)   # noqa: E731
+        elif uniq.dim() == 4:
+            flat = lambda: uniq                                                              # noqa: E731
+        else:
+            raise ValueError(f"pixel_values of shape {tuple(pixel_values.shape)}, expect to be of 4 or 5 dimensions")
+        vit_feat = self.vision_features(flat, key=(pixel_values.data_ptr(), tuple(pixel_values.shape), pixel_values._version, tuple(usz)))
+        if vit_feat.shape[0] != sum(npatch) * self.P:
+            raise ValueError(f"{vit_feat.shape[0] // self.P} image tiles given, image_sizes need {sum(npatch)}")
+        return vit_feat, usz, npatch
+
     def projector_fwd(self, ws: WeightSet, vit_feat, tag, extra_rows=0):
         R, H, D = vit_feat.shape[0], self.H, self.D
         z = self._buf((tag, "proj_z", R), (R, H))
@@ -443,25 +472,8 @@ class LlavaHipEngine:
         if self.anyres:
             # ---- LLaVA-Next (reference LlavaNext/__init__.py:205-265): tiles -> ViT -> projector -> anyres pack (row gather)
             from .models.LlavaNext import anyres as AR
-            if image_sizes is None:
-                raise ValueError("LLaVA-Next forward needs image_sizes")
-            sizes = [tuple(int(v) for v in sz) for sz in (image_sizes.tolist() if isinstance(image_sizes, torch.Tensor) else image_sizes)]
-            if len(sizes) != n_img:
-                raise ValueError(f"{len(sizes)} image_sizes for {n_img} images")
-            usz = sizes[: n_img // image_dup]
-            npatch = [AR.image_size_to_num_patches(sz, c["image_grid_pinpoints"], c["image_size"]) for sz in usz]
-            if uniq.dim() == 5:
-                if max(npatch) > uniq.shape[1]:
-                    raise ValueError(f"pixel_values holds {uniq.shape[1]} tiles per image, image_sizes need {max(npatch)}")
-                flat = lambda: torch.cat([uniq[i, :k] for i, k in enumerate(npatch)], dim=0)   # noqa: E731
-            elif uniq.dim() == 4:
-                flat = lambda: uniq                                                              # noqa: E731
-            else:
-                raise ValueError(f"pixel_values of shape {tuple(pixel_values.shape)}, expect to be of 4 or 5 dimensions")
-            vit_feat = self.vision_features(flat, key=(pixel_values.data_ptr(), tuple(pixel_values.shape), pixel_values._version, tuple(usz)))
+            vit_feat, usz, npatch = self.anyres_vision_features(pixel_values, image_sizes, image_dup)
             n_rows = vit_feat.shape[0]
-            if n_rows != sum(npatch) * self.P:
-                raise ValueError(f"{n_rows // self.P} image tiles given, image_sizes need {sum(npatch)}")
             ext, z, h = self.projector_fwd(ws, vit_feat, tag, extra_rows=1)
             ext[n_rows].copy_(ws.v["image_newline"])
             cached = meta.get("anyres") if meta is not None else None

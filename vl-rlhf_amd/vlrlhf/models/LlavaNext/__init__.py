@@ -57,8 +57,11 @@ class LlavaNextForRL(LlavaForRL):
         return ref
 
     def prefetch_vision(self, img_input_dict):
-        """nothing to do ahead of time: the tile selection depends on image_sizes and the ViT result is cached by the first pass"""
-        return None
+        """run the frozen tower on the CALLER's stream before the reference pass is forked onto its side stream: both passes then
+        read the cached features (computing them inside the side-stream pass would let the policy pass read them unordered)"""
+        pv, sizes = img_input_dict.get("pixel_values"), img_input_dict.get("image_sizes")
+        if pv is not None and sizes is not None:
+            self.engine.anyres_vision_features(pv, sizes, int(getattr(pv, "_vlr_dup", 1)))
 
     @staticmethod
     def _merge_input_ids_with_image_features(image_features, feature_lens, inputs_embeds, input_ids, attention_mask, position_ids=None,
