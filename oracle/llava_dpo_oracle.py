@@ -303,7 +303,10 @@ def random_lora(cfg, r, alpha, seed=0, b_std=0.0, dropout=0.0):
     """peft init: A ~ U(-1/sqrt(in), 1/sqrt(in)) (kaiming_uniform a=sqrt(5)), B = 0 (b_std > 0: N(0, b_std) for tests)."""
     g = torch.Generator().manual_seed(seed)
     H, I = cfg["hidden"], cfg["inter"]
-    dims = dict(q_proj=(H, H), k_proj=(H, H), v_proj=(H, H), o_proj=(H, H), gate_proj=(I, H), up_proj=(I, H), down_proj=(H, I))
+    nh = cfg["heads"]
+    hd = cfg.get("head_dim", H // nh)
+    Nq, Nkv = nh * hd, cfg.get("kv_heads", nh) * hd
+    dims = dict(q_proj=(Nq, H), k_proj=(Nkv, H), v_proj=(Nkv, H), o_proj=(H, Nq), gate_proj=(I, H), up_proj=(I, H), down_proj=(H, I))
     Wl = {}
     for l in range(cfg["layers"]):
         for t in LORA_TARGETS:
@@ -586,7 +589,7 @@ def llavanext_merge(image_features, feature_lens, inputs_embeds, input_ids, atte
 
 
 def llavanext_forward(W, cfg, input_ids, attention_mask, labels, pixel_values, image_sizes, emulate_bf16=False,
-                      dedupe_images=True, collect=None):
+                      dedupe_images=True, collect=None, lora=None):
     """LlavaNextForRL.forward on the training path (LlavaNext/__init__.py:205-265, 306-316): embeddings with `<image>` ids
     mapped to 0 (:209-211), ViT on the first num_patches tiles of every image, projector, pack, merge, Mistral decoder
     (grouped-query attention: cfg['kv_heads']).  pixel_values [n_img, max_patches, 3, s, s], image_sizes [n_img, 2]."""
@@ -606,7 +609,7 @@ def llavanext_forward(W, cfg, input_ids, attention_mask, labels, pixel_values, i
         packed, lens = torch.cat([packed, packed], 0), torch.cat([lens, lens], 0)
     merged, mask, pos, mlabels, img_map = llavanext_merge(packed, lens, emb, input_ids, attention_mask, labels, cfg["image_token"],
                                                           cfg.get("padding_side", "left"))
-    hidden = llama_hidden(merged, mask, pos, W, cfg, emulate_bf16, collect=collect)
+    hidden = llama_hidden(merged, mask, pos, W, cfg, emulate_bf16, collect=collect, lora=lora)
     aux = dict(vit_feat=feat, projected=img, packed=packed, feature_lens=lens, merged=merged, mask=mask, pos=pos, img_map=img_map,
                hidden=hidden, num_patches=npatch)
     return lm_logits(hidden, W, emulate_bf16), mlabels, aux
@@ -619,7 +622,7 @@ def concatenated_forward(W, cfg, batch, loss_type="sigmoid", emulate_bf16=False,
     if cfg.get("image_grid_pinpoints"):      # LLaVA-Next
         logits, labels, _ = llavanext_forward(W, cfg, cb["concatenated_input_ids"], cb["concatenated_attention_mask"],
                                               cb["concatenated_labels"], cb["concatenated_img_input_dict"]["pixel_values"],
-                                              cb["concatenated_img_input_dict"]["image_sizes"], emulate_bf16, collect=collect)
+                                              cb["concatenated_img_input_dict"]["image_sizes"], emulate_bf16, collect=collect, lora=lora)
     else:
         logits, labels, _ = llava_forward(W, cfg, cb["concatenated_input_ids"], cb["concatenated_attention_mask"],
                                           cb["concatenated_labels"], cb["concatenated_img_input_dict"]["pixel_values"],

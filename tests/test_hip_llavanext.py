@@ -120,3 +120,32 @@ def test_llavanext_save_and_reload(tmp_path):
     m2 = MyAutoModel.from_pretrained(str(tmp_path))
     assert isinstance(m2, LlavaNextForRL) and m2.engine.nkv == 1 and m2.engine.anyres
     assert torch.equal(m2.engine.policy.flat, model.engine.policy.flat)
+
+
+def test_llavanext_lora_step_matches_oracle():
+    """what the reference's LLaVA-Next script actually runs (scripts/dpo_llavanext.sh: --use_lora True): adapters on the seven
+    decoder linears of a grouped-query decoder (k/v adapters are narrower than q), frozen base, reference = adapters disabled."""
+    from vlrlhf.models.LlavaNext import LlavaNextDPOTrainer, LlavaNextForRL
+    z, cfg, W, W_ref, batch, rows = load_case("llavanext_small")
+    lora = O.random_lora(cfg, r=8, alpha=16, seed=3, b_std=0.05)
+    lora["W"] = {k: v.bfloat16().float() for k, v in lora["W"].items()}
+    model = LlavaNextForRL.from_state_dict(cfg, W)
+    tr = LlavaNextDPOTrainer(model, None, cfg["beta"], 0, "sigmoid", SimpleNamespace(gradient_accumulation_steps=1), None, -100, 0,
+                             peft_config=dict(r=8, lora_alpha=16, lora_dropout=0.0, target_modules="auto", bias="none", seed=5))
+    assert tr.ref_model is None and tr.is_peft_model
+    eng = model.engine
+    eng.load_lora_state_dict(lora["W"])
+    assert tuple(eng.lv["l0.b_qkv"].shape) == (256 + 2 * 128, 8)
+    eng.init_optimizer()
+    loss = tr.training_step(model, batch)
+    torch.cuda.synchronize()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in lora["W"].items()}
+    l2 = dict(lora, W=leaves)
+    l16, m16 = O.compute_loss(W, W, cfg, batch, cfg["beta"], emulate_bf16=True, lora=l2)
+    l16.backward()
+    assert abs(float(loss) - float(l16)) < TOL_LOSS_BF16 + 2.5e-3, (float(loss), float(l16))
+    named = dict(model.named_parameters())
+    for k, v in leaves.items():
+        hip = named[k.replace(".weight", ".default.weight")].grad
+        assert tuple(hip.shape) == tuple(v.grad.shape), k
+        assert cosine(hip, v.grad) > 0.97, (k, cosine(hip, v.grad))

@@ -137,8 +137,11 @@ extern "C" int vlr_decoder_layer_bwd(const vlr_llama_cfg* cfg, const vlr_layer_w
 // u = dropout_t(x) A_t^T is kept for the backward ([M][7r] per layer: qkv | o | gate,up | down).
 // Dropout target t of a layer uses seed + t (t = 0..6 in q,k,v,o,gate,up,down order).
 // ---------------------------------------------------------------------------------------------------------------------
-static int lora_group_fwd(int n, int r, int in, int out, const void* x, void* y, int ldy, const void* A, const void* B, void* u,
+// outs[t]: output features of sub-target t (they differ under grouped-query attention: q has heads*hd, k and v kv_heads*hd)
+static int lora_group_fwd(int n, int r, int in, const int* outs, const void* x, void* y, int ldy, const void* A, const void* B, void* u,
                           int ldu, float scale, float p, uint64_t seed, void* ws_xd, int M, hipStream_t st) {
+    size_t ofs[4] = {0, 0, 0, 0};
+    for (int t = 0; t < n; ++t) ofs[t + 1] = ofs[t] + (size_t)outs[t];
     if (p > 0.f) {
         for (int t = 0; t < n; ++t) {
             void* xd_t = off(ws_xd, (size_t)t * M * in);          // kept for the backward (dA_t = s v_t^T drop_t(x))
@@ -149,21 +152,24 @@ static int lora_group_fwd(int n, int r, int in, int out, const void* x, void* y,
         CHECK(vlr_gemm_bf16(0, x, A, u, nullptr, nullptr, M, n * r, in, in, in, ldu, 0, 0, 0, 0, st));
     }
     for (int t = 0; t < n; ++t)
-        CHECK(vlr_gemm_bf16_scaled(0, off(u, (size_t)t * r), off(B, (size_t)t * out * r), off(y, (size_t)t * out), nullptr, nullptr, M, out, r,
+        CHECK(vlr_gemm_bf16_scaled(0, off(u, (size_t)t * r), off(B, ofs[t] * r), off(y, ofs[t]), nullptr, nullptr, M, outs[t], r,
                                    ldu, r, ldy, 0, 0, 1, 0, scale, st));
     return VLR_OK;
 }
 
 // dx [M][in] already holds dy W; adds the adapter path and writes the adapter gradients
-static int lora_group_bwd(int n, int r, int in, int out, const void* x, const void* dy, int lddy, const void* A, const void* B,
+static int lora_group_bwd(int n, int r, int in, const int* outs, const void* x, const void* dy, int lddy, const void* A, const void* B,
                           void* dA, void* dB, const void* u, int ldu, void* v, void* dx, float scale, float p, uint64_t seed,
                           void* ws_xd, int accumulate, int M, hipStream_t st) {
     const int nr = n * r;
+    size_t ofs[4] = {0, 0, 0, 0};
+    for (int t = 0; t < n; ++t) ofs[t + 1] = ofs[t] + (size_t)outs[t];
     for (int t = 0; t < n; ++t) {
-        const void* dyt = off(dy, (size_t)t * out);
-        CHECK(vlr_gemm_bf16_scaled(2, dyt, off(u, (size_t)t * r), off(dB, (size_t)t * out * r), nullptr, nullptr, out, r, M, lddy, ldu, r,
+        const void* dyt = off(dy, ofs[t]);
+        const int out = outs[t];
+        CHECK(vlr_gemm_bf16_scaled(2, dyt, off(u, (size_t)t * r), off(dB, ofs[t] * r), nullptr, nullptr, out, r, M, lddy, ldu, r,
                                    0, 0, accumulate, 0, scale, st));                                                // dB_t = s dy_t^T u_t
-        CHECK(vlr_gemm_bf16(1, dyt, off(B, (size_t)t * out * r), off(v, (size_t)t * r), nullptr, nullptr, M, r, out, lddy, r, nr,
+        CHECK(vlr_gemm_bf16(1, dyt, off(B, ofs[t] * r), off(v, (size_t)t * r), nullptr, nullptr, M, r, out, lddy, r, nr,
                             0, 0, 0, 0, st));                                                                       // v_t = dy_t B_t
     }
     if (p > 0.f) {
@@ -195,25 +201,27 @@ extern "C" int vlr_decoder_layer_fwd_lora(const vlr_llama_cfg* cfg, const vlr_la
                                           const int* pos, const int* key_mask, int batch, int S, vlr_stream_t st) {
     VLR_REQUIRE(cfg && w && lw && a && u && x_in && pos, "vlr_decoder_layer_fwd_lora: null argument");
     CHECK(lora_check("vlr_decoder_layer_fwd_lora", lw, ws_xd));
-    VLR_REQUIRE(cfg->kv_heads == 0 || cfg->kv_heads == cfg->heads, "vlr_decoder_layer_fwd_lora: grouped-query attention is not supported by the LoRA path yet");
     const int H = cfg->hidden, I = cfg->inter, M = batch * S, r = lw->r, ldu = 7 * r;
+    const int kvh = cfg->kv_heads > 0 ? cfg->kv_heads : cfg->heads;
+    const int Nq = cfg->heads * cfg->head_dim, Nkv = kvh * cfg->head_dim, N = Nq + 2 * Nkv;
+    VLR_REQUIRE(Nq == H, "vlr_decoder_layer_fwd_lora: heads*head_dim != hidden");
+    const int o_qkv[3] = {Nq, Nkv, Nkv}, o_h[1] = {H}, o_gu[2] = {I, I};
     const float sc = lw->scale, p = lw->dropout;
 #define XD(seg) (ws_xd ? (void*)off(ws_xd, (size_t)(seg) * M * H) : nullptr)   // segment base in units of M*H elements
-    VLR_REQUIRE(cfg->heads * cfg->head_dim == H, "vlr_decoder_layer_fwd_lora: heads*head_dim != hidden");
     CHECK(vlr_rmsnorm_fwd(x_in, w->ln1, a->xn1, a->rstd1, M, H, cfg->rms_eps, st));
-    CHECK(vlr_gemm_bf16(0, a->xn1, w->wqkv, a->qkv, nullptr, nullptr, M, 3 * H, H, H, H, 3 * H, 0, 0, 0, 0, st));
-    CHECK(lora_group_fwd(3, r, H, H, a->xn1, a->qkv, 3 * H, lw->a_qkv, lw->b_qkv, u, ldu, sc, p, seed + 0, ws_xd, M, st));   // xd segments: q,k,v | o | gate,up | down
-    CHECK(vlr_rope(a->qkv, pos, cfg->rope_cos, cfg->rope_sin, M, H, cfg->head_dim, 3 * H, cfg->max_pos, 0, st));
-    CHECK(vlr_attn_fwd(a->qkv, off(a->qkv, H), off(a->qkv, 2 * (size_t)H), 3 * H, a->attn, H, a->lse, key_mask, batch, S,
-                       cfg->heads, cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));
+    CHECK(vlr_gemm_bf16(0, a->xn1, w->wqkv, a->qkv, nullptr, nullptr, M, N, H, H, H, N, 0, 0, 0, 0, st));
+    CHECK(lora_group_fwd(3, r, H, o_qkv, a->xn1, a->qkv, N, lw->a_qkv, lw->b_qkv, u, ldu, sc, p, seed + 0, ws_xd, M, st));   // xd segments: q,k,v | o | gate,up | down
+    CHECK(vlr_rope_heads(a->qkv, pos, cfg->rope_cos, cfg->rope_sin, M, cfg->heads + kvh, cfg->head_dim, N, cfg->max_pos, 0, st));
+    CHECK(vlr_attn_fwd_gqa(a->qkv, off(a->qkv, Nq), off(a->qkv, (size_t)Nq + Nkv), N, a->attn, Nq, a->lse, key_mask, batch, S,
+                           cfg->heads, kvh, cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));
     CHECK(vlr_gemm_bf16(0, a->attn, w->wo, a->x_mid, nullptr, x_in, M, H, H, H, H, H, H, 0, 0, 0, st));
-    CHECK(lora_group_fwd(1, r, H, H, a->attn, a->x_mid, H, lw->a_o, lw->b_o, off(u, 3 * (size_t)r), ldu, sc, p, seed + 3, XD(3), M, st));
+    CHECK(lora_group_fwd(1, r, H, o_h, a->attn, a->x_mid, H, lw->a_o, lw->b_o, off(u, 3 * (size_t)r), ldu, sc, p, seed + 3, XD(3), M, st));
     CHECK(vlr_rmsnorm_fwd(a->x_mid, w->ln2, a->xn2, a->rstd2, M, H, cfg->rms_eps, st));
     CHECK(vlr_gemm_bf16(0, a->xn2, w->wgu, a->gu, nullptr, nullptr, M, 2 * I, H, H, H, 2 * I, 0, 0, 0, 0, st));
-    CHECK(lora_group_fwd(2, r, H, I, a->xn2, a->gu, 2 * I, lw->a_gu, lw->b_gu, off(u, 4 * (size_t)r), ldu, sc, p, seed + 4, XD(4), M, st));
+    CHECK(lora_group_fwd(2, r, H, o_gu, a->xn2, a->gu, 2 * I, lw->a_gu, lw->b_gu, off(u, 4 * (size_t)r), ldu, sc, p, seed + 4, XD(4), M, st));
     CHECK(vlr_swiglu_fwd(a->gu, a->act, M, I, st));
     CHECK(vlr_gemm_bf16(0, a->act, w->wdown, a->x_out, nullptr, a->x_mid, M, H, I, I, I, H, H, 0, 0, 0, st));
-    CHECK(lora_group_fwd(1, r, I, H, a->act, a->x_out, H, lw->a_down, lw->b_down, off(u, 6 * (size_t)r), ldu, sc, p, seed + 6, XD(6), M, st));
+    CHECK(lora_group_fwd(1, r, I, o_h, a->act, a->x_out, H, lw->a_down, lw->b_down, off(u, 6 * (size_t)r), ldu, sc, p, seed + 6, XD(6), M, st));
     return VLR_OK;
 }
 
@@ -224,29 +232,32 @@ extern "C" int vlr_decoder_layer_bwd_lora(const vlr_llama_cfg* cfg, const vlr_la
                                           int S, vlr_stream_t st) {
     VLR_REQUIRE(cfg && w && lw && lg && a && u && ws && ws_v && x_in && dx_out && dx_in && pos, "vlr_decoder_layer_bwd_lora: null argument");
     CHECK(lora_check("vlr_decoder_layer_bwd_lora", lw, ws_xd));
-    VLR_REQUIRE(cfg->kv_heads == 0 || cfg->kv_heads == cfg->heads, "vlr_decoder_layer_bwd_lora: grouped-query attention is not supported by the LoRA path yet");
     const int H = cfg->hidden, I = cfg->inter, M = batch * S, r = lw->r, ldu = 7 * r;
+    const int kvh = cfg->kv_heads > 0 ? cfg->kv_heads : cfg->heads;
+    const int Nq = cfg->heads * cfg->head_dim, Nkv = kvh * cfg->head_dim, N = Nq + 2 * Nkv;
+    VLR_REQUIRE(Nq == H, "vlr_decoder_layer_bwd_lora: heads*head_dim != hidden");
+    const int o_qkv[3] = {Nq, Nkv, Nkv}, o_h[1] = {H}, o_gu[2] = {I, I};
     const float sc = lw->scale, p = lw->dropout;
 #define XD(seg) (ws_xd ? (void*)off(ws_xd, (size_t)(seg) * M * H) : nullptr)   // segment base in units of M*H elements
     // ---- MLP
     CHECK(vlr_gemm_bf16(1, dx_out, w->wdown, ws->dact, nullptr, nullptr, M, I, H, H, I, I, 0, 0, 0, 0, st));
-    CHECK(lora_group_bwd(1, r, I, H, a->act, dx_out, H, lw->a_down, lw->b_down, lg->a_down, lg->b_down, off(u, 6 * (size_t)r), ldu, ws_v,
+    CHECK(lora_group_bwd(1, r, I, o_h, a->act, dx_out, H, lw->a_down, lw->b_down, lg->a_down, lg->b_down, off(u, 6 * (size_t)r), ldu, ws_v,
                          ws->dact, sc, p, seed + 6, XD(6), accumulate, M, st));
     CHECK(vlr_swiglu_bwd(a->gu, ws->dact, M, I, st));   // gu now holds [dgate | dup]
     CHECK(vlr_gemm_bf16(1, a->gu, w->wgu, ws->dxn, nullptr, nullptr, M, H, 2 * I, 2 * I, H, H, 0, 0, 0, 0, st));
-    CHECK(lora_group_bwd(2, r, H, I, a->xn2, a->gu, 2 * I, lw->a_gu, lw->b_gu, lg->a_gu, lg->b_gu, off(u, 4 * (size_t)r), ldu, ws_v,
+    CHECK(lora_group_bwd(2, r, H, o_gu, a->xn2, a->gu, 2 * I, lw->a_gu, lw->b_gu, lg->a_gu, lg->b_gu, off(u, 4 * (size_t)r), ldu, ws_v,
                          ws->dxn, sc, p, seed + 4, XD(4), accumulate, M, st));
     CHECK(vlr_rmsnorm_bwd(ws->dxn, a->x_mid, w->ln2, a->rstd2, dx_out, ws->dx_mid, nullptr, 0, ws->norm_ws, M, H, st));
     // ---- attention
     CHECK(vlr_gemm_bf16(1, ws->dx_mid, w->wo, ws->dattn, nullptr, nullptr, M, H, H, H, H, H, 0, 0, 0, 0, st));
-    CHECK(lora_group_bwd(1, r, H, H, a->attn, ws->dx_mid, H, lw->a_o, lw->b_o, lg->a_o, lg->b_o, off(u, 3 * (size_t)r), ldu, ws_v,
+    CHECK(lora_group_bwd(1, r, H, o_h, a->attn, ws->dx_mid, H, lw->a_o, lw->b_o, lg->a_o, lg->b_o, off(u, 3 * (size_t)r), ldu, ws_v,
                          ws->dattn, sc, p, seed + 3, XD(3), accumulate, M, st));
-    CHECK(vlr_attn_bwd(a->qkv, off(a->qkv, H), off(a->qkv, 2 * (size_t)H), 3 * H, a->attn, ws->dattn, H, a->lse, ws->delta,
-                       key_mask, ws->dqkv, off(ws->dqkv, H), off(ws->dqkv, 2 * (size_t)H), 3 * H, batch, S, cfg->heads,
-                       cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));
-    CHECK(vlr_rope(ws->dqkv, pos, cfg->rope_cos, cfg->rope_sin, M, H, cfg->head_dim, 3 * H, cfg->max_pos, 1, st));
-    CHECK(vlr_gemm_bf16(1, ws->dqkv, w->wqkv, ws->dxn, nullptr, nullptr, M, H, 3 * H, 3 * H, H, H, 0, 0, 0, 0, st));
-    CHECK(lora_group_bwd(3, r, H, H, a->xn1, ws->dqkv, 3 * H, lw->a_qkv, lw->b_qkv, lg->a_qkv, lg->b_qkv, u, ldu, ws_v, ws->dxn, sc, p,
+    CHECK(vlr_attn_bwd_gqa(a->qkv, off(a->qkv, Nq), off(a->qkv, (size_t)Nq + Nkv), N, a->attn, ws->dattn, Nq, a->lse, ws->delta,
+                           key_mask, ws->dqkv, off(ws->dqkv, Nq), off(ws->dqkv, (size_t)Nq + Nkv), N, batch, S, cfg->heads, kvh,
+                           cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));
+    CHECK(vlr_rope_heads(ws->dqkv, pos, cfg->rope_cos, cfg->rope_sin, M, cfg->heads + kvh, cfg->head_dim, N, cfg->max_pos, 1, st));
+    CHECK(vlr_gemm_bf16(1, ws->dqkv, w->wqkv, ws->dxn, nullptr, nullptr, M, H, N, N, H, H, 0, 0, 0, 0, st));
+    CHECK(lora_group_bwd(3, r, H, o_qkv, a->xn1, ws->dqkv, N, lw->a_qkv, lw->b_qkv, lg->a_qkv, lg->b_qkv, u, ldu, ws_v, ws->dxn, sc, p,
                          seed + 0, ws_xd, accumulate, M, st));
     CHECK(vlr_rmsnorm_bwd(ws->dxn, x_in, w->ln1, a->rstd1, ws->dx_mid, dx_in, nullptr, 0, ws->norm_ws, M, H, st));
     return VLR_OK;

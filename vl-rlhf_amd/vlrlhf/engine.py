@@ -99,8 +99,12 @@ class LoraLayout:
 
     def __init__(self, cfg, r):
         H, I, L = cfg["hidden"], cfg["inter"], cfg["layers"]
+        nh = cfg.get("heads") or 1
+        nkv = cfg.get("kv_heads") or nh
+        hd = cfg.get("head_dim") or H // nh
+        Nq, Nkv = nh * hd, nkv * hd
         self.r, self.L = r, L
-        per = dict(a_qkv=(3 * r, H), b_qkv=(3 * H, r), a_o=(r, H), b_o=(H, r), a_gu=(2 * r, H), b_gu=(2 * I, r),
+        per = dict(a_qkv=(3 * r, H), b_qkv=(Nq + 2 * Nkv, r), a_o=(r, Nq), b_o=(H, r), a_gu=(2 * r, H), b_gu=(2 * I, r),
                    a_down=(r, I), b_down=(H, r))
         self.offset, self.shape = {}, {}
         o = 0
@@ -110,7 +114,7 @@ class LoraLayout:
                 self.shape[f"l{l}.{k}"] = per[k]
                 o += _align(per[k][0] * per[k][1])
         self.numel = o
-        self.out_dim = dict(q_proj=H, k_proj=H, v_proj=H, o_proj=H, gate_proj=I, up_proj=I, down_proj=H)
+        self.out_dim = dict(q_proj=Nq, k_proj=Nkv, v_proj=Nkv, o_proj=H, gate_proj=I, up_proj=I, down_proj=H)
 
     def hf_names(self, prefix="base_model.model.language_model.model.layers."):
         """peft adapter-file name -> (flat key, row_lo, row_hi)"""
@@ -118,10 +122,12 @@ class LoraLayout:
         r = self.r
         for l in range(self.L):
             for g, mod, ts in LORA_GROUPS:
+                row = 0
                 for i, t in enumerate(ts):
                     od = self.out_dim[t]
                     out[f"{prefix}{l}.{mod}.{t}.lora_A.weight"] = (f"l{l}.a_{g}", i * r, (i + 1) * r)
-                    out[f"{prefix}{l}.{mod}.{t}.lora_B.weight"] = (f"l{l}.b_{g}", i * od, (i + 1) * od)
+                    out[f"{prefix}{l}.{mod}.{t}.lora_B.weight"] = (f"l{l}.b_{g}", row, row + od)
+                    row += od
         return out
 
 
@@ -280,8 +286,8 @@ class LlavaHipEngine:
         trainable parameters (gradients, optimizer state, DDP bucket) are the adapters."""
         if r <= 0 or r % 8:
             raise ValueError(f"lora_r must be a positive multiple of 8 for the gfx950 GEMM tiles, got {r}")
-        if self.nkv != self.nh or self.anyres:
-            raise NotImplementedError("LoRA on grouped-query / LLaVA-Next models is not on the MI355X path yet (full fine-tuning is)")
+        if self.Nq != self.H:
+            raise NotImplementedError("LoRA needs heads * head_dim == hidden_size on the MI355X path")
         if not 0.0 <= dropout < 1.0:
             raise ValueError(f"lora_dropout must be in [0, 1), got {dropout}")
         self.lora = dict(r=int(r), scale=float(alpha) / r, dropout=float(dropout), alpha=float(alpha))
@@ -340,12 +346,14 @@ class LlavaHipEngine:
             for g in ("qkv", "o", "gu", "down"):
                 W = ws.v[f"l{l}.w{g}"]
                 A, B = self.lv[f"l{l}.a_{g}"], self.lv[f"l{l}.b_{g}"]
-                n = A.shape[0] // r
-                out, inn = W.shape[0] // n, W.shape[1]
-                for t in range(n):
-                    Wt = W[t * out:(t + 1) * out]
-                    _hip.call("vlr_gemm_bf16_scaled", 1, B[t * out:(t + 1) * out], A[t * r:(t + 1) * r], Wt, None, Wt,
+                inn = W.shape[1]
+                row = 0
+                for t, name in enumerate(dict(qkv=("q_proj", "k_proj", "v_proj"), o=("o_proj",), gu=("gate_proj", "up_proj"), down=("down_proj",))[g]):
+                    out = self.lora_layout.out_dim[name]
+                    Wt = W[row:row + out]
+                    _hip.call("vlr_gemm_bf16_scaled", 1, B[row:row + out], A[t * r:(t + 1) * r], Wt, None, Wt,
                               out, inn, r, r, inn, inn, inn, 0, 0, 0, sc)
+                    row += out
         return ws
 
     # ------------------------------------------------------------------------------------------------ workspaces
