@@ -162,6 +162,22 @@ __device__ __forceinline__ bf16x8 pfrag_ks(const char* half, int cbase, int s, i
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
+// Widen the register-direct epilogue stores (guide T21).  A lane (lm, lq) holds columns 4 lq .. 4 lq + 3 of one row of the two
+// 16-column tiles j = 0, 1 (packed bf16: two dwords each).  v_permlane16_swap_b32 exchanges the odd 16-lane rows of its first
+// operand with the even rows of the second, so afterwards the lane holds EIGHT consecutive columns of ONE tile:
+//   lq 0: tile 0 cols 0-7 | lq 1: tile 1 cols 0-7 | lq 2: tile 0 cols 8-15 | lq 3: tile 1 cols 8-15
+// -> one 16-byte store per lane instead of two 8-byte ones (the store tail is issue-bound: half the instructions).
+__device__ __forceinline__ u32x4 widen_pair(const f32x4& t0, const f32x4& t1) {
+    const uint32_t a0 = pack_bf16(t0[0], t0[1]), a1 = pack_bf16(t0[2], t0[3]);
+    const uint32_t b0 = pack_bf16(t1[0], t1[1]), b1 = pack_bf16(t1[2], t1[3]);
+    const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+    const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+    u32x4 w = {s0[0], s1[0], s0[1], s1[1]};
+    return w;
+}
+// column (inside the wave's 32-column strip) of the 8 values widen_pair leaves in lane group lq
+__device__ __forceinline__ int widen_col(int lq) { return (lq & 1) * 16 + (lq >> 1) * 8; }
+
 #define PFENCE() __builtin_amdgcn_sched_barrier(0)
 #define PBAR()                               \
     do {                                     \
@@ -462,25 +478,25 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int gm = m0 + a * 128 + wr * 64 + i * 16 + lm_;
+                f32x4 h[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const int gn = n0 + wc * 32 + j * 16 + 4 * lq_;
                     const f32x4 g = acc[a][i][0][j], u = acc[a][i][1][j];
-                    f32x4 h;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) h[e] = g[e] / (1.f + __expf(-g[e])) * u[e];
-                    if (gm < p.M && gn + 4 <= I) {
-                        u32x2 o;
-                        if (p.store_c) {
-                            o[0] = pack_bf16(g[0], g[1]); o[1] = pack_bf16(g[2], g[3]);
-                            *reinterpret_cast<u32x2*>(C + (size_t)gm * p.ldc + gn) = o;
-                            o[0] = pack_bf16(u[0], u[1]); o[1] = pack_bf16(u[2], u[3]);
-                            *reinterpret_cast<u32x2*>(C + (size_t)gm * p.ldc + I + gn) = o;
-                        }
-                        o[0] = pack_bf16(h[0], h[1]); o[1] = pack_bf16(h[2], h[3]);
-                        *reinterpret_cast<u32x2*>(C2 + (size_t)gm * p.ldc2 + gn) = o;
+                    for (int e = 0; e < 4; ++e) h[j][e] = g[e] / (1.f + __expf(-g[e])) * u[e];
+                }
+                const int gn = n0 + wc * 32 + widen_col(lq_);
+                const bool ok = gm < p.M && gn + 8 <= I;
+                if (p.store_c) {
+                    const u32x4 wg = widen_pair(acc[a][i][0][0], acc[a][i][0][1]);
+                    const u32x4 wu = widen_pair(acc[a][i][1][0], acc[a][i][1][1]);
+                    if (ok) {
+                        *reinterpret_cast<u32x4*>(C + (size_t)gm * p.ldc + gn) = wg;
+                        *reinterpret_cast<u32x4*>(C + (size_t)gm * p.ldc + I + gn) = wu;
                     }
                 }
+                const u32x4 wh = widen_pair(h[0], h[1]);
+                if (ok) *reinterpret_cast<u32x4*>(C2 + (size_t)gm * p.ldc2 + gn) = wh;
             }
     } else if constexpr (CONT && FUSE == 2) {
         // RoPE epilogue: acc[a][i][0][j] / acc[a][i][1][j] = features d / d + 64 of one head (rotate-half partners)
@@ -497,28 +513,29 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                     ps = p.pos[gm];
                     ps = ps < 0 ? 0 : (ps >= p.max_pos ? p.max_pos - 1 : ps);
                 }
+                f32x4 x1[2], x2[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int c = wc * 32 + j * 16 + 4 * lq_;          // column of the 128-wide half: head c >> 6, feature c & 63
-                    const int gn = n0 + (c >> 6) * 128 + (c & 63);
-                    f32x4 x1 = acc[a][i][0][j], x2 = acc[a][i][1][j];
+                    x1[j] = acc[a][i][0][j];
+                    x2[j] = acc[a][i][1][j];
                     if (rot) {
                         const f32x4 cs = *reinterpret_cast<const f32x4*>(p.rope_cos + (size_t)ps * 64 + (c & 63));
                         const f32x4 sn = *reinterpret_cast<const f32x4*>(p.rope_sin + (size_t)ps * 64 + (c & 63));
-                        const f32x4 y1 = x1, y2 = x2;
+                        const f32x4 y1 = x1[j], y2 = x2[j];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            x1[e] = y1[e] * cs[e] - y2[e] * sn[e];
-                            x2[e] = y2[e] * cs[e] + y1[e] * sn[e];
+                            x1[j][e] = y1[e] * cs[e] - y2[e] * sn[e];
+                            x2[j][e] = y2[e] * cs[e] + y1[e] * sn[e];
                         }
                     }
-                    if (gm < p.M) {
-                        u32x2 o;
-                        o[0] = pack_bf16(x1[0], x1[1]); o[1] = pack_bf16(x1[2], x1[3]);
-                        *reinterpret_cast<u32x2*>(C + (size_t)gm * p.ldc + gn) = o;
-                        o[0] = pack_bf16(x2[0], x2[1]); o[1] = pack_bf16(x2[2], x2[3]);
-                        *reinterpret_cast<u32x2*>(C + (size_t)gm * p.ldc + gn + 64) = o;
-                    }
+                }
+                const u32x4 w1 = widen_pair(x1[0], x1[1]), w2 = widen_pair(x2[0], x2[1]);
+                const int c8 = wc * 32 + widen_col(lq_);
+                const int gn = n0 + (c8 >> 6) * 128 + (c8 & 63);
+                if (gm < p.M) {
+                    *reinterpret_cast<u32x4*>(C + (size_t)gm * p.ldc + gn) = w1;
+                    *reinterpret_cast<u32x4*>(C + (size_t)gm * p.ldc + gn + 64) = w2;
                 }
             }
     } else if constexpr (CONT) {
@@ -531,16 +548,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
             for (int i = 0; i < 4; ++i) {
                 const int gm = m0 + a * 128 + wr * 64 + i * 16 + lm_;
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int gn = n0 + b * 128 + wc * 32 + j * 16 + 4 * lq_;
-                        const f32x4 v = acc[a][i][b][j];
-                        u32x2 o;
-                        o[0] = pack_bf16(p.alpha * v[0], p.alpha * v[1]);
-                        o[1] = pack_bf16(p.alpha * v[2], p.alpha * v[3]);
-                        if (gm < p.M && gn + 4 <= p.N) *reinterpret_cast<u32x2*>(C + (size_t)gm * p.ldc + gn) = o;
-                    }
+                for (int b = 0; b < 2; ++b) {
+                    const int gn = n0 + b * 128 + wc * 32 + widen_col(lq_);
+                    const u32x4 w = widen_pair(p.alpha * acc[a][i][b][0], p.alpha * acc[a][i][b][1]);
+                    if (gm < p.M && gn + 8 <= p.N) *reinterpret_cast<u32x4*>(C + (size_t)gm * p.ldc + gn) = w;
+                }
             }
     }
     if constexpr (CONT) {
@@ -708,8 +720,8 @@ bool vlr_gemm256p_fused_try_launch(const GemmParams& p, hipStream_t stream) {
     const int ntiles = tiles_m * tiles_n;
     if (ntiles <= n_cu || p.K < 4 * PK) return false;                      // persistent continuous pipeline only
     if (p.fuse == 2 && (p.N % PT != 0 || p.rope_cols % PT != 0)) return false;
-    if (p.fuse == 1 && ((p.N >> 1) % 8 != 0 || p.ldc2 % 4 != 0)) return false;
-    if ((((uintptr_t)p.A | (uintptr_t)p.B) & 15) || p.lda % 8 != 0 || p.ldb % 8 != 0 || p.ldc % 4 != 0) return false;
+    if (p.fuse == 1 && ((p.N >> 1) % 8 != 0 || p.ldc2 % 8 != 0 || ((uintptr_t)p.C2 & 15))) return false;
+    if ((((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.C) & 15) || p.lda % 8 != 0 || p.ldb % 8 != 0 || p.ldc % 8 != 0) return false;
     const int pi = vlr_prof_begin(VLR_K_GEMM256P, 2.0 * p.M * p.N * p.K, stream);
     if (p.fuse == 1) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 1>), dim3(n_cu), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
     else hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 2>), dim3(n_cu), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
@@ -768,7 +780,8 @@ bool vlr_gemm256p_try_launch(int layout, const GemmParams& p, hipStream_t stream
     // continuous pipeline across tiles: persistent launch, plain bf16 epilogue (C = alpha * A B), at least 4 K tiles
     static int cont = -1;
     if (cont < 0) { const char* e = getenv("VLR_GEMM_CONT"); cont = (e && e[0] == '0') ? 0 : 1; }
-    if (cont && ntiles > tiles && !p.bias && !p.residual && !p.accumulate && !p.out_f32 && p.act == ACT_NONE && p.K >= 4 * PK && p.ldc % 4 == 0) {
+    if (cont && ntiles > tiles && !p.bias && !p.residual && !p.accumulate && !p.out_f32 && p.act == ACT_NONE && p.K >= 4 * PK && p.ldc % 8 == 0 && p.N % 8 == 0 &&
+        !((uintptr_t)p.C & 15)) {
         if (layout == 0) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true>), dim3(tiles), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
         else if (layout == 1) hipLaunchKernelGGL((gemm256p_kernel<false, true, 0, true>), dim3(tiles), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
         else hipLaunchKernelGGL((gemm256p_kernel<true, true, 0, true>), dim3(tiles), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
