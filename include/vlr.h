@@ -60,6 +60,11 @@ int vlr_gemm_swiglu(const void* x, const void* wgu, void* gu, void* act, int M, 
                     vlr_stream_t stream);
 int vlr_gemm_qkv_rope(const void* x, const void* wqkv, void* qkv, const int* pos, const float* cos_t, const float* sin_t, int M,
                       int N, int rope_cols, int K, int ldx, int head_dim, int max_pos, vlr_stream_t stream);
+/*  vlr_gemm_swiglu_bwd: backward of the MLP's first half in one pass - d act = dy [M][H] . wdown [H][I] stays in the
+ *                     accumulators and gu [M][2I] (gate | up of the forward) is replaced in place by d gate | d up.  dact_ws
+ *                     [M][I] is scratch for the rows / shapes that take the plain GEMM + vlr_swiglu_bwd. */
+int vlr_gemm_swiglu_bwd(const void* dy, const void* wdown, void* gu_inout, void* dact_ws, int M, int I, int H,
+                        vlr_stream_t stream);
 
 /* ---- normalisation / activations (transformers LlamaRMSNorm, CLIP LayerNorm, SwiGLU, GELU; call sites
  *      Llava/__init__.py:178-191,232) ------------------------------------------------------------------------- */

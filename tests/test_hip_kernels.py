@@ -780,3 +780,27 @@ def test_attention_gqa_fwd_bwd(hip, B, S, nh, nkv, masked):
     check(dqkv[valid][:, Hq:Hq + Hkv], g[valid][:, Hq:Hq + Hkv], 2e-2, "gqa dk")
     check(dqkv[valid][:, Hq + Hkv:], g[valid][:, Hq + Hkv:], 2e-2, "gqa dv")
     assert torch.isfinite(dqkv.float()).all() and torch.isfinite(o.float()).all()
+
+
+@pytest.mark.parametrize("shape", [(4104, 2304, 512), (4352, 2184, 320), (12792, 1024, 256), (300, 256, 128)])
+def test_gemm_swiglu_bwd_fused(hip, shape):
+    """vlr_gemm_swiglu_bwd: d act = dy Wdown stays in the accumulators, gate | up are replaced in place by d gate | d up; against the
+    fp32 reference and against the unfused pair (plain dgrad GEMM + vlr_swiglu_bwd), incl. a ragged M / I and the small-shape fallback."""
+    M, I, H = shape
+    dy = rnd(M, H, seed=1)
+    w = rnd(H, I, scale=0.05, seed=2)
+    gu0 = rnd(M, 2 * I, seed=3)
+    g, u = gu0[:, :I].float(), gu0[:, I:].float()
+    dact = dy.float() @ w.float()
+    sg = torch.sigmoid(g)
+    ref = torch.cat([dact * u * sg * (1 + g * (1 - sg)), dact * g * sg], dim=1)
+    gu = gu0.clone()
+    ws = torch.empty(M, I, dtype=torch.bfloat16, device=DEV)
+    hip.call("vlr_gemm_swiglu_bwd", dy, w, gu, ws, M, I, H)
+    torch.cuda.synchronize()
+    check(gu, ref, 8e-3, f"swiglu bwd fused {shape}")
+    gu2 = gu0.clone()
+    hip.call("vlr_gemm_bf16", 1, dy, w, ws, None, None, M, I, H, H, I, I, 0, 0, 0, 0)
+    hip.call("vlr_swiglu_bwd", gu2, ws, M, I)
+    torch.cuda.synchronize()
+    check(gu, gu2, 1.6e-2, f"fused vs unfused {shape}")

@@ -27,6 +27,7 @@ struct GemmParams {
     //  2 RoPE   : B = [q | k | v] weights, head_dim 128.  The B-lo / B-hi half tiles hold the first / second 64 features of the
     //             tile's two heads, so a lane owns both members of every rotate-half pair; columns < rope_cols are rotated by
     //             pos[row] in fp32 before the single rounding to bf16, the rest (v) pass through.
+    //  3 SwiGLU backward (NN): acc = d act; C2 = gate | up [M][2I] is replaced in place by d gate | d up; C is not written.
     int fuse;
     int store_c;
     void* C2;
@@ -51,3 +52,5 @@ bool vlr_gemm256p_try_launch(int layout, const GemmParams& p, hipStream_t stream
 // fused-epilogue variants (p.fuse = 1 | 2, layout NT): false when the shape does not qualify for the persistent
 // continuous-pipeline kernel - the caller then runs the plain GEMM followed by the elementwise kernel
 bool vlr_gemm256p_fused_try_launch(const GemmParams& p, hipStream_t stream);
+// fuse = 3 (NN): d act = dy . Wdown with the SwiGLU backward applied in the epilogue to gate | up in p.C2 (in place)
+bool vlr_gemm256p_swiglu_bwd_try_launch(const GemmParams& p, hipStream_t stream);

@@ -539,3 +539,32 @@ extern "C" int vlr_gemm_qkv_rope(const void* x, const void* wqkv, void* qkv, con
     }
     return VLR_OK;
 }
+
+extern "C" int vlr_swiglu_bwd(void* gu_inout, const void* dact, int M, int I, hipStream_t st);
+
+// d gate | d up (in place in gu [M][2I]) = SwiGLU'(gate, up) * (dy [M][H] . wdown [H][I]): the dgrad of the down projection with
+// the SwiGLU backward in its epilogue - d act [M][I] is never written (dact_ws is only used for rows / shapes that fall back)
+extern "C" int vlr_gemm_swiglu_bwd(const void* dy, const void* wdown, void* gu, void* dact_ws, int M, int I, int H, hipStream_t stream) {
+    VLR_REQUIRE(dy && wdown && gu && dact_ws, "vlr_gemm_swiglu_bwd: null operand");
+    VLR_REQUIRE(M > 0 && I > 0 && H > 0 && I % 8 == 0 && H % 8 == 0, "vlr_gemm_swiglu_bwd: bad shape M=%d I=%d H=%d", M, I, H);
+    const int tn = (I + 255) / 256;
+    const int peel = choose_peel(M, I, tn);
+    const int tm256 = (M + 255) / 256;
+    const int M1 = peel ? (tm256 - peel) * 256 : M;
+    GemmParams p = fused_params(dy, wdown, dact_ws, M1, I, H, H, I, I);
+    p.fuse = 3; p.C2 = gu; p.ldc2 = 2 * I;
+    int done = 0;
+    if (vlr_gemm256p_swiglu_bwd_try_launch(p, stream)) {
+        int rc = vlr_check_launch("vlr_gemm_swiglu_bwd(fused)");
+        if (rc != VLR_OK) return rc;
+        done = M1;
+    }
+    if (done < M) {
+        const bf16_t* dyr = (const bf16_t*)dy + (size_t)done * H;
+        bf16_t* da = (bf16_t*)dact_ws + (size_t)done * I;
+        int rc = gemm_impl(1, dyr, wdown, da, nullptr, nullptr, M - done, I, H, H, I, I, 0, 0, 0, 0, 1.0f, stream);
+        if (rc != VLR_OK) return rc;
+        return vlr_swiglu_bwd((bf16_t*)gu + (size_t)done * 2 * I, da, M - done, I, stream);
+    }
+    return VLR_OK;
+}

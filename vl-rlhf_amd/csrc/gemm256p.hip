@@ -194,7 +194,7 @@ __device__ __forceinline__ int widen_col(int lq) { return (lq & 1) * 16 + (lq >>
 // accumulator registers (8 bytes per lane, no LDS, no barrier) and the K loop of tile i+1 starts with its data resident.
 template <bool A_KS, bool B_KS, int ABL = 0, bool CONT = false, int FUSE = 0>
 __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_t* __restrict__ zero16) {
-    static_assert(FUSE == 0 || (CONT && !A_KS && !B_KS), "fused epilogues: NT layout, continuous pipeline only");
+    static_assert(FUSE == 0 || (CONT && !A_KS && (FUSE == 3 ? B_KS : !B_KS)), "fused epilogues: continuous pipeline; 1, 2 NT, 3 NN");
     constexpr int NW = FUSE == 1 ? 128 : PT;      // output columns (of the gate half, for SwiGLU) per workgroup tile
     extern __shared__ __attribute__((aligned(16))) char smem[];   // P_LDS_BYTES
     const int t = threadIdx.x;
@@ -498,6 +498,58 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                 const u32x4 wh = widen_pair(h[0], h[1]);
                 if (ok) *reinterpret_cast<u32x4*>(C2 + (size_t)gm * p.ldc2 + gn) = wh;
             }
+    } else if constexpr (CONT && FUSE == 3) {
+        // SwiGLU backward epilogue (dgrad of the down projection, NN): acc = d act [rows][cols of I]; gate | up of the forward sit in
+        // C2 [M][2I] and are overwritten IN PLACE with d gate | d up (each element is read and written by the same lane)
+        bf16_t* GU = reinterpret_cast<bf16_t*>(p.C2);
+        const int I = p.N;
+        const int lm_ = lane & 15, lq_ = lane >> 4;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            // one batch of loads per A half: 8 x (gate, up) x 16 bytes in flight, then the arithmetic, then the stores
+            u32x4 gq[4][2], uq[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int gm = m0 + a * 128 + wr * 64 + i * 16 + lm_;
+                const int gmc = gm < p.M ? gm : p.M - 1;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    int gn = n0 + b * 128 + wc * 32 + widen_col(lq_);
+                    gn = gn + 8 <= I ? gn : I - 8;
+                    gq[i][b] = *reinterpret_cast<const u32x4*>(GU + (size_t)gmc * p.ldc2 + gn);
+                    uq[i][b] = *reinterpret_cast<const u32x4*>(GU + (size_t)gmc * p.ldc2 + I + gn);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int gm = m0 + a * 128 + wr * 64 + i * 16 + lm_;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int gn = n0 + b * 128 + wc * 32 + widen_col(lq_);
+                    // bring d act into the same 8-consecutive-column layout as the 16-byte gate / up loads (fp32 bits through the swap)
+                    float d[8], g[8], u[8], dg[8], du[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, acc[a][i][b][0][e]),
+                                                                         __builtin_bit_cast(uint32_t, acc[a][i][b][1][e]), false, false);
+                        d[e] = __builtin_bit_cast(float, sw[0]);
+                        d[4 + e] = __builtin_bit_cast(float, sw[1]);
+                    }
+                    unpack8(gq[i][b], g);
+                    unpack8(uq[i][b], u);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float sg = 1.f / (1.f + __expf(-g[e]));
+                        du[e] = d[e] * g[e] * sg;
+                        dg[e] = d[e] * u[e] * sg * (1.f + g[e] * (1.f - sg));
+                    }
+                    if (gm < p.M && gn + 8 <= I) {
+                        *reinterpret_cast<u32x4*>(GU + (size_t)gm * p.ldc2 + gn) = pack8(dg);
+                        *reinterpret_cast<u32x4*>(GU + (size_t)gm * p.ldc2 + I + gn) = pack8(du);
+                    }
+                }
+            }
+        }
     } else if constexpr (CONT && FUSE == 2) {
         // RoPE epilogue: acc[a][i][0][j] / acc[a][i][1][j] = features d / d + 64 of one head (rotate-half partners)
         bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
@@ -711,6 +763,7 @@ bool vlr_gemm256p_fused_try_launch(const GemmParams& p, hipStream_t stream) {
         hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, 0, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
         hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, 0, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
     }
+    if (p.fuse == 3) return false;       // NN: vlr_gemm256p_swiglu_bwd_try_launch
     if (p.fuse < 1 || p.fuse > 2 || !((on >> (p.fuse - 1)) & 1)) return false;
     bf16_t* zero16 = gemm256p_zero16();
     if (!zero16) return false;
@@ -725,6 +778,27 @@ bool vlr_gemm256p_fused_try_launch(const GemmParams& p, hipStream_t stream) {
     const int pi = vlr_prof_begin(VLR_K_GEMM256P, 2.0 * p.M * p.N * p.K, stream);
     if (p.fuse == 1) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 1>), dim3(n_cu), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
     else hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 2>), dim3(n_cu), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
+    vlr_prof_end(pi, stream);
+    return true;
+}
+
+// d act = dy . Wdown (NN) with the SwiGLU backward in the epilogue: p.C2 = gate | up [M][2I] (in/out), p.N = I, p.C unused
+bool vlr_gemm256p_swiglu_bwd_try_launch(const GemmParams& p, hipStream_t stream) {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("VLR_GEMM_FUSE");
+        on = e ? ((atoi(e) >> 2) & 1) : 1;               // bit 2
+        hipFuncSetAttribute((const void*)gemm256p_kernel<false, true, 0, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+    }
+    if (!on) return false;
+    bf16_t* zero16 = gemm256p_zero16();
+    if (!zero16) return false;
+    const int n_cu = gemm256p_n_cu();
+    const int ntiles = ((p.M + PT - 1) / PT) * ((p.N + PT - 1) / PT);
+    if (ntiles <= n_cu || p.K < 4 * PK) return false;
+    if ((((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.C2) & 15) || p.lda % 8 != 0 || p.ldb % 8 != 0 || p.N % 8 != 0 || p.ldc2 % 8 != 0) return false;
+    const int pi = vlr_prof_begin(VLR_K_GEMM256P, 2.0 * p.M * p.N * p.K, stream);
+    hipLaunchKernelGGL((gemm256p_kernel<false, true, 0, true, 3>), dim3(n_cu), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
     vlr_prof_end(pi, stream);
     return true;
 }

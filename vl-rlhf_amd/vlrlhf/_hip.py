@@ -6,7 +6,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libvlr_hip.so")
+LIB_PATH = os.environ.get("VLR_LIB") or os.path.join(os.path.dirname(_HERE), "libvlr_hip.so")   # VLR_LIB: A/B another build of the library
 
 _lib = None
 
@@ -94,6 +94,7 @@ _SIGS = {
     "vlr_decoder_layer_fwd": [P, P, P, P, P, P, I, I, P],
     "vlr_decoder_layer_fwd_ex": [P, P, P, P, P, P, I, I, I, P],
     "vlr_gemm_swiglu": [P, P, P, P, I, I, I, I, I, P],
+    "vlr_gemm_swiglu_bwd": [P, P, P, P, I, I, I, P],
     "vlr_gemm_qkv_rope": [P, P, P, P, P, P, I, I, I, I, I, I, I, P],
     "vlr_decoder_layer_bwd": [P, P, P, I, P, P, P, P, P, P, P, I, I, P],
     "vlr_vit_layer_fwd": [P, P, P, P, I, I, P],
