@@ -45,9 +45,9 @@ int vlr_gemm_bf16_scaled(int layout, const void* A, const void* B, void* C, cons
                          float alpha, vlr_stream_t stream);
 /* Optional fp32 scratch for split-K: problems with few output tiles and a long reduction (the LoRA adapter gradients;
  * the ragged last tile rows of the decoder GEMMs) are split along K into fp32 partials and reduced by a second kernel
- * that applies the epilogue.  Without it they run un-split.  The buffer is cut in two slots handed to the first two
- * distinct streams that launch such a GEMM (policy pass + reference pass on a side stream); further streams run
- * un-split.  64 MiB per slot covers the 7B shapes.  (NULL, 0) unregisters. */
+ * that applies the epilogue.  Without it they run un-split.  The buffer is cut in 64 MiB slots (covers the 7B shapes; at most
+ * eight), one per distinct stream that launches such a GEMM (policy pass, reference pass on a side stream, ...); further
+ * streams run un-split.  Registering again forgets the stream assignment.  (NULL, 0) unregisters. */
 int vlr_gemm_set_splitk_workspace(void* workspace, long bytes);
 /* Fused forward projections of the decoder layer (transformers LlamaMLP / LlamaAttention; call site
  * src/vlrlhf/models/Llava/__init__.py:232).  The elementwise op that follows the projection runs on the fp32 accumulators

@@ -298,22 +298,35 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // The registered scratch is cut in two slots, one per stream (the DPO step runs the frozen reference forward on a side
 // stream next to the policy forward): the first two distinct streams that ask get a slot each, any further stream runs
 // un-split.  Re-registering forgets the stream assignment.
+#define SPLITK_SLOT_BYTES (64L << 20)
+#define SPLITK_MAX_SLOTS 8
 static float* g_splitk_ws = nullptr;
 static long g_splitk_bytes = 0;          // bytes per slot
-static hipStream_t g_splitk_stream[2] = {nullptr, nullptr};
+static int g_splitk_nslots = 0;
+static hipStream_t g_splitk_stream[SPLITK_MAX_SLOTS];
 static int g_splitk_nstream = 0;
 extern "C" int vlr_gemm_set_splitk_workspace(void* ws, long bytes) {
     VLR_REQUIRE((ws && bytes > 0) || (!ws && bytes == 0), "vlr_gemm_set_splitk_workspace: (ptr, bytes) or (NULL, 0)");
     g_splitk_ws = (float*)ws;
-    g_splitk_bytes = (bytes / 2) & ~255L;
+    // slots of 64 MiB (covers the 7B shapes), one per stream, at most 8; a smaller buffer is cut in two
+    int n = (int)(bytes / SPLITK_SLOT_BYTES);
+    if (n > SPLITK_MAX_SLOTS) n = SPLITK_MAX_SLOTS;
+    if (n >= 2) { g_splitk_nslots = n; g_splitk_bytes = SPLITK_SLOT_BYTES; }
+    else { g_splitk_nslots = ws ? 2 : 0; g_splitk_bytes = (bytes / 2) & ~255L; }
     g_splitk_nstream = 0;
     return VLR_OK;
 }
+// Which split a GEMM takes must not depend on which OTHER streams happened to run split-K GEMMs earlier in the process: the
+// reference pass (side stream) and the policy pass (main stream) of one step have to produce bit-identical results for
+// identical weights (policy == reference => loss == ln 2 exactly).  With two slots, a third stream - e.g. a new trainer's side
+// stream after an earlier trainer's - silently ran un-split and summed in a different order (found by the full-size
+// LLaVA-Next test, which failed or passed depending on the test order).  Now: one slot per stream, eight of them, and the
+// engine re-registers the workspace (forgetting the assignment) when it is constructed.
 static float* splitk_slot(hipStream_t st) {
     if (!g_splitk_ws) return nullptr;
     for (int i = 0; i < g_splitk_nstream; ++i)
         if (g_splitk_stream[i] == st) return (float*)((char*)g_splitk_ws + (size_t)i * g_splitk_bytes);
-    if (g_splitk_nstream < 2) {
+    if (g_splitk_nstream < g_splitk_nslots) {
         g_splitk_stream[g_splitk_nstream] = st;
         return (float*)((char*)g_splitk_ws + (size_t)(g_splitk_nstream++) * g_splitk_bytes);
     }

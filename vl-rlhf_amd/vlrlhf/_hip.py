@@ -223,7 +223,7 @@ def ensure_splitk_workspace(device="cuda", force=False):
     allocated once and never freed, so the pointer registered in the library cannot dangle."""
     global _splitk_ws
     if _splitk_ws is None:
-        _splitk_ws = torch.empty(128 << 20, dtype=torch.uint8, device=device)
+        _splitk_ws = torch.empty(512 << 20, dtype=torch.uint8, device=device)      # eight 64 MiB slots, one per stream
         force = True
     if force:
         rc = lib().vlr_gemm_set_splitk_workspace(_splitk_ws.data_ptr(), _splitk_ws.numel())

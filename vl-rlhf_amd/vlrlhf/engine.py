@@ -258,7 +258,7 @@ class LlavaHipEngine:
         self._opt_stream = torch.cuda.Stream(self.dev) if os.environ.get("VLR_ASYNC_OPT", "0") == "1" else None
         self._opt_done = None
         # split-K scratch of the GEMM dispatcher (ragged last tile rows, LoRA adapter gradients): two 64 MiB slots (main + side stream)
-        _hip.ensure_splitk_workspace(self.dev)
+        _hip.ensure_splitk_workspace(self.dev, force=True)      # a new engine brings new streams: forget the old slot assignment
 
     # ------------------------------------------------------------------------------------------------ weights
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
