@@ -450,6 +450,48 @@ def gen_processor_answers():
     print(f"[golden] processor answers -> {path}")
 
 
+def gen_dataset_answers():
+    """The reference's own pair mining for VLFeedback (src/vlrlhf/utils/data.py:11-82), captured without the hub: `load_dataset`
+    is replaced by a stand-in whose .map() hands us the reference's nested `make_batch_pairs`, which is then run on synthetic
+    completion lists for score_margin -1 (largest gap only) and 1.0.  -> tests/golden/vlfeedback_pairs.json"""
+    import vlrlhf.utils.data as RD
+    captured = {}
+
+    class FakeDS:
+        column_names = ["prompt", "img_path", "completions", "id"]
+
+        def map(self, fn, **kw):
+            captured["fn"] = fn
+            return self
+
+    RD.load_dataset = lambda *a, **k: FakeDS()
+    g = np.random.default_rng(3)
+    aspects = ("Helpfulness", "Ethical Considerations", "Visual Faithfulness")
+    samples = dict(prompt=[], img_path=[], completions=[])
+    for i in range(9):
+        n = int(g.integers(2, 5))
+        annos = []
+        for c in range(n):
+            a = {asp: {"Rating": str(int(g.integers(1, 6)))} for asp in aspects}
+            if i == 4 and c == 1:
+                a["Helpfulness"]["Rating"] = "N/A"                    # the reference skips pairs whose rating does not parse
+            annos.append(a)
+        if i == 6:
+            annos = [annos[0]] * n                                      # all ties: the sample yields nothing
+        samples["prompt"].append(f"question {i}?")
+        samples["img_path"].append(f"img_{i}.jpg")
+        samples["completions"].append(dict(annotations=annos, response=[f"answer {i}.{c}" for c in range(n)]))
+    out = dict(samples=samples, results={})
+    for margin in (-1, 1.0):
+        RD.make_vlfeedback_paired_dataset(types.SimpleNamespace(score_margin=margin))
+        res = captured["fn"](samples)
+        out["results"][str(margin)] = {k: list(v) for k, v in res.items()}
+    path = os.path.join(OUT_DIR, "vlfeedback_pairs.json")
+    with open(path, "w") as f:
+        json.dump(out, f)
+    print(f"[golden] vlfeedback pairs -> {path}: {[len(v['prompt']) for v in out['results'].values()]} pairs")
+
+
 OPT = dict(lr=1e-3, beta1=0.9, beta2=0.98, eps=1e-6, weight_decay=0.05, max_grad_norm=1.0)
 
 CASES = {
@@ -471,6 +513,9 @@ if __name__ == "__main__":
     torch.set_num_threads(4)
     if sys.argv[1:] == ["processor"]:        # adds the processor fixture without regenerating the tensor fixtures
         gen_processor_answers()
+        sys.exit(0)
+    if sys.argv[1:] == ["datasets"]:
+        gen_dataset_answers()
         sys.exit(0)
     gen_known_answers()
     gen_processor_answers()

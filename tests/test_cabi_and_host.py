@@ -274,3 +274,23 @@ def test_ctypes_signatures_match_the_header():
         assert have == want, f"{name}: header {want} vs ctypes {have}"
         checked += 1
     assert checked >= 45
+
+
+def test_vlfeedback_pair_mining_matches_reference(tmp_path):
+    """utils/data.py: the pair mining of `vlfeedback_paired` against the reference's own `make_batch_pairs` (captured by
+    oracle/make_golden.py datasets): largest-gap-only (score_margin -1) and margin 1.0, unparsable ratings and all-tie samples."""
+    from vlrlhf.utils.data import DATASET_MAP, vlfeedback_pairs
+    g = json.load(open(os.path.join(GOLDEN, "vlfeedback_pairs.json")))
+    s = g["samples"]
+    samples = [dict(prompt=s["prompt"][i], img_path=s["img_path"][i], completions=s["completions"][i]) for i in range(len(s["prompt"]))]
+    for margin, exp in g["results"].items():
+        rows = vlfeedback_pairs(samples, float(margin) if margin != "-1" else -1)
+        got = {k: [r[k] for r in rows] for k in ("prompt", "chosen", "rejected", "img_path")}
+        assert got == {k: exp[k] for k in got}, margin
+    # the entry through DATASET_MAP on a local export
+    p = tmp_path / "vlf.jsonl"
+    p.write_text("\n".join(json.dumps(x) for x in samples))
+    rows = DATASET_MAP["vlfeedback_paired"](SimpleNamespace(data_path=str(p), image_root="/imgs", score_margin=-1))
+    assert len(rows) == len(g["results"]["-1"]["prompt"]) and rows[0]["img_path"].startswith("/imgs/")
+    with pytest.raises(RuntimeError, match="no network"):
+        DATASET_MAP["vlfeedback_paired"](SimpleNamespace(data_path=None, score_margin=-1))
