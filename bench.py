@@ -340,6 +340,8 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
+        if reducer is not None and reducer.native is not None:
+            reducer.native.close()
         dist.destroy_process_group()
 
 

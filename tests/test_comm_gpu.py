@@ -43,3 +43,30 @@ def test_single_rank_allreduce_through_the_c_abi():
     assert l.vlr_allreduce_bucket(comm, x.data_ptr(), 8, 5, None) == 1 and b"dtype" in l.vlr_last_error()
     assert l.vlr_comm_destroy(comm) == 0
     print(f"[comm] RCCL library in use: {lib_path}")
+
+
+@pytest.mark.gpu
+def test_native_comm_staged_construction_one_rank_nccl():
+    """parallel.NativeComm on a real RCCL process group of one rank: the staged, collective construction (library check ->
+    unique id with its ok flag -> join -> self-check) and an in-place bucket reduction on a side stream."""
+    import torch.distributed as dist
+    from vlrlhf.parallel import NativeComm, free_port
+    torch.cuda.set_device(0)
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1)
+    try:
+        nc = NativeComm()
+        assert "rccl" in nc.library and nc.world == 1
+        g = torch.randn(1 << 22, device="cuda").bfloat16()
+        want = g.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        nc.all_reduce_(g[1000:1 << 21], side)
+        side.synchronize()
+        assert torch.equal(g, want)
+        nc.close()
+        assert nc.comm is None
+    finally:
+        if created:
+            dist.destroy_process_group()

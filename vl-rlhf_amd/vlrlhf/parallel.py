@@ -20,37 +20,65 @@ import torch
 import torch.distributed as dist
 
 
+def _all_ok(ok: bool, group=None) -> bool:
+    """True iff `ok` on EVERY rank (one tiny all-reduce on the torch process group)"""
+    flag = torch.tensor([1 if ok else 0], device="cuda")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(flag))
+
+
 class NativeComm:
-    """RCCL communicator owned by libvlr_hip.so (one per process)."""
+    """RCCL communicator owned by libvlr_hip.so (one per process).  Construction is collective and staged so that a failure on one
+    rank can never leave the others blocked inside ncclCommInitRank: (1) every rank loads RCCL through the library and the ranks
+    agree that all could; (2) rank 0 creates the unique id and its success travels with the id; only then (3) all ranks join."""
 
     def __init__(self, group=None):
         from . import _hip
         self._hip = _hip
+        self.comm = None
         l = _hip.lib()
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
-        nbytes = _hip.helper("vlr_comm_unique_id_bytes")
         dev = torch.device("cuda", torch.cuda.current_device())
-        idt = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        # (1) the RCCL library resolves on every rank
+        self.library = l.vlr_comm_library().decode()
+        err = "" if self.library else l.vlr_last_error().decode()
+        if not _all_ok(bool(self.library), group):
+            raise _hip.VlrError(f"RCCL could not be loaded on every rank ({err or 'another rank failed'})")
+        # (2) unique id from rank 0: [ok flag | id bytes]
+        nbytes = _hip.helper("vlr_comm_unique_id_bytes")
+        idt = torch.zeros(1 + nbytes, dtype=torch.uint8, device=dev)
         if self.rank == 0:
             buf = (C.c_ubyte * nbytes)()
-            if l.vlr_comm_unique_id(buf) != 0:
-                raise _hip.VlrError(l.vlr_last_error().decode())
-            idt.copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
+            if l.vlr_comm_unique_id(buf) == 0:
+                idt[0] = 1
+                idt[1:].copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
+            else:
+                err = l.vlr_last_error().decode()
         dist.broadcast(idt, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        host = (C.c_ubyte * nbytes).from_buffer_copy(bytes(idt.cpu().numpy().tobytes()))
+        host_id = idt.cpu()
+        if int(host_id[0]) != 1:
+            raise _hip.VlrError(f"rank 0 could not create an RCCL unique id ({err or 'see rank 0'})")
+        # (3) join
+        host = (C.c_ubyte * nbytes).from_buffer_copy(bytes(host_id[1:].numpy().tobytes()))
         comm = C.c_void_p()
-        if l.vlr_comm_init(host, self.rank, self.world, C.byref(comm)) != 0:
-            raise _hip.VlrError(l.vlr_last_error().decode())
-        self.comm = comm
-        self.library = l.vlr_comm_library().decode()
+        rc = l.vlr_comm_init(host, self.rank, self.world, C.byref(comm))
+        err = "" if rc == 0 else l.vlr_last_error().decode()
+        if rc == 0:
+            self.comm = comm
+        if not _all_ok(rc == 0, group):
+            self.close()
+            raise _hip.VlrError(f"vlr_comm_init failed ({err or 'on another rank'})")
         # trust, but verify: sum of (rank + 1) over the ranks, in both dtypes the reducer uses
-        for dt, code in ((torch.bfloat16, 0), (torch.float32, 1)):
+        good = True
+        for dt in (torch.bfloat16, torch.float32):
             t = torch.full((1024,), float(self.rank + 1), dtype=dt, device=dev)
             self.all_reduce_(t, torch.cuda.current_stream())
             torch.cuda.current_stream().synchronize()
             want = self.world * (self.world + 1) / 2
-            if not bool((t.float() == want).all()):
-                raise _hip.VlrError(f"vlr_allreduce_bucket self-check failed: got {float(t[0])}, expected {want}")
+            good = good and bool((t.float() == want).all())
+        if not _all_ok(good, group):
+            self.close()
+            raise _hip.VlrError("vlr_allreduce_bucket self-check failed (sum of rank + 1 over the ranks)")
 
     def all_reduce_(self, t: torch.Tensor, stream):
         code = {torch.bfloat16: 0, torch.float32: 1}[t.dtype]
@@ -71,23 +99,17 @@ def make_transport(group=None, cuda=True):
         return None, "torch", ""
     if dist.get_backend(group) != "nccl":       # e.g. gloo ranks sharing one GPU in the tests: RCCL refuses duplicate devices
         return None, "torch", f"process group backend is {dist.get_backend(group)}"
-    ok, note, comm = 1, "", None
+    # NativeComm's stages are collective and agree on success / failure among themselves: every rank either returns a working
+    # communicator or raises
     try:
         comm = NativeComm(group)
     except Exception as e:          # noqa: BLE001 - any failure of the native transport is reported, not swallowed
         if want == "native":
             raise
-        ok, note = 0, f"{type(e).__name__}: {e}"
-    # every rank must take the same path
-    flag = torch.tensor([ok], device="cuda")
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    if int(flag) == 0:
-        if comm is not None:
-            comm.close()
+        note = f"{type(e).__name__}: {e}"
         if dist.get_rank(group) == 0:
-            print(f"[vlrlhf.parallel] native RCCL transport unavailable ({note or 'another rank failed'}); "
-                  "using torch.distributed all_reduce", file=sys.stderr, flush=True)
-        return None, "torch", note or "another rank failed"
+            print(f"[vlrlhf.parallel] native RCCL transport unavailable ({note}); using torch.distributed all_reduce", file=sys.stderr, flush=True)
+        return None, "torch", note
     return comm, "native", comm.library
 
 
