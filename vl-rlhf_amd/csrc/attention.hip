@@ -286,6 +286,12 @@ __device__ __forceinline__ void attn_dma4(const float* sbase, uint32_t voff, uin
 // order, so that wait also drained the NEXT tile's DMA in the middle of the current tile's MFMAs, every iteration (found in
 // the r01 ISA: vmcnt(7)..vmcnt(0) between the QK^T MFMAs; the double buffering never overlapped anything).
 #define ATTN_RETIRE(frag) asm volatile("" : "+v"(frag))
+// s_setprio(1) around the MFMA groups of the LDS-DMA kernels: two independent workgroups share a CU, so a wave in its matrix
+// section should win the issue arbitration against its SIMD partner's softmax / address arithmetic (guide T5)
+#ifndef ATTN_SETPRIO
+#define ATTN_SETPRIO 1
+#endif
+#define ATTN_PRIO(n) do { if (ATTN_SETPRIO) __builtin_amdgcn_s_setprio(n); } while (0)
 #define ATTN_MAX_TILES 128   // S <= 8192
 template <int D>
 struct AttnFwd2 {
@@ -763,10 +769,13 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 1) void attn_bwd_dq2_kernel(const
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
+            ATTN_PRIO(1);
+#pragma unroll
             for (int st = 0; st < 8; ++st) {
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(k_lds, kb * 32, 2 * st, lane), qf[st], s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(v_lds, kb * 32, 2 * st, lane), dof[st], dp, 0, 0, 0);
             }
+            ATTN_PRIO(0);
             if (need_mask) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -779,6 +788,7 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 1) void attn_bwd_dq2_kernel(const
                 const float pp = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], scale_log2, -L2));   // masked / L2=+inf -> 0
                 s[r] = pp * (dp[r] - dl) * scale;
             }
+            ATTN_PRIO(1);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const bf16x8 dsf = pack_frag(s, h);
@@ -787,6 +797,7 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 1) void attn_bwd_dq2_kernel(const
                 for (int db = 0; db < 4; ++db)
                     acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(k_lds, db * 32, ks, lane), dsf, acc[db], 0, 0, 0);
             }
+            ATTN_PRIO(0);
         }
     }
     if (qi < S) write_rows<D>(acc, 1.f, dq + (tok0 + qi) * (size_t)lddq + head * D, g);
@@ -865,10 +876,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(const bf16_t* __rest
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
+            ATTN_PRIO(1);
+#pragma unroll
             for (int st = 0; st < 8; ++st) {
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(q_lds, qb * 32, 2 * st, lane), kf[st], s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(do_lds, qb * 32, 2 * st, lane), vf[st], dp, 0, 0, 0);
             }
+            ATTN_PRIO(0);
             f32x16 pm;
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
@@ -886,6 +900,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(const bf16_t* __rest
                     s[r] = pv > 0.f ? pv * (dp[r] - dl[e]) * scale : 0.f;
                 }
             }
+            ATTN_PRIO(1);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const bf16x8 pf = pack_frag(pm, h);
@@ -897,6 +912,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(const bf16_t* __rest
                     adk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(q_lds, db * 32, ks, lane), dsf, adk[db], 0, 0, 0);
                 }
             }
+            ATTN_PRIO(0);
         }
     }
     if (ki < S) {
