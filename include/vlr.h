@@ -137,6 +137,19 @@ int vlr_dlogits_rows(const float* logits, const int* tgt, const float* lse, cons
                      const float* dlogps, int average, int R, int V, long ld, void* dlogits, long ldd,
                      vlr_stream_t stream);
 int vlr_seq_sum(const float* tok_logp, const int* seq_off, int nseq, int average, float* out, vlr_stream_t stream);
+/* Fused lm-head + log-softmax + label pick on the R response rows (SURVEY 8b `vlr_lmhead_logps_fwd/bwd`): hg [R][H] bf16 are the
+ * gathered final hidden states, w_lm [V][H]; tok_logp[r] = logit[r][tgt[r]] - lse[r].  When vlr_lmhead_is_fused(R, V, H) the [R][V]
+ * logits never reach HBM: the forward GEMM's epilogue leaves per-wave (max, sum exp) partials in `workspace`
+ * (vlr_lmhead_workspace_bytes) that a second kernel folds in a fixed order, the backward recomputes the GEMM and writes
+ * d logits [R][V] bf16 = g_r * ([v == tgt_r] - softmax) straight from its epilogue (g_r = dlogps of the row's sequence, / row count
+ * when `average`).  Otherwise `logits_ws` ([R][V] fp32) carries the logits through vlr_logp_rows / vlr_dlogits_rows. */
+long vlr_lmhead_workspace_bytes(int R, int V);
+int vlr_lmhead_is_fused(int R, int V, int H);
+int vlr_lmhead_logps_fwd(const void* hg, const void* w_lm, const int* tgt, float* tok_logp, float* lse, void* workspace,
+                         float* logits_ws, int R, int V, int H, vlr_stream_t stream);
+int vlr_lmhead_logps_bwd(const void* hg, const void* w_lm, const int* tgt, const float* lse, const int* seq_off, int nseq,
+                         const float* dlogps, int average, void* dlogits, void* workspace, float* logits_ws, int R, int V, int H,
+                         vlr_stream_t stream);
 
 /* ---- DPO loss, forward + backward (VLDPOTrainer.dpo_loss, base/trainer.py:244-301).
  * loss_type 0 sigmoid|ddpo, 1 hinge, 2 ipo, 3 kto_pair (losses has 2n entries).  dpc/dpr = d(sum_i g_i*loss_i)/d

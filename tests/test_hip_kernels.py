@@ -804,3 +804,40 @@ def test_gemm_swiglu_bwd_fused(hip, shape):
     hip.call("vlr_swiglu_bwd", gu2, ws, M, I)
     torch.cuda.synchronize()
     check(gu, gu2, 1.6e-2, f"fused vs unfused {shape}")
+
+
+@pytest.mark.parametrize("shape,average", [((2100, 8200, 512), False), ((2304, 32064, 256), True), ((300, 512, 128), False)])
+def test_lmhead_logps_fused(hip, shape, average):
+    """vlr_lmhead_logps_fwd / _bwd: fused lm-head + log-softmax pick (no [R][V] logits in HBM when the persistent kernel takes the
+    shape; V not a multiple of 256 -> a partial last column tile) against torch log_softmax and against the unfused entry points."""
+    R, V, H = shape
+    hg = rnd(R, H, seed=1)
+    w = rnd(V, H, scale=0.2, seed=2)
+    g = torch.Generator().manual_seed(3)
+    tgt = torch.randint(0, V, (R,), generator=g, dtype=torch.int32).to(DEV)
+    tgt[:4] = torch.tensor([0, V - 1, 255, 256], dtype=torch.int32)          # tile boundaries and the last valid column
+    nseq = 5
+    cuts = torch.sort(torch.randint(1, R, (nseq - 1,), generator=g)).values.tolist()
+    seq_off = torch.tensor([0] + cuts + [R], dtype=torch.int32, device=DEV)
+    dlogps = torch.randn(nseq, generator=g).to(DEV)
+    fused = bool(hip.helper("vlr_lmhead_is_fused", R, V, H))
+    assert fused == (R >= 2000)
+    ws = torch.empty(int(hip.lib().vlr_lmhead_workspace_bytes(R, V)), dtype=torch.uint8, device=DEV)
+    logits_ws = None if fused else torch.empty(R, V, dtype=torch.float32, device=DEV)
+    tok = torch.full((R,), float("nan"), device=DEV)
+    lse = torch.full((R,), float("nan"), device=DEV)
+    hip.call("vlr_lmhead_logps_fwd", hg, w, tgt, tok, lse, ws, logits_ws, R, V, H)
+    dl = torch.full((R, V), float("nan"), dtype=torch.bfloat16, device=DEV)
+    hip.call("vlr_lmhead_logps_bwd", hg, w, tgt, lse, seq_off, nseq, dlogps, int(average), dl, ws, logits_ws, R, V, H)
+    torch.cuda.synchronize()
+    logits = hg.float() @ w.float().t()
+    ref_lse = torch.logsumexp(logits, -1)
+    ref_tok = logits.gather(1, tgt.long()[:, None]).squeeze(1) - ref_lse
+    assert float((lse - ref_lse).abs().max()) < 2e-3 and float((tok - ref_tok).abs().max()) < 2e-3
+    seq = torch.bucketize(torch.arange(R, device=DEV), seq_off[1:].long(), right=True)
+    coef = dlogps[seq]
+    if average:
+        coef = coef / (seq_off[1:] - seq_off[:-1]).float()[seq]
+    ref_dl = coef[:, None] * (torch.nn.functional.one_hot(tgt.long(), V).float() - torch.softmax(logits, -1))
+    check(dl, ref_dl, 8e-3, f"lm-head d logits {shape}")
+    assert torch.isfinite(dl.float()).all()

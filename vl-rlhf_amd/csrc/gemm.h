@@ -37,6 +37,13 @@ struct GemmParams {
     const float* rope_sin;
     int max_pos;
     int rope_cols;
+    //  4 lm-head log-probs, forward (NT, A = response-row hidden states [R][H], B = lm_head [V][H]): no logits leave the kernel -
+    //    every wave reduces its 64 columns of a row to (max, sum exp) -> part[row][tile_n * 4 + wc][2] and the lane that owns the
+    //    row's target column stores that logit to f1[row]; `pos` = target ids.  A second kernel folds the partials (gemm.hip).
+    //  5 lm-head log-probs, backward: C (bf16 [R][V]) = f1[row] * ([col == target] - exp(logit - f0[row])), f0 = lse, f1 = dlogps
+    //    of the row's sequence (/ count when averaging)
+    float* f0;
+    float* f1;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -54,3 +61,6 @@ bool vlr_gemm256p_try_launch(int layout, const GemmParams& p, hipStream_t stream
 bool vlr_gemm256p_fused_try_launch(const GemmParams& p, hipStream_t stream);
 // fuse = 3 (NN): d act = dy . Wdown with the SwiGLU backward applied in the epilogue to gate | up in p.C2 (in place)
 bool vlr_gemm256p_swiglu_bwd_try_launch(const GemmParams& p, hipStream_t stream);
+// fuse = 4 | 5: the lm-head GEMM with the log-softmax statistics / the logits gradient in its epilogue
+bool vlr_gemm256p_lmhead_try_launch(const GemmParams& p, hipStream_t stream);
+int vlr_gemm256p_lmhead_parts(int V);      // partial (max, sum) pairs per row the fuse = 4 epilogue writes

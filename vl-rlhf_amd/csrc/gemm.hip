@@ -422,6 +422,7 @@ static int gemm_impl(int layout, const void* A, const void* B, void* C, const vo
     p.alpha = alpha;
     p.splitk = 1; p.kchunk = 0; p.part = nullptr;
     p.fuse = 0; p.store_c = 1; p.C2 = nullptr; p.ldc2 = 0; p.pos = nullptr; p.rope_cos = p.rope_sin = nullptr; p.max_pos = 0; p.rope_cols = 0;
+    p.f0 = p.f1 = nullptr;
     const int pi = vlr_prof_begin(layout, 2.0 * M * N * K, stream);
     // ---- split-K for problems whose output is a handful of tiles but whose reduction is long: the LoRA adapter gradients
     // (TN: dB = dy^T u [out x r], dA = v^T x [r x in], reduction over all tokens) - 32..96 workgroups would leave most CUs idle
@@ -495,6 +496,7 @@ static GemmParams fused_params(const void* A, const void* B, void* C, int M, int
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = 0;
     p.act = 0; p.accumulate = 0; p.out_f32 = 0; p.flags = 0; p.alpha = 1.f; p.splitk = 1; p.kchunk = 0; p.part = nullptr;
     p.fuse = 0; p.store_c = 1; p.C2 = nullptr; p.ldc2 = 0; p.pos = nullptr; p.rope_cos = p.rope_sin = nullptr; p.max_pos = 0; p.rope_cols = 0;
+    p.f0 = p.f1 = nullptr;
     return p;
 }
 
@@ -580,4 +582,95 @@ extern "C" int vlr_gemm_swiglu_bwd(const void* dy, const void* wdown, void* gu, 
         return vlr_swiglu_bwd((bf16_t*)gu + (size_t)done * 2 * I, da, M - done, I, stream);
     }
     return VLR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused lm-head + log-softmax pick (VLDPOTrainer.get_batch_logps on the response rows, reference base/trainer.py:148-188): the
+// [R][V] logits never reach HBM.  Forward: GEMM epilogue -> per-wave (max, sum exp) partials + the target logit, folded by
+// lmhead_fold_kernel into lse and tok_logp.  Backward: the GEMM is recomputed and its epilogue writes d logits (bf16) directly.
+// Shapes the persistent kernel does not take go through the fp32 logits buffer (`logits_ws`, [R][V] fp32) as before.
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int vlr_logp_rows(const float* logits, const int* row_idx, const int* tgt, int R, int V, long ld, float* tok_logp, float* lse,
+                             hipStream_t st);
+extern "C" int vlr_dlogits_rows(const float* logits, const int* tgt, const float* lse, const int* seq_off, int nseq, const float* dlogps,
+                                int average, int R, int V, long ld, void* dlogits, long ldd, hipStream_t st);
+
+__global__ __launch_bounds__(64) void lmhead_fold_kernel(const float* __restrict__ parts, int nparts, const float* __restrict__ tok_raw,
+                                                         float* __restrict__ tok_logp, float* __restrict__ lse) {
+    const int r = blockIdx.x, l = threadIdx.x;
+    const float* pr = parts + (size_t)r * nparts * 2;
+    float m = -INFINITY;
+    for (int i = l; i < nparts; i += 64) m = fmaxf(m, pr[2 * i]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int i = l; i < nparts; i += 64) {
+        const float mi = pr[2 * i];
+        if (mi > -INFINITY) s += pr[2 * i + 1] * __expf(mi - m);
+    }
+    s = wave_sum(s);                       // fixed order: deterministic
+    if (l == 0) {
+        const float z = m + logf(s);
+        lse[r] = z;
+        tok_logp[r] = tok_raw[r] - z;
+    }
+}
+// g[r] = dlogps[sequence of row r] (/ rows of the sequence when averaging)
+__global__ void lmhead_rowcoef_kernel(const int* __restrict__ seq_off, int nseq, const float* __restrict__ dlogps, int average, int R,
+                                      float* __restrict__ g) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    int b = 0;
+    while (b + 1 < nseq && seq_off[b + 1] <= r) ++b;
+    float v = dlogps[b];
+    if (average) v /= (float)(seq_off[b + 1] - seq_off[b]);
+    g[r] = v;
+}
+
+extern "C" long vlr_lmhead_workspace_bytes(int R, int V) { return ((long)R * vlr_gemm256p_lmhead_parts(V) * 2 + 2L * R) * 4; }
+
+// 1 if the fused kernels take (R, V, H): the caller then needs no fp32 logits buffer
+extern "C" int vlr_lmhead_is_fused(int R, int V, int H) {
+    const char* e = getenv("VLR_GEMM_FUSE");
+    if (e && !((atoi(e) >> 3) & 1)) return 0;
+    const long ntiles = (long)((R + 255) / 256) * ((V + 255) / 256);
+    return ntiles > 256 && H >= 256 && H % 8 == 0 && V % 8 == 0;
+}
+
+extern "C" int vlr_lmhead_logps_fwd(const void* hg, const void* w_lm, const int* tgt, float* tok_logp, float* lse, void* workspace,
+                                    float* logits_ws, int R, int V, int H, hipStream_t stream) {
+    VLR_REQUIRE(hg && w_lm && tgt && tok_logp && lse, "vlr_lmhead_logps_fwd: null operand");
+    VLR_REQUIRE(R > 0 && V % 8 == 0 && H % 8 == 0, "vlr_lmhead_logps_fwd: bad shape R=%d V=%d H=%d", R, V, H);
+    if (workspace && vlr_lmhead_is_fused(R, V, H)) {
+        const int nparts = vlr_gemm256p_lmhead_parts(V);
+        float* parts = (float*)workspace;
+        float* tok_raw = parts + (size_t)R * nparts * 2;
+        GemmParams p = fused_params(hg, w_lm, nullptr, R, V, H, H, H, V);
+        p.fuse = 4; p.pos = tgt; p.C2 = parts; p.f1 = tok_raw;
+        if (vlr_gemm256p_lmhead_try_launch(p, stream)) {
+            hipLaunchKernelGGL(lmhead_fold_kernel, dim3(R), dim3(64), 0, stream, (const float*)parts, nparts, (const float*)tok_raw, tok_logp, lse);
+            return vlr_check_launch("vlr_lmhead_logps_fwd(fused)");
+        }
+    }
+    VLR_REQUIRE(logits_ws, "vlr_lmhead_logps_fwd: this shape needs the fp32 logits buffer [R][V]");
+    int rc = gemm_impl(0, hg, w_lm, logits_ws, nullptr, nullptr, R, V, H, H, H, V, 0, 0, 0, 1, 1.0f, stream);
+    if (rc != VLR_OK) return rc;
+    return vlr_logp_rows(logits_ws, nullptr, tgt, R, V, V, tok_logp, lse, stream);
+}
+
+extern "C" int vlr_lmhead_logps_bwd(const void* hg, const void* w_lm, const int* tgt, const float* lse, const int* seq_off, int nseq,
+                                    const float* dlogps, int average, void* dlogits, void* workspace, float* logits_ws, int R, int V,
+                                    int H, hipStream_t stream) {
+    VLR_REQUIRE(hg && w_lm && tgt && lse && seq_off && dlogps && dlogits, "vlr_lmhead_logps_bwd: null operand");
+    VLR_REQUIRE(R > 0 && V % 8 == 0 && H % 8 == 0 && nseq > 0, "vlr_lmhead_logps_bwd: bad shape R=%d V=%d H=%d", R, V, H);
+    if (workspace && vlr_lmhead_is_fused(R, V, H)) {
+        float* coef = (float*)workspace + (size_t)R * vlr_gemm256p_lmhead_parts(V) * 2 + R;
+        hipLaunchKernelGGL(lmhead_rowcoef_kernel, dim3((R + 255) / 256), dim3(256), 0, stream, seq_off, nseq, dlogps, average, R, coef);
+        GemmParams p = fused_params(hg, w_lm, dlogits, R, V, H, H, H, V);
+        p.fuse = 5; p.pos = tgt; p.f0 = const_cast<float*>(lse); p.f1 = coef;
+        if (vlr_gemm256p_lmhead_try_launch(p, stream)) return vlr_check_launch("vlr_lmhead_logps_bwd(fused)");
+    }
+    VLR_REQUIRE(logits_ws, "vlr_lmhead_logps_bwd: this shape needs the fp32 logits buffer [R][V]");
+    int rc = gemm_impl(0, hg, w_lm, logits_ws, nullptr, nullptr, R, V, H, H, H, V, 0, 0, 0, 1, 1.0f, stream);
+    if (rc != VLR_OK) return rc;
+    return vlr_dlogits_rows(logits_ws, tgt, lse, seq_off, nseq, dlogps, average, R, V, V, dlogits, V, stream);
 }

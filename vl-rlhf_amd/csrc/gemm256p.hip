@@ -194,7 +194,7 @@ __device__ __forceinline__ int widen_col(int lq) { return (lq & 1) * 16 + (lq >>
 // accumulator registers (8 bytes per lane, no LDS, no barrier) and the K loop of tile i+1 starts with its data resident.
 template <bool A_KS, bool B_KS, int ABL = 0, bool CONT = false, int FUSE = 0>
 __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_t* __restrict__ zero16) {
-    static_assert(FUSE == 0 || (CONT && !A_KS && (FUSE == 3 ? B_KS : !B_KS)), "fused epilogues: continuous pipeline; 1, 2 NT, 3 NN");
+    static_assert(FUSE == 0 || (CONT && !A_KS && (FUSE == 3 ? B_KS : !B_KS)), "fused epilogues: continuous pipeline; 1, 2, 4, 5 NT, 3 NN");
     constexpr int NW = FUSE == 1 ? 128 : PT;      // output columns (of the gate half, for SwiGLU) per workgroup tile
     extern __shared__ __attribute__((aligned(16))) char smem[];   // P_LDS_BYTES
     const int t = threadIdx.x;
@@ -498,6 +498,78 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                 const u32x4 wh = widen_pair(h[0], h[1]);
                 if (ok) *reinterpret_cast<u32x4*>(C2 + (size_t)gm * p.ldc2 + gn) = wh;
             }
+    } else if constexpr (CONT && FUSE == 4) {
+        // lm-head forward: per row, this wave's 64 columns (wc*32..+32 of both B halves) -> (max, sum exp) partial + the target logit
+        const int lm_ = lane & 15, lq_ = lane >> 4;
+        const int nparts = tiles_n * 4;
+        const int part = (n0 / PT) * 4 + wc;
+        float* __restrict__ parts = reinterpret_cast<float*>(p.C2);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int gm = m0 + a * 128 + wr * 64 + i * 16 + lm_;
+                const int tg = gm < p.M ? p.pos[gm] : -1;
+                float mx = -INFINITY;
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int gn = n0 + b * 128 + wc * 32 + j * 16 + 4 * lq_;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float v = acc[a][i][b][j][e];
+                            if (gn + e < p.N) mx = fmaxf(mx, v);
+                            if (gn + e == tg) p.f1[gm] = v;               // exactly one lane of one workgroup owns the target column
+                        }
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                float sm = 0.f;
+                if (mx > -INFINITY) {
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int gn = n0 + b * 128 + wc * 32 + j * 16 + 4 * lq_;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (gn + e < p.N) sm += __expf(acc[a][i][b][j][e] - mx);
+                        }
+                }
+                sm += __shfl_xor(sm, 16);
+                sm += __shfl_xor(sm, 32);
+                if (lq_ == 0 && gm < p.M) {
+                    f32x2 o = {mx, sm};
+                    *reinterpret_cast<f32x2*>(parts + ((size_t)gm * nparts + part) * 2) = o;
+                }
+            }
+    } else if constexpr (CONT && FUSE == 5) {
+        // lm-head backward: d logits = g_row * ([col == target] - exp(logit - lse_row)), rounded once, 16-byte stores
+        bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+        const int lm_ = lane & 15, lq_ = lane >> 4;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int gm = m0 + a * 128 + wr * 64 + i * 16 + lm_;
+                const int gmc = gm < p.M ? gm : p.M - 1;
+                const int tg = p.pos[gmc];
+                const float z = p.f0[gmc], g = p.f1[gmc];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    f32x4 d[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int gn0 = n0 + b * 128 + wc * 32 + j * 16 + 4 * lq_;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) d[j][e] = g * ((gn0 + e == tg ? 1.f : 0.f) - __expf(acc[a][i][b][j][e] - z));
+                    }
+                    const int gn = n0 + b * 128 + wc * 32 + widen_col(lq_);
+                    const u32x4 w = widen_pair(d[0], d[1]);
+                    if (gm < p.M && gn + 8 <= p.N) *reinterpret_cast<u32x4*>(C + (size_t)gm * p.ldc + gn) = w;
+                }
+            }
     } else if constexpr (CONT && FUSE == 3) {
         // SwiGLU backward epilogue (dgrad of the down projection, NN): acc = d act [rows][cols of I]; gate | up of the forward sit in
         // C2 [M][2I] and are overwritten IN PLACE with d gate | d up (each element is read and written by the same lane)
@@ -799,6 +871,31 @@ bool vlr_gemm256p_swiglu_bwd_try_launch(const GemmParams& p, hipStream_t stream)
     if ((((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.C2) & 15) || p.lda % 8 != 0 || p.ldb % 8 != 0 || p.N % 8 != 0 || p.ldc2 % 8 != 0) return false;
     const int pi = vlr_prof_begin(VLR_K_GEMM256P, 2.0 * p.M * p.N * p.K, stream);
     hipLaunchKernelGGL((gemm256p_kernel<false, true, 0, true, 3>), dim3(n_cu), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
+    vlr_prof_end(pi, stream);
+    return true;
+}
+
+int vlr_gemm256p_lmhead_parts(int V) { return ((V + PT - 1) / PT) * 4; }
+
+bool vlr_gemm256p_lmhead_try_launch(const GemmParams& p, hipStream_t stream) {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("VLR_GEMM_FUSE");
+        on = e ? ((atoi(e) >> 3) & 1) : 1;               // bit 3
+        hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, 0, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+        hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, 0, true, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+    }
+    if (!on || (p.fuse != 4 && p.fuse != 5)) return false;
+    bf16_t* zero16 = gemm256p_zero16();
+    if (!zero16) return false;
+    const int n_cu = gemm256p_n_cu();
+    const int ntiles = ((p.M + PT - 1) / PT) * ((p.N + PT - 1) / PT);
+    if (ntiles <= n_cu || p.K < 4 * PK) return false;
+    if ((((uintptr_t)p.A | (uintptr_t)p.B) & 15) || p.lda % 8 != 0 || p.ldb % 8 != 0 || p.N % 8 != 0) return false;
+    if (p.fuse == 5 && (p.ldc % 8 != 0 || ((uintptr_t)p.C & 15))) return false;
+    const int pi = vlr_prof_begin(VLR_K_GEMM256P, 2.0 * p.M * p.N * p.K, stream);
+    if (p.fuse == 4) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 4>), dim3(n_cu), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
+    else hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 5>), dim3(n_cu), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
     vlr_prof_end(pi, stream);
     return true;
 }

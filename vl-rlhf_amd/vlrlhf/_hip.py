@@ -88,6 +88,8 @@ _SIGS = {
     "vlr_logp_rows": [P, P, P, I, I, L, P, P, P],
     "vlr_dlogits_rows": [P, P, P, P, I, P, I, I, I, L, P, L, P],
     "vlr_seq_sum": [P, P, I, I, P, P],
+    "vlr_lmhead_logps_fwd": [P, P, P, P, P, P, P, I, I, I, P],
+    "vlr_lmhead_logps_bwd": [P, P, P, P, P, I, P, I, P, P, P, I, I, I, P],
     "vlr_dpo_loss": [P, P, P, P, I, F, F, I, I, P, P, P, P, P, P, P, P],
     "vlr_grad_sqnorm": [P, L, F, F, F, P, P, P],
     "vlr_adamw_step": [P, P, P, P, P, L, F, F, F, F, F, I, P, P],
@@ -113,6 +115,7 @@ _INT_HELPERS = {
     "vlr_prof_enable": [I],
     "vlr_prof_collect": [P, I],
     "vlr_gemm_set_splitk_workspace": [P, L],
+    "vlr_lmhead_is_fused": [I, I, I],
     "vlr_comm_unique_id_bytes": [],
     "vlr_comm_unique_id": [P],
     "vlr_comm_init": [P, I, I, P],
@@ -136,6 +139,8 @@ def lib():
         l.vlr_last_error.argtypes = []
         l.vlr_comm_library.restype = C.c_char_p
         l.vlr_comm_library.argtypes = []
+        l.vlr_lmhead_workspace_bytes.restype = C.c_long
+        l.vlr_lmhead_workspace_bytes.argtypes = [I, I]
         for name, sig in _SIGS.items():
             fn = getattr(l, name)
             fn.restype = I
@@ -149,7 +154,7 @@ def lib():
 
 
 def exported_symbols():
-    return list(_SIGS) + list(_INT_HELPERS) + ["vlr_last_error", "vlr_comm_library"]
+    return list(_SIGS) + list(_INT_HELPERS) + ["vlr_last_error", "vlr_comm_library", "vlr_lmhead_workspace_bytes"]
 
 
 def ptr(t):

@@ -598,11 +598,14 @@ class LlavaHipEngine:
             return logps, lp
         hg = torch.empty(R, H, dtype=BF16, device=self.dev)
         _hip.call("vlr_gather_rows", ctx["hidden"], rows, hg, R, H)
-        logits = self._buf(("logits", ctx["tag"], R), (R, V), torch.float32)    # per pass: the reference pass runs on a side stream
-        _hip.call("vlr_gemm_bf16", 0, hg, ws.v["lm_head"], logits, None, None, R, V, H, H, H, V, 0, 0, 0, 1)
+        # fused lm-head + log-softmax pick: at the 7B shapes the [R][V] logits never reach HBM (include/vlr.h); small shapes go
+        # through an fp32 logits buffer (per pass tag: the reference pass runs on a side stream)
+        fused = bool(_hip.helper("vlr_lmhead_is_fused", R, V, H))
+        lws = self._buf(("lmhead_ws", ctx["tag"], R), (int(_hip.lib().vlr_lmhead_workspace_bytes(R, V)),), torch.uint8)
+        logits = None if fused else self._buf(("logits", ctx["tag"], R), (R, V), torch.float32)
         tok = torch.empty(R, dtype=torch.float32, device=self.dev)
         lse = torch.empty(R, dtype=torch.float32, device=self.dev)
-        _hip.call("vlr_logp_rows", logits, None, tgt, R, V, V, tok, lse)
+        _hip.call("vlr_lmhead_logps_fwd", hg, ws.v["lm_head"], tgt, tok, lse, lws, logits, R, V, H)
         _hip.call("vlr_seq_sum", tok, seq_off, Bn, int(average), logps)
         lp.update(hg=hg, lse=lse, tok=tok)
         return logps, lp
@@ -646,12 +649,13 @@ class LlavaHipEngine:
             if not acc and self.lora is None:
                 self.gv["lm_head"].zero_()
             return dhidden
-        logits = self._buf(("logits", ctx["tag"], R), (R, V), torch.float32)
-        # recompute the logits of the response rows: a later forward of the same pass tag may have reused the buffer
-        _hip.call("vlr_gemm_bf16", 0, lp["hg"], ctx["ws"].v["lm_head"], logits, None, None, R, V, H, H, H, V, 0, 0, 0, 1)
+        # d logits (bf16 [R][V]): the lm-head GEMM is recomputed and its epilogue writes the gradient directly (fused shapes)
+        fused = bool(_hip.helper("vlr_lmhead_is_fused", R, V, H))
+        lws = self._buf(("lmhead_ws", ctx["tag"], R), (int(_hip.lib().vlr_lmhead_workspace_bytes(R, V)),), torch.uint8)
+        logits = None if fused else self._buf(("logits", ctx["tag"], R), (R, V), torch.float32)
         dl = self._buf(("dlogits", R), (R, V))
-        _hip.call("vlr_dlogits_rows", logits, lp["tgt"], lp["lse"], lp["seq_off"], ctx["Bn"],
-                  dlogps.to(torch.float32).contiguous(), int(lp["average"]), R, V, V, dl, V)
+        _hip.call("vlr_lmhead_logps_bwd", lp["hg"], ctx["ws"].v["lm_head"], lp["tgt"], lp["lse"], lp["seq_off"], ctx["Bn"],
+                  dlogps.to(torch.float32).contiguous(), int(lp["average"]), dl, lws, logits, R, V, H)
         dhg = torch.empty(R, H, dtype=BF16, device=self.dev)
         _hip.call("vlr_gemm_bf16", 1, dl, ctx["ws"].v["lm_head"], dhg, None, None, R, H, V, V, H, H, 0, 0, 0, 0)
         if self.lora is None:                 # under LoRA the lm_head is frozen (not a target module)
