@@ -35,7 +35,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2516.6          # 256 CU x 4096 FLOP/clk/CU x 2.4 GHz (MI355X_MICROARCH.md: ~2.5 PF dense)
-PROFILE_FILE = "profiles/r02_rocprofv3_kernel_stats_bench.txt"   # rocprofv3 --kernel-trace --stats of this command; `frac` can be recomputed from it
+PROFILE_FILE = "profiles/r02_rocprofv3_kernel_stats_bench.csv"   # rocprofv3 --kernel-trace --stats of this command; `frac` can be recomputed from it
 TFLOP_PER_PAIR = {"ref_in_step": 174.87, "ref_precomputed": 131.24}
 
 
@@ -271,9 +271,11 @@ def main():
         exposed_ms = round((dt / a.steps - float(t2)) * 1e3, 2)
         reducer.enabled = True
     # HBM traffic of the dominant kernel: PMC passes cannot run inside the timed region; the committed rocprofv3 --pmc
-    # result (profiles/r01_pmc_hbm_traffic_8phase.*, tools/pmc_traffic.sh) is quoted when present
+    # result (profiles/r02_pmc_hbm_traffic.*, tools/pmc_traffic.sh) is quoted when present
     traffic = None
-    tf = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_8phase.json")
+    tf = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
+    if not os.path.exists(tf):
+        tf = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_8phase.json")
     if os.path.exists(tf):
         traffic = round(json.load(open(tf))["gemm_hbm_bytes_per_launch"])
     # roofline of the DOMINANT kernel: the 8-phase 256x256 GEMM alone (its launches are timed under their own id; the
@@ -319,7 +321,8 @@ def main():
                          "algorithmic_bytes_per_launch": round(2.0 * g_bytes / max(1, g_dec)), "launches": g_n, "avg_launch_ms": round(g_ms / max(1, g_n), 4), "per_kernel": per_kernel,
                          "profile_file": PROFILE_FILE,
                          "kernel_share_of_step": round(g_ms * 1e-3 / dt, 3), "all_gemm_share_of_step": round(all_ms * 1e-3 / dt, 3),
-                         "step_frac": round(pairs_per_s / world * per_pair / PEAK_BF16_TFLOPS, 4)},
+                         "step_frac": round(pairs_per_s / world * per_pair / PEAK_BF16_TFLOPS, 4),
+                         "step_frac_note": "algorithmic TFLOP per pair of SURVEY.md 8d (lm-head counted on all S positions; the kernel evaluates it on the response rows only, ~1.3 % fewer executed FLOPs) / nominal 2516.6 TF/s; this chip sustains 1828 TF/s on random bf16 operands in a register-only MFMA loop (profiles/r02_gemm_ceiling_mfma_only_and_ablation.txt)"},
         }
         if a.layers:
             line["INVALID"] = "reduced layer count (debug run)"

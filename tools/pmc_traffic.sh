@@ -2,7 +2,7 @@
 # HBM traffic of every kernel of one DPO step: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in SEPARATE passes (guide: TCC slots),
 # bytes = 2*FETCH_SIZE + WRITE_SIZE (KiB; gfx950 FETCH_SIZE counts half of a wide coalesced read - MI355X_MICROARCH.md, HBM).
 # Writes gpurun_out/pmc_hbm_traffic.{txt,json}; copy them to profiles/ to have them judged.
-cd /root/repo
+cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 for c in FETCH_SIZE WRITE_SIZE; do
