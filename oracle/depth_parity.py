@@ -82,8 +82,63 @@ def run(case, variants, cfg, log):
     return spec, out
 
 
+GRAD_LAYERS = (0, 17, 31)
+
+
+class _Leaves:
+    """HashedWeights with a few tensors replaced by autograd leaves (the weight gradients of the other ~280 tensors are never formed)"""
+
+    def __init__(self, base, names):
+        self.base = base
+        self.leaves = {n: base[n].clone().requires_grad_(True) for n in names}
+
+    def __getitem__(self, k):
+        return self.leaves[k] if k in self.leaves else self.base[k]
+
+    def __contains__(self, k):
+        return k in self.base
+
+    def keys(self):
+        return self.base.keys()
+
+
+def run_grads(cfg, log):
+    """fp32 gradients of the DPO loss of the `small` case w.r.t. every weight of decoder layers 0, 17, 31, the final norm and the
+    lm-head: per tensor the Frobenius norm and a 256-element probe -> tests/golden/llava7b_depth<L>_small_grads.json"""
+    spec = CASES["small"]
+    batch = O.synthetic_batch(spec["pairs"], spec["text_len"], cfg["image_token"], 32000, cfg["image_size"], spec["seed"], ragged=spec["ragged"])
+    Wr = O.HashedWeights(cfg, seed=0, cache=True)
+    Wp = O.HashedWeights(cfg, seed=0, delta=1e-3, seed_delta=1, cache=True)
+    L = cfg["layers"]
+    names = ["language_model.model.norm.weight", "language_model.lm_head.weight"]
+    for l in sorted(set(min(x, L - 1) for x in GRAD_LAYERS)):
+        p = f"language_model.model.layers.{l}."
+        names += [p + n for n in ("self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight", "self_attn.o_proj.weight",
+                                  "mlp.gate_proj.weight", "mlp.up_proj.weight", "mlp.down_proj.weight", "input_layernorm.weight",
+                                  "post_attention_layernorm.weight")]
+    t0 = time.time()
+    WL = _Leaves(Wp, names)
+    loss, _ = O.compute_loss(WL, Wr, cfg, batch, 0.1)
+    log(f"grads: forward done, loss {float(loss):.7f} [{time.time() - t0:.0f} s]")
+    loss.backward()
+    out = {}
+    for n in names:
+        g = WL.leaves[n].grad
+        flat = g.reshape(-1)
+        stride = max(1, flat.numel() // 256)
+        out[n] = dict(norm=float(g.double().norm()), stride=stride, probe=flat[::stride][:256].tolist())
+    log(f"grads: backward done [{time.time() - t0:.0f} s]")
+    path = os.path.join(ROOT, "tests", "golden", f"llava7b_depth{L}_small_grads.json")
+    with open(path, "w") as f:
+        json.dump(dict(layers=L, spec=spec, loss=float(loss), grads=out), f)
+    log(f"grads -> {path}")
+
+
 def main():
     case = sys.argv[1] if len(sys.argv) > 1 else "small"
+    if case == "grads":
+        layers = int(os.environ.get("VLR_DEPTH_LAYERS", "32"))
+        return run_grads(dict(O.LLAVA_1_5_7B, layers=layers), lambda s_: print(s_, flush=True))
     layers = int(os.environ.get("VLR_DEPTH_LAYERS", "32"))
     cfg = dict(O.LLAVA_1_5_7B, layers=layers)
     variants = VARIANTS if case == "small" else VARIANTS[:2]

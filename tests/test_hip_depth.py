@@ -144,3 +144,51 @@ def test_depth32_configs0_shape_vs_fp32_oracle(full32):
     assert abs(float(loss) - got["loss"]) < 1e-6
     n = model.engine.grad_norm()
     assert math.isfinite(n) and n > 1e-4
+
+
+def _check_grads(model, g, label):
+    named = dict(model.named_parameters())
+    worst_cos, worst_norm = 1.0, 0.0
+    for name, e in g["grads"].items():
+        hip = named[name].grad.float().reshape(-1)
+        norm = float(hip.double().norm())
+        probe = hip[:: e["stride"]][:256].cpu()
+        want = torch.tensor(e["probe"])
+        cs = float(torch.dot(probe, want) / (probe.norm() * want.norm() + 1e-30))
+        nr = abs(norm / e["norm"] - 1.0)
+        worst_cos, worst_norm = min(worst_cos, cs), max(worst_norm, nr)
+        assert cs > 0.9, f"{label} {name}: gradient probe cosine {cs:.3f} vs the fp32 oracle"
+        assert nr < 0.15, f"{label} {name}: gradient norm {norm:.4g} vs {e['norm']:.4g}"
+    print(f"[depth grads {label}] {len(g['grads'])} tensors: worst probe cosine {worst_cos:.4f}, worst norm deviation {worst_norm:.3f}")
+
+
+def _grad_case(layers, label):
+    from vlrlhf.utils.synthetic import synthetic_batch
+    g = _golden(f"llava7b_depth{layers}_small_grads")
+    cfg, model, ref, tr = _build(layers)
+    sp = g["spec"]
+    batch = tr._prepare_inputs(synthetic_batch(sp["pairs"], sp["text_len"], cfg["image_token"], 32000, cfg["image_size"], sp["seed"], ragged=sp["ragged"]))
+    model.engine.zero_grad()
+    loss = tr.training_step(model, batch)
+    torch.cuda.synchronize()
+    assert abs(float(loss) - g["loss"]) < 2e-2
+    _check_grads(model, g, label)
+    del model, ref, tr
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def test_depth2_gradients_vs_fp32_oracle():
+    """BACKWARD at the true widths: weight gradients of both layers, the final norm and the lm-head against fp32 autograd of the oracle"""
+    _grad_case(2, "L2")
+
+
+def test_depth32_gradients_vs_fp32_oracle():
+    """BACKWARD at full depth: the gradients that have travelled through 31, 14 and 0 further layers (layers 0, 17, 31), the final
+    norm and the lm-head, against fp32 autograd of the oracle on the same 7B model (norm within 15 %, 256-element probe cosine > 0.9)"""
+    if torch.cuda.mem_get_info()[1] < 200 * (1 << 30):
+        pytest.skip("needs a 288 GB device")
+    if not os.path.exists(os.path.join(GOLDEN, "llava7b_depth32_small_grads.json")):
+        pytest.skip("golden not generated yet (python oracle/depth_parity.py grads)")
+    _grad_case(32, "L32")
