@@ -602,10 +602,12 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                     float d[8], g[8], u[8], dg[8], du[8];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, acc[a][i][b][0][e]),
-                                                                         __builtin_bit_cast(uint32_t, acc[a][i][b][1][e]), false, false);
-                        d[e] = __builtin_bit_cast(float, sw[0]);
-                        d[4 + e] = __builtin_bit_cast(float, sw[1]);
+                        // inline asm, one swap per element: the builtin on the four fp32 lanes of an accumulator was folded into a
+                        // single swap by hipcc 7.2 (all eight values came out equal to element 0)
+                        float x0 = acc[a][i][b][0][e], x1 = acc[a][i][b][1][e];
+                        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x0), "+v"(x1));   // nops: VALU-write -> swap-read and swap-write -> VALU-read hazards are not tracked through inline asm
+                        d[e] = x0;
+                        d[4 + e] = x1;
                     }
                     unpack8(gq[i][b], g);
                     unpack8(uq[i][b], u);
