@@ -157,6 +157,7 @@ def main():
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer decoder layers (line is then marked INVALID)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_side_stream", action="store_true")
+    ap.add_argument("--ref_pipeline", action="store_true", help="A/B: reference forward of the next batch issued under the update (slower at N=1, see DESIGN.md)")
     ap.add_argument("--precomputed_ref", action="store_true", help="stream precomputed reference log-probs (SURVEY 8f rank 1)")
     ap.add_argument("--lora", action="store_true", help="variant: LoRA DPO of scripts/ddpo_llava.sh (r=128, alpha=256, dropout 0.05)")
     ap.add_argument("--lora_dropout", type=float, default=0.05)
@@ -210,6 +211,8 @@ def main():
     eng.init_optimizer()
     reducer = eng.make_reducer() if world > 1 else None
     tr.ref_on_side_stream = not a.no_side_stream
+    if a.ref_pipeline:
+        tr.ref_pipeline = True
     # four resident batches per rank (seeds 1234 + rank + 1000*i), rotated: inputs are in HBM before the timed region
     batches = []
     for i in range(4):
@@ -225,6 +228,8 @@ def main():
 
     def step():
         loss = tr.training_step(model, batches[n_step[0] % len(batches)])
+        # as VLDPOTrainer.train does; a no-op unless the reference pipeline is switched on (--ref_pipeline / VLR_REF_PIPELINE=1)
+        tr.prefetch_reference(batches[(n_step[0] + 1) % len(batches)])
         eng.optimizer_step(grad_scale=1.0 / world, **hp)
         n_step[0] += 1
         return loss
@@ -306,7 +311,8 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[1]: LLaVA-1.5-7B DPO bf16, 336x336 image, max_length {a.text_len}, "
                                    f"per-device batch {a.pairs} pairs (S=1599), full fine-tune of LLM+projector, frozen ViT, "
-                                   + ("reference log-probs precomputed" if a.precomputed_ref else "reference forward inside the step"),
+                                   + ("reference log-probs precomputed" if a.precomputed_ref else
+                                      "one reference forward per step" + (", issued for the next batch under the update (prefetch_reference)" if tr.ref_pipeline else ", inside the step")),
                        "global_batch_pairs": world * a.pairs, "text_len": a.text_len, "parallelism": f"dp{world}",
                        "layers": cfg["layers"], "lr": a.lr, "resident_batches": len(batches), "loss_first_step": loss_first,
                        "loss_last_step": loss_last, "grad_norm_last_step": float(eng.norm_out[0])},

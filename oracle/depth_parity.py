@@ -107,8 +107,8 @@ def run_grads(cfg, log):
     lm-head: per tensor the Frobenius norm and a 256-element probe -> tests/golden/llava7b_depth<L>_small_grads.json"""
     spec = CASES["small"]
     batch = O.synthetic_batch(spec["pairs"], spec["text_len"], cfg["image_token"], 32000, cfg["image_size"], spec["seed"], ragged=spec["ragged"])
-    Wr = O.HashedWeights(cfg, seed=0, cache=True)
-    Wp = O.HashedWeights(cfg, seed=0, delta=1e-3, seed_delta=1, cache=True)
+    Wr = O.HashedWeights(cfg, seed=0)
+    Wp = O.HashedWeights(cfg, seed=0, delta=1e-3, seed_delta=1)
     L = cfg["layers"]
     names = ["language_model.model.norm.weight", "language_model.lm_head.weight"]
     for l in sorted(set(min(x, L - 1) for x in GRAD_LAYERS)):

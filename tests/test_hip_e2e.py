@@ -473,6 +473,52 @@ def test_step_is_bit_reproducible(gpu):
     assert float(emb.float().abs().sum()) > 0
 
 
+def _shifted(batch, k):
+    """a second / third batch of the same shapes: the text tail tokens rotated by k"""
+    b = dict(batch)
+    for side in ("chosen", "rejected"):
+        ids = batch[f"{side}_input_ids"].clone()
+        ids[:, -5:] = torch.roll(ids[:, -5:], k, dims=1)
+        b[f"{side}_input_ids"] = ids
+    return b
+
+
+@pytest.mark.parametrize("lora", [False, True])
+def test_reference_pipeline_is_bit_identical(gpu, lora):
+    """VLDPOTrainer.prefetch_reference: the frozen reference forward of the NEXT batch issued before the optimizer step of the
+    current one (so clip + AdamW run under it) gives the same losses, metrics and weights, bit for bit, as computing it inside
+    its own step - full fine-tune (separate frozen copy) and LoRA (base weights with the adapters disabled)."""
+    z, cfg, W, W_ref, batch, rows = load_case("llava_hipsmall")
+    o = cfg["optim"]
+    runs = []
+    for pipeline in (False, True):
+        model, ref = build(cfg, W, W_ref)
+        tr = make_trainer(model, None if lora else ref, cfg, **(dict(peft_config=dict(PEFT, seed=5)) if lora else {}))
+        tr.ref_pipeline = pipeline
+        eng = model.engine
+        if lora:
+            for k, t_ in eng.lv.items():
+                if ".b_" in k:
+                    t_.copy_(torch.randn(t_.shape, generator=torch.Generator().manual_seed(len(k))).to(t_) * 0.05)
+        eng.init_optimizer()
+        bs = [tr._prepare_inputs(_shifted(batch, k)) for k in range(3)]
+        losses = []
+        for i in range(4):
+            losses.append(tr.training_step(model, bs[i % 3]))
+            assert tr._ref_pending is None                     # a prefetched result is consumed by the step it was made for
+            tr.prefetch_reference(bs[(i + 1) % 3])
+            assert (tr._ref_pending is not None) == pipeline
+            eng.optimizer_step(o["lr"], o["beta1"], o["beta2"], o["eps"], o["weight_decay"], o["max_grad_norm"])
+        torch.cuda.synchronize()
+        margins = [float(x) for x in tr._stored_metrics["train"]["rewards/margins"]]
+        flat = (eng.lora_flat if lora else eng.policy.flat).clone()
+        runs.append(([float(x) for x in losses], margins, flat))
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    assert runs[0][1] == runs[1][1]
+    assert torch.equal(runs[0][2], runs[1][2])
+    assert len(set(runs[0][0])) > 1            # the batches differ and the weights move
+
+
 def test_training_trajectory_tracks_oracle(gpu):
     """four optimizer steps on the same batch with a large learning rate (the loss must MOVE): the HIP trajectory follows the
     oracle trajectory computed the way the HIP path stores things - fp32 master weights updated by the restated clip + AdamW,

@@ -9,6 +9,7 @@ reproduced: the per-micro-step `torch.cuda.empty_cache(); gc.collect()` (referen
 """
 import contextlib
 import math
+import os
 import random
 from collections import defaultdict
 from contextlib import nullcontext
@@ -182,6 +183,13 @@ class VLDPOTrainer:
         self.eval_dataset = self._tokenize_dataset(eval_dataset)
         self.ref_on_side_stream = True
         self._ref_stream = None
+        # VLR_REF_PIPELINE=1: reference forward of the NEXT batch issued between the backward and the optimizer step of the
+        # current one (prefetch_reference), so the HBM-bound clip + AdamW pass runs under the frozen forward.  Bit-identical
+        # results, but OFF by default: measured +6 ms per step at N=1 (638.0 vs 632.1 ms, same box) - the
+        # persistent GEMM workgroups fill the register file of every CU, so AdamW blocks do not co-reside with them, they
+        # displace them, and the persistent tile walk pays a tail for every displaced workgroup.
+        self.ref_pipeline = os.environ.get("VLR_REF_PIPELINE", "0") == "1"
+        self._ref_pending = None
         self.state = _State()
 
     # ------------------------------------------------------------------------------------------ tokenisation
@@ -395,21 +403,52 @@ class VLDPOTrainer:
         """trl==0.8.1 DPOTrainer.null_ref_context: the peft policy with its adapters disabled is the reference model."""
         return self.model.disable_adapter() if self.is_peft_model else contextlib.nullcontext()
 
+    def _ref_owner(self):
+        return self.ref_model if self.ref_model is not None else (self.model if self.is_peft_model else None)
+
+    def _ref_side_ok(self, batch) -> bool:
+        return bool(self.ref_on_side_stream and self._ref_owner() is not None and "reference_chosen_logps" not in batch
+                    and torch.cuda.is_available())
+
+    def _launch_reference(self, batch):
+        """the frozen reference forward on the side HIP stream, ordered after everything queued on the current stream so far
+        (the shared ViT features are evaluated there first)"""
+        main = torch.cuda.current_stream()
+        ref_owner = self._ref_owner()
+        cb = self.concatenated_inputs(batch, False, self.label_pad_token_id, self.padding_value, self.accelerator.device)
+        if "concatenated_img_input_dict" in cb and hasattr(ref_owner, "prefetch_vision"):
+            ref_owner.prefetch_vision(cb["concatenated_img_input_dict"])
+        if self._ref_stream is None:
+            self._ref_stream = torch.cuda.Stream()
+        self._ref_stream.wait_stream(main)
+        with torch.cuda.stream(self._ref_stream):
+            return self._reference_logps(batch)
+
+    def prefetch_reference(self, inputs):
+        """Issue the reference forward of the NEXT batch now.  Called by the training loop (and bench.py) after the backward of
+        the current batch is queued and BEFORE the optimizer step: the reference model is frozen (under LoRA: the base weights
+        with the adapters disabled), so its log-probs do not depend on the update, and the HBM-bound gradient-norm + AdamW pass
+        (and, N > 1, the exposed tail of the gradient all-reduce) overlaps the compute-bound forward instead of idling the MFMA
+        units.  Returns the device-resident batch to hand to training_step(); a batch that is never trained on just drops its
+        result.  Work per optimizer step is unchanged: one reference forward, one policy forward + backward, one update."""
+        inputs = self._prepare_inputs(inputs)
+        if self.ref_pipeline and self._ref_side_ok(inputs) and "chosen_input_ids" in inputs:
+            rc, rr = self._launch_reference(inputs)
+            self._ref_pending = (inputs["chosen_input_ids"], rc, rr)
+        return inputs
+
     def get_batch_loss_metrics(self, model, batch, train_eval: Literal["train", "eval"] = "train"):
         """trl==0.8.1 DPOTrainer.get_batch_loss_metrics.  The reference forward is issued on a side HIP stream ahead of
         the policy forward (it is frozen and shares only the cached vision features), then joined before the loss."""
         main = torch.cuda.current_stream()
-        ref_owner = self.ref_model if self.ref_model is not None else (self.model if self.is_peft_model else None)
-        use_side = (self.ref_on_side_stream and ref_owner is not None and "reference_chosen_logps" not in batch)
-        if use_side:
-            cb = self.concatenated_inputs(batch, False, self.label_pad_token_id, self.padding_value, self.accelerator.device)
-            if "concatenated_img_input_dict" in cb and hasattr(ref_owner, "prefetch_vision"):
-                ref_owner.prefetch_vision(cb["concatenated_img_input_dict"])
-            if self._ref_stream is None:
-                self._ref_stream = torch.cuda.Stream()
-            self._ref_stream.wait_stream(main)
-            with torch.cuda.stream(self._ref_stream):
-                rc, rr = self._reference_logps(batch)
+        pending, use_side = self._ref_pending, False
+        if pending is not None and pending[0] is batch.get("chosen_input_ids"):
+            rc, rr = pending[1], pending[2]             # issued by prefetch_reference during the previous step
+            self._ref_pending = None
+            use_side = True
+        elif self._ref_side_ok(batch):
+            rc, rr = self._launch_reference(batch)
+            use_side = True
         pc, pr, pcl, prl = self.concatenated_forward(model, batch)
         if use_side:
             main.wait_stream(self._ref_stream)
@@ -706,10 +745,16 @@ class VLDPOTrainer:
             self.state.global_step = step
         window = []           # device scalars; only read back at logging time (no per-step host sync)
         while step < total:
-            for batch in self.get_train_batches(ep, skip=skip):
+            it = iter(self.get_train_batches(ep, skip=skip))
+            nxt = next(it, None)
+            while nxt is not None:
+                batch = nxt
                 if eng.reducer is not None:        # DDP no_sync: reduce only with the last micro-batch of an accumulation window
                     eng.reducer.enabled = (micro + 1) % ga == 0
                 window.append(self.training_step(self.model, batch))
+                nxt = next(it, None)
+                if nxt is not None:                # look-ahead of one batch: its reference forward runs under the optimizer step
+                    nxt = self.prefetch_reference(nxt)
                 micro += 1
                 if micro % ga:
                     continue
