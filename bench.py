@@ -202,9 +202,11 @@ def main():
         del ref
         tr = Trainer(model, None, 0.1, 0, loss_type, args, None, -100, 0,
                              peft_config=dict(r=128, lora_alpha=256, lora_dropout=a.lora_dropout, target_modules="auto", bias="none", seed=rank))
-        for k, t_ in eng.lv.items():             # peft initialises B = 0; random B so the adapter GEMMs do real arithmetic
+        gen = torch.Generator(device=eng.dev)
+        gen.manual_seed(4321 + rank)
+        for k, t_ in eng.lv.items():             # peft initialises B = 0; random B (seeded) so the adapter GEMMs do real arithmetic
             if ".b_" in k:
-                t_.normal_(0.0, 1e-3)
+                t_.normal_(0.0, 1e-3, generator=gen)
     else:
         tr = Trainer(model, None if a.precomputed_ref else ref, 0.1, 0, loss_type, args, None, -100, 0,
                      precompute_ref_log_probs=a.precomputed_ref)

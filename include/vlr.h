@@ -65,6 +65,27 @@ int vlr_gemm_qkv_rope(const void* x, const void* wqkv, void* qkv, const int* pos
  *                     [M][I] is scratch for the rows / shapes that take the plain GEMM + vlr_swiglu_bwd. */
 int vlr_gemm_swiglu_bwd(const void* dy, const void* wdown, void* gu_inout, void* dact_ws, int M, int I, int H,
                         vlr_stream_t stream);
+/* The same projections with the LoRA adapters of the group riding the K loop of the base GEMM (peft lora.Linear.forward,
+ * result = base(x) + lora_B(lora_A(dropout(x))) * scaling; reference targets src/vlrlhf/models/Llava/__init__.py:273-286):
+ * after the K tiles of x . W^T the kernel runs on into u . Bl^T, u [M][ldu] = scaling * dropout_t(x) A_t^T of the group's
+ * targets side by side (r columns each, written by the caller's lora_A GEMMs), Bl = the lora_B rows of the group [N][r].  The
+ * adapter term is block-diagonal: an output tile of target t multiplies only u_t.  One rounding, fused SwiGLU / RoPE / residual
+ * epilogues as above; shapes / rows the persistent kernel does not take run base GEMM + one skinny GEMM per target.
+ *  vlr_gemm_lora         : y [M][ldy] = x [M][K] . W[N][K]^T + u . Bl^T (+ residual [M][ldr])          (o_proj, down_proj)
+ *  vlr_gemm_swiglu_lora  : gate | up with u = u_gate | u_up, Bl = [B_gate ; B_up] [2I][r]; gu is always stored
+ *  vlr_gemm_qkv_rope_lora: q | k | v with u = u_q | u_k | u_v, Bl = [B_q ; B_k ; B_v]; q_cols + 2 * kv_cols = N */
+/*  vlr_gemm_dropout_acc  : dx [M][in] += scaling / (1 - p) * mask .* (v [M][ldv] . A [r][in]) - the input-gradient term of one
+ *                          target under lora_dropout; the mask is regenerated from (seed, row * in + col) as in vlr_dropout and the
+ *                          product never reaches HBM (scratch [M][in] only for shapes the fused kernel does not take) */
+int vlr_gemm_dropout_acc(const void* v, int ldv, const void* A, void* dx, void* scratch, int M, int in, int r, float p,
+                         uint64_t seed, float scale, vlr_stream_t stream);
+int vlr_gemm_lora(const void* x, int ldx, const void* W, void* y, int ldy, const void* residual, int ldr, int M, int N, int K,
+                  const void* u, int ldu, const void* Bl, int r, vlr_stream_t stream);
+int vlr_gemm_swiglu_lora(const void* x, const void* wgu, void* gu, void* act, int M, int I, int K, int ldx, const void* u, int ldu,
+                         const void* Bl, int r, vlr_stream_t stream);
+int vlr_gemm_qkv_rope_lora(const void* x, const void* wqkv, void* qkv, const int* pos, const float* cos_t, const float* sin_t, int M,
+                           int N, int rope_cols, int K, int ldx, int head_dim, int max_pos, const void* u, int ldu, const void* Bl,
+                           int r, int q_cols, int kv_cols, vlr_stream_t stream);
 
 /* ---- normalisation / activations (transformers LlamaRMSNorm, CLIP LayerNorm, SwiGLU, GELU; call sites
  *      Llava/__init__.py:178-191,232) ------------------------------------------------------------------------- */

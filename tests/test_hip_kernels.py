@@ -742,6 +742,124 @@ def test_gemm_qkv_rope_fused(hip, shape):
     assert torch.isfinite(out.float()).all()
 
 
+# ---------------------------------------------------------------------------------------------------- LoRA adapter segment
+def _blockdiag_add(y, u, Bl, r, bounds):
+    """y[:, block t] += u[:, t*r:(t+1)*r] Bl[block t rows]^T (fp32)"""
+    lo = 0
+    for t, hi in enumerate(bounds):
+        y[:, lo:hi] += u[:, t * r:(t + 1) * r].float() @ Bl[lo:hi].float().t()
+        lo = hi
+    return y
+
+
+@pytest.mark.parametrize("shape", [(4352, 4352, 512, 128, True), (12792, 4096, 256, 64, True), (4104, 4360, 320, 24, False), (300, 256, 128, 16, True)])
+def test_gemm_lora_segment(hip, shape):
+    """vlr_gemm_lora: y = x W^T + u Bl^T (+ residual) in ONE K loop (the adapter operands are a second segment of the reduction);
+    big shapes run the persistent segment kernel (asserted: > 256 tiles; ragged M / N, r not a multiple of the 64-wide K tile, a
+    peeled tail), the small one base GEMM + skinny GEMM."""
+    M, N, K, r, res = shape
+    assert M < 1000 or ((M + 255) // 256) * ((N + 255) // 256) > 256
+    x, W = rnd(M, K, seed=1), rnd(N, K, scale=0.05, seed=2)
+    ldu = 7 * r                                        # u sits inside the layer's [M][7r] buffer
+    ubuf = rnd(M, ldu, scale=0.5, seed=3)
+    u = ubuf[:, 3 * r:4 * r]
+    Bl = rnd(N, r, scale=0.05, seed=4)
+    resid = rnd(M, N, seed=5) if res else None
+    ref = _blockdiag_add(x.float() @ W.float().t(), u, Bl, r, [N])
+    if res:
+        ref = ref + resid.float()
+    y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    hip.call("vlr_gemm_lora", x, K, W, y, N, resid, N, M, N, K, u, ldu, Bl, r)
+    torch.cuda.synchronize()
+    check(y, ref, 8e-3, f"gemm_lora {shape}")
+
+
+@pytest.mark.parametrize("shape", [(4352, 2176, 512, 128), (4104, 2184, 320, 40), (12792, 2048, 256, 64), (300, 256, 128, 16)])
+def test_gemm_swiglu_lora_segment(hip, shape):
+    """vlr_gemm_swiglu_lora: gate and up take DIFFERENT adapter inputs (u_gate | u_up); the gate half of a tile reads zeros over the
+    up adapter's K range and vice versa."""
+    M, I, K, r = shape
+    x, w = rnd(M, K, seed=1), rnd(2 * I, K, scale=0.05, seed=2)
+    u = rnd(M, 2 * r, scale=0.5, seed=3)
+    Bl = rnd(2 * I, r, scale=0.05, seed=4)
+    gu_ref = _blockdiag_add(x.float() @ w.float().t(), u, Bl, r, [I, 2 * I])
+    act_ref = F.silu(gu_ref[:, :I]) * gu_ref[:, I:]
+    gu = torch.full((M, 2 * I), float("nan"), dtype=torch.bfloat16, device=DEV)
+    act = torch.full((M, I), float("nan"), dtype=torch.bfloat16, device=DEV)
+    hip.call("vlr_gemm_swiglu_lora", x, w, gu, act, M, I, K, K, u, 2 * r, Bl, r)
+    torch.cuda.synchronize()
+    check(gu, gu_ref, 8e-3, f"swiglu lora gate|up {shape}")
+    check(act, act_ref, 8e-3, f"swiglu lora act {shape}")
+
+
+@pytest.mark.parametrize("shape", [(4104, 512, 12, 12, 128), (6400, 320, 16, 4, 64), (12792, 256, 8, 8, 32), (300, 128, 2, 2, 16)])
+def test_gemm_qkv_rope_lora_segment(hip, shape):
+    """vlr_gemm_qkv_rope_lora: three adapters (q, k, v; grouped-query widths) + RoPE in the epilogue of one GEMM"""
+    M, K, nh, nkv, r = shape
+    hd = 128
+    Nq, Nkv = nh * hd, nkv * hd
+    N, rope_cols = Nq + 2 * Nkv, Nq + Nkv
+    max_pos = 700
+    x, w = rnd(M, K, seed=3), rnd(N, K, scale=0.05, seed=4)
+    u = rnd(M, 3 * r, scale=0.5, seed=6)
+    Bl = rnd(N, r, scale=0.05, seed=7)
+    pos = torch.randint(0, max_pos, (M,), generator=torch.Generator().manual_seed(5), dtype=torch.int32).to(DEV)
+    cos = torch.empty(max_pos, hd // 2, dtype=torch.float32, device=DEV)
+    sin = torch.empty_like(cos)
+    hip.call("vlr_rope_table", cos, sin, max_pos, hd, 10000.0)
+    y = _blockdiag_add(x.float() @ w.float().t(), u, Bl, r, [Nq, Nq + Nkv, N])
+    ref = y.clone()
+    heads = y[:, :rope_cols].view(M, nh + nkv, hd)
+    c, s_ = cos[pos.long()][:, None, :], sin[pos.long()][:, None, :]
+    x1, x2 = heads[..., : hd // 2], heads[..., hd // 2:]
+    ref[:, :rope_cols] = torch.cat([x1 * c - x2 * s_, x2 * c + x1 * s_], -1).reshape(M, rope_cols)
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    hip.call("vlr_gemm_qkv_rope_lora", x, w, out, pos, cos, sin, M, N, rope_cols, K, K, hd, max_pos, u, 3 * r, Bl, r, Nq, Nkv)
+    torch.cuda.synchronize()
+    check(out, ref, 8e-3, f"qkv rope lora {shape}")
+
+
+@pytest.mark.parametrize("shape", [(4352, 4352, 512), (12792, 4096, 256), (4104, 4360, 320)])
+def test_gemm_residual_continuous(hip, shape):
+    """NT GEMM with a residual add at shapes the persistent kernels take (o_proj / down_proj of the forward), out of place and in
+    place (C == residual).  The residual epilogue of the continuous pipeline itself (default off for plain GEMMs, VLR_GEMM_CONT_RES=1)
+    is what test_gemm_lora_segment runs with residual=True."""
+    M, N, K = shape
+    x, W, resid = rnd(M, K, seed=1), rnd(N, K, scale=0.05, seed=2), rnd(M, N, seed=3)
+    ref = x.float() @ W.float().t() + resid.float()
+    y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    hip.call("vlr_gemm_bf16", 0, x, W, y, None, resid, M, N, K, K, K, N, N, 0, 0, 0)
+    torch.cuda.synchronize()
+    check(y, ref, 8e-3, f"residual cont {shape}")
+    y2 = resid.clone()
+    hip.call("vlr_gemm_bf16", 0, x, W, y2, None, y2, M, N, K, K, K, N, N, 0, 0, 0)
+    torch.cuda.synchronize()
+    check(y2, ref, 8e-3, f"residual in place {shape}")
+
+
+@pytest.mark.parametrize("shape", [(12792, 4096, 128, 0.05), (4104, 4360, 64, 0.25), (6400, 11008, 24, 0.1), (300, 256, 16, 0.5)])
+def test_gemm_dropout_acc(hip, shape):
+    """vlr_gemm_dropout_acc: dx += s/(1-p) mask .* (v A) with the mask regenerated in the GEMM epilogue - the kept / dropped
+    positions are EXACTLY those of vlr_dropout_mask for the same seed, the values those of the fp32 product."""
+    M, n_in, r, pdrop = shape
+    seed, scale = 0x1234567 + r, 1.75
+    v = rnd(M, 3 * r, scale=0.5, seed=1)[:, r:2 * r]          # one target's slice of the [M][n r] buffer
+    A = rnd(r, n_in, scale=0.1, seed=2)
+    dx0 = rnd(M, n_in, seed=3)
+    mask = torch.empty(M * n_in, dtype=torch.uint8, device=DEV)
+    hip.call("vlr_dropout_mask", mask, M * n_in, pdrop, seed)
+    keep = mask.view(M, n_in).bool()
+    prod = v.float() @ A.float()
+    ref = dx0.float() + torch.where(keep, prod * (scale / (1 - pdrop)), torch.zeros_like(prod))
+    dx = dx0.clone()
+    scratch = torch.empty(M, n_in, dtype=torch.bfloat16, device=DEV)
+    hip.call("vlr_gemm_dropout_acc", v, 3 * r, A, dx, scratch, M, n_in, r, pdrop, seed, scale)
+    torch.cuda.synchronize()
+    check(dx, ref, 8e-3, f"dropout acc {shape}")
+    assert torch.equal(dx[~keep], dx0[~keep])                 # dropped positions are untouched, bit for bit
+    assert 0.5 * pdrop < float((~keep).float().mean()) < 1.5 * pdrop
+
+
 # ---------------------------------------------------------------------------------------------------- grouped-query attention
 @pytest.mark.parametrize("B,S,nh,nkv,masked", [(2, 200, 4, 2, True), (1, 333, 8, 2, True), (3, 130, 4, 1, False), (9, 70, 2, 1, False)])
 def test_attention_gqa_fwd_bwd(hip, B, S, nh, nkv, masked):

@@ -33,6 +33,17 @@ void vlr_prof_end(int idx, hipStream_t st);
         }                                      \
     } while (0)
 
+// counter-based dropout (elementwise.hip, the GEMM epilogue of gemm256p.hip): splitmix64 of (key ^ counter); a group of 8
+// consecutive elements g takes its eight 16-bit lanes from mix64(key ^ 2g) (elements 0-3) and mix64(key ^ (2g + 1)) (4-7); an
+// element is kept when its lane >= thr = round(p * 65536).  oracle/llava_dpo_oracle.py:dropout_mask restates it.
+__host__ __device__ inline uint64_t vlr_mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static inline uint32_t vlr_dropout_thr(float p) { return (uint32_t)(p * 65536.0f + 0.5f); }
+
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
 __device__ __forceinline__ float bf16lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float bf16hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }

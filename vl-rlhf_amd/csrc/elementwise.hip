@@ -322,12 +322,6 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict_
 // iff its 16-bit lane (r_{e/4} >> 16*(e%4)) & 0xffff >= thr, thr = round(p * 65536).  Stateless, so the backward
 // regenerates the mask from (seed, index) instead of storing it.  oracle/llava_dpo_oracle.py:dropout_mask restates it.
 // ------------------------------------------------------------------------------------------------------------
-__host__ __device__ inline uint64_t vlr_mix64(uint64_t z) {
-    z += 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
 __device__ __forceinline__ uint32_t dropout_keep8(uint64_t key, long g, uint32_t thr) {
     const uint64_t r0 = vlr_mix64(key ^ (uint64_t)(2 * g)), r1 = vlr_mix64(key ^ (uint64_t)(2 * g + 1));
     uint32_t keep = 0;
@@ -548,22 +542,21 @@ extern "C" int vlr_gelu_bwd(const void* z, const void* dh, void* dz, long n, hip
                        (bf16_t*)dz, n / 8);
     return vlr_check_launch("vlr_gelu_bwd");
 }
-static inline uint32_t dropout_thr(float p) { return (uint32_t)(p * 65536.0f + 0.5f); }
 extern "C" int vlr_dropout(const void* x, void* out, long n, float p, uint64_t seed, float alpha, int add, hipStream_t st) {
     VLR_REQUIRE(n > 0 && n % 8 == 0 && p >= 0.f && p < 1.f, "vlr_dropout: n %% 8 == 0 and 0 <= p < 1 required (n=%ld p=%g)", n, (double)p);
     const float scale = alpha / (1.f - p);
     if (add)
         hipLaunchKernelGGL(dropout_kernel<true>, dim3(grid_for(n / 8, 256)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)out, n / 8,
-                           vlr_mix64(seed), dropout_thr(p), scale);
+                           vlr_mix64(seed), vlr_dropout_thr(p), scale);
     else
         hipLaunchKernelGGL(dropout_kernel<false>, dim3(grid_for(n / 8, 256)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)out, n / 8,
-                           vlr_mix64(seed), dropout_thr(p), scale);
+                           vlr_mix64(seed), vlr_dropout_thr(p), scale);
     return vlr_check_launch("vlr_dropout");
 }
 extern "C" int vlr_dropout_mask(void* mask_u8, long n, float p, uint64_t seed, hipStream_t st) {
     VLR_REQUIRE(n > 0 && n % 8 == 0 && p >= 0.f && p < 1.f, "vlr_dropout_mask: n %% 8 == 0 and 0 <= p < 1 required");
     hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, st, (uint8_t*)mask_u8, n / 8, vlr_mix64(seed),
-                       dropout_thr(p));
+                       vlr_dropout_thr(p));
     return vlr_check_launch("vlr_dropout_mask");
 }
 extern "C" int vlr_im2col(const float* pixel_values, void* patches, int n_img, int image_size, int patch, int Kp,

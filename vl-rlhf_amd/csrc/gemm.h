@@ -44,6 +44,21 @@ struct GemmParams {
     //    of the row's sequence (/ count when averaging)
     float* f0;
     float* f1;
+    // ---- adapter segment (LoRA, NT only; template SEG of gemm256p_kernel): the K loop runs on past K into a second pair of
+    // operands, C = A B^T + A2 B2^T with B2 block-diagonal over the output blocks [0,seg_b0) [seg_b0,seg_b1) [seg_b1,N):
+    //   A2 [M][lda2] = s * dropout_t(x) A_t^T of the group's targets side by side (K2 columns each), B2 [N][ldb2] = lora_B rows.
+    // An output tile of block t multiplies only A2[:, t*K2 .. (t+1)*K2) (the zero blocks are never touched); with fuse = 1 the
+    // gate half uses A2[:, 0..K2) and the up half A2[:, K2..2*K2) (the other half's K range is fed from the zero page).
+    // K % 64 == 0 required; K2 == 0: no segment.
+    const bf16_t* A2;
+    const bf16_t* B2;
+    int lda2, ldb2, K2;
+    int seg_b0, seg_b1;
+    // ---- fuse = 6 (NN, LDS-image epilogue): C += keep(row * drop_ld + col) ? alpha * acc : 0 - the LoRA input-gradient term
+    // dx += scaling/(1-p) * mask_t .* (v_t A_t) without materialising v_t A_t (counter-based mask of common.h)
+    uint64_t drop_key;
+    uint32_t drop_thr;
+    int drop_ld;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -58,6 +73,8 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 bool vlr_gemm256p_try_launch(int layout, const GemmParams& p, hipStream_t stream);
 // fused-epilogue variants (p.fuse = 1 | 2, layout NT): false when the shape does not qualify for the persistent
 // continuous-pipeline kernel - the caller then runs the plain GEMM followed by the elementwise kernel
+bool vlr_gemm256p_dropacc_try_launch(const GemmParams& p, hipStream_t stream);
+bool vlr_gemm256p_seg_try_launch(const GemmParams& p, hipStream_t stream);
 bool vlr_gemm256p_fused_try_launch(const GemmParams& p, hipStream_t stream);
 // fuse = 3 (NN): d act = dy . Wdown with the SwiGLU backward applied in the epilogue to gate | up in p.C2 (in place)
 bool vlr_gemm256p_swiglu_bwd_try_launch(const GemmParams& p, hipStream_t stream);

@@ -423,6 +423,7 @@ static int gemm_impl(int layout, const void* A, const void* B, void* C, const vo
     p.splitk = 1; p.kchunk = 0; p.part = nullptr;
     p.fuse = 0; p.store_c = 1; p.C2 = nullptr; p.ldc2 = 0; p.pos = nullptr; p.rope_cos = p.rope_sin = nullptr; p.max_pos = 0; p.rope_cols = 0;
     p.f0 = p.f1 = nullptr;
+    p.A2 = p.B2 = nullptr; p.lda2 = p.ldb2 = p.K2 = 0; p.seg_b0 = p.seg_b1 = 0x7fffffff; p.drop_key = 0; p.drop_thr = 0; p.drop_ld = 0;
     const int pi = vlr_prof_begin(layout, 2.0 * M * N * K, stream);
     // ---- split-K for problems whose output is a handful of tiles but whose reduction is long: the LoRA adapter gradients
     // (TN: dB = dy^T u [out x r], dA = v^T x [r x in], reduction over all tokens) - 32..96 workgroups would leave most CUs idle
@@ -497,40 +498,88 @@ static GemmParams fused_params(const void* A, const void* B, void* C, int M, int
     p.act = 0; p.accumulate = 0; p.out_f32 = 0; p.flags = 0; p.alpha = 1.f; p.splitk = 1; p.kchunk = 0; p.part = nullptr;
     p.fuse = 0; p.store_c = 1; p.C2 = nullptr; p.ldc2 = 0; p.pos = nullptr; p.rope_cos = p.rope_sin = nullptr; p.max_pos = 0; p.rope_cols = 0;
     p.f0 = p.f1 = nullptr;
+    p.A2 = p.B2 = nullptr; p.lda2 = p.ldb2 = p.K2 = 0; p.seg_b0 = p.seg_b1 = 0x7fffffff; p.drop_key = 0; p.drop_thr = 0; p.drop_ld = 0;
     return p;
 }
 
-extern "C" int vlr_gemm_swiglu(const void* x, const void* wgu, void* gu, void* act, int M, int I, int K, int ldx, int store_gu,
-                               hipStream_t stream) {
+// LoRA adapter segment of a fused linear group (GemmParams::A2...): u = s * dropout_t(x) A_t^T of the group's targets side by
+// side [M][ldu] (r columns each), Bl = lora_B rows [N][r]; the output blocks are [0,b0) [b0,b1) [b1,N).  u == nullptr: none.
+struct SegArgs { const void* u; int ldu; const void* Bl; int r; int b0, b1; };
+static void seg_set(GemmParams& p, const SegArgs* sg) {
+    if (!sg || !sg->u) return;
+    p.A2 = (const bf16_t*)sg->u; p.lda2 = sg->ldu; p.B2 = (const bf16_t*)sg->Bl; p.ldb2 = sg->r; p.K2 = sg->r;
+    p.seg_b0 = sg->b0; p.seg_b1 = sg->b1;
+}
+// rows [row0, row0 + Mr) that the segment kernel did not take: y[:, block t] += u_t Bl_t^T, one skinny GEMM per block
+static int seg_fallback_add(const SegArgs* sg, void* y, int ldy, int row0, int Mr, int N, hipStream_t stream) {
+    if (!sg || !sg->u) return VLR_OK;
+    const int bounds[4] = {0, sg->b0 < N ? sg->b0 : N, sg->b1 < N ? sg->b1 : N, N};
+    for (int t = 0; t < 3; ++t) {
+        const int lo = bounds[t], w = bounds[t + 1] - bounds[t];
+        if (w <= 0) continue;
+        int rc = gemm_impl(0, (const bf16_t*)sg->u + (size_t)row0 * sg->ldu + (size_t)t * sg->r, (const bf16_t*)sg->Bl + (size_t)lo * sg->r,
+                           (bf16_t*)y + (size_t)row0 * ldy + lo, nullptr, nullptr, Mr, w, sg->r, sg->ldu, sg->r, ldy, 0, 0, 1, 0, 1.0f, stream);
+        if (rc != VLR_OK) return rc;
+    }
+    return VLR_OK;
+}
+static int seg_check(const char* who, const SegArgs* sg) {
+    if (!sg || !sg->u) return VLR_OK;
+    VLR_REQUIRE(sg->Bl && sg->r > 0 && sg->r % 8 == 0 && sg->ldu % 8 == 0 && sg->ldu >= sg->r, "%s: adapter segment r=%d ldu=%d", who, sg->r, sg->ldu);
+    VLR_REQUIRE(sg->b0 > 0 && sg->b1 >= sg->b0 && sg->b0 % 8 == 0 && (sg->b1 % 8 == 0 || sg->b1 == 0x7fffffff), "%s: adapter block bounds %d %d", who, sg->b0, sg->b1);
+    return VLR_OK;
+}
+
+static int gemm_swiglu_impl(const void* x, const void* wgu, void* gu, void* act, int M, int I, int K, int ldx, int store_gu,
+                            const SegArgs* sg, hipStream_t stream) {
     VLR_REQUIRE(x && wgu && gu && act, "vlr_gemm_swiglu: null operand");
     VLR_REQUIRE(M > 0 && I > 0 && K > 0 && I % 8 == 0 && K % 8 == 0 && ldx % 8 == 0, "vlr_gemm_swiglu: bad shape M=%d I=%d K=%d ldx=%d", M, I, K, ldx);
+    { int rc = seg_check("vlr_gemm_swiglu_lora", sg); if (rc != VLR_OK) return rc; }
+    const bool seg = sg && sg->u;
     const int tn = (I + 127) / 128;
     const int peel = choose_peel(M, 2 * I, tn);
     const int tm256 = (M + 255) / 256;
     const int M1 = peel ? (tm256 - peel) * 256 : M;
     GemmParams p = fused_params(x, wgu, gu, M1, 2 * I, K, ldx, K, 2 * I);
     p.fuse = 1; p.store_c = store_gu; p.C2 = act; p.ldc2 = I;
+    seg_set(p, sg);
     int done = 0;
-    if (vlr_gemm256p_fused_try_launch(p, stream)) {
+    if (seg ? vlr_gemm256p_seg_try_launch(p, stream) : vlr_gemm256p_fused_try_launch(p, stream)) {
         int rc = vlr_check_launch("vlr_gemm_swiglu(fused)");
         if (rc != VLR_OK) return rc;
         done = M1;
     }
-    if (done < M) {       // remaining rows: plain GEMM + SwiGLU kernel
+    if (done < M) {       // remaining rows: plain GEMM (+ the adapter GEMMs) + SwiGLU kernel
         const bf16_t* xa = (const bf16_t*)x + (size_t)done * ldx;
         bf16_t* gur = (bf16_t*)gu + (size_t)done * 2 * I;
         int rc = gemm_impl(0, xa, wgu, gur, nullptr, nullptr, M - done, 2 * I, K, ldx, K, 2 * I, 0, 0, 0, 0, 1.0f, stream);
+        if (rc != VLR_OK) return rc;
+        rc = seg_fallback_add(sg, gu, 2 * I, done, M - done, 2 * I, stream);
         if (rc != VLR_OK) return rc;
         return vlr_swiglu_fwd(gur, (bf16_t*)act + (size_t)done * I, M - done, I, stream);
     }
     return VLR_OK;
 }
+extern "C" int vlr_gemm_swiglu(const void* x, const void* wgu, void* gu, void* act, int M, int I, int K, int ldx, int store_gu,
+                               hipStream_t stream) {
+    return gemm_swiglu_impl(x, wgu, gu, act, M, I, K, ldx, store_gu, nullptr, stream);
+}
+// the same with the LoRA adapters of gate_proj / up_proj riding the K loop: u [M][ldu] = s drop(x) A_gate^T | s drop(x) A_up^T
+// (r columns each), Bl = [lora_B gate ; lora_B up] [2I][r].  gate | up are always stored (the backward needs them).
+extern "C" int vlr_gemm_swiglu_lora(const void* x, const void* wgu, void* gu, void* act, int M, int I, int K, int ldx, const void* u,
+                                    int ldu, const void* Bl, int r, hipStream_t stream) {
+    VLR_REQUIRE(u && Bl, "vlr_gemm_swiglu_lora: null adapter operand");
+    const SegArgs sg = {u, ldu, Bl, r, I, 0x7fffffff};
+    return gemm_swiglu_impl(x, wgu, gu, act, M, I, K, ldx, 1, &sg, stream);
+}
 
-extern "C" int vlr_gemm_qkv_rope(const void* x, const void* wqkv, void* qkv, const int* pos, const float* cos_t, const float* sin_t,
-                                 int M, int N, int rope_cols, int K, int ldx, int head_dim, int max_pos, hipStream_t stream) {
+static int gemm_qkv_rope_impl(const void* x, const void* wqkv, void* qkv, const int* pos, const float* cos_t, const float* sin_t,
+                              int M, int N, int rope_cols, int K, int ldx, int head_dim, int max_pos, const SegArgs* sg, hipStream_t stream) {
     VLR_REQUIRE(x && wqkv && qkv && pos && cos_t && sin_t, "vlr_gemm_qkv_rope: null operand");
     VLR_REQUIRE(M > 0 && N > 0 && K > 0 && N % 8 == 0 && K % 8 == 0 && ldx % 8 == 0, "vlr_gemm_qkv_rope: bad shape M=%d N=%d K=%d", M, N, K);
     VLR_REQUIRE(head_dim % 16 == 0 && rope_cols % head_dim == 0 && rope_cols <= N, "vlr_gemm_qkv_rope: rope_cols %d / head_dim %d / N %d", rope_cols, head_dim, N);
+    { int rc = seg_check("vlr_gemm_qkv_rope_lora", sg); if (rc != VLR_OK) return rc; }
+    const bool seg = sg && sg->u;
     int done = 0;
     if (head_dim == 128) {
         const int tn = (N + 255) / 256;
@@ -539,7 +588,8 @@ extern "C" int vlr_gemm_qkv_rope(const void* x, const void* wqkv, void* qkv, con
         const int M1 = peel ? (tm256 - peel) * 256 : M;
         GemmParams p = fused_params(x, wqkv, qkv, M1, N, K, ldx, K, N);
         p.fuse = 2; p.pos = pos; p.rope_cos = cos_t; p.rope_sin = sin_t; p.max_pos = max_pos; p.rope_cols = rope_cols;
-        if (vlr_gemm256p_fused_try_launch(p, stream)) {
+        seg_set(p, sg);
+        if (seg ? vlr_gemm256p_seg_try_launch(p, stream) : vlr_gemm256p_fused_try_launch(p, stream)) {
             int rc = vlr_check_launch("vlr_gemm_qkv_rope(fused)");
             if (rc != VLR_OK) return rc;
             done = M1;
@@ -549,8 +599,71 @@ extern "C" int vlr_gemm_qkv_rope(const void* x, const void* wqkv, void* qkv, con
         bf16_t* qr = (bf16_t*)qkv + (size_t)done * N;
         int rc = gemm_impl(0, (const bf16_t*)x + (size_t)done * ldx, wqkv, qr, nullptr, nullptr, M - done, N, K, ldx, K, N, 0, 0, 0, 0, 1.0f, stream);
         if (rc != VLR_OK) return rc;
+        rc = seg_fallback_add(sg, qkv, N, done, M - done, N, stream);
+        if (rc != VLR_OK) return rc;
         // the q and k column blocks are rope_cols / head_dim consecutive heads
         return vlr_rope_heads(qr, pos + done, cos_t, sin_t, M - done, rope_cols / head_dim, head_dim, N, max_pos, 0, stream);
+    }
+    return VLR_OK;
+}
+extern "C" int vlr_gemm_qkv_rope(const void* x, const void* wqkv, void* qkv, const int* pos, const float* cos_t, const float* sin_t,
+                                 int M, int N, int rope_cols, int K, int ldx, int head_dim, int max_pos, hipStream_t stream) {
+    return gemm_qkv_rope_impl(x, wqkv, qkv, pos, cos_t, sin_t, M, N, rope_cols, K, ldx, head_dim, max_pos, nullptr, stream);
+}
+// the same with the LoRA adapters of q_proj / k_proj / v_proj: u [M][ldu] = the three s drop_t(x) A_t^T side by side, Bl = lora_B
+// rows of q | k | v [N][r]; q_cols / kv_cols = widths of the q and of the k (= v) output blocks
+extern "C" int vlr_gemm_qkv_rope_lora(const void* x, const void* wqkv, void* qkv, const int* pos, const float* cos_t, const float* sin_t,
+                                      int M, int N, int rope_cols, int K, int ldx, int head_dim, int max_pos, const void* u, int ldu,
+                                      const void* Bl, int r, int q_cols, int kv_cols, hipStream_t stream) {
+    VLR_REQUIRE(u && Bl, "vlr_gemm_qkv_rope_lora: null adapter operand");
+    VLR_REQUIRE(q_cols > 0 && kv_cols > 0 && q_cols + 2 * kv_cols == N, "vlr_gemm_qkv_rope_lora: q_cols %d + 2 * kv_cols %d != N %d", q_cols, kv_cols, N);
+    const SegArgs sg = {u, ldu, Bl, r, q_cols, q_cols + kv_cols};
+    return gemm_qkv_rope_impl(x, wqkv, qkv, pos, cos_t, sin_t, M, N, rope_cols, K, ldx, head_dim, max_pos, &sg, stream);
+}
+
+extern "C" int vlr_dropout(const void* x, void* out, long n, float p, uint64_t seed, float alpha, int add, hipStream_t st);
+// dx [M][in] += scale / (1 - p) * mask_seed .* (v [M][ldv] . A [r][in]): the input-gradient term of one LoRA target with
+// lora_dropout (mask index = row * in + col, the mask the forward applied to x).  `scratch` [M][in] is used only when the fused
+// kernel does not take the shape (then: product -> scratch, vlr_dropout(add) -> dx).
+extern "C" int vlr_gemm_dropout_acc(const void* v, int ldv, const void* A, void* dx, void* scratch, int M, int in, int r, float p,
+                                    uint64_t seed, float scale, hipStream_t stream) {
+    VLR_REQUIRE(v && A && dx && scratch, "vlr_gemm_dropout_acc: null operand");
+    VLR_REQUIRE(M > 0 && in > 0 && r > 0 && in % 8 == 0 && r % 8 == 0 && ldv % 8 == 0, "vlr_gemm_dropout_acc: bad shape M=%d in=%d r=%d ldv=%d", M, in, r, ldv);
+    VLR_REQUIRE(p >= 0.f && p < 1.f, "vlr_gemm_dropout_acc: 0 <= p < 1 required, got %g", (double)p);
+    GemmParams g = fused_params(v, A, dx, M, in, r, ldv, in, in);
+    g.fuse = 6; g.accumulate = 1; g.alpha = scale / (1.f - p);
+    g.drop_key = vlr_mix64(seed); g.drop_thr = vlr_dropout_thr(p); g.drop_ld = in;
+    if (vlr_gemm256p_dropacc_try_launch(g, stream)) return vlr_check_launch("vlr_gemm_dropout_acc(fused)");
+    int rc = gemm_impl(1, v, A, scratch, nullptr, nullptr, M, in, r, ldv, in, in, 0, 0, 0, 0, 1.0f, stream);
+    if (rc != VLR_OK) return rc;
+    return vlr_dropout(scratch, dx, (long)M * in, p, seed, scale, 1, stream);
+}
+
+// y [M][ldy] = x W^T + u Bl^T (+ residual): one adapted linear (o_proj, down_proj) with its LoRA adapter riding the K loop
+extern "C" int vlr_gemm_lora(const void* x, int ldx, const void* W, void* y, int ldy, const void* residual, int ldr, int M, int N, int K,
+                             const void* u, int ldu, const void* Bl, int r, hipStream_t stream) {
+    VLR_REQUIRE(x && W && y && u && Bl, "vlr_gemm_lora: null operand");
+    VLR_REQUIRE(M > 0 && N > 0 && K > 0 && N % 8 == 0 && K % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "vlr_gemm_lora: bad shape M=%d N=%d K=%d", M, N, K);
+    const SegArgs sg = {u, ldu, Bl, r, 0x7fffffff, 0x7fffffff};
+    VLR_REQUIRE(r > 0 && r % 8 == 0 && ldu % 8 == 0 && ldu >= r, "vlr_gemm_lora: adapter segment r=%d ldu=%d", r, ldu);
+    const int tn = (N + 255) / 256;
+    const int peel = choose_peel(M, N, tn);
+    const int tm256 = (M + 255) / 256;
+    const int M1 = peel ? (tm256 - peel) * 256 : M;
+    GemmParams p = fused_params(x, W, y, M1, N, K, ldx, K, ldy);
+    p.residual = (const bf16_t*)residual; p.ldr = ldr;
+    seg_set(p, &sg);
+    int done = 0;
+    if (vlr_gemm256p_seg_try_launch(p, stream)) {
+        int rc = vlr_check_launch("vlr_gemm_lora(fused)");
+        if (rc != VLR_OK) return rc;
+        done = M1;
+    }
+    if (done < M) {
+        int rc = gemm_impl(0, (const bf16_t*)x + (size_t)done * ldx, W, (bf16_t*)y + (size_t)done * ldy, nullptr,
+                           residual ? (const bf16_t*)residual + (size_t)done * ldr : nullptr, M - done, N, K, ldx, K, ldy, ldr, 0, 0, 0, 1.0f, stream);
+        if (rc != VLR_OK) return rc;
+        return seg_fallback_add(&sg, y, ldy, done, M - done, N, stream);
     }
     return VLR_OK;
 }

@@ -101,6 +101,22 @@ __device__ __forceinline__ void stage_kc_b(const bf16_t* __restrict__ P, int ld,
         lds_dma16(g, half + R * 128);
     }
 }
+// adapter segment, B operand (lora_B rows [N][ld], K2 columns): half h of a SwiGLU tile (gate / up rows) owns the K range
+// [h*K2, (h+1)*K2) of the tile's 2*K2-wide segment and reads zeros elsewhere; plain / RoPE tiles own [0, K2)
+template <int FUSE>
+__device__ __forceinline__ void stage_seg_b(const bf16_t* __restrict__ P, int ld, int n0, int h, int N, int k0, int K2,
+                                            const bf16_t* __restrict__ zero16, char* half, int wave, int lane) {
+    const int koff = FUSE == 1 ? h * K2 : 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int R = (wave + 8 * i) * 8;
+        const int r = R + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const int k = k0 + c * 8 - koff;
+        const bf16_t* g = (k >= 0 && k + 8 <= K2) ? P + (size_t)b_src_row<FUSE>(n0, h, r, N) * ld + k : zero16;
+        lds_dma16(g, half + R * 128);
+    }
+}
 __device__ __forceinline__ void piece_off_ks(int ld, int col0, int ncols, int wave, int lane, uint32_t (&off)[2]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -192,9 +208,11 @@ __device__ __forceinline__ int widen_col(int lq) { return (lq & 1) * 16 + (lq >>
 // CONT = true: continuous pipeline across the output tiles of a persistent workgroup (plain bf16 epilogue only): the last K tiles
 // of tile i stage the first K tiles of tile i+1 (same slots, same counted wait), the epilogue stores straight from the
 // accumulator registers (8 bytes per lane, no LDS, no barrier) and the K loop of tile i+1 starts with its data resident.
-template <bool A_KS, bool B_KS, int ABL = 0, bool CONT = false, int FUSE = 0>
+template <bool A_KS, bool B_KS, int ABL = 0, bool CONT = false, int FUSE = 0, bool SEG = false>
 __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_t* __restrict__ zero16) {
-    static_assert(FUSE == 0 || (CONT && !A_KS && (FUSE == 3 ? B_KS : !B_KS)), "fused epilogues: continuous pipeline; 1, 2, 4, 5 NT, 3 NN");
+    static_assert(FUSE == 0 || (FUSE == 6 && !CONT && !A_KS && B_KS) || (FUSE != 6 && CONT && !A_KS && (FUSE == 3 ? B_KS : !B_KS)),
+                  "fused epilogues: continuous pipeline; 1, 2, 4, 5 NT, 3 NN; 6 (dropout-accumulate) NN on the LDS-image epilogue");
+    static_assert(!SEG || (!A_KS && !B_KS && FUSE <= 2), "adapter segment: NT, plain / SwiGLU / RoPE epilogues");
     constexpr int NW = FUSE == 1 ? 128 : PT;      // output columns (of the gate half, for SwiGLU) per workgroup tile
     extern __shared__ __attribute__((aligned(16))) char smem[];   // P_LDS_BYTES
     const int t = threadIdx.x;
@@ -251,7 +269,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[a][i][b][j][r] = 0.f;
 
-    const int nt = (p.K + PK - 1) / PK;
+    // SEG: K tiles [0, nt1) come from (A, B), [nt1, nt) from the adapter pair (A2 columns of this tile's output block, B2)
+    const int nt1 = (p.K + PK - 1) / PK;
+    const int k2t = !SEG ? 0 : (FUSE == 1 ? 2 * p.K2 : p.K2);
+    const int nt = nt1 + (k2t + PK - 1) / PK;
+    const int a2off = (!SEG || FUSE == 1) ? 0 : (n0 >= p.seg_b0 ? (n0 >= p.seg_b1 ? 2 : 1) : 0) * p.K2;
     // half h of K tile `tile`: 0 A-lo, 1 A-hi, 2 B-lo, 3 B-hi
     // diagnostics (template ABL via VLR_GEMM_ABLATE, NT only, timing only - results are wrong): 1 no DMA in the K loop,
     // 2 no fragment reads after the first K tile, 4 no barriers in the K loop
@@ -289,6 +311,17 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                         else stage_kc_b<FUSE>(p.B, p.ldb, n0n, h - 2, p.N, k0, p.K, zero16, dst, wave, lane);
                     }
                 }
+                return;
+            }
+        }
+        if constexpr (SEG && !fast) {
+            if (tile >= nt1) {
+                int ln = lane;                       // opaque per call: keeps the adapter-segment addresses out of the loop-invariant
+                asm volatile("" : "+v"(ln));         // set hipcc would otherwise carry (and spill) through the whole K loop
+                char* dst = smem + ((tile + parb) & 1) * BUF_BYTES + h * HALF_BYTES;
+                const int k0 = (tile - nt1) * PK;
+                if constexpr (h < 2) stage_kc(p.A2 + a2off, p.lda2, m0 + h * 128, p.M, k0, k2t, zero16, dst, wave, ln);
+                else stage_seg_b<FUSE>(p.B2, p.ldb2, n0, h - 2, p.N, k0, p.K2, zero16, dst, wave, ln);
                 return;
             }
         }
@@ -461,7 +494,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
         flip = -flip;
     };
     // steady state: every staged tile (kt+1, kt+2) exists and is full -> no checks, no K-tail path in the hot loop
-    const int n_fast = nt - 2 - (ktail ? 1 : 0);
+    const int n_fast = (SEG ? nt1 : nt) - 2 - (ktail ? 1 : 0);     // SEG: K % 64 == 0, the adapter tiles take the general path
     int kt = 0;
     for (; kt < n_fast; ++kt) ktile(kt, FAST{});
     for (; kt < nt; ++kt) ktile(kt, SLOW{});
@@ -676,7 +709,20 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     const int gn = n0 + b * 128 + wc * 32 + widen_col(lq_);
-                    const u32x4 w = widen_pair(p.alpha * acc[a][i][b][0], p.alpha * acc[a][i][b][1]);
+                    f32x4 v[2] = {p.alpha * acc[a][i][b][0], p.alpha * acc[a][i][b][1]};
+                    if (p.residual) {
+                        // residual add in fp32 before the single rounding: 8-byte reads in the accumulator layout (4 consecutive
+                        // columns of tile j), then the same widening as the plain store
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int gr = n0 + b * 128 + wc * 32 + j * 16 + 4 * lq_;
+                            if (gm < p.M && gr + 4 <= p.N) {
+                                const u32x2 w = *reinterpret_cast<const u32x2*>(p.residual + (size_t)gm * p.ldr + gr);
+                                v[j][0] += bf16lo(w[0]); v[j][1] += bf16hi(w[0]); v[j][2] += bf16lo(w[1]); v[j][3] += bf16hi(w[1]);
+                            }
+                        }
+                    }
+                    const u32x4 w = widen_pair(v[0], v[1]);
                     if (gm < p.M && gn + 8 <= p.N) *reinterpret_cast<u32x4*>(C + (size_t)gm * p.ldc + gn) = w;
                 }
             }
@@ -724,12 +770,20 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                         f32x4 v = acc[a][i][b][j];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = apply_act(p.alpha * v[e] + bv[e], p.act);
+                        if constexpr (FUSE == 6) {
+                            // keep mask of elements (gm, gn .. gn+3): half a hash group (gn % 4 == 0, drop_ld % 8 == 0)
+                            const long idx = (long)gm * p.drop_ld + gn;
+                            const uint64_t rr = vlr_mix64(p.drop_key ^ (uint64_t)(2 * (idx >> 3) + ((idx >> 2) & 1)));
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if ((uint32_t)((rr >> (16 * e)) & 0xffffu) < p.drop_thr) v[e] = 0.f;
+                        }
                         if (gm < p.M && nok) {
                             if (p.residual) {
                                 const u32x2 w = *reinterpret_cast<const u32x2*>(p.residual + (size_t)gm * p.ldr + gn);
                                 v[0] += bf16lo(w[0]); v[1] += bf16hi(w[0]); v[2] += bf16lo(w[1]); v[3] += bf16hi(w[1]);
                             }
-                            if (p.accumulate) {
+                            if (FUSE != 6 && p.accumulate) {      // fuse 6 accumulates in the coalesced copy-out below
                                 const u32x2 w = *reinterpret_cast<const u32x2*>(Cold + (size_t)gm * p.ldc + gn);
                                 v[0] += bf16lo(w[0]); v[1] += bf16hi(w[0]); v[2] += bf16lo(w[1]); v[3] += bf16hi(w[1]);
                             }
@@ -749,8 +803,20 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
         for (int it = 0; it < 16; ++it) {
             const int row = it * 16 + wave * 2 + (lane >> 5);
             const int gm = m0 + row;
-            if (gm < p.M && gn + 8 <= p.N)
-                *reinterpret_cast<u32x4*>(C + (size_t)gm * p.ldc + gn) = *reinterpret_cast<const u32x4*>(smem + row * C_STRIDE + cch * 16);
+            if (gm < p.M && gn + 8 <= p.N) {
+                u32x4 w = *reinterpret_cast<const u32x4*>(smem + row * C_STRIDE + cch * 16);
+                if constexpr (FUSE == 6) {
+                    // C += (rounded masked product): full 512-byte rows read and written once, 16 B per lane (the K loop is two
+                    // tiles long - this read-modify-write IS the kernel); same two roundings as product -> scratch -> add
+                    float o[8], d[8];
+                    unpack8(*reinterpret_cast<const u32x4*>(C + (size_t)gm * p.ldc + gn), o);
+                    unpack8(w, d);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] += d[e];
+                    w = pack8(o);
+                }
+                *reinterpret_cast<u32x4*>(C + (size_t)gm * p.ldc + gn) = w;
+            }
         }
     } else {
     // fp32 output (lm-head logits): one 64x32 quadrant at a time through a wave-private fp32 patch, 16-byte global accesses
@@ -856,6 +922,61 @@ bool vlr_gemm256p_fused_try_launch(const GemmParams& p, hipStream_t stream) {
     return true;
 }
 
+// C = A B^T + A2 B2^T (adapter segment, GemmParams::A2...), NT, persistent continuous pipeline only: fuse 0 (plain, optional
+// residual), 1 (SwiGLU), 2 (RoPE).  false: the caller runs the base GEMM and the adapter GEMMs separately.
+bool vlr_gemm256p_seg_try_launch(const GemmParams& p, hipStream_t stream) {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("VLR_GEMM_SEG");
+        on = (e && e[0] == '0') ? 0 : 1;
+        hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, 0, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+        hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, 0, true, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+        hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, 0, true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+    }
+    if (!on || p.fuse < 0 || p.fuse > 2 || p.K2 <= 0 || !p.A2 || !p.B2) return false;
+    bf16_t* zero16 = gemm256p_zero16();
+    if (!zero16) return false;
+    const int n_cu = gemm256p_n_cu();
+    const int tiles_m = (p.M + PT - 1) / PT;
+    const int tiles_n = p.fuse == 1 ? ((p.N >> 1) + 127) / 128 : (p.N + PT - 1) / PT;
+    if (tiles_m * tiles_n <= n_cu || p.K < 4 * PK || p.K % PK != 0) return false;
+    if (p.K2 % 8 != 0 || p.lda2 % 8 != 0 || p.ldb2 % 8 != 0 || (((uintptr_t)p.A2 | (uintptr_t)p.B2) & 15)) return false;
+    if (p.fuse != 1 && ((p.seg_b0 < p.N && p.seg_b0 % PT != 0) || (p.seg_b1 < p.N && p.seg_b1 % PT != 0))) return false;   // a tile lies in one block
+    if (p.fuse == 2 && (p.N % PT != 0 || p.rope_cols % PT != 0)) return false;
+    if (p.fuse == 1 && ((p.N >> 1) % 8 != 0 || p.ldc2 % 8 != 0 || ((uintptr_t)p.C2 & 15))) return false;
+    if ((((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.C) & 15) || p.lda % 8 != 0 || p.ldb % 8 != 0 || p.ldc % 8 != 0 || p.N % 8 != 0) return false;
+    if (p.bias || p.accumulate || p.out_f32 || p.act != ACT_NONE) return false;
+    if (p.residual && (p.fuse != 0 || p.ldr % 4 != 0 || ((uintptr_t)p.residual & 7) || (const void*)p.residual == (const void*)p.C)) return false;
+    const int pi = vlr_prof_begin(VLR_K_GEMM256P, 2.0 * p.M * p.N * (p.K + p.K2), stream);
+    if (p.fuse == 0) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 0, true>), dim3(n_cu), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
+    else if (p.fuse == 1) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 1, true>), dim3(n_cu), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
+    else hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 2, true>), dim3(n_cu), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
+    vlr_prof_end(pi, stream);
+    return true;
+}
+
+// dx [M][N] += keep ? alpha * (A [M][K] . B [K][N]) : 0 (NN; fuse 6).  Any tile count >= 192 (K is the adapter rank: the launch is
+// store-bound, no peeling); false -> the caller materialises the product and runs the dropout-accumulate kernel.
+bool vlr_gemm256p_dropacc_try_launch(const GemmParams& p, hipStream_t stream) {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("VLR_GEMM_DROPACC");
+        on = (e && e[0] == '0') ? 0 : 1;
+        hipFuncSetAttribute((const void*)gemm256p_kernel<false, true, 0, false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES);
+    }
+    if (!on || p.fuse != 6) return false;
+    bf16_t* zero16 = gemm256p_zero16();
+    if (!zero16) return false;
+    const int n_cu = gemm256p_n_cu();
+    const int ntiles = ((p.M + PT - 1) / PT) * ((p.N + PT - 1) / PT);
+    if (ntiles < 192) return false;
+    if ((((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.C) & 15) || p.lda % 8 != 0 || p.ldb % 8 != 0 || p.N % 8 != 0 || p.ldc % 8 != 0 || p.drop_ld % 8 != 0) return false;
+    const int pi = vlr_prof_begin(VLR_K_GEMM256P, 2.0 * p.M * p.N * p.K, stream);
+    hipLaunchKernelGGL((gemm256p_kernel<false, true, 0, false, 6>), dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), P_LDS_BYTES, stream, p, (const bf16_t*)zero16);
+    vlr_prof_end(pi, stream);
+    return true;
+}
+
 // d act = dy . Wdown (NN) with the SwiGLU backward in the epilogue: p.C2 = gate | up [M][2I] (in/out), p.N = I, p.C unused
 bool vlr_gemm256p_swiglu_bwd_try_launch(const GemmParams& p, hipStream_t stream) {
     static int on = -1;
@@ -953,7 +1074,15 @@ bool vlr_gemm256p_try_launch(int layout, const GemmParams& p, hipStream_t stream
     // continuous pipeline across tiles: persistent launch, plain bf16 epilogue (C = alpha * A B), at least 4 K tiles
     static int cont = -1;
     if (cont < 0) { const char* e = getenv("VLR_GEMM_CONT"); cont = (e && e[0] == '0') ? 0 : 1; }
-    if (cont && ntiles > tiles && !p.bias && !p.residual && !p.accumulate && !p.out_f32 && p.act == ACT_NONE && p.K >= 4 * PK && p.ldc % 8 == 0 && p.N % 8 == 0 &&
+    static int cont_res = -1;
+    // residual epilogue on the continuous pipeline: OFF by default - measured 1.4 ms per step SLOWER than the LDS-image epilogue of
+    // the per-tile kernel (635.8 vs 634.4 ms, same box, bit-identical losses): its 8-byte residual reads sit between the K loop and
+    // the stores and are not hidden.  (The adapter-segment kernels use it: they exist only as continuous pipelines.)
+    if (cont_res < 0) { const char* e = getenv("VLR_GEMM_CONT_RES"); cont_res = (e && e[0] == '1') ? 1 : 0; }
+    // (an in-place residual, C == residual, stays on the LDS-image epilogue: the widened store of one lane covers columns another
+    // lane still has to read)
+    const bool res_ok = !p.residual || (cont_res && p.ldr % 4 == 0 && !((uintptr_t)p.residual & 7) && (const void*)p.residual != (const void*)p.C);
+    if (cont && ntiles > tiles && !p.bias && res_ok && !p.accumulate && !p.out_f32 && p.act == ACT_NONE && p.K >= 4 * PK && p.ldc % 8 == 0 && p.N % 8 == 0 &&
         !((uintptr_t)p.C & 15)) {
         if (layout == 0) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true>), dim3(tiles), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
         else if (layout == 1) hipLaunchKernelGGL((gemm256p_kernel<false, true, 0, true>), dim3(tiles), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);

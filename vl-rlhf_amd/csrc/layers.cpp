@@ -137,22 +137,19 @@ extern "C" int vlr_decoder_layer_bwd(const vlr_llama_cfg* cfg, const vlr_layer_w
 // Dropout target t of a layer uses seed + t (t = 0..6 in q,k,v,o,gate,up,down order).
 // ---------------------------------------------------------------------------------------------------------------------
 // outs[t]: output features of sub-target t (they differ under grouped-query attention: q has heads*hd, k and v kv_heads*hd)
-static int lora_group_fwd(int n, int r, int in, const int* outs, const void* x, void* y, int ldy, const void* A, const void* B, void* u,
-                          int ldu, float scale, float p, uint64_t seed, void* ws_xd, int M, hipStream_t st) {
-    size_t ofs[4] = {0, 0, 0, 0};
-    for (int t = 0; t < n; ++t) ofs[t + 1] = ofs[t] + (size_t)outs[t];
+// u_t = s * dropout_t(x) A_t^T for the n sub-targets of a group (the B half rides the K loop of the base GEMM: vlr_gemm_*_lora)
+static int lora_group_a(int n, int r, int in, const void* x, int ldx, const void* A, void* u, int ldu, float scale, float p,
+                        uint64_t seed, void* ws_xd, int M, hipStream_t st) {
     if (p > 0.f) {
         for (int t = 0; t < n; ++t) {
             void* xd_t = off(ws_xd, (size_t)t * M * in);          // kept for the backward (dA_t = s v_t^T drop_t(x))
             CHECK(vlr_dropout(x, xd_t, (long)M * in, p, seed + t, 1.f, 0, st));
-            CHECK(vlr_gemm_bf16(0, xd_t, off(A, (size_t)t * r * in), off(u, (size_t)t * r), nullptr, nullptr, M, r, in, in, in, ldu, 0, 0, 0, 0, st));
+            CHECK(vlr_gemm_bf16_scaled(0, xd_t, off(A, (size_t)t * r * in), off(u, (size_t)t * r), nullptr, nullptr, M, r, in, in, in, ldu,
+                                       0, 0, 0, 0, scale, st));
         }
     } else {
-        CHECK(vlr_gemm_bf16(0, x, A, u, nullptr, nullptr, M, n * r, in, in, in, ldu, 0, 0, 0, 0, st));
+        CHECK(vlr_gemm_bf16_scaled(0, x, A, u, nullptr, nullptr, M, n * r, in, ldx, in, ldu, 0, 0, 0, 0, scale, st));
     }
-    for (int t = 0; t < n; ++t)
-        CHECK(vlr_gemm_bf16_scaled(0, off(u, (size_t)t * r), off(B, ofs[t] * r), off(y, ofs[t]), nullptr, nullptr, M, outs[t], r,
-                                   ldu, r, ldy, 0, 0, 1, 0, scale, st));
     return VLR_OK;
 }
 
@@ -166,8 +163,8 @@ static int lora_group_bwd(int n, int r, int in, const int* outs, const void* x, 
     for (int t = 0; t < n; ++t) {
         const void* dyt = off(dy, ofs[t]);
         const int out = outs[t];
-        CHECK(vlr_gemm_bf16_scaled(2, dyt, off(u, (size_t)t * r), off(dB, ofs[t] * r), nullptr, nullptr, out, r, M, lddy, ldu, r,
-                                   0, 0, accumulate, 0, scale, st));                                                // dB_t = s dy_t^T u_t
+        CHECK(vlr_gemm_bf16(2, dyt, off(u, (size_t)t * r), off(dB, ofs[t] * r), nullptr, nullptr, out, r, M, lddy, ldu, r,
+                            0, 0, accumulate, 0, st));                                               // dB_t = dy_t^T (s u_t): u is stored scaled
         CHECK(vlr_gemm_bf16(1, dyt, off(B, ofs[t] * r), off(v, (size_t)t * r), nullptr, nullptr, M, r, out, lddy, r, nr,
                             0, 0, 0, 0, st));                                                                       // v_t = dy_t B_t
     }
@@ -176,9 +173,7 @@ static int lora_group_bwd(int n, int r, int in, const int* outs, const void* x, 
             void* xd_t = off(ws_xd, (size_t)t * M * in);          // drop_t(x) saved by the forward; dead after dA_t -> reused as scratch
             CHECK(vlr_gemm_bf16_scaled(2, off(v, (size_t)t * r), xd_t, off(dA, (size_t)t * r * in), nullptr, nullptr, r, in, M, nr, in, in,
                                        0, 0, accumulate, 0, scale, st));                                            // dA_t = s v_t^T drop_t(x)
-            CHECK(vlr_gemm_bf16(1, off(v, (size_t)t * r), off(A, (size_t)t * r * in), xd_t, nullptr, nullptr, M, in, r, nr, in, in,
-                                0, 0, 0, 0, st));
-            CHECK(vlr_dropout(xd_t, dx, (long)M * in, p, seed + t, scale, 1, st));                                   // dx += s mask_t (v_t A_t)/(1-p)
+            CHECK(vlr_gemm_dropout_acc(off(v, (size_t)t * r), nr, off(A, (size_t)t * r * in), dx, xd_t, M, in, r, p, seed + t, scale, st));   // dx += s mask_t (v_t A_t)/(1-p)
         }
     } else {
         CHECK(vlr_gemm_bf16_scaled(2, v, x, dA, nullptr, nullptr, nr, in, M, nr, in, in, 0, 0, accumulate, 0, scale, st));  // dA = s v^T x
@@ -204,23 +199,21 @@ extern "C" int vlr_decoder_layer_fwd_lora(const vlr_llama_cfg* cfg, const vlr_la
     const int kvh = cfg->kv_heads > 0 ? cfg->kv_heads : cfg->heads;
     const int Nq = cfg->heads * cfg->head_dim, Nkv = kvh * cfg->head_dim, N = Nq + 2 * Nkv;
     VLR_REQUIRE(Nq == H, "vlr_decoder_layer_fwd_lora: heads*head_dim != hidden");
-    const int o_qkv[3] = {Nq, Nkv, Nkv}, o_h[1] = {H}, o_gu[2] = {I, I};
     const float sc = lw->scale, p = lw->dropout;
 #define XD(seg) (ws_xd ? (void*)off(ws_xd, (size_t)(seg) * M * H) : nullptr)   // segment base in units of M*H elements
     CHECK(vlr_rmsnorm_fwd(x_in, w->ln1, a->xn1, a->rstd1, M, H, cfg->rms_eps, st));
-    CHECK(vlr_gemm_bf16(0, a->xn1, w->wqkv, a->qkv, nullptr, nullptr, M, N, H, H, H, N, 0, 0, 0, 0, st));
-    CHECK(lora_group_fwd(3, r, H, o_qkv, a->xn1, a->qkv, N, lw->a_qkv, lw->b_qkv, u, ldu, sc, p, seed + 0, ws_xd, M, st));   // xd segments: q,k,v | o | gate,up | down
-    CHECK(vlr_rope_heads(a->qkv, pos, cfg->rope_cos, cfg->rope_sin, M, cfg->heads + kvh, cfg->head_dim, N, cfg->max_pos, 0, st));
+    CHECK(lora_group_a(3, r, H, a->xn1, H, lw->a_qkv, u, ldu, sc, p, seed + 0, ws_xd, M, st));                     // xd segments: q,k,v | o | gate,up | down
+    CHECK(vlr_gemm_qkv_rope_lora(a->xn1, w->wqkv, a->qkv, pos, cfg->rope_cos, cfg->rope_sin, M, N, Nq + Nkv, H, H, cfg->head_dim,
+                                 cfg->max_pos, u, ldu, lw->b_qkv, r, Nq, Nkv, st));
     CHECK(vlr_attn_fwd_gqa(a->qkv, off(a->qkv, Nq), off(a->qkv, (size_t)Nq + Nkv), N, a->attn, Nq, a->lse, key_mask, batch, S,
                            cfg->heads, kvh, cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));
-    CHECK(vlr_gemm_bf16(0, a->attn, w->wo, a->x_mid, nullptr, x_in, M, H, H, H, H, H, H, 0, 0, 0, st));
-    CHECK(lora_group_fwd(1, r, H, o_h, a->attn, a->x_mid, H, lw->a_o, lw->b_o, off(u, 3 * (size_t)r), ldu, sc, p, seed + 3, XD(3), M, st));
+    CHECK(lora_group_a(1, r, H, a->attn, H, lw->a_o, off(u, 3 * (size_t)r), ldu, sc, p, seed + 3, XD(3), M, st));
+    CHECK(vlr_gemm_lora(a->attn, H, w->wo, a->x_mid, H, x_in, H, M, H, H, off(u, 3 * (size_t)r), ldu, lw->b_o, r, st));
     CHECK(vlr_rmsnorm_fwd(a->x_mid, w->ln2, a->xn2, a->rstd2, M, H, cfg->rms_eps, st));
-    CHECK(vlr_gemm_bf16(0, a->xn2, w->wgu, a->gu, nullptr, nullptr, M, 2 * I, H, H, H, 2 * I, 0, 0, 0, 0, st));
-    CHECK(lora_group_fwd(2, r, H, o_gu, a->xn2, a->gu, 2 * I, lw->a_gu, lw->b_gu, off(u, 4 * (size_t)r), ldu, sc, p, seed + 4, XD(4), M, st));
-    CHECK(vlr_swiglu_fwd(a->gu, a->act, M, I, st));
-    CHECK(vlr_gemm_bf16(0, a->act, w->wdown, a->x_out, nullptr, a->x_mid, M, H, I, I, I, H, H, 0, 0, 0, st));
-    CHECK(lora_group_fwd(1, r, I, o_h, a->act, a->x_out, H, lw->a_down, lw->b_down, off(u, 6 * (size_t)r), ldu, sc, p, seed + 6, XD(6), M, st));
+    CHECK(lora_group_a(2, r, H, a->xn2, H, lw->a_gu, off(u, 4 * (size_t)r), ldu, sc, p, seed + 4, XD(4), M, st));
+    CHECK(vlr_gemm_swiglu_lora(a->xn2, w->wgu, a->gu, a->act, M, I, H, H, off(u, 4 * (size_t)r), ldu, lw->b_gu, r, st));
+    CHECK(lora_group_a(1, r, I, a->act, I, lw->a_down, off(u, 6 * (size_t)r), ldu, sc, p, seed + 6, XD(6), M, st));
+    CHECK(vlr_gemm_lora(a->act, I, w->wdown, a->x_out, H, a->x_mid, H, M, H, I, off(u, 6 * (size_t)r), ldu, lw->b_down, r, st));
     return VLR_OK;
 }
 
