@@ -73,7 +73,9 @@ int vlr_gemm_swiglu_bwd(const void* dy, const void* wdown, void* gu_inout, void*
  * epilogues as above; shapes / rows the persistent kernel does not take run base GEMM + one skinny GEMM per target.
  *  vlr_gemm_lora         : y [M][ldy] = x [M][K] . W[N][K]^T + u . Bl^T (+ residual [M][ldr])          (o_proj, down_proj)
  *  vlr_gemm_swiglu_lora  : gate | up with u = u_gate | u_up, Bl = [B_gate ; B_up] [2I][r]; gu is always stored
- *  vlr_gemm_qkv_rope_lora: q | k | v with u = u_q | u_k | u_v, Bl = [B_q ; B_k ; B_v]; q_cols + 2 * kv_cols = N */
+ *  vlr_gemm_qkv_rope_lora: q | k | v with u = u_q | u_k | u_v, Bl = [B_q ; B_k ; B_v]; q_cols + 2 * kv_cols = N.  kv_cols = 0: ONE
+ *                          adapter over the whole fused projection (u [M][r], Bl [N][r]).  bias [N] (NULL = none) is added before
+ *                          the rotation; with a bias the projection runs as GEMM (+ adapter GEMMs) + RoPE kernel. */
 /*  vlr_gemm_dropout_acc  : dx [M][in] += scaling / (1 - p) * mask .* (v [M][ldv] . A [r][in]) - the input-gradient term of one
  *                          target under lora_dropout; the mask is regenerated from (seed, row * in + col) as in vlr_dropout and the
  *                          product never reaches HBM (scratch [M][in] only for shapes the fused kernel does not take) */
@@ -83,9 +85,9 @@ int vlr_gemm_lora(const void* x, int ldx, const void* W, void* y, int ldy, const
                   const void* u, int ldu, const void* Bl, int r, vlr_stream_t stream);
 int vlr_gemm_swiglu_lora(const void* x, const void* wgu, void* gu, void* act, int M, int I, int K, int ldx, const void* u, int ldu,
                          const void* Bl, int r, vlr_stream_t stream);
-int vlr_gemm_qkv_rope_lora(const void* x, const void* wqkv, void* qkv, const int* pos, const float* cos_t, const float* sin_t, int M,
-                           int N, int rope_cols, int K, int ldx, int head_dim, int max_pos, const void* u, int ldu, const void* Bl,
-                           int r, int q_cols, int kv_cols, vlr_stream_t stream);
+int vlr_gemm_qkv_rope_lora(const void* x, const void* wqkv, const void* bias, void* qkv, const int* pos, const float* cos_t,
+                           const float* sin_t, int M, int N, int rope_cols, int K, int ldx, int head_dim, int max_pos, const void* u,
+                           int ldu, const void* Bl, int r, int q_cols, int kv_cols, vlr_stream_t stream);
 
 /* ---- normalisation / activations (transformers LlamaRMSNorm, CLIP LayerNorm, SwiGLU, GELU; call sites
  *      Llava/__init__.py:178-191,232) ------------------------------------------------------------------------- */
@@ -203,6 +205,8 @@ typedef struct {
  * qkv / dqkv activations [M][Nq + 2 Nkv], attn / dattn [M][Nq].  hidden == Nq for LLaMA / Mistral. */
 typedef struct {  /* bf16 weights of one decoder layer; q|k|v and gate|up are stored fused */
     const void* ln1; const void* wqkv; const void* wo; const void* ln2; const void* wgu; const void* wdown;
+    const void* bqkv;       /* [Nq + 2 Nkv] bias of the fused q|k|v projection (Qwen c_attn, QwenVL/modeling_qwen.py:104); NULL = none.
+                             * Its gradient is the column sum of the dqkv scratch after vlr_decoder_layer_bwd (vlr_colsum). */
 } vlr_layer_weights;
 typedef struct {  /* bf16 gradient buffers, same shapes */
     void* ln1; void* wqkv; void* wo; void* ln2; void* wgu; void* wdown;
@@ -243,7 +247,9 @@ typedef struct {
     const void* a_qkv; const void* b_qkv;   /* [3r][H], [3H][r] */
     const void* a_o;   const void* b_o;     /* [r][H],  [H][r]  */
     const void* a_gu;  const void* b_gu;    /* [2r][H], [2I][r] */
-    const void* a_down; const void* b_down; /* [r][I],  [H][r]  */
+    const void* a_down; const void* b_down; /* [r][I],  [H][r]; both NULL: no adapter on the down projection */
+    int qkv_targets;  /* 0 or 3: q_proj, k_proj, v_proj adapted separately (a_qkv [3r][H], u_q | u_k | u_v); 1: ONE adapter on the
+                       * fused projection (Qwen c_attn: a_qkv [r][H], b_qkv [N][r]) */
 } vlr_lora_weights;
 typedef struct {
     void* a_qkv; void* b_qkv; void* a_o; void* b_o; void* a_gu; void* b_gu; void* a_down; void* b_down;

@@ -814,7 +814,7 @@ def test_gemm_qkv_rope_lora_segment(hip, shape):
     x1, x2 = heads[..., : hd // 2], heads[..., hd // 2:]
     ref[:, :rope_cols] = torch.cat([x1 * c - x2 * s_, x2 * c + x1 * s_], -1).reshape(M, rope_cols)
     out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
-    hip.call("vlr_gemm_qkv_rope_lora", x, w, out, pos, cos, sin, M, N, rope_cols, K, K, hd, max_pos, u, 3 * r, Bl, r, Nq, Nkv)
+    hip.call("vlr_gemm_qkv_rope_lora", x, w, None, out, pos, cos, sin, M, N, rope_cols, K, K, hd, max_pos, u, 3 * r, Bl, r, Nq, Nkv)
     torch.cuda.synchronize()
     check(out, ref, 8e-3, f"qkv rope lora {shape}")
 

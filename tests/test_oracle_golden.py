@@ -291,3 +291,49 @@ def test_llavanext_oracle_matches_reference_golden():
             close(leaves[k[5:]].grad, t(z, k), 2e-3, k)
             n += 1
     assert n >= 10
+
+
+# ------------------------------------------------------------------------------------------------------------ Qwen-VL
+def test_qwenvl_oracle_matches_reference_golden():
+    """oracle/qwenvl_oracle.py against tests/golden/qwenvl_small.npz = outputs of the reference's own QWenLMHeadModel /
+    VisionTransformer / Resampler forward (oracle/make_golden_qwenvl.py): vision features, logits, image_position_map, the image
+    paths decoded from the ids, log-probs / losses of three loss types, and autograd gradients."""
+    from oracle import qwenvl_oracle as Q
+    z, cfg, W, W_ref, batch, _ = load_case("qwenvl_small")
+    px = batch["img_input_dict"]["pixel_values"]
+    paths = json.loads(bytes(z["paths_json"]).decode())
+    vf = Q.qwen_visual(px, W_ref, cfg["visual"])
+    assert torch.allclose(vf, t(z, "visual_features"), rtol=2e-4, atol=2e-4), float((vf - t(z, "visual_features")).abs().max())
+    cb = O.concatenated_inputs({k: v for k, v in batch.items() if k != "img_input_dict"}, padding_value=cfg["pad_token_id"])
+    ids, am, lab = cb["concatenated_input_ids"], cb["concatenated_attention_mask"], cb["concatenated_labels"]
+    assert Q.decode_image_paths(ids, cfg["image_start_id"]) == paths + paths
+    Wg = {k: (v.clone().requires_grad_(True) if any(k == g[5:] or k == g[11:] for g in z.files if g.startswith("grad")) else v) for k, v in W.items()}
+    logits, img_map, _ = Q.qwenvl_forward(Wg, cfg, ids, am, torch.cat([px, px], 0))
+    ref_logits = t(z, "logits")
+    assert torch.equal(img_map, t(z, "image_position_map"))
+    assert float((logits - ref_logits).abs().max()) < 2e-3 * float(ref_logits.abs().max())
+    for lt in ("sigmoid", "ipo", "ddpo"):
+        pc, pr, _, _ = Q.concatenated_forward(W, cfg, dict(batch, pixel_values=px), lt)
+        rc, rr, _, _ = Q.concatenated_forward(W_ref, cfg, dict(batch, pixel_values=px), lt)
+        assert torch.allclose(torch.cat([pc, pr]), t(z, f"{lt}.logps"), rtol=1e-4, atol=2e-3)
+        assert torch.allclose(torch.cat([rc, rr]), t(z, f"{lt}.ref_logps"), rtol=1e-4, atol=2e-3)
+        losses, _, _ = O.dpo_loss(pc, pr, rc, rr, cfg["beta"], 0.0, lt, False)
+        assert torch.allclose(losses, t(z, f"{lt}.losses"), rtol=2e-3, atol=2e-4), (lt, losses, t(z, f"{lt}.losses"))
+    # gradients of the sigmoid loss through the oracle's own forward
+    lp = O.get_batch_logps(logits, lab)
+    n = batch["chosen_input_ids"].shape[0]
+    rl = t(z, "sigmoid.ref_logps")
+    losses, _, _ = O.dpo_loss(lp[:n], lp[n:], rl[:n], rl[n:], cfg["beta"], 0.0, "sigmoid", False)
+    losses.mean().backward()
+    checked = 0
+    for k in z.files:
+        if k.startswith("grad."):
+            g, ref = Wg[k[5:]].grad, t(z, k)
+            assert float((g - ref).abs().max()) <= 2e-3 * float(ref.abs().max()) + 1e-7, k
+            checked += 1
+        elif k.startswith("grad_probe."):
+            g, ref = Wg[k[11:]].grad, t(z, k)
+            assert float((g.reshape(-1)[::17] - ref).abs().max()) <= 2e-3 * float(ref.abs().max()) + 1e-7, k
+            assert abs(float(g.norm()) - float(z["grad_norm." + k[11:]])) <= 2e-3 * float(z["grad_norm." + k[11:]]), k
+            checked += 1
+    assert checked == 10

@@ -574,14 +574,15 @@ extern "C" int vlr_gemm_swiglu_lora(const void* x, const void* wgu, void* gu, vo
 }
 
 static int gemm_qkv_rope_impl(const void* x, const void* wqkv, void* qkv, const int* pos, const float* cos_t, const float* sin_t,
-                              int M, int N, int rope_cols, int K, int ldx, int head_dim, int max_pos, const SegArgs* sg, hipStream_t stream) {
+                              int M, int N, int rope_cols, int K, int ldx, int head_dim, int max_pos, const SegArgs* sg, const void* bias,
+                              hipStream_t stream) {
     VLR_REQUIRE(x && wqkv && qkv && pos && cos_t && sin_t, "vlr_gemm_qkv_rope: null operand");
     VLR_REQUIRE(M > 0 && N > 0 && K > 0 && N % 8 == 0 && K % 8 == 0 && ldx % 8 == 0, "vlr_gemm_qkv_rope: bad shape M=%d N=%d K=%d", M, N, K);
     VLR_REQUIRE(head_dim % 16 == 0 && rope_cols % head_dim == 0 && rope_cols <= N, "vlr_gemm_qkv_rope: rope_cols %d / head_dim %d / N %d", rope_cols, head_dim, N);
     { int rc = seg_check("vlr_gemm_qkv_rope_lora", sg); if (rc != VLR_OK) return rc; }
     const bool seg = sg && sg->u;
     int done = 0;
-    if (head_dim == 128) {
+    if (head_dim == 128 && !bias) {
         const int tn = (N + 255) / 256;
         const int peel = choose_peel(M, N, tn);
         const int tm256 = (M + 255) / 256;
@@ -597,7 +598,7 @@ static int gemm_qkv_rope_impl(const void* x, const void* wqkv, void* qkv, const 
     }
     if (done < M) {
         bf16_t* qr = (bf16_t*)qkv + (size_t)done * N;
-        int rc = gemm_impl(0, (const bf16_t*)x + (size_t)done * ldx, wqkv, qr, nullptr, nullptr, M - done, N, K, ldx, K, N, 0, 0, 0, 0, 1.0f, stream);
+        int rc = gemm_impl(0, (const bf16_t*)x + (size_t)done * ldx, wqkv, qr, bias, nullptr, M - done, N, K, ldx, K, N, 0, 0, 0, 0, 1.0f, stream);
         if (rc != VLR_OK) return rc;
         rc = seg_fallback_add(sg, qkv, N, done, M - done, N, stream);
         if (rc != VLR_OK) return rc;
@@ -608,17 +609,18 @@ static int gemm_qkv_rope_impl(const void* x, const void* wqkv, void* qkv, const 
 }
 extern "C" int vlr_gemm_qkv_rope(const void* x, const void* wqkv, void* qkv, const int* pos, const float* cos_t, const float* sin_t,
                                  int M, int N, int rope_cols, int K, int ldx, int head_dim, int max_pos, hipStream_t stream) {
-    return gemm_qkv_rope_impl(x, wqkv, qkv, pos, cos_t, sin_t, M, N, rope_cols, K, ldx, head_dim, max_pos, nullptr, stream);
+    return gemm_qkv_rope_impl(x, wqkv, qkv, pos, cos_t, sin_t, M, N, rope_cols, K, ldx, head_dim, max_pos, nullptr, nullptr, stream);
 }
 // the same with the LoRA adapters of q_proj / k_proj / v_proj: u [M][ldu] = the three s drop_t(x) A_t^T side by side, Bl = lora_B
 // rows of q | k | v [N][r]; q_cols / kv_cols = widths of the q and of the k (= v) output blocks
-extern "C" int vlr_gemm_qkv_rope_lora(const void* x, const void* wqkv, void* qkv, const int* pos, const float* cos_t, const float* sin_t,
-                                      int M, int N, int rope_cols, int K, int ldx, int head_dim, int max_pos, const void* u, int ldu,
-                                      const void* Bl, int r, int q_cols, int kv_cols, hipStream_t stream) {
+extern "C" int vlr_gemm_qkv_rope_lora(const void* x, const void* wqkv, const void* bias, void* qkv, const int* pos, const float* cos_t,
+                                      const float* sin_t, int M, int N, int rope_cols, int K, int ldx, int head_dim, int max_pos,
+                                      const void* u, int ldu, const void* Bl, int r, int q_cols, int kv_cols, hipStream_t stream) {
     VLR_REQUIRE(u && Bl, "vlr_gemm_qkv_rope_lora: null adapter operand");
-    VLR_REQUIRE(q_cols > 0 && kv_cols > 0 && q_cols + 2 * kv_cols == N, "vlr_gemm_qkv_rope_lora: q_cols %d + 2 * kv_cols %d != N %d", q_cols, kv_cols, N);
-    const SegArgs sg = {u, ldu, Bl, r, q_cols, q_cols + kv_cols};
-    return gemm_qkv_rope_impl(x, wqkv, qkv, pos, cos_t, sin_t, M, N, rope_cols, K, ldx, head_dim, max_pos, &sg, stream);
+    VLR_REQUIRE((kv_cols == 0 && q_cols == N) || (q_cols > 0 && kv_cols > 0 && q_cols + 2 * kv_cols == N),
+                "vlr_gemm_qkv_rope_lora: q_cols %d + 2 * kv_cols %d != N %d", q_cols, kv_cols, N);
+    const SegArgs sg = {u, ldu, Bl, r, kv_cols ? q_cols : 0x7fffffff, kv_cols ? q_cols + kv_cols : 0x7fffffff};
+    return gemm_qkv_rope_impl(x, wqkv, qkv, pos, cos_t, sin_t, M, N, rope_cols, K, ldx, head_dim, max_pos, &sg, bias, stream);
 }
 
 extern "C" int vlr_dropout(const void* x, void* out, long n, float p, uint64_t seed, float alpha, int add, hipStream_t st);

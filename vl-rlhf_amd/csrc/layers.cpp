@@ -70,8 +70,13 @@ extern "C" int vlr_decoder_layer_fwd_ex(const vlr_llama_cfg* cfg, const vlr_laye
     CHECK(vlr_rmsnorm_fwd(x_in, w->ln1, a->xn1, a->rstd1, M, H, cfg->rms_eps, st));
     // q|k|v projection with RoPE applied to the fp32 accumulators in the GEMM epilogue (plain GEMM + rope kernel for the rows /
     // shapes the persistent kernel does not take)
-    CHECK(vlr_gemm_qkv_rope(a->xn1, w->wqkv, a->qkv, pos, cfg->rope_cos, cfg->rope_sin, M, N, Nq + Nkv, H, H, cfg->head_dim,
-                            cfg->max_pos, st));
+    if (w->bqkv) {   // biased fused projection (Qwen c_attn): the bias is added before the rotation -> GEMM with bias, then the RoPE kernel
+        CHECK(vlr_gemm_bf16(0, a->xn1, w->wqkv, a->qkv, w->bqkv, nullptr, M, N, H, H, H, N, 0, 0, 0, 0, st));
+        CHECK(vlr_rope_heads(a->qkv, pos, cfg->rope_cos, cfg->rope_sin, M, cfg->heads + kvh, cfg->head_dim, N, cfg->max_pos, 0, st));
+    } else {
+        CHECK(vlr_gemm_qkv_rope(a->xn1, w->wqkv, a->qkv, pos, cfg->rope_cos, cfg->rope_sin, M, N, Nq + Nkv, H, H, cfg->head_dim,
+                                cfg->max_pos, st));
+    }
     CHECK(vlr_attn_fwd_gqa(a->qkv, off(a->qkv, Nq), off(a->qkv, (size_t)Nq + Nkv), N, a->attn, Nq, a->lse, key_mask, batch, S,
                            cfg->heads, kvh, cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));
     CHECK(vlr_gemm_bf16(0, a->attn, w->wo, a->x_mid, nullptr, x_in, M, H, Nq, Nq, Nq, H, H, 0, 0, 0, st));
@@ -186,7 +191,8 @@ static int lora_check(const char* who, const vlr_lora_weights* lw, const void* w
     VLR_REQUIRE(lw->r > 0 && lw->r % 8 == 0, "%s: LoRA rank must be a positive multiple of 8, got %d", who, lw->r);
     VLR_REQUIRE(lw->dropout >= 0.f && lw->dropout < 1.f, "%s: lora_dropout must be in [0,1), got %g", who, (double)lw->dropout);
     VLR_REQUIRE(lw->dropout == 0.f || ws_xd, "%s: lora_dropout > 0 needs the xd buffer [M][6*hidden + inter]", who);
-    VLR_REQUIRE(lw->a_qkv && lw->b_qkv && lw->a_o && lw->b_o && lw->a_gu && lw->b_gu && lw->a_down && lw->b_down, "%s: null adapter pointer", who);
+    VLR_REQUIRE(lw->a_qkv && lw->b_qkv && lw->a_o && lw->b_o && lw->a_gu && lw->b_gu && (!lw->a_down == !lw->b_down), "%s: null adapter pointer", who);
+    VLR_REQUIRE(lw->qkv_targets == 0 || lw->qkv_targets == 1 || lw->qkv_targets == 3, "%s: qkv_targets must be 1 or 3, got %d", who, lw->qkv_targets);
     return VLR_OK;
 }
 
@@ -202,9 +208,10 @@ extern "C" int vlr_decoder_layer_fwd_lora(const vlr_llama_cfg* cfg, const vlr_la
     const float sc = lw->scale, p = lw->dropout;
 #define XD(seg) (ws_xd ? (void*)off(ws_xd, (size_t)(seg) * M * H) : nullptr)   // segment base in units of M*H elements
     CHECK(vlr_rmsnorm_fwd(x_in, w->ln1, a->xn1, a->rstd1, M, H, cfg->rms_eps, st));
-    CHECK(lora_group_a(3, r, H, a->xn1, H, lw->a_qkv, u, ldu, sc, p, seed + 0, ws_xd, M, st));                     // xd segments: q,k,v | o | gate,up | down
-    CHECK(vlr_gemm_qkv_rope_lora(a->xn1, w->wqkv, a->qkv, pos, cfg->rope_cos, cfg->rope_sin, M, N, Nq + Nkv, H, H, cfg->head_dim,
-                                 cfg->max_pos, u, ldu, lw->b_qkv, r, Nq, Nkv, st));
+    const int nq = lw->qkv_targets == 1 ? 1 : 3;             // one adapter over the fused projection (Qwen c_attn) or q, k, v separately
+    CHECK(lora_group_a(nq, r, H, a->xn1, H, lw->a_qkv, u, ldu, sc, p, seed + 0, ws_xd, M, st));                    // xd segments: q,k,v | o | gate,up | down
+    CHECK(vlr_gemm_qkv_rope_lora(a->xn1, w->wqkv, w->bqkv, a->qkv, pos, cfg->rope_cos, cfg->rope_sin, M, N, Nq + Nkv, H, H,
+                                 cfg->head_dim, cfg->max_pos, u, ldu, lw->b_qkv, r, nq == 1 ? N : Nq, nq == 1 ? 0 : Nkv, st));
     CHECK(vlr_attn_fwd_gqa(a->qkv, off(a->qkv, Nq), off(a->qkv, (size_t)Nq + Nkv), N, a->attn, Nq, a->lse, key_mask, batch, S,
                            cfg->heads, kvh, cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));
     CHECK(lora_group_a(1, r, H, a->attn, H, lw->a_o, off(u, 3 * (size_t)r), ldu, sc, p, seed + 3, XD(3), M, st));
@@ -212,8 +219,12 @@ extern "C" int vlr_decoder_layer_fwd_lora(const vlr_llama_cfg* cfg, const vlr_la
     CHECK(vlr_rmsnorm_fwd(a->x_mid, w->ln2, a->xn2, a->rstd2, M, H, cfg->rms_eps, st));
     CHECK(lora_group_a(2, r, H, a->xn2, H, lw->a_gu, off(u, 4 * (size_t)r), ldu, sc, p, seed + 4, XD(4), M, st));
     CHECK(vlr_gemm_swiglu_lora(a->xn2, w->wgu, a->gu, a->act, M, I, H, H, off(u, 4 * (size_t)r), ldu, lw->b_gu, r, st));
-    CHECK(lora_group_a(1, r, I, a->act, I, lw->a_down, off(u, 6 * (size_t)r), ldu, sc, p, seed + 6, XD(6), M, st));
-    CHECK(vlr_gemm_lora(a->act, I, w->wdown, a->x_out, H, a->x_mid, H, M, H, I, off(u, 6 * (size_t)r), ldu, lw->b_down, r, st));
+    if (lw->a_down) {
+        CHECK(lora_group_a(1, r, I, a->act, I, lw->a_down, off(u, 6 * (size_t)r), ldu, sc, p, seed + 6, XD(6), M, st));
+        CHECK(vlr_gemm_lora(a->act, I, w->wdown, a->x_out, H, a->x_mid, H, M, H, I, off(u, 6 * (size_t)r), ldu, lw->b_down, r, st));
+    } else {
+        CHECK(vlr_gemm_bf16(0, a->act, w->wdown, a->x_out, nullptr, a->x_mid, M, H, I, I, I, H, H, 0, 0, 0, st));
+    }
     return VLR_OK;
 }
 
@@ -233,8 +244,9 @@ extern "C" int vlr_decoder_layer_bwd_lora(const vlr_llama_cfg* cfg, const vlr_la
 #define XD(seg) (ws_xd ? (void*)off(ws_xd, (size_t)(seg) * M * H) : nullptr)   // segment base in units of M*H elements
     // ---- MLP
     CHECK(vlr_gemm_bf16(1, dx_out, w->wdown, ws->dact, nullptr, nullptr, M, I, H, H, I, I, 0, 0, 0, 0, st));
-    CHECK(lora_group_bwd(1, r, I, o_h, a->act, dx_out, H, lw->a_down, lw->b_down, lg->a_down, lg->b_down, off(u, 6 * (size_t)r), ldu, ws_v,
-                         ws->dact, sc, p, seed + 6, XD(6), accumulate, M, st));
+    if (lw->a_down)
+        CHECK(lora_group_bwd(1, r, I, o_h, a->act, dx_out, H, lw->a_down, lw->b_down, lg->a_down, lg->b_down, off(u, 6 * (size_t)r), ldu, ws_v,
+                             ws->dact, sc, p, seed + 6, XD(6), accumulate, M, st));
     CHECK(vlr_swiglu_bwd(a->gu, ws->dact, M, I, st));   // gu now holds [dgate | dup]
     CHECK(vlr_gemm_bf16(1, a->gu, w->wgu, ws->dxn, nullptr, nullptr, M, H, 2 * I, 2 * I, H, H, 0, 0, 0, 0, st));
     CHECK(lora_group_bwd(2, r, H, o_gu, a->xn2, a->gu, 2 * I, lw->a_gu, lw->b_gu, lg->a_gu, lg->b_gu, off(u, 4 * (size_t)r), ldu, ws_v,
@@ -249,8 +261,10 @@ extern "C" int vlr_decoder_layer_bwd_lora(const vlr_llama_cfg* cfg, const vlr_la
                            cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));
     CHECK(vlr_rope_heads(ws->dqkv, pos, cfg->rope_cos, cfg->rope_sin, M, cfg->heads + kvh, cfg->head_dim, N, cfg->max_pos, 1, st));
     CHECK(vlr_gemm_bf16(1, ws->dqkv, w->wqkv, ws->dxn, nullptr, nullptr, M, H, N, N, H, H, 0, 0, 0, 0, st));
-    CHECK(lora_group_bwd(3, r, H, o_qkv, a->xn1, ws->dqkv, N, lw->a_qkv, lw->b_qkv, lg->a_qkv, lg->b_qkv, u, ldu, ws_v, ws->dxn, sc, p,
-                         seed + 0, ws_xd, accumulate, M, st));
+    const int o_all[1] = {N};
+    const int nq = lw->qkv_targets == 1 ? 1 : 3;
+    CHECK(lora_group_bwd(nq, r, H, nq == 1 ? o_all : o_qkv, a->xn1, ws->dqkv, N, lw->a_qkv, lw->b_qkv, lg->a_qkv, lg->b_qkv, u, ldu, ws_v, ws->dxn,
+                         sc, p, seed + 0, ws_xd, accumulate, M, st));
     CHECK(vlr_rmsnorm_bwd(ws->dxn, x_in, w->ln1, a->rstd1, ws->dx_mid, dx_in, nullptr, 0, ws->norm_ws, M, H, st));
     return VLR_OK;
 }

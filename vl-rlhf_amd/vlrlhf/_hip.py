@@ -19,7 +19,7 @@ class LlamaCfg(C.Structure):
 
 
 class LayerWeights(C.Structure):
-    _fields_ = [(n, P) for n in ("ln1", "wqkv", "wo", "ln2", "wgu", "wdown")]
+    _fields_ = [(n, P) for n in ("ln1", "wqkv", "wo", "ln2", "wgu", "wdown", "bqkv")]
 
 
 class LayerGrads(C.Structure):
@@ -35,7 +35,7 @@ class LayerBwdWs(C.Structure):
 
 
 class LoraWeights(C.Structure):
-    _fields_ = [("r", I), ("scale", F), ("dropout", F)] + [(n, P) for n in ("a_qkv", "b_qkv", "a_o", "b_o", "a_gu", "b_gu", "a_down", "b_down")]
+    _fields_ = [("r", I), ("scale", F), ("dropout", F)] + [(n, P) for n in ("a_qkv", "b_qkv", "a_o", "b_o", "a_gu", "b_gu", "a_down", "b_down")] + [("qkv_targets", I)]
 
 
 class LoraGrads(C.Structure):
@@ -101,7 +101,7 @@ _SIGS = {
     "vlr_gemm_lora": [P, I, P, P, I, P, I, I, I, I, P, I, P, I, P],
     "vlr_gemm_dropout_acc": [P, I, P, P, P, I, I, I, F, U64, F, P],
     "vlr_gemm_swiglu_lora": [P, P, P, P, I, I, I, I, P, I, P, I, P],
-    "vlr_gemm_qkv_rope_lora": [P, P, P, P, P, P, I, I, I, I, I, I, I, P, I, P, I, I, I, P],
+    "vlr_gemm_qkv_rope_lora": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P, I, P, I, I, I, P],
     "vlr_decoder_layer_bwd": [P, P, P, I, P, P, P, P, P, P, P, I, I, P],
     "vlr_vit_layer_fwd": [P, P, P, P, I, I, P],
     "vlr_decoder_layer_fwd_lora": [P, P, P, P, P, P, U64, P, P, P, I, I, P],

@@ -274,7 +274,8 @@ class LlavaHipEngine:
 
     def layer_weights(self, ws: WeightSet, l):
         v = ws.v
-        return _hip.LayerWeights(*(v[f"l{l}.{k}"].data_ptr() for k in ("ln1", "wqkv", "wo", "ln2", "wgu", "wdown")))
+        return _hip.LayerWeights(*(v[f"l{l}.{k}"].data_ptr() for k in ("ln1", "wqkv", "wo", "ln2", "wgu", "wdown")),
+                                 v[f"l{l}.bqkv"].data_ptr() if f"l{l}.bqkv" in v else None)
 
     def layer_grads(self, l):
         return _hip.LayerGrads(*(self.gv[f"l{l}.{k}"].data_ptr() for k in ("ln1", "wqkv", "wo", "ln2", "wgu", "wdown")))
