@@ -274,6 +274,12 @@ int vlr_layers_join(vlr_stream_t stream);
 typedef struct {
     int hidden, mlp, heads, head_dim;
     float ln_eps;
+    /* the following default (0) to the CLIP tower of LLaVA; the Qwen-VL tower (QwenVL/visual.py:244-300) sets them */
+    int act;            /* MLP activation: 0 / 1 quick_gelu (CLIP), 2 exact GELU (nn.GELU) */
+    int head_dim_pad;   /* > head_dim: q|k|v rows and the attention output are laid out with head_dim_pad (128) features per head
+                         * (weight rows / columns of the padding are zero) so that head_dim 104 runs on the 128-wide attention kernel;
+                         * ws->qkv is [M][3*heads*head_dim_pad], ws->attn [M][heads*head_dim_pad] */
+    float attn_scale;   /* softmax scale; 0 = 1/sqrt(head_dim) (of the TRUE head_dim when 0 and head_dim_pad is set) */
 } vlr_vit_cfg;
 typedef struct {  /* bf16; q|k|v fused [3D][D] + bias [3D] */
     const void* ln1_w; const void* ln1_b; const void* wqkv; const void* bqkv; const void* wo; const void* bo;

@@ -221,33 +221,8 @@ def gen_model():
 
 
 # ------------------------------------------------------------------------------------------------- tokenisation fixture
-class StandInTokenizer:
-    """Deterministic stand-in with the interface QwenVLProcessor / QwenVLDPOTrainer.tokenize_row use (tokenization_qwen.py): text is
-    split on the special strings; ordinary text -> one id per character (ord % 200 + 256); "<img>path</img>" -> the 256-slot image
-    encoding of tokenization_qwen.py:283-294 (utf-8 bytes, then <imgpad>); specials -> their ids."""
-    im_start_id, im_end_id, eod_id = 151644, 151645, 151643
-    img_start_id, img_end_id, img_pad_id = 151857, 151858, 151859
-    SPECIAL = {"<|im_start|>": 151644, "<|im_end|>": 151645, "<|endoftext|>": 151643}
-
-    def __init__(self):
-        self.pad_token_id = self.eod_id
-        self.eos_token_id = self.eod_id
-        self.padding_side = "right"
-
-    def __call__(self, text):
-        import re
-        ids = []
-        for part in re.split(r"(<\\|im_start\\|>|<\\|im_end\\|>|<\\|endoftext\\|>|<img>.*?</img>)", text):
-            if not part:
-                continue
-            if part in self.SPECIAL:
-                ids.append(self.SPECIAL[part])
-            elif part.startswith("<img>") and part.endswith("</img>"):
-                b = list(part[5:-6].encode("utf-8"))
-                ids += [self.img_start_id] + b + [self.img_pad_id] * (256 - len(b)) + [self.img_end_id]
-            else:
-                ids += [ord(c) % 200 + 256 for c in part]
-        return types.SimpleNamespace(input_ids=ids)
+sys.path.insert(0, ROOT)
+from tests.qwen_standin import StandInTokenizer  # noqa: E402
 
 
 def gen_tokenize():

@@ -1,0 +1,107 @@
+"""Host side of the Qwen-VL wrapper (no GPU): processor / tokenize_row against outputs of the REFERENCE's own QwenVLProcessor and
+QwenVLDPOTrainer.tokenize_row (tests/golden/qwenvl_tokenize.json, written by oracle/make_golden_qwenvl.py with the stand-in tokenizer
+of tests/qwen_standin.py), image-path decoding, parameter / adapter naming against the reference model's state_dict keys."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "vl-rlhf_amd"))
+
+from tests.golden_util import GOLDEN  # noqa: E402
+from tests.qwen_standin import StandInTokenizer  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def fx():
+    with open(os.path.join(GOLDEN, "qwenvl_tokenize.json")) as f:
+        return json.load(f)
+
+
+def _processor():
+    from vlrlhf.models.QwenVL import QwenVLProcessor
+    p = QwenVLProcessor(tokenizer=StandInTokenizer(), image_size=448)
+    p.train()
+    return p
+
+
+def test_processor_matches_reference(fx):
+    from vlrlhf.models.QwenVL import QwenVLProcessor
+    p = _processor()
+    assert p.tokenizer.padding_side == "right" and p.tokenizer.pad_token_id == p.tokenizer.eod_id
+    fmt = [QwenVLProcessor.format_multimodal_prompt(r["prompt"], r["img_path"]) for r in fx["rows"]]
+    assert fmt == fx["format_multimodal_prompt"]
+    assert [QwenVLProcessor.is_multimodal_prompt_valid(x) for x in fmt] == fx["is_valid"]
+    assert [QwenVLProcessor.remove_image_placeholder(x) for x in fmt] == fx["removed"]
+    conv = [[{"from": "user", "value": f}, {"from": "assistant", "value": r["chosen"]}] for f, r in zip(fmt, fx["rows"])]
+    assert p.process_batch_conv(conv) == fx["process_batch_conv"]
+    with pytest.raises(ValueError):
+        p.process_batch_conv(conv[0])
+    with pytest.raises(AssertionError):
+        QwenVLProcessor.format_multimodal_prompt("<image> a <image> b", ["x.png"])
+    t = p.chat_template
+    assert (t.user_begin, t.assistant_end, t.image_placeholder) == ("<|im_start|>user", "<|im_end|>", "<img>")
+
+
+def test_tokenize_row_matches_reference(fx):
+    from vlrlhf.models.QwenVL import QwenVLDPOTrainer
+    p = _processor()
+    for case in fx["cases"]:
+        tr = QwenVLDPOTrainer.__new__(QwenVLDPOTrainer)
+        tr.processor, tr.tokenizer = p, p.tokenizer
+        tr.max_length, tr.max_prompt_length = case["max_length"], case["max_prompt_length"]
+        tr.truncation_mode, tr.label_pad_token_id = case["truncation_mode"], -100
+        for row, want in zip(fx["rows"], case["out"]):
+            got = tr.tokenize_row(dict(row))
+            assert got == want, (case["max_length"], case["truncation_mode"], row["img_path"])
+    tr.truncation_mode = "middle"
+    tr.max_length, tr.max_prompt_length = 100, 50
+    with pytest.raises(ValueError):
+        tr.tokenize_row(dict(fx["rows"][0]))
+
+
+def test_image_paths_are_decoded_from_the_ids():
+    from vlrlhf.models.QwenVL import decode_image_paths
+    z = np.load(os.path.join(GOLDEN, "qwenvl_small.npz"))
+    cfg = json.loads(bytes(z["config_json"]).decode())
+    paths = json.loads(bytes(z["paths_json"]).decode())
+    ids = torch.from_numpy(z["batch.chosen_input_ids"])
+    assert decode_image_paths(ids, cfg["image_start_id"]) == paths
+    tok = StandInTokenizer()
+    row = torch.tensor([tok("Picture 1: <img>a/b c.jpg</img>\nhello").input_ids])
+    assert decode_image_paths(row, tok.img_start_id) == ["a/b c.jpg"]
+    assert int((row == tok.img_pad_id).sum()) == 256 - len("a/b c.jpg")
+
+
+def test_parameter_and_adapter_names_follow_the_reference_checkpoint():
+    from vlrlhf.engine import LoraLayout, ParamLayout
+    z = np.load(os.path.join(GOLDEN, "qwenvl_small.npz"))
+    cfg = json.loads(bytes(z["config_json"]).decode())
+    ref_keys = {k[4:] for k in z.files if k.startswith("w16.")}
+    lay = ParamLayout(cfg)
+    mine = {hf for hf, _, _, _ in lay.hf_names()}
+    assert mine == {k for k in ref_keys if not k.startswith("transformer.visual.")}      # every LM tensor of the reference, nothing else
+    assert lay.shape["l0.bqkv"] == (3 * cfg["hidden"],) and lay.offset["l0.bqkv"] >= lay.n_decay                # biases: no weight decay
+    gate_up = [hf for hf, name, r0, rows in lay.hf_names() if name == "l1.wgu"]
+    assert gate_up == ["transformer.h.1.mlp.w2.weight", "transformer.h.1.mlp.w1.weight"]  # c_proj(w1(x) * silu(w2(x))): gate = w2, up = w1
+    lo = LoraLayout(cfg, 8)
+    names = lo.hf_names()
+    assert lo.qkv_targets == 1 and "l0.a_down" not in lo.shape
+    assert names["base_model.model.transformer.h.0.attn.c_attn.lora_A.weight"] == ("l0.a_qkv", 0, 8)
+    assert names["base_model.model.transformer.h.1.attn.c_attn.lora_B.weight"] == ("l1.b_qkv", 0, 3 * cfg["hidden"])
+    assert names["base_model.model.transformer.h.0.mlp.w1.lora_A.weight"] == ("l0.a_gu", 8, 16)                 # up = second sub-target
+    assert names["base_model.model.transformer.h.0.mlp.w2.lora_B.weight"] == ("l0.b_gu", 0, cfg["inter"])
+    assert not any("mlp.c_proj" in n for n in names)
+    assert len(names) == 2 * 4 * cfg["layers"]
+
+
+def test_registry_dispatches_qwen():
+    from vlrlhf.utils.auto_load import auto_core_mapper
+    cm = auto_core_mapper("QWenLMHeadModel")
+    assert cm.model.__name__ == "QwenVLForRL" and cm.dpo_trainer.__name__ == "QwenVLDPOTrainer"
+    with pytest.raises(NotImplementedError):
+        auto_core_mapper("InternLMXComposer2ForCausalLM")

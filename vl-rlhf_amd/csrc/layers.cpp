@@ -275,13 +275,17 @@ extern "C" int vlr_vit_layer_fwd(const vlr_vit_cfg* cfg, const vlr_vit_layer_wei
     VLR_REQUIRE(cfg && w && ws && x, "vlr_vit_layer_fwd: null argument");
     const int D = cfg->hidden, F = cfg->mlp, M = n_img * T;
     VLR_REQUIRE(cfg->heads * cfg->head_dim == D, "vlr_vit_layer_fwd: heads*head_dim != hidden");
+    const int hdp = cfg->head_dim_pad > cfg->head_dim ? cfg->head_dim_pad : cfg->head_dim;   // per-head width of the q|k|v / attention buffers
+    const int A = cfg->heads * hdp;
+    const float scale = cfg->attn_scale > 0.f ? cfg->attn_scale : 1.0f / sqrtf((float)cfg->head_dim);
+    const int act = cfg->act == 2 ? 2 /*gelu*/ : 1 /*quick_gelu*/;
     CHECK(vlr_layernorm_fwd(x, w->ln1_w, w->ln1_b, ws->xn, M, D, cfg->ln_eps, st));
-    CHECK(vlr_gemm_bf16(0, ws->xn, w->wqkv, ws->qkv, w->bqkv, nullptr, M, 3 * D, D, D, D, 3 * D, 0, 0, 0, 0, st));
-    CHECK(vlr_attn_fwd(ws->qkv, off(ws->qkv, D), off(ws->qkv, 2 * (size_t)D), 3 * D, ws->attn, D, nullptr, nullptr, n_img, T,
-                       cfg->heads, cfg->head_dim, 0, 1.0f / sqrtf((float)cfg->head_dim), st));
-    CHECK(vlr_gemm_bf16(0, ws->attn, w->wo, x, w->bo, x, M, D, D, D, D, D, D, 0, 0, 0, st));
+    CHECK(vlr_gemm_bf16(0, ws->xn, w->wqkv, ws->qkv, w->bqkv, nullptr, M, 3 * A, D, D, D, 3 * A, 0, 0, 0, 0, st));
+    CHECK(vlr_attn_fwd(ws->qkv, off(ws->qkv, A), off(ws->qkv, 2 * (size_t)A), 3 * A, ws->attn, A, nullptr, nullptr, n_img, T,
+                       cfg->heads, hdp, 0, scale, st));
+    CHECK(vlr_gemm_bf16(0, ws->attn, w->wo, x, w->bo, x, M, D, A, A, A, D, D, 0, 0, 0, st));
     CHECK(vlr_layernorm_fwd(x, w->ln2_w, w->ln2_b, ws->xn, M, D, cfg->ln_eps, st));
-    CHECK(vlr_gemm_bf16(0, ws->xn, w->w1, ws->h, w->b1, nullptr, M, F, D, D, D, F, 0, 1 /*quick_gelu*/, 0, 0, st));
+    CHECK(vlr_gemm_bf16(0, ws->xn, w->w1, ws->h, w->b1, nullptr, M, F, D, D, D, F, 0, act, 0, 0, st));
     CHECK(vlr_gemm_bf16(0, ws->h, w->w2, x, w->b2, x, M, D, F, F, F, D, D, 0, 0, 0, st));
     return VLR_OK;
 }

@@ -43,7 +43,7 @@ class LoraGrads(C.Structure):
 
 
 class VitCfg(C.Structure):
-    _fields_ = [("hidden", I), ("mlp", I), ("heads", I), ("head_dim", I), ("ln_eps", F)]
+    _fields_ = [("hidden", I), ("mlp", I), ("heads", I), ("head_dim", I), ("ln_eps", F), ("act", I), ("head_dim_pad", I), ("attn_scale", F)]
 
 
 class VitLayerWeights(C.Structure):

@@ -31,7 +31,7 @@ class ParamLayout:
     embed_tokens) so contiguous slices are the DDP buckets; then the no-decay region (norm weights, biases)."""
 
     def __init__(self, cfg):
-        H, I, V, D, L = cfg["hidden"], cfg["inter"], cfg["vocab"], cfg["vit_hidden"], cfg["layers"]
+        H, I, V, D, L = cfg["hidden"], cfg["inter"], cfg["vocab"], cfg.get("vit_hidden", 8), cfg["layers"]
         assert H % 8 == 0 and I % 8 == 0 and V % 8 == 0 and D % 8 == 0
         nh = cfg.get("heads") or 1
         nkv = cfg.get("kv_heads") or nh                       # grouped-query attention (Mistral, InternLM2)
@@ -39,28 +39,47 @@ class ParamLayout:
         Nq, Nkv = nh * hd, nkv * hd
         self.entries = []   # (name, shape, [(hf_name, row0, rows)])
         e = self.entries
-        lm = "language_model."
-        e.append(("lm_head", (V, H), [(lm + "lm_head.weight", 0, V)]))
+        qwen = cfg.get("family") == "qwen_vl"
+        if qwen:
+            # Qwen-VL (reference models/QwenVL/modeling_qwen.py): fused biased c_attn, MLP c_proj(w1(x) * silu(w2(x))) -> gate = w2,
+            # up = w1; no projector (the resampler is part of the frozen vision tower)
+            lm, layer = "", "transformer.h.{}."
+            nm = dict(lm_head="lm_head.weight", embed="transformer.wte.weight", norm="transformer.ln_f.weight", down="mlp.c_proj.weight",
+                      gate="mlp.w2.weight", up="mlp.w1.weight", o="attn.c_proj.weight", ln1="ln_1.weight", ln2="ln_2.weight")
+        else:
+            lm, layer = "language_model.", "language_model.model.layers.{}."
+            nm = dict(lm_head=lm + "lm_head.weight", embed=lm + "model.embed_tokens.weight", norm=lm + "model.norm.weight",
+                      down="mlp.down_proj.weight", gate="mlp.gate_proj.weight", up="mlp.up_proj.weight", o="self_attn.o_proj.weight",
+                      ln1="input_layernorm.weight", ln2="post_attention_layernorm.weight")
+        e.append(("lm_head", (V, H), [(nm["lm_head"], 0, V)]))
         for l in range(L - 1, -1, -1):
-            p = f"{lm}model.layers.{l}."
-            e.append((f"l{l}.wdown", (H, I), [(p + "mlp.down_proj.weight", 0, H)]))
-            e.append((f"l{l}.wgu", (2 * I, H), [(p + "mlp.gate_proj.weight", 0, I), (p + "mlp.up_proj.weight", I, I)]))
-            e.append((f"l{l}.wo", (H, Nq), [(p + "self_attn.o_proj.weight", 0, H)]))
-            e.append((f"l{l}.wqkv", (Nq + 2 * Nkv, H), [(p + "self_attn.q_proj.weight", 0, Nq), (p + "self_attn.k_proj.weight", Nq, Nkv),
-                                                        (p + "self_attn.v_proj.weight", Nq + Nkv, Nkv)]))
-        e.append(("proj.w2", (H, H), [("multi_modal_projector.linear_2.weight", 0, H)]))
-        e.append(("proj.w1", (H, D), [("multi_modal_projector.linear_1.weight", 0, H)]))
+            p = layer.format(l)
+            e.append((f"l{l}.wdown", (H, I), [(p + nm["down"], 0, H)]))
+            e.append((f"l{l}.wgu", (2 * I, H), [(p + nm["gate"], 0, I), (p + nm["up"], I, I)]))
+            e.append((f"l{l}.wo", (H, Nq), [(p + nm["o"], 0, H)]))
+            if qwen:
+                e.append((f"l{l}.wqkv", (Nq + 2 * Nkv, H), [(p + "attn.c_attn.weight", 0, Nq + 2 * Nkv)]))
+            else:
+                e.append((f"l{l}.wqkv", (Nq + 2 * Nkv, H), [(p + "self_attn.q_proj.weight", 0, Nq), (p + "self_attn.k_proj.weight", Nq, Nkv),
+                                                            (p + "self_attn.v_proj.weight", Nq + Nkv, Nkv)]))
+        self.tail_start = "embed" if qwen else "proj.w2"
+        if not qwen:
+            e.append(("proj.w2", (H, H), [("multi_modal_projector.linear_2.weight", 0, H)]))
+            e.append(("proj.w1", (H, D), [("multi_modal_projector.linear_1.weight", 0, H)]))
         if cfg.get("image_grid_pinpoints"):                   # LLaVA-Next: the row appended to every line of the un-padded tile grid
             e.append(("image_newline", (H,), [("image_newline", 0, H)]))
-        e.append(("embed", (V, H), [(lm + "model.embed_tokens.weight", 0, V)]))
+        e.append(("embed", (V, H), [(nm["embed"], 0, V)]))
         self.n_decay_entries = len(e)
-        e.append(("norm", (H,), [(lm + "model.norm.weight", 0, H)]))
+        e.append(("norm", (H,), [(nm["norm"], 0, H)]))
         for l in range(L - 1, -1, -1):
-            p = f"{lm}model.layers.{l}."
-            e.append((f"l{l}.ln2", (H,), [(p + "post_attention_layernorm.weight", 0, H)]))
-            e.append((f"l{l}.ln1", (H,), [(p + "input_layernorm.weight", 0, H)]))
-        e.append(("proj.b2", (H,), [("multi_modal_projector.linear_2.bias", 0, H)]))
-        e.append(("proj.b1", (H,), [("multi_modal_projector.linear_1.bias", 0, H)]))
+            p = layer.format(l)
+            e.append((f"l{l}.ln2", (H,), [(p + nm["ln2"], 0, H)]))
+            e.append((f"l{l}.ln1", (H,), [(p + nm["ln1"], 0, H)]))
+            if qwen:
+                e.append((f"l{l}.bqkv", (Nq + 2 * Nkv,), [(p + "attn.c_attn.bias", 0, Nq + 2 * Nkv)]))
+        if not qwen:
+            e.append(("proj.b2", (H,), [("multi_modal_projector.linear_2.bias", 0, H)]))
+            e.append(("proj.b1", (H,), [("multi_modal_projector.linear_1.bias", 0, H)]))
         self.offset = {}
         off = 0
         for i, (name, shape, _) in enumerate(e):
@@ -72,11 +91,12 @@ class ParamLayout:
         self.shape = {name: shape for name, shape, _ in e}
         # DDP buckets = contiguous slices of the flat gradient in backward-completion order
         self.bucket_after = {}   # event name -> (start, end)
-        self.bucket_after["lm_head"] = (0, self.offset[f"l{L - 1}.wdown"] if L else self.offset["proj.w2"])
+        ts = self.offset[self.tail_start]
+        self.bucket_after["lm_head"] = (0, self.offset[f"l{L - 1}.wdown"] if L else ts)
         for l in range(L - 1, -1, -1):
-            end = self.offset[f"l{l - 1}.wdown"] if l > 0 else self.offset["proj.w2"]
+            end = self.offset[f"l{l - 1}.wdown"] if l > 0 else ts
             self.bucket_after[f"layer{l}"] = (self.offset[f"l{l}.wdown"], end)
-        self.bucket_after["tail"] = (self.offset["proj.w2"], self.numel)
+        self.bucket_after["tail"] = (ts, self.numel)
 
     def hf_names(self):
         for name, shape, parts in self.entries:
@@ -89,13 +109,16 @@ LORA_KEYS = ("a_qkv", "b_qkv", "a_o", "b_o", "a_gu", "b_gu", "a_down", "b_down")
 LORA_GROUPS = (("qkv", "self_attn", ("q_proj", "k_proj", "v_proj")), ("o", "self_attn", ("o_proj",)),
                ("gu", "mlp", ("gate_proj", "up_proj")), ("down", "mlp", ("down_proj",)))
 LORA_TARGETS = tuple(t for _, _, ts in LORA_GROUPS for t in ts)
+# Qwen-VL (QwenVLForRL.default_lora_target, reference models/QwenVL/__init__.py:26-28): ONE adapter over the fused c_attn, attn.c_proj,
+# w2 (= gate) and w1 (= up); mlp.c_proj has none
+QWEN_LORA_GROUPS = (("qkv", "attn", ("c_attn",)), ("o", "attn", ("c_proj",)), ("gu", "mlp", ("w2", "w1")))
 
 
 class LoraLayout:
-    """Flat bf16 layout of the peft adapters on the seven decoder linears (LlavaForRL.default_lora_target,
-    /root/reference src/vlrlhf/models/Llava/__init__.py:273-286).  Per layer: a_qkv [3r,H] | b_qkv [3H,r] | a_o [r,H] |
-    b_o [H,r] | a_gu [2r,H] | b_gu [2I,r] | a_down [r,I] | b_down [H,r]; sub-targets of a fused group are stacked rows,
-    matching vlr_lora_weights (include/vlr.h)."""
+    """Flat bf16 layout of the peft adapters on the decoder linears.  LLaVA / LLaVA-Next (LlavaForRL.default_lora_target,
+    /root/reference src/vlrlhf/models/Llava/__init__.py:273-286), per layer: a_qkv [3r,H] | b_qkv [3H,r] | a_o [r,H] | b_o [H,r] |
+    a_gu [2r,H] | b_gu [2I,r] | a_down [r,I] | b_down [H,r]; Qwen-VL: a_qkv [r,H] | b_qkv [3H,r] | a_o | b_o | a_gu | b_gu.
+    Sub-targets of a fused group are stacked rows, matching vlr_lora_weights (include/vlr.h)."""
 
     def __init__(self, cfg, r):
         H, I, L = cfg["hidden"], cfg["inter"], cfg["layers"]
@@ -104,24 +127,34 @@ class LoraLayout:
         hd = cfg.get("head_dim") or H // nh
         Nq, Nkv = nh * hd, nkv * hd
         self.r, self.L = r, L
-        per = dict(a_qkv=(3 * r, H), b_qkv=(Nq + 2 * Nkv, r), a_o=(r, Nq), b_o=(H, r), a_gu=(2 * r, H), b_gu=(2 * I, r),
-                   a_down=(r, I), b_down=(H, r))
+        self.qwen = cfg.get("family") == "qwen_vl"
+        if self.qwen:
+            self.groups, self.prefix = QWEN_LORA_GROUPS, "base_model.model.transformer.h."
+            per = dict(a_qkv=(r, H), b_qkv=(Nq + 2 * Nkv, r), a_o=(r, Nq), b_o=(H, r), a_gu=(2 * r, H), b_gu=(2 * I, r))
+            self.out_dim = dict(c_attn=Nq + 2 * Nkv, c_proj=H, w2=I, w1=I)
+        else:
+            self.groups, self.prefix = LORA_GROUPS, "base_model.model.language_model.model.layers."
+            per = dict(a_qkv=(3 * r, H), b_qkv=(Nq + 2 * Nkv, r), a_o=(r, Nq), b_o=(H, r), a_gu=(2 * r, H), b_gu=(2 * I, r),
+                       a_down=(r, I), b_down=(H, r))
+            self.out_dim = dict(q_proj=Nq, k_proj=Nkv, v_proj=Nkv, o_proj=H, gate_proj=I, up_proj=I, down_proj=H)
+        self.keys = tuple(k for k in LORA_KEYS if k in per)
+        self.qkv_targets = 1 if self.qwen else 3
         self.offset, self.shape = {}, {}
         o = 0
         for l in range(L):
-            for k in LORA_KEYS:
+            for k in self.keys:
                 self.offset[f"l{l}.{k}"] = o
                 self.shape[f"l{l}.{k}"] = per[k]
                 o += _align(per[k][0] * per[k][1])
         self.numel = o
-        self.out_dim = dict(q_proj=Nq, k_proj=Nkv, v_proj=Nkv, o_proj=H, gate_proj=I, up_proj=I, down_proj=H)
 
-    def hf_names(self, prefix="base_model.model.language_model.model.layers."):
+    def hf_names(self, prefix=None):
         """peft adapter-file name -> (flat key, row_lo, row_hi)"""
+        prefix = self.prefix if prefix is None else prefix
         out = {}
         r = self.r
         for l in range(self.L):
-            for g, mod, ts in LORA_GROUPS:
+            for g, mod, ts in self.groups:
                 row = 0
                 for i, t in enumerate(ts):
                     od = self.out_dim[t]
@@ -219,8 +252,8 @@ class LlavaHipEngine:
         self.Nq, self.Nkv = self.nh * self.hd, self.nkv * self.hd
         self.Nqkv = self.Nq + 2 * self.Nkv
         self.anyres = bool(c.get("image_grid_pinpoints"))      # LLaVA-Next tiles
-        self.D = c["vit_hidden"]
-        self.P = (c["image_size"] // c["patch_size"]) ** 2
+        self.D = c.get("vit_hidden", 8)
+        self.P = (c["image_size"] // c["patch_size"]) ** 2 if "image_size" in c else 0
         self.layout = ParamLayout(c)
         self.max_pos = max_positions
         self.cos = torch.empty(max_positions, self.hd // 2, dtype=torch.float32, device=self.dev)
@@ -228,10 +261,7 @@ class LlavaHipEngine:
         _hip.call("vlr_rope_table", self.cos, self.sin, max_positions, self.hd, float(c.get("rope_theta", 10000.0)))
         self.llama_cfg = _hip.LlamaCfg(self.H, self.I, self.nh, self.hd, float(c.get("rms_eps", 1e-5)), max_positions,
                                        self.cos.data_ptr(), self.sin.data_ptr(), self.nkv)
-        self.vit_cfg = _hip.VitCfg(self.D, c["vit_mlp"], c["vit_heads"], self.D // c["vit_heads"],
-                                   float(c.get("vit_ln_eps", 1e-5)))
-        if self.D // c["vit_heads"] != 64:
-            raise ValueError("ViT head_dim must be 64 for the gfx950 attention kernels")
+        self._init_vision_cfg()
         self.vision: Optional[VisionWeights] = None
         self.policy = WeightSet(self.layout, self.dev)
         self.grads = torch.zeros(self.layout.numel, dtype=BF16, device=self.dev)
@@ -249,7 +279,7 @@ class LlavaHipEngine:
         self.lora_active = True                  # False inside LlavaForRL.disable_adapter() (reference pass)
         self.training = True                     # lora_dropout only in training mode
         self._norm_ws = torch.empty(_hip.helper("vlr_rmsnorm_bwd_workspace_bytes", self.H), dtype=torch.uint8, device=self.dev)
-        self._colsum_ws = torch.empty(_hip.helper("vlr_colsum_workspace_bytes", max(self.H, 8)), dtype=torch.uint8, device=self.dev)
+        self._colsum_ws = torch.empty(_hip.helper("vlr_colsum_workspace_bytes", max(self.H, self.Nqkv, 8)), dtype=torch.uint8, device=self.dev)
         self._sq_ws = torch.empty(_hip.helper("vlr_grad_sqnorm_workspace_bytes"), dtype=torch.uint8, device=self.dev)
         self.norm_out = torch.zeros(3, dtype=torch.float32, device=self.dev)
         # Optional (VLR_ASYNC_OPT=1): clip + AdamW (HBM-bound, 32 ms) on their own stream so that they overlap the next step's
@@ -261,12 +291,24 @@ class LlavaHipEngine:
         _hip.ensure_splitk_workspace(self.dev, force=True)      # a new engine brings new streams: forget the old slot assignment
 
     # ------------------------------------------------------------------------------------------------ weights
+    vision_prefix = "vision_tower."
+
+    def _init_vision_cfg(self):
+        c = self.cfg
+        self.vit_cfg = _hip.VitCfg(self.D, c["vit_mlp"], c["vit_heads"], self.D // c["vit_heads"],
+                                   float(c.get("vit_ln_eps", 1e-5)))
+        if self.D // c["vit_heads"] != 64:
+            raise ValueError("ViT head_dim must be 64 for the gfx950 attention kernels")
+
+    def _load_vision(self, sd):
+        return VisionWeights(self.cfg, sd, self.dev)
+
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
         self.policy.load_state_dict(sd)
-        self.vision = VisionWeights(self.cfg, sd, self.dev)
+        self.vision = self._load_vision(sd)
         # the frozen tower's ORIGINAL tensors (bf16, ~0.6 GB for CLIP-L): save_pretrained writes them back so that the
         # output directory reloads (reference trainer._save writes the whole model)
-        self.vision_sd = {k: v.detach().to(device=self.dev, dtype=BF16) for k, v in sd.items() if k.startswith("vision_tower.")}
+        self.vision_sd = {k: v.detach().to(device=self.dev, dtype=BF16) for k, v in sd.items() if k.startswith(self.vision_prefix)}
         self._vit_cache = None
         self._weights_version += 1
         if self.master is not None:
@@ -335,8 +377,9 @@ class LlavaHipEngine:
     def _lora_structs(self, l, train):
         lo = self.lora
         p = lo["dropout"] if (train and self.training) else 0.0
-        w = _hip.LoraWeights(lo["r"], lo["scale"], p, *(self.lv[f"l{l}.{k}"].data_ptr() for k in LORA_KEYS))
-        g = _hip.LoraGrads(*(self.lgv[f"l{l}.{k}"].data_ptr() for k in LORA_KEYS))
+        ptr = lambda views, k: views[f"l{l}.{k}"].data_ptr() if f"l{l}.{k}" in views else None   # noqa: E731  (no down adapter: NULL)
+        w = _hip.LoraWeights(lo["r"], lo["scale"], p, *(ptr(self.lv, k) for k in LORA_KEYS), self.lora_layout.qkv_targets)
+        g = _hip.LoraGrads(*(ptr(self.lgv, k) for k in LORA_KEYS))
         return w, g
 
     def merged_weights(self) -> WeightSet:
@@ -344,12 +387,12 @@ class LlavaHipEngine:
         ws = self.policy.clone()
         r, sc = self.lora["r"], self.lora["scale"]
         for l in range(self.L):
-            for g in ("qkv", "o", "gu", "down"):
+            for g, _, targets in self.lora_layout.groups:
                 W = ws.v[f"l{l}.w{g}"]
                 A, B = self.lv[f"l{l}.a_{g}"], self.lv[f"l{l}.b_{g}"]
                 inn = W.shape[1]
                 row = 0
-                for t, name in enumerate(dict(qkv=("q_proj", "k_proj", "v_proj"), o=("o_proj",), gu=("gate_proj", "up_proj"), down=("down_proj",))[g]):
+                for t, name in enumerate(targets):
                     out = self.lora_layout.out_dim[name]
                     Wt = W[row:row + out]
                     _hip.call("vlr_gemm_bf16_scaled", 1, B[row:row + out], A[t * r:(t + 1) * r], Wt, None, Wt,
@@ -459,18 +502,11 @@ class LlavaHipEngine:
         return out, z, h
 
     # ------------------------------------------------------------------------------------------------ forward
-    def forward_hidden(self, ws: WeightSet, input_ids, attention_mask, labels, pixel_values, image_dup=1, save=False,
-                       tag="ref", image_sizes=None):
-        """embed -> ViT -> projector -> merge -> decoder -> final RMSNorm.  Returns a context dict with the final
-        hidden states [Bn*S, H] and the merged labels / mask / positions."""
+    def _embed_inputs(self, ws, ids, am, lab, pixel_values, image_dup, tag, image_sizes, meta):
+        """vision tower -> projector -> merge index: everything in front of the decoder.  Returns the merged-sequence geometry
+        (S, src / inv maps, mask, positions, merged labels, image map) and the feature rows `feats` the merge gathers from."""
         c = self.cfg
-        if ws is self.policy:
-            self.wait_optimizer()
-        Bn, T = input_ids.shape
-        meta = getattr(input_ids, "_vlr_meta", None)      # per-batch cache of host-side integers (None: always recompute)
-        ids = input_ids.to(self.dev).contiguous()
-        am = attention_mask.to(self.dev).contiguous()
-        lab = labels.to(self.dev).contiguous() if labels is not None else None
+        Bn, T = ids.shape
         n_img = pixel_values.shape[0]
         if image_dup > 1:
             assert n_img % image_dup == 0
@@ -535,6 +571,25 @@ class LlavaHipEngine:
                     f"The input provided to the model are wrong. The number of image tokens is {int(n_img_tok.sum())} while"
                     f" the number of image given to the model is {n_img}. This prevents correct indexing and breaks batch"
                     " generation.")
+        return dict(S=S, M=M, src=src, mask=mask, pos=pos, labels=mlabels, img_map=img_map, inv=inv, feats=feats, vit_feat=vit_feat,
+                    proj_z=z, proj_h=h, n_rows=n_rows, n_feat=n_feat, pack=pack)
+
+    def forward_hidden(self, ws: WeightSet, input_ids, attention_mask, labels, pixel_values, image_dup=1, save=False,
+                       tag="ref", image_sizes=None):
+        """embed -> ViT -> projector -> merge -> decoder -> final RMSNorm.  Returns a context dict with the final
+        hidden states [Bn*S, H] and the merged labels / mask / positions."""
+        c = self.cfg
+        if ws is self.policy:
+            self.wait_optimizer()
+        Bn, T = input_ids.shape
+        meta = getattr(input_ids, "_vlr_meta", None)      # per-batch cache of host-side integers (None: always recompute)
+        ids = input_ids.to(self.dev).contiguous()
+        am = attention_mask.to(self.dev).contiguous()
+        lab = labels.to(self.dev).contiguous() if labels is not None else None
+        e = self._embed_inputs(ws, ids, am, lab, pixel_values, image_dup, tag, image_sizes, meta)
+        S, M = e["S"], e["M"]
+        src, mask, pos, mlabels, img_map, inv = e["src"], e["mask"], e["pos"], e["labels"], e["img_map"], e["inv"]
+        feats, vit_feat, z, h, n_rows, n_feat, pack = e["feats"], e["vit_feat"], e["proj_z"], e["proj_h"], e["n_rows"], e["n_feat"], e["pack"]
         x0 = self._buf((tag, "x0", Bn, S), (M, self.H))
         _hip.call("vlr_merge_fwd", src, ids, ws.v["embed"], feats, x0, Bn, T, S, self.H)
         x = x0
@@ -691,11 +746,22 @@ class LlavaHipEngine:
             x_in = ctx["acts"][l - 1]["x_out"] if l > 0 else ctx["x0"]
             _hip.call("vlr_decoder_layer_bwd", self.llama_cfg, self.layer_weights(ws, l), self.layer_grads(l), acc,
                       a["struct"], lws, x_in, cur, nxt, ctx["pos"], ctx["mask"], Bn, S)
+            if f"l{l}.bqkv" in self.gv:              # bias of the fused q|k|v projection: column sum of this layer's d qkv (post rope-transpose)
+                _hip.call("vlr_colsum", wsb["dqkv"], M, self.Nqkv, self.Nqkv, self.gv[f"l{l}.bqkv"], acc, self._colsum_ws)
             cur, nxt = nxt, cur
             if self.reducer is not None:
                 _hip.call("vlr_layers_join")          # wgrad GEMMs of this layer run on the library's side stream
                 self.reducer.bucket_ready(f"layer{l}")
         _hip.call("vlr_layers_join")
+        self._embed_backward(ctx, cur, acc)
+        self.grad_fresh = False
+        if self.reducer is not None:
+            self.reducer.bucket_ready("tail")
+
+    def _embed_backward(self, ctx, cur, acc):
+        """gradient of the merged embeddings `cur` [M,H] -> embed_tokens rows, projector (and image_newline) gradients"""
+        ws = ctx["ws"]
+        Bn, S, H = ctx["Bn"], ctx["S"], self.H
         # ---- merge + projector
         n_rows, dup = ctx["n_rows"], ctx["image_dup"]
         if not acc:
@@ -727,9 +793,6 @@ class LlavaHipEngine:
         _hip.call("vlr_gelu_bwd", ctx["proj_z"], dh, dz, dz.numel())
         _hip.call("vlr_colsum", dz, n_rows, H, H, self.gv["proj.b1"], acc, self._colsum_ws)
         _hip.call("vlr_gemm_bf16", 2, dz, ctx["vit_feat"], self.gv["proj.w1"], None, None, H, D, n_rows, H, D, D, 0, 0, acc, 0)
-        self.grad_fresh = False
-        if self.reducer is not None:
-            self.reducer.bucket_ready("tail")
 
     def _hidden_backward_lora(self, ctx, dhidden, dxa, dxb):
         """LoRA backward: data gradients through the frozen decoder + adapter gradients only; nothing below the first

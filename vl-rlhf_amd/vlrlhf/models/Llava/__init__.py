@@ -171,17 +171,19 @@ def _hf_from_cfg(c: dict) -> dict:
 
 
 class LlavaForRL(nn.Module):
+    engine_cls = LlavaHipEngine
+
     def __init__(self, cfg: dict, engine: Optional[LlavaHipEngine] = None, weights: Optional[WeightSet] = None,
                  trainable: bool = True):
         super().__init__()
-        self.engine = engine if engine is not None else LlavaHipEngine(cfg)
+        self.engine = engine if engine is not None else self.engine_cls(cfg)
         self.weights = weights if weights is not None else self.engine.policy
         self.config = _Config(cfg)
         self.config.setdefault("is_encoder_decoder", False)
-        self.config.setdefault("image_token_index", cfg["image_token"])
+        self.config.setdefault("image_token_index", cfg.get("image_token", -1))
         self.config.setdefault("ignore_index", -100)
         self.config.setdefault("use_cache", False)
-        self.pad_token_id = cfg.get("model_pad_token_id", cfg["image_token"] + 1)
+        self.pad_token_id = cfg.get("model_pad_token_id", cfg.get("image_token", -1) + 1)
         self._trainable = trainable and self.weights is self.engine.policy
         self._params = nn.ParameterDict()
         self._hf_names = {}
@@ -338,7 +340,7 @@ class LlavaForRL(nn.Module):
 
     def create_reference_model(self):
         """trl.create_reference_model: a frozen deep copy of the policy weights sharing the engine (and the frozen ViT)."""
-        ref = LlavaForRL(dict(self.engine.cfg), engine=self.engine, weights=self.weights.clone(), trainable=False)
+        ref = type(self)(dict(self.engine.cfg), engine=self.engine, weights=self.weights.clone(), trainable=False)
         ref.eval()
         return ref
 

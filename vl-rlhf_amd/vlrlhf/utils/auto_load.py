@@ -12,9 +12,11 @@ MODEL_NICKNAME_MAP = {
     "InstructBlipForConditionalGeneration": "InstructBlip",
     "LlavaForRL": "Llava",
     "LlavaNextForRL": "LlavaNext",
+    "QWenLMHeadModel": "QwenVL",
+    "QwenVLForRL": "QwenVL",
 }
 FLASH_ATTN_MODELS = ["LlavaForConditionalGeneration", "LlavaNextForConditionalGeneration", "LlavaForRL"]
-IMPLEMENTED = ["Llava", "LlavaNext"]
+IMPLEMENTED = ["Llava", "LlavaNext", "QwenVL"]
 
 
 def _architecture(model_name_or_path):
