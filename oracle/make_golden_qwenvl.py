@@ -178,7 +178,7 @@ def gen_model():
     for lt in ("sigmoid", "ipo", "ddpo"):
         tr.loss_type, tr.beta, tr.label_smoothing, tr.reference_free = lt, cfg["beta"], 0.0, False
         tr.label_pad_token_id, tr.is_encoder_decoder = -100, False
-        kw = dict(average_log_prob=(lt == "ipo"), label_pad_token_id=-100, is_encoder_decoder=False)
+        kw = dict(average_log_prob=False, label_pad_token_id=-100, is_encoder_decoder=False)      # as concatenated_forward calls it (base/trainer.py:230)
         if lt == "ddpo":
             kw["mask_shared_tokens"] = True
         lp = G.VLDPOTrainer.get_batch_logps(out.logits, cb["labels"], **kw)

@@ -526,7 +526,8 @@ static int seg_fallback_add(const SegArgs* sg, void* y, int ldy, int row0, int M
 static int seg_check(const char* who, const SegArgs* sg) {
     if (!sg || !sg->u) return VLR_OK;
     VLR_REQUIRE(sg->Bl && sg->r > 0 && sg->r % 8 == 0 && sg->ldu % 8 == 0 && sg->ldu >= sg->r, "%s: adapter segment r=%d ldu=%d", who, sg->r, sg->ldu);
-    VLR_REQUIRE(sg->b0 > 0 && sg->b1 >= sg->b0 && sg->b0 % 8 == 0 && (sg->b1 % 8 == 0 || sg->b1 == 0x7fffffff), "%s: adapter block bounds %d %d", who, sg->b0, sg->b1);
+    VLR_REQUIRE(sg->b0 > 0 && sg->b1 >= sg->b0 && (sg->b0 % 8 == 0 || sg->b0 == 0x7fffffff) && (sg->b1 % 8 == 0 || sg->b1 == 0x7fffffff),
+                "%s: adapter block bounds %d %d", who, sg->b0, sg->b1);
     return VLR_OK;
 }
 
