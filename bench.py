@@ -39,6 +39,21 @@ PROFILE_FILE = "profiles/r02_rocprofv3_kernel_stats_bench.csv"   # rocprofv3 --k
 TFLOP_PER_PAIR = {"ref_in_step": 174.87, "ref_precomputed": 131.24}
 
 
+def tflop_per_pair_qwen(cfg, S, ref_in_step=True, lora=False):
+    """same counting rules for Qwen-VL: decoder as below (S = T: the 256 image slots are part of the ids), frozen ViT-bigG + resampler
+    once per image; under LoRA the backward is the data gradient only (1x forward instead of 2x; adapter FLOPs not counted)"""
+    H, I, V, L, nh = cfg["hidden"], cfg["inter"], cfg["vocab"], cfg["layers"], cfg["heads"]
+    dense = 2 * (L * (4 * H * H + 3 * H * I) + V * H)
+    attn = L * 4 * H * (S + 1) / 2
+    fwd = 2 * S * (dense + attn)
+    v = cfg["visual"]
+    W, E, T, nq = v["width"], v["output_dim"], (v["image_size"] // v["patch_size"]) ** 2, v.get("n_queries", 256)
+    F = int(W * v["mlp_ratio"])
+    vit = v["layers"] * (2 * T * (4 * W * W + 2 * W * F) + 4 * T * T * W) + 2 * T * (W * E + 2 * E * E) + 4 * nq * T * E + 4 * nq * E * E
+    passes = (1 if ref_in_step else 0) + 1 + (1 if lora else 2)
+    return (passes * fwd + vit) / 1e12
+
+
 def tflop_per_pair(cfg, S, tiles_per_image=1, ref_in_step=True):
     """BASELINE.md section 3 counting rules for any decoder of this family (2 FLOP/MAC, causal attention at half, lm-head on all
     positions, backward = 2x forward, frozen ViT once per image tile, reference forward 1x when it runs inside the step);
@@ -161,7 +176,7 @@ def main():
     ap.add_argument("--precomputed_ref", action="store_true", help="stream precomputed reference log-probs (SURVEY 8f rank 1)")
     ap.add_argument("--lora", action="store_true", help="variant: LoRA DPO of scripts/ddpo_llava.sh (r=128, alpha=256, dropout 0.05)")
     ap.add_argument("--lora_dropout", type=float, default=0.05)
-    ap.add_argument("--model", default="llava", choices=["llava", "llava_next"],
+    ap.add_argument("--model", default="llava", choices=["llava", "llava_next", "qwen_vl"],
                     help="llava_next: variant on BASELINE.json configs[3] (LLaVA-Next-Mistral-7B, anyres 672x672 image, DDPO); not the headline line")
     ap.add_argument("--loss_type", default=None)
     ap.add_argument("--dry_run_launch", action="store_true", help="CPU test of the self-launch path: no model, gloo, no-op steps")
@@ -191,24 +206,32 @@ def main():
         from vlrlhf.models.LlavaNext import LLAVA_NEXT_MISTRAL_7B, LlavaNextDPOTrainer, LlavaNextForRL
         from vlrlhf.utils.synthetic import synthetic_batch_anyres
         cfg, LlavaForRL, Trainer = dict(LLAVA_NEXT_MISTRAL_7B), LlavaNextForRL, LlavaNextDPOTrainer
+    qwen = a.model == "qwen_vl"
+    if qwen:
+        from vlrlhf.models.QwenVL import QWEN_VL_CHAT, QwenVLDPOTrainer, QwenVLForRL
+        from vlrlhf.utils.synthetic import init_hashed_qwen, synthetic_batch_qwen
+        cfg, LlavaForRL, Trainer = dict(QWEN_VL_CHAT), QwenVLForRL, QwenVLDPOTrainer
     loss_type = a.loss_type or ("ddpo" if nxt else "sigmoid")
     if a.layers:
         cfg["layers"] = a.layers
     model = LlavaForRL(cfg)
-    ref = init_random_model(model, seed=0, std=0.02, policy_delta=1e-3)
+    pad_id = cfg["pad_token_id"] if qwen else 0
+    lora_r, lora_alpha = (64, 16) if qwen else (128, 256)          # scripts/dpo_qwenvl.sh / scripts/ddpo_llava.sh
+    ref = init_hashed_qwen(model, seed=0, std=0.02, policy_delta=1e-3, with_reference=not a.lora) if qwen else \
+        init_random_model(model, seed=0, std=0.02, policy_delta=1e-3)
     eng = model.engine
     args = SimpleNamespace(gradient_accumulation_steps=1)
     if a.lora:
         del ref
-        tr = Trainer(model, None, 0.1, 0, loss_type, args, None, -100, 0,
-                             peft_config=dict(r=128, lora_alpha=256, lora_dropout=a.lora_dropout, target_modules="auto", bias="none", seed=rank))
+        tr = Trainer(model, None, 0.1, 0, loss_type, args, None, -100, pad_id,
+                             peft_config=dict(r=lora_r, lora_alpha=lora_alpha, lora_dropout=a.lora_dropout, target_modules="auto", bias="none", seed=rank))
         gen = torch.Generator(device=eng.dev)
         gen.manual_seed(4321 + rank)
         for k, t_ in eng.lv.items():             # peft initialises B = 0; random B (seeded) so the adapter GEMMs do real arithmetic
             if ".b_" in k:
                 t_.normal_(0.0, 1e-3, generator=gen)
     else:
-        tr = Trainer(model, None if a.precomputed_ref else ref, 0.1, 0, loss_type, args, None, -100, 0,
+        tr = Trainer(model, None if a.precomputed_ref else ref, 0.1, 0, loss_type, args, None, -100, pad_id,
                      precompute_ref_log_probs=a.precomputed_ref)
     eng.init_optimizer()
     reducer = eng.make_reducer() if world > 1 else None
@@ -218,8 +241,11 @@ def main():
     # four resident batches per rank (seeds 1234 + rank + 1000*i), rotated: inputs are in HBM before the timed region
     batches = []
     for i in range(4):
-        mk = synthetic_batch_anyres if nxt else synthetic_batch
-        b_ = tr._prepare_inputs(mk(a.pairs, a.text_len, cfg["image_token"], 32000, cfg["image_size"], seed=1234 + rank + 1000 * i))
+        if qwen:
+            b_ = tr._prepare_inputs(synthetic_batch_qwen(a.pairs, a.text_len, cfg, seed=1234 + rank + 1000 * i))
+        else:
+            mk = synthetic_batch_anyres if nxt else synthetic_batch
+            b_ = tr._prepare_inputs(mk(a.pairs, a.text_len, cfg["image_token"], 32000, cfg["image_size"], seed=1234 + rank + 1000 * i))
         if a.precomputed_ref:
             with torch.no_grad():
                 rc, rr, _, _ = tr.concatenated_forward(ref, b_)
@@ -304,6 +330,8 @@ def main():
     if nxt:
         n_tiles = int(batches[0]["img_input_dict"]["pixel_values"].shape[1])
         per_pair = tflop_per_pair(cfg, S_dec, n_tiles, not a.precomputed_ref)
+    if qwen:
+        per_pair = tflop_per_pair_qwen(cfg, S_dec, not a.precomputed_ref, a.lora)
     if rank == 0:
         achieved = g_flop / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
         line = {
@@ -341,7 +369,17 @@ def main():
                                           "full fine-tune of LLM+projector+image_newline, frozen ViT, reference forward inside the step")
             line["config"]["variant"] = "llava_next (not the headline configuration)"
             line["config"]["tflop_per_pair"] = round(per_pair, 2)
-        if a.lora:
+        if qwen:
+            line["metric"] = "preference-pairs/sec (chosen+rejected) Qwen-VL-Chat DPO step"
+            line["config"]["workload"] = (f"variant on BASELINE.json configs[2]: Qwen-VL-Chat DPO bf16, 448x448 image (1024 patches -> 256 resampler "
+                                          f"slots inside the ids), max_length {a.text_len}, per-device batch {a.pairs} pairs (S={S_dec}), "
+                                          + (f"LoRA r={lora_r} alpha={lora_alpha} dropout={a.lora_dropout} on c_attn / attn.c_proj / w1 / w2 (scripts/dpo_qwenvl.sh), frozen base, "
+                                             "reference = adapters disabled" if a.lora else "full fine-tune of the language model, reference forward inside the step")
+                                          + ", frozen vision tower + resampler")
+            line["config"]["variant"] = "qwen_vl" + ("+lora" if a.lora else "") + " (not the headline configuration)"
+            line["config"]["tflop_per_pair"] = round(per_pair, 2)
+            line["roofline"]["step_frac"] = round(pairs_per_s / world * per_pair / PEAK_BF16_TFLOPS, 4)
+        elif a.lora:
             line["config"]["workload"] = line["config"]["workload"].replace(
                 "full fine-tune of LLM+projector", "LoRA r=128 alpha=256 dropout=0.05 on the 7 decoder linears (scripts/ddpo_llava.sh), frozen base")
             line["config"]["variant"] = "lora (not the headline configuration)"

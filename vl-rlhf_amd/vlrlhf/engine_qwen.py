@@ -48,8 +48,9 @@ class QwenVisionWeights:
             raise ValueError(f"Qwen-VL vision tower: width {W} / heads {nh} / output_dim {E} do not fit the 128-wide attention kernel")
         dv = lambda t: t.to(BF16).to(device).contiguous()  # noqa: E731
         g = lambda k: sd[prefix + k].float()                # noqa: E731
+        src_dev = sd[prefix + "conv1.weight"].device         # packing runs where the checkpoint tensors live (host or device)
         self.Kp = _align(3 * P * P, 8)
-        w = torch.zeros(W, self.Kp)
+        w = torch.zeros(W, self.Kp, device=src_dev)
         w[:, : 3 * P * P] = g("conv1.weight").reshape(W, -1)
         self.patch_w = dv(w)
         self.pos = dv(get_abs_pos(g("positional_embedding"), self.T))                       # [T, W]
@@ -57,18 +58,19 @@ class QwenVisionWeights:
         # q|k|v rows: the reference stores them per head as [q_h | k_h | v_h] (visual.py:203-211); here q | k | v blocks of
         # heads x 128 rows, rows d >= head_dim of every head zero
         A = nh * self.hdp
-        idx = torch.arange(nh)[:, None] * 3 * hd + torch.arange(hd)[None, :]               # row of (head, d) of the q block in the reference
+        ar = lambda n_: torch.arange(n_, device=src_dev)     # noqa: E731
+        idx = ar(nh)[:, None] * 3 * hd + ar(hd)[None, :]                                   # row of (head, d) of the q block in the reference
         self.layers, self._keep = [], []
         for l in range(L):
             p = f"transformer.resblocks.{l}."
             wi, bi = g(p + "attn.in_proj.weight"), g(p + "attn.in_proj.bias")
-            wqkv, bqkv = torch.zeros(3 * A, W), torch.zeros(3 * A)
+            wqkv, bqkv = torch.zeros(3 * A, W, device=src_dev), torch.zeros(3 * A, device=src_dev)
             for blk in range(3):
                 rows = (idx + blk * hd).reshape(-1)
-                dst = (blk * A + torch.arange(nh)[:, None] * self.hdp + torch.arange(hd)[None, :]).reshape(-1)
+                dst = (blk * A + ar(nh)[:, None] * self.hdp + ar(hd)[None, :]).reshape(-1)
                 wqkv[dst], bqkv[dst] = wi[rows], bi[rows]
-            wo = torch.zeros(W, A)
-            cols = (torch.arange(nh)[:, None] * self.hdp + torch.arange(hd)[None, :]).reshape(-1)
+            wo = torch.zeros(W, A, device=src_dev)
+            cols = (ar(nh)[:, None] * self.hdp + ar(hd)[None, :]).reshape(-1)
             wo[:, cols] = g(p + "attn.out_proj.weight")
             t = dict(ln1_w=dv(g(p + "ln_1.weight")), ln1_b=dv(g(p + "ln_1.bias")), wqkv=dv(wqkv), bqkv=dv(bqkv), wo=dv(wo),
                      bo=dv(g(p + "attn.out_proj.bias")), ln2_w=dv(g(p + "ln_2.weight")), ln2_b=dv(g(p + "ln_2.bias")),

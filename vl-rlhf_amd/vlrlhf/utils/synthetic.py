@@ -175,3 +175,86 @@ def synthetic_batch_anyres(pairs, text_len, image_token, vocab_hi, image_size, s
     tiles = torch.stack([synthetic_pixels(n, image_size, seed + 11 + i) for i in range(pairs)])
     batch["img_input_dict"] = dict(pixel_values=tiles, image_sizes=torch.tensor([list(image_hw)] * pairs, dtype=torch.long))
     return batch
+
+
+# ---------------------------------------------------------------------------------------------------- Qwen-VL (BASELINE configs[2])
+def qwen_vision_shapes(vcfg, prefix="transformer.visual."):
+    """tensor shapes of the Qwen-VL vision tower's state_dict (reference models/QwenVL/visual.py:330-390)"""
+    W, E, L, P = vcfg["width"], vcfg["output_dim"], vcfg["layers"], vcfg["patch_size"]
+    F = int(W * vcfg["mlp_ratio"])
+    nq = int(vcfg.get("n_queries", 256))
+    sh = {prefix + "positional_embedding": (256, W), prefix + "proj": (E, E), prefix + "conv1.weight": (W, 3, P, P),
+          prefix + "ln_pre.weight": (W,), prefix + "ln_pre.bias": (W,), prefix + "ln_post.weight": (E,), prefix + "ln_post.bias": (E,)}
+    for i in range(L):
+        p = f"{prefix}transformer.resblocks.{i}."
+        for nm in ("ln_1", "ln_2"):
+            sh[p + nm + ".weight"], sh[p + nm + ".bias"] = (W,), (W,)
+        sh[p + "attn.in_proj.weight"], sh[p + "attn.in_proj.bias"] = (3 * W, W), (3 * W,)
+        sh[p + "attn.out_proj.weight"], sh[p + "attn.out_proj.bias"] = (W, W), (W,)
+        sh[p + "mlp.c_fc.weight"], sh[p + "mlp.c_fc.bias"] = (F, W), (F,)
+        sh[p + "mlp.c_proj.weight"], sh[p + "mlp.c_proj.bias"] = (W, F), (W,)
+    a = prefix + "attn_pool."
+    sh.update({a + "pos_embed": (nq, E), a + "query": (nq, E), a + "kv_proj.weight": (E, W), a + "attn.in_proj_weight": (3 * E, E),
+               a + "attn.in_proj_bias": (3 * E,), a + "attn.out_proj.weight": (E, E), a + "attn.out_proj.bias": (E,),
+               a + "ln_q.weight": (E,), a + "ln_q.bias": (E,), a + "ln_kv.weight": (E,), a + "ln_kv.bias": (E,)})
+    return sh
+
+
+def init_hashed_qwen(model, seed=0, std=0.02, policy_delta=1e-3, seed_delta=1, with_reference=True):
+    """hashed_normal weights for a QwenVLForRL (names = the reference checkpoint's keys).  Returns the reference model (or None)."""
+    eng = model.engine
+    dev = eng.dev
+
+    def draw(name, shape, delta):
+        numel = 1
+        for s_ in shape:
+            numel *= s_
+        n = hashed_normal(numel, seed, name, dev).view(*shape)
+        gain = name.endswith((".weight",)) and (".ln_" in name or "ln_f" in name or "ln_pre" in name or "ln_post" in name)
+        t = ((n * 0.05 + 1.0) if gain else n * std).to(torch.bfloat16)
+        if delta > 0 and not name.startswith("transformer.visual."):
+            t = (t.float() + hashed_normal(numel, seed_delta, name, dev).view(*shape) * delta).to(torch.bfloat16)
+        return t
+
+    ref = model.create_reference_model() if with_reference else None
+    for ws, delta in (((ref.weights, 0.0),) if ref is not None else ()) + ((eng.policy, policy_delta if ref is not None else 0.0),):
+        for hf, name, r0, rows in eng.layout.hf_names():
+            dst = ws.v[name]
+            if dst.dim() == 1:
+                dst.copy_(draw(hf, tuple(dst.shape), delta))
+            else:
+                dst[r0:r0 + rows].copy_(draw(hf, (rows, dst.shape[1]), delta))
+    eng.vision = eng._load_vision({k: draw(k, s_, 0.0) for k, s_ in qwen_vision_shapes(eng.cfg["visual"]).items()})
+    eng._vit_cache = None
+    return ref
+
+
+def synthetic_batch_qwen(pairs, text_len, cfg, seed, prompt_frac=0.5):
+    """`pairs` preference pairs of `text_len` ids each (the 258 ids of one <img>...</img> slot included, as the Qwen tokenizer emits
+    them); chosen / rejected share prompt and image; responses of different lengths so that right padding occurs."""
+    g = torch.Generator().manual_seed(seed)
+    st, nq, s = cfg["image_start_id"], cfg["visual"].get("n_queries", 256), cfg["visual"]["image_size"]
+    lo_txt = 256                                          # ids below 256 are raw bytes (image paths)
+    vocab_hi = min(cfg["vocab"], st) - 1
+    n_prompt = max(nq + 8, int(text_len * prompt_frac))
+    batch = {k: [] for k in ("chosen_input_ids", "chosen_attention_mask", "chosen_labels", "rejected_input_ids", "rejected_attention_mask",
+                             "rejected_labels")}
+    pad = cfg.get("pad_token_id", 0)
+    for i in range(pairs):
+        path = list(f"synthetic/{seed}/{i}.png".encode())
+        slot = [st] + path + [st + 2] * (nq - len(path)) + [st + 1]
+        pre = torch.randint(lo_txt, vocab_hi, (3,), generator=g).tolist()
+        post = torch.randint(lo_txt, vocab_hi, (n_prompt - len(slot) - 3,), generator=g).tolist()
+        prompt = pre + slot + post
+        for side, frac in (("chosen", 1.0), ("rejected", 0.8 - 0.1 * (i % 3))):
+            n_resp = max(4, int((text_len - n_prompt) * frac))
+            resp = torch.randint(lo_txt, vocab_hi, (n_resp,), generator=g).tolist()
+            ids = prompt + resp
+            k = text_len - len(ids)
+            batch[f"{side}_input_ids"].append(ids + [pad] * k)
+            batch[f"{side}_attention_mask"].append([1] * len(ids) + [0] * k)
+            batch[f"{side}_labels"].append([-100] * len(prompt) + resp + [-100] * k)
+    out = {k: torch.tensor(v, dtype=torch.long) for k, v in batch.items()}
+    out["img_input_dict"] = dict(pixel_values=torch.randn(pairs, 3, s, s, generator=g))
+    out["img_path"] = [f"synthetic/{seed}/{i}.png" for i in range(pairs)]
+    return out
