@@ -130,7 +130,7 @@ def clip_vit_features(pixel_values, W: Dict[str, torch.Tensor], cfg: dict, emula
     eps = cfg.get("vit_ln_eps", 1e-5)
     x = r(F.layer_norm(x, (D,), W[prefix + "pre_layrnorm.weight"], W[prefix + "pre_layrnorm.bias"], eps))
     hd = D // nh
-    n_eval = cfg["vit_layers"] - 1          # vision_feature_layer = -2
+    n_eval = cfg["vit_layers"] + 1 + cfg.get("vit_feature_layer", -2)   # vision_feature_layer = -2 (LLaVA); -1 = every layer (InternLM-XC2)
     for i in range(n_eval):
         p = f"{prefix}encoder.layers.{i}."
         h = r(F.layer_norm(x, (D,), W[p + "layer_norm1.weight"], W[p + "layer_norm1.bias"], eps))

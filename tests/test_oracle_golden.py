@@ -337,3 +337,44 @@ def test_qwenvl_oracle_matches_reference_golden():
             assert abs(float(g.norm()) - float(z["grad_norm." + k[11:]])) <= 2e-3 * float(z["grad_norm." + k[11:]]), k
             checked += 1
     assert checked == 10
+
+
+# ------------------------------------------------------------------------------------------------------------ InternLM-XComposer2
+def test_internlm_oracle_matches_reference_golden():
+    """oracle/internlm_oracle.py against tests/golden/internlmxc2_small.npz = outputs of the reference's own InternLMXC2ForRL forward
+    (LLaVA-style merge, InternLM2 decoder with the fused grouped-query wqkv and PLoRA on the image rows) and autograd."""
+    from oracle import internlm_oracle as IL
+    z, cfg, W, W_ref, batch, _ = load_case("internlmxc2_small")
+    cb = O.concatenated_inputs(batch, padding_value=cfg["model_pad_token_id"])
+    ids, am, lab = cb["concatenated_input_ids"], cb["concatenated_attention_mask"], cb["concatenated_labels"]
+    px2 = cb["concatenated_img_input_dict"]["pixel_values"]
+    names = {k.split(".", 1)[1] for k in z.files if k.startswith(("grad.", "grad_probe."))}
+    Wg = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in W.items()}
+    logits, labels, aux = IL.internlm_forward(Wg, cfg, ids, am, lab, px2)
+    assert torch.equal(labels, t(z, "merged_labels")) and torch.equal(aux["img_map"], t(z, "image_position_map"))
+    n = batch["chosen_input_ids"].shape[0]
+    assert torch.allclose(aux["image_features"][:n], t(z, "image_features"), rtol=2e-4, atol=2e-4)
+    ref_logits = t(z, "logits")
+    assert float((logits - ref_logits).abs().max()) < 2e-3 * float(ref_logits.abs().max())
+    for lt in ("sigmoid", "ddpo"):
+        pc, pr, _, _ = IL.concatenated_forward(W, cfg, batch, lt)
+        rc, rr, _, _ = IL.concatenated_forward(W_ref, cfg, batch, lt)
+        assert torch.allclose(torch.cat([pc, pr]), t(z, f"{lt}.logps"), rtol=1e-4, atol=2e-3)
+        assert torch.allclose(torch.cat([rc, rr]), t(z, f"{lt}.ref_logps"), rtol=1e-4, atol=2e-3)
+        losses, _, _ = O.dpo_loss(pc, pr, rc, rr, cfg["beta"], 0.0, lt, False)
+        assert torch.allclose(losses, t(z, f"{lt}.losses"), rtol=2e-3, atol=2e-4)
+    lp = O.get_batch_logps(logits, labels)
+    rl = t(z, "sigmoid.ref_logps")
+    losses, _, _ = O.dpo_loss(lp[:n], lp[n:], rl[:n], rl[n:], cfg["beta"], 0.0, "sigmoid", False)
+    losses.mean().backward()
+    checked = 0
+    for k in z.files:
+        if k.startswith("grad."):
+            g, ref = Wg[k[5:]].grad, t(z, k)
+            assert float((g - ref).abs().max()) <= 2e-3 * float(ref.abs().max()) + 1e-7, k
+            checked += 1
+        elif k.startswith("grad_probe."):
+            g, ref = Wg[k[11:]].grad, t(z, k)
+            assert float((g.reshape(-1)[::17] - ref).abs().max()) <= 2e-3 * float(ref.abs().max()) + 1e-7, k
+            checked += 1
+    assert checked == 13
