@@ -114,6 +114,12 @@ int vlr_colsum(const void* X, int R, int C, int ld, void* out, int accumulate, v
 int vlr_colsum_f32(const void* X, int R, int C, int ld, float* out, void* workspace, vlr_stream_t stream);
 int vlr_gather_rows(const void* src, const int* rows, void* dst, int R, int H, vlr_stream_t stream);
 int vlr_scatter_rows(const void* src, const int* rows, void* dst, int R, int H, vlr_stream_t stream);
+/* strided row-list operations on a column block of a wider matrix (PLoRA of InternLM-XComposer2, reference
+ * models/InternLMXC2/build_mlp.py:194-202: `res[im_mask] += Plora_B(Plora_A(x[im_mask]))`):
+ *   vlr_rows_gather: dst [R][W] (contiguous) = src[rows[r]][0:W], src row stride lds
+ *   vlr_rows_add   : dst[rows[r]][0:W] += src [R][W], dst row stride ldd; `rows` must not repeat */
+int vlr_rows_gather(const void* src, int lds, const int* rows, void* dst, int R, int W, vlr_stream_t stream);
+int vlr_rows_add(const void* src, const int* rows, void* dst, int ldd, int R, int W, vlr_stream_t stream);
 int vlr_cast_f32_to_bf16(const float* src, void* dst, long n, vlr_stream_t stream);
 int vlr_cast_bf16_to_f32(const void* src, float* dst, long n, vlr_stream_t stream);
 int vlr_rowdot(const void* X, const float* v, float* out, int M, int H, vlr_stream_t stream);

@@ -1,0 +1,168 @@
+"""InternLM-XComposer2-VL (BASELINE.json configs[4]) on the MI355X against tests/golden/internlmxc2_small.npz - outputs of the
+reference's own InternLMXC2ForRL forward (LLaVA-style merge, InternLM2 decoder with PLoRA on the image rows) in eval mode, its
+get_batch_logps / dpo_loss and autograd (oracle/make_golden_internlm.py) - and, for the stochastic parts (PLoRA dropout, peft LoRA),
+against the CPU oracle's restatement with the SAME counter-based masks."""
+import math
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import internlm_oracle as IL  # noqa: E402  (checker only)
+from oracle import llava_dpo_oracle as O  # noqa: E402  (checker only)
+from tests.golden_util import load_case, t  # noqa: E402
+from tests.test_hip_e2e import TOL_LOGPS_FP32, TOL_LOSS_BF16, TOL_LOSS_FP32, cosine, relmax  # noqa: E402
+
+
+def build(lora=None, loss_type="sigmoid", **over):
+    from vlrlhf.models.InternLMXC2 import InternLMXC2DPOTrainer, InternLMXC2ForRL
+    z, cfg, W, W_ref, batch, _ = load_case("internlmxc2_small")
+    cfg = dict(cfg, **over)
+    model = InternLMXC2ForRL.from_state_dict(cfg, W)
+    ref = None
+    if lora is None:
+        ref = model.create_reference_model()
+        ref.weights.load_state_dict(W_ref)
+    kw = dict(peft_config=lora) if lora is not None else {}
+    tr = InternLMXC2DPOTrainer(model, ref, cfg["beta"], 0, loss_type, SimpleNamespace(gradient_accumulation_steps=1), None, -100,
+                               cfg["model_pad_token_id"], **kw)
+    return z, cfg, W, W_ref, batch, model, ref, tr
+
+
+def test_internlm_forward_matches_reference_golden():
+    z, cfg, W, W_ref, batch, model, ref, tr = build()
+    cb = tr.concatenated_inputs(batch, device=torch.device("cuda"))
+    model.eval()
+    with torch.no_grad():
+        out = model(input_ids=cb["concatenated_input_ids"], attention_mask=cb["concatenated_attention_mask"],
+                    labels=cb["concatenated_labels"], use_cache=False, **cb["concatenated_img_input_dict"])
+    c = out.logits.c
+    assert torch.equal(out.labels.cpu(), t(z, "merged_labels")) and torch.equal(out.image_position_map.cpu(), t(z, "image_position_map"))
+    P = (cfg["image_size"] // cfg["patch_size"]) ** 2
+    assert relmax(c["feats"].reshape(-1, P, cfg["hidden"]), t(z, "image_features")) < 3e-2      # CLIP LAST hidden state -> mlp2x_gelu
+    assert torch.equal(c["pos"][0].cpu().long(), torch.arange(c["S"]))                           # rotary position = index in the merged sequence
+    valid = c["mask"].bool().cpu()
+    logits = out.logits.materialize().cpu()
+    assert relmax(logits[valid], t(z, "logits")[valid]) < 4e-2
+    for lt, kw in (("sigmoid", {}), ("ddpo", dict(mask_shared_tokens=True))):
+        lp = tr.get_batch_logps(out.logits, out.labels, **kw)
+        assert float((lp.cpu() - t(z, f"{lt}.logps")).abs().max()) < TOL_LOGPS_FP32, lt
+    with torch.no_grad():
+        rc, rr, _, _ = tr.concatenated_forward(ref, batch)
+        pc, pr, _, _ = tr.concatenated_forward(model, batch)
+    assert float((torch.cat([rc, rr]).cpu() - t(z, "sigmoid.ref_logps")).abs().max()) < TOL_LOGPS_FP32
+    losses, _, _ = tr.dpo_loss(pc, pr, rc, rr)
+    assert float((losses.cpu() - t(z, "sigmoid.losses")).abs().max()) < 2.5e-2
+    bad = cb["concatenated_input_ids"].clone()
+    bad[0, 1] = cfg["image_token"]                                   # one more <ImageHere> than images
+    with pytest.raises(ValueError, match="image tokens"):
+        model(input_ids=bad, attention_mask=cb["concatenated_attention_mask"], labels=cb["concatenated_labels"], **cb["concatenated_img_input_dict"])
+
+
+def test_internlm_train_step_gradients_match_reference_autograd():
+    """full fine-tune (tower + projector frozen): base weights AND the PLoRA pairs get gradients; dropout off = the reference's eval-mode
+    autograd.  wqkv / its Plora_B live in q | k | v row order inside the engine: compared after undoing the permutation."""
+    z, cfg, W, W_ref, batch, model, ref, tr = build(plora_dropout=0.0)
+    eng = model.engine
+    eng.init_optimizer()
+    loss = tr.training_step(model, batch)
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(z["sigmoid.loss"])) < TOL_LOSS_FP32, (float(loss), float(z["sigmoid.loss"]))
+    gsd = type(eng.policy)(eng.layout, eng.dev, eng.grads).state_dict()      # gradients under checkpoint names / row order
+    assert "vision_proj.0.weight" in gsd and float(gsd["vision_proj.0.weight"].float().abs().max()) == 0.0      # frozen: never written
+    n = 0
+    for k in z.files:
+        if k.startswith("grad."):
+            name, ref_g = k[5:], t(z, k)
+            mine = gsd[name].float().cpu()
+        elif k.startswith("grad_probe."):
+            name, ref_g = k[11:], t(z, k)
+            mine = gsd[name].float().cpu().reshape(-1)[::17]
+            assert abs(float(gsd[name].float().norm()) / float(z["grad_norm." + name]) - 1.0) < 6e-2, name
+        else:
+            continue
+        cs = cosine(mine, ref_g)
+        assert cs > 0.99, f"{name}: cosine {cs:.4f}"
+        n += 1
+    assert n == 13
+    before = eng.policy.v["proj.w1"].clone()
+    eng.optimizer_step(lr=1e-3, beta1=0.9, beta2=0.95, eps=1e-6, weight_decay=0.1, max_grad_norm=1.0)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.policy.v["proj.w1"], before)              # outside the optimizer's range: no update, no weight decay
+    loss2 = tr.training_step(model, batch)
+    assert torch.isfinite(loss2) and float(loss2) < float(loss)
+
+
+def test_internlm_policy_equal_reference_gives_ln2():
+    z, cfg, W, W_ref, batch, model, ref, tr = build(plora_dropout=0.0)
+    ref.weights.load_state_dict(W)
+    loss = tr.training_step(model, batch)
+    assert float(loss) == pytest.approx(math.log(2.0), abs=1e-6)
+
+
+def test_internlm_plora_dropout_step_matches_oracle():
+    """training mode: PLoRA's dropout (p = 0.05 in the model code; 0.25 here to make it bite) on the image rows of the policy pass only"""
+    z, cfg, W, W_ref, batch, model, ref, tr = build(plora_dropout=0.25)
+    eng = model.engine
+    loss = tr.training_step(model, batch)
+    torch.cuda.synchronize()
+    from vlrlhf.engine_internlm import PLORA_SEED_XOR
+    pseed = ((eng.plora_seed << 40) + (eng._plora_calls << 16)) ^ PLORA_SEED_XOR
+    with torch.no_grad():
+        l16, _ = IL.compute_loss(W, W_ref, cfg, batch, cfg["beta"], emulate_bf16=True, plora=dict(seed=pseed, p=0.25))
+        l_nodrop, _ = IL.compute_loss(W, W_ref, cfg, batch, cfg["beta"], emulate_bf16=True)
+    assert abs(float(loss) - float(l16)) < TOL_LOSS_BF16 + 2e-3, (float(loss), float(l16))
+    assert abs(float(l16) - float(l_nodrop)) > 3 * abs(float(loss) - float(l16))      # the mask matters and it is the right one
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.25])
+def test_internlm_lora_step_matches_oracle(dropout):
+    """scripts/dpo_internlmxc2vl7b.sh: peft LoRA on the five PLoRA linears (one adapter over the fused wqkv, lora_B rows in the
+    checkpoint's per-K/V-head order), base + PLoRA frozen but active, reference = adapters disabled"""
+    pc = dict(r=8, lora_alpha=8, lora_dropout=dropout, target_modules="auto", bias="none", seed=5)
+    z, cfg, W, W_ref, batch, model, ref, tr = build(lora=pc, plora_dropout=0.0)
+    assert tr.ref_model is None and tr.is_peft_model
+    lora = IL.random_lora(cfg, r=8, alpha=8, seed=3, b_std=0.05, dropout=dropout)
+    lora["W"] = {k: v.bfloat16().float() for k, v in lora["W"].items()}
+    eng = model.engine
+    eng.load_lora_state_dict(lora["W"])
+    names = [n for n, _ in model.named_parameters()]
+    assert len(names) == 2 * 5 * cfg["layers"] and all(".lora_" in n for n in names)
+    base_before = eng.policy.flat.clone()
+    eng.init_optimizer()
+    loss = tr.training_step(model, batch)
+    torch.cuda.synchronize()
+    lora["seed"] = (5 << 40) + (eng._lora_calls << 16)
+    Wl = {k: v.clone().requires_grad_(True) for k, v in lora["W"].items()}
+    l16, _ = IL.compute_loss(W, W, cfg, batch, cfg["beta"], emulate_bf16=True, lora=dict(lora, W=Wl))
+    assert abs(float(loss) - float(l16)) < TOL_LOSS_BF16 + 2e-3, (float(loss), float(l16))
+    l16.backward()
+    # adapter gradients under checkpoint names / row order
+    eng.lv, keep = eng.lgv, eng.lv
+    try:
+        gsd = eng.lora_state_dict()
+    finally:
+        eng.lv = keep
+    for k, v in Wl.items():
+        cs = cosine(gsd[k], v.grad)
+        assert cs > 0.98, f"{k}: cosine {cs:.4f}"
+    eng.optimizer_step(lr=1e-3, beta1=0.9, beta2=0.95, eps=1e-6, weight_decay=0.1, max_grad_norm=1.0)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.policy.flat, base_before)
+    assert set(model.lora_state_dict()) == set(lora["W"])
+
+
+def test_internlm_save_and_reload(tmp_path):
+    from vlrlhf.models.InternLMXC2 import InternLMXC2ForRL
+    from vlrlhf.utils.auto_load import MyAutoModel
+    z, cfg, W, W_ref, batch, model, ref, tr = build()
+    sd = model.state_dict()
+    k = "model.layers.1.attention.wqkv.weight"
+    assert torch.equal(sd[k].float().cpu(), W[k])                    # back in the checkpoint's per-K/V-head row order
+    assert not torch.equal(model.engine.policy.v["l1.wqkv"].float().cpu(), W[k])
+    model.save_pretrained(str(tmp_path))
+    m2 = MyAutoModel.from_pretrained(str(tmp_path))
+    assert isinstance(m2, InternLMXC2ForRL) and m2.engine.nkv == cfg["kv_heads"]
+    assert torch.equal(m2.engine.policy.flat, model.engine.policy.flat)

@@ -400,6 +400,28 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const bf16_t* __restr
     for (int c = threadIdx.x * 8; c < H; c += 256 * 8)
         *reinterpret_cast<u32x4*>(dst + d + c) = *reinterpret_cast<const u32x4*>(src + (size_t)r * H + c);
 }
+// strided variants for sub-matrices (PLoRA of InternLM-XComposer2: the image rows of one column block of a fused activation)
+__global__ __launch_bounds__(256) void rows_gather_kernel(const bf16_t* __restrict__ src, int lds, const int* __restrict__ rows,
+                                                          bf16_t* __restrict__ dst, int W) {
+    const int r = blockIdx.x;
+    const size_t s = (size_t)rows[r] * lds;
+    for (int c = threadIdx.x * 8; c < W; c += 256 * 8)
+        *reinterpret_cast<u32x4*>(dst + (size_t)r * W + c) = *reinterpret_cast<const u32x4*>(src + s + c);
+}
+// dst[rows[r]][0:W] += src[r][0:W]  (fp32 add, one rounding; the row list has no duplicates: every destination row has one writer)
+__global__ __launch_bounds__(256) void rows_add_kernel(const bf16_t* __restrict__ src, const int* __restrict__ rows,
+                                                       bf16_t* __restrict__ dst, int ldd, int W) {
+    const int r = blockIdx.x;
+    bf16_t* d = dst + (size_t)rows[r] * ldd;
+    for (int c = threadIdx.x * 8; c < W; c += 256 * 8) {
+        float a[8], b[8];
+        unpack8(*reinterpret_cast<const u32x4*>(src + (size_t)r * W + c), a);
+        unpack8(*reinterpret_cast<const u32x4*>(d + c), b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += b[e];
+        *reinterpret_cast<u32x4*>(d + c) = pack8(a);
+    }
+}
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = f32_to_bf16(src[i]);
 }
@@ -576,6 +598,16 @@ extern "C" int vlr_scatter_rows(const void* src, const int* rows, void* dst, int
     VLR_REQUIRE(R > 0 && H % 8 == 0, "vlr_scatter_rows: bad shape");
     hipLaunchKernelGGL(scatter_rows_kernel, dim3(R), dim3(256), 0, st, (const bf16_t*)src, rows, (bf16_t*)dst, R, H);
     return vlr_check_launch("vlr_scatter_rows");
+}
+extern "C" int vlr_rows_gather(const void* src, int lds, const int* rows, void* dst, int R, int W, hipStream_t st) {
+    VLR_REQUIRE(R > 0 && W > 0 && W % 8 == 0 && lds % 8 == 0 && lds >= W, "vlr_rows_gather: bad shape R=%d W=%d lds=%d", R, W, lds);
+    hipLaunchKernelGGL(rows_gather_kernel, dim3(R), dim3(256), 0, st, (const bf16_t*)src, lds, rows, (bf16_t*)dst, W);
+    return vlr_check_launch("vlr_rows_gather");
+}
+extern "C" int vlr_rows_add(const void* src, const int* rows, void* dst, int ldd, int R, int W, hipStream_t st) {
+    VLR_REQUIRE(R > 0 && W > 0 && W % 8 == 0 && ldd % 8 == 0 && ldd >= W, "vlr_rows_add: bad shape R=%d W=%d ldd=%d", R, W, ldd);
+    hipLaunchKernelGGL(rows_add_kernel, dim3(R), dim3(256), 0, st, (const bf16_t*)src, rows, (bf16_t*)dst, ldd, W);
+    return vlr_check_launch("vlr_rows_add");
 }
 extern "C" int vlr_cast_f32_to_bf16(const float* src, void* dst, long n, hipStream_t st) {
     VLR_REQUIRE(n > 0, "vlr_cast_f32_to_bf16: n");

@@ -74,6 +74,8 @@ _SIGS = {
     "vlr_colsum_f32": [P, I, I, I, P, P, P],
     "vlr_gather_rows": [P, P, P, I, I, P],
     "vlr_scatter_rows": [P, P, P, I, I, P],
+    "vlr_rows_gather": [P, I, P, P, I, I, P],
+    "vlr_rows_add": [P, P, P, I, I, I, P],
     "vlr_cast_f32_to_bf16": [P, P, L, P],
     "vlr_cast_bf16_to_f32": [P, P, L, P],
     "vlr_rowdot": [P, P, P, I, I, P],

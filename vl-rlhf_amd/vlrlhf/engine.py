@@ -40,7 +40,20 @@ class ParamLayout:
         self.entries = []   # (name, shape, [(hf_name, row0, rows)])
         e = self.entries
         qwen = cfg.get("family") == "qwen_vl"
-        if qwen:
+        ilm = cfg.get("family") == "internlm_xc2"
+        self.row_perm = {}          # entry name -> row permutation applied when loading (engine row i = checkpoint row perm[i])
+        if ilm:
+            # InternLM-XComposer2 (reference models/InternLMXC2/modeling_internlm2.py): fused grouped-query wqkv with rows laid out per
+            # K/V head as [q_0..q_{g-1} | k | v] (re-ordered to q | k | v blocks at load time), w2(silu(w1(x)) * w3(x)), and a PLoRA pair
+            # (build_mlp.py:158-203) on every linear - base-model weights, trained by a full fine-tune
+            lm, layer = "", "model.layers.{}."
+            nm = dict(lm_head="output.weight", embed="model.tok_embeddings.weight", norm="model.norm.weight", down="feed_forward.w2.weight",
+                      gate="feed_forward.w1.weight", up="feed_forward.w3.weight", o="attention.wo.weight", ln1="attention_norm.weight",
+                      ln2="ffn_norm.weight")
+            g_ = nh // nkv
+            idx = torch.arange((nh + 2 * nkv) * hd).view(nkv, g_ + 2, hd)
+            qkv_perm = torch.cat([idx[:, :g_].reshape(-1), idx[:, g_].reshape(-1), idx[:, g_ + 1].reshape(-1)])
+        elif qwen:
             # Qwen-VL (reference models/QwenVL/modeling_qwen.py): fused biased c_attn, MLP c_proj(w1(x) * silu(w2(x))) -> gate = w2,
             # up = w1; no projector (the resampler is part of the frozen vision tower)
             lm, layer = "", "transformer.h.{}."
@@ -59,11 +72,20 @@ class ParamLayout:
             e.append((f"l{l}.wo", (H, Nq), [(p + nm["o"], 0, H)]))
             if qwen:
                 e.append((f"l{l}.wqkv", (Nq + 2 * Nkv, H), [(p + "attn.c_attn.weight", 0, Nq + 2 * Nkv)]))
+            elif ilm:
+                pr = int(cfg.get("plora_r", 256))
+                e.append((f"l{l}.wqkv", (Nq + 2 * Nkv, H), [(p + "attention.wqkv.weight", 0, Nq + 2 * Nkv)]))
+                self.row_perm[f"l{l}.wqkv"] = qkv_perm
+                for key, mod, din, dout in (("qkv", "attention.wqkv", H, Nq + 2 * Nkv), ("o", "attention.wo", Nq, H), ("g", "feed_forward.w1", H, I),
+                                            ("u", "feed_forward.w3", H, I), ("d", "feed_forward.w2", I, H)):
+                    e.append((f"l{l}.pa_{key}", (pr, din), [(p + mod + ".Plora_A.weight", 0, pr)]))
+                    e.append((f"l{l}.pb_{key}", (dout, pr), [(p + mod + ".Plora_B.weight", 0, dout)]))
+                self.row_perm[f"l{l}.pb_qkv"] = qkv_perm
             else:
                 e.append((f"l{l}.wqkv", (Nq + 2 * Nkv, H), [(p + "self_attn.q_proj.weight", 0, Nq), (p + "self_attn.k_proj.weight", Nq, Nkv),
                                                             (p + "self_attn.v_proj.weight", Nq + Nkv, Nkv)]))
-        self.tail_start = "embed" if qwen else "proj.w2"
-        if not qwen:
+        self.tail_start = "embed" if (qwen or ilm) else "proj.w2"
+        if not (qwen or ilm):
             e.append(("proj.w2", (H, H), [("multi_modal_projector.linear_2.weight", 0, H)]))
             e.append(("proj.w1", (H, D), [("multi_modal_projector.linear_1.weight", 0, H)]))
         if cfg.get("image_grid_pinpoints"):                   # LLaVA-Next: the row appended to every line of the un-padded tile grid
@@ -77,17 +99,28 @@ class ParamLayout:
             e.append((f"l{l}.ln1", (H,), [(p + nm["ln1"], 0, H)]))
             if qwen:
                 e.append((f"l{l}.bqkv", (Nq + 2 * Nkv,), [(p + "attn.c_attn.bias", 0, Nq + 2 * Nkv)]))
-        if not qwen:
+        if not (qwen or ilm):
             e.append(("proj.b2", (H,), [("multi_modal_projector.linear_2.bias", 0, H)]))
             e.append(("proj.b1", (H,), [("multi_modal_projector.linear_1.bias", 0, H)]))
+        self.n_trainable_entries = len(e)
+        if ilm:      # --freeze_vision_tower freezes the projector too (InternLMXC2/__init__.py:252-255): kept OUTSIDE the optimizer's range
+            e.append(("proj.w2", (H, H), [("vision_proj.2.weight", 0, H)]))
+            e.append(("proj.w1", (H, D), [("vision_proj.0.weight", 0, H)]))
+            e.append(("proj.b2", (H,), [("vision_proj.2.bias", 0, H)]))
+            e.append(("proj.b1", (H,), [("vision_proj.0.bias", 0, H)]))
         self.offset = {}
         off = 0
+        self.n_opt = None
         for i, (name, shape, _) in enumerate(e):
             if i == self.n_decay_entries:
                 self.n_decay = off
+            if i == self.n_trainable_entries:
+                self.n_opt = off
             self.offset[name] = off
             off += _align(int(math.prod(shape)))
         self.numel = off
+        if self.n_opt is None:
+            self.n_opt = off           # elements [0, n_opt) are trainable (optimizer, gradient norm, DDP buckets); the rest is frozen
         self.shape = {name: shape for name, shape, _ in e}
         # DDP buckets = contiguous slices of the flat gradient in backward-completion order
         self.bucket_after = {}   # event name -> (start, end)
@@ -96,7 +129,7 @@ class ParamLayout:
         for l in range(L - 1, -1, -1):
             end = self.offset[f"l{l - 1}.wdown"] if l > 0 else ts
             self.bucket_after[f"layer{l}"] = (self.offset[f"l{l}.wdown"], end)
-        self.bucket_after["tail"] = (ts, self.numel)
+        self.bucket_after["tail"] = (ts, self.n_opt)
 
     def hf_names(self):
         for name, shape, parts in self.entries:
@@ -112,6 +145,9 @@ LORA_TARGETS = tuple(t for _, _, ts in LORA_GROUPS for t in ts)
 # Qwen-VL (QwenVLForRL.default_lora_target, reference models/QwenVL/__init__.py:26-28): ONE adapter over the fused c_attn, attn.c_proj,
 # w2 (= gate) and w1 (= up); mlp.c_proj has none
 QWEN_LORA_GROUPS = (("qkv", "attn", ("c_attn",)), ("o", "attn", ("c_proj",)), ("gu", "mlp", ("w2", "w1")))
+# InternLM-XComposer2 (InternLMXC2ForRL.default_lora_target, reference models/InternLMXC2/__init__.py:244-245): peft adapters on the five
+# PLoRA linears - one over the fused grouped-query wqkv (lora_B rows in the checkpoint's per-K/V-head order)
+ILM_LORA_GROUPS = (("qkv", "attention", ("wqkv",)), ("o", "attention", ("wo",)), ("gu", "feed_forward", ("w1", "w3")), ("down", "feed_forward", ("w2",)))
 
 
 class LoraLayout:
@@ -128,7 +164,15 @@ class LoraLayout:
         Nq, Nkv = nh * hd, nkv * hd
         self.r, self.L = r, L
         self.qwen = cfg.get("family") == "qwen_vl"
-        if self.qwen:
+        self.row_perm = {}
+        if cfg.get("family") == "internlm_xc2":
+            self.groups, self.prefix = ILM_LORA_GROUPS, "base_model.model.model.layers."
+            per = dict(a_qkv=(r, H), b_qkv=(Nq + 2 * Nkv, r), a_o=(r, Nq), b_o=(H, r), a_gu=(2 * r, H), b_gu=(2 * I, r), a_down=(r, I), b_down=(H, r))
+            self.out_dim = dict(wqkv=Nq + 2 * Nkv, wo=H, w1=I, w3=I, w2=H)
+            g_ = nh // nkv
+            idx = torch.arange((nh + 2 * nkv) * hd).view(nkv, g_ + 2, hd)
+            self.row_perm["b_qkv"] = torch.cat([idx[:, :g_].reshape(-1), idx[:, g_].reshape(-1), idx[:, g_ + 1].reshape(-1)])
+        elif self.qwen:
             self.groups, self.prefix = QWEN_LORA_GROUPS, "base_model.model.transformer.h."
             per = dict(a_qkv=(r, H), b_qkv=(Nq + 2 * Nkv, r), a_o=(r, Nq), b_o=(H, r), a_gu=(2 * r, H), b_gu=(2 * I, r))
             self.out_dim = dict(c_attn=Nq + 2 * Nkv, c_proj=H, w2=I, w1=I)
@@ -138,7 +182,7 @@ class LoraLayout:
                        a_down=(r, I), b_down=(H, r))
             self.out_dim = dict(q_proj=Nq, k_proj=Nkv, v_proj=Nkv, o_proj=H, gate_proj=I, up_proj=I, down_proj=H)
         self.keys = tuple(k for k in LORA_KEYS if k in per)
-        self.qkv_targets = 1 if self.qwen else 3
+        self.qkv_targets = 1 if (self.qwen or cfg.get("family") == "internlm_xc2") else 3
         self.offset, self.shape = {}, {}
         o = 0
         for l in range(L):
@@ -187,6 +231,9 @@ class WeightSet:
                 continue
             t = sd[hf]
             dst = self.v[name]
+            perm = self.layout.row_perm.get(name)
+            if perm is not None:
+                t = t[perm.to(t.device)]
             if dst.dim() == 1:
                 dst.copy_(t.to(BF16))
             else:
@@ -198,6 +245,12 @@ class WeightSet:
         out = {}
         for hf, name, r0, rows in self.layout.hf_names():
             v = self.v[name]
+            perm = self.layout.row_perm.get(name)
+            if perm is not None:                  # back to the checkpoint's row order (a copy, not a view)
+                inv = torch.empty_like(perm)
+                inv[perm] = torch.arange(perm.numel())
+                out[hf] = v[inv.to(v.device)]
+                continue
             out[hf] = v if v.dim() == 1 else v[r0:r0 + rows]
         return out
 
@@ -217,7 +270,7 @@ class VisionWeights:
         self.pre_w, self.pre_b = dv(sd[prefix + "pre_layrnorm.weight"]), dv(sd[prefix + "pre_layrnorm.bias"])
         self.layers = []
         self._keep = []
-        for i in range(cfg["vit_layers"] - 1):        # vision_feature_layer = -2: the last layer is never evaluated
+        for i in range(cfg["vit_layers"] + 1 + int(cfg.get("vit_feature_layer", -2))):   # vision_feature_layer -2 (LLaVA): the last layer is never evaluated; -1: all
             p = f"{prefix}encoder.layers.{i}."
             t = dict(
                 ln1_w=dv(sd[p + "layer_norm1.weight"]), ln1_b=dv(sd[p + "layer_norm1.bias"]),
@@ -233,6 +286,8 @@ class VisionWeights:
 
 
 class LlavaHipEngine:
+    custom_layers = False          # True: the subclass composes the decoder layer itself (_layer_forward / _hidden_backward_custom)
+
     def __init__(self, cfg: dict, device="cuda", max_positions: int = 4096):
         if not torch.cuda.is_available():
             raise _hip.VlrError("LlavaHipEngine needs an MI355X (torch.cuda.is_available() is False); "
@@ -301,7 +356,7 @@ class LlavaHipEngine:
             raise ValueError("ViT head_dim must be 64 for the gfx950 attention kernels")
 
     def _load_vision(self, sd):
-        return VisionWeights(self.cfg, sd, self.dev)
+        return VisionWeights(self.cfg, sd, self.dev, prefix=self.vision_prefix + "vision_model.")
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
         self.policy.load_state_dict(sd)
@@ -358,7 +413,16 @@ class LlavaHipEngine:
 
     def lora_state_dict(self):
         """adapter tensors under their peft adapter-file names (adapter_model.safetensors layout)"""
-        return {n: self.lv[k][lo:hi].clone() for n, (k, lo, hi) in self.lora_layout.hf_names().items()}
+        out = {}
+        for n, (k, lo, hi) in self.lora_layout.hf_names().items():
+            t = self.lv[k][lo:hi].clone()
+            perm = self.lora_layout.row_perm.get(k.split(".", 1)[1])
+            if perm is not None:                  # back to the checkpoint's row order
+                inv = torch.empty_like(perm)
+                inv[perm] = torch.arange(perm.numel())
+                t = t[inv.to(t.device)]
+            out[n] = t
+        return out
 
     def load_lora_state_dict(self, sd):
         names = self.lora_layout.hf_names()
@@ -370,6 +434,9 @@ class LlavaHipEngine:
             t = norm[n]
             if tuple(t.shape) != tuple(self.lv[k][lo:hi].shape):
                 raise ValueError(f"shape mismatch for {n}: {tuple(t.shape)} vs {tuple(self.lv[k][lo:hi].shape)}")
+            perm = self.lora_layout.row_perm.get(k.split(".", 1)[1])
+            if perm is not None:
+                t = t[perm.to(t.device)]
             self.lv[k][lo:hi].copy_(t)
         if self.master is not None:
             self.init_optimizer()
@@ -603,7 +670,9 @@ class LlavaHipEngine:
             drop = self.lora["dropout"] > 0 and self.training
         for l in range(self.L):
             a = self._layer_acts(tag if save else tag + "/scratch", l if save else (l % 2), Bn, S)   # scratch per pass tag (side stream)
-            if use_lora:
+            if self.custom_layers:
+                self._layer_forward(ws, l, a, x, e, Bn, S, save, use_lora, lora_seed)
+            elif use_lora:
                 if "u" not in a or a["u"].shape[1] != 7 * r:
                     a["u"] = torch.empty(M, 7 * r, dtype=BF16, device=self.dev)
                 lw, _ = self._lora_structs(l, train=True)
@@ -625,7 +694,7 @@ class LlavaHipEngine:
         return dict(ws=ws, Bn=Bn, T=T, S=S, M=M, ids=ids, src=src, inv=inv, mask=mask, labels=mlabels, pos=pos,
                     img_map=img_map.bool(), hidden=hidden, rstd_f=rstd_f, x_last=x, x0=x0, acts=acts if save else None,
                     vit_feat=vit_feat, feats=feats, proj_z=z, proj_h=h, image_dup=image_dup, n_rows=n_rows, n_feat=n_feat,
-                    pack=pack, tag=tag, lora_seed=lora_seed, meta=meta)
+                    pack=pack, tag=tag, lora_seed=lora_seed, meta=meta, extra=e.get("extra"))
 
     # ------------------------------------------------------------------------------------------------ log-probs
     def logps_forward(self, ctx, labels, shared_mask=None, average=False, label_pad=-100):
@@ -731,6 +800,8 @@ class LlavaHipEngine:
         Sp = _align(S, 64)
         dxa = self._buf(("dxa", M), (M, H))
         dxb = self._buf(("dxb", M), (M, H))
+        if self.custom_layers:
+            return self._hidden_backward_custom(ctx, dhidden, dxa, dxb)
         if self.lora is not None:
             return self._hidden_backward_lora(ctx, dhidden, dxa, dxb)
         _hip.call("vlr_rmsnorm_bwd", dhidden, ctx["x_last"], ws.v["norm"], ctx["rstd_f"], None, dxa, self.gv["norm"], acc,
@@ -910,7 +981,7 @@ class LlavaHipEngine:
                       float(beta1), float(beta2), float(eps), float(weight_decay), self.opt_step, self.norm_out)
             self.grad_fresh = True
             return self.norm_out
-        n = self.layout.numel
+        n = self.layout.n_opt
         _hip.call("vlr_grad_sqnorm", self.grads, n, float(max_grad_norm if max_grad_norm else 0.0), float(grad_scale), 0.0,
                   self._sq_ws, self.norm_out)
         self.opt_step += 1

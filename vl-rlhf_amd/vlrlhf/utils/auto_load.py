@@ -14,9 +14,10 @@ MODEL_NICKNAME_MAP = {
     "LlavaNextForRL": "LlavaNext",
     "QWenLMHeadModel": "QwenVL",
     "QwenVLForRL": "QwenVL",
+    "InternLMXC2ForRL": "InternLMXC2",
 }
 FLASH_ATTN_MODELS = ["LlavaForConditionalGeneration", "LlavaNextForConditionalGeneration", "LlavaForRL"]
-IMPLEMENTED = ["Llava", "LlavaNext", "QwenVL"]
+IMPLEMENTED = ["Llava", "LlavaNext", "QwenVL", "InternLMXC2"]
 
 
 def _architecture(model_name_or_path):
