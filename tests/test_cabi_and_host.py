@@ -194,7 +194,7 @@ def test_registry_surface():
     assert auto_core_mapper("LlavaForConditionalGeneration") is core_mapper
     assert core_mapper.dpo_trainer.__mro__[1].__name__ == "VLDPOTrainer"
     with pytest.raises(NotImplementedError):
-        auto_core_mapper("InternLMXComposer2ForCausalLM")
+        auto_core_mapper("InstructBlipForConditionalGeneration")
     import inspect
     from vlrlhf.base.trainer import VLDPOTrainer
     params = list(inspect.signature(VLDPOTrainer.__init__).parameters)[1:]

@@ -104,4 +104,4 @@ def test_registry_dispatches_qwen():
     cm = auto_core_mapper("QWenLMHeadModel")
     assert cm.model.__name__ == "QwenVLForRL" and cm.dpo_trainer.__name__ == "QwenVLDPOTrainer"
     with pytest.raises(NotImplementedError):
-        auto_core_mapper("InternLMXComposer2ForCausalLM")
+        auto_core_mapper("InstructBlipForConditionalGeneration")
