@@ -102,7 +102,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "tests", "golden")
 GRAD_KEYS = ["model.layers.0.attention.wqkv.weight", "model.layers.0.attention.wqkv.Plora_A.weight", "model.layers.1.attention.wqkv.Plora_B.weight",
              "model.layers.1.attention.wo.weight", "model.layers.0.attention.wo.Plora_B.weight", "model.layers.0.feed_forward.w1.weight",
-             "model.layers.1.feed_forward.w3.Plora_A.weight", "model.layers.1.feed_forward.w2.weight", "model.layers.0.feed_forward.w2.Plora_B.weight",
+             "model.layers.0.feed_forward.w3.Plora_A.weight", "model.layers.1.feed_forward.w2.weight", "model.layers.0.feed_forward.w2.Plora_B.weight",
              "model.layers.0.attention_norm.weight", "model.norm.weight", "output.weight", "model.tok_embeddings.weight"]
 
 

@@ -378,3 +378,26 @@ def test_internlm_oracle_matches_reference_golden():
             assert float((g.reshape(-1)[::17] - ref).abs().max()) <= 2e-3 * float(ref.abs().max()) + 1e-7, k
             checked += 1
     assert checked == 13
+
+
+def test_internlm_gqa_row_order_matches_reference_rearrange():
+    """the load-time row permutation of the fused grouped-query wqkv (oracle.qkv_row_order = engine ParamLayout.row_perm) against the
+    reference's split of the projection output (modeling_internlm2.py:320-330: "b q (h gs d) -> b q h gs d", gs = 2 + group; q = first
+    `group` slots of every K/V head, k = slot -2, v = slot -1), restated here with plain reshapes, for 8 query heads over 2 K/V heads."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "vl-rlhf_amd"))
+    from oracle import internlm_oracle as IL
+    from vlrlhf.engine import LoraLayout, ParamLayout
+    nh, nkv, hd, H = 8, 2, 16, 128
+    g = nh // nkv
+    y = torch.randn(3, 5, (nh + 2 * nkv) * hd)
+    v5 = y.view(3, 5, nkv, g + 2, hd)
+    q_ref, k_ref, v_ref = v5[..., :g, :].reshape(3, 5, nh * hd), v5[..., -2, :].reshape(3, 5, nkv * hd), v5[..., -1, :].reshape(3, 5, nkv * hd)
+    perm = IL.qkv_row_order(nh, nkv, hd)
+    yp = y[..., perm]
+    assert torch.equal(yp[..., : nh * hd], q_ref) and torch.equal(yp[..., nh * hd: (nh + nkv) * hd], k_ref) and torch.equal(yp[..., (nh + nkv) * hd:], v_ref)
+    cfg = dict(family="internlm_xc2", hidden=H, inter=64, layers=1, heads=nh, kv_heads=nkv, vocab=32, vit_hidden=16)
+    lay = ParamLayout(cfg)
+    assert torch.equal(lay.row_perm["l0.wqkv"], perm) and torch.equal(lay.row_perm["l0.pb_qkv"], perm)
+    assert torch.equal(LoraLayout(cfg, 8).row_perm["b_qkv"], perm)
+    assert lay.n_opt == lay.offset["proj.w2"] < lay.numel                 # the frozen projector sits behind the optimizer's range
