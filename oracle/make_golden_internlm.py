@@ -235,5 +235,32 @@ def main():
     print("logps", res["sigmoid"]["logps"], res["sigmoid"]["ref_logps"])
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and (len(sys.argv) < 2 or sys.argv[1] == "model"):
     main()
+
+
+def gen_tokenize():
+    """the reference's InternLMXC2Processor.process_batch_conv / format_multimodal_prompt with the stand-in tokenizer of
+    tests/qwen_standin.py -> tests/golden/internlm_tokenize.json"""
+    sys.path.insert(0, ROOT)
+    from tests.qwen_standin import StandInInternLMTokenizer
+    proc = RI.InternLMXC2Processor.__new__(RI.InternLMXC2Processor)
+    proc._InternLMXC2Processor__tokenizer = StandInInternLMTokenizer()
+    rows = [dict(prompt="What is in the picture?", answer="A dog on a sofa.", img_path="imgs/a.jpg"),
+            dict(prompt="<image>Describe it. 中文", answer="", img_path="b.png"),
+            dict(prompt="hi <image> there", answer="yes " * 7, img_path="c.jpeg")]
+    fmt = [RI.InternLMXC2Processor.format_multimodal_prompt(r["prompt"], r["img_path"]) for r in rows]
+    conv = [[{"from": "user", "value": f}, {"from": "assistant", "value": r["answer"]}] for f, r in zip(fmt, rows)]
+    out = dict(rows=rows, format_multimodal_prompt=fmt, process_batch_conv=proc.process_batch_conv(conv),
+               process_batch_conv_end=proc.process_batch_conv(conv, add_end_for_empty_value=True),
+               is_valid=[RI.InternLMXC2Processor.is_multimodal_prompt_valid(x) for x in fmt],
+               removed=[RI.InternLMXC2Processor.remove_image_placeholder(x) for x in fmt],
+               template=vars(proc.chat_template))
+    path = os.path.join(OUT, "internlm_tokenize.json")
+    with open(path, "w") as f:
+        json.dump(out, f, ensure_ascii=False)
+    print("wrote", path, f"{os.path.getsize(path) / 1e3:.1f} kB")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "tokenize":
+    gen_tokenize()

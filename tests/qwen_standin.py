@@ -32,3 +32,21 @@ class StandInTokenizer:
             else:
                 ids += [ord(c) % 200 + 256 for c in part]
         return types.SimpleNamespace(input_ids=ids, attention_mask=[1] * len(ids))
+
+
+class StandInInternLMTokenizer:
+    """stand-in for the InternLM2 sentencepiece tokenizer (its model file is not in the container): one id per character, the chat
+    markers and <ImageHere> as single ids, BOS prepended when add_special_tokens; returns dicts like a HF tokenizer"""
+    SPECIAL = {"[UNUSED_TOKEN_146]": 92543, "[UNUSED_TOKEN_145]": 92542, "<ImageHere>": 92544, "<s>": 1, "</s>": 2}
+    _SPLIT = re.compile(r"(\[UNUSED_TOKEN_146\]|\[UNUSED_TOKEN_145\]|<ImageHere>|<s>|</s>)")
+    pad_token_id, eos_token_id, bos_token_id = 2, 2, 1
+
+    def __init__(self):
+        self.padding_side = "right"
+
+    def __call__(self, text, padding=False, add_special_tokens=True):
+        ids = [1] if add_special_tokens else []
+        for part in self._SPLIT.split(text):
+            if part:
+                ids += [self.SPECIAL[part]] if part in self.SPECIAL else [ord(c) % 5000 + 300 for c in part]
+        return dict(input_ids=ids, attention_mask=[1] * len(ids))

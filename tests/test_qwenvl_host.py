@@ -105,3 +105,26 @@ def test_registry_dispatches_qwen():
     assert cm.model.__name__ == "QwenVLForRL" and cm.dpo_trainer.__name__ == "QwenVLDPOTrainer"
     with pytest.raises(NotImplementedError):
         auto_core_mapper("InstructBlipForConditionalGeneration")
+
+
+def test_internlm_processor_matches_reference():
+    """InternLMXC2Processor.process_batch_conv / format_multimodal_prompt against the recorded outputs of the reference's own
+    functions (tests/golden/internlm_tokenize.json, oracle/make_golden_internlm.py tokenize) with the stand-in tokenizer"""
+    from tests.qwen_standin import StandInInternLMTokenizer
+    from vlrlhf.models.InternLMXC2 import InternLMXC2Processor
+    with open(os.path.join(GOLDEN, "internlm_tokenize.json")) as f:
+        fx = json.load(f)
+    p = InternLMXC2Processor(tokenizer=StandInInternLMTokenizer(), image_size=490)
+    p.train()
+    fmt = [InternLMXC2Processor.format_multimodal_prompt(r["prompt"], r["img_path"]) for r in fx["rows"]]
+    assert fmt == fx["format_multimodal_prompt"]
+    assert [InternLMXC2Processor.is_multimodal_prompt_valid(x) for x in fmt] == fx["is_valid"]
+    assert [InternLMXC2Processor.remove_image_placeholder(x) for x in fmt] == fx["removed"]
+    conv = [[{"from": "user", "value": f}, {"from": "assistant", "value": r["answer"]}] for f, r in zip(fmt, fx["rows"])]
+    assert p.process_batch_conv(conv) == fx["process_batch_conv"]
+    assert p.process_batch_conv(conv, add_end_for_empty_value=True) == fx["process_batch_conv_end"]
+    assert vars(p.chat_template) == fx["template"]
+    with pytest.raises(ValueError):
+        p.process_batch_conv(conv[0])
+    from vlrlhf.utils.auto_load import auto_core_mapper
+    assert auto_core_mapper("InternLMXComposer2ForCausalLM").model.__name__ == "InternLMXC2ForRL"
