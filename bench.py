@@ -67,7 +67,7 @@ def tflop_per_pair(cfg, S, tiles_per_image=1, ref_in_step=True):
     attn = L * 4 * Nq * (S + 1) / 2
     fwd = 2 * S * (dense + attn)
     D, F, T = cfg["vit_hidden"], cfg["vit_mlp"], (cfg["image_size"] // cfg["patch_size"]) ** 2 + 1
-    vit = (cfg["vit_layers"] - 1) * (2 * T * (4 * D * D + 2 * D * F) + 4 * T * T * D) * tiles_per_image
+    vit = (cfg["vit_layers"] + 1 + cfg.get("vit_feature_layer", -2)) * (2 * T * (4 * D * D + 2 * D * F) + 4 * T * T * D) * tiles_per_image
     proj = 2 * (T - 1) * (D * H + H * H) * tiles_per_image
     return ((4 if ref_in_step else 3) * fwd + vit + 3 * proj) / 1e12
 
@@ -176,7 +176,7 @@ def main():
     ap.add_argument("--precomputed_ref", action="store_true", help="stream precomputed reference log-probs (SURVEY 8f rank 1)")
     ap.add_argument("--lora", action="store_true", help="variant: LoRA DPO of scripts/ddpo_llava.sh (r=128, alpha=256, dropout 0.05)")
     ap.add_argument("--lora_dropout", type=float, default=0.05)
-    ap.add_argument("--model", default="llava", choices=["llava", "llava_next", "qwen_vl"],
+    ap.add_argument("--model", default="llava", choices=["llava", "llava_next", "qwen_vl", "internlm_xc2"],
                     help="llava_next: variant on BASELINE.json configs[3] (LLaVA-Next-Mistral-7B, anyres 672x672 image, DDPO); not the headline line")
     ap.add_argument("--loss_type", default=None)
     ap.add_argument("--dry_run_launch", action="store_true", help="CPU test of the self-launch path: no model, gloo, no-op steps")
@@ -211,12 +211,16 @@ def main():
         from vlrlhf.models.QwenVL import QWEN_VL_CHAT, QwenVLDPOTrainer, QwenVLForRL
         from vlrlhf.utils.synthetic import init_hashed_qwen, synthetic_batch_qwen
         cfg, LlavaForRL, Trainer = dict(QWEN_VL_CHAT), QwenVLForRL, QwenVLDPOTrainer
+    ilm = a.model == "internlm_xc2"
+    if ilm:
+        from vlrlhf.models.InternLMXC2 import INTERNLM_XC2_VL_7B, InternLMXC2DPOTrainer, InternLMXC2ForRL
+        cfg, LlavaForRL, Trainer = dict(INTERNLM_XC2_VL_7B), InternLMXC2ForRL, InternLMXC2DPOTrainer
     loss_type = a.loss_type or ("ddpo" if nxt else "sigmoid")
     if a.layers:
         cfg["layers"] = a.layers
     model = LlavaForRL(cfg)
-    pad_id = cfg["pad_token_id"] if qwen else 0
-    lora_r, lora_alpha = (64, 16) if qwen else (128, 256)          # scripts/dpo_qwenvl.sh / scripts/ddpo_llava.sh
+    pad_id = cfg["pad_token_id"] if qwen else (cfg["model_pad_token_id"] if ilm else 0)
+    lora_r, lora_alpha = (64, 16) if qwen else ((64, 64) if ilm else (128, 256))    # scripts/dpo_qwenvl.sh / dpo_internlmxc2vl7b.sh / ddpo_llava.sh
     ref = init_hashed_qwen(model, seed=0, std=0.02, policy_delta=1e-3, with_reference=not a.lora) if qwen else \
         init_random_model(model, seed=0, std=0.02, policy_delta=1e-3)
     eng = model.engine
@@ -369,7 +373,19 @@ def main():
                                           "full fine-tune of LLM+projector+image_newline, frozen ViT, reference forward inside the step")
             line["config"]["variant"] = "llava_next (not the headline configuration)"
             line["config"]["tflop_per_pair"] = round(per_pair, 2)
-        if qwen:
+        if ilm:
+            line["metric"] = "preference-pairs/sec (chosen+rejected) InternLM-XComposer2-VL-7B DPO step"
+            per_pair_i = tflop_per_pair(cfg, S_dec, 1, not a.precomputed_ref)
+            line["config"]["workload"] = (f"variant on BASELINE.json configs[4]: InternLM-XComposer2-VL-7B DPO bf16, 490x490 image (1225 patches), "
+                                          f"max_length {a.text_len}, per-device batch {a.pairs} pairs (S={S_dec}), "
+                                          + (f"LoRA r={lora_r} alpha={lora_alpha} dropout={a.lora_dropout} on wqkv / wo / w1 / w2 / w3 over the frozen PLoRA decoder "
+                                             "(scripts/dpo_internlmxc2vl7b.sh), reference = adapters disabled" if a.lora else
+                                             "full fine-tune of the decoder incl. its PLoRA pairs, reference forward inside the step")
+                                          + ", frozen ViT + projector; decoder layer composed from the library's primitives (un-fused)")
+            line["config"]["variant"] = "internlm_xc2" + ("+lora" if a.lora else "") + " (not the headline configuration)"
+            line["config"]["tflop_per_pair"] = round(per_pair_i, 2)
+            line["roofline"]["step_frac"] = None if a.lora else round(pairs_per_s / world * per_pair_i / PEAK_BF16_TFLOPS, 4)
+        elif qwen:
             line["metric"] = "preference-pairs/sec (chosen+rejected) Qwen-VL-Chat DPO step"
             line["config"]["workload"] = (f"variant on BASELINE.json configs[2]: Qwen-VL-Chat DPO bf16, 448x448 image (1024 patches -> 256 resampler "
                                           f"slots inside the ids), max_length {a.text_len}, per-device batch {a.pairs} pairs (S={S_dec}), "

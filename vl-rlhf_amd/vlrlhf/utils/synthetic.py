@@ -53,7 +53,7 @@ def init_hashed_model(model, seed=0, std=0.02, policy_delta=1e-3, seed_delta=1):
         n = hashed_normal(numel, seed, name, dev).view(*shape)
         gain = name.endswith(("norm.weight", "norm1.weight", "norm2.weight", "layrnorm.weight"))
         t = ((n * 0.05 + 1.0) if gain else n * std).to(torch.bfloat16)
-        if delta > 0 and not name.startswith("vision_tower."):
+        if delta > 0 and not name.startswith(("vision_tower.", "vit.", "vision_proj.")):
             t = (t.float() + hashed_normal(numel, seed_delta, name, dev).view(*shape) * delta).to(torch.bfloat16)
         return t
 
@@ -68,10 +68,10 @@ def init_hashed_model(model, seed=0, std=0.02, policy_delta=1e-3, seed_delta=1):
     c = eng.cfg
     D, P, F = c["vit_hidden"], c["patch_size"], c["vit_mlp"]
     T = (c["image_size"] // P) ** 2 + 1
-    vp = "vision_tower.vision_model."
+    vp = getattr(eng, "vision_prefix", "vision_tower.") + "vision_model."
     sh = {vp + "embeddings.class_embedding": (D,), vp + "embeddings.patch_embedding.weight": (D, 3, P, P),
           vp + "embeddings.position_embedding.weight": (T, D), vp + "pre_layrnorm.weight": (D,), vp + "pre_layrnorm.bias": (D,)}
-    for i in range(c["vit_layers"] - 1):
+    for i in range(c["vit_layers"] + 1 + int(c.get("vit_feature_layer", -2))):
         p = f"{vp}encoder.layers.{i}."
         for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
             sh[p + f"self_attn.{nm}.weight"], sh[p + f"self_attn.{nm}.bias"] = (D, D), (D,)
@@ -79,7 +79,7 @@ def init_hashed_model(model, seed=0, std=0.02, policy_delta=1e-3, seed_delta=1):
             sh[p + nm + ".weight"], sh[p + nm + ".bias"] = (D,), (D,)
         sh[p + "mlp.fc1.weight"], sh[p + "mlp.fc1.bias"] = (F, D), (F,)
         sh[p + "mlp.fc2.weight"], sh[p + "mlp.fc2.bias"] = (D, F), (D,)
-    eng.vision = VisionWeights(c, {k: draw(k, s_, 0.0) for k, s_ in sh.items()}, dev)
+    eng.vision = VisionWeights(c, {k: draw(k, s_, 0.0) for k, s_ in sh.items()}, dev, prefix=vp)
     eng._vit_cache = None
     return ref
 
