@@ -654,6 +654,7 @@ class LlavaHipEngine:
         am = attention_mask.to(self.dev).contiguous()
         lab = labels.to(self.dev).contiguous() if labels is not None else None
         e = self._embed_inputs(ws, ids, am, lab, pixel_values, image_dup, tag, image_sizes, meta)
+        e["tag"] = tag               # scratch buffers of custom layers are keyed per pass (the reference pass runs on a side stream)
         S, M = e["S"], e["M"]
         src, mask, pos, mlabels, img_map, inv = e["src"], e["mask"], e["pos"], e["labels"], e["img_map"], e["inv"]
         feats, vit_feat, z, h, n_rows, n_feat, pack = e["feats"], e["vit_feat"], e["proj_z"], e["proj_h"], e["n_rows"], e["n_feat"], e["pack"]

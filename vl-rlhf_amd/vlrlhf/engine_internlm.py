@@ -68,19 +68,19 @@ class InternLMHipEngine(LlavaHipEngine):
     def _gemm(self, layout, A, B, C, M, N, K, lda, ldb, ldc, residual=None, ldr=0, accumulate=0, alpha=1.0):
         _hip.call("vlr_gemm_bf16_scaled", layout, A, B, C, None, residual, M, N, K, lda, ldb, ldc, ldr, 0, accumulate, 0, float(alpha))
 
-    def _plora_fwd(self, ws, l, key, x_in, n_in, y, ldy, n_out, ex, train, seed, keep):
+    def _plora_fwd(self, ws, l, key, x_in, n_in, y, ldy, n_out, ex, train, seed, keep, tag):
         """y[img rows] += scale * (drop(x_in[img rows]) A^T) B^T;  y is a [M, n_out] column block with row stride ldy"""
         R, rows, r = ex["R"], ex["rows"], self.plora_r
         if R == 0:
             return None
         A, B = ws.v[f"l{l}.pa_{key}"], ws.v[f"l{l}.pb_{key}"]
-        xs = torch.empty(R, n_in, dtype=BF16, device=self.dev) if keep else self._buf(("pl_xs", R, n_in), (R, n_in))
+        xs = torch.empty(R, n_in, dtype=BF16, device=self.dev) if keep else self._buf((tag, "pl_xs", R, n_in), (R, n_in))
         _hip.call("vlr_gather_rows", x_in, rows, xs, R, n_in)
         if train and self.plora_p > 0:
             _hip.call("vlr_dropout", xs, xs, R * n_in, self.plora_p, seed + PLORA_T[key], 1.0, 0)
-        up = torch.empty(R, r, dtype=BF16, device=self.dev) if keep else self._buf(("pl_up", R), (R, r))
+        up = torch.empty(R, r, dtype=BF16, device=self.dev) if keep else self._buf((tag, "pl_up", R), (R, r))
         self._gemm(0, xs, A, up, R, r, n_in, n_in, n_in, r, alpha=self.plora_scale)
-        yp = self._buf(("pl_y", R, n_out), (R, n_out))
+        yp = self._buf((tag, "pl_y", R, n_out), (R, n_out))
         self._gemm(0, up, B, yp, R, n_out, r, r, r, n_out)
         _hip.call("vlr_rows_add", yp, rows, y, ldy, R, n_out)
         return (xs, up) if keep else None
@@ -104,7 +104,7 @@ class InternLMHipEngine(LlavaHipEngine):
             _hip.call("vlr_dropout", dxr, dxr, R * n_in, self.plora_p, seed + PLORA_T[key], 1.0, 0)
         _hip.call("vlr_rows_add", dxr, rows, dx, n_in, R, n_in)
 
-    def _lora_fwd(self, l, grp, t, x_in, n_in, y, ldy, n_out, row0, seed, keep, M):
+    def _lora_fwd(self, l, grp, t, x_in, n_in, y, ldy, n_out, row0, seed, keep, M, tag):
         """peft adapter of sub-target t of group grp on ALL rows: y += (s drop(x) A_t^T) B_t^T"""
         lo = self.lora
         r = lo["r"]
@@ -113,9 +113,9 @@ class InternLMHipEngine(LlavaHipEngine):
         p = lo["dropout"] if self.training else 0.0
         xd = x_in
         if p > 0:
-            xd = torch.empty(M, n_in, dtype=BF16, device=self.dev) if keep else self._buf(("lo_xd", M, n_in), (M, n_in))
+            xd = torch.empty(M, n_in, dtype=BF16, device=self.dev) if keep else self._buf((tag, "lo_xd", M, n_in), (M, n_in))
             _hip.call("vlr_dropout", x_in, xd, M * n_in, p, seed, 1.0, 0)
-        u = torch.empty(M, r, dtype=BF16, device=self.dev) if keep else self._buf(("lo_u", M), (M, r))
+        u = torch.empty(M, r, dtype=BF16, device=self.dev) if keep else self._buf((tag, "lo_u", M), (M, r))
         self._gemm(0, xd, A, u, M, r, n_in, n_in, n_in, r, alpha=lo["scale"])
         self._gemm(0, u, B, y, M, n_out, r, r, r, ldy, accumulate=1)
         return (xd, u) if keep else None
@@ -156,9 +156,9 @@ class InternLMHipEngine(LlavaHipEngine):
 
         def adapters(key, x_in, y, ldy):
             grp, t, row0, n_in, n_out = tg[key]
-            kept["p_" + key] = self._plora_fwd(ws, l, key, x_in, n_in, y, ldy, n_out, ex, train, pseed + 8 * l, keep_p)
+            kept["p_" + key] = self._plora_fwd(ws, l, key, x_in, n_in, y, ldy, n_out, ex, train, pseed + 8 * l, keep_p, e["tag"])
             if use_lora:
-                kept["l_" + key] = self._lora_fwd(l, grp, t, x_in, n_in, y, ldy, n_out, row0, lora_seed + 8 * l + PLORA_T[key], save, M)
+                kept["l_" + key] = self._lora_fwd(l, grp, t, x_in, n_in, y, ldy, n_out, row0, lora_seed + 8 * l + PLORA_T[key], save, M, e["tag"])
 
         _hip.call("vlr_rmsnorm_fwd", x, ws.v[f"l{l}.ln1"], a["xn1"], a["rstd1"], M, H, c.rms_eps)
         self._gemm(0, a["xn1"], ws.v[f"l{l}.wqkv"], a["qkv"], M, N, H, H, H, N)
