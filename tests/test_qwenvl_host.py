@@ -128,3 +128,37 @@ def test_internlm_processor_matches_reference():
         p.process_batch_conv(conv[0])
     from vlrlhf.utils.auto_load import auto_core_mapper
     assert auto_core_mapper("InternLMXComposer2ForCausalLM").model.__name__ == "InternLMXC2ForRL"
+
+
+def test_image_loading_and_collators(tmp_path):
+    """Qwen-VL `visual.image_transform` / InternLM `vis_processor` (bicubic resize of the RGB image to s x s, [0,1], CLIP mean / std):
+    the loader against a by-hand evaluation, and the two DPO collators (pad + `img_input_dict.pixel_values` in row order)."""
+    from PIL import Image
+    from vlrlhf.models.InternLMXC2 import InternLMXC2DPODataCollatorWithPadding, InternLMXC2Processor
+    from vlrlhf.models.Llava import CLIP_MEAN, CLIP_STD
+    from vlrlhf.models.QwenVL import QwenVLDPODataCollatorWithPadding, QwenVLProcessor, load_qwen_pixel_values
+    from tests.qwen_standin import StandInInternLMTokenizer
+    rng = np.random.default_rng(0)
+    paths = []
+    for i, (h, w) in enumerate([(50, 80), (33, 21)]):
+        p = str(tmp_path / f"im{i}.png")
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(p)
+        paths.append(p)
+    px = load_qwen_pixel_values(paths, 56)
+    assert px.shape == (2, 3, 56, 56) and px.dtype == torch.float32
+    im = np.asarray(Image.open(paths[1]).convert("RGB").resize((56, 56), Image.BICUBIC), dtype=np.float32) / 255.0
+    want = (torch.from_numpy(im).permute(2, 0, 1) - torch.tensor(CLIP_MEAN).view(3, 1, 1)) / torch.tensor(CLIP_STD).view(3, 1, 1)
+    assert torch.allclose(px[1], want, atol=1e-6)
+    t_ = torch.randn(3, 8, 8)
+    assert torch.equal(load_qwen_pixel_values([t_, t_], 8)[0], t_)              # synthetic tensors pass through
+    feats = [dict(chosen_input_ids=[5, 6, 7], chosen_attention_mask=[1, 1, 1], chosen_labels=[-100, 6, 7], rejected_input_ids=[5, 9],
+                  rejected_attention_mask=[1, 1], rejected_labels=[-100, 9], prompt_input_ids=[5], prompt_attention_mask=[1], img_path=paths[i])
+             for i in range(2)]
+    qc = QwenVLDPODataCollatorWithPadding(pad_token_id=151643, processor=QwenVLProcessor(tokenizer=StandInTokenizer(), image_size=56))
+    b = qc([dict(f) for f in feats])
+    assert b["img_input_dict"]["pixel_values"].shape == (2, 3, 56, 56) and torch.equal(b["img_input_dict"]["pixel_values"], px)
+    assert b["rejected_input_ids"].shape == (2, 2) and b["img_path"] == paths
+    ic = InternLMXC2DPODataCollatorWithPadding(pad_token_id=2, processor=InternLMXC2Processor(tokenizer=StandInInternLMTokenizer(), image_size=42))
+    b2 = ic([dict(f) for f in feats])
+    assert b2["img_input_dict"]["pixel_values"].shape == (2, 3, 42, 42)
+    assert torch.equal(b2["img_input_dict"]["pixel_values"], load_qwen_pixel_values(paths, 42))
