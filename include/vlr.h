@@ -60,6 +60,9 @@ int vlr_gemm_swiglu(const void* x, const void* wgu, void* gu, void* act, int M, 
                     vlr_stream_t stream);
 int vlr_gemm_qkv_rope(const void* x, const void* wqkv, void* qkv, const int* pos, const float* cos_t, const float* sin_t, int M,
                       int N, int rope_cols, int K, int ldx, int head_dim, int max_pos, vlr_stream_t stream);
+/*  vlr_gemm_qkv_rope_bias: the same with a bias [N] on the projection (Qwen c_attn, QwenVL/modeling_qwen.py:104), NULL = none */
+int vlr_gemm_qkv_rope_bias(const void* x, const void* wqkv, const void* bias, void* qkv, const int* pos, const float* cos_t,
+                           const float* sin_t, int M, int N, int rope_cols, int K, int ldx, int head_dim, int max_pos, vlr_stream_t stream);
 /*  vlr_gemm_swiglu_bwd: backward of the MLP's first half in one pass - d act = dy [M][H] . wdown [H][I] stays in the
  *                     accumulators and gu [M][2I] (gate | up of the forward) is replaced in place by d gate | d up.  dact_ws
  *                     [M][I] is scratch for the rows / shapes that take the plain GEMM + vlr_swiglu_bwd. */
@@ -75,7 +78,7 @@ int vlr_gemm_swiglu_bwd(const void* dy, const void* wdown, void* gu_inout, void*
  *  vlr_gemm_swiglu_lora  : gate | up with u = u_gate | u_up, Bl = [B_gate ; B_up] [2I][r]; gu is always stored
  *  vlr_gemm_qkv_rope_lora: q | k | v with u = u_q | u_k | u_v, Bl = [B_q ; B_k ; B_v]; q_cols + 2 * kv_cols = N.  kv_cols = 0: ONE
  *                          adapter over the whole fused projection (u [M][r], Bl [N][r]).  bias [N] (NULL = none) is added before
- *                          the rotation; with a bias the projection runs as GEMM (+ adapter GEMMs) + RoPE kernel. */
+ *                          the rotation. */
 /*  vlr_gemm_dropout_acc  : dx [M][in] += scaling / (1 - p) * mask .* (v [M][ldv] . A [r][in]) - the input-gradient term of one
  *                          target under lora_dropout; the mask is regenerated from (seed, row * in + col) as in vlr_dropout and the
  *                          product never reaches HBM (scratch [M][in] only for shapes the fused kernel does not take) */

@@ -740,6 +740,17 @@ def test_gemm_qkv_rope_fused(hip, shape):
     torch.cuda.synchronize()
     check(out, ref, 8e-3, f"qkv rope {shape}")
     assert torch.isfinite(out.float()).all()
+    # biased projection (Qwen c_attn): the bias enters before the rotation
+    bias = rnd(N, scale=0.5, seed=9)
+    yb = y + bias.float()
+    refb = yb.clone()
+    hb = yb[:, :rope_cols].view(M, nh + nkv, hd)
+    b1, b2 = hb[..., : hd // 2], hb[..., hd // 2:]
+    refb[:, :rope_cols] = torch.cat([b1 * c - b2 * s_, b2 * c + b1 * s_], -1).reshape(M, rope_cols)
+    out.fill_(float("nan"))
+    hip.call("vlr_gemm_qkv_rope_bias", x, w, bias, out, pos, cos, sin, M, N, rope_cols, K, K, hd, max_pos)
+    torch.cuda.synchronize()
+    check(out, refb, 8e-3, f"qkv rope bias {shape}")
 
 
 # ---------------------------------------------------------------------------------------------------- LoRA adapter segment

@@ -583,13 +583,14 @@ static int gemm_qkv_rope_impl(const void* x, const void* wqkv, void* qkv, const 
     { int rc = seg_check("vlr_gemm_qkv_rope_lora", sg); if (rc != VLR_OK) return rc; }
     const bool seg = sg && sg->u;
     int done = 0;
-    if (head_dim == 128 && !bias) {
+    if (head_dim == 128 && (!bias || !((uintptr_t)bias & 7))) {
         const int tn = (N + 255) / 256;
         const int peel = choose_peel(M, N, tn);
         const int tm256 = (M + 255) / 256;
         const int M1 = peel ? (tm256 - peel) * 256 : M;
         GemmParams p = fused_params(x, wqkv, qkv, M1, N, K, ldx, K, N);
         p.fuse = 2; p.pos = pos; p.rope_cos = cos_t; p.rope_sin = sin_t; p.max_pos = max_pos; p.rope_cols = rope_cols;
+        p.bias = (const bf16_t*)bias;
         seg_set(p, sg);
         if (seg ? vlr_gemm256p_seg_try_launch(p, stream) : vlr_gemm256p_fused_try_launch(p, stream)) {
             int rc = vlr_check_launch("vlr_gemm_qkv_rope(fused)");
@@ -611,6 +612,11 @@ static int gemm_qkv_rope_impl(const void* x, const void* wqkv, void* qkv, const 
 extern "C" int vlr_gemm_qkv_rope(const void* x, const void* wqkv, void* qkv, const int* pos, const float* cos_t, const float* sin_t,
                                  int M, int N, int rope_cols, int K, int ldx, int head_dim, int max_pos, hipStream_t stream) {
     return gemm_qkv_rope_impl(x, wqkv, qkv, pos, cos_t, sin_t, M, N, rope_cols, K, ldx, head_dim, max_pos, nullptr, nullptr, stream);
+}
+// the same with a bias [N] on the projection (Qwen c_attn), added to the accumulators before the rotation
+extern "C" int vlr_gemm_qkv_rope_bias(const void* x, const void* wqkv, const void* bias, void* qkv, const int* pos, const float* cos_t,
+                                      const float* sin_t, int M, int N, int rope_cols, int K, int ldx, int head_dim, int max_pos, hipStream_t stream) {
+    return gemm_qkv_rope_impl(x, wqkv, qkv, pos, cos_t, sin_t, M, N, rope_cols, K, ldx, head_dim, max_pos, nullptr, bias, stream);
 }
 // the same with the LoRA adapters of q_proj / k_proj / v_proj: u [M][ldu] = the three s drop_t(x) A_t^T side by side, Bl = lora_B
 // rows of q | k | v [N][r]; q_cols / kv_cols = widths of the q and of the k (= v) output blocks

@@ -678,6 +678,12 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                     const int c = wc * 32 + j * 16 + 4 * lq_;          // column of the 128-wide half: head c >> 6, feature c & 63
                     x1[j] = acc[a][i][0][j];
                     x2[j] = acc[a][i][1][j];
+                    if (p.bias) {                                      // biased fused projection (Qwen c_attn): added before the rotation
+                        const bf16_t* bp = p.bias + n0 + (c >> 6) * 128 + (c & 63);
+                        const u32x2 b1 = *reinterpret_cast<const u32x2*>(bp), b2 = *reinterpret_cast<const u32x2*>(bp + 64);
+                        x1[j][0] += bf16lo(b1[0]); x1[j][1] += bf16hi(b1[0]); x1[j][2] += bf16lo(b1[1]); x1[j][3] += bf16hi(b1[1]);
+                        x2[j][0] += bf16lo(b2[0]); x2[j][1] += bf16hi(b2[0]); x2[j][2] += bf16lo(b2[1]); x2[j][3] += bf16hi(b2[1]);
+                    }
                     if (rot) {
                         const f32x4 cs = *reinterpret_cast<const f32x4*>(p.rope_cos + (size_t)ps * 64 + (c & 63));
                         const f32x4 sn = *reinterpret_cast<const f32x4*>(p.rope_sin + (size_t)ps * 64 + (c & 63));
@@ -945,7 +951,8 @@ bool vlr_gemm256p_seg_try_launch(const GemmParams& p, hipStream_t stream) {
     if (p.fuse == 2 && (p.N % PT != 0 || p.rope_cols % PT != 0)) return false;
     if (p.fuse == 1 && ((p.N >> 1) % 8 != 0 || p.ldc2 % 8 != 0 || ((uintptr_t)p.C2 & 15))) return false;
     if ((((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.C) & 15) || p.lda % 8 != 0 || p.ldb % 8 != 0 || p.ldc % 8 != 0 || p.N % 8 != 0) return false;
-    if (p.bias || p.accumulate || p.out_f32 || p.act != ACT_NONE) return false;
+    if ((p.bias && p.fuse != 2) || p.accumulate || p.out_f32 || p.act != ACT_NONE) return false;
+    if (p.bias && ((uintptr_t)p.bias & 7)) return false;
     if (p.residual && (p.fuse != 0 || p.ldr % 4 != 0 || ((uintptr_t)p.residual & 7) || (const void*)p.residual == (const void*)p.C)) return false;
     const int pi = vlr_prof_begin(VLR_K_GEMM256P, 2.0 * p.M * p.N * (p.K + p.K2), stream);
     if (p.fuse == 0) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 0, true>), dim3(n_cu), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);

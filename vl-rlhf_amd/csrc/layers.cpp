@@ -70,13 +70,9 @@ extern "C" int vlr_decoder_layer_fwd_ex(const vlr_llama_cfg* cfg, const vlr_laye
     CHECK(vlr_rmsnorm_fwd(x_in, w->ln1, a->xn1, a->rstd1, M, H, cfg->rms_eps, st));
     // q|k|v projection with RoPE applied to the fp32 accumulators in the GEMM epilogue (plain GEMM + rope kernel for the rows /
     // shapes the persistent kernel does not take)
-    if (w->bqkv) {   // biased fused projection (Qwen c_attn): the bias is added before the rotation -> GEMM with bias, then the RoPE kernel
-        CHECK(vlr_gemm_bf16(0, a->xn1, w->wqkv, a->qkv, w->bqkv, nullptr, M, N, H, H, H, N, 0, 0, 0, 0, st));
-        CHECK(vlr_rope_heads(a->qkv, pos, cfg->rope_cos, cfg->rope_sin, M, cfg->heads + kvh, cfg->head_dim, N, cfg->max_pos, 0, st));
-    } else {
-        CHECK(vlr_gemm_qkv_rope(a->xn1, w->wqkv, a->qkv, pos, cfg->rope_cos, cfg->rope_sin, M, N, Nq + Nkv, H, H, cfg->head_dim,
-                                cfg->max_pos, st));
-    }
+    // (a bias of the fused projection - Qwen c_attn - is added to the accumulators before the rotation)
+    CHECK(vlr_gemm_qkv_rope_bias(a->xn1, w->wqkv, w->bqkv, a->qkv, pos, cfg->rope_cos, cfg->rope_sin, M, N, Nq + Nkv, H, H, cfg->head_dim,
+                                 cfg->max_pos, st));
     CHECK(vlr_attn_fwd_gqa(a->qkv, off(a->qkv, Nq), off(a->qkv, (size_t)Nq + Nkv), N, a->attn, Nq, a->lse, key_mask, batch, S,
                            cfg->heads, kvh, cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));
     CHECK(vlr_gemm_bf16(0, a->attn, w->wo, a->x_mid, nullptr, x_in, M, H, Nq, Nq, Nq, H, H, 0, 0, 0, st));
