@@ -99,6 +99,11 @@ int vlr_rmsnorm_bwd_workspace_bytes(int H);
 int vlr_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
                     void* dw, int dw_accumulate, void* workspace, int M, int H, vlr_stream_t stream);
 int vlr_layernorm_fwd(const void* x, const void* w, const void* b, void* y, int M, int D, float eps, vlr_stream_t stream);
+/* backward of y = LayerNorm(x) * w + b (Qwen-VL resampler: ln_q / ln_kv / ln_post, QwenVL/visual.py:122-123,391): mean and rstd are
+ * recomputed from x; dx may be NULL, dw / db (bf16 [D], `accumulate`: +=) may be NULL; workspace = vlr_layernorm_bwd_workspace_bytes(D) */
+int vlr_layernorm_bwd_workspace_bytes(int D);
+int vlr_layernorm_bwd(const void* dy, const void* x, const void* w, float eps, void* dx, void* dw, void* db, int accumulate,
+                      void* workspace, int M, int D, vlr_stream_t stream);
 int vlr_vit_embed_ln(const void* patch_embeds, const void* cls, const void* pos, const void* w, const void* b, void* y,
                      int n_img, int T, int D, float eps, vlr_stream_t stream);
 int vlr_im2col(const float* pixel_values, void* patches, int n_img, int image_size, int patch, int Kp, vlr_stream_t stream);

@@ -65,7 +65,10 @@ CFG = dict(
 )
 GRAD_KEYS = ["transformer.h.0.attn.c_attn.weight", "transformer.h.0.attn.c_attn.bias", "transformer.h.1.attn.c_proj.weight",
              "transformer.h.0.mlp.w1.weight", "transformer.h.1.mlp.w2.weight", "transformer.h.1.mlp.c_proj.weight",
-             "transformer.h.0.ln_1.weight", "transformer.ln_f.weight", "lm_head.weight", "transformer.wte.weight"]
+             "transformer.h.0.ln_1.weight", "transformer.ln_f.weight", "lm_head.weight", "transformer.wte.weight"] + \
+            ["transformer.visual.attn_pool." + k for k in ("query", "kv_proj.weight", "attn.in_proj_weight", "attn.in_proj_bias",
+                                                           "attn.out_proj.weight", "attn.out_proj.bias", "ln_q.weight", "ln_q.bias",
+                                                           "ln_kv.weight", "ln_kv.bias")]
 
 
 def build(cfg, seed):
@@ -162,7 +165,8 @@ def gen_model():
     with torch.no_grad():
         g = torch.Generator().manual_seed(7)
         for (n, p), q in zip(policy.named_parameters(), ref.parameters()):
-            if "visual" not in n:         # the vision tower is shared and frozen (--freeze_vision_tower True); the LLM differs
+            if "visual" not in n or ("attn_pool" in n and "pos_embed" not in n):
+                # the ViT trunk is shared and frozen; the LLM and the resampler (re-enabled by freeze_vision_tower, :33-37) are trained
                 p.copy_((q + cfg["perturb"] * q.abs().mean() * torch.randn(q.shape, generator=g)).to(torch.bfloat16).float())
     batch, paths, pixels = make_batch(cfg, 3)
     cb = concat(batch, cfg["pad_token_id"])
@@ -171,6 +175,7 @@ def gen_model():
     with torch.no_grad():
         rout, _ = ref_forward(ref, cb["input_ids"], cb["attention_mask"], pixels)
         vis_feat = ref.transformer.visual(torch.stack([pixels[p] for p in paths], 0))
+        pol_feat = policy.transformer.visual(torch.stack([pixels[p] for p in paths], 0))
     tr = G.VLDPOTrainer.__new__(G.VLDPOTrainer)
     tr.accelerator = types.SimpleNamespace(device=torch.device("cpu"))
     res = {}
@@ -204,6 +209,7 @@ def gen_model():
     z["paths_json"] = np.frombuffer(json.dumps(paths).encode(), dtype=np.uint8)
     z["rows_json"] = np.frombuffer(json.dumps([]).encode(), dtype=np.uint8)
     z["visual_features"] = vis_feat.numpy()
+    z["policy_visual_features"] = pol_feat.numpy()
     z["image_position_map"] = out.image_position_map.numpy()
     z["logits"] = out.logits.detach().numpy().astype(np.float32)
     for lt, d in res.items():

@@ -687,6 +687,27 @@ def test_gemm_accumulate_odd_tile_counts(hip, layout, shape):
     check(c, ref, 8e-3, f"accumulate {shape} layout {layout}")
 
 
+@pytest.mark.parametrize("M,D", [(1024, 4096), (300, 256), (37, 1664)])
+def test_layernorm_bwd(hip, M, D):
+    """vlr_layernorm_bwd (statistics recomputed from x) against torch autograd of F.layer_norm, with and without accumulation"""
+    x = rnd(M, D, seed=1)
+    w, b = (1 + 0.1 * torch.randn(D)).bfloat16().to(DEV), (0.1 * torch.randn(D)).bfloat16().to(DEV)
+    dy = rnd(M, D, seed=2)
+    xf, wf, bf = x.float().requires_grad_(True), w.float().requires_grad_(True), b.float().requires_grad_(True)
+    F.layer_norm(xf, (D,), wf, bf, 1e-6).backward(dy.float())
+    ws = torch.empty(hip.helper("vlr_layernorm_bwd_workspace_bytes", D), dtype=torch.uint8, device=DEV)
+    dx = torch.empty_like(x)
+    dw, db = torch.full((D,), 0.5, dtype=torch.bfloat16, device=DEV), torch.zeros(D, dtype=torch.bfloat16, device=DEV)
+    hip.call("vlr_layernorm_bwd", dy, x, w, 1e-6, dx, dw, db, 0, ws, M, D)
+    torch.cuda.synchronize()
+    check(dx, xf.grad, 8e-3, "ln dx")
+    check(dw, wf.grad, 8e-3, "ln dw")
+    check(db, bf.grad, 8e-3, "ln db")
+    hip.call("vlr_layernorm_bwd", dy, x, w, 1e-6, None, dw, db, 1, ws, M, D)      # accumulate, no dx
+    torch.cuda.synchronize()
+    check(dw, 2 * wf.grad, 1.2e-2, "ln dw accumulate")
+
+
 # ---------------------------------------------------------------------------------------------------- fused epilogues
 @pytest.mark.parametrize("shape", [(4104, 2176, 512), (4352, 2184, 320), (12792, 2048, 256), (300, 256, 128)])
 @pytest.mark.parametrize("store_gu", [1, 0])

@@ -35,7 +35,10 @@ def test_qwenvl_forward_matches_reference_golden():
     px = batch["img_input_dict"]["pixel_values"]
     feat = model.engine.vision_features(px.cuda())
     nq, E = cfg["visual"]["n_queries"], cfg["visual"]["output_dim"]
-    assert relmax(feat.reshape(-1, nq, E), t(z, "visual_features")) < 3e-2          # ViT (head_dim 104 on the 128-wide kernel) + resampler
+    assert relmax(feat.reshape(-1, nq, E), t(z, "policy_visual_features")) < 3e-2   # ViT (head_dim 104 on the 128-wide kernel) + resampler
+    xr = model.engine.vit_trunk(px.cuda())
+    fr, _ = model.engine.resampler_fwd(ref.weights, xr, px.shape[0], "vf", False)   # the reference model's own (different) resampler
+    assert relmax(fr.reshape(-1, nq, E), t(z, "visual_features")) < 3e-2
     cb = tr.concatenated_inputs(batch, device=torch.device("cuda"))
     model.eval()
     with torch.no_grad():
@@ -87,8 +90,9 @@ def test_qwenvl_losses_match_reference_golden(loss_type):
 
 
 def test_qwenvl_train_step_gradients_match_reference_autograd():
-    """full fine-tune of the language model (vision tower frozen): loss and the gradients the reference's autograd produced - the
-    fused biased c_attn (weight AND bias), c_proj, w1 / w2 (stored as up / gate), mlp.c_proj, norms, lm_head, wte"""
+    """full fine-tune as the reference runs it (ViT trunk frozen, language model AND the resampler `attn_pool` trained): loss and the
+    gradients the reference's autograd produced - the fused biased c_attn (weight AND bias), c_proj, w1 / w2 (stored as up / gate),
+    mlp.c_proj, norms, lm_head, wte, and the resampler's query, kv_proj, in_proj (weight / bias), out_proj, ln_q, ln_kv"""
     z, cfg, W, W_ref, batch, model, ref, tr = build()
     eng = model.engine
     eng.init_optimizer()
@@ -96,7 +100,7 @@ def test_qwenvl_train_step_gradients_match_reference_autograd():
     torch.cuda.synchronize()
     assert abs(float(loss) - float(z["sigmoid.loss"])) < TOL_LOSS_FP32, (float(loss), float(z["sigmoid.loss"]))
     g = {n: p.grad for n, p in model.named_parameters()}
-    assert not any(n.startswith("transformer.visual") for n in g)
+    assert all(n.startswith("transformer.visual.attn_pool.") for n in g if n.startswith("transformer.visual"))
     n = 0
     for k in z.files:
         if k.startswith("grad."):
@@ -109,9 +113,9 @@ def test_qwenvl_train_step_gradients_match_reference_autograd():
         else:
             continue
         cs = cosine(mine, ref_g)
-        assert cs > 0.99, f"{name}: cosine {cs:.4f}"
+        assert cs > (0.98 if "attn_pool" in name else 0.99), f"{name}: cosine {cs:.4f}"
         n += 1
-    assert n == 10
+    assert n == 20
     eng.optimizer_step(lr=1e-3, beta1=0.9, beta2=0.98, eps=1e-6, weight_decay=0.05, max_grad_norm=1.0)
     loss2 = tr.training_step(model, batch)
     assert torch.isfinite(loss2) and float(loss2) < float(loss)
@@ -146,7 +150,7 @@ def test_qwenvl_lora_step_matches_oracle(dropout):
     px = batch["img_input_dict"]["pixel_values"]
     Wl = {k: v.clone().requires_grad_(True) for k, v in lora["W"].items()}
     l16, m16 = Q.compute_loss(W, W, cfg, dict(batch, pixel_values=px), cfg["beta"], emulate_bf16=True, lora=dict(lora, W=Wl))
-    assert abs(float(loss) - float(l16)) < TOL_LOSS_BF16, (float(loss), float(l16))
+    assert abs(float(loss) - float(l16)) < TOL_LOSS_BF16 + 1e-3, (float(loss), float(l16))      # (this fixture's weights are scaled x3)
     l16.backward()
     named = dict(model.named_parameters())
     worst = 1.0

@@ -304,6 +304,7 @@ def test_qwenvl_oracle_matches_reference_golden():
     paths = json.loads(bytes(z["paths_json"]).decode())
     vf = Q.qwen_visual(px, W_ref, cfg["visual"])
     assert torch.allclose(vf, t(z, "visual_features"), rtol=2e-4, atol=2e-4), float((vf - t(z, "visual_features")).abs().max())
+    assert torch.allclose(Q.qwen_visual(px, W, cfg["visual"]), t(z, "policy_visual_features"), rtol=2e-4, atol=2e-4)   # the policy's resampler differs
     cb = O.concatenated_inputs({k: v for k, v in batch.items() if k != "img_input_dict"}, padding_value=cfg["pad_token_id"])
     ids, am, lab = cb["concatenated_input_ids"], cb["concatenated_attention_mask"], cb["concatenated_labels"]
     assert Q.decode_image_paths(ids, cfg["image_start_id"]) == paths + paths
@@ -336,7 +337,7 @@ def test_qwenvl_oracle_matches_reference_golden():
             assert float((g.reshape(-1)[::17] - ref).abs().max()) <= 2e-3 * float(ref.abs().max()) + 1e-7, k
             assert abs(float(g.norm()) - float(z["grad_norm." + k[11:]])) <= 2e-3 * float(z["grad_norm." + k[11:]]), k
             checked += 1
-    assert checked == 10
+    assert checked == 20                  # ten language-model tensors + ten resampler tensors (trainable in a full fine-tune)
 
 
 # ------------------------------------------------------------------------------------------------------------ InternLM-XComposer2

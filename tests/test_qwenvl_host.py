@@ -84,7 +84,10 @@ def test_parameter_and_adapter_names_follow_the_reference_checkpoint():
     ref_keys = {k[4:] for k in z.files if k.startswith("w16.")}
     lay = ParamLayout(cfg)
     mine = {hf for hf, _, _, _ in lay.hf_names()}
-    assert mine == {k for k in ref_keys if not k.startswith("transformer.visual.")}      # every LM tensor of the reference, nothing else
+    ap = "transformer.visual.attn_pool."
+    assert mine == {k for k in ref_keys if not k.startswith("transformer.visual.") or (k.startswith(ap) and not k.endswith("pos_embed"))}
+    # = every LM tensor of the reference + the trainable resampler (QwenVLForRL.freeze_vision_tower re-enables attn_pool), nothing else
+    assert lay.offset["ap.query"] < lay.n_decay <= lay.offset["ap.lnq_w"]                 # LayerNorms and biases: no weight decay
     assert lay.shape["l0.bqkv"] == (3 * cfg["hidden"],) and lay.offset["l0.bqkv"] >= lay.n_decay                # biases: no weight decay
     gate_up = [hf for hf, name, r0, rows in lay.hf_names() if name == "l1.wgu"]
     assert gate_up == ["transformer.h.1.mlp.w2.weight", "transformer.h.1.mlp.w1.weight"]  # c_proj(w1(x) * silu(w2(x))): gate = w2, up = w1

@@ -140,6 +140,94 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* __res
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// LayerNorm backward (Qwen-VL resampler: ln_q / ln_kv / ln_post are in front of or behind trainable weights).  mean / rstd are
+// recomputed from x: dx = rstd * (g - mean(g) - xh * mean(g * xh)), g = dy * w, xh = (x - mean) * rstd;
+// dw = sum_rows dy * xh, db = sum_rows dy -> per-block partials [G][D] | [G][D], reduced in a fixed order
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                            const bf16_t* __restrict__ w, float eps, bf16_t* __restrict__ dx,
+                                                            float* __restrict__ part, int M, int D) {
+    __shared__ float red[16];
+    constexpr int MAXC = 2;  // D <= 4096
+    float dwacc[MAXC][8], dbacc[MAXC][8];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dwacc[i][e] = dbacc[i][e] = 0.f;
+    for (int row = blockIdx.x; row < M; row += gridDim.x) {
+        const size_t off = (size_t)row * D;
+        float xv[MAXC][8], gv[MAXC][8], dv[MAXC][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = (i * 256 + threadIdx.x) * 8;
+            if (c < D) {
+                unpack8(*reinterpret_cast<const u32x4*>(x + off + c), xv[i]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += xv[i][e];
+            }
+        }
+        const float mean = block_sum(s, red) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = (i * 256 + threadIdx.x) * 8;
+            if (c < D) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    xv[i][e] -= mean;
+                    q += xv[i][e] * xv[i][e];
+                }
+            }
+        }
+        const float rs = rsqrtf(block_sum(q, red) / (float)D + eps);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = (i * 256 + threadIdx.x) * 8;
+            if (c < D) {
+                float wv[8];
+                unpack8(*reinterpret_cast<const u32x4*>(dy + off + c), dv[i]);
+                unpack8(*reinterpret_cast<const u32x4*>(w + c), wv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    xv[i][e] *= rs;                       // xh
+                    gv[i][e] = dv[i][e] * wv[e];
+                    sg += gv[i][e];
+                    sgx += gv[i][e] * xv[i][e];
+                    dwacc[i][e] += dv[i][e] * xv[i][e];
+                    dbacc[i][e] += dv[i][e];
+                }
+            }
+        }
+        sg = block_sum(sg, red) / (float)D;
+        sgx = block_sum(sgx, red) / (float)D;
+        if (dx) {
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+                const int c = (i * 256 + threadIdx.x) * 8;
+                if (c < D) {
+                    float o[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = rs * (gv[i][e] - sg - xv[i][e] * sgx);
+                    *reinterpret_cast<u32x4*>(dx + off + c) = pack8(o);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = (i * 256 + threadIdx.x) * 8;
+        if (c < D) {
+            float* d = part + (size_t)blockIdx.x * D + c;
+            float* b = part + (size_t)(gridDim.x + blockIdx.x) * D + c;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { d[e] = dwacc[i][e]; b[e] = dbacc[i][e]; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // LayerNorm forward (CLIP ViT; frozen tower, no backward).  Optional fused "embedding assemble": when pe != null the
 // input row (b, t) is (t == 0 ? cls : pe[b, t-1]) + pos[t]  (CLIPVisionEmbeddings + pre_layrnorm).
 // ------------------------------------------------------------------------------------------------------------
@@ -501,6 +589,21 @@ extern "C" int vlr_colsum_f32(const void* X, int R, int C, int ld, float* out, v
                        (float*)workspace);
     hipLaunchKernelGGL(reduce_partials_f32_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)workspace, gy, C, out);
     return vlr_check_launch("vlr_colsum_f32");
+}
+
+#define VLR_LN_BWD_BLOCKS 256
+extern "C" int vlr_layernorm_bwd_workspace_bytes(int D) { return 2 * VLR_LN_BWD_BLOCKS * D * 4; }
+// dx (may be NULL) / dw / db (may be NULL together) of y = LayerNorm(x) * w + b; dw, db bf16 [D] (accumulate: +=)
+extern "C" int vlr_layernorm_bwd(const void* dy, const void* x, const void* w, float eps, void* dx, void* dw, void* db,
+                                 int accumulate, void* workspace, int M, int D, hipStream_t st) {
+    VLR_REQUIRE(M > 0 && D % 8 == 0 && D <= 4096 && workspace, "vlr_layernorm_bwd: bad shape M=%d D=%d", M, D);
+    const int G = M < VLR_LN_BWD_BLOCKS ? M : VLR_LN_BWD_BLOCKS;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(G), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, eps,
+                       (bf16_t*)dx, (float*)workspace, M, D);
+    if (dw) hipLaunchKernelGGL(reduce_partials_kernel, dim3((D + 255) / 256), dim3(256), 0, st, (const float*)workspace, G, D, (bf16_t*)dw, accumulate);
+    if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3((D + 255) / 256), dim3(256), 0, st, (const float*)workspace + (size_t)G * D, G, D,
+                               (bf16_t*)db, accumulate);
+    return vlr_check_launch("vlr_layernorm_bwd");
 }
 
 extern "C" int vlr_layernorm_fwd(const void* x, const void* w, const void* b, void* y, int M, int D, float eps,

@@ -61,6 +61,7 @@ _SIGS = {
     "vlr_rmsnorm_fwd": [P, P, P, P, I, I, F, P],
     "vlr_rmsnorm_bwd": [P, P, P, P, P, P, P, I, P, I, I, P],
     "vlr_layernorm_fwd": [P, P, P, P, I, I, F, P],
+    "vlr_layernorm_bwd": [P, P, P, F, P, P, P, I, P, I, I, P],
     "vlr_vit_embed_ln": [P, P, P, P, P, P, I, I, I, F, P],
     "vlr_im2col": [P, P, I, I, I, I, P],
     "vlr_rope_table": [P, P, I, I, F, P],
@@ -116,6 +117,7 @@ _SIGS = {
 }
 _INT_HELPERS = {
     "vlr_rmsnorm_bwd_workspace_bytes": [I],
+    "vlr_layernorm_bwd_workspace_bytes": [I],
     "vlr_colsum_workspace_bytes": [I],
     "vlr_grad_sqnorm_workspace_bytes": [],
     "vlr_abi_version": [],

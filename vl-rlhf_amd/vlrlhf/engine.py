@@ -91,6 +91,16 @@ class ParamLayout:
         if cfg.get("image_grid_pinpoints"):                   # LLaVA-Next: the row appended to every line of the un-padded tile grid
             e.append(("image_newline", (H,), [("image_newline", 0, H)]))
         e.append(("embed", (V, H), [(nm["embed"], 0, V)]))
+        ap = "transformer.visual.attn_pool."
+        if qwen and cfg.get("visual"):
+            # the resampler of the Qwen-VL vision tower stays trainable in a full fine-tune (QwenVLForRL.freeze_vision_tower,
+            # reference models/QwenVL/__init__.py:33-37): its weights live in the trainable buffer; the ViT trunk, ln_post and proj do not
+            vq = cfg["visual"]
+            E_, W_, nq_ = vq["output_dim"], vq["width"], int(vq.get("n_queries", 256))
+            e.append(("ap.win", (3 * E_, E_), [(ap + "attn.in_proj_weight", 0, 3 * E_)]))
+            e.append(("ap.wo", (E_, E_), [(ap + "attn.out_proj.weight", 0, E_)]))
+            e.append(("ap.kv", (E_, W_), [(ap + "kv_proj.weight", 0, E_)]))
+            e.append(("ap.query", (nq_, E_), [(ap + "query", 0, nq_)]))
         self.n_decay_entries = len(e)
         e.append(("norm", (H,), [(nm["norm"], 0, H)]))
         for l in range(L - 1, -1, -1):
@@ -99,6 +109,12 @@ class ParamLayout:
             e.append((f"l{l}.ln1", (H,), [(p + nm["ln1"], 0, H)]))
             if qwen:
                 e.append((f"l{l}.bqkv", (Nq + 2 * Nkv,), [(p + "attn.c_attn.bias", 0, Nq + 2 * Nkv)]))
+        if qwen and cfg.get("visual"):
+            E_ = cfg["visual"]["output_dim"]
+            e.append(("ap.bin", (3 * E_,), [(ap + "attn.in_proj_bias", 0, 3 * E_)]))
+            e.append(("ap.bo", (E_,), [(ap + "attn.out_proj.bias", 0, E_)]))
+            for k_, n_ in (("lnq_w", "ln_q.weight"), ("lnq_b", "ln_q.bias"), ("lnkv_w", "ln_kv.weight"), ("lnkv_b", "ln_kv.bias")):
+                e.append((f"ap.{k_}", (E_,), [(ap + n_, 0, E_)]))
         if not (qwen or ilm):
             e.append(("proj.b2", (H,), [("multi_modal_projector.linear_2.bias", 0, H)]))
             e.append(("proj.b1", (H,), [("multi_modal_projector.linear_1.bias", 0, H)]))

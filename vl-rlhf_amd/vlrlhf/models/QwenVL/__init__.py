@@ -4,8 +4,8 @@ BASELINE.json configs[2] (Qwen-VL-Chat, LoRA r 64 on c_attn / attn.c_proj / w1 /
 
 Differences that are deliberate: the reference model opens the image files INSIDE forward (the paths are byte strings in the token
 ids, modeling_qwen.py:525-537); here the collator loads and normalises them ahead of the step (`img_input_dict.pixel_values`, so
-the prefetching loader can overlap it) and forward decodes the paths only when no pixels were handed in.  The vision tower incl.
-the resampler is frozen (what the shipped LoRA script trains); a full fine-tune trains the language model only."""
+the prefetching loader can overlap it) and forward decodes the paths only when no pixels were handed in.  The ViT trunk is frozen;
+the resampler (`attn_pool`) trains with the language model in a full fine-tune, as in the reference, and is frozen under LoRA."""
 import json
 import os
 import re
@@ -119,7 +119,7 @@ class QwenVLForRL(LlavaForRL):
 
     def freeze_vision_tower(self):
         """reference :33-37 freezes the tower and re-enables `attn_pool`; under the shipped LoRA configuration peft freezes it again.
-        The MI355X path keeps the whole tower frozen in both modes."""
+        Same here: the engine trains `ap.*` in a full fine-tune and nothing of the tower under LoRA."""
         self._vision_frozen = True
 
     def prepare_default_generation_kwargs(self, generation_config):
@@ -131,7 +131,7 @@ class QwenVLForRL(LlavaForRL):
         pv = img_input_dict.get("pixel_values")
         if pv is not None:
             dup = getattr(pv, "_vlr_dup", 1)
-            self.engine.vision_features(pv[: pv.shape[0] // dup] if dup > 1 else pv)
+            self.engine.vit_trunk(pv[: pv.shape[0] // dup] if dup > 1 else pv)      # the frozen trunk, once, on the caller's stream
 
     def _pixels_from_ids(self, input_ids):
         """the reference behaviour: image files named in the ids are opened here (cached per ids tensor: the reference pass and the
