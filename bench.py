@@ -390,8 +390,8 @@ def main():
             line["config"]["workload"] = (f"variant on BASELINE.json configs[2]: Qwen-VL-Chat DPO bf16, 448x448 image (1024 patches -> 256 resampler "
                                           f"slots inside the ids), max_length {a.text_len}, per-device batch {a.pairs} pairs (S={S_dec}), "
                                           + (f"LoRA r={lora_r} alpha={lora_alpha} dropout={a.lora_dropout} on c_attn / attn.c_proj / w1 / w2 (scripts/dpo_qwenvl.sh), frozen base, "
-                                             "reference = adapters disabled" if a.lora else "full fine-tune of the language model, reference forward inside the step")
-                                          + ", frozen vision tower + resampler")
+                                             "reference = adapters disabled, frozen vision tower incl. resampler" if a.lora else
+                                             "full fine-tune of the language model + resampler (attn_pool), reference forward inside the step, frozen ViT trunk"))
             line["config"]["variant"] = "qwen_vl" + ("+lora" if a.lora else "") + " (not the headline configuration)"
             line["config"]["tflop_per_pair"] = round(per_pair, 2)
             line["roofline"]["step_frac"] = round(pairs_per_s / world * per_pair / PEAK_BF16_TFLOPS, 4)
