@@ -76,7 +76,7 @@ def test_internlm_xcomposer2_7b_full_size_properties():
     torch.cuda.synchronize()
     assert int(model._last_ctx["extra"]["R"]) == 4 * 1225
     assert abs(float(loss) - math.log(2.0)) < 1e-6, float(loss)
-    for k in ("l0.pa_qkv", "l0.pb_g", "l30.pb_o", "l5.wqkv", "l31.wdown"):
+    for k in ("l0.pa_qkv", "l0.pb_gu", "l30.pb_o", "l5.wqkv", "l31.wdown"):
         g = eng.gv[k].float()
         assert torch.isfinite(g).all() and (float(g.abs().max()) > 0) == (k != "never"), k
     proj_before = eng.policy.v["proj.w2"].clone()

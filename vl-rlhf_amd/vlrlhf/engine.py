@@ -76,10 +76,13 @@ class ParamLayout:
                 pr = int(cfg.get("plora_r", 256))
                 e.append((f"l{l}.wqkv", (Nq + 2 * Nkv, H), [(p + "attention.wqkv.weight", 0, Nq + 2 * Nkv)]))
                 self.row_perm[f"l{l}.wqkv"] = qkv_perm
-                for key, mod, din, dout in (("qkv", "attention.wqkv", H, Nq + 2 * Nkv), ("o", "attention.wo", Nq, H), ("g", "feed_forward.w1", H, I),
-                                            ("u", "feed_forward.w3", H, I), ("d", "feed_forward.w2", I, H)):
+                for key, mod, din, dout in (("qkv", "attention.wqkv", H, Nq + 2 * Nkv), ("o", "attention.wo", Nq, H), ("d", "feed_forward.w2", I, H)):
                     e.append((f"l{l}.pa_{key}", (pr, din), [(p + mod + ".Plora_A.weight", 0, pr)]))
                     e.append((f"l{l}.pb_{key}", (dout, pr), [(p + mod + ".Plora_B.weight", 0, dout)]))
+                # gate (w1) and up (w3): Plora_A stacked [2r][H], Plora_B stacked [2I][r] like the fused gate|up weight, so that the pair
+                # can ride the K loop of the fused SwiGLU GEMM as its adapter segment
+                e.append((f"l{l}.pa_gu", (2 * pr, H), [(p + "feed_forward.w1.Plora_A.weight", 0, pr), (p + "feed_forward.w3.Plora_A.weight", pr, pr)]))
+                e.append((f"l{l}.pb_gu", (2 * I, pr), [(p + "feed_forward.w1.Plora_B.weight", 0, I), (p + "feed_forward.w3.Plora_B.weight", I, I)]))
                 self.row_perm[f"l{l}.pb_qkv"] = qkv_perm
             else:
                 e.append((f"l{l}.wqkv", (Nq + 2 * Nkv, H), [(p + "self_attn.q_proj.weight", 0, Nq), (p + "self_attn.k_proj.weight", Nq, Nkv),

@@ -41,6 +41,8 @@ class InternLMHipEngine(LlavaHipEngine):
         self.plora_p = float(c.get("plora_dropout", 0.05))
         self._plora_calls = 0
         self.plora_seed = int(c.get("seed", 0))
+        import os
+        self.fused_forward = os.environ.get("VLR_ILM_FUSED", "1") != "0"     # PLoRA rides the fused projections where no peft LoRA is stacked on top
 
     # ------------------------------------------------------------------------------------------------ embed
     def _embed_inputs(self, ws, ids, am, lab, pixel_values, image_dup, tag, image_sizes, meta):
@@ -65,6 +67,15 @@ class InternLMHipEngine(LlavaHipEngine):
                   ctx["n_rows"], ctx["image_dup"])
 
     # ------------------------------------------------------------------------------------------------ adapters
+    def _pab(self, views, l, key):
+        """(Plora_A [r][in], Plora_B [out][r]) of target `key`; gate (w1) / up (w3) are the two halves of the stacked `gu` pair"""
+        r, I = self.plora_r, self.I
+        if key == "g":
+            return views[f"l{l}.pa_gu"][:r], views[f"l{l}.pb_gu"][:I]
+        if key == "u":
+            return views[f"l{l}.pa_gu"][r:], views[f"l{l}.pb_gu"][I:]
+        return views[f"l{l}.pa_{key}"], views[f"l{l}.pb_{key}"]
+
     def _gemm(self, layout, A, B, C, M, N, K, lda, ldb, ldc, residual=None, ldr=0, accumulate=0, alpha=1.0):
         _hip.call("vlr_gemm_bf16_scaled", layout, A, B, C, None, residual, M, N, K, lda, ldb, ldc, ldr, 0, accumulate, 0, float(alpha))
 
@@ -73,7 +84,7 @@ class InternLMHipEngine(LlavaHipEngine):
         R, rows, r = ex["R"], ex["rows"], self.plora_r
         if R == 0:
             return None
-        A, B = ws.v[f"l{l}.pa_{key}"], ws.v[f"l{l}.pb_{key}"]
+        A, B = self._pab(ws.v, l, key)
         xs = torch.empty(R, n_in, dtype=BF16, device=self.dev) if keep else self._buf((tag, "pl_xs", R, n_in), (R, n_in))
         _hip.call("vlr_gather_rows", x_in, rows, xs, R, n_in)
         if train and self.plora_p > 0:
@@ -85,19 +96,64 @@ class InternLMHipEngine(LlavaHipEngine):
         _hip.call("vlr_rows_add", yp, rows, y, ldy, R, n_out)
         return (xs, up) if keep else None
 
+    def _plora_u(self, ws, l, key, x_in, n_in, u, ldu, ex, train, seed, keep, tag):
+        """u [M][ldu] (column block of r) = scale * drop(x_in[img rows]) A^T on the image rows, ZERO on the text rows: the adapter-segment
+        GEMMs (vlr_gemm_*_lora) then add u B^T inside the K loop of the base projection - PLoRA without a separate pass over y"""
+        R, rows, r = ex["R"], ex["rows"], self.plora_r
+        M = u.shape[0]
+        if ldu == r:
+            u.zero_()
+        else:
+            u[:, :r].zero_()
+        if R == 0:
+            return None
+        A, _ = self._pab(ws.v, l, key)
+        xs = torch.empty(R, n_in, dtype=BF16, device=self.dev) if keep else self._buf((tag, "pl_xs", R, n_in), (R, n_in))
+        _hip.call("vlr_gather_rows", x_in, rows, xs, R, n_in)
+        if train and self.plora_p > 0:
+            _hip.call("vlr_dropout", xs, xs, R * n_in, self.plora_p, seed + PLORA_T[key], 1.0, 0)
+        up = torch.empty(R, r, dtype=BF16, device=self.dev) if keep else self._buf((tag, "pl_up", R), (R, r))
+        self._gemm(0, xs, A, up, R, r, n_in, n_in, n_in, r, alpha=self.plora_scale)
+        _hip.call("vlr_rows_add", up, rows, u, ldu, R, r)
+        return (xs, up) if keep else None
+
+    def _layer_forward_fused(self, ws, l, a, x, e, Bn, S, save, train, pseed, keep_p):
+        """policy (full fine-tune) / reference pass: only PLoRA sits on the linears, and it rides the fused projections"""
+        c, H, I, N, M, r = self.llama_cfg, self.H, self.I, self.Nqkv, Bn * S, self.plora_r
+        ex, pos, mask, tag = e["extra"], e["pos"], e["mask"], e["tag"]
+        kept = {}
+        ub = self._buf((tag, "pl_ufull", M), (M, 2 * r))
+        u1 = ub[:, :r]
+        _hip.call("vlr_rmsnorm_fwd", x, ws.v[f"l{l}.ln1"], a["xn1"], a["rstd1"], M, H, c.rms_eps)
+        kept["p_qkv"] = self._plora_u(ws, l, "qkv", a["xn1"], H, u1, 2 * r, ex, train, pseed, keep_p, tag)
+        _hip.call("vlr_gemm_qkv_rope_lora", a["xn1"], ws.v[f"l{l}.wqkv"], None, a["qkv"], pos, self.cos, self.sin, M, N, self.Nq + self.Nkv, H, H,
+                  self.hd, self.max_pos, u1, 2 * r, ws.v[f"l{l}.pb_qkv"], r, N, 0)
+        _hip.call("vlr_attn_fwd_gqa", a["qkv"], a["qkv"][:, self.Nq:], a["qkv"][:, self.Nq + self.Nkv:], N, a["attn"], self.Nq, a["lse"], mask,
+                  Bn, S, self.nh, self.nkv, self.hd, 1, 1.0 / math.sqrt(self.hd))
+        kept["p_o"] = self._plora_u(ws, l, "o", a["attn"], self.Nq, u1, 2 * r, ex, train, pseed, keep_p, tag)
+        _hip.call("vlr_gemm_lora", a["attn"], self.Nq, ws.v[f"l{l}.wo"], a["x_mid"], H, x, H, M, H, self.Nq, u1, 2 * r, ws.v[f"l{l}.pb_o"], r)
+        _hip.call("vlr_rmsnorm_fwd", a["x_mid"], ws.v[f"l{l}.ln2"], a["xn2"], a["rstd2"], M, H, c.rms_eps)
+        kept["p_g"] = self._plora_u(ws, l, "g", a["xn2"], H, ub, 2 * r, ex, train, pseed, keep_p, tag)
+        kept["p_u"] = self._plora_u(ws, l, "u", a["xn2"], H, ub[:, r:], 2 * r, ex, train, pseed, keep_p, tag)
+        _hip.call("vlr_gemm_swiglu_lora", a["xn2"], ws.v[f"l{l}.wgu"], a["gu"], a["act"], M, I, H, H, ub, 2 * r, ws.v[f"l{l}.pb_gu"], r)
+        kept["p_d"] = self._plora_u(ws, l, "d", a["act"], I, u1, 2 * r, ex, train, pseed, keep_p, tag)
+        _hip.call("vlr_gemm_lora", a["act"], I, ws.v[f"l{l}.wdown"], a["x_out"], H, a["x_mid"], H, M, H, I, u1, 2 * r, ws.v[f"l{l}.pb_d"], r)
+        return kept
+
     def _plora_bwd(self, ws, l, key, kept, dy, lddy, n_out, dx, n_in, ex, train, seed, acc, trainable):
         R, rows, r = ex["R"], ex["rows"], self.plora_r
         if R == 0:
             return
-        A, B = ws.v[f"l{l}.pa_{key}"], ws.v[f"l{l}.pb_{key}"]
+        A, B = self._pab(ws.v, l, key)
         dyr = self._buf(("pl_dy", R, n_out), (R, n_out))
         _hip.call("vlr_rows_gather", dy, lddy, rows, dyr, R, n_out)
         v = self._buf(("pl_v", R), (R, r))
         self._gemm(1, dyr, B, v, R, r, n_out, n_out, r, r)                                   # v = dy B
         if trainable:
             xs, up = kept
-            self._gemm(2, dyr, up, self.gv[f"l{l}.pb_{key}"], n_out, r, R, n_out, r, r, accumulate=acc)            # dB = dy^T (s u)
-            self._gemm(2, v, xs, self.gv[f"l{l}.pa_{key}"], r, n_in, R, r, n_in, n_in, accumulate=acc, alpha=self.plora_scale)   # dA = s v^T drop(x)
+            gA, gB = self._pab(self.gv, l, key)
+            self._gemm(2, dyr, up, gB, n_out, r, R, n_out, r, r, accumulate=acc)            # dB = dy^T (s u)
+            self._gemm(2, v, xs, gA, r, n_in, R, r, n_in, n_in, accumulate=acc, alpha=self.plora_scale)   # dA = s v^T drop(x)
         dxr = self._buf(("pl_dx", R, n_in), (R, n_in))
         self._gemm(1, v, A, dxr, R, n_in, r, r, n_in, n_in, alpha=self.plora_scale)
         if train and self.plora_p > 0:
@@ -151,6 +207,11 @@ class InternLMHipEngine(LlavaHipEngine):
             self._plora_calls += 1
         pseed = ((self.plora_seed << 40) + (self._plora_calls << 16)) ^ PLORA_SEED_XOR
         keep_p = save and self.lora is None          # PLoRA weights are trainable only in a full fine-tune
+        if not use_lora and self.fused_forward:
+            kept = self._layer_forward_fused(ws, l, a, x, e, Bn, S, save, train, pseed + 8 * l, keep_p)
+            if save:
+                a["kept"], a["pseed"], a["train"] = kept, pseed + 8 * l, train
+            return
         kept: Dict[str, object] = {}
         tg = self._targets()
 
