@@ -100,6 +100,37 @@ __device__ __forceinline__ void write_rows(const f32x16* acc, float mul, bf16_t*
         }
 }
 
+// Same result through LDS: the accumulator layout gives every lane ONE row, so write_rows issues 16 8-byte stores per lane that
+// each touch 32 different rows (store-issue bound, guide T21).  Here the wave drops its 32 x D tile into a private LDS image
+// (16-byte chunks XOR-swizzled by the row: the 8-byte writes are 2-way conflicted at worst, the reads conflict free) and
+// stores WHOLE rows: one wave instruction = 64 / (D/8) rows x D bf16, contiguous.  Rows >= nvalid are not written.
+template <int D>
+__device__ __forceinline__ void write_rows_staged(const f32x16* acc, float mul, char* stage, bf16_t* __restrict__ dst0, size_t ld,
+                                                  int nvalid) {
+    constexpr int CPR = D / 8, RB = D * 2, RPI = 64 / CPR;
+    // the lane id is recomputed here (v_mbcnt) instead of being kept alive across the tile loop: the kernels sit at the 256-register
+    // edge and one more live VGPR spills inside the loop (a scratch reload there also drains the DMA queue)
+    const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int row = lane & 31, g = lane >> 5;
+#pragma unroll
+    for (int db = 0; db < D / 32; ++db)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            u32x2 w;
+            w[0] = pack_bf16(acc[db][4 * rq] * mul, acc[db][4 * rq + 1] * mul);
+            w[1] = pack_bf16(acc[db][4 * rq + 2] * mul, acc[db][4 * rq + 3] * mul);
+            *reinterpret_cast<u32x2*>(stage + row * RB + (((db * 4 + rq) ^ (row & (CPR - 1))) << 4) + g * 8) = w;
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes (in order per wave) before its reads
+    const int c = lane % CPR, r0 = lane / CPR;
+#pragma unroll
+    for (int i = 0; i < 32 / RPI; ++i) {
+        const int r = i * RPI + r0;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(stage + r * RB + ((c ^ (r & (CPR - 1))) << 4));
+        if (r < nvalid) *reinterpret_cast<u32x4*>(dst0 + (size_t)r * ld + c * 8) = v;
+    }
+}
+
 // key-validity of a 64-key tile -> additive bias row in LDS; returns (block-uniform) whether any key is masked
 __device__ __forceinline__ int stage_bias(float* bias_lds, const int* __restrict__ kmask, size_t tok0, int k0, int S, int t) {
     int bad = 0;
@@ -248,28 +279,58 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 // blocks of a head over all XCDs: 3.5x the algorithmic HBM traffic, measured, profiles/r01_pmc_hbm_traffic_*).
 struct AttnGrid {
     int heads, kv_heads, group, nblk, n_kvp;   // n_kvp = batch * kv_heads
+    int epi;                                   // 1: epilogue stores whole rows through LDS (write_rows_staged)
+    unsigned* ctr;                             // persistent kernels: [8 XCDs][32] ticket / exit counters of this stream, else NULL
+    int items;                                 // persistent kernels: work items per XCD
+    // Order of the blocks inside an XCD.  The slots are sorted by work for the causal kernels (slot 0 = the block with the most
+    // tiles) and the hardware hands workgroups to free CUs in index order - list scheduling.  K/V-head-major order (lpt = 1: all
+    // blocks of one head, then the next head) keeps a head's K/V in the XCD's L2 but starts the last head's heaviest block when
+    // the chip is nearly drained: 13-15 % over the balanced time at S = 1599, 30 % at S = 4096 / batch 1 (simulated and
+    // measured, tools/attn_sweep.py).  Slot-major order over ALL heads is longest-job-first (within 1.5 % of balanced) but
+    // streams every head's K/V through the L2 for every slot.  In between: bundles of `lpt` heads, slot-major inside a bundle,
+    // the remainder bundle FIRST (a small last bundle has the same late-start problem).
+    int lpt;
+    __device__ __forceinline__ void split(int s, int per, int& g0, int& gn, int& r) const {
+        const int n_x = (n_kvp + 7) / 8;
+        const int G = lpt < n_x ? lpt : n_x;
+        int first = n_x % G;
+        if (first == 0) first = G;
+        if (s < first * per) { g0 = 0; gn = first; r = s; }
+        else {
+            const int s2 = s - first * per;
+            g0 = first + (s2 / (G * per)) * G;
+            gn = G;
+            r = s2 % (G * per);
+        }
+    }
     __host__ __device__ int per_kvp(bool loop_members) const { return loop_members ? nblk : group * nblk; }
     __host__ int grid(bool loop_members) const { return 8 * ((n_kvp + 7) / 8) * per_kvp(loop_members); }
     // member-major inside a K/V head; returns false for the padding workgroups of the last XCD round
     __device__ __forceinline__ bool decode(int L, int& head, int& kvhead, int& b, int& slot) const {
         const int xcd = L & 7, s = L >> 3, per = group * nblk;
-        const int kvp = (s / per) * 8 + xcd;
+        int g0, gn, r;
+        split(s, per, g0, gn, r);
+        const int gw = gn * group;           // slot-major inside the bundle; the query heads of one K/V head stay adjacent
+        slot = r / gw;
+        const int r2 = r % gw;
+        const int member = r2 % group;
+        const int kvp = (g0 + r2 / group) * 8 + xcd;
         if (kvp >= n_kvp) return false;
-        const int rem = s % per;
         b = kvp / kv_heads;
         kvhead = kvp % kv_heads;
-        head = kvhead * group + rem / nblk;
-        slot = rem % nblk;
+        head = kvhead * group + member;
         return true;
     }
     // one workgroup per (K/V head, key block): the kernel loops over the group's query heads itself
     __device__ __forceinline__ bool decode_kv(int L, int& kvhead, int& b, int& slot) const {
         const int xcd = L & 7, s = L >> 3;
-        const int kvp = (s / nblk) * 8 + xcd;
+        int g0, gn, r;
+        split(s, nblk, g0, gn, r);
+        const int kvp = (g0 + r % gn) * 8 + xcd;
         if (kvp >= n_kvp) return false;
         b = kvp / kv_heads;
         kvhead = kvp % kv_heads;
-        slot = s % nblk;
+        slot = r / gn;
         return true;
     }
 };
@@ -280,6 +341,25 @@ __device__ __forceinline__ void attn_dma16(const bf16_t* sbase, uint32_t voff, u
 // 4 bytes per lane -> LDS [m0 + lane*4]: one wave instruction moves 64 consecutive floats (per-tile lse / delta rows)
 __device__ __forceinline__ void attn_dma4(const float* sbase, uint32_t voff, uint32_t lds_addr) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+}
+// key-validity masks of the first nkv KV tiles, one 64-bit word per tile (bit = key is masked or past S).  Wave w takes tiles
+// w, w+4, ...; four tiles' loads are issued before the first ballot (one load latency per four tiles instead of one per tile:
+// this runs before the first MFMA of every workgroup)
+__device__ __forceinline__ void attn_tile_masks(unsigned long long* tilemask, const int* __restrict__ kmask, size_t tok0, int S,
+                                                int nkv, int wave, int lane) {
+    for (int base = wave; base < nkv; base += 16) {
+        int ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int key = (base + 4 * u) * KV_TILE + lane;
+            ok[u] = key < S ? (kmask ? kmask[tok0 + key] : 1) : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned long long bad = __builtin_amdgcn_ballot_w64(ok[u] == 0);
+            if (lane == 0 && base + 4 * u < nkv) tilemask[base + 4 * u] = bad;
+        }
+    }
 }
 // Retire the prologue's global loads of loop-invariant fragments HERE.  hipcc places the s_waitcnt vmcnt(N) for a loaded register at
 // its first use - inside the tile loop - and cannot see the LDS-DMA instructions (inline asm) issued there: vmcnt retires in
@@ -301,17 +381,18 @@ struct AttnFwd2 {
     static constexpr int NPIECE = KV_TILE / RPP / 4;    // pieces per wave and tile (4 waves)
 };
 template <int D, bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
-                                                           const bf16_t* __restrict__ v, int ld, bf16_t* __restrict__ o,
-                                                           int ldo, float* __restrict__ lse, const int* __restrict__ kmask,
-                                                           int S, int Sp, float scale_log2, AttnGrid ag) {
+__device__ __forceinline__ unsigned attn_fwd2_block(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                    const bf16_t* __restrict__ v, int ld, bf16_t* __restrict__ o,
+                                                    int ldo, float* __restrict__ lse, const int* __restrict__ kmask,
+                                                    int S, int Sp, float scale_log2, const AttnGrid& ag, int L, char* smem,
+                                                    unsigned* ctr) {
     using CF = AttnFwd2<D>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][K tile | V tile] | tile masks
     unsigned long long* tilemask = reinterpret_cast<unsigned long long*>(smem + 4 * CF::TILE_BYTES);
     const int t = threadIdx.x, lane = t & 63, g = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     int head, kvhead, b, qslot;
-    if (!ag.decode(blockIdx.x, head, kvhead, b, qslot)) return;
+    unsigned nxt = 0;          // persistent kernel: the workgroup's next ticket (thread 0), drawn under the LAST tile
+    if (!ag.decode(L, head, kvhead, b, qslot)) return (ctr && t == 0) ? atomicAdd(ctr, 1u) : 0u;
     const int nh = ag.heads;
     const size_t tok0 = (size_t)b * S;
     const bf16_t* qh = q + tok0 * ld + head * D;
@@ -348,12 +429,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
     issue_tile(0);
 
     // key-validity masks, one 64-bit word per KV tile (bit = key is masked)
-    for (int tl = wave; tl < nkv; tl += 4) {
-        const int key = tl * KV_TILE + lane;
-        const bool ok = key < S && (!kmask || kmask[tok0 + key] != 0);
-        const unsigned long long bad = __builtin_amdgcn_ballot_w64(!ok);
-        if (lane == 0) tilemask[tl] = bad;
-    }
+    attn_tile_masks(tilemask, kmask, tok0, S, nkv, wave, lane);
 
     bf16x8 qf[D / 16];
 #pragma unroll
@@ -378,6 +454,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         if (it + 1 < nkv) issue_tile(it + 1);
+        else if (ctr && t == 0) nxt = atomicAdd(ctr, 1u);  // late, so that the blocks stay dynamically balanced to the end
         if (CAUSAL && k0 > qw0 + 31) continue;             // wave-uniform: whole tile is in this wave's future
         const char* k_lds = smem + (it & 1) * 2 * CF::TILE_BYTES;
         const char* v_lds = k_lds + CF::TILE_BYTES;
@@ -393,7 +470,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
         }
         // masks only where a tile needs them: diagonal tiles (causal) and tiles holding padded / out-of-range keys
         const unsigned long long mk = tilemask[it];
-        if ((CAUSAL && k0 + KV_TILE - 1 > qw0) || mk != 0ull) {
+        if (CAUSAL && mk == 0ull) {
+            if (k0 + KV_TILE - 1 > qw0) {
+                // diagonal tile, no padded key (one per wave and block): key kk = c(kb, r) + 4g is in the query's future iff
+                // c > qi - k0 - 4g - a compare against an inline constant and a select per score
+                const int thr = qi - k0 - 4 * g;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (kb * 32 + (r & 3) + 8 * (r >> 2) > thr) s[kb][r] = -INFINITY;
+            }
+        } else if ((CAUSAL && k0 + KV_TILE - 1 > qw0) || mk != 0ull) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -437,11 +525,53 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
                 acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(v_lds, db * 32, ks, lane), pf, acc[db], 0, 0, 0);
         }
     }
-    if (qi < S) {
+    {
         const float inv = l > 0.f ? 1.f / l : 0.f;
-        write_rows<D>(acc, inv, o + (tok0 + qi) * (size_t)ldo + head * D, g);
+        if (ag.epi) {
+            // the buffer tile nkv-1 did NOT use is free: every wave passed the last barrier, i.e. finished tile nkv-2
+            char* stage = smem + (nkv & 1) * 2 * CF::TILE_BYTES + wave * (32 * D * 2);
+            write_rows_staged<D>(acc, inv, stage, o + (tok0 + qw0) * (size_t)ldo + head * D, ldo, S - qw0);
+        } else if (qi < S) {
+            write_rows<D>(acc, inv, o + (tok0 + qi) * (size_t)ldo + head * D, g);
+        }
     }
     if (lse && g == 0 && qi < Sp) lse[((size_t)b * nh + head) * Sp + qi] = (qi < S && l > 0.f) ? m + log2f(l) : INFINITY;
+    return nxt;
+}
+// One workgroup per query block (ag.ctr == NULL), or PERSISTENT workgroups (two per CU) that draw query blocks from a per-XCD
+// ticket counter: a workgroup lives ~40 us at S = 1599 and the fixed cost around it (dispatch, LDS / register allocation, the
+// prologue's first memory round trip) was 20-30 % of the kernel (tools/attn_sweep.py: TF/s against S at constant work).  The
+// next ticket is drawn under the LAST tile of the current block (latency hidden, and no block is promised before a
+// workgroup is nearly free: drawing it at the start made the last round static and cost 2-20 %); the order of the blocks inside an XCD
+// (heaviest first, all blocks of one K/V head consecutively) is the same as the one-workgroup-per-block grid.  The last
+// workgroup of an XCD to leave resets its counters for the next launch on this stream.
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                           const bf16_t* __restrict__ v, int ld, bf16_t* __restrict__ o,
+                                                           int ldo, float* __restrict__ lse, const int* __restrict__ kmask,
+                                                           int S, int Sp, float scale_log2, AttnGrid ag) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][K tile | V tile] | tile masks
+    if (!ag.ctr) {
+        attn_fwd2_block<D, CAUSAL>(q, k, v, ld, o, ldo, lse, kmask, S, Sp, scale_log2, ag, blockIdx.x, smem, nullptr);
+        return;
+    }
+    __shared__ int s_item;
+    const int xcd = blockIdx.x & 7;
+    unsigned* ctr = ag.ctr + xcd * 32;
+    if (threadIdx.x == 0) s_item = (int)atomicAdd(ctr, 1u);
+    __syncthreads();
+    int item = __builtin_amdgcn_readfirstlane(s_item);
+    while (item < ag.items) {
+        const unsigned nxt = attn_fwd2_block<D, CAUSAL>(q, k, v, ld, o, ldo, lse, kmask, S, Sp, scale_log2, ag, item * 8 + xcd, smem, ctr);
+        __syncthreads();                 // every wave is done with the tiles, the masks and s_item
+        if (threadIdx.x == 0) s_item = (int)nxt;
+        __syncthreads();
+        item = __builtin_amdgcn_readfirstlane(s_item);
+    }
+    if (threadIdx.x == 0 && atomicAdd(ctr + 1, 1u) == (unsigned)(gridDim.x / 8 - 1)) {
+        ctr[0] = 0;
+        ctr[1] = 0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -728,12 +858,7 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 1) void attn_bwd_dq2_kernel(const
         attn_issue_tile128(vh, ld, it * KV_TILE, S, dst + TB, wave, lane);
     };
     issue(0);
-    for (int tl = wave; tl < nkv; tl += 4) {
-        const int key = tl * KV_TILE + lane;
-        const bool ok = key < S && (!kmask || kmask[tok0 + key] != 0);
-        const unsigned long long bad = __builtin_amdgcn_ballot_w64(!ok);
-        if (lane == 0) tilemask[tl] = bad;
-    }
+    attn_tile_masks(tilemask, kmask, tok0, S, nkv, wave, lane);
 
     bf16x8 qf[8], dof[8];
 #pragma unroll
@@ -800,7 +925,12 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 1) void attn_bwd_dq2_kernel(const
             ATTN_PRIO(0);
         }
     }
-    if (qi < S) write_rows<D>(acc, 1.f, dq + (tok0 + qi) * (size_t)lddq + head * D, g);
+    if (ag.epi) {
+        char* stage = smem + (nkv & 1) * 2 * TB + wave * (32 * D * 2);   // the buffer the last tile did not use
+        write_rows_staged<D>(acc, 1.f, stage, dq + (tok0 + qw0) * (size_t)lddq + head * D, lddq, S - qw0);
+    } else if (qi < S) {
+        write_rows<D>(acc, 1.f, dq + (tok0 + qi) * (size_t)lddq + head * D, g);
+    }
 }
 
 template <bool CAUSAL>
@@ -915,13 +1045,59 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(const bf16_t* __rest
             ATTN_PRIO(0);
         }
     }
-    if (ki < S) {
+    if (ag.epi) {
+        char* stage = smem + (nit & 1) * 2 * TB + wave * (32 * D * 2);   // the buffer the last tile did not use
+        write_rows_staged<D>(adk, 1.f, stage, dk + (tok0 + kw0) * (size_t)lddkv + kvhead * D, lddkv, S - kw0);
+        write_rows_staged<D>(adv, 1.f, stage, dv + (tok0 + kw0) * (size_t)lddkv + kvhead * D, lddkv, S - kw0);
+    } else if (ki < S) {
         write_rows<D>(adk, 1.f, dk + (tok0 + ki) * (size_t)lddkv + kvhead * D, g);
         write_rows<D>(adv, 1.f, dv + (tok0 + ki) * (size_t)lddkv + kvhead * D, g);
     }
 }
 
 // ============================================================================================================
+static int attn_lpt_on() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("VLR_ATTN_LPT");      // K/V heads per bundle: 1 = head-major, large = slot-major over all heads
+        on = e ? atoi(e) : 8;
+        if (on < 1) on = 1;
+    }
+    return on;
+}
+static int attn_epi_on() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("VLR_ATTN_EPI");
+        on = (e && e[0] == '0') ? 0 : 1;
+    }
+    return on;
+}
+// ticket counters of the persistent kernels: one set per stream (the reference forward runs on a side stream beside the policy
+// forward), zero at rest - the kernels reset them on the way out
+#define ATTN_CTR_SLOTS 8
+static unsigned* attn_counters(hipStream_t st) {
+    static int on = -1;
+    static unsigned* buf = nullptr;
+    static int buf_dev = -1;
+    static hipStream_t streams[ATTN_CTR_SLOTS];
+    static int nstreams = 0;
+    if (on < 0) {
+        const char* e = getenv("VLR_ATTN_PERSIST");
+        on = (e && e[0] == '0') ? 0 : 1;
+        if (on && (hipGetDevice(&buf_dev) != hipSuccess ||
+                   hipMalloc((void**)&buf, ATTN_CTR_SLOTS * 8 * 32 * sizeof(unsigned)) != hipSuccess ||
+                   hipMemset(buf, 0, ATTN_CTR_SLOTS * 8 * 32 * sizeof(unsigned)) != hipSuccess)) on = 0;
+    }
+    if (!on) return nullptr;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != buf_dev) return nullptr;   // one process per GPU: the counters live on the first device used
+    for (int i = 0; i < nstreams; ++i)
+        if (streams[i] == st) return buf + (size_t)i * 8 * 32;
+    if (nstreams == ATTN_CTR_SLOTS) return nullptr;
+    streams[nstreams] = st;
+    return buf + (size_t)(nstreams++) * 8 * 32;
+}
 static int attn_dma_on() {
     static int on = -1;
     if (on < 0) {
@@ -957,8 +1133,20 @@ extern "C" int vlr_attn_fwd_gqa(const void* q, const void* k, const void* v, int
     }
     AttnGrid ag;
     ag.heads = heads; ag.kv_heads = kv_heads; ag.group = heads / kv_heads; ag.nblk = (S + 127) / 128; ag.n_kvp = batch * kv_heads;
+    ag.epi = attn_epi_on();
+    ag.lpt = attn_lpt_on();
+    int fgrid = ag.grid(false);
+    static int resident = 0;                 // workgroups the chip holds at once: two per CU, whole XCD octets
+    if (!resident) {
+        int dev = 0, cus = 0;
+        resident = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 8)
+                       ? 2 * (cus & ~7) : 512;
+    }
+    ag.ctr = fgrid > resident ? attn_counters(st) : nullptr;   // more query blocks than that: persistent workgroups
+    ag.items = fgrid / 8;
+    if (ag.ctr) fgrid = resident;
 #define LAUNCH2(D_, C_)                                                                                                 \
-    hipLaunchKernelGGL((attn_fwd2_kernel<D_, C_>), dim3(ag.grid(false)), dim3(256), AttnFwd2<D_>::LDS_BYTES, st, (const bf16_t*)q, \
+    hipLaunchKernelGGL((attn_fwd2_kernel<D_, C_>), dim3(fgrid), dim3(256), AttnFwd2<D_>::LDS_BYTES, st, (const bf16_t*)q, \
                        (const bf16_t*)k, (const bf16_t*)v, ld, (bf16_t*)o, ldo, lse, key_mask, S, Sp, sl2, ag)
     if (dma) {
         if (head_dim == 128) { if (causal) LAUNCH2(128, true); else LAUNCH2(128, false); }
@@ -1004,6 +1192,9 @@ extern "C" int vlr_attn_bwd_gqa(const void* q, const void* k, const void* v, int
     }
     AttnGrid ag;
     ag.heads = heads; ag.kv_heads = kv_heads; ag.group = heads / kv_heads; ag.nblk = (S + 127) / 128; ag.n_kvp = batch * kv_heads;
+    ag.epi = attn_epi_on();
+    ag.lpt = attn_lpt_on();
+    ag.ctr = nullptr; ag.items = 0;
     if (dma) {
         if (causal) {
             hipLaunchKernelGGL((attn_bwd_dq2_kernel<true>), dim3(ag.grid(false)), dim3(256), LDS_DQ, st, (const bf16_t*)q, (const bf16_t*)k,

@@ -274,8 +274,6 @@ class InternLMHipEngine(LlavaHipEngine):
                 self._gemm(2, cur, a["act"], g("wdown"), H, I, M, H, I, I, accumulate=acc)
             self._gemm(1, cur, ws.v[f"l{l}.wdown"], dact, M, I, H, H, I, I)
             adapters_bwd("d", cur, H, dact)
-            if full:             # the up / gate weight gradients need gate | up BEFORE swiglu_bwd overwrites them? no: they need d gate | d up
-                pass
             _hip.call("vlr_swiglu_bwd", a["gu"], dact, M, I)                  # gu now holds [d gate | d up]
             if full:
                 self._gemm(2, a["gu"], a["xn2"], g("wgu"), 2 * I, H, M, 2 * I, H, H, accumulate=acc)

@@ -16,7 +16,7 @@ The ViT trunk, ln_post and proj are frozen.  The resampler is trainable in a ful
 engine's trainable buffer (`ap.*`) and `resampler_bwd` back-propagates through the same combined-sequence construction.
 """
 import math
-from typing import Dict, Optional
+from typing import Dict
 
 import numpy as np
 import torch
