@@ -19,6 +19,8 @@
 // scale*log2(e), so P = exp2(s*scale*log2e - L2).  Fully masked query rows give O = 0, L2 = +inf (P == 0 in bwd).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 #define KV_TILE 64
@@ -933,7 +935,12 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 1) void attn_bwd_dq2_kernel(const
     }
 }
 
-template <bool CAUSAL>
+// PIPE: the tile body as fenced half-units so that every LDS fragment is requested two half-units (8 MFMAs, 256 cycles) before
+// the MFMA that consumes it.  Left to itself hipcc sinks each ds_read next to its MFMA (`ds_read; s_waitcnt lgkmcnt(0);
+// v_mfma`, 64 times per tile): with ONE wave per SIMD (423 registers) nothing hides that latency and the kernel ran at 20 % MFMA
+// utilisation - 4.5 us per tile against 0.9 us of MFMA work.  The unit table is at the tile body.
+// Same arithmetic in the same order per accumulator as the unpipelined body (PIPE = false, VLR_ATTN_PIPE=0): bit-identical.
+template <bool CAUSAL, int PIPE>
 __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                             const bf16_t* __restrict__ v, int ld,
                                                             const bf16_t* __restrict__ dout, int ldo,
@@ -990,6 +997,143 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(const bf16_t* __rest
 #pragma unroll
     for (int st = 0; st < 8; ++st) { ATTN_RETIRE(kf[st]); ATTN_RETIRE(vf[st]); }
 
+    if constexpr (PIPE > 0) {
+        // one tile: barrier, next tile's DMA, the fenced half-units.  Two loops per query head - the leading tiles that need masks
+        // (the diagonal of a causal block; every tile when the key block holds padded keys), then the rest - so that each loop
+        // holds ONE body: with both bodies in one loop hipcc moved all 128 accumulator registers between AGPRs and VGPRs at
+        // every iteration.  Every wave runs nq iterations per head whatever its split, so the barriers match.
+        auto tile = [&](int j, int it, auto mask_c) {
+            const int q0 = q_start + it * KV_TILE;
+            const float* lse_t = reinterpret_cast<const float*>(smem + 4 * TB + (j & 1) * 512);   // this tile's 64 lse | 64 delta (tail = +inf)
+            const float* dl_t = lse_t + 64;
+            ATTN_TILE_BARRIER();
+            if (j + 1 < nit) issue(j + 1);
+            if (CAUSAL && q0 + KV_TILE - 1 < kw0) return;     // every query of the tile precedes this wave's keys
+            const char* q_lds = smem + (j & 1) * 2 * TB;
+            const char* do_lds = q_lds + TB;
+            auto tile_body = [&](auto mask_c) {
+                constexpr bool MASK = decltype(mask_c)::value;
+                // per-tile opaque copy of the lane id: the ~40 lane-derived LDS addresses are recomputed per tile instead of being held
+                // (and spilled) across the loop
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                const int gl = ln >> 5;
+                // sixteen half-units of 4 MFMAs, each fed by 4 LDS fragments (16 registers) requested AHEAD half-units earlier:
+                //   x = 0..7   S / dP:  qb = x >> 2, k-slots {2 (x & 3), 2 (x & 3) + 1}
+                //   x = 8..15  dV / dK: qb = (x - 8) >> 2, h = ((x - 8) >> 1) & 1, d blocks {2 (x & 1), 2 (x & 1) + 1}
+                // P / dS of accumulator rows 4 rq .. 4 rq + 3 of qb are VALU work beside half-unit 4 + 4 qb + rq (S, dP of qb are complete
+                // after x = 4 qb + 3; dV / dK of (qb, h) start at x = 8 + 4 qb + 2 h); they are packed to bf16 as soon as a half (h) is done
+                constexpr int AHEAD = PIPE;
+                bf16x8 u[16][4];
+                f32x4 l2v[8], dlv[8];
+                f32x16 sc[2], dpc[2];
+                f32x4 pmq[8];
+                bf16x8 pf[2][2], dsf[2][2];
+                auto ldh = [&](auto xc) {
+                    constexpr int X = decltype(xc)::value;
+                    if constexpr (X < 8) {
+                        constexpr int qb = X >> 2;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            u[X][2 * i] = frag_row<D>(q_lds, qb * 32, 2 * (2 * (X & 3) + i), ln);
+                            u[X][2 * i + 1] = frag_row<D>(do_lds, qb * 32, 2 * (2 * (X & 3) + i), ln);
+                        }
+                    } else {
+                        constexpr int qb = (X - 8) >> 2, h = ((X - 8) >> 1) & 1;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            u[X][2 * i] = frag_tr<D>(do_lds, (2 * (X & 1) + i) * 32, qb * 2 + h, ln);
+                            u[X][2 * i + 1] = frag_tr<D>(q_lds, (2 * (X & 1) + i) * 32, qb * 2 + h, ln);
+                        }
+                    }
+                };
+                auto ldl = [&](auto pc) {                    // lse / delta of the queries of P / dS slice pc = 4 qb + rq
+                    constexpr int P = decltype(pc)::value, qb = P >> 2, rq = P & 3;
+                    l2v[P] = *reinterpret_cast<const f32x4*>(lse_t + qb * 32 + 8 * rq + 4 * gl);
+                    dlv[P] = *reinterpret_cast<const f32x4*>(dl_t + qb * 32 + 8 * rq + 4 * gl);
+                };
+                auto mmh = [&](auto xc) {
+                    constexpr int X = decltype(xc)::value;
+                    if constexpr (X < 8) {
+                        constexpr int qb = X >> 2;
+                        if constexpr ((X & 3) == 0) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) { sc[qb][r] = 0.f; dpc[qb][r] = 0.f; }
+                        }
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            sc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[X][2 * i], kf[2 * (X & 3) + i], sc[qb], 0, 0, 0);
+                            dpc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[X][2 * i + 1], vf[2 * (X & 3) + i], dpc[qb], 0, 0, 0);
+                        }
+                    } else {
+                        constexpr int qb = (X - 8) >> 2, h = ((X - 8) >> 1) & 1;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            adv[2 * (X & 1) + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[X][2 * i], pf[qb][h], adv[2 * (X & 1) + i], 0, 0, 0);
+                            adk[2 * (X & 1) + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[X][2 * i + 1], dsf[qb][h], adk[2 * (X & 1) + i], 0, 0, 0);
+                        }
+                    }
+                };
+                auto pds = [&](auto pc) {
+                    constexpr int P = decltype(pc)::value, qb = P >> 2, rq = P & 3;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * rq + e;
+                        float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[qb][r], scale_log2, -l2v[P][e]));   // l2 = +inf past S -> 0
+                        if constexpr (MASK) {
+                            const int qq = q0 + qb * 32 + 8 * rq + 4 * gl + e;
+                            if (!key_ok || (CAUSAL && ki > qq)) pv = 0.f;
+                        }
+                        pmq[P][e] = pv;
+                        sc[qb][r] = pv > 0.f ? pv * (dpc[qb][r] - dlv[P][e]) * scale : 0.f;
+                    }
+                    if constexpr (rq & 1) {                  // rows 8h .. 8h+7 done: the bf16 operands of dV / dK (pack_frag order)
+                        constexpr int h = rq >> 1;
+                        u32x4 wp, wd;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const f32x4& pp = pmq[P - 1 + (i >> 1)];
+                            wp[i] = pack_bf16(pp[2 * (i & 1)], pp[2 * (i & 1) + 1]);
+                            wd[i] = pack_bf16(sc[qb][8 * h + 2 * i], sc[qb][8 * h + 2 * i + 1]);
+                        }
+                        pf[qb][h] = __builtin_bit_cast(bf16x8, wp);
+                        dsf[qb][h] = __builtin_bit_cast(bf16x8, wd);
+                    }
+                };
+#define DKV_FENCE() __builtin_amdgcn_sched_barrier(0)
+                auto step = [&](auto xc) {
+                    constexpr int X = decltype(xc)::value;
+                    if constexpr (X + AHEAD < 16) ldh(std::integral_constant<int, X + AHEAD>{});
+                    if constexpr (X + 1 >= 4 && X + 1 < 12) ldl(std::integral_constant<int, X + 1 - 4>{});
+                    DKV_FENCE();
+                    mmh(xc);
+                    if constexpr (X >= 4 && X < 12) pds(std::integral_constant<int, X - 4>{});
+                    DKV_FENCE();
+                };
+                ldh(std::integral_constant<int, 0>{});
+                if constexpr (AHEAD > 1) ldh(std::integral_constant<int, 1>{});
+                DKV_FENCE();
+                step(std::integral_constant<int, 0>{});  step(std::integral_constant<int, 1>{});
+                step(std::integral_constant<int, 2>{});  step(std::integral_constant<int, 3>{});
+                step(std::integral_constant<int, 4>{});  step(std::integral_constant<int, 5>{});
+                step(std::integral_constant<int, 6>{});  step(std::integral_constant<int, 7>{});
+                step(std::integral_constant<int, 8>{});  step(std::integral_constant<int, 9>{});
+                step(std::integral_constant<int, 10>{}); step(std::integral_constant<int, 11>{});
+                step(std::integral_constant<int, 12>{}); step(std::integral_constant<int, 13>{});
+                step(std::integral_constant<int, 14>{}); step(std::integral_constant<int, 15>{});
+#undef DKV_FENCE
+            };
+            tile_body(mask_c);
+        };
+        // tiles with q0 < kw0 + 31 hold queries that precede some of this wave's keys
+        const int n_mask = any_bad_key ? nq : (CAUSAL ? min(nq, (kw0 + 31 - q_start + KV_TILE - 1) / KV_TILE) : 0);
+        int j = 0;
+        for (int m = 0; m < group; ++m) {
+            int it = 0;
+            for (; it < n_mask; ++it, ++j) tile(j, it, std::true_type{});
+            for (; it < nq; ++it, ++j) tile(j, it, std::false_type{});
+        }
+    } else
     for (int j = 0; j < nit; ++j) {
         const int q0 = q_start + (j % nq) * KV_TILE;
         const float* lse_t = reinterpret_cast<const float*>(smem + 4 * TB + (j & 1) * 512);   // this tile's 64 lse | 64 delta (tail = +inf)
@@ -1003,6 +1147,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(const bf16_t* __rest
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             f32x16 s, dp;
+
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
@@ -1062,6 +1207,14 @@ static int attn_lpt_on() {
         const char* e = getenv("VLR_ATTN_LPT");      // K/V heads per bundle: 1 = head-major, large = slot-major over all heads
         on = e ? atoi(e) : 8;
         if (on < 1) on = 1;
+    }
+    return on;
+}
+static int attn_pipe_on() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("VLR_ATTN_PIPE");      // dK,dV kernel: LDS fragments requested this many half-units ahead (0 = unpipelined body)
+        on = e ? atoi(e) : 2;
     }
     return on;
 }
@@ -1187,8 +1340,12 @@ extern "C" int vlr_attn_bwd_gqa(const void* q, const void* k, const void* v, int
         attr = true;
         hipFuncSetAttribute((const void*)attn_bwd_dq2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ);
         hipFuncSetAttribute((const void*)attn_bwd_dq2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ);
-        hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DKV);
-        hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DKV);
+        hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DKV);
+        hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DKV);
+        hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DKV);
+        hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DKV);
+        hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DKV);
+        hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DKV);
     }
     AttnGrid ag;
     ag.heads = heads; ag.kv_heads = kv_heads; ag.group = heads / kv_heads; ag.nblk = (S + 127) / 128; ag.n_kvp = batch * kv_heads;
@@ -1199,13 +1356,23 @@ extern "C" int vlr_attn_bwd_gqa(const void* q, const void* k, const void* v, int
         if (causal) {
             hipLaunchKernelGGL((attn_bwd_dq2_kernel<true>), dim3(ag.grid(false)), dim3(256), LDS_DQ, st, (const bf16_t*)q, (const bf16_t*)k,
                                (const bf16_t*)v, ld, (const bf16_t*)dout, ldo, lse, delta_ws, key_mask, (bf16_t*)dq, ldd, S, Sp, scale, ag);
-            hipLaunchKernelGGL((attn_bwd_dkv2_kernel<true>), dim3(ag.grid(true)), dim3(256), LDS_DKV, st, (const bf16_t*)q, (const bf16_t*)k,
-                               (const bf16_t*)v, ld, (const bf16_t*)dout, ldo, lse, delta_ws, key_mask, (bf16_t*)dk, (bf16_t*)dv, ldd, S, Sp, scale, ag);
+#define DKV_LAUNCH(P_)                                                                                                    \
+    hipLaunchKernelGGL((attn_bwd_dkv2_kernel<true, P_>), dim3(ag.grid(true)), dim3(256), LDS_DKV, st, (const bf16_t*)q, (const bf16_t*)k, \
+                       (const bf16_t*)v, ld, (const bf16_t*)dout, ldo, lse, delta_ws, key_mask, (bf16_t*)dk, (bf16_t*)dv, ldd, S, Sp, scale, ag)
+            if (attn_pipe_on() >= 2) DKV_LAUNCH(2);
+            else if (attn_pipe_on() == 1) DKV_LAUNCH(1);
+            else DKV_LAUNCH(0);
+#undef DKV_LAUNCH
         } else {
             hipLaunchKernelGGL((attn_bwd_dq2_kernel<false>), dim3(ag.grid(false)), dim3(256), LDS_DQ, st, (const bf16_t*)q, (const bf16_t*)k,
                                (const bf16_t*)v, ld, (const bf16_t*)dout, ldo, lse, delta_ws, key_mask, (bf16_t*)dq, ldd, S, Sp, scale, ag);
-            hipLaunchKernelGGL((attn_bwd_dkv2_kernel<false>), dim3(ag.grid(true)), dim3(256), LDS_DKV, st, (const bf16_t*)q, (const bf16_t*)k,
-                               (const bf16_t*)v, ld, (const bf16_t*)dout, ldo, lse, delta_ws, key_mask, (bf16_t*)dk, (bf16_t*)dv, ldd, S, Sp, scale, ag);
+#define DKV_LAUNCH(P_)                                                                                                    \
+    hipLaunchKernelGGL((attn_bwd_dkv2_kernel<false, P_>), dim3(ag.grid(true)), dim3(256), LDS_DKV, st, (const bf16_t*)q, (const bf16_t*)k, \
+                       (const bf16_t*)v, ld, (const bf16_t*)dout, ldo, lse, delta_ws, key_mask, (bf16_t*)dk, (bf16_t*)dv, ldd, S, Sp, scale, ag)
+            if (attn_pipe_on() >= 2) DKV_LAUNCH(2);
+            else if (attn_pipe_on() == 1) DKV_LAUNCH(1);
+            else DKV_LAUNCH(0);
+#undef DKV_LAUNCH
         }
     } else if (causal) {
         hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), grid, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,
