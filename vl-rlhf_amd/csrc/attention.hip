@@ -581,8 +581,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out,
                                                          int ldo, float* __restrict__ delta, int S, int Sp, int nh) {
-    const size_t row = blockIdx.x;   // token row b*S+s
-    const int b = (int)(row / S), s = (int)(row % S);
+    // one workgroup per PADDED row: rows [S, Sp) are written as zeros - the dK,dV kernel multiplies P (exactly 0 there: lse is
+    // +inf) by (dP - delta) without a guard, and 0 x (stale NaN) would poison dK
+    const int b = (int)(blockIdx.x / Sp), s = (int)(blockIdx.x % Sp);
+    if (s >= S) {
+        for (int h = threadIdx.x; h < nh; h += 256) delta[((size_t)b * nh + h) * Sp + s] = 0.f;
+        return;
+    }
+    const size_t row = (size_t)b * S + s;   // token row
     for (int c = threadIdx.x * 8; c < nh * 128; c += 256 * 8) {
         float a[8], d[8];
         unpack8(*reinterpret_cast<const u32x4*>(dout + row * ldo + c), a);
@@ -913,7 +919,7 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 1) void attn_bwd_dq2_kernel(const
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float pp = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], scale_log2, -L2));   // masked / L2=+inf -> 0
-                s[r] = pp * (dp[r] - dl) * scale;
+                s[r] = pp * (dp[r] - dl);          // x scale: once, on dQ in the epilogue
             }
             ATTN_PRIO(1);
 #pragma unroll
@@ -929,9 +935,9 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 1) void attn_bwd_dq2_kernel(const
     }
     if (ag.epi) {
         char* stage = smem + (nkv & 1) * 2 * TB + wave * (32 * D * 2);   // the buffer the last tile did not use
-        write_rows_staged<D>(acc, 1.f, stage, dq + (tok0 + qw0) * (size_t)lddq + head * D, lddq, S - qw0);
+        write_rows_staged<D>(acc, scale, stage, dq + (tok0 + qw0) * (size_t)lddq + head * D, lddq, S - qw0);
     } else if (qi < S) {
-        write_rows<D>(acc, 1.f, dq + (tok0 + qi) * (size_t)lddq + head * D, g);
+        write_rows<D>(acc, scale, dq + (tok0 + qi) * (size_t)lddq + head * D, g);
     }
 }
 
@@ -939,7 +945,7 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 1) void attn_bwd_dq2_kernel(const
 // the MFMA that consumes it.  Left to itself hipcc sinks each ds_read next to its MFMA (`ds_read; s_waitcnt lgkmcnt(0);
 // v_mfma`, 64 times per tile): with ONE wave per SIMD (423 registers) nothing hides that latency and the kernel ran at 20 % MFMA
 // utilisation - 4.5 us per tile against 0.9 us of MFMA work.  The unit table is at the tile body.
-// Same arithmetic in the same order per accumulator as the unpipelined body (PIPE = false, VLR_ATTN_PIPE=0): bit-identical.
+// Same arithmetic in the same order per accumulator as the unpipelined body (PIPE = 0, VLR_ATTN_PIPE=0): bit-identical.
 template <bool CAUSAL, int PIPE>
 __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                             const bf16_t* __restrict__ v, int ld,
@@ -1085,7 +1091,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(const bf16_t* __rest
                             if (!key_ok || (CAUSAL && ki > qq)) pv = 0.f;
                         }
                         pmq[P][e] = pv;
-                        sc[qb][r] = pv > 0.f ? pv * (dpc[qb][r] - dlv[P][e]) * scale : 0.f;
+                        sc[qb][r] = pv * (dpc[qb][r] - dlv[P][e]);   // x scale: once, on dK in the epilogue; delta is finite on padded rows
                     }
                     if constexpr (rq & 1) {                  // rows 8h .. 8h+7 done: the bf16 operands of dV / dK (pack_frag order)
                         constexpr int h = rq >> 1;
@@ -1172,7 +1178,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(const bf16_t* __rest
                         if (!key_ok || (CAUSAL && ki > qq)) pv = 0.f;
                     }
                     pm[r] = pv;
-                    s[r] = pv > 0.f ? pv * (dp[r] - dl[e]) * scale : 0.f;
+                    s[r] = pv * (dp[r] - dl[e]);
                 }
             }
             ATTN_PRIO(1);
@@ -1192,10 +1198,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(const bf16_t* __rest
     }
     if (ag.epi) {
         char* stage = smem + (nit & 1) * 2 * TB + wave * (32 * D * 2);   // the buffer the last tile did not use
-        write_rows_staged<D>(adk, 1.f, stage, dk + (tok0 + kw0) * (size_t)lddkv + kvhead * D, lddkv, S - kw0);
+        write_rows_staged<D>(adk, scale, stage, dk + (tok0 + kw0) * (size_t)lddkv + kvhead * D, lddkv, S - kw0);
         write_rows_staged<D>(adv, 1.f, stage, dv + (tok0 + kw0) * (size_t)lddkv + kvhead * D, lddkv, S - kw0);
     } else if (ki < S) {
-        write_rows<D>(adk, 1.f, dk + (tok0 + ki) * (size_t)lddkv + kvhead * D, g);
+        write_rows<D>(adk, scale, dk + (tok0 + ki) * (size_t)lddkv + kvhead * D, g);
         write_rows<D>(adv, 1.f, dv + (tok0 + ki) * (size_t)lddkv + kvhead * D, g);
     }
 }
@@ -1331,7 +1337,7 @@ extern "C" int vlr_attn_bwd_gqa(const void* q, const void* k, const void* v, int
     VLR_REQUIRE(dma || heads == kv_heads, "vlr_attn_bwd: grouped-query attention needs the LDS-DMA kernels (S <= %d, VLR_ATTN_DMA != 0)", ATTN_MAX_TILES * KV_TILE);
     const int Sp = (S + 63) / 64 * 64;   // lse and delta_ws are [batch][heads][Sp] floats
     const int pi = vlr_prof_begin(VLR_K_ATTN_BWD, 10.0 * S * S * heads * head_dim * batch * (causal ? 0.5 : 1.0), st);
-    hipLaunchKernelGGL(attn_delta_kernel, dim3(batch * S), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)o, ldo,
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(batch * Sp), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)o, ldo,
                        delta_ws, S, Sp, heads);
     const dim3 grid((S + 127) / 128, heads, batch);
     constexpr int LDS_DQ = 4 * KV_TILE * 128 * 2 + ATTN_MAX_TILES * 8, LDS_DKV = 4 * KV_TILE * 128 * 2 + 1024;
