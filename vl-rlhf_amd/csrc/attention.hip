@@ -1082,14 +1082,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(const bf16_t* __rest
                 };
                 auto pds = [&](auto pc) {
                     constexpr int P = decltype(pc)::value, qb = P >> 2, rq = P & 3;
+                    // MASK: one word of "masked" bits per lane (= key): bit c <-> query q0 + 32 qb + c + 4g (the lane's scores sit at
+                    // c = 8 rq + e); a padded key masks all of them, causality the queries before the key: c < ki - query0.  A select on
+                    // a bit test - the `!key_ok || ki > qq` form compiled to a divergent branch around every exp
+                    uint32_t bad = 0;
+                    if constexpr (MASK) {
+                        const int thr = ki - q0 - 32 * qb - 4 * gl;
+                        bad = !key_ok ? 0xffffffffu : (!CAUSAL || thr <= 0 ? 0u : (thr >= 32 ? 0xffffffffu : ((1u << thr) - 1u)));
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int r = 4 * rq + e;
                         float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[qb][r], scale_log2, -l2v[P][e]));   // l2 = +inf past S -> 0
-                        if constexpr (MASK) {
-                            const int qq = q0 + qb * 32 + 8 * rq + 4 * gl + e;
-                            if (!key_ok || (CAUSAL && ki > qq)) pv = 0.f;
-                        }
+                        if constexpr (MASK) pv = (bad & (1u << (8 * rq + e))) ? 0.f : pv;
                         pmq[P][e] = pv;
                         sc[qb][r] = pv * (dpc[qb][r] - dlv[P][e]);   // x scale: once, on dK in the epilogue; delta is finite on padded rows
                     }
