@@ -348,6 +348,52 @@ def test_attention_bwd(hip, B, S, nh, masked):
         assert float(dqkv[~valid][:, H:].abs().max()) == 0.0
 
 
+def test_attention_schedule_paths(hip):
+    """80 K/V heads = 10 per XCD: bundles of 8 + a remainder bundle of 2 in the block order; 640 query blocks > the 512 resident
+    workgroups: persistent forward on the ticket counters (twice, so the self-reset is exercised); right padding -> masked tiles in
+    every kernel; the backward workspace arrives full of NaN (delta rows past S must come back as zeros: dS has no guard)."""
+    B, S, nh, hd = 5, 900, 16, 128
+    H = nh * hd
+    qkv = rnd(B * S, 3 * H, seed=31)
+    do = rnd(B * S, H, seed=32)
+    km = torch.ones(B, S, dtype=torch.int32, device=DEV)
+    km[0, S - 70:] = 0
+    km[3, S - 5:] = 0
+    do.view(B, S, H)[0, S - 70:] = 0
+    do.view(B, S, H)[3, S - 5:] = 0
+    scale = 1.0 / math.sqrt(hd)
+    Sp = (S + 63) // 64 * 64
+    lse = torch.zeros(B, nh, Sp, dtype=torch.float32, device=DEV)
+    outs = []
+    for _ in range(2):
+        o = torch.full((B * S, H), float("nan"), dtype=torch.bfloat16, device=DEV)
+        hip.call("vlr_attn_fwd", qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, o, H, lse, km, B, S, nh, hd, 1, scale)
+        outs.append(o)
+    dqkv = torch.full((B * S, 3 * H), float("nan"), dtype=torch.bfloat16, device=DEV)
+    delta = torch.full((B, nh, Sp), float("nan"), dtype=torch.float32, device=DEV)
+    hip.call("vlr_attn_bwd", qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, outs[0], do, H, lse, delta, km, dqkv, dqkv[:, H:],
+             dqkv[:, 2 * H:], 3 * H, B, S, nh, hd, 1, scale)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    assert float(delta[:, :, S:].abs().max()) == 0.0 and torch.isfinite(delta).all()
+    valid = km.reshape(-1) != 0
+    g = torch.empty(B * S, 3 * H, device=DEV)
+    ref = torch.empty(B * S, H, device=DEV)
+    for b in range(B):                      # one sequence at a time: the eager reference holds S x S per head
+        x = qkv[b * S:(b + 1) * S].float().requires_grad_(True)
+        q, k, v = (x[:, i * H:(i + 1) * H].reshape(1, S, nh, hd).transpose(1, 2) for i in range(3))
+        r = ref_attention(q, k, v, True, km[b:b + 1], scale).transpose(1, 2).reshape(S, H)
+        (r * do[b * S:(b + 1) * S].float()).sum().backward()
+        ref[b * S:(b + 1) * S] = r.detach()
+        g[b * S:(b + 1) * S] = x.grad
+    check(outs[0][valid], ref[valid], 1.2e-2, "attention fwd (persistent, bundled order)")
+    check(dqkv[valid][:, :H], g[valid][:, :H], 2e-2, "dq")
+    check(dqkv[valid][:, H:2 * H], g[valid][:, H:2 * H], 2e-2, "dk")
+    check(dqkv[valid][:, 2 * H:], g[valid][:, 2 * H:], 2e-2, "dv")
+    assert torch.isfinite(dqkv.float()).all()
+    assert float(dqkv[~valid][:, H:].abs().max()) == 0.0
+
+
 # ---------------------------------------------------------------------------------------------------- merge
 def test_merge_matches_oracle(hip):
     H, P, V, image_token, model_pad = 64, 5, 90, 80, 81
