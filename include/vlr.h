@@ -24,7 +24,9 @@ typedef struct ihipStream_t* vlr_stream_t; /* == hipStream_t */
 const char* vlr_last_error(void);
 int vlr_abi_version(void);
 /* in-library kernel timing (HIP events on the launch stream): kernels 0 gemm NT, 1 gemm NN, 2 gemm TN, 3 attention fwd,
- * 4 attention bwd, 5 the 256x256 eight-phase GEMM kernel alone (the sub-launches of 0-2).  vlr_prof_collect fills out[k*3 + {0,1,2}] = {launches, total ms, algorithmic FLOPs}. */
+ * 4 attention bwd, 5 the 256x256 eight-phase GEMM kernel alone (the sub-launches of 0-2).  vlr_prof_collect fills out[k*3 + {0,1,2}] = {launches, total ms, algorithmic FLOPs}.
+ * vlr_prof_enable(0) stops; (N >= 1) starts and brackets one launch in N, picked pseudo-randomly per kernel id - launches and FLOPs
+ * stay exact, `total ms` is the sampled mean x launches (an event pair is two queue packets around the kernel: N = 1 perturbs the step). */
 int vlr_prof_enable(int on);
 int vlr_prof_collect(double* out_host, int n_kernels);
 

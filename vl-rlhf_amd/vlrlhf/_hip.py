@@ -185,8 +185,9 @@ _prof = None   # {entry point: [(start_event, end_event, args)]} while bench.py 
 PROF_KERNELS = ["gemm_nt", "gemm_nn", "gemm_tn", "attn_fwd", "attn_bwd", "gemm256p"]
 
 
-def lib_profile_start():
-    lib().vlr_prof_enable(1)
+def lib_profile_start(sample=1):
+    """brackets one launch in `sample` with HIP events (api.cpp); counts and work stay exact, time is the scaled sampled mean"""
+    lib().vlr_prof_enable(max(1, int(sample)))
 
 
 def lib_profile_stop():
