@@ -202,6 +202,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = apply_act(p.alpha * v[e] + bv[e], p.act);
+                if (p.fuse == 6) {      // dropout-accumulate: the keep mask of elements (gm, gn .. gn+7) - one hash group of vlr_dropout
+                    const long grp = ((long)gm * p.drop_ld + gn) >> 3;
+                    const uint64_t r0 = vlr_mix64(p.drop_key ^ (uint64_t)(2 * grp)), r1 = vlr_mix64(p.drop_key ^ (uint64_t)(2 * grp + 1));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if ((uint32_t)((r0 >> (16 * e)) & 0xffffu) < p.drop_thr) v[e] = 0.f;
+                        if ((uint32_t)((r1 >> (16 * e)) & 0xffffu) < p.drop_thr) v[4 + e] = 0.f;
+                    }
+                }
                 if (p.residual) {
                     float rv[8];
                     unpack8(*reinterpret_cast<const u32x4*>(p.residual + (size_t)gm * p.ldr + gn), rv);
@@ -642,7 +651,20 @@ extern "C" int vlr_gemm_dropout_acc(const void* v, int ldv, const void* A, void*
     GemmParams g = fused_params(v, A, dx, M, in, r, ldv, in, in);
     g.fuse = 6; g.accumulate = 1; g.alpha = scale / (1.f - p);
     g.drop_key = vlr_mix64(seed); g.drop_thr = vlr_dropout_thr(p); g.drop_ld = in;
-    if (vlr_gemm256p_dropacc_try_launch(g, stream)) return vlr_check_launch("vlr_gemm_dropout_acc(fused)");
+    // K is the adapter rank: the launch is one read-modify-write pass over dx with a few MFMAs per tile.  The 256x256 kernel holds one
+    // tile per CU and its load - add - store of the 128 KB output tile is exposed (157 us per [12792 x 4096] launch = 1.3 TB/s);
+    // the 128x128 kernel keeps several workgroups per CU in flight and adds in fp32 before the one rounding.  VLR_GEMM_DROPACC: 2 (default)
+    // 128x128, 1 256x256, 0 product + dropout-accumulate kernel
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("VLR_GEMM_DROPACC"); mode = e ? atoi(e) : 2; }
+    if (mode == 2 && in % 8 == 0 && !(((uintptr_t)v | (uintptr_t)A | (uintptr_t)dx) & 15)) {
+        const int tiles = ((M + BM - 1) / BM) * ((in + BN - 1) / BN);
+        const int pi = vlr_prof_begin(1, 2.0 * M * in * r, stream);
+        hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), dim3(tiles), dim3(256), 0, stream, g);
+        vlr_prof_end(pi, stream);
+        return vlr_check_launch("vlr_gemm_dropout_acc(128)");
+    }
+    if (mode && vlr_gemm256p_dropacc_try_launch(g, stream)) return vlr_check_launch("vlr_gemm_dropout_acc(fused)");
     int rc = gemm_impl(1, v, A, scratch, nullptr, nullptr, M, in, r, ldv, in, in, 0, 0, 0, 0, 1.0f, stream);
     if (rc != VLR_OK) return rc;
     return vlr_dropout(scratch, dx, (long)M * in, p, seed, scale, 1, stream);
