@@ -181,6 +181,7 @@ def main():
                     help="llava_next: variant on BASELINE.json configs[3] (LLaVA-Next-Mistral-7B, anyres 672x672 image, DDPO); not the headline line")
     ap.add_argument("--loss_type", default=None)
     ap.add_argument("--dry_run_launch", action="store_true", help="CPU test of the self-launch path: no model, gloo, no-op steps")
+    ap.add_argument("--gradient_checkpointing", action="store_true", help="variant: keep only the layer inputs, re-run each layer's forward in the backward (reference scripts' --gradient_checkpointing True)")
     ap.add_argument("--lr", type=float, default=2e-8, help="learning rate of the timed steps (kernel arithmetic does not depend on it)")
     a = ap.parse_args()
 
@@ -225,6 +226,7 @@ def main():
     ref = init_hashed_qwen(model, seed=0, std=0.02, policy_delta=1e-3, with_reference=not a.lora) if qwen else \
         init_random_model(model, seed=0, std=0.02, policy_delta=1e-3)
     eng = model.engine
+    eng.gradient_checkpointing = bool(a.gradient_checkpointing)
     args = SimpleNamespace(gradient_accumulation_steps=1)
     if a.lora:
         del ref
@@ -350,7 +352,8 @@ def main():
                                       "one reference forward per step" + (", issued for the next batch under the update (prefetch_reference)" if tr.ref_pipeline else ", inside the step")),
                        "global_batch_pairs": world * a.pairs, "text_len": a.text_len, "parallelism": f"dp{world}",
                        "layers": cfg["layers"], "lr": a.lr, "resident_batches": len(batches), "loss_first_step": loss_first,
-                       "loss_last_step": loss_last, "grad_norm_last_step": float(eng.norm_out[0])},
+                       "loss_last_step": loss_last, "grad_norm_last_step": float(eng.norm_out[0]),
+                       "residual_stream": "fp32" if eng.resid_f32 else "bf16", "gradient_checkpointing": bool(eng.gradient_checkpointing)},
             "rccl_ranks": dist.get_world_size() if world > 1 else 1,
             "comm": {"transport": reducer.transport if reducer is not None else None,
                      "library": (reducer.transport_note if reducer is not None and reducer.transport == "native" else

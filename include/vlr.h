@@ -45,6 +45,11 @@ int vlr_gemm_bf16(int layout, const void* A, const void* B, void* C, const void*
 int vlr_gemm_bf16_scaled(int layout, const void* A, const void* B, void* C, const void* bias, const void* residual, int M,
                          int N, int K, int lda, int ldb, int ldc, int ldr, int act, int accumulate, int out_f32,
                          float alpha, vlr_stream_t stream);
+/* fp32 residual stream (vlr_llama_cfg.resid_f32): C fp32 [M][ldc] = A . B (layout as above) + residual fp32 [M][ldr] (NULL: none);
+ * in place (C == residual) is allowed.  Replaces the `hidden_states = residual + hidden_states` adds of transformers
+ * LlamaDecoderLayer.forward (call site src/vlrlhf/models/Llava/__init__.py:232) without the bf16 rounding of the sum. */
+int vlr_gemm_bf16_f32res(int layout, const void* A, const void* B, float* C, const float* residual, int M, int N, int K,
+                         int lda, int ldb, int ldc, int ldr, vlr_stream_t stream);
 /* Optional fp32 scratch for split-K: problems with few output tiles and a long reduction (the LoRA adapter gradients;
  * the ragged last tile rows of the decoder GEMMs) are split along K into fp32 partials and reduced by a second kernel
  * that applies the epilogue.  Without it they run un-split.  The buffer is cut in 64 MiB slots (covers the 7B shapes; at most
@@ -88,6 +93,9 @@ int vlr_gemm_dropout_acc(const void* v, int ldv, const void* A, void* dx, void* 
                          uint64_t seed, float scale, vlr_stream_t stream);
 int vlr_gemm_lora(const void* x, int ldx, const void* W, void* y, int ldy, const void* residual, int ldr, int M, int N, int K,
                   const void* u, int ldu, const void* Bl, int r, vlr_stream_t stream);
+/*  vlr_gemm_lora_f32res  : the same on the fp32 residual stream - y fp32 [M][ldy] = x W^T + u Bl^T + residual fp32 [M][ldr] */
+int vlr_gemm_lora_f32res(const void* x, int ldx, const void* W, float* y, int ldy, const float* residual, int ldr, int M, int N, int K,
+                         const void* u, int ldu, const void* Bl, int r, vlr_stream_t stream);
 int vlr_gemm_swiglu_lora(const void* x, const void* wgu, void* gu, void* act, int M, int I, int K, int ldx, const void* u, int ldu,
                          const void* Bl, int r, vlr_stream_t stream);
 int vlr_gemm_qkv_rope_lora(const void* x, const void* wqkv, const void* bias, void* qkv, const int* pos, const float* cos_t,
@@ -97,9 +105,14 @@ int vlr_gemm_qkv_rope_lora(const void* x, const void* wqkv, const void* bias, vo
 /* ---- normalisation / activations (transformers LlamaRMSNorm, CLIP LayerNorm, SwiGLU, GELU; call sites
  *      Llava/__init__.py:178-191,232) ------------------------------------------------------------------------- */
 int vlr_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int M, int H, float eps, vlr_stream_t stream);
+/* x fp32 [M][H] (fp32 residual stream); y bf16 */
+int vlr_rmsnorm_fwd_f32(const float* x, const void* w, void* y, float* rstd, int M, int H, float eps, vlr_stream_t stream);
 int vlr_rmsnorm_bwd_workspace_bytes(int H);
 int vlr_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
                     void* dw, int dw_accumulate, void* workspace, int M, int H, vlr_stream_t stream);
+/* the same with the forward input x in fp32; dy / dres / dx (the gradient stream) are bf16 */
+int vlr_rmsnorm_bwd_f32(const void* dy, const float* x, const void* w, const float* rstd, const void* dres, void* dx,
+                        void* dw, int dw_accumulate, void* workspace, int M, int H, vlr_stream_t stream);
 int vlr_layernorm_fwd(const void* x, const void* w, const void* b, void* y, int M, int D, float eps, vlr_stream_t stream);
 /* backward of y = LayerNorm(x) * w + b (Qwen-VL resampler: ln_q / ln_kv / ln_post, QwenVL/visual.py:122-123,391): mean and rstd are
  * recomputed from x; dx may be NULL, dw / db (bf16 [D], `accumulate`: +=) may be NULL; workspace = vlr_layernorm_bwd_workspace_bytes(D) */
@@ -216,6 +229,11 @@ typedef struct {
     const float* rope_cos;  /* [max_pos][head_dim/2] */
     const float* rope_sin;
     int kv_heads;           /* grouped-query attention (Mistral, InternLM2): K/V heads, a divisor of heads; 0 = heads */
+    int resid_f32;          /* 1: the residual stream (x_in, acts.x_mid, acts.x_out) is fp32 [M][hidden] - never rounded to bf16; the
+                             * norms read it in fp32, o_proj / down_proj add their fp32 accumulators to it (vlr_gemm_bf16_f32res).
+                             * HF runs the bf16 checkpoint's residual adds in bf16 (transformers LlamaDecoderLayer.forward); this mode
+                             * is what brings the 32-layer loss within north_star's tolerance of the fp32 reference.  The gradient
+                             * stream (dx_out / dx_in) stays bf16.  0: bf16 stream (ABI v3 behaviour) */
 } vlr_llama_cfg;
 /* Shapes with Nq = heads*head_dim, Nkv = kv_heads*head_dim: wqkv [Nq + 2 Nkv][hidden] (q | k | v rows), wo [hidden][Nq],
  * qkv / dqkv activations [M][Nq + 2 Nkv], attn / dattn [M][Nq].  hidden == Nq for LLaMA / Mistral. */

@@ -29,7 +29,7 @@ CASES = {
     "small": dict(pairs=1, text_len=128, seed=11, ragged=True),
     "configs0": dict(pairs=4, text_len=256, seed=12, ragged=True),
 }
-ALL = frozenset(("w", "vit", "x0", "xn", "qkv", "rope", "p", "attn", "resid", "gu", "act", "hidden"))
+ALL = frozenset(("w", "vit", "x0", "xn", "qkv", "v", "rope", "p", "attn", "resid", "gu", "act", "hidden"))
 MFMA_OPERANDS = frozenset(("w", "xn", "rope", "p", "attn", "act", "hidden"))      # what any bf16-MFMA pipeline must round
 VARIANTS = [
     ("fp32", False, "reference-exact arithmetic (bf16-representable weights)"),
@@ -40,6 +40,7 @@ VARIANTS = [
     ("only_gemm_out", frozenset(("qkv", "gu")), "q/k/v and gate/up GEMM outputs only (storage choice)"),
     ("only_vit", frozenset(("vit",)), "vision tower + projector only"),
     ("mfma_operands", MFMA_OPERANDS, "only the operands of the MFMAs (xn, rope'd q/k, P, attn, act, hidden): floor of ANY bf16-MFMA path"),
+    ("hip_f32resid", MFMA_OPERANDS | {"vit", "v"}, "what the HIP path rounds with the fp32 residual stream (round 3): MFMA operands + v + the vision tower"),
     ("mfma_operands-hidden", MFMA_OPERANDS - {"hidden"}, "the floor if the lm-head consumed an unrounded hidden state"),
 ]
 
@@ -178,7 +179,7 @@ def main():
             dl = max(abs(a - b) for k in ("policy_chosen_logps", "policy_rejected_logps", "reference_chosen_logps", "reference_rejected_logps")
                      for a, b in zip(r[k], out["fp32"][k]))
             lines.append(f"{name:24s} {r['loss']:11.7f} {d:12.3e} {d / abs(ref):9.2e}   {dl:12.4f}   {r['what']}")
-        with open(os.path.join(ROOT, "profiles", f"r02_bf16_error_budget_L{layers}.txt"), "w") as f:
+        with open(os.path.join(ROOT, "profiles", f"r03_bf16_error_budget_L{layers}.txt"), "w") as f:
             f.write("\n".join(lines) + "\n")
         log("\n".join(lines))
 

@@ -40,7 +40,7 @@ CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 def _rt(x, on, tag=None):
     """bf16 round trip.  `on`: False (fp32, reference-exact), True (every tensor the HIP path stores as bf16), or a set of
     rounding-point tags (error-budget runs, oracle/depth_parity.py): only tensors whose tag is in the set are rounded.
-    Tags of the decoder: x0 xn qkv rope p attn resid gu act hidden; "w" weights; "vit" the whole vision tower +
+    Tags of the decoder: x0 xn qkv v rope p attn resid gu act hidden; "w" weights; "vit" the whole vision tower +
     projector.  "p" (softmax probabilities, the A operand of the P.V MFMA) is rounded only when named explicitly."""
     if isinstance(on, (set, frozenset)):
         on = tag in on
@@ -338,6 +338,7 @@ def llama_hidden(embeds, attention_mask, position_ids, W, cfg, emulate_bf16=Fals
         v = r(h @ r(W[p + "self_attn.v_proj.weight"], "w").t(), "qkv")
         if lora is not None:
             q, k, v = (r(y + lora_delta(h, lora, i, t, r), "qkv") for y, t in ((q, "q_proj"), (k, "k_proj"), (v, "v_proj")))
+        v = r(v, "v")          # tag "v": the value projection alone (an MFMA operand as stored; q / k are operands only after RoPE)
         q = q.reshape(B, S, nh, hd).transpose(1, 2)
         k, v = (t.reshape(B, S, nkv, hd).transpose(1, 2) for t in (k, v))
         q, k = r(apply_rope(q, cos, sin), "rope"), r(apply_rope(k, cos, sin), "rope")

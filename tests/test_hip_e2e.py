@@ -473,6 +473,36 @@ def test_step_is_bit_reproducible(gpu):
     assert float(emb.float().abs().sum()) > 0
 
 
+@pytest.mark.parametrize("lora", [False, True])
+def test_gradient_checkpointing_is_bit_identical(gpu, lora):
+    """--gradient_checkpointing True (reference dpo.py:99, every shipped script): the engine keeps only the layer inputs and re-runs each
+    layer's forward before its backward - loss and EVERY gradient bit-identical to the run that keeps all activations (LoRA: with
+    lora_dropout, whose counter-based masks the recompute regenerates)."""
+    z, cfg, W, W_ref, batch, rows = load_case("llava_hipsmall")
+    outs = []
+    for ckpt in (False, True):
+        model, ref = build(cfg, W, W_ref)
+        kw = dict(peft_config=dict(PEFT, lora_dropout=0.25, seed=5)) if lora else {}
+        tr = make_trainer(model, None if lora else ref, cfg, **kw)
+        if lora:
+            for k, t in model.engine.lv.items():          # peft init has B = 0: give the adapters something to do
+                if ".b_" in k:
+                    t.copy_(torch.randn(t.shape, generator=torch.Generator().manual_seed(len(k))).mul(0.02))
+        if ckpt:
+            model.gradient_checkpointing_enable()
+        assert model.is_gradient_checkpointing == ckpt
+        model.train()
+        loss = tr.training_step(model, batch)
+        torch.cuda.synchronize()
+        g = model.engine.lora_grads if lora else model.engine.grads
+        outs.append((float(loss), g.clone()))
+        if ckpt:          # the per-layer activation sets were never allocated
+            assert not any(isinstance(k, tuple) and len(k) == 4 and k[0] == "policy" and isinstance(k[1], int) for k in model.engine._ws)
+    assert outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][1].float().abs().sum()) > 0
+
+
 def _shifted(batch, k):
     """a second / third batch of the same shapes: the text tail tokens rotated by k"""
     b = dict(batch)

@@ -1038,3 +1038,145 @@ def test_lmhead_logps_fused(hip, shape, average):
     ref_dl = coef[:, None] * (torch.nn.functional.one_hot(tgt.long(), V).float() - torch.softmax(logits, -1))
     check(dl, ref_dl, 8e-3, f"lm-head d logits {shape}")
     assert torch.isfinite(dl.float()).all()
+
+
+# ---------------------------------------------------------------------------------------------------- fp32 residual stream (ABI v4)
+@pytest.mark.parametrize("M,H", [(37, 256), (513, 4096)])
+def test_rmsnorm_f32_stream(hip, M, H):
+    """vlr_rmsnorm_fwd_f32 / _bwd_f32: x is the fp32 residual stream (values that are NOT bf16-representable), y / gradients bf16."""
+    x = rnd(M, H, seed=1, dtype=torch.float32) * (1 + 1e-3 * rnd(M, H, seed=7, dtype=torch.float32))
+    w, dy, dres = (1 + 0.1 * rnd(H, seed=2).float()).bfloat16(), rnd(M, H, seed=3), rnd(M, H, seed=4)
+    y = torch.empty(M, H, dtype=torch.bfloat16, device=DEV)
+    rstd = torch.empty(M, dtype=torch.float32, device=DEV)
+    hip.call("vlr_rmsnorm_fwd_f32", x, w, y, rstd, M, H, 1e-5)
+    xf = x.clone().requires_grad_(True)
+    wf = w.float().requires_grad_(True)
+    ref = O.rms_norm(xf, wf, 1e-5)
+    torch.cuda.synchronize()
+    check(y, ref, 5e-3, "rmsnorm fwd f32")
+    check(rstd, torch.rsqrt(x.pow(2).mean(-1) + 1e-5), 1e-5, "rstd f32")
+    (ref * dy.float()).sum().backward()
+    ws = torch.empty(hip.helper("vlr_rmsnorm_bwd_workspace_bytes", H), dtype=torch.uint8, device=DEV)
+    dx = torch.empty(M, H, dtype=torch.bfloat16, device=DEV)
+    dw = torch.empty(H, dtype=torch.bfloat16, device=DEV)
+    hip.call("vlr_rmsnorm_bwd_f32", dy, x, w, rstd, dres, dx, dw, 0, ws, M, H)
+    torch.cuda.synchronize()
+    check(dx, xf.grad + dres.float(), 8e-3, "rmsnorm dx f32")
+    check(dw, wf.grad, 8e-3, "rmsnorm dw f32")
+
+
+# small: 128x128 kernel; (2048, 4096): 128 tiles of 256^2 -> per-tile kernel, fp32 patches; big ones: persistent continuous pipeline
+# with the register-direct fp32 epilogue, a peeled tail on the split-K path (12792 rows), ragged N
+F32RES_SHAPES = [(300, 264, 136), (2048, 4096, 1024), (12792, 4096, 512), (8200, 4360, 320)]
+
+
+@pytest.mark.parametrize("inplace", [False, True])
+@pytest.mark.parametrize("shape", F32RES_SHAPES)
+def test_gemm_f32res(hip, shape, inplace):
+    """vlr_gemm_bf16_f32res: C fp32 = A B^T + residual fp32 - bf16 x bf16 products are exact in fp32, so the result matches the fp32
+    reference to accumulation-order noise (nothing is rounded to bf16)."""
+    M, N, K = shape
+    a, b = rnd(M, K, seed=1, scale=0.3), rnd(N, K, seed=2, scale=0.3)
+    res = rnd(M, N, seed=3, dtype=torch.float32) * 1.001
+    ref = a.float() @ b.float().t() + res
+    c = res.clone() if inplace else torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+    hip.call("vlr_gemm_bf16_f32res", 0, a, b, c, c if inplace else res, M, N, K, K, K, N, N)
+    torch.cuda.synchronize()
+    check(c, ref, 2e-5, f"gemm f32res {shape} inplace={inplace}")
+    if not inplace:                      # no residual
+        hip.call("vlr_gemm_bf16_f32res", 0, a, b, c, None, M, N, K, K, K, N, 0)
+        torch.cuda.synchronize()
+        check(c, a.float() @ b.float().t(), 2e-5, f"gemm f32 out {shape}")
+
+
+@pytest.mark.parametrize("shape", [(4352, 4352, 512, 128), (12792, 4096, 256, 64), (300, 256, 128, 16)])
+def test_gemm_lora_f32res(hip, shape):
+    """vlr_gemm_lora_f32res: y fp32 = x W^T + u Bl^T + residual fp32 (adapter segment in the K loop on the big shapes)"""
+    M, N, K, r = shape
+    x, W = rnd(M, K, seed=1), rnd(N, K, scale=0.05, seed=2)
+    ldu = 7 * r
+    ubuf = rnd(M, ldu, scale=0.5, seed=3)
+    u = ubuf[:, 3 * r:4 * r]
+    Bl = rnd(N, r, scale=0.05, seed=4)
+    resid = rnd(M, N, seed=5, dtype=torch.float32) * 1.001
+    ref = _blockdiag_add(x.float() @ W.float().t(), u, Bl, r, [N]) + resid
+    y = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+    hip.call("vlr_gemm_lora_f32res", x, K, W, y, N, resid, N, M, N, K, u, ldu, Bl, r)
+    torch.cuda.synchronize()
+    check(y, ref, 2e-5, f"gemm_lora_f32res {shape}")
+
+
+def test_decoder_layer_f32_stream(hip):
+    """vlr_decoder_layer_fwd / _bwd with vlr_llama_cfg.resid_f32 = 1: the stream enters and leaves in fp32; against the oracle that
+    rounds only what this path rounds (MFMA operands), and fp32 autograd for the gradients."""
+    from vlrlhf import _hip as HH
+    B, S, nh, hd, I = 2, 70, 2, 128, 384
+    H = nh * hd
+    M = B * S
+    cfgo = dict(hidden=H, inter=I, layers=1, heads=nh, vocab=8, rms_eps=1e-5)
+    g = torch.Generator().manual_seed(0)
+    W = {}
+    p = "language_model.model.layers.0."
+    for nm, shp in (("self_attn.q_proj", (H, H)), ("self_attn.k_proj", (H, H)), ("self_attn.v_proj", (H, H)),
+                    ("self_attn.o_proj", (H, H)), ("mlp.gate_proj", (I, H)), ("mlp.up_proj", (I, H)), ("mlp.down_proj", (H, I))):
+        W[p + nm + ".weight"] = (torch.randn(*shp, generator=g) * 0.05).bfloat16().float()
+    W[p + "input_layernorm.weight"] = (1 + 0.1 * torch.randn(H, generator=g)).bfloat16().float()
+    W[p + "post_attention_layernorm.weight"] = (1 + 0.1 * torch.randn(H, generator=g)).bfloat16().float()
+    W["language_model.model.norm.weight"] = torch.ones(H)
+    x = torch.randn(B, S, H, generator=g)                       # fp32 stream: not bf16-representable
+    am = torch.ones(B, S, dtype=torch.long)
+    am[1, S - 6:] = 0
+    pos = (am.cumsum(-1) - 1).masked_fill(am == 0, 1)
+    dy = torch.randn(B, S, H, generator=g).bfloat16().float()
+    dy[am == 0] = 0
+    leaves = {k: v.clone().requires_grad_(True) for k, v in W.items()}
+    xg = x.clone().requires_grad_(True)
+    col = []
+    O.llama_hidden(xg, am, pos, leaves, cfgo, emulate_bf16=False, collect=col)
+    (col[0] * dy).sum().backward()
+    col16 = []
+    with torch.no_grad():
+        O.llama_hidden(x, am, pos, W, cfgo, emulate_bf16=frozenset(("w", "xn", "rope", "v", "p", "attn", "act", "hidden")), collect=col16)
+
+    def dv(t, dt=torch.bfloat16):
+        return t.to(dt).to(DEV).contiguous()
+
+    wqkv = dv(torch.cat([W[p + f"self_attn.{n}_proj.weight"] for n in "qkv"], 0))
+    wgu = dv(torch.cat([W[p + "mlp.gate_proj.weight"], W[p + "mlp.up_proj.weight"]], 0))
+    wo, wdown = dv(W[p + "self_attn.o_proj.weight"]), dv(W[p + "mlp.down_proj.weight"])
+    ln1, ln2 = dv(W[p + "input_layernorm.weight"]), dv(W[p + "post_attention_layernorm.weight"])
+    cos_t = torch.empty(256, hd // 2, device=DEV)
+    sin_t = torch.empty_like(cos_t)
+    hip.call("vlr_rope_table", cos_t, sin_t, 256, hd, 10000.0)
+    cfg = HH.LlamaCfg(H, I, nh, hd, 1e-5, 256, cos_t.data_ptr(), sin_t.data_ptr(), 0, 1)
+    lw = HH.LayerWeights(*(t.data_ptr() for t in (ln1, wqkv, wo, ln2, wgu, wdown)))
+    Sp = (S + 63) // 64 * 64
+    f32 = ("rstd1", "rstd2", "lse", "x_mid", "x_out")
+    shapes = dict(xn1=(M, H), rstd1=(M,), qkv=(M, 3 * H), attn=(M, H), lse=(B, nh, Sp), x_mid=(M, H), xn2=(M, H), rstd2=(M,), gu=(M, 2 * I),
+                  act=(M, I), x_out=(M, H))
+    bufs = {k: torch.zeros(*s, dtype=torch.float32 if k in f32 else torch.bfloat16, device=DEV) for k, s in shapes.items()}
+    la = HH.LayerActs(*(bufs[k].data_ptr() for k in ("xn1", "rstd1", "qkv", "attn", "lse", "x_mid", "xn2", "rstd2", "gu", "act", "x_out")))
+    xin = dv(x.reshape(M, H), torch.float32)
+    posd = pos.to(torch.int32).to(DEV)
+    kmd = am.to(torch.int32).to(DEV)
+    hip.call("vlr_decoder_layer_fwd", cfg, lw, la, xin, posd, kmd, B, S)
+    torch.cuda.synchronize()
+    valid = (am.reshape(-1) != 0)
+    e_emu = relerr(bufs["x_out"].cpu()[valid], col16[0].reshape(M, H)[valid])
+    e_f32 = relerr(bufs["x_out"].cpu()[valid], col[0].detach().reshape(M, H)[valid])
+    assert e_emu < 4e-3 and e_f32 < 6e-3, (e_emu, e_f32)       # the bf16 stream sits at 1-2e-2 here (test_decoder_layer_fwd_bwd_vs_oracle)
+    grads = {k: torch.full_like(t, float("nan")) for k, t in dict(ln1=ln1, wqkv=wqkv, wo=wo, ln2=ln2, wgu=wgu, wdown=wdown).items()}
+    lg = HH.LayerGrads(*(grads[k].data_ptr() for k in ("ln1", "wqkv", "wo", "ln2", "wgu", "wdown")))
+    wsb = {k: torch.empty(*s, dtype=torch.bfloat16, device=DEV) for k, s in dict(dact=(M, I), dxn=(M, H), dattn=(M, H), dqkv=(M, 3 * H), dx_mid=(M, H)).items()}
+    delta = torch.zeros(B, nh, Sp, dtype=torch.float32, device=DEV)
+    nws = torch.empty(hip.helper("vlr_rmsnorm_bwd_workspace_bytes", H), dtype=torch.uint8, device=DEV)
+    lws = HH.LayerBwdWs(wsb["dact"].data_ptr(), wsb["dxn"].data_ptr(), wsb["dattn"].data_ptr(), wsb["dqkv"].data_ptr(),
+                        wsb["dx_mid"].data_ptr(), delta.data_ptr(), nws.data_ptr())
+    dxin = torch.empty(M, H, dtype=torch.bfloat16, device=DEV)
+    hip.call("vlr_decoder_layer_bwd", cfg, lw, lg, 0, la, lws, xin, dv(dy.reshape(M, H)), dxin, posd, kmd, B, S)
+    torch.cuda.synchronize()
+    check(dxin.cpu()[valid], xg.grad.reshape(M, H)[valid], 4e-2, "layer dx (f32 stream)")
+    gq = torch.cat([leaves[p + f"self_attn.{n}_proj.weight"].grad for n in "qkv"], 0)
+    check(grads["wqkv"].cpu(), gq, 4e-2, "dWqkv (f32 stream)")
+    check(grads["wdown"].cpu(), leaves[p + "mlp.down_proj.weight"].grad, 4e-2, "dWdown (f32 stream)")
+    check(grads["ln2"].cpu(), leaves[p + "post_attention_layernorm.weight"].grad, 4e-2, "dln2 (f32 stream)")

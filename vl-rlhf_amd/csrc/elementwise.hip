@@ -6,16 +6,24 @@
 // ------------------------------------------------------------------------------------------------------------
 // RMSNorm forward: y = w * x * rsqrt(mean(x^2) + eps); one workgroup per row.  (LlamaRMSNorm, fp32 internal)
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+// eight consecutive elements of a bf16 or an fp32 row (the residual stream is fp32 when vlr_llama_cfg::resid_f32 is set)
+__device__ __forceinline__ void load8(const bf16_t* p, float* v) { unpack8(*reinterpret_cast<const u32x4*>(p), v); }
+__device__ __forceinline__ void load8(const float* p, float* v) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+}
+template <typename XT>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const XT* __restrict__ x, const bf16_t* __restrict__ w,
                                                           bf16_t* __restrict__ y, float* __restrict__ rstd_out, int H,
                                                           float eps) {
     __shared__ float red[16];
     const size_t row = blockIdx.x;
-    const bf16_t* xr = x + row * H;
+    const XT* xr = x + row * H;
     float ss = 0.f;
     for (int c = threadIdx.x * 8; c < H; c += 256 * 8) {
         float v[8];
-        unpack8(*reinterpret_cast<const u32x4*>(xr + c), v);
+        load8(xr + c, v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
     }
@@ -24,7 +32,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
     if (threadIdx.x == 0 && rstd_out) rstd_out[row] = rstd;
     for (int c = threadIdx.x * 8; c < H; c += 256 * 8) {
         float v[8], g[8];
-        unpack8(*reinterpret_cast<const u32x4*>(xr + c), v);
+        load8(xr + c, v);
         unpack8(*reinterpret_cast<const u32x4*>(w + c), g);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = g[e] * (v[e] * rstd);
@@ -34,7 +42,8 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
 
 // RMSNorm backward.  dx = rstd * (dy*w - xhat * mean(dy*w*xhat)) (+ dres), dw partial[j] += dy*xhat.
 // Workgroup b walks rows b, b+G, ...; its dw partial goes to dw_part[b][H] (reduced by reduce_partials_kernel).
-__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+template <typename XT>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const XT* __restrict__ x,
                                                           const bf16_t* __restrict__ w, const float* __restrict__ rstd,
                                                           const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
                                                           float* __restrict__ dw_part, int M, int H) {
@@ -56,7 +65,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
             if (c < H) {
                 float a[8], b[8], g[8];
                 unpack8(*reinterpret_cast<const u32x4*>(dy + off + c), a);
-                unpack8(*reinterpret_cast<const u32x4*>(x + off + c), b);
+                load8(x + off + c, b);
                 unpack8(*reinterpret_cast<const u32x4*>(w + c), g);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -541,9 +550,16 @@ static inline int grid_for(long n, int per_block, int cap = 256 * 16) {
 extern "C" int vlr_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int M, int H, float eps,
                                hipStream_t st) {
     VLR_REQUIRE(M > 0 && H > 0 && H % 8 == 0, "vlr_rmsnorm_fwd: bad shape M=%d H=%d", M, H);
-    hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(M), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y,
+    hipLaunchKernelGGL(rmsnorm_fwd_kernel<bf16_t>, dim3(M), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y,
                        rstd, H, eps);
     return vlr_check_launch("vlr_rmsnorm_fwd");
+}
+// the same on an fp32 residual stream x [M][H]: y stays bf16 (the A operand of the projection that follows), rounded once
+extern "C" int vlr_rmsnorm_fwd_f32(const float* x, const void* w, void* y, float* rstd, int M, int H, float eps, hipStream_t st) {
+    VLR_REQUIRE(x && w && y, "vlr_rmsnorm_fwd_f32: null argument");
+    VLR_REQUIRE(M > 0 && H > 0 && H % 8 == 0, "vlr_rmsnorm_fwd_f32: bad shape M=%d H=%d", M, H);
+    hipLaunchKernelGGL(rmsnorm_fwd_kernel<float>, dim3(M), dim3(256), 0, st, x, (const bf16_t*)w, (bf16_t*)y, rstd, H, eps);
+    return vlr_check_launch("vlr_rmsnorm_fwd_f32");
 }
 
 // 1024 workgroups (4 per CU) keep enough loads in flight for an HBM-bound pass; their dw partials are reduced in two
@@ -552,13 +568,29 @@ extern "C" int vlr_rmsnorm_fwd(const void* x, const void* w, void* y, float* rst
 #define VLR_NORM_BWD_STAGE2 16
 extern "C" int vlr_rmsnorm_bwd_workspace_bytes(int H) { return (VLR_NORM_BWD_BLOCKS + VLR_NORM_BWD_STAGE2) * H * 4; }
 
+static int rmsnorm_bwd_impl(const void* dy, const void* x, int x_f32, const void* w, const float* rstd, const void* dres,
+                            void* dx, void* dw, int dw_accumulate, void* workspace, int M, int H, hipStream_t st);
 extern "C" int vlr_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres,
                                void* dx, void* dw, int dw_accumulate, void* workspace, int M, int H, hipStream_t st) {
+    return rmsnorm_bwd_impl(dy, x, 0, w, rstd, dres, dx, dw, dw_accumulate, workspace, M, H, st);
+}
+// the same with the forward input x kept in fp32 (fp32 residual stream); the gradient stream dy / dres / dx stays bf16
+extern "C" int vlr_rmsnorm_bwd_f32(const void* dy, const float* x, const void* w, const float* rstd, const void* dres,
+                                   void* dx, void* dw, int dw_accumulate, void* workspace, int M, int H, hipStream_t st) {
+    return rmsnorm_bwd_impl(dy, x, 1, w, rstd, dres, dx, dw, dw_accumulate, workspace, M, H, st);
+}
+static int rmsnorm_bwd_impl(const void* dy, const void* x, int x_f32, const void* w, const float* rstd, const void* dres,
+                            void* dx, void* dw, int dw_accumulate, void* workspace, int M, int H, hipStream_t st) {
+    VLR_REQUIRE(dy && x && w && rstd && dx, "vlr_rmsnorm_bwd: null argument");
     VLR_REQUIRE(M > 0 && H % 8 == 0 && H <= 8192, "vlr_rmsnorm_bwd: bad shape M=%d H=%d (H<=8192)", M, H);
     VLR_REQUIRE(workspace, "vlr_rmsnorm_bwd: workspace of vlr_rmsnorm_bwd_workspace_bytes(H) required");
     const int G = M < VLR_NORM_BWD_BLOCKS ? M : VLR_NORM_BWD_BLOCKS;
-    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(G), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x,
-                       (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, (float*)workspace, M, H);
+    if (x_f32)
+        hipLaunchKernelGGL(rmsnorm_bwd_kernel<float>, dim3(G), dim3(256), 0, st, (const bf16_t*)dy, (const float*)x,
+                           (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, (float*)workspace, M, H);
+    else
+        hipLaunchKernelGGL(rmsnorm_bwd_kernel<bf16_t>, dim3(G), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x,
+                           (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, (float*)workspace, M, H);
     if (dw) {
         float* part2 = (float*)workspace + (size_t)VLR_NORM_BWD_BLOCKS * H;
         const int S2 = G < VLR_NORM_BWD_STAGE2 ? 1 : VLR_NORM_BWD_STAGE2;

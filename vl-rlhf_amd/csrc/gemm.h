@@ -9,7 +9,7 @@ struct GemmParams {
     const bf16_t* B;
     void* C;
     const bf16_t* bias;      // [N] or null
-    const bf16_t* residual;  // [M,N] ld = ldr, or null
+    const bf16_t* residual;  // [M,N] ld = ldr, or null (res_f32: an fp32 tensor behind the same pointer, ldr in floats)
     int M, N, K;
     int lda, ldb, ldc, ldr;
     int act;
@@ -59,6 +59,9 @@ struct GemmParams {
     uint64_t drop_key;
     uint32_t drop_thr;
     int drop_ld;
+    // ---- fp32 residual stream (vlr_llama_cfg::resid_f32): residual is read as fp32 [M][ldr]; with out_f32 the o_proj / down_proj
+    // launches are C fp32 = acc + residual fp32 (no rounding of the stream at all)
+    int res_f32;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {

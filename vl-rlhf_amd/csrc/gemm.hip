@@ -245,8 +245,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = apply_act(p.alpha * v[e] + bv[e], p.act);
                 if (p.residual) {
-                    const u32x2 w = *reinterpret_cast<const u32x2*>(p.residual + (size_t)gm * p.ldr + gn);
-                    v[0] += bf16lo(w[0]); v[1] += bf16hi(w[0]); v[2] += bf16lo(w[1]); v[3] += bf16hi(w[1]);
+                    if (p.res_f32) {
+                        v += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.residual) + (size_t)gm * p.ldr + gn);
+                    } else {
+                        const u32x2 w = *reinterpret_cast<const u32x2*>(p.residual + (size_t)gm * p.ldr + gn);
+                        v[0] += bf16lo(w[0]); v[1] += bf16hi(w[0]); v[2] += bf16lo(w[1]); v[3] += bf16hi(w[1]);
+                    }
                 }
                 float* dst = C + (size_t)gm * p.ldc + gn;
                 if (p.accumulate) {
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, int M, int N, void* Cv,
                                                             int ldc, int out_f32, int accumulate,
                                                             const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual,
-                                                            int ldr, int act) {
+                                                            int ldr, int act, int res_f32) {
     const long n4 = (long)M * N / 4;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         f32x4 v = *reinterpret_cast<const f32x4*>(part + i * 4);
@@ -283,8 +287,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
             for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act);
         }
         if (residual) {
-            const u32x2 w = *reinterpret_cast<const u32x2*>(residual + m * ldr + n);
-            v[0] += bf16lo(w[0]); v[1] += bf16hi(w[0]); v[2] += bf16lo(w[1]); v[3] += bf16hi(w[1]);
+            if (res_f32) {
+                v += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(residual) + m * ldr + n);
+            } else {
+                const u32x2 w = *reinterpret_cast<const u32x2*>(residual + m * ldr + n);
+                v[0] += bf16lo(w[0]); v[1] += bf16hi(w[0]); v[2] += bf16lo(w[1]); v[3] += bf16hi(w[1]);
+            }
         }
         if (out_f32) {
             float* dst = reinterpret_cast<float*>(Cv) + m * ldc + n;
@@ -365,13 +373,18 @@ static bool launch_splitk128(int layout, GemmParams p, hipStream_t stream, int m
     int rg = (int)((n4 + 255) / 256);
     if (rg > 2048) rg = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, stream, ws, splits, p.M, p.N, p.C, p.ldc, p.out_f32,
-                       p.accumulate, p.bias, p.residual, p.ldr, p.act);
+                       p.accumulate, p.bias, p.residual, p.ldr, p.act, p.res_f32);
     return true;
 }
 
+static int gemm_impl_ex(int layout, const void* A, const void* B, void* C, const void* bias, const void* residual, int M, int N,
+                        int K, int lda, int ldb, int ldc, int ldr, int act, int accumulate, int out_f32, float alpha, int res_f32,
+                        hipStream_t stream);
 static int gemm_impl(int layout, const void* A, const void* B, void* C, const void* bias, const void* residual, int M, int N,
                      int K, int lda, int ldb, int ldc, int ldr, int act, int accumulate, int out_f32, float alpha,
-                     hipStream_t stream);
+                     hipStream_t stream) {
+    return gemm_impl_ex(layout, A, B, C, bias, residual, M, N, K, lda, ldb, ldc, ldr, act, accumulate, out_f32, alpha, 0, stream);
+}
 
 // wave quantisation (see gemm_impl): how many of the last 256-row tile rows to peel off so that the 256x256-tile part is a
 // whole number of rounds on the 256 CUs; tn = workgroup tiles per tile row
@@ -405,9 +418,17 @@ extern "C" int vlr_gemm_bf16_scaled(int layout, const void* A, const void* B, vo
     return gemm_impl(layout, A, B, C, bias, residual, M, N, K, lda, ldb, ldc, ldr, act, accumulate, out_f32, alpha, stream);
 }
 
-static int gemm_impl(int layout, const void* A, const void* B, void* C, const void* bias, const void* residual, int M, int N,
-                     int K, int lda, int ldb, int ldc, int ldr, int act, int accumulate, int out_f32, float alpha,
-                     hipStream_t stream) {
+// fp32 residual stream (vlr_llama_cfg::resid_f32; o_proj / down_proj of the decoder layer): C fp32 [M][ldc] = A . B + residual
+// fp32 [M][ldr] (NULL: none) - the stream is never rounded.  Same layouts and dispatch as vlr_gemm_bf16.
+extern "C" int vlr_gemm_bf16_f32res(int layout, const void* A, const void* B, float* C, const float* residual, int M, int N, int K,
+                                    int lda, int ldb, int ldc, int ldr, hipStream_t stream) {
+    return gemm_impl_ex(layout, A, B, C, nullptr, residual, M, N, K, lda, ldb, ldc, ldr, 0, 0, 1, 1.0f, 1, stream);
+}
+
+static int gemm_impl_ex(int layout, const void* A, const void* B, void* C, const void* bias, const void* residual, int M, int N,
+                        int K, int lda, int ldb, int ldc, int ldr, int act, int accumulate, int out_f32, float alpha, int res_f32,
+                        hipStream_t stream) {
+    VLR_REQUIRE(!res_f32 || out_f32, "vlr_gemm_bf16: an fp32 residual needs an fp32 output");
     VLR_REQUIRE(layout >= 0 && layout <= 2, "vlr_gemm_bf16: layout must be 0 (NT), 1 (NN) or 2 (TN), got %d", layout);
     VLR_REQUIRE(M > 0 && N > 0 && K > 0, "vlr_gemm_bf16: empty problem M=%d N=%d K=%d", M, N, K);
     VLR_REQUIRE(A && B && C, "vlr_gemm_bf16: null operand");
@@ -433,6 +454,7 @@ static int gemm_impl(int layout, const void* A, const void* B, void* C, const vo
     p.fuse = 0; p.store_c = 1; p.C2 = nullptr; p.ldc2 = 0; p.pos = nullptr; p.rope_cos = p.rope_sin = nullptr; p.max_pos = 0; p.rope_cols = 0;
     p.f0 = p.f1 = nullptr;
     p.A2 = p.B2 = nullptr; p.lda2 = p.ldb2 = p.K2 = 0; p.seg_b0 = p.seg_b1 = 0x7fffffff; p.drop_key = 0; p.drop_thr = 0; p.drop_ld = 0;
+    p.res_f32 = residual ? res_f32 : 0;
     const int pi = vlr_prof_begin(layout, 2.0 * M * N * K, stream);
     // ---- split-K for problems whose output is a handful of tiles but whose reduction is long: the LoRA adapter gradients
     // (TN: dB = dy^T u [out x r], dA = v^T x [r x in], reduction over all tokens) - 32..96 workgroups would leave most CUs idle
@@ -462,7 +484,7 @@ static int gemm_impl(int layout, const void* A, const void* B, void* C, const vo
         const size_t esz = out_f32 ? 4 : 2;
         p2.A = layout == 2 ? p.A + M1 : p.A + (size_t)M1 * lda;
         p2.C = (char*)p.C + (size_t)M1 * ldc * esz;
-        if (p.residual) p2.residual = p.residual + (size_t)M1 * ldr;
+        if (p.residual) p2.residual = (const bf16_t*)((const char*)p.residual + (size_t)M1 * ldr * (p.res_f32 ? 4 : 2));
         if (vlr_gemm256p_try_launch(layout, p1, stream)) {
             const int t2 = ((p2.M + BM - 1) / BM) * ((N + BN - 1) / BN);
             // the peeled rows are few tiles with the full reduction depth (e.g. 504 x 4096 x 22016 = 128 tiles x 688 k-steps):
@@ -507,7 +529,7 @@ static GemmParams fused_params(const void* A, const void* B, void* C, int M, int
     p.act = 0; p.accumulate = 0; p.out_f32 = 0; p.flags = 0; p.alpha = 1.f; p.splitk = 1; p.kchunk = 0; p.part = nullptr;
     p.fuse = 0; p.store_c = 1; p.C2 = nullptr; p.ldc2 = 0; p.pos = nullptr; p.rope_cos = p.rope_sin = nullptr; p.max_pos = 0; p.rope_cols = 0;
     p.f0 = p.f1 = nullptr;
-    p.A2 = p.B2 = nullptr; p.lda2 = p.ldb2 = p.K2 = 0; p.seg_b0 = p.seg_b1 = 0x7fffffff; p.drop_key = 0; p.drop_thr = 0; p.drop_ld = 0;
+    p.A2 = p.B2 = nullptr; p.lda2 = p.ldb2 = p.K2 = 0; p.seg_b0 = p.seg_b1 = 0x7fffffff; p.drop_key = 0; p.drop_thr = 0; p.drop_ld = 0; p.res_f32 = 0;
     return p;
 }
 
@@ -520,14 +542,14 @@ static void seg_set(GemmParams& p, const SegArgs* sg) {
     p.seg_b0 = sg->b0; p.seg_b1 = sg->b1;
 }
 // rows [row0, row0 + Mr) that the segment kernel did not take: y[:, block t] += u_t Bl_t^T, one skinny GEMM per block
-static int seg_fallback_add(const SegArgs* sg, void* y, int ldy, int row0, int Mr, int N, hipStream_t stream) {
+static int seg_fallback_add(const SegArgs* sg, void* y, int ldy, int row0, int Mr, int N, hipStream_t stream, int y_f32 = 0) {
     if (!sg || !sg->u) return VLR_OK;
     const int bounds[4] = {0, sg->b0 < N ? sg->b0 : N, sg->b1 < N ? sg->b1 : N, N};
     for (int t = 0; t < 3; ++t) {
         const int lo = bounds[t], w = bounds[t + 1] - bounds[t];
         if (w <= 0) continue;
         int rc = gemm_impl(0, (const bf16_t*)sg->u + (size_t)row0 * sg->ldu + (size_t)t * sg->r, (const bf16_t*)sg->Bl + (size_t)lo * sg->r,
-                           (bf16_t*)y + (size_t)row0 * ldy + lo, nullptr, nullptr, Mr, w, sg->r, sg->ldu, sg->r, ldy, 0, 0, 1, 0, 1.0f, stream);
+                           (char*)y + ((size_t)row0 * ldy + lo) * (y_f32 ? 4 : 2), nullptr, nullptr, Mr, w, sg->r, sg->ldu, sg->r, ldy, 0, 0, 1, y_f32, 1.0f, stream);
         if (rc != VLR_OK) return rc;
     }
     return VLR_OK;
@@ -671,8 +693,19 @@ extern "C" int vlr_gemm_dropout_acc(const void* v, int ldv, const void* A, void*
 }
 
 // y [M][ldy] = x W^T + u Bl^T (+ residual): one adapted linear (o_proj, down_proj) with its LoRA adapter riding the K loop
+static int gemm_lora_impl(const void* x, int ldx, const void* W, void* y, int ldy, const void* residual, int ldr, int M, int N, int K,
+                          const void* u, int ldu, const void* Bl, int r, int f32, hipStream_t stream);
 extern "C" int vlr_gemm_lora(const void* x, int ldx, const void* W, void* y, int ldy, const void* residual, int ldr, int M, int N, int K,
                              const void* u, int ldu, const void* Bl, int r, hipStream_t stream) {
+    return gemm_lora_impl(x, ldx, W, y, ldy, residual, ldr, M, N, K, u, ldu, Bl, r, 0, stream);
+}
+// the same on the fp32 residual stream: y fp32 [M][ldy] = x W^T + u Bl^T + residual fp32 [M][ldr]
+extern "C" int vlr_gemm_lora_f32res(const void* x, int ldx, const void* W, float* y, int ldy, const float* residual, int ldr, int M, int N,
+                                    int K, const void* u, int ldu, const void* Bl, int r, hipStream_t stream) {
+    return gemm_lora_impl(x, ldx, W, y, ldy, residual, ldr, M, N, K, u, ldu, Bl, r, 1, stream);
+}
+static int gemm_lora_impl(const void* x, int ldx, const void* W, void* y, int ldy, const void* residual, int ldr, int M, int N, int K,
+                          const void* u, int ldu, const void* Bl, int r, int f32, hipStream_t stream) {
     VLR_REQUIRE(x && W && y && u && Bl, "vlr_gemm_lora: null operand");
     VLR_REQUIRE(M > 0 && N > 0 && K > 0 && N % 8 == 0 && K % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "vlr_gemm_lora: bad shape M=%d N=%d K=%d", M, N, K);
     const SegArgs sg = {u, ldu, Bl, r, 0x7fffffff, 0x7fffffff};
@@ -683,6 +716,7 @@ extern "C" int vlr_gemm_lora(const void* x, int ldx, const void* W, void* y, int
     const int M1 = peel ? (tm256 - peel) * 256 : M;
     GemmParams p = fused_params(x, W, y, M1, N, K, ldx, K, ldy);
     p.residual = (const bf16_t*)residual; p.ldr = ldr;
+    p.out_f32 = f32; p.res_f32 = (f32 && residual) ? 1 : 0;
     seg_set(p, &sg);
     int done = 0;
     if (vlr_gemm256p_seg_try_launch(p, stream)) {
@@ -691,10 +725,12 @@ extern "C" int vlr_gemm_lora(const void* x, int ldx, const void* W, void* y, int
         done = M1;
     }
     if (done < M) {
-        int rc = gemm_impl(0, (const bf16_t*)x + (size_t)done * ldx, W, (bf16_t*)y + (size_t)done * ldy, nullptr,
-                           residual ? (const bf16_t*)residual + (size_t)done * ldr : nullptr, M - done, N, K, ldx, K, ldy, ldr, 0, 0, 0, 1.0f, stream);
+        const size_t esz = f32 ? 4 : 2;
+        int rc = gemm_impl_ex(0, (const bf16_t*)x + (size_t)done * ldx, W, (char*)y + (size_t)done * ldy * esz, nullptr,
+                              residual ? (const char*)residual + (size_t)done * ldr * esz : nullptr, M - done, N, K, ldx, K, ldy, ldr, 0, 0, f32, 1.0f,
+                              f32, stream);
         if (rc != VLR_OK) return rc;
-        return seg_fallback_add(&sg, y, ldy, done, M - done, N, stream);
+        return seg_fallback_add(&sg, y, ldy, done, M - done, N, stream, f32);
     }
     return VLR_OK;
 }

@@ -704,6 +704,43 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                 }
             }
     } else if constexpr (CONT) {
+      if (p.out_f32) {
+        // fp32 output (fp32 residual stream: x_new = x + attn Wo^T / x + act Wdown^T): a lane's four consecutive columns are one
+        // 16-byte access - residual read and store straight from / to the accumulator layout, nothing is rounded.  The 16 residual
+        // loads of an A half are issued together (the fragment registers of the K loop are dead here), then added and stored.
+        float* C = reinterpret_cast<float*>(p.C);
+        const float* R = reinterpret_cast<const float*>(p.residual);
+        const int lm_ = lane & 15, lq_ = lane >> 4;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            f32x4 rv[4][2][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int gm = m0 + a * 128 + wr * 64 + i * 16 + lm_;
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int gn = n0 + b * 128 + wc * 32 + j * 16 + 4 * lq_;
+                        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                        if (R && gm < p.M && gn + 4 <= p.N) z = *reinterpret_cast<const f32x4*>(R + (size_t)gm * p.ldr + gn);
+                        rv[i][b][j] = z;
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int gm = m0 + a * 128 + wr * 64 + i * 16 + lm_;
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int gn = n0 + b * 128 + wc * 32 + j * 16 + 4 * lq_;
+                        const f32x4 v = p.alpha * acc[a][i][b][j] + rv[i][b][j];
+                        if (gm < p.M && gn + 4 <= p.N) *reinterpret_cast<f32x4*>(C + (size_t)gm * p.ldc + gn) = v;
+                    }
+            }
+        }
+      } else {
         // plain bf16 epilogue straight from the registers: lane (lm, lq) of tile (i, j) holds C[row lm][cols 4 lq .. +3]
         bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
         const int lm_ = lane & 15, lq_ = lane >> 4;
@@ -732,6 +769,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                     if (gm < p.M && gn + 8 <= p.N) *reinterpret_cast<u32x4*>(C + (size_t)gm * p.ldc + gn) = w;
                 }
             }
+      }
     }
     if constexpr (CONT) {
         parb = (parb + nt) & 1;
@@ -855,8 +893,12 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = apply_act(p.alpha * v[e] + bv[e], p.act);
                 if (p.residual) {
-                    const u32x2 w = *reinterpret_cast<const u32x2*>(p.residual + (size_t)gm * p.ldr + gn);
-                    v[0] += bf16lo(w[0]); v[1] += bf16hi(w[0]); v[2] += bf16lo(w[1]); v[3] += bf16hi(w[1]);
+                    if (p.res_f32) {
+                        v += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.residual) + (size_t)gm * p.ldr + gn);
+                    } else {
+                        const u32x2 w = *reinterpret_cast<const u32x2*>(p.residual + (size_t)gm * p.ldr + gn);
+                        v[0] += bf16lo(w[0]); v[1] += bf16hi(w[0]); v[2] += bf16lo(w[1]); v[3] += bf16hi(w[1]);
+                    }
                 }
                 float* dst = C + (size_t)gm * p.ldc + gn;
                 if (p.accumulate) {
@@ -951,9 +993,11 @@ bool vlr_gemm256p_seg_try_launch(const GemmParams& p, hipStream_t stream) {
     if (p.fuse == 2 && (p.N % PT != 0 || p.rope_cols % PT != 0)) return false;
     if (p.fuse == 1 && ((p.N >> 1) % 8 != 0 || p.ldc2 % 8 != 0 || ((uintptr_t)p.C2 & 15))) return false;
     if ((((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.C) & 15) || p.lda % 8 != 0 || p.ldb % 8 != 0 || p.ldc % 8 != 0 || p.N % 8 != 0) return false;
-    if ((p.bias && p.fuse != 2) || p.accumulate || p.out_f32 || p.act != ACT_NONE) return false;
+    if ((p.bias && p.fuse != 2) || p.accumulate || p.act != ACT_NONE) return false;
     if (p.bias && ((uintptr_t)p.bias & 7)) return false;
-    if (p.residual && (p.fuse != 0 || p.ldr % 4 != 0 || ((uintptr_t)p.residual & 7) || (const void*)p.residual == (const void*)p.C)) return false;
+    if (p.out_f32) {          // fp32 residual stream: y fp32 = x W^T + u Bl^T + residual fp32 (register-direct 16-byte accesses)
+        if (p.fuse != 0 || p.ldc % 4 != 0 || (p.residual && (!p.res_f32 || p.ldr % 4 != 0 || ((uintptr_t)p.residual & 15)))) return false;
+    } else if (p.residual && (p.res_f32 || p.fuse != 0 || p.ldr % 4 != 0 || ((uintptr_t)p.residual & 7) || (const void*)p.residual == (const void*)p.C)) return false;
     const int pi = vlr_prof_begin(VLR_K_GEMM256P, 2.0 * p.M * p.N * (p.K + p.K2), stream);
     if (p.fuse == 0) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 0, true>), dim3(n_cu), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
     else if (p.fuse == 1) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 1, true>), dim3(n_cu), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
@@ -1089,8 +1133,13 @@ bool vlr_gemm256p_try_launch(int layout, const GemmParams& p, hipStream_t stream
     // (an in-place residual, C == residual, stays on the LDS-image epilogue: the widened store of one lane covers columns another
     // lane still has to read)
     const bool res_ok = !p.residual || (cont_res && p.ldr % 4 == 0 && !((uintptr_t)p.residual & 7) && (const void*)p.residual != (const void*)p.C);
-    if (cont && ntiles > tiles && !p.bias && res_ok && !p.accumulate && !p.out_f32 && p.act == ACT_NONE && p.K >= 4 * PK && p.ldc % 8 == 0 && p.N % 8 == 0 &&
-        !((uintptr_t)p.C & 15)) {
+    // fp32 residual stream: C fp32 = acc + residual fp32, 16-byte accesses in the accumulator layout (in place is fine: a lane reads
+    // exactly the bytes it writes).  VLR_GEMM_F32RES_CONT=0 sends these launches to the per-tile kernel's fp32 patches instead.
+    static int f32_cont = -1;
+    if (f32_cont < 0) { const char* e = getenv("VLR_GEMM_F32RES_CONT"); f32_cont = (e && e[0] == '0') ? 0 : 1; }
+    const bool f32_ok = p.out_f32 && f32_cont && (!p.residual || (p.res_f32 && p.ldr % 4 == 0 && !((uintptr_t)p.residual & 15))) && p.ldc % 4 == 0 && p.N % 4 == 0;
+    if (cont && ntiles > tiles && !p.bias && (p.out_f32 ? f32_ok : (res_ok && !p.res_f32)) && !p.accumulate && p.act == ACT_NONE && p.K >= 4 * PK &&
+        (p.out_f32 || (p.ldc % 8 == 0 && p.N % 8 == 0)) && !((uintptr_t)p.C & 15)) {
         if (layout == 0) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true>), dim3(tiles), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
         else if (layout == 1) hipLaunchKernelGGL((gemm256p_kernel<false, true, 0, true>), dim3(tiles), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
         else hipLaunchKernelGGL((gemm256p_kernel<true, true, 0, true>), dim3(tiles), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);

@@ -55,6 +55,22 @@ extern "C" int vlr_layers_join(vlr_stream_t stream) {
         if (rc_ != VLR_OK) return rc_;  \
     } while (0)
 
+// fp32 residual stream (cfg->resid_f32): x_in / x_mid / x_out are fp32 [M][H]; the norms read them in fp32 and the o_proj / down_proj
+// GEMMs add their fp32 accumulators to them without any rounding.  The gradient stream stays bf16.
+static int norm_fwd(int f32, const void* x, const void* w, void* y, float* rstd, int M, int H, float eps, hipStream_t st) {
+    return f32 ? vlr_rmsnorm_fwd_f32((const float*)x, w, y, rstd, M, H, eps, st) : vlr_rmsnorm_fwd(x, w, y, rstd, M, H, eps, st);
+}
+static int norm_bwd(int f32, const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx, void* dw,
+                    int acc, void* ws, int M, int H, hipStream_t st) {
+    return f32 ? vlr_rmsnorm_bwd_f32(dy, (const float*)x, w, rstd, dres, dx, dw, acc, ws, M, H, st)
+               : vlr_rmsnorm_bwd(dy, x, w, rstd, dres, dx, dw, acc, ws, M, H, st);
+}
+// y = a W^T + residual (NT), on the bf16 or the fp32 stream
+static int proj_res(int f32, const void* a, const void* W, void* y, const void* res, int M, int N, int K, hipStream_t st) {
+    return f32 ? vlr_gemm_bf16_f32res(0, a, W, (float*)y, (const float*)res, M, N, K, K, K, N, N, st)
+               : vlr_gemm_bf16(0, a, W, y, nullptr, res, M, N, K, K, K, N, N, 0, 0, 0, st);
+}
+
 static inline const char* off(const void* p, size_t elems) { return (const char*)p + elems * 2; }
 static inline char* off(void* p, size_t elems) { return (char*)p + elems * 2; }
 
@@ -67,7 +83,8 @@ extern "C" int vlr_decoder_layer_fwd_ex(const vlr_llama_cfg* cfg, const vlr_laye
     const int kvh = cfg->kv_heads > 0 ? cfg->kv_heads : cfg->heads;
     VLR_REQUIRE(cfg->heads % kvh == 0, "vlr_decoder_layer_fwd: heads %d is not a multiple of kv_heads %d", cfg->heads, kvh);
     const int Nq = cfg->heads * cfg->head_dim, Nkv = kvh * cfg->head_dim, N = Nq + 2 * Nkv;
-    CHECK(vlr_rmsnorm_fwd(x_in, w->ln1, a->xn1, a->rstd1, M, H, cfg->rms_eps, st));
+    const int rf = cfg->resid_f32;
+    CHECK(norm_fwd(rf, x_in, w->ln1, a->xn1, a->rstd1, M, H, cfg->rms_eps, st));
     // q|k|v projection with RoPE applied to the fp32 accumulators in the GEMM epilogue (plain GEMM + rope kernel for the rows /
     // shapes the persistent kernel does not take)
     // (a bias of the fused projection - Qwen c_attn - is added to the accumulators before the rotation)
@@ -75,11 +92,11 @@ extern "C" int vlr_decoder_layer_fwd_ex(const vlr_llama_cfg* cfg, const vlr_laye
                                  cfg->max_pos, st));
     CHECK(vlr_attn_fwd_gqa(a->qkv, off(a->qkv, Nq), off(a->qkv, (size_t)Nq + Nkv), N, a->attn, Nq, a->lse, key_mask, batch, S,
                            cfg->heads, kvh, cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));
-    CHECK(vlr_gemm_bf16(0, a->attn, w->wo, a->x_mid, nullptr, x_in, M, H, Nq, Nq, Nq, H, H, 0, 0, 0, st));
-    CHECK(vlr_rmsnorm_fwd(a->x_mid, w->ln2, a->xn2, a->rstd2, M, H, cfg->rms_eps, st));
+    CHECK(proj_res(rf, a->attn, w->wo, a->x_mid, x_in, M, H, Nq, st));
+    CHECK(norm_fwd(rf, a->x_mid, w->ln2, a->xn2, a->rstd2, M, H, cfg->rms_eps, st));
     // gate|up projection with act = silu(gate) * up computed in the epilogue
     CHECK(vlr_gemm_swiglu(a->xn2, w->wgu, a->gu, a->act, M, I, H, H, keep_for_backward, st));
-    CHECK(vlr_gemm_bf16(0, a->act, w->wdown, a->x_out, nullptr, a->x_mid, M, H, I, I, I, H, H, 0, 0, 0, st));
+    CHECK(proj_res(rf, a->act, w->wdown, a->x_out, a->x_mid, M, H, I, st));
     return VLR_OK;
 }
 extern "C" int vlr_decoder_layer_fwd(const vlr_llama_cfg* cfg, const vlr_layer_weights* w, const vlr_layer_acts* a,
@@ -108,7 +125,7 @@ extern "C" int vlr_decoder_layer_bwd(const vlr_llama_cfg* cfg, const vlr_layer_w
     if (two) side_done(1);
     CHECK(vlr_gemm_bf16(1, a->gu, w->wgu, ws->dxn, nullptr, nullptr, M, H, 2 * I, 2 * I, H, H, 0, 0, 0, 0, st));
     if (two) wait_side(2, st);                           // previous layer's dWo GEMM still reads ws->dx_mid
-    CHECK(vlr_rmsnorm_bwd(ws->dxn, a->x_mid, w->ln2, a->rstd2, dx_out, ws->dx_mid, g->ln2, accumulate, ws->norm_ws, M, H, st));
+    CHECK(norm_bwd(cfg->resid_f32, ws->dxn, a->x_mid, w->ln2, a->rstd2, dx_out, ws->dx_mid, g->ln2, accumulate, ws->norm_ws, M, H, st));
     // ---- attention
     if (two) { sd = fork_side(st); }
     CHECK(vlr_gemm_bf16(2, ws->dx_mid, a->attn, g->wo, nullptr, nullptr, H, Nq, M, H, Nq, Nq, 0, 0, accumulate, 0, sd));
@@ -126,7 +143,7 @@ extern "C" int vlr_decoder_layer_bwd(const vlr_llama_cfg* cfg, const vlr_layer_w
     CHECK(vlr_gemm_bf16(1, ws->dqkv, w->wqkv, ws->dxn, nullptr, nullptr, M, H, N, N, H, H, 0, 0, 0, 0, st));
     if (two) { wait_side(0, st); wait_side(1, st); }     // this layer's dWdown / dWgu read dx_out / gu: done before dx_in (the
                                                          // buffer the NEXT layer overwrites dx_out with) is produced
-    CHECK(vlr_rmsnorm_bwd(ws->dxn, x_in, w->ln1, a->rstd1, ws->dx_mid, dx_in, g->ln1, accumulate, ws->norm_ws, M, H, st));
+    CHECK(norm_bwd(cfg->resid_f32, ws->dxn, x_in, w->ln1, a->rstd1, ws->dx_mid, dx_in, g->ln1, accumulate, ws->norm_ws, M, H, st));
     return VLR_OK;
 }
 
@@ -203,7 +220,8 @@ extern "C" int vlr_decoder_layer_fwd_lora(const vlr_llama_cfg* cfg, const vlr_la
     VLR_REQUIRE(Nq == H, "vlr_decoder_layer_fwd_lora: heads*head_dim != hidden");
     const float sc = lw->scale, p = lw->dropout;
 #define XD(seg) (ws_xd ? (void*)off(ws_xd, (size_t)(seg) * M * H) : nullptr)   // segment base in units of M*H elements
-    CHECK(vlr_rmsnorm_fwd(x_in, w->ln1, a->xn1, a->rstd1, M, H, cfg->rms_eps, st));
+    const int rf = cfg->resid_f32;
+    CHECK(norm_fwd(rf, x_in, w->ln1, a->xn1, a->rstd1, M, H, cfg->rms_eps, st));
     const int nq = lw->qkv_targets == 1 ? 1 : 3;             // one adapter over the fused projection (Qwen c_attn) or q, k, v separately
     CHECK(lora_group_a(nq, r, H, a->xn1, H, lw->a_qkv, u, ldu, sc, p, seed + 0, ws_xd, M, st));                    // xd segments: q,k,v | o | gate,up | down
     CHECK(vlr_gemm_qkv_rope_lora(a->xn1, w->wqkv, w->bqkv, a->qkv, pos, cfg->rope_cos, cfg->rope_sin, M, N, Nq + Nkv, H, H,
@@ -211,15 +229,17 @@ extern "C" int vlr_decoder_layer_fwd_lora(const vlr_llama_cfg* cfg, const vlr_la
     CHECK(vlr_attn_fwd_gqa(a->qkv, off(a->qkv, Nq), off(a->qkv, (size_t)Nq + Nkv), N, a->attn, Nq, a->lse, key_mask, batch, S,
                            cfg->heads, kvh, cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));
     CHECK(lora_group_a(1, r, H, a->attn, H, lw->a_o, off(u, 3 * (size_t)r), ldu, sc, p, seed + 3, XD(3), M, st));
-    CHECK(vlr_gemm_lora(a->attn, H, w->wo, a->x_mid, H, x_in, H, M, H, H, off(u, 3 * (size_t)r), ldu, lw->b_o, r, st));
-    CHECK(vlr_rmsnorm_fwd(a->x_mid, w->ln2, a->xn2, a->rstd2, M, H, cfg->rms_eps, st));
+    if (rf) CHECK(vlr_gemm_lora_f32res(a->attn, H, w->wo, (float*)a->x_mid, H, (const float*)x_in, H, M, H, H, off(u, 3 * (size_t)r), ldu, lw->b_o, r, st));
+    else CHECK(vlr_gemm_lora(a->attn, H, w->wo, a->x_mid, H, x_in, H, M, H, H, off(u, 3 * (size_t)r), ldu, lw->b_o, r, st));
+    CHECK(norm_fwd(rf, a->x_mid, w->ln2, a->xn2, a->rstd2, M, H, cfg->rms_eps, st));
     CHECK(lora_group_a(2, r, H, a->xn2, H, lw->a_gu, off(u, 4 * (size_t)r), ldu, sc, p, seed + 4, XD(4), M, st));
     CHECK(vlr_gemm_swiglu_lora(a->xn2, w->wgu, a->gu, a->act, M, I, H, H, off(u, 4 * (size_t)r), ldu, lw->b_gu, r, st));
     if (lw->a_down) {
         CHECK(lora_group_a(1, r, I, a->act, I, lw->a_down, off(u, 6 * (size_t)r), ldu, sc, p, seed + 6, XD(6), M, st));
-        CHECK(vlr_gemm_lora(a->act, I, w->wdown, a->x_out, H, a->x_mid, H, M, H, I, off(u, 6 * (size_t)r), ldu, lw->b_down, r, st));
+        if (rf) CHECK(vlr_gemm_lora_f32res(a->act, I, w->wdown, (float*)a->x_out, H, (const float*)a->x_mid, H, M, H, I, off(u, 6 * (size_t)r), ldu, lw->b_down, r, st));
+        else CHECK(vlr_gemm_lora(a->act, I, w->wdown, a->x_out, H, a->x_mid, H, M, H, I, off(u, 6 * (size_t)r), ldu, lw->b_down, r, st));
     } else {
-        CHECK(vlr_gemm_bf16(0, a->act, w->wdown, a->x_out, nullptr, a->x_mid, M, H, I, I, I, H, H, 0, 0, 0, st));
+        CHECK(proj_res(rf, a->act, w->wdown, a->x_out, a->x_mid, M, H, I, st));
     }
     return VLR_OK;
 }
@@ -247,7 +267,7 @@ extern "C" int vlr_decoder_layer_bwd_lora(const vlr_llama_cfg* cfg, const vlr_la
     CHECK(vlr_gemm_bf16(1, a->gu, w->wgu, ws->dxn, nullptr, nullptr, M, H, 2 * I, 2 * I, H, H, 0, 0, 0, 0, st));
     CHECK(lora_group_bwd(2, r, H, o_gu, a->xn2, a->gu, 2 * I, lw->a_gu, lw->b_gu, lg->a_gu, lg->b_gu, off(u, 4 * (size_t)r), ldu, ws_v,
                          ws->dxn, sc, p, seed + 4, XD(4), accumulate, M, st));
-    CHECK(vlr_rmsnorm_bwd(ws->dxn, a->x_mid, w->ln2, a->rstd2, dx_out, ws->dx_mid, nullptr, 0, ws->norm_ws, M, H, st));
+    CHECK(norm_bwd(cfg->resid_f32, ws->dxn, a->x_mid, w->ln2, a->rstd2, dx_out, ws->dx_mid, nullptr, 0, ws->norm_ws, M, H, st));
     // ---- attention
     CHECK(vlr_gemm_bf16(1, ws->dx_mid, w->wo, ws->dattn, nullptr, nullptr, M, H, H, H, H, H, 0, 0, 0, 0, st));
     CHECK(lora_group_bwd(1, r, H, o_h, a->attn, ws->dx_mid, H, lw->a_o, lw->b_o, lg->a_o, lg->b_o, off(u, 3 * (size_t)r), ldu, ws_v,
@@ -261,7 +281,7 @@ extern "C" int vlr_decoder_layer_bwd_lora(const vlr_llama_cfg* cfg, const vlr_la
     const int nq = lw->qkv_targets == 1 ? 1 : 3;
     CHECK(lora_group_bwd(nq, r, H, nq == 1 ? o_all : o_qkv, a->xn1, ws->dqkv, N, lw->a_qkv, lw->b_qkv, lg->a_qkv, lg->b_qkv, u, ldu, ws_v, ws->dxn,
                          sc, p, seed + 0, ws_xd, accumulate, M, st));
-    CHECK(vlr_rmsnorm_bwd(ws->dxn, x_in, w->ln1, a->rstd1, ws->dx_mid, dx_in, nullptr, 0, ws->norm_ws, M, H, st));
+    CHECK(norm_bwd(cfg->resid_f32, ws->dxn, x_in, w->ln1, a->rstd1, ws->dx_mid, dx_in, nullptr, 0, ws->norm_ws, M, H, st));
     return VLR_OK;
 }
 

@@ -15,7 +15,7 @@ P, I, L, F, U64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint64
 
 class LlamaCfg(C.Structure):
     _fields_ = [("hidden", I), ("inter", I), ("heads", I), ("head_dim", I), ("rms_eps", F), ("max_pos", I),
-                ("rope_cos", P), ("rope_sin", P), ("kv_heads", I)]
+                ("rope_cos", P), ("rope_sin", P), ("kv_heads", I), ("resid_f32", I)]
 
 
 class LayerWeights(C.Structure):
@@ -60,6 +60,10 @@ _SIGS = {
     "vlr_gemm_bf16_scaled": [I, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, F, P],
     "vlr_rmsnorm_fwd": [P, P, P, P, I, I, F, P],
     "vlr_rmsnorm_bwd": [P, P, P, P, P, P, P, I, P, I, I, P],
+    "vlr_rmsnorm_fwd_f32": [P, P, P, P, I, I, F, P],
+    "vlr_rmsnorm_bwd_f32": [P, P, P, P, P, P, P, I, P, I, I, P],
+    "vlr_gemm_bf16_f32res": [I, P, P, P, P, I, I, I, I, I, I, I, P],
+    "vlr_gemm_lora_f32res": [P, I, P, P, I, P, I, I, I, I, P, I, P, I, P],
     "vlr_layernorm_fwd": [P, P, P, P, I, I, F, P],
     "vlr_layernorm_bwd": [P, P, P, F, P, P, P, I, P, I, I, P],
     "vlr_vit_embed_ln": [P, P, P, P, P, P, I, I, I, F, P],

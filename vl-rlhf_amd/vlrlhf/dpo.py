@@ -116,6 +116,9 @@ def main(argv=None):
     rank, local, world = init_distributed_from_env()
     training_args.local_rank = local
     model, ref_model, lora_config = auto_load_rlmodel(script_args, training_args, lora_args)
+    # reference dpo.py:99 (gradient_checkpointing_kwargs use_reentrant=False; every shipped script passes --gradient_checkpointing True):
+    # the engine keeps only the layer inputs and re-runs each layer's forward right before its backward (engine.hidden_backward)
+    model.engine.gradient_checkpointing = bool(training_args.gradient_checkpointing)
     processor = MyAutoProcessor.from_pretrained(script_args.model_name_or_path)
     processor.train()
     dataset = DATASET_MAP[script_args.dataset_name](script_args)

@@ -306,6 +306,7 @@ class VisionWeights:
 
 class LlavaHipEngine:
     custom_layers = False          # True: the subclass composes the decoder layer itself (_layer_forward / _hidden_backward_custom)
+    supports_resid_f32 = True      # False: the subclass adds to the residual stream with bf16 primitives
 
     def __init__(self, cfg: dict, device="cuda", max_positions: int = 4096):
         if not torch.cuda.is_available():
@@ -333,8 +334,16 @@ class LlavaHipEngine:
         self.cos = torch.empty(max_positions, self.hd // 2, dtype=torch.float32, device=self.dev)
         self.sin = torch.empty_like(self.cos)
         _hip.call("vlr_rope_table", self.cos, self.sin, max_positions, self.hd, float(c.get("rope_theta", 10000.0)))
+        # fp32 residual stream (include/vlr.h vlr_llama_cfg.resid_f32): x0 and every layer's x_mid / x_out are fp32, never rounded.
+        # Default ON (VLR_RESID_F32=0 or cfg["resid_f32"] = False: the bf16 stream of ABI v3); engines that compose their own layers
+        # from bf16 primitives opt out (supports_resid_f32).
+        self.resid_f32 = bool(c.get("resid_f32", os.environ.get("VLR_RESID_F32", "1") != "0")) and self.supports_resid_f32
+        self.RDT = torch.float32 if self.resid_f32 else BF16      # dtype of the residual stream
+        # gradient checkpointing (reference scripts: --gradient_checkpointing True, dpo.py:99 non-reentrant): only the layer inputs
+        # are kept by the forward; the backward re-runs each layer's forward into one scratch set right before its backward
+        self.gradient_checkpointing = bool(c.get("gradient_checkpointing", False))
         self.llama_cfg = _hip.LlamaCfg(self.H, self.I, self.nh, self.hd, float(c.get("rms_eps", 1e-5)), max_positions,
-                                       self.cos.data_ptr(), self.sin.data_ptr(), self.nkv)
+                                       self.cos.data_ptr(), self.sin.data_ptr(), self.nkv, int(self.resid_f32))
         self._init_vision_cfg()
         self.vision: Optional[VisionWeights] = None
         self.policy = WeightSet(self.layout, self.dev)
@@ -503,12 +512,53 @@ class LlavaHipEngine:
             t = dict(xn1=torch.empty(M, H, dtype=BF16, device=self.dev), rstd1=torch.empty(M, dtype=torch.float32, device=self.dev),
                      qkv=torch.empty(M, self.Nqkv, dtype=BF16, device=self.dev), attn=torch.empty(M, self.Nq, dtype=BF16, device=self.dev),
                      lse=torch.empty(Bn, self.nh, Sp, dtype=torch.float32, device=self.dev),
-                     x_mid=torch.empty(M, H, dtype=BF16, device=self.dev), xn2=torch.empty(M, H, dtype=BF16, device=self.dev),
+                     x_mid=torch.empty(M, H, dtype=self.RDT, device=self.dev), xn2=torch.empty(M, H, dtype=BF16, device=self.dev),
                      rstd2=torch.empty(M, dtype=torch.float32, device=self.dev), gu=torch.empty(M, 2 * I, dtype=BF16, device=self.dev),
-                     act=torch.empty(M, I, dtype=BF16, device=self.dev), x_out=torch.empty(M, H, dtype=BF16, device=self.dev))
+                     act=torch.empty(M, I, dtype=BF16, device=self.dev), x_out=torch.empty(M, H, dtype=self.RDT, device=self.dev))
             t["struct"] = _hip.LayerActs(*(t[n].data_ptr() for n in ("xn1", "rstd1", "qkv", "attn", "lse", "x_mid", "xn2", "rstd2", "gu", "act", "x_out")))
             self._ws[k] = t
         return t
+
+    def _ckpt_acts(self, tag, l, Bn, S):
+        """gradient checkpointing: every layer shares ONE scratch activation set; only x_out (= the next layer's input) is per layer"""
+        k = (tag, "ckpt", l, Bn, S)
+        t = self._ws.get(k)
+        if t is None:
+            base = self._layer_acts(tag + "/ckpt", 0, Bn, S)
+            t = {n: v for n, v in base.items() if n != "struct"}
+            t["x_out"] = torch.empty(Bn * S, self.H, dtype=self.RDT, device=self.dev)
+            t["struct"] = _hip.LayerActs(*(t[n].data_ptr() for n in ("xn1", "rstd1", "qkv", "attn", "lse", "x_mid", "xn2", "rstd2", "gu", "act", "x_out")))
+            t["shared"] = base            # LoRA: u / xd live in the shared set
+            self._ws[k] = t
+        return t
+
+    def _norm_fwd(self, x, w, y, rstd, M):
+        _hip.call("vlr_rmsnorm_fwd_f32" if x.dtype == torch.float32 else "vlr_rmsnorm_fwd", x, w, y, rstd, M, self.H, self.llama_cfg.rms_eps)
+
+    def _norm_bwd(self, dy, x, w, rstd, dres, dx, dw, acc, M):
+        _hip.call("vlr_rmsnorm_bwd_f32" if x.dtype == torch.float32 else "vlr_rmsnorm_bwd", dy, x, w, rstd, dres, dx, dw, acc, self._norm_ws, M, self.H)
+
+    def _layer_fwd_call(self, ws, l, a, x, e, Bn, S, keep, use_lora, lora_seed):
+        """one decoder layer forward into the activation set `a` (keep: also write what only the backward reads)"""
+        M = Bn * S
+        if self.custom_layers:
+            self._layer_forward(ws, l, a, x, e, Bn, S, keep, use_lora, lora_seed)
+        elif use_lora:
+            r = self.lora["r"]
+            sh = a.get("shared", a)
+            if "u" not in sh or sh["u"].shape[1] != 7 * r:
+                sh["u"] = torch.empty(M, 7 * r, dtype=BF16, device=self.dev)
+            lw, _ = self._lora_structs(l, train=True)
+            xd = None
+            if self.lora["dropout"] > 0 and self.training:     # dropped inputs of the seven targets, kept per layer for the backward
+                if "xd" not in sh:
+                    sh["xd"] = torch.empty(M, 6 * self.H + self.I, dtype=BF16, device=self.dev)
+                xd = sh["xd"]
+            _hip.call("vlr_decoder_layer_fwd_lora", self.llama_cfg, self.layer_weights(ws, l), lw, a["struct"], sh["u"], xd,
+                      lora_seed + 8 * l, x, e["pos"], e["mask"], Bn, S)
+        else:
+            _hip.call("vlr_decoder_layer_fwd_ex", self.llama_cfg, self.layer_weights(ws, l), a["struct"], x, e["pos"], e["mask"], Bn, S,
+                      int(keep))
 
     # ------------------------------------------------------------------------------------------------ vision
     def vision_features(self, pixel_values: torch.Tensor, key=None) -> torch.Tensor:
@@ -679,42 +729,34 @@ class LlavaHipEngine:
         feats, vit_feat, z, h, n_rows, n_feat, pack = e["feats"], e["vit_feat"], e["proj_z"], e["proj_h"], e["n_rows"], e["n_feat"], e["pack"]
         x0 = self._buf((tag, "x0", Bn, S), (M, self.H))
         _hip.call("vlr_merge_fwd", src, ids, ws.v["embed"], feats, x0, Bn, T, S, self.H)
+        if self.resid_f32:                 # the merged embeddings are bf16 values (table rows / projector output): exact in fp32
+            x0b, x0 = x0, self._buf((tag, "x0f", Bn, S), (M, self.H), torch.float32)
+            _hip.call("vlr_cast_bf16_to_f32", x0b, x0, M * self.H)
         x = x0
         acts = []
         use_lora = self.lora is not None and self.lora_active and ws is self.policy
         lora_seed = None
         if use_lora:
-            r = self.lora["r"]
             self._lora_calls += 1
             lora_seed = (self.lora_seed << 40) + (self._lora_calls << 16)        # + 8*layer + target inside the library
-            drop = self.lora["dropout"] > 0 and self.training
+        ckpt = bool(save and self.gradient_checkpointing and not self.custom_layers)   # (composed layers keep their activations)
         for l in range(self.L):
-            a = self._layer_acts(tag if save else tag + "/scratch", l if save else (l % 2), Bn, S)   # scratch per pass tag (side stream)
-            if self.custom_layers:
-                self._layer_forward(ws, l, a, x, e, Bn, S, save, use_lora, lora_seed)
-            elif use_lora:
-                if "u" not in a or a["u"].shape[1] != 7 * r:
-                    a["u"] = torch.empty(M, 7 * r, dtype=BF16, device=self.dev)
-                lw, _ = self._lora_structs(l, train=True)
-                xd = None
-                if drop:                                   # dropped inputs of the seven targets, kept per layer for the backward
-                    if "xd" not in a:
-                        a["xd"] = torch.empty(M, 6 * self.H + self.I, dtype=BF16, device=self.dev)
-                    xd = a["xd"]
-                _hip.call("vlr_decoder_layer_fwd_lora", self.llama_cfg, self.layer_weights(ws, l), lw, a["struct"], a["u"], xd,
-                          lora_seed + 8 * l, x, pos, mask, Bn, S)
+            if ckpt:
+                a = self._ckpt_acts(tag, l, Bn, S)
             else:
-                _hip.call("vlr_decoder_layer_fwd_ex", self.llama_cfg, self.layer_weights(ws, l), a["struct"], x, pos, mask, Bn, S,
-                          int(save))
+                a = self._layer_acts(tag if save else tag + "/scratch", l if save else (l % 2), Bn, S)   # scratch per pass tag (side stream)
+            # checkpointing: this pass keeps x_out only - what the backward reads is written by the recompute (hidden_backward)
+            self._layer_fwd_call(ws, l, a, x, e, Bn, S, save and not ckpt, use_lora, lora_seed)
             acts.append(a)
             x = a["x_out"]
         hidden = torch.empty(M, self.H, dtype=BF16, device=self.dev)
         rstd_f = self._buf((tag, "rstd_f", M), (M,), torch.float32)
-        _hip.call("vlr_rmsnorm_fwd", x, ws.v["norm"], hidden, rstd_f, M, self.H, self.llama_cfg.rms_eps)
+        self._norm_fwd(x, ws.v["norm"], hidden, rstd_f, M)
         return dict(ws=ws, Bn=Bn, T=T, S=S, M=M, ids=ids, src=src, inv=inv, mask=mask, labels=mlabels, pos=pos,
                     img_map=img_map.bool(), hidden=hidden, rstd_f=rstd_f, x_last=x, x0=x0, acts=acts if save else None,
                     vit_feat=vit_feat, feats=feats, proj_z=z, proj_h=h, image_dup=image_dup, n_rows=n_rows, n_feat=n_feat,
-                    pack=pack, tag=tag, lora_seed=lora_seed, meta=meta, extra=e.get("extra"))
+                    pack=pack, tag=tag, lora_seed=lora_seed, meta=meta, extra=e.get("extra"), ckpt=ckpt, use_lora=use_lora,
+                    embed=dict(pos=e["pos"], mask=e["mask"], extra=e.get("extra"), tag=tag, img_map=e["img_map"]))
 
     # ------------------------------------------------------------------------------------------------ log-probs
     def logps_forward(self, ctx, labels, shared_mask=None, average=False, label_pad=-100):
@@ -824,8 +866,7 @@ class LlavaHipEngine:
             return self._hidden_backward_custom(ctx, dhidden, dxa, dxb)
         if self.lora is not None:
             return self._hidden_backward_lora(ctx, dhidden, dxa, dxb)
-        _hip.call("vlr_rmsnorm_bwd", dhidden, ctx["x_last"], ws.v["norm"], ctx["rstd_f"], None, dxa, self.gv["norm"], acc,
-                  self._norm_ws, M, H)
+        self._norm_bwd(dhidden, ctx["x_last"], ws.v["norm"], ctx["rstd_f"], None, dxa, self.gv["norm"], acc, M)
         wsb = dict(dact=self._buf(("dact", M), (M, I)), dxn=self._buf(("dxn", M), (M, H)), dattn=self._buf(("dattn", M), (M, self.Nq)),
                    dqkv=self._buf(("dqkv", M), (M, self.Nqkv)), dx_mid=self._buf(("dx_mid", M), (M, H)),
                    delta=self._buf(("delta", Bn, S), (Bn, self.nh, Sp), torch.float32))
@@ -835,6 +876,9 @@ class LlavaHipEngine:
         for l in range(self.L - 1, -1, -1):
             a = ctx["acts"][l]
             x_in = ctx["acts"][l - 1]["x_out"] if l > 0 else ctx["x0"]
+            if ctx["ckpt"]:
+                _hip.call("vlr_layers_join")          # the previous layer's weight-gradient GEMMs still read the shared activation set
+                self._layer_fwd_call(ws, l, a, x_in, ctx["embed"], Bn, S, True, False, None)
             _hip.call("vlr_decoder_layer_bwd", self.llama_cfg, self.layer_weights(ws, l), self.layer_grads(l), acc,
                       a["struct"], lws, x_in, cur, nxt, ctx["pos"], ctx["mask"], Bn, S)
             if f"l{l}.bqkv" in self.gv:              # bias of the fused q|k|v projection: column sum of this layer's d qkv (post rope-transpose)
@@ -895,7 +939,7 @@ class LlavaHipEngine:
         acc = int(not self.grad_fresh)
         Sp = _align(S, 64)
         r = self.lora["r"]
-        _hip.call("vlr_rmsnorm_bwd", dhidden, ctx["x_last"], ws.v["norm"], ctx["rstd_f"], None, dxa, None, 0, self._norm_ws, M, H)
+        self._norm_bwd(dhidden, ctx["x_last"], ws.v["norm"], ctx["rstd_f"], None, dxa, None, 0, M)
         wsb = dict(dact=self._buf(("dact", M), (M, I)), dxn=self._buf(("dxn", M), (M, H)), dattn=self._buf(("dattn", M), (M, H)),
                    dqkv=self._buf(("dqkv", M), (M, 3 * H)), dx_mid=self._buf(("dx_mid", M), (M, H)),
                    delta=self._buf(("delta", Bn, S), (Bn, self.nh, Sp), torch.float32))
@@ -908,8 +952,11 @@ class LlavaHipEngine:
             a = ctx["acts"][l]
             x_in = ctx["acts"][l - 1]["x_out"] if l > 0 else ctx["x0"]
             lw, lg = self._lora_structs(l, train=True)
-            _hip.call("vlr_decoder_layer_bwd_lora", self.llama_cfg, self.layer_weights(ws, l), lw, lg, acc, a["struct"], a["u"],
-                      lws, ws_v, a["xd"] if drop else None, ctx["lora_seed"] + 8 * l, x_in, cur, nxt, ctx["pos"], ctx["mask"], Bn, S)
+            if ctx["ckpt"]:
+                self._layer_fwd_call(ws, l, a, x_in, ctx["embed"], Bn, S, True, True, ctx["lora_seed"])
+            sh = a.get("shared", a)
+            _hip.call("vlr_decoder_layer_bwd_lora", self.llama_cfg, self.layer_weights(ws, l), lw, lg, acc, a["struct"], sh["u"],
+                      lws, ws_v, sh["xd"] if drop else None, ctx["lora_seed"] + 8 * l, x_in, cur, nxt, ctx["pos"], ctx["mask"], Bn, S)
             cur, nxt = nxt, cur
         self.grad_fresh = False
         if self.reducer is not None:

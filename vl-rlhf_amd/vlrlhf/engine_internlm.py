@@ -29,6 +29,7 @@ PLORA_SEED_XOR = 0x2A5A5A5A5A
 
 class InternLMHipEngine(LlavaHipEngine):
     custom_layers = True
+    supports_resid_f32 = False     # the composed layer adds the adapter terms to the stream with bf16 primitives (vlr_rows_add, accumulate GEMMs)
     vision_prefix = "vit.vision_tower."
 
     def __init__(self, cfg: dict, device="cuda", max_positions: int = 8192):

@@ -370,6 +370,18 @@ class LlavaForRL(nn.Module):
     def freeze_vision_tower(self):
         self._vision_frozen = True          # the MI355X path keeps the tower frozen (reference default, auto_load.py:554)
 
+    def gradient_checkpointing_enable(self, gradient_checkpointing_kwargs=None):
+        """transformers PreTrainedModel API (the HF Trainer calls it for --gradient_checkpointing True, reference dpo.py:99): the engine
+        keeps only each decoder layer's input and re-runs the layer's forward right before its backward - bit-identical results"""
+        self.engine.gradient_checkpointing = True
+
+    def gradient_checkpointing_disable(self):
+        self.engine.gradient_checkpointing = False
+
+    @property
+    def is_gradient_checkpointing(self):
+        return bool(self.engine.gradient_checkpointing)
+
     def prepare_default_generation_kwargs(self, generation_config):
         generation_config.max_new_tokens = 1024
         generation_config.do_sample = False
