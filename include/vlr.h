@@ -50,11 +50,19 @@ int vlr_gemm_bf16_scaled(int layout, const void* A, const void* B, void* C, cons
  * LlamaDecoderLayer.forward (call site src/vlrlhf/models/Llava/__init__.py:232) without the bf16 rounding of the sum. */
 int vlr_gemm_bf16_f32res(int layout, const void* A, const void* B, float* C, const float* residual, int M, int N, int K,
                          int lda, int ldb, int ldc, int ldr, vlr_stream_t stream);
+/* Tile schedule of the persistent (continuous-pipeline) GEMM launches: bit 0 = stream-K tail (the last 1.x rounds of an XCD's tiles
+ * are cut into equal K ranges per workgroup; a tile shared by two workgroups is finished by one of them from the other's fp32
+ * accumulator slab - fixed order, deterministic), bit 1 = XCD rotation (the eight XCDs' tile boundaries are offset by 1/8 of a tile so
+ * that their output-store bursts do not coincide).  Both need the 128 MiB-per-stream scratch of vlr_gemm_set_splitk_workspace and
+ * K >= 1024; otherwise a launch runs plain rounds.  -1 = back to the default (environment VLR_GEMM_SCHED, else the built-in one).
+ * Results are bit-identical run to run for a given mode; different modes sum K in different orders (last-bit differences). */
+int vlr_gemm_set_sched(int mode);
 /* Optional fp32 scratch for split-K: problems with few output tiles and a long reduction (the LoRA adapter gradients;
  * the ragged last tile rows of the decoder GEMMs) are split along K into fp32 partials and reduced by a second kernel
- * that applies the epilogue.  Without it they run un-split.  The buffer is cut in 64 MiB slots (covers the 7B shapes; at most
- * eight), one per distinct stream that launches such a GEMM (policy pass, reference pass on a side stream, ...); further
- * streams run un-split.  Registering again forgets the stream assignment.  (NULL, 0) unregisters. */
+ * that applies the epilogue.  Without it they run un-split.  The buffer is cut in 128 MiB slots (at most eight; below 256 MiB in
+ * total: 64 MiB slots, which cover the split-K partials of the 7B shapes but not the stream-K slabs of vlr_gemm_set_sched), one per
+ * distinct stream that launches such a GEMM (policy pass, reference pass on a side stream, ...); further streams run un-split.
+ * Registering again forgets the stream assignment.  (NULL, 0) unregisters. */
 int vlr_gemm_set_splitk_workspace(void* workspace, long bytes);
 /* Fused forward projections of the decoder layer (transformers LlamaMLP / LlamaAttention; call site
  * src/vlrlhf/models/Llava/__init__.py:232).  The elementwise op that follows the projection runs on the fp32 accumulators

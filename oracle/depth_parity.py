@@ -41,6 +41,13 @@ VARIANTS = [
     ("only_vit", frozenset(("vit",)), "vision tower + projector only"),
     ("mfma_operands", MFMA_OPERANDS, "only the operands of the MFMAs (xn, rope'd q/k, P, attn, act, hidden): floor of ANY bf16-MFMA path"),
     ("hip_f32resid", MFMA_OPERANDS | {"vit", "v"}, "what the HIP path rounds with the fp32 residual stream (round 3): MFMA operands + v + the vision tower"),
+    ("f32resid-hidden", (MFMA_OPERANDS | {"vit", "v"}) - {"hidden"}, "hip_f32resid with an unrounded hidden state into the lm-head"),
+    ("f32resid-vit", MFMA_OPERANDS | {"v"}, "hip_f32resid with an exact vision tower + projector"),
+    ("only_xn", frozenset(("xn",)), "RMSNorm outputs (A operand of the q|k|v and gate|up GEMMs) only"),
+    ("only_ropev", frozenset(("rope", "v")), "q / k after RoPE and v (the attention operands) only"),
+    ("only_p", frozenset(("p",)), "softmax probabilities (A operand of P.V) only"),
+    ("only_attn", frozenset(("attn",)), "attention output (A operand of o_proj) only"),
+    ("only_act", frozenset(("act",)), "silu(gate) * up (A operand of down_proj) only"),
     ("mfma_operands-hidden", MFMA_OPERANDS - {"hidden"}, "the floor if the lm-head consumed an unrounded hidden state"),
 ]
 
@@ -176,9 +183,11 @@ def main():
                  f"{'variant':24s} {'loss':>11s} {'|d| vs fp32':>12s} {'rel':>9s}   max |d logp|   what is rounded to bf16"]
         for name, r in out.items():
             d = abs(r["loss"] - ref)
-            dl = max(abs(a - b) for k in ("policy_chosen_logps", "policy_rejected_logps", "reference_chosen_logps", "reference_rejected_logps")
-                     for a, b in zip(r[k], out["fp32"][k]))
-            lines.append(f"{name:24s} {r['loss']:11.7f} {d:12.3e} {d / abs(ref):9.2e}   {dl:12.4f}   {r['what']}")
+            dls = [abs(a - b) for k in ("policy_chosen_logps", "policy_rejected_logps", "reference_chosen_logps", "reference_rejected_logps")
+                   for a, b in zip(r[k], out["fp32"][k])]
+            dl = max(dls)
+            rms = (sum(x * x for x in dls) / len(dls)) ** 0.5
+            lines.append(f"{name:24s} {r['loss']:11.7f} {d:12.3e} {d / abs(ref):9.2e}   {dl:12.4f} (rms {rms:.4f})   {r['what']}")
         with open(os.path.join(ROOT, "profiles", f"r03_bf16_error_budget_L{layers}.txt"), "w") as f:
             f.write("\n".join(lines) + "\n")
         log("\n".join(lines))

@@ -1180,3 +1180,136 @@ def test_decoder_layer_f32_stream(hip):
     check(grads["wqkv"].cpu(), gq, 4e-2, "dWqkv (f32 stream)")
     check(grads["wdown"].cpu(), leaves[p + "mlp.down_proj.weight"].grad, 4e-2, "dWdown (f32 stream)")
     check(grads["ln2"].cpu(), leaves[p + "post_attention_layernorm.weight"].grad, 4e-2, "dln2 (f32 stream)")
+
+
+# ---------------------------------------------------------------------------------------------------- attention at the sizes the step runs
+@pytest.mark.parametrize("B,S,nh,nkv", [(2, 1599, 32, 32), (1, 4975, 32, 8)])
+def test_attention_at_step_sizes(hip, B, S, nh, nkv):
+    """Kernel-level parity at the sequence lengths and head counts of the benchmark configurations: S = 1599 with 32 heads (BASELINE
+    configs[1]) and S = 4975 with 32 query / 8 K/V heads (configs[3], LLaVA-Next-Mistral) - forward AND backward against an fp32 eager
+    reference evaluated one query head at a time (S x S fp32 per head), with right padding on the first sequence."""
+    hd = 128
+    Hq, Hkv = nh * hd, nkv * hd
+    N = Hq + 2 * Hkv
+    grp = nh // nkv
+    qkv = rnd(B * S, N, seed=41)
+    do = rnd(B * S, Hq, seed=42)
+    km = torch.ones(B, S, dtype=torch.int32, device=DEV)
+    km[0, S - 37:] = 0
+    do.view(B, S, Hq)[0, S - 37:] = 0
+    scale = 1.0 / math.sqrt(hd)
+    Sp = (S + 63) // 64 * 64
+    o = torch.full((B * S, Hq), float("nan"), dtype=torch.bfloat16, device=DEV)
+    lse = torch.zeros(B, nh, Sp, dtype=torch.float32, device=DEV)
+    hip.call("vlr_attn_fwd_gqa", qkv, qkv[:, Hq:], qkv[:, Hq + Hkv:], N, o, Hq, lse, km, B, S, nh, nkv, hd, 1, scale)
+    dqkv = torch.full((B * S, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    delta = torch.full((B, nh, Sp), float("nan"), dtype=torch.float32, device=DEV)
+    hip.call("vlr_attn_bwd_gqa", qkv, qkv[:, Hq:], qkv[:, Hq + Hkv:], N, o, do, Hq, lse, delta, km, dqkv, dqkv[:, Hq:],
+             dqkv[:, Hq + Hkv:], N, B, S, nh, nkv, hd, 1, scale)
+    torch.cuda.synchronize()
+    ref = torch.empty(B * S, Hq, device=DEV)
+    g = torch.zeros(B * S, N, device=DEV)
+    tril = torch.ones(S, S, dtype=torch.bool, device=DEV).tril()
+    for b in range(B):
+        rows = slice(b * S, (b + 1) * S)
+        vis = tril & (km[b][None, :] != 0)
+        for h in range(nh):
+            kv = h // grp
+            q = qkv[rows, h * hd:(h + 1) * hd].float().requires_grad_(True)
+            k = qkv[rows, Hq + kv * hd: Hq + (kv + 1) * hd].float().requires_grad_(True)
+            v = qkv[rows, Hq + Hkv + kv * hd: Hq + Hkv + (kv + 1) * hd].float().requires_grad_(True)
+            p = torch.softmax(((q @ k.t()) * scale).masked_fill(~vis, float("-inf")), -1)
+            r = p @ v
+            (r * do[rows, h * hd:(h + 1) * hd].float()).sum().backward()
+            ref[rows, h * hd:(h + 1) * hd] = r.detach()
+            g[rows, h * hd:(h + 1) * hd] = q.grad
+            g[rows, Hq + kv * hd: Hq + (kv + 1) * hd] += k.grad              # K/V heads are shared by `grp` query heads
+            g[rows, Hq + Hkv + kv * hd: Hq + Hkv + (kv + 1) * hd] += v.grad
+            del q, k, v, p, r
+    valid = km.reshape(-1) != 0
+    check(o[valid], ref[valid], 1.2e-2, f"attention fwd S={S}")
+    check(dqkv[valid][:, :Hq], g[valid][:, :Hq], 2e-2, f"dq S={S}")
+    check(dqkv[valid][:, Hq:Hq + Hkv], g[valid][:, Hq:Hq + Hkv], 2e-2, f"dk S={S}")
+    check(dqkv[valid][:, Hq + Hkv:], g[valid][:, Hq + Hkv:], 2e-2, f"dv S={S}")
+    assert torch.isfinite(dqkv.float()).all() and torch.isfinite(o.float()).all()
+    assert float(dqkv[~valid][:, Hq:].abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------- persistent tile schedules
+def _with_sched(hip, mode, fn):
+    from vlrlhf import _hip as HH
+    HH.ensure_splitk_workspace(DEV, force=True)
+    assert hip.helper("vlr_gemm_set_sched", mode) == 0
+    try:
+        return fn()
+    finally:
+        hip.helper("vlr_gemm_set_sched", -1)
+
+
+# tiles % 256 != 0 in every case (a stream-K tail exists), K >= 1024; (M, N, K): 800 / 688+ / 1376-tile shapes of the 7B step, scaled K
+SCHED_SHAPES = [(12792, 4096, 1024), (4096, 11008, 1088), (5000, 4360, 2048)]
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("shape", SCHED_SHAPES)
+def test_gemm_sched_modes(hip, layout, shape):
+    """vlr_gemm_set_sched: stream-K tail (1), XCD rotation (2), both (3) against the fp32 reference and against plain rounds (0); each
+    mode twice - bit-identical (fixed summation order through the slabs), and a NaN-filled output proves every tile is written once."""
+    M, N, K = shape
+    if layout == 2:
+        K = K + 40
+    a, b = rnd(M, K, seed=1, scale=0.5), rnd(N, K, seed=2, scale=0.5)
+    ref = a.float() @ b.float().t()
+    A = a if layout != 2 else a.t().contiguous()
+    Bm = b if layout == 0 else b.t().contiguous()
+    lda = K if layout != 2 else M
+    ldb = K if layout == 0 else N
+    outs = {}
+    for mode in (0, 1, 2, 3):
+        def run():
+            res = []
+            for _ in range(2):
+                c = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+                hip.call("vlr_gemm_bf16", layout, A, Bm, c, None, None, M, N, K, lda, ldb, N, 0, 0, 0, 0)
+                torch.cuda.synchronize()
+                res.append(c)
+            return res
+        c1, c2 = _with_sched(hip, mode, run)
+        assert torch.equal(c1, c2), f"mode {mode}: not reproducible"
+        check(c1, ref, 8e-3, f"gemm sched {mode} layout {layout} {shape}")
+        outs[mode] = c1
+    for mode in (1, 2, 3):       # same products, another fp32 summation order: at most the last bf16 bit of a few elements
+        d = (outs[mode].float() - outs[0].float()).abs()
+        assert float(d.max()) <= 2e-2 * float(ref.abs().max()) and float((d > 0).float().mean()) < 0.2, mode
+
+
+def test_gemm_sched_fused_epilogues(hip):
+    """the fused SwiGLU / RoPE / SwiGLU-backward / fp32-residual launches under every schedule mode: equal to mode 0 up to summation order"""
+    M, I, H = 6648, 2176, 1024                                   # 26 x 17 = 442 SwiGLU tiles; 26 x 9 o_proj-like tiles
+    x, wgu = rnd(M, H, seed=1), rnd(2 * I, H, scale=0.05, seed=2)
+    dy, wdown = rnd(M, H, seed=3), rnd(H, I, scale=0.05, seed=4)
+    res = rnd(M, 4352, seed=5, dtype=torch.float32)
+    wo = rnd(4352, H, scale=0.05, seed=6)
+    base = {}
+    for mode in (0, 1, 2, 3):
+        def run():
+            gu = torch.full((M, 2 * I), float("nan"), dtype=torch.bfloat16, device=DEV)
+            act = torch.full((M, I), float("nan"), dtype=torch.bfloat16, device=DEV)
+            hip.call("vlr_gemm_swiglu", x, wgu, gu, act, M, I, H, H, 1)
+            gub = gu.clone()
+            dws = torch.empty(M, I, dtype=torch.bfloat16, device=DEV)
+            hip.call("vlr_gemm_swiglu_bwd", dy, wdown, gub, dws, M, I, H)
+            y = torch.full((M, 4352), float("nan"), dtype=torch.float32, device=DEV)
+            hip.call("vlr_gemm_bf16_f32res", 0, x, wo, y, res, M, 4352, H, H, H, 4352, 4352)
+            torch.cuda.synchronize()
+            return gu, act, gub, y
+        out = _with_sched(hip, mode, run)
+        assert all(torch.isfinite(t.float()).all() for t in out), mode
+        if mode == 0:
+            base = out
+            g, u = (x.float() @ wgu.float().t()).split(I, dim=1)
+            check(out[1], F.silu(g) * u, 8e-3, "swiglu act")
+            check(out[3], x.float() @ wo.float().t() + res, 2e-5, "f32res")
+        else:
+            for t0, t1, tol in zip(base, out, (8e-3, 8e-3, 1.6e-2, 2e-5)):
+                check(t1, t0, tol, f"fused epilogue under sched {mode}")

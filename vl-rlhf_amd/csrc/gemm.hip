@@ -325,14 +325,37 @@ static int g_splitk_nstream = 0;
 extern "C" int vlr_gemm_set_splitk_workspace(void* ws, long bytes) {
     VLR_REQUIRE((ws && bytes > 0) || (!ws && bytes == 0), "vlr_gemm_set_splitk_workspace: (ptr, bytes) or (NULL, 0)");
     g_splitk_ws = (float*)ws;
-    // slots of 64 MiB (covers the 7B shapes), one per stream, at most 8; a smaller buffer is cut in two
-    int n = (int)(bytes / SPLITK_SLOT_BYTES);
+    // slots of 128 MiB (split-K partials of the 7B shapes in the first 64 MiB; the stream-K / rotation slabs of the persistent GEMM
+    // kernels - gemm.h, GemmParams::sched - use all of it), one per stream, at most 8; below 256 MiB: 64 MiB slots (no slabs: the
+    // persistent kernels then run plain rounds); a still smaller buffer is cut in two
+    int n = (int)(bytes / VLR_SK_WS_BYTES);
     if (n > SPLITK_MAX_SLOTS) n = SPLITK_MAX_SLOTS;
-    if (n >= 2) { g_splitk_nslots = n; g_splitk_bytes = SPLITK_SLOT_BYTES; }
-    else { g_splitk_nslots = ws ? 2 : 0; g_splitk_bytes = (bytes / 2) & ~255L; }
+    if (n >= 2) {
+        g_splitk_nslots = n; g_splitk_bytes = VLR_SK_WS_BYTES;
+        for (int i = 0; i < n; ++i)        // flags = "published at launch epoch e"; epochs start at 1 and never repeat
+            if (hipMemset((char*)ws + (size_t)i * VLR_SK_WS_BYTES + VLR_SK_FLAG_OFF, 0, 64 << 10) != hipSuccess) { g_splitk_nslots = 0; break; }
+    } else {
+        n = (int)(bytes / SPLITK_SLOT_BYTES);
+        if (n > SPLITK_MAX_SLOTS) n = SPLITK_MAX_SLOTS;
+        if (n >= 2) { g_splitk_nslots = n; g_splitk_bytes = SPLITK_SLOT_BYTES; }
+        else { g_splitk_nslots = ws ? 2 : 0; g_splitk_bytes = (bytes / 2) & ~255L; }
+    }
     g_splitk_nstream = 0;
     return VLR_OK;
 }
+// persistent schedule of the continuous-pipeline GEMM kernels (GemmParams::sched): bit 0 stream-K tail, bit 1 XCD rotation.
+// Default from VLR_GEMM_SCHED (else 0 until measured - see DESIGN.md); vlr_gemm_set_sched(-1) re-reads the environment.
+static int g_sched = -1;
+int vlr_gemm_sched_mode() {
+    if (g_sched < 0) { const char* e = getenv("VLR_GEMM_SCHED"); g_sched = e ? (atoi(e) & 3) : VLR_SCHED_DEFAULT; }
+    return g_sched;
+}
+extern "C" int vlr_gemm_set_sched(int mode) {
+    VLR_REQUIRE(mode >= -1 && mode <= 3, "vlr_gemm_set_sched: mode 0..3 (bit 0 stream-K tail, bit 1 XCD rotation) or -1, got %d", mode);
+    g_sched = mode;
+    return VLR_OK;
+}
+static uint32_t g_sk_epoch = 0;
 // Which split a GEMM takes must not depend on which OTHER streams happened to run split-K GEMMs earlier in the process: the
 // reference pass (side stream) and the policy pass (main stream) of one step have to produce bit-identical results for
 // identical weights (policy == reference => loss == ln 2 exactly).  With two slots, a third stream - e.g. a new trainer's side
@@ -348,6 +371,12 @@ static float* splitk_slot(hipStream_t st) {
         return (float*)((char*)g_splitk_ws + (size_t)(g_splitk_nstream++) * g_splitk_bytes);
     }
     return nullptr;
+}
+float* vlr_gemm_sk_workspace(hipStream_t stream, uint32_t* epoch) {
+    if (g_splitk_bytes < VLR_SK_WS_BYTES) return nullptr;
+    float* ws = splitk_slot(stream);
+    if (ws) *epoch = ++g_sk_epoch;
+    return ws;
 }
 // split-K launch of the 128x128 kernel: few output tiles, long reduction.  Returns false when it does not apply.
 static bool launch_splitk128(int layout, GemmParams p, hipStream_t stream, int min_k) {
@@ -388,9 +417,11 @@ static int gemm_impl(int layout, const void* A, const void* B, void* C, const vo
 
 // wave quantisation (see gemm_impl): how many of the last 256-row tile rows to peel off so that the 256x256-tile part is a
 // whole number of rounds on the 256 CUs; tn = workgroup tiles per tile row
-static int choose_peel(int M, int N, int tn) {
+static int choose_peel(int M, int N, int tn, int K = 0, hipStream_t stream = nullptr) {
     const int tm256 = (M + 255) / 256;
     int peel = 0;
+    // stream-K tail (GemmParams::sched bit 0): the persistent kernel balances its last rounds itself - every row takes the same path
+    if ((vlr_gemm_sched_mode() & 1) && K >= VLR_SK_MIN_KTILES * 64 && g_splitk_bytes >= VLR_SK_WS_BYTES && splitk_slot(stream)) return 0;
     if ((long)tm256 * tn >= 512) {
         const int full = tm256 * tn;
         const double base = (double)((full + 255) / 256);
@@ -455,6 +486,7 @@ static int gemm_impl_ex(int layout, const void* A, const void* B, void* C, const
     p.f0 = p.f1 = nullptr;
     p.A2 = p.B2 = nullptr; p.lda2 = p.ldb2 = p.K2 = 0; p.seg_b0 = p.seg_b1 = 0x7fffffff; p.drop_key = 0; p.drop_thr = 0; p.drop_ld = 0;
     p.res_f32 = residual ? res_f32 : 0;
+    p.sched = 0; p.sk_ws = nullptr; p.sk_epoch = 0;
     const int pi = vlr_prof_begin(layout, 2.0 * M * N * K, stream);
     // ---- split-K for problems whose output is a handful of tiles but whose reduction is long: the LoRA adapter gradients
     // (TN: dB = dy^T u [out x r], dA = v^T x [r x in], reduction over all tokens) - 32..96 workgroups would leave most CUs idle
@@ -475,7 +507,9 @@ static int gemm_impl_ex(int layout, const void* A, const void* B, void* C, const
     static int split_on = -1;
     if (split_on < 0) { const char* e = getenv("VLR_GEMM_SPLIT"); split_on = (e && e[0] == '0') ? 0 : 1; }
     const int tm256 = (M + 255) / 256, tn256 = (N + 255) / 256;
-    const int peel = split_on ? choose_peel(M, N, tn256) : 0;
+    // (launches that take the per-tile kernel - bias, activation, accumulate, a bf16 residual - cannot use the stream-K tail: peel as before)
+    const bool sk_elig = !bias && !accumulate && act == ACT_NONE && (out_f32 || !residual);
+    const int peel = split_on ? choose_peel(M, N, tn256, sk_elig ? K : 0, stream) : 0;
     if (peel) {
         const int M1 = (tm256 - peel) * 256;
         GemmParams p1 = p, p2 = p;
@@ -530,6 +564,7 @@ static GemmParams fused_params(const void* A, const void* B, void* C, int M, int
     p.fuse = 0; p.store_c = 1; p.C2 = nullptr; p.ldc2 = 0; p.pos = nullptr; p.rope_cos = p.rope_sin = nullptr; p.max_pos = 0; p.rope_cols = 0;
     p.f0 = p.f1 = nullptr;
     p.A2 = p.B2 = nullptr; p.lda2 = p.ldb2 = p.K2 = 0; p.seg_b0 = p.seg_b1 = 0x7fffffff; p.drop_key = 0; p.drop_thr = 0; p.drop_ld = 0; p.res_f32 = 0;
+    p.sched = 0; p.sk_ws = nullptr; p.sk_epoch = 0;
     return p;
 }
 
@@ -569,7 +604,7 @@ static int gemm_swiglu_impl(const void* x, const void* wgu, void* gu, void* act,
     { int rc = seg_check("vlr_gemm_swiglu_lora", sg); if (rc != VLR_OK) return rc; }
     const bool seg = sg && sg->u;
     const int tn = (I + 127) / 128;
-    const int peel = choose_peel(M, 2 * I, tn);
+    const int peel = choose_peel(M, 2 * I, tn, seg ? 0 : K, stream);
     const int tm256 = (M + 255) / 256;
     const int M1 = peel ? (tm256 - peel) * 256 : M;
     GemmParams p = fused_params(x, wgu, gu, M1, 2 * I, K, ldx, K, 2 * I);
@@ -616,7 +651,7 @@ static int gemm_qkv_rope_impl(const void* x, const void* wqkv, void* qkv, const 
     int done = 0;
     if (head_dim == 128 && (!bias || !((uintptr_t)bias & 7))) {
         const int tn = (N + 255) / 256;
-        const int peel = choose_peel(M, N, tn);
+        const int peel = choose_peel(M, N, tn, seg ? 0 : K, stream);
         const int tm256 = (M + 255) / 256;
         const int M1 = peel ? (tm256 - peel) * 256 : M;
         GemmParams p = fused_params(x, wqkv, qkv, M1, N, K, ldx, K, N);
@@ -711,7 +746,7 @@ static int gemm_lora_impl(const void* x, int ldx, const void* W, void* y, int ld
     const SegArgs sg = {u, ldu, Bl, r, 0x7fffffff, 0x7fffffff};
     VLR_REQUIRE(r > 0 && r % 8 == 0 && ldu % 8 == 0 && ldu >= r, "vlr_gemm_lora: adapter segment r=%d ldu=%d", r, ldu);
     const int tn = (N + 255) / 256;
-    const int peel = choose_peel(M, N, tn);
+    const int peel = choose_peel(M, N, tn);          // (adapter-segment kernels run plain rounds)
     const int tm256 = (M + 255) / 256;
     const int M1 = peel ? (tm256 - peel) * 256 : M;
     GemmParams p = fused_params(x, W, y, M1, N, K, ldx, K, ldy);
@@ -743,7 +778,7 @@ extern "C" int vlr_gemm_swiglu_bwd(const void* dy, const void* wdown, void* gu, 
     VLR_REQUIRE(dy && wdown && gu && dact_ws, "vlr_gemm_swiglu_bwd: null operand");
     VLR_REQUIRE(M > 0 && I > 0 && H > 0 && I % 8 == 0 && H % 8 == 0, "vlr_gemm_swiglu_bwd: bad shape M=%d I=%d H=%d", M, I, H);
     const int tn = (I + 255) / 256;
-    const int peel = choose_peel(M, I, tn);
+    const int peel = choose_peel(M, I, tn, H, stream);
     const int tm256 = (M + 255) / 256;
     const int M1 = peel ? (tm256 - peel) * 256 : M;
     GemmParams p = fused_params(dy, wdown, dact_ws, M1, I, H, H, I, I);

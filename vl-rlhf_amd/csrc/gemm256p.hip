@@ -35,6 +35,10 @@
 #define BUF_BYTES (4 * HALF_BYTES)   // A-lo | A-hi | B-lo | B-hi
 #define C_STRIDE 528                 // bytes per row of the bf16 C image (256 cols + 16 B pad: conflict-free 8-byte writes)
 #define P_LDS_BYTES (256 * C_STRIDE)  // 132 KiB: the two K-tile buffers (128 KiB) / the epilogue's C image
+#define PTAB_PIECES 512                // capacity of the piece table behind them (8 ints per piece)
+#define PTAB_BYTES (PTAB_PIECES * 32)
+#define CONT_LDS_BYTES (2 * BUF_BYTES + PTAB_BYTES)      // dynamic LDS of the continuous-pipeline kernels
+#define TILE_LDS_BYTES (P_LDS_BYTES + PTAB_BYTES)        // ... of the per-tile kernels
 
 typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
@@ -229,33 +233,100 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     // 10-12 us per tile, measured (K sweep: 0.23 ms of fixed cost per 2304-tile launch).
     const int tiles_m = (p.M + PT - 1) / PT, tiles_n = FUSE == 1 ? ((p.N >> 1) + NW - 1) / NW : (p.N + PT - 1) / PT;
     const int nwg = tiles_m * tiles_n;
-    // tile `titer` of this workgroup -> (m0, n0); false when the workgroup has no such tile
-    auto tile_coords = [&](int titer, int& m0_, int& n0_) -> bool {
-        // gridDim == nwg: one tile per workgroup (any count); gridDim < nwg: persistent, gridDim is a multiple of 8
-        if (titer > 0 && (int)gridDim.x >= nwg) return false;
-        const int b = blockIdx.x, xcd = b & 7, idx = (b >> 3) + titer * ((int)gridDim.x >> 3);
-        const int q = nwg >> 3, rem = nwg & 7;
-        if (idx >= q + (xcd < rem ? 1 : 0)) return false;
-        const int pid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
-        const int GROUP = 8;
-        const int per_group = GROUP * tiles_n;
-        const int gid = pid / per_group;
-        const int first_m = gid * GROUP;
-        const int gsz = min(tiles_m - first_m, GROUP);
-        m0_ = (first_m + (pid % per_group) % gsz) * PT;
-        n0_ = ((pid % per_group) / gsz) * NW;
-        return true;
-    };
-    int parb = 0;                 // CONT: buffer parity of the current tile's K tile 0 (K tiles keep alternating across tiles)
+    // SEG: K tiles [0, nt1) come from (A, B), [nt1, nt) from the adapter pair (A2 columns of this tile's output block, B2)
+    const int nt1 = (p.K + PK - 1) / PK;
+    const int k2t = !SEG ? 0 : (FUSE == 1 ? 2 * p.K2 : p.K2);
+    const int nt = nt1 + (k2t + PK - 1) / PK;
+    // ---- the workgroup's list of PIECES: a piece = K tiles [kb, ke) of one output tile.  Plain rounds: piece i = tile (j + i * G8) of
+    // this XCD's tiles, whole K (j = blockIdx / 8, G8 = gridDim / 8).  GemmParams::sched adds (continuous pipeline only, K >= 1024):
+    //  bit 0, stream-K tail: the XCD's last T = G8 + (tiles % G8) tiles are not run as 1 full + 1 nearly empty round; their T * nt K
+    //         tiles are cut into G8 equal contiguous ranges (boundaries snapped off the first / last 4 K tiles of a tile), one per
+    //         workgroup, i.e. 1.x tile-times each.  A tile that straddles two ranges is FINISHED by workgroup j, which holds its head
+    //         [0, k) at the end of its range; workgroup j + 1 computed the tail [k, nt) at the start of its range, long before, and left
+    //         its fp32 accumulators in its slab (write-through stores, then a per-wave flag = launch epoch).  Fixed summation order:
+    //         head + tail - deterministic.
+    //  bit 1, XCD rotation: the workgroups of XCD x != 0 start their first tile at K tile x * nt / 8 (accumulators -> own slab) and run
+    //         its head [0, x * nt / 8) as their LAST piece: every later tile boundary of XCD x is shifted by x / 8 of a tile, so the
+    //         eight XCDs' C-store bursts are spread over the tile time instead of hitting the fabric together.
+    const int G8 = (int)gridDim.x >> 3, xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const bool persistent = (int)gridDim.x < nwg;                  // else: one tile per workgroup, gridDim == nwg (any count)
+    const int n_x = (nwg >> 3) + (xcd < (nwg & 7) ? 1 : 0);       // tiles of this XCD
+    const bool sk_ok = CONT && persistent && nt >= VLR_SK_MIN_KTILES && p.sk_ws != nullptr && n_x >= G8;
+    const bool sk_tail = sk_ok && (p.sched & 1) && (n_x % G8) != 0;
+    const int r_dp = sk_tail ? n_x / G8 - 1 : (persistent ? (n_x - jx + G8 - 1) / G8 : 1);   // whole-K tiles this workgroup runs first
+    int kr = 0;                                                    // rotation offset (K tiles); 0 = none
+    if (sk_ok && (p.sched & 2) && xcd != 0 && r_dp >= 1) {
+        kr = (xcd * nt) >> 3;
+        kr = kr < 4 ? 4 : (kr > nt - 4 ? nt - 4 : kr);
+    }
+    int tb[4] = {0, 0, 0, 0};                                     // boundaries of the tail pieces in (tail tile, K tile) units
+    int n_tp = 0, tail0 = 0;
+    if (sk_tail) {
+        tail0 = r_dp * G8;                                         // first local tile of the stream-K tail
+        const int U = (n_x - tail0) * nt;
+        int bb[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {                              // range [bound(jx), bound(jx + 1)) of this workgroup
+            const int i = jx + e;
+            int b = (i * U) / G8;                                  // < 2^31: at most 32 x (64 tiles x 1000 K tiles)
+            const int r = b % nt;
+            if (r < 4) b -= r; else if (nt - r < 4) b += nt - r;
+            bb[e] = i >= G8 ? U : b;
+        }
+        tb[0] = bb[0];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int s_ = tb[c];
+            int e_ = (s_ / nt + 1) * nt;
+            e_ = e_ < bb[1] ? e_ : bb[1];
+            tb[c + 1] = e_;
+            if (s_ < bb[1]) n_tp = c + 1;
+        }
+    }
+    // The piece list is written ONCE into LDS behind the K-tile buffers (lane l of wave 0 computes pieces l, l + 64, ...): the ~25
+    // scalars of the enumeration are dead before the K loop starts, an iteration reads its own and the next piece (two broadcast
+    // ds_reads) - kept live in SGPRs across the K loop they pushed the kernel into scratch.
+    const int npieces = __builtin_amdgcn_readfirstlane(r_dp + n_tp + (kr ? 1 : 0));
+    int* ptab = reinterpret_cast<int*>(smem + (CONT ? 2 * BUF_BYTES : P_LDS_BYTES));
+    if (t < 64) {
+        for (int i = t; i < npieces; i += 64) {
+            // piece i: whole-K tiles first (the first one rotated), then the stream-K tail pieces, then the head of the rotated tile
+            const int c = i - r_dp;
+            const int kind = i < r_dp ? 0 : (c < n_tp ? 1 : 2);
+            const int s_ = c <= 0 ? tb[0] : (c == 1 ? tb[1] : tb[2]), e_ = c <= 0 ? tb[1] : (c == 1 ? tb[2] : tb[3]);
+            const int tt = s_ / nt;
+            const int idx = kind == 0 ? jx + i * G8 : (kind == 1 ? tail0 + tt : jx);
+            const int q = nwg >> 3, rem = nwg & 7;
+            const int pid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+            const int GROUP = 8;
+            const int per_group = GROUP * tiles_n;
+            const int first_m = (pid / per_group) * GROUP;
+            const int gsz = min(tiles_m - first_m, GROUP);
+            const int kb_ = kind == 0 ? (i == 0 ? kr : 0) : (kind == 1 ? s_ - tt * nt : 0);
+            const int ke_ = kind == 1 ? e_ - tt * nt : (kind == 2 ? kr : nt);
+            ptab[i * 8 + 0] = (first_m + (pid % per_group) % gsz) * PT;
+            ptab[i * 8 + 1] = ((pid % per_group) / gsz) * NW;
+            ptab[i * 8 + 2] = kb_;
+            ptab[i * 8 + 3] = ke_;
+            ptab[i * 8 + 4] = kind == 0 ? ((i == 0 && kr) ? 4 : 0) : (kind == 1 ? ((kb_ > 0 ? 1 : 0) | (ke_ < nt ? 2 : 0)) : 8);
+        }
+    }
+    __syncthreads();
+    if (npieces <= 0) return;
+    int parb = 0;                 // CONT: buffer parity of the current piece's K tile 0 (K tiles keep alternating across pieces)
     for (int titer = 0;; ++titer) {
     // per-tile opaque copy of the lane id: keeps hipcc from hoisting every lane-derived address out of the tile loop (it did,
     // and spilled 100-200 bytes per lane into the K loop)
     int lane = lane0;
     asm volatile("" : "+v"(lane));
-    int m0, n0, m0n = 0, n0n = 0;
-    if (!tile_coords(titer, m0, n0)) break;
-    const bool has_next = CONT && tile_coords(titer + 1, m0n, n0n);
+#define RFL(x) __builtin_amdgcn_readfirstlane(x)
+    const int m0 = RFL(ptab[titer * 8 + 0]), n0 = RFL(ptab[titer * 8 + 1]), kb = RFL(ptab[titer * 8 + 2]);
+    const int ntp = RFL(ptab[titer * 8 + 3]) - kb, pfl = RFL(ptab[titer * 8 + 4]);
+    const bool has_next = CONT && titer + 1 < npieces;
+    const int tnx = has_next ? titer + 1 : titer;
+    const int m0n = RFL(ptab[tnx * 8 + 0]), n0n = RFL(ptab[tnx * 8 + 1]), kbn = RFL(ptab[tnx * 8 + 2]);
     const bool first = !CONT || titer == 0;
+    parb = RFL(parb);
 
     f32x4 acc[2][4][2][2];   // [A half a][16-row tile i][B half b][16-col tile j]
 #pragma unroll
@@ -269,10 +340,6 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[a][i][b][j][r] = 0.f;
 
-    // SEG: K tiles [0, nt1) come from (A, B), [nt1, nt) from the adapter pair (A2 columns of this tile's output block, B2)
-    const int nt1 = (p.K + PK - 1) / PK;
-    const int k2t = !SEG ? 0 : (FUSE == 1 ? 2 * p.K2 : p.K2);
-    const int nt = nt1 + (k2t + PK - 1) / PK;
     const int a2off = (!SEG || FUSE == 1) ? 0 : (n0 >= p.seg_b0 ? (n0 >= p.seg_b1 ? 2 : 1) : 0) * p.K2;
     // half h of K tile `tile`: 0 A-lo, 1 A-hi, 2 B-lo, 3 B-hi
     // diagnostics (template ABL via VLR_GEMM_ABLATE, NT only, timing only - results are wrong): 1 no DMA in the K loop,
@@ -293,16 +360,17 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     const bool ktail = (p.K % PK) != 0;          // only the last K tile can be partial: it takes the general (zero-filling) path
     const uint32_t lds_wave = (uint32_t)(uintptr_t)(lvoid_t*)smem + wave * 1024;
     // fastc = true: the caller guarantees tile < nt and that the tile is a full one (steady-state loop): no checks at all
+    // `tile` is relative to the piece: K tile kb + tile of this output tile; tile >= ntp: K tile kbn + (tile - ntp) of the NEXT piece
     auto stage = [&](int tile, auto hc, auto fastc) {
         constexpr int h = decltype(hc)::value;
         constexpr bool fast = decltype(fastc)::value;
         if constexpr (abl_dma) { if (in_loop) return; }
         if constexpr (!fast) {
-            if (tile >= nt) {
-                if constexpr (CONT) {      // the K loop runs on into the next output tile: its K tile (tile - nt), general path
+            if (tile >= ntp) {
+                if constexpr (CONT) {      // the K loop runs on into the next piece: its first K tiles, general path
                     if (!has_next) return;
                     char* dst = smem + ((tile + parb) & 1) * BUF_BYTES + h * HALF_BYTES;
-                    const int k0 = (tile - nt) * PK;
+                    const int k0 = (kbn + tile - ntp) * PK;
                     if constexpr (h < 2) {
                         if constexpr (A_KS) stage_ks(p.A, p.lda, m0n + h * 128, p.M, k0, p.K, zero16, dst, wave, lane);
                         else stage_kc(p.A, p.lda, m0n + h * 128, p.M, k0, p.K, zero16, dst, wave, lane);
@@ -315,19 +383,19 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
             }
         }
         if constexpr (SEG && !fast) {
-            if (tile >= nt1) {
+            if (kb + tile >= nt1) {
                 int ln = lane;                       // opaque per call: keeps the adapter-segment addresses out of the loop-invariant
                 asm volatile("" : "+v"(ln));         // set hipcc would otherwise carry (and spill) through the whole K loop
                 char* dst = smem + ((tile + parb) & 1) * BUF_BYTES + h * HALF_BYTES;
-                const int k0 = (tile - nt1) * PK;
+                const int k0 = (kb + tile - nt1) * PK;
                 if constexpr (h < 2) stage_kc(p.A2 + a2off, p.lda2, m0 + h * 128, p.M, k0, k2t, zero16, dst, wave, ln);
                 else stage_seg_b<FUSE>(p.B2, p.ldb2, n0, h - 2, p.N, k0, p.K2, zero16, dst, wave, ln);
                 return;
             }
         }
-        if (!fast && ktail && tile == nt - 1) {
+        if (!fast && ktail && kb + tile == nt - 1) {
             char* dst = smem + ((tile + parb) & 1) * BUF_BYTES + h * HALF_BYTES;
-            const int k0 = tile * PK;
+            const int k0 = (kb + tile) * PK;
             if constexpr (h < 2) {
                 if constexpr (A_KS) stage_ks(p.A, p.lda, m0 + h * 128, p.M, k0, p.K, zero16, dst, wave, lane);
                 else stage_kc(p.A, p.lda, m0 + h * 128, p.M, k0, p.K, zero16, dst, wave, lane);
@@ -339,11 +407,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
         }
         const uint32_t dst = lds_wave + ((tile + parb) & 1) * BUF_BYTES + h * HALF_BYTES;
         if constexpr (h < 2) {
-            const char* base = (const char*)p.A + (size_t)tile * stepA;
+            const char* base = (const char*)p.A + (size_t)(kb + tile) * stepA;
             lds_dma16_s(base, offA[h][0], dst);
             lds_dma16_s(base, offA[h][1], dst + 8192);
         } else {
-            const char* base = (const char*)p.B + (size_t)tile * stepB;
+            const char* base = (const char*)p.B + (size_t)(kb + tile) * stepB;
             lds_dma16_s(base, offB[h - 2][0], dst);
             lds_dma16_s(base, offB[h - 2][1], dst + 8192);
         }
@@ -360,7 +428,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
         stage(0, H_BLO{}, SLOW{}); stage(0, H_ALO{}, SLOW{}); stage(0, H_BHI{}, SLOW{}); stage(0, H_AHI{}, SLOW{});
         stage(1, H_BLO{}, SLOW{}); stage(1, H_ALO{}, SLOW{}); stage(1, H_BHI{}, SLOW{});
         // (from the second tile on the previous tile's stores are still in flight and vmcnt counts them too: wait for everything)
-        if (titer == 0 && nt >= 2) PWAIT_VM(6); else PWAIT_VM(0);
+        if (titer == 0 && ntp >= 2) PWAIT_VM(6); else PWAIT_VM(0);
         PBAR();
         if (wr == 1) PBAR();      // waves 4-7 run one barrier behind waves 0-3
     }
@@ -483,7 +551,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
         // ---------------- phase 4: no reads; stage B-hi of tile kt+2; the counted wait that makes tile kt+1 resident
         stage(kt + 2, H_BHI{}, fastc);
         PFENCE();
-        if (decltype(fastc)::value || kt + 2 < nt || (CONT && has_next)) PWAIT_VM(6); else PWAIT_VM(0);
+        if (decltype(fastc)::value || kt + 2 < ntp || (CONT && has_next)) PWAIT_VM(6); else PWAIT_VM(0);
         LBAR();
         PMFMA(fa1, fb0, 1, 0);
         LBAR();
@@ -494,12 +562,73 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
         flip = -flip;
     };
     // steady state: every staged tile (kt+1, kt+2) exists and is full -> no checks, no K-tail path in the hot loop
-    const int n_fast = (SEG ? nt1 : nt) - 2 - (ktail ? 1 : 0);     // SEG: K % 64 == 0, the adapter tiles take the general path
+    // (absolute K tiles kb + kt + 2 below `lim` are whole tiles of (A, B); SEG: K % 64 == 0, the adapter tiles take the general path)
+    const int lim = (SEG ? nt1 : nt) - (ktail ? 1 : 0) - kb;
+    const int n_fast = (ntp < lim ? ntp : lim) - 2;
     int kt = 0;
     for (; kt < n_fast; ++kt) ktile(kt, FAST{});
-    for (; kt < nt; ++kt) ktile(kt, SLOW{});
+    for (; kt < ntp; ++kt) ktile(kt, SLOW{});
 #undef PMFMA
-    if constexpr (CONT && FUSE == 1) {
+    // ---- stream-K / rotation hand-off of the fp32 accumulators (GemmParams::sched).  Slab = this wave's 128 accumulator registers as
+    // 64 x (64 lanes x 8 B): fully coalesced, agent-scope write-through stores / loads (sc1) - no fence, no barrier: wave w of the
+    // finishing workgroup needs only what wave w of its partner wrote, so the flag is per wave.
+    bool piece_done = false;
+    if constexpr (CONT) {
+        if (pfl) {
+            const bool own = (pfl & 12) != 0;
+            const int sblk = own ? (int)blockIdx.x : ((pfl & 1) ? (int)blockIdx.x - 8 : (int)blockIdx.x);   // partner slabs are indexed by the WRITER (block >= 8) - 8
+            unsigned long long* slab = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(p.sk_ws) + (own ? VLR_SK_SELF_OFF : 0)) +
+                                       ((size_t)sblk * 8 + wave) * (64 * 64) + lane;
+            unsigned int* flags = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(p.sk_ws) + VLR_SK_FLAG_OFF);
+            if (pfl & 5) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const int q = ((a * 4 + i) * 2 + b) * 2 + j;
+                                const f32x4 v = acc[a][i][b][j];
+                                const unsigned long long lo = (unsigned long long)__builtin_bit_cast(uint32_t, v[0]) | ((unsigned long long)__builtin_bit_cast(uint32_t, v[1]) << 32);
+                                const unsigned long long hi = (unsigned long long)__builtin_bit_cast(uint32_t, v[2]) | ((unsigned long long)__builtin_bit_cast(uint32_t, v[3]) << 32);
+                                __hip_atomic_store(slab + (2 * q) * 64, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                __hip_atomic_store(slab + (2 * q + 1) * 64, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                if (pfl & 1) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the slab has reached L2 before the flag says so
+                    if (lane == 0) __hip_atomic_store(flags + blockIdx.x * 8 + wave, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                piece_done = true;                                         // no epilogue: the finishing piece writes this tile
+            } else {
+                if (pfl & 2) {
+                    const unsigned int* fp = flags + (blockIdx.x + 8) * 8 + wave;
+                    while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch) __builtin_amdgcn_s_sleep(8);
+                }
+                // (fl & 2: the partner is block + 8, whose slab index is (block + 8) - 8 = this block's index - `slab` above)
+                const unsigned long long* rs = slab;
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const int q = ((a * 4 + i) * 2 + b) * 2 + j;
+                                const unsigned long long lo = __hip_atomic_load(rs + (2 * q) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                const unsigned long long hi = __hip_atomic_load(rs + (2 * q + 1) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                f32x4 t;
+                                t[0] = __builtin_bit_cast(float, (uint32_t)lo); t[1] = __builtin_bit_cast(float, (uint32_t)(lo >> 32));
+                                t[2] = __builtin_bit_cast(float, (uint32_t)hi); t[3] = __builtin_bit_cast(float, (uint32_t)(hi >> 32));
+                                acc[a][i][b][j] += t;                      // head (this piece) + tail (the slab): one fixed order
+                            }
+            }
+        }
+    }
+    if (piece_done) {
+    } else if constexpr (CONT && FUSE == 1) {
         // SwiGLU epilogue: acc[a][i][0][j] = gate, acc[a][i][1][j] = the matching up columns; act = silu(gate) * up from the fp32
         // accumulators (one rounding), gate | up stored for the backward only when asked
         bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
@@ -772,7 +901,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
       }
     }
     if constexpr (CONT) {
-        parb = (parb + nt) & 1;
+        parb = (parb + ntp) & 1;
         if (!has_next) {
             if (wr == 0) PBAR();  // balance the extra barrier of waves 4-7
             break;
@@ -920,6 +1049,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     quadrant(I1{}, I1{});
     }
     __syncthreads();              // every wave is done with the LDS image / patches before the next tile's DMA lands
+    if (titer + 1 >= npieces) break;            // (per-tile kernels: whole tiles only)
     }   // persistent tile loop
 }
 
@@ -943,13 +1073,26 @@ static bf16_t* gemm256p_zero16() {
     return z;
 }
 
-bool vlr_gemm256p_fused_try_launch(const GemmParams& p, hipStream_t stream) {
+// stream-K tail / XCD rotation of a persistent continuous-pipeline launch (GemmParams::sched): needs more tiles than workgroups, K >= 1024
+// and the caller's 128 MiB scratch slot for this stream; otherwise plain rounds
+static void sk_prepare(GemmParams& p, int ntiles, int grid, hipStream_t stream) {
+    p.sched = 0; p.sk_ws = nullptr; p.sk_epoch = 0;
+    const int mode = vlr_gemm_sched_mode();
+    if (!mode || ntiles <= grid || (grid & 7) || (p.K + PK - 1) / PK < VLR_SK_MIN_KTILES) return;
+    uint32_t ep = 0;
+    float* ws = vlr_gemm_sk_workspace(stream, &ep);
+    if (!ws) return;
+    p.sched = mode; p.sk_ws = ws; p.sk_epoch = ep;
+}
+
+bool vlr_gemm256p_fused_try_launch(const GemmParams& p_in, hipStream_t stream) {
+    GemmParams p = p_in;
     static int on = -1;
     if (on < 0) {
         const char* e = getenv("VLR_GEMM_FUSE");
         on = e ? atoi(e) : 3;               // bit 0 SwiGLU, bit 1 RoPE
-        hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, 0, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
-        hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, 0, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+        hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, 0, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, CONT_LDS_BYTES);
+        hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, 0, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, CONT_LDS_BYTES);
     }
     if (p.fuse == 3) return false;       // NN: vlr_gemm256p_swiglu_bwd_try_launch
     if (p.fuse < 1 || p.fuse > 2 || !((on >> (p.fuse - 1)) & 1)) return false;
@@ -963,9 +1106,10 @@ bool vlr_gemm256p_fused_try_launch(const GemmParams& p, hipStream_t stream) {
     if (p.fuse == 2 && (p.N % PT != 0 || p.rope_cols % PT != 0)) return false;
     if (p.fuse == 1 && ((p.N >> 1) % 8 != 0 || p.ldc2 % 8 != 0 || ((uintptr_t)p.C2 & 15))) return false;
     if ((((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.C) & 15) || p.lda % 8 != 0 || p.ldb % 8 != 0 || p.ldc % 8 != 0) return false;
+    sk_prepare(p, ntiles, n_cu, stream);
     const int pi = vlr_prof_begin(VLR_K_GEMM256P, 2.0 * p.M * p.N * p.K, stream);
-    if (p.fuse == 1) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 1>), dim3(n_cu), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
-    else hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 2>), dim3(n_cu), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
+    if (p.fuse == 1) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 1>), dim3(n_cu), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
+    else hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 2>), dim3(n_cu), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
     vlr_prof_end(pi, stream);
     return true;
 }
@@ -977,9 +1121,9 @@ bool vlr_gemm256p_seg_try_launch(const GemmParams& p, hipStream_t stream) {
     if (on < 0) {
         const char* e = getenv("VLR_GEMM_SEG");
         on = (e && e[0] == '0') ? 0 : 1;
-        hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, 0, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
-        hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, 0, true, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
-        hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, 0, true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+        hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, 0, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CONT_LDS_BYTES);
+        hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, 0, true, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CONT_LDS_BYTES);
+        hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, 0, true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CONT_LDS_BYTES);
     }
     if (!on || p.fuse < 0 || p.fuse > 2 || p.K2 <= 0 || !p.A2 || !p.B2) return false;
     bf16_t* zero16 = gemm256p_zero16();
@@ -999,9 +1143,9 @@ bool vlr_gemm256p_seg_try_launch(const GemmParams& p, hipStream_t stream) {
         if (p.fuse != 0 || p.ldc % 4 != 0 || (p.residual && (!p.res_f32 || p.ldr % 4 != 0 || ((uintptr_t)p.residual & 15)))) return false;
     } else if (p.residual && (p.res_f32 || p.fuse != 0 || p.ldr % 4 != 0 || ((uintptr_t)p.residual & 7) || (const void*)p.residual == (const void*)p.C)) return false;
     const int pi = vlr_prof_begin(VLR_K_GEMM256P, 2.0 * p.M * p.N * (p.K + p.K2), stream);
-    if (p.fuse == 0) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 0, true>), dim3(n_cu), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
-    else if (p.fuse == 1) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 1, true>), dim3(n_cu), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
-    else hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 2, true>), dim3(n_cu), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
+    if (p.fuse == 0) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 0, true>), dim3(n_cu), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
+    else if (p.fuse == 1) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 1, true>), dim3(n_cu), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
+    else hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 2, true>), dim3(n_cu), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
     vlr_prof_end(pi, stream);
     return true;
 }
@@ -1013,7 +1157,7 @@ bool vlr_gemm256p_dropacc_try_launch(const GemmParams& p, hipStream_t stream) {
     if (on < 0) {
         const char* e = getenv("VLR_GEMM_DROPACC");
         on = (e && e[0] == '0') ? 0 : 1;
-        hipFuncSetAttribute((const void*)gemm256p_kernel<false, true, 0, false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES);
+        hipFuncSetAttribute((const void*)gemm256p_kernel<false, true, 0, false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_LDS_BYTES);
     }
     if (!on || p.fuse != 6) return false;
     bf16_t* zero16 = gemm256p_zero16();
@@ -1023,18 +1167,19 @@ bool vlr_gemm256p_dropacc_try_launch(const GemmParams& p, hipStream_t stream) {
     if (ntiles < 192) return false;
     if ((((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.C) & 15) || p.lda % 8 != 0 || p.ldb % 8 != 0 || p.N % 8 != 0 || p.ldc % 8 != 0 || p.drop_ld % 8 != 0) return false;
     const int pi = vlr_prof_begin(VLR_K_GEMM256P, 2.0 * p.M * p.N * p.K, stream);
-    hipLaunchKernelGGL((gemm256p_kernel<false, true, 0, false, 6>), dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), P_LDS_BYTES, stream, p, (const bf16_t*)zero16);
+    hipLaunchKernelGGL((gemm256p_kernel<false, true, 0, false, 6>), dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), TILE_LDS_BYTES, stream, p, (const bf16_t*)zero16);
     vlr_prof_end(pi, stream);
     return true;
 }
 
 // d act = dy . Wdown (NN) with the SwiGLU backward in the epilogue: p.C2 = gate | up [M][2I] (in/out), p.N = I, p.C unused
-bool vlr_gemm256p_swiglu_bwd_try_launch(const GemmParams& p, hipStream_t stream) {
+bool vlr_gemm256p_swiglu_bwd_try_launch(const GemmParams& p_in, hipStream_t stream) {
+    GemmParams p = p_in;
     static int on = -1;
     if (on < 0) {
         const char* e = getenv("VLR_GEMM_FUSE");
         on = e ? ((atoi(e) >> 2) & 1) : 1;               // bit 2
-        hipFuncSetAttribute((const void*)gemm256p_kernel<false, true, 0, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+        hipFuncSetAttribute((const void*)gemm256p_kernel<false, true, 0, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, CONT_LDS_BYTES);
     }
     if (!on) return false;
     bf16_t* zero16 = gemm256p_zero16();
@@ -1043,21 +1188,23 @@ bool vlr_gemm256p_swiglu_bwd_try_launch(const GemmParams& p, hipStream_t stream)
     const int ntiles = ((p.M + PT - 1) / PT) * ((p.N + PT - 1) / PT);
     if (ntiles <= n_cu || p.K < 4 * PK) return false;
     if ((((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.C2) & 15) || p.lda % 8 != 0 || p.ldb % 8 != 0 || p.N % 8 != 0 || p.ldc2 % 8 != 0) return false;
+    sk_prepare(p, ntiles, n_cu, stream);
     const int pi = vlr_prof_begin(VLR_K_GEMM256P, 2.0 * p.M * p.N * p.K, stream);
-    hipLaunchKernelGGL((gemm256p_kernel<false, true, 0, true, 3>), dim3(n_cu), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
+    hipLaunchKernelGGL((gemm256p_kernel<false, true, 0, true, 3>), dim3(n_cu), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
     vlr_prof_end(pi, stream);
     return true;
 }
 
 int vlr_gemm256p_lmhead_parts(int V) { return ((V + PT - 1) / PT) * 4; }
 
-bool vlr_gemm256p_lmhead_try_launch(const GemmParams& p, hipStream_t stream) {
+bool vlr_gemm256p_lmhead_try_launch(const GemmParams& p_in, hipStream_t stream) {
+    GemmParams p = p_in;
     static int on = -1;
     if (on < 0) {
         const char* e = getenv("VLR_GEMM_FUSE");
         on = e ? ((atoi(e) >> 3) & 1) : 1;               // bit 3
-        hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, 0, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
-        hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, 0, true, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+        hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, 0, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, CONT_LDS_BYTES);
+        hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, 0, true, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, CONT_LDS_BYTES);
     }
     if (!on || (p.fuse != 4 && p.fuse != 5)) return false;
     bf16_t* zero16 = gemm256p_zero16();
@@ -1067,27 +1214,30 @@ bool vlr_gemm256p_lmhead_try_launch(const GemmParams& p, hipStream_t stream) {
     if (ntiles <= n_cu || p.K < 4 * PK) return false;
     if ((((uintptr_t)p.A | (uintptr_t)p.B) & 15) || p.lda % 8 != 0 || p.ldb % 8 != 0 || p.N % 8 != 0) return false;
     if (p.fuse == 5 && (p.ldc % 8 != 0 || ((uintptr_t)p.C & 15))) return false;
+    sk_prepare(p, ntiles, n_cu, stream);
     const int pi = vlr_prof_begin(VLR_K_GEMM256P, 2.0 * p.M * p.N * p.K, stream);
-    if (p.fuse == 4) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 4>), dim3(n_cu), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
-    else hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 5>), dim3(n_cu), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
+    if (p.fuse == 4) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 4>), dim3(n_cu), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
+    else hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 5>), dim3(n_cu), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
     vlr_prof_end(pi, stream);
     return true;
 }
 
 // returns false when the problem does not qualify (caller falls back to the staggered / 128x128 kernels)
-bool vlr_gemm256p_try_launch(int layout, const GemmParams& p, hipStream_t stream) {
+bool vlr_gemm256p_try_launch(int layout, const GemmParams& p_in, hipStream_t stream) {
+    GemmParams p = p_in;
+    p.sched = 0; p.sk_ws = nullptr; p.sk_epoch = 0;
     static int mode = -1;
     static bf16_t* zero16 = nullptr;
     if (mode < 0) {
         const char* e = getenv("VLR_GEMM_8PHASE");
         mode = e ? atoi(e) : 7;            // bit 0 NT, bit 1 NN, bit 2 TN
         if (mode) {
-            hipFuncSetAttribute((const void*)gemm256p_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES);
-            hipFuncSetAttribute((const void*)gemm256p_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES);
-            hipFuncSetAttribute((const void*)gemm256p_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES);
-            hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
-            hipFuncSetAttribute((const void*)gemm256p_kernel<false, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
-            hipFuncSetAttribute((const void*)gemm256p_kernel<true, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+            hipFuncSetAttribute((const void*)gemm256p_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_LDS_BYTES);
+            hipFuncSetAttribute((const void*)gemm256p_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_LDS_BYTES);
+            hipFuncSetAttribute((const void*)gemm256p_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_LDS_BYTES);
+            hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CONT_LDS_BYTES);
+            hipFuncSetAttribute((const void*)gemm256p_kernel<false, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CONT_LDS_BYTES);
+            hipFuncSetAttribute((const void*)gemm256p_kernel<true, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CONT_LDS_BYTES);
             if (hipMalloc((void**)&zero16, 256) != hipSuccess || hipMemset(zero16, 0, 256) != hipSuccess) mode = 0;
         }
     }
@@ -1115,8 +1265,8 @@ bool vlr_gemm256p_try_launch(int layout, const GemmParams& p, hipStream_t stream
     static int abl = -1;
     if (abl < 0) { const char* e = getenv("VLR_GEMM_ABLATE"); abl = e ? atoi(e) : 0; }
     if (layout == 0 && abl) {
-#define PABL(n) case n: hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, n>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES); \
-        hipLaunchKernelGGL((gemm256p_kernel<false, false, n>), dim3(tiles), dim3(512), P_LDS_BYTES, stream, p, (const bf16_t*)zero16); return true;
+#define PABL(n) case n: hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, n>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_LDS_BYTES); \
+        hipLaunchKernelGGL((gemm256p_kernel<false, false, n>), dim3(tiles), dim3(512), TILE_LDS_BYTES, stream, p, (const bf16_t*)zero16); return true;
         switch (abl) { PABL(1) PABL(4) PABL(5) PABL(8) default: break; }   // 2, 3, 6, 7 (no fragment reads) spill; 8 = no epilogue
 #undef PABL
     }
@@ -1140,15 +1290,16 @@ bool vlr_gemm256p_try_launch(int layout, const GemmParams& p, hipStream_t stream
     const bool f32_ok = p.out_f32 && f32_cont && (!p.residual || (p.res_f32 && p.ldr % 4 == 0 && !((uintptr_t)p.residual & 15))) && p.ldc % 4 == 0 && p.N % 4 == 0;
     if (cont && ntiles > tiles && !p.bias && (p.out_f32 ? f32_ok : (res_ok && !p.res_f32)) && !p.accumulate && p.act == ACT_NONE && p.K >= 4 * PK &&
         (p.out_f32 || (p.ldc % 8 == 0 && p.N % 8 == 0)) && !((uintptr_t)p.C & 15)) {
-        if (layout == 0) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true>), dim3(tiles), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
-        else if (layout == 1) hipLaunchKernelGGL((gemm256p_kernel<false, true, 0, true>), dim3(tiles), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
-        else hipLaunchKernelGGL((gemm256p_kernel<true, true, 0, true>), dim3(tiles), dim3(512), 2 * BUF_BYTES, stream, p, (const bf16_t*)zero16);
+        sk_prepare(p, ntiles, tiles, stream);
+        if (layout == 0) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true>), dim3(tiles), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
+        else if (layout == 1) hipLaunchKernelGGL((gemm256p_kernel<false, true, 0, true>), dim3(tiles), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
+        else hipLaunchKernelGGL((gemm256p_kernel<true, true, 0, true>), dim3(tiles), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
         vlr_prof_end(pi, stream);
         return true;
     }
-    if (layout == 0) hipLaunchKernelGGL((gemm256p_kernel<false, false>), dim3(tiles), dim3(512), P_LDS_BYTES, stream, p, (const bf16_t*)zero16);
-    else if (layout == 1) hipLaunchKernelGGL((gemm256p_kernel<false, true>), dim3(tiles), dim3(512), P_LDS_BYTES, stream, p, (const bf16_t*)zero16);
-    else hipLaunchKernelGGL((gemm256p_kernel<true, true>), dim3(tiles), dim3(512), P_LDS_BYTES, stream, p, (const bf16_t*)zero16);
+    if (layout == 0) hipLaunchKernelGGL((gemm256p_kernel<false, false>), dim3(tiles), dim3(512), TILE_LDS_BYTES, stream, p, (const bf16_t*)zero16);
+    else if (layout == 1) hipLaunchKernelGGL((gemm256p_kernel<false, true>), dim3(tiles), dim3(512), TILE_LDS_BYTES, stream, p, (const bf16_t*)zero16);
+    else hipLaunchKernelGGL((gemm256p_kernel<true, true>), dim3(tiles), dim3(512), TILE_LDS_BYTES, stream, p, (const bf16_t*)zero16);
     vlr_prof_end(pi, stream);
     return true;
 }

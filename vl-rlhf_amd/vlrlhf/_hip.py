@@ -128,6 +128,7 @@ _INT_HELPERS = {
     "vlr_prof_enable": [I],
     "vlr_prof_collect": [P, I],
     "vlr_gemm_set_splitk_workspace": [P, L],
+    "vlr_gemm_set_sched": [I],
     "vlr_lmhead_is_fused": [I, I, I],
     "vlr_comm_unique_id_bytes": [],
     "vlr_comm_unique_id": [P],
@@ -238,11 +239,12 @@ _splitk_ws = None
 
 
 def ensure_splitk_workspace(device="cuda", force=False):
-    """process-wide fp32 scratch of the GEMM dispatcher's split-K path (include/vlr.h: two 64 MiB slots, one per stream);
+    """process-wide fp32 scratch of the GEMM dispatcher (include/vlr.h: split-K partials and the stream-K / rotation slabs of the
+    persistent kernels, one 128 MiB slot per stream);
     allocated once and never freed, so the pointer registered in the library cannot dangle."""
     global _splitk_ws
     if _splitk_ws is None:
-        _splitk_ws = torch.empty(512 << 20, dtype=torch.uint8, device=device)      # eight 64 MiB slots, one per stream
+        _splitk_ws = torch.empty(1 << 30, dtype=torch.uint8, device=device)        # eight 128 MiB slots, one per stream
         force = True
     if force:
         rc = lib().vlr_gemm_set_splitk_workspace(_splitk_ws.data_ptr(), _splitk_ws.numel())
