@@ -35,7 +35,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2516.6          # 256 CU x 4096 FLOP/clk/CU x 2.4 GHz (MI355X_MICROARCH.md: ~2.5 PF dense)
-PROFILE_FILE = "profiles/r02_rocprofv3_kernel_stats_bench.csv"   # rocprofv3 --kernel-trace --stats of this command; `frac` can be recomputed from it
+PROFILE_FILE = "profiles/r03_rocprofv3_kernel_stats_bench.csv"   # rocprofv3 --kernel-trace --stats of this command; `frac` can be recomputed from it
 TFLOP_PER_PAIR = {"ref_in_step": 174.87, "ref_precomputed": 131.24}
 
 
@@ -313,11 +313,13 @@ def main():
     # HBM traffic of the dominant kernel: PMC passes cannot run inside the timed region; the committed rocprofv3 --pmc
     # result (profiles/r02_pmc_hbm_traffic.*, tools/pmc_traffic.sh) is quoted when present
     traffic = None
-    tf = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
-    if not os.path.exists(tf):
-        tf = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_8phase.json")
-    if os.path.exists(tf):
-        traffic = round(json.load(open(tf))["gemm_hbm_bytes_per_launch"])
+    traffic_file = None
+    for name in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic_8phase.json"):
+        tf = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(tf):
+            traffic = round(json.load(open(tf))["gemm_hbm_bytes_per_launch"])
+            traffic_file = "profiles/" + name
+            break
     # roofline of the DOMINANT kernel: the 8-phase 256x256 GEMM alone (its launches are timed under their own id; the
     # gemm_nt/nn/tn entries of per_kernel are whole vlr_gemm_bf16 calls incl. peeled rows and split-K reduces)
     g_n, g_ms, g_flop = prof["gemm256p"]
@@ -330,7 +332,9 @@ def main():
     Nqkv_ = eng.Nqkv
     for m_, n_, k_ in ((M_, Nqkv_, H_), (M_, H_, eng.Nq), (M_, 2 * I_, H_), (M_, H_, I_)):
         g_bytes += per_shape * (m_ * k_ + n_ * k_ + m_ * n_)
-    per_kernel = {k: {"launches": n, "ms": round(ms, 2), "tflops": round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else 0.0}
+    # every entry with its own fraction of the nominal bf16 MFMA peak (attention included: the kernels furthest below it)
+    per_kernel = {k: {"launches": n, "ms": round(ms, 2), "tflops": round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else 0.0,
+                      "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if ms > 0 else 0.0}
                   for k, (n, ms, fl) in prof.items()}
     pairs_per_s = world * a.pairs * a.steps / dt
     per_pair = TFLOP_PER_PAIR["ref_precomputed" if a.precomputed_ref else "ref_in_step"]
@@ -361,10 +365,11 @@ def main():
                      "exposed_ms_per_step": exposed_ms, "bytes_per_step": 2 * (eng.lora_layout.numel if a.lora else eng.layout.numel)},
             "roofline": {"bound": "mfma", "kernel": "gemm256p_kernel<A_KS,B_KS> (8-phase 256x256x64 bf16 GEMM: NT/NN/TN)", "achieved": round(achieved, 1),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                         "traffic": traffic, "traffic_unit": "bytes/launch leaving L2 (2*FETCH_SIZE+WRITE_SIZE, rocprofv3 --pmc, offline pass; A+B of a decoder GEMM fit the 256 MB Infinity Cache, so most of the re-reads never reach HBM)",
+                         "traffic": traffic, "traffic_source": traffic_file, "traffic_unit": "bytes/launch leaving L2 (2*FETCH_SIZE+WRITE_SIZE, rocprofv3 --pmc, OFFLINE pass of tools/pmc_traffic.sh with the same binary - counters cannot be collected inside the timed region; A+B of a decoder GEMM fit the 256 MB Infinity Cache, so most of the re-reads never reach HBM)",
                          "algorithmic_bytes_per_launch": round(2.0 * g_bytes / max(1, g_dec)), "launches": g_n, "avg_launch_ms": round(g_ms / max(1, g_n), 4), "event_sampling": f"one launch in {max(1, a.prof_sample)} bracketed by HIP events (pseudo-random per kernel id); launches and FLOPs exact, ms = sampled mean x launches", "per_kernel": per_kernel,
                          "profile_file": PROFILE_FILE,
                          "kernel_share_of_step": round(g_ms * 1e-3 / dt, 3), "all_gemm_share_of_step": round(all_ms * 1e-3 / dt, 3),
+                         "share_note": "kernel_share = the 256x256 kernel's launches alone; all_gemm_share = every vlr_gemm_* call by layout (fused launches, peeled rows and split-K reduces included), so all_gemm_share >= kernel_share",
                          "step_frac": round(pairs_per_s / world * per_pair / PEAK_BF16_TFLOPS, 4),
                          "step_frac_note": "algorithmic TFLOP per pair of SURVEY.md 8d (lm-head counted on all S positions; the kernel evaluates it on the response rows only, ~1.3 % fewer executed FLOPs) / nominal 2516.6 TF/s; this chip sustains 1828 TF/s on random bf16 operands in a register-only MFMA loop (profiles/r02_gemm_ceiling_mfma_only_and_ablation.txt)"},
         }

@@ -185,6 +185,10 @@ int vlr_merge_index(const long* input_ids, const long* attention_mask, const lon
                     long* out_labels, int* out_pos, unsigned char* img_map, int* inv_map, int* info, vlr_stream_t stream);
 int vlr_merge_fwd(const int* src, const long* input_ids, const void* embed_table, const void* feats, void* out, int Bn,
                   int T, int S, int H, vlr_stream_t stream);
+/* the same into an fp32 residual stream (vlr_llama_cfg.resid_f32): out fp32 [Bn][S][H]; embed_table bf16 (rows widened exactly);
+ * feats fp32 [rows][H] when feats_f32 (the projector's unrounded output), else bf16 */
+int vlr_merge_fwd_f32(const int* src, const long* input_ids, const void* embed_table, const void* feats, int feats_f32, float* out,
+                      int Bn, int T, int S, int H, vlr_stream_t stream);
 int vlr_merge_bwd(const void* dmerged, const int* src, const int* inv_map, const long* input_ids, void* dfeats,
                   void* dembed_table, int Bn, int T, int S, int H, int n_feat_rows, int dup, vlr_stream_t stream);
 
@@ -338,6 +342,13 @@ int vlr_vit_layer_fwd(const vlr_vit_cfg* cfg, const vlr_vit_layer_weights* w, co
  *      bytes on rank 0; the launcher carries them to every rank; vlr_comm_init blocks until all `world` ranks called
  *      it.  vlr_allreduce_bucket: in-place SUM over one contiguous slice of the flat gradient buffer, enqueued on
  *      `stream` (dtype 0 = bf16, 1 = fp32); 1/world is folded into the optimizer's gradient scale. */
+/* vlr_set_comm_cus(k): the persistent GEMM / attention launches leave k CUs (rounded up to whole XCD octets) to the RCCL kernels
+ * that run beside the backward (default: environment VLR_COMM_CUS, else 0); vlr_compute_cus() = what is left for them.
+ * vlr_comm_probe: diagnostics only - a streaming copy src -> dst of n bytes on exactly `wgs` workgroups, the stand-in for one RCCL
+ * ring kernel in the single-GPU interference bench (tools/comm_interference.py); no communicator involved. */
+int vlr_set_comm_cus(int k);
+int vlr_compute_cus(void);
+int vlr_comm_probe(const void* src, void* dst, long n_bytes, int wgs, vlr_stream_t stream);
 int vlr_comm_unique_id_bytes(void);
 const char* vlr_comm_library(void);   /* path of the RCCL library in use ("" + vlr_last_error() when none loads) */
 int vlr_comm_unique_id(void* id_host);

@@ -43,6 +43,9 @@ VARIANTS = [
     ("hip_f32resid", MFMA_OPERANDS | {"vit", "v"}, "what the HIP path rounds with the fp32 residual stream (round 3): MFMA operands + v + the vision tower"),
     ("f32resid-hidden", (MFMA_OPERANDS | {"vit", "v"}) - {"hidden"}, "hip_f32resid with an unrounded hidden state into the lm-head"),
     ("f32resid-vit", MFMA_OPERANDS | {"v"}, "hip_f32resid with an exact vision tower + projector"),
+    ("f32resid+vit_f32", MFMA_OPERANDS | {"v", "vit_op"}, "hip_f32resid with an fp32 residual stream inside the ViT and an fp32 projector output (operands still bf16)"),
+    ("f32resid+vit_f32resid", MFMA_OPERANDS | {"v", "vit_op", "vit_out"}, "... fp32 residual stream inside the ViT only (projector output rounded)"),
+    ("f32resid+vit_f32out", MFMA_OPERANDS | {"v", "vit_op", "vit_resid"}, "... fp32 projector output only (bf16 residual stream inside the ViT)"),
     ("only_xn", frozenset(("xn",)), "RMSNorm outputs (A operand of the q|k|v and gate|up GEMMs) only"),
     ("only_ropev", frozenset(("rope", "v")), "q / k after RoPE and v (the attention operands) only"),
     ("only_p", frozenset(("p",)), "softmax probabilities (A operand of P.V) only"),

@@ -118,7 +118,11 @@ def clip_vit_features(pixel_values, W: Dict[str, torch.Tensor], cfg: dict, emula
                       prefix="vision_tower.vision_model."):
     """hidden_states[-2] of the CLIP ViT with the CLS token dropped (Llava/__init__.py:178-183).  Pre-LN encoder:
     x += out_proj(attn(LN1(x))); x += fc2(quick_gelu(fc1(LN2(x)))).  Only layers 0..L-2 are evaluated."""
-    r = lambda t: _rt(t, emulate_bf16, "vit")  # noqa: E731
+    # tag "vit" = the whole tower + projector; finer (error-budget runs): "vit_op" MFMA operands only, "vit_resid" the tower's residual
+    # stream, "vit_out" the projector output (= the image rows of the merged embeddings)
+    whole = (emulate_bf16 is True) or (isinstance(emulate_bf16, (set, frozenset)) and "vit" in emulate_bf16)
+    r = lambda t: _rt(t, True if whole else emulate_bf16, "vit_op")  # noqa: E731
+    rr = lambda t: _rt(t, True if whole else emulate_bf16, "vit_resid")  # noqa: E731
     B = pixel_values.shape[0]
     D, P, nh = cfg["vit_hidden"], cfg["patch_size"], cfg["vit_heads"]
     g = cfg["image_size"] // P
@@ -128,7 +132,7 @@ def clip_vit_features(pixel_values, W: Dict[str, torch.Tensor], cfg: dict, emula
     cls = W[prefix + "embeddings.class_embedding"].reshape(1, 1, D).expand(B, 1, D)
     x = torch.cat([cls, x], dim=1) + W[prefix + "embeddings.position_embedding.weight"][None]
     eps = cfg.get("vit_ln_eps", 1e-5)
-    x = r(F.layer_norm(x, (D,), W[prefix + "pre_layrnorm.weight"], W[prefix + "pre_layrnorm.bias"], eps))
+    x = rr(F.layer_norm(x, (D,), W[prefix + "pre_layrnorm.weight"], W[prefix + "pre_layrnorm.bias"], eps))
     hd = D // nh
     n_eval = cfg["vit_layers"] + 1 + cfg.get("vit_feature_layer", -2)   # vision_feature_layer = -2 (LLaVA); -1 = every layer (InternLM-XC2)
     for i in range(n_eval):
@@ -141,18 +145,19 @@ def clip_vit_features(pixel_values, W: Dict[str, torch.Tensor], cfg: dict, emula
         q, k, v = (t.reshape(B, T, nh, hd).transpose(1, 2) for t in (q, k, v))
         a = torch.softmax((q @ k.transpose(-1, -2)) * (hd ** -0.5), dim=-1) @ v
         a = r(a.transpose(1, 2).reshape(B, T, D))
-        x = r(x + (a @ r(W[p + "self_attn.out_proj.weight"]).t() + W[p + "self_attn.out_proj.bias"]))
+        x = rr(x + (a @ r(W[p + "self_attn.out_proj.weight"]).t() + W[p + "self_attn.out_proj.bias"]))
         h = r(F.layer_norm(x, (D,), W[p + "layer_norm2.weight"], W[p + "layer_norm2.bias"], eps))
         h = r(quick_gelu(h @ r(W[p + "mlp.fc1.weight"]).t() + W[p + "mlp.fc1.bias"]))
-        x = r(x + (h @ r(W[p + "mlp.fc2.weight"]).t() + W[p + "mlp.fc2.bias"]))
+        x = rr(x + (h @ r(W[p + "mlp.fc2.weight"]).t() + W[p + "mlp.fc2.bias"]))
     return x[:, 1:]
 
 
 def projector(feat, W, emulate_bf16=False, prefix="multi_modal_projector."):
     """Linear -> GELU(erf) -> Linear (transformers LlavaMultiModalProjector; call site Llava/__init__.py:191)."""
-    r = lambda t: _rt(t, emulate_bf16, "vit")  # noqa: E731
+    whole = (emulate_bf16 is True) or (isinstance(emulate_bf16, (set, frozenset)) and "vit" in emulate_bf16)
+    r = lambda t: _rt(t, True if whole else emulate_bf16, "vit_op")  # noqa: E731
     h = r(F.gelu(r(feat) @ r(W[prefix + "linear_1.weight"]).t() + W[prefix + "linear_1.bias"]))
-    return r(h @ r(W[prefix + "linear_2.weight"]).t() + W[prefix + "linear_2.bias"])
+    return _rt(h @ r(W[prefix + "linear_2.weight"]).t() + W[prefix + "linear_2.bias"], True if whole else emulate_bf16, "vit_out")
 
 
 # ----------------------------------------------------------------------------------------------------------

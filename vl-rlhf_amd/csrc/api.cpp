@@ -70,7 +70,7 @@ extern "C" int vlr_prof_collect(double* out, int nk) {
     for (auto& r : g_prof) {
         hipEventSynchronize(r.b);
         float ms = 0.f;
-        hipEventElapsedTime(&ms, r.a, r.b);
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;     // a bracket whose launch was declined (end never recorded)
         ms_sum[r.kernel] += ms; n_sampled[r.kernel] += 1.0;
     }
     for (int k = 0; k < nk && k < VLR_PROF_KERNELS; ++k) {
@@ -79,4 +79,26 @@ extern "C" int vlr_prof_collect(double* out, int nk) {
         out[k * 3 + 2] = g_prof_work[k];
     }
     return VLR_OK;
+}
+
+// ---- CUs left to the compute kernels.  The persistent GEMM / attention launches size their grids to this many CUs (whole XCD
+// octets): under data parallelism the RCCL ring kernels of the gradient exchange run beside the backward, and a persistent launch
+// that fills every CU is displaced by them workgroup by workgroup (every displaced workgroup is a tail on a 256-workgroup launch -
+// DESIGN.md section 5).  vlr_set_comm_cus(k) / VLR_COMM_CUS=k leaves k CUs (rounded up to a multiple of 8: one per XCD) free.
+#include <stdlib.h>
+static int g_comm_cus = -1;
+extern "C" int vlr_set_comm_cus(int k) {
+    VLR_REQUIRE(k >= -1 && k <= 128, "vlr_set_comm_cus: 0 <= k <= 128 (or -1: back to VLR_COMM_CUS / 0), got %d", k);
+    g_comm_cus = k;
+    return VLR_OK;
+}
+extern "C" int vlr_compute_cus(void) {
+    static int dev_cus = 0;
+    if (!dev_cus) {
+        int dev = 0, cus = 0;
+        dev_cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 8) ? cus : 256;
+    }
+    if (g_comm_cus < 0) { const char* e = getenv("VLR_COMM_CUS"); g_comm_cus = e ? atoi(e) : 0; if (g_comm_cus < 0 || g_comm_cus > 128) g_comm_cus = 0; }
+    int n = (dev_cus & ~7) - ((g_comm_cus + 7) & ~7);
+    return n < 8 ? 8 : n;
 }

@@ -1244,12 +1244,7 @@ extern "C" int vlr_attn_fwd_gqa(const void* q, const void* k, const void* v, int
     ag.epi = attn_epi_on();
     ag.lpt = attn_lpt_on();
     int fgrid = ag.grid(false);
-    static int resident = 0;                 // workgroups the chip holds at once: two per CU, whole XCD octets
-    if (!resident) {
-        int dev = 0, cus = 0;
-        resident = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 8)
-                       ? 2 * (cus & ~7) : 512;
-    }
+    const int resident = 2 * vlr_compute_cus();       // workgroups the chip holds at once: two per CU, whole XCD octets (minus the CUs left to RCCL)
     ag.ctr = fgrid > resident ? attn_counters(st) : nullptr;   // more query blocks than that: persistent workgroups
     ag.items = fgrid / 8;
     if (ag.ctr) fgrid = resident;

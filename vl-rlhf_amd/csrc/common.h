@@ -22,6 +22,7 @@ void vlr_set_error(const char* fmt, ...);
 int vlr_check_launch(const char* what);
 // kernel ids for the in-library profiler (api.cpp)
 enum { VLR_K_GEMM_NT = 0, VLR_K_GEMM_NN = 1, VLR_K_GEMM_TN = 2, VLR_K_ATTN_FWD = 3, VLR_K_ATTN_BWD = 4, VLR_K_GEMM256P = 5, VLR_K_COUNT = 6 };
+extern "C" int vlr_compute_cus(void);      // CUs the persistent kernels may fill (api.cpp: device CUs - vlr_set_comm_cus, whole XCD octets)
 int vlr_prof_begin(int kernel, double work, hipStream_t st);
 void vlr_prof_end(int idx, hipStream_t st);
 

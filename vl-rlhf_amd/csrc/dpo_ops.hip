@@ -217,6 +217,36 @@ __global__ __launch_bounds__(256) void merge_gather_kernel(const int* __restrict
         *reinterpret_cast<u32x4*>(out + pos * H + c) = v;
     }
 }
+// the same for the fp32 residual stream: out fp32; embedding rows are bf16 (exact in fp32), feature rows fp32 (the projector's
+// unrounded output) or bf16 (feats_f32 = 0)
+__global__ __launch_bounds__(256) void merge_gather_f32_kernel(const int* __restrict__ src, const long* __restrict__ ids,
+                                                               const bf16_t* __restrict__ table, const void* __restrict__ feats,
+                                                               int feats_f32, float* __restrict__ out, int T, int S, int H) {
+    const size_t pos = blockIdx.x;
+    const int b = (int)(pos / S);
+    const int sv = src[pos];
+    const bf16_t* from16 = nullptr;
+    const float* from32 = nullptr;
+    if (sv >= 0) from16 = table + (size_t)ids[(size_t)b * T + sv] * H;
+    else if (sv != SRC_ZERO) {
+        if (feats_f32) from32 = reinterpret_cast<const float*>(feats) + (size_t)(-(sv + 1)) * H;
+        else from16 = reinterpret_cast<const bf16_t*>(feats) + (size_t)(-(sv + 1)) * H;
+    }
+    for (int c = threadIdx.x * 8; c < H; c += 256 * 8) {
+        f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+        if (from32) {
+            lo = *reinterpret_cast<const f32x4*>(from32 + c);
+            hi = *reinterpret_cast<const f32x4*>(from32 + c + 4);
+        } else if (from16) {
+            float v[8];
+            unpack8(*reinterpret_cast<const u32x4*>(from16 + c), v);
+            lo = f32x4{v[0], v[1], v[2], v[3]};
+            hi = f32x4{v[4], v[5], v[6], v[7]};
+        }
+        *reinterpret_cast<f32x4*>(out + pos * H + c) = lo;
+        *reinterpret_cast<f32x4*>(out + pos * H + c + 4) = hi;
+    }
+}
 // d_feats[f] = sum over the `dup` positions that consumed feature row f
 __global__ __launch_bounds__(256) void merge_bwd_feats_kernel(const bf16_t* __restrict__ dmerged,
                                                               const int* __restrict__ inv_map, bf16_t* __restrict__ dfeats,
@@ -551,6 +581,14 @@ extern "C" int vlr_merge_fwd(const int* src, const long* input_ids, const void* 
     hipLaunchKernelGGL(merge_gather_kernel, dim3(Bn * S), dim3(256), 0, st, src, input_ids, (const bf16_t*)embed_table,
                        (const bf16_t*)feats, (bf16_t*)out, T, S, H);
     return vlr_check_launch("vlr_merge_fwd");
+}
+extern "C" int vlr_merge_fwd_f32(const int* src, const long* input_ids, const void* embed_table, const void* feats, int feats_f32,
+                                 float* out, int Bn, int T, int S, int H, hipStream_t st) {
+    VLR_REQUIRE(src && input_ids && embed_table && out, "vlr_merge_fwd_f32: null argument");
+    VLR_REQUIRE(Bn > 0 && H % 8 == 0, "vlr_merge_fwd_f32: bad shape");
+    hipLaunchKernelGGL(merge_gather_f32_kernel, dim3(Bn * S), dim3(256), 0, st, src, input_ids, (const bf16_t*)embed_table, feats,
+                       feats_f32, out, T, S, H);
+    return vlr_check_launch("vlr_merge_fwd_f32");
 }
 extern "C" int vlr_merge_bwd(const void* dmerged, const int* src, const int* inv_map, const long* input_ids,
                              void* dfeats, void* dembed_table, int Bn, int T, int S, int H, int n_feat_rows, int dup,

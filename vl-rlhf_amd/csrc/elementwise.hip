@@ -759,3 +759,14 @@ extern "C" int vlr_rowdot(const void* X, const float* v, float* out, int M, int 
     hipLaunchKernelGGL(rowdot_kernel, dim3(M), dim3(256), 0, st, (const bf16_t*)X, v, out, H);
     return vlr_check_launch("vlr_rowdot");
 }
+
+// diagnostics (include/vlr.h vlr_comm_probe): what an RCCL ring kernel looks like to the compute kernels - a fixed, small number of
+// workgroups that stream a bucket through HBM for a while.  16 B per lane, grid-stride.
+__global__ __launch_bounds__(256) void comm_probe_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, long n16) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) dst[i] = src[i];
+}
+extern "C" int vlr_comm_probe(const void* src, void* dst, long n_bytes, int wgs, hipStream_t st) {
+    VLR_REQUIRE(src && dst && n_bytes > 0 && n_bytes % 16 == 0 && wgs > 0 && wgs <= 1024, "vlr_comm_probe: bad arguments");
+    hipLaunchKernelGGL(comm_probe_kernel, dim3(wgs), dim3(256), 0, st, (const u32x4*)src, (u32x4*)dst, n_bytes / 16);
+    return vlr_check_launch("vlr_comm_probe");
+}

@@ -347,11 +347,11 @@ extern "C" int vlr_gemm_set_splitk_workspace(void* ws, long bytes) {
 // Default from VLR_GEMM_SCHED (else 0 until measured - see DESIGN.md); vlr_gemm_set_sched(-1) re-reads the environment.
 static int g_sched = -1;
 int vlr_gemm_sched_mode() {
-    if (g_sched < 0) { const char* e = getenv("VLR_GEMM_SCHED"); g_sched = e ? (atoi(e) & 3) : VLR_SCHED_DEFAULT; }
+    if (g_sched < 0) { const char* e = getenv("VLR_GEMM_SCHED"); g_sched = e ? (atoi(e) & 7) : VLR_SCHED_DEFAULT; }
     return g_sched;
 }
 extern "C" int vlr_gemm_set_sched(int mode) {
-    VLR_REQUIRE(mode >= -1 && mode <= 3, "vlr_gemm_set_sched: mode 0..3 (bit 0 stream-K tail, bit 1 XCD rotation) or -1, got %d", mode);
+    VLR_REQUIRE(mode >= -1 && mode <= 7, "vlr_gemm_set_sched: mode 0..7 (bit 0 stream-K tail, bit 1 XCD rotation, bit 2 XCD round barrier) or -1, got %d", mode);
     g_sched = mode;
     return VLR_OK;
 }
@@ -422,15 +422,16 @@ static int choose_peel(int M, int N, int tn, int K = 0, hipStream_t stream = nul
     int peel = 0;
     // stream-K tail (GemmParams::sched bit 0): the persistent kernel balances its last rounds itself - every row takes the same path
     if ((vlr_gemm_sched_mode() & 1) && K >= VLR_SK_MIN_KTILES * 64 && g_splitk_bytes >= VLR_SK_WS_BYTES && splitk_slot(stream)) return 0;
-    if ((long)tm256 * tn >= 512) {
+    const int ncu = vlr_compute_cus();          // workgroups of a persistent round (256 on MI355X; fewer when CUs are left to RCCL)
+    if ((long)tm256 * tn >= 2 * ncu) {
         const int full = tm256 * tn;
-        const double base = (double)((full + 255) / 256);
+        const double base = (double)((full + ncu - 1) / ncu);
         double best = base;
         for (int r = 1; r <= 3 && tm256 - r >= 2; ++r) {
             const int t1 = (tm256 - r) * tn;
             const int rem_rows = M - (tm256 - r) * 256;
             const long t128 = (long)((rem_rows + 127) / 128) * ((N + 127) / 128);
-            const double est = (double)((t1 + 255) / 256) + 0.7 * (double)((t128 + 511) / 512);
+            const double est = (double)((t1 + ncu - 1) / ncu) + 0.7 * (double)((t128 + 2 * ncu - 1) / (2 * ncu));
             if (est < best - 0.05) { best = est; peel = r; }
         }
     }
@@ -611,7 +612,10 @@ static int gemm_swiglu_impl(const void* x, const void* wgu, void* gu, void* act,
     p.fuse = 1; p.store_c = store_gu; p.C2 = act; p.ldc2 = I;
     seg_set(p, sg);
     int done = 0;
-    if (seg ? vlr_gemm256p_seg_try_launch(p, stream) : vlr_gemm256p_fused_try_launch(p, stream)) {
+    const int pi_ = vlr_prof_begin(VLR_K_GEMM_NT, 2.0 * M1 * 2 * I * K, stream);    // per-layout totals of the bench line (the fallback rows below are counted by gemm_impl)
+    const bool took_ = seg ? vlr_gemm256p_seg_try_launch(p, stream) : vlr_gemm256p_fused_try_launch(p, stream);
+    vlr_prof_end(took_ ? pi_ : -1, stream);
+    if (took_) {
         int rc = vlr_check_launch("vlr_gemm_swiglu(fused)");
         if (rc != VLR_OK) return rc;
         done = M1;
@@ -658,7 +662,10 @@ static int gemm_qkv_rope_impl(const void* x, const void* wqkv, void* qkv, const 
         p.fuse = 2; p.pos = pos; p.rope_cos = cos_t; p.rope_sin = sin_t; p.max_pos = max_pos; p.rope_cols = rope_cols;
         p.bias = (const bf16_t*)bias;
         seg_set(p, sg);
-        if (seg ? vlr_gemm256p_seg_try_launch(p, stream) : vlr_gemm256p_fused_try_launch(p, stream)) {
+        const int pi_ = vlr_prof_begin(VLR_K_GEMM_NT, 2.0 * M1 * N * K, stream);
+        const bool took_ = seg ? vlr_gemm256p_seg_try_launch(p, stream) : vlr_gemm256p_fused_try_launch(p, stream);
+        vlr_prof_end(took_ ? pi_ : -1, stream);
+        if (took_) {
             int rc = vlr_check_launch("vlr_gemm_qkv_rope(fused)");
             if (rc != VLR_OK) return rc;
             done = M1;
@@ -754,7 +761,10 @@ static int gemm_lora_impl(const void* x, int ldx, const void* W, void* y, int ld
     p.out_f32 = f32; p.res_f32 = (f32 && residual) ? 1 : 0;
     seg_set(p, &sg);
     int done = 0;
-    if (vlr_gemm256p_seg_try_launch(p, stream)) {
+    const int pi_ = vlr_prof_begin(VLR_K_GEMM_NT, 2.0 * M1 * N * K, stream);
+    const bool took_ = vlr_gemm256p_seg_try_launch(p, stream);
+    vlr_prof_end(took_ ? pi_ : -1, stream);
+    if (took_) {
         int rc = vlr_check_launch("vlr_gemm_lora(fused)");
         if (rc != VLR_OK) return rc;
         done = M1;
@@ -784,7 +794,10 @@ extern "C" int vlr_gemm_swiglu_bwd(const void* dy, const void* wdown, void* gu, 
     GemmParams p = fused_params(dy, wdown, dact_ws, M1, I, H, H, I, I);
     p.fuse = 3; p.C2 = gu; p.ldc2 = 2 * I;
     int done = 0;
-    if (vlr_gemm256p_swiglu_bwd_try_launch(p, stream)) {
+    const int pi_ = vlr_prof_begin(VLR_K_GEMM_NN, 2.0 * M1 * I * H, stream);
+    const bool took_ = vlr_gemm256p_swiglu_bwd_try_launch(p, stream);
+    vlr_prof_end(took_ ? pi_ : -1, stream);
+    if (took_) {
         int rc = vlr_check_launch("vlr_gemm_swiglu_bwd(fused)");
         if (rc != VLR_OK) return rc;
         done = M1;
@@ -848,7 +861,7 @@ extern "C" int vlr_lmhead_is_fused(int R, int V, int H) {
     const char* e = getenv("VLR_GEMM_FUSE");
     if (e && !((atoi(e) >> 3) & 1)) return 0;
     const long ntiles = (long)((R + 255) / 256) * ((V + 255) / 256);
-    return ntiles > 256 && H >= 256 && H % 8 == 0 && V % 8 == 0;
+    return ntiles > vlr_compute_cus() && H >= 256 && H % 8 == 0 && V % 8 == 0;     // the predicate of vlr_gemm256p_lmhead_try_launch
 }
 
 extern "C" int vlr_lmhead_logps_fwd(const void* hg, const void* w_lm, const int* tgt, float* tok_logp, float* lse, void* workspace,
@@ -861,7 +874,10 @@ extern "C" int vlr_lmhead_logps_fwd(const void* hg, const void* w_lm, const int*
         float* tok_raw = parts + (size_t)R * nparts * 2;
         GemmParams p = fused_params(hg, w_lm, nullptr, R, V, H, H, H, V);
         p.fuse = 4; p.pos = tgt; p.C2 = parts; p.f1 = tok_raw;
-        if (vlr_gemm256p_lmhead_try_launch(p, stream)) {
+        const int pi_ = vlr_prof_begin(VLR_K_GEMM_NT, 2.0 * R * V * H, stream);
+        const bool took_ = vlr_gemm256p_lmhead_try_launch(p, stream);
+        vlr_prof_end(took_ ? pi_ : -1, stream);
+        if (took_) {
             hipLaunchKernelGGL(lmhead_fold_kernel, dim3(R), dim3(64), 0, stream, (const float*)parts, nparts, (const float*)tok_raw, tok_logp, lse);
             return vlr_check_launch("vlr_lmhead_logps_fwd(fused)");
         }
@@ -882,7 +898,10 @@ extern "C" int vlr_lmhead_logps_bwd(const void* hg, const void* w_lm, const int*
         hipLaunchKernelGGL(lmhead_rowcoef_kernel, dim3((R + 255) / 256), dim3(256), 0, stream, seq_off, nseq, dlogps, average, R, coef);
         GemmParams p = fused_params(hg, w_lm, dlogits, R, V, H, H, H, V);
         p.fuse = 5; p.pos = tgt; p.f0 = const_cast<float*>(lse); p.f1 = coef;
-        if (vlr_gemm256p_lmhead_try_launch(p, stream)) return vlr_check_launch("vlr_lmhead_logps_bwd(fused)");
+        const int pi_ = vlr_prof_begin(VLR_K_GEMM_NT, 2.0 * R * V * H, stream);
+        const bool took_ = vlr_gemm256p_lmhead_try_launch(p, stream);
+        vlr_prof_end(took_ ? pi_ : -1, stream);
+        if (took_) return vlr_check_launch("vlr_lmhead_logps_bwd(fused)");
     }
     VLR_REQUIRE(logits_ws, "vlr_lmhead_logps_bwd: this shape needs the fp32 logits buffer [R][V]");
     int rc = gemm_impl(0, hg, w_lm, logits_ws, nullptr, nullptr, R, V, H, H, H, V, 0, 0, 0, 1, 1.0f, stream);

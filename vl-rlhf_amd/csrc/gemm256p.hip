@@ -327,6 +327,17 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     const int m0n = RFL(ptab[tnx * 8 + 0]), n0n = RFL(ptab[tnx * 8 + 1]), kbn = RFL(ptab[tnx * 8 + 2]);
     const bool first = !CONT || titer == 0;
     parb = RFL(parb);
+    if constexpr (CONT) {
+        // sched bit 2 (experiment): the workgroups of an XCD start every whole-K round together (one arrival counter per XCD, zeroed by
+        // the host before the launch; rounds that every workgroup of the XCD runs) - tests whether drift between the workgroups that
+        // share A / B panels in the XCD's L2 costs anything
+        if ((p.sched & 4) && p.sk_ws && titer > 0 && titer < n_x / G8 && pfl == 0) {
+            unsigned int* ctr = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(p.sk_ws) + VLR_SK_FLAG_OFF + 32768) + xcd * 16;
+            if (t == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int want = (unsigned int)(G8 * titer);
+            while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(2);
+        }
+    }
 
     f32x4 acc[2][4][2][2];   // [A half a][16-row tile i][B half b][16-col tile j]
 #pragma unroll
@@ -575,55 +586,62 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     bool piece_done = false;
     if constexpr (CONT) {
         if (pfl) {
+            // Slab of this wave: its 32 accumulator quads as [q][lane] x 16 B (1 KiB per q, fully coalesced), moved by inline-asm
+            // dwordx4 accesses with sc1 (agent-scope write-through / L1 bypass: the partner sits on another CU of the same XCD) straight
+            // from / into the accumulator registers.  No element reads of the accumulator vectors: hipcc 7.2 folds them (all four
+            // stored values came out as element 0 - seen in the ISA of the first version of this loop, the miscompile of the
+            // SwiGLU-backward epilogue below).  Loads: 16 per statement with their own s_waitcnt (the compiler does not count asm loads).
             const bool own = (pfl & 12) != 0;
             const int sblk = own ? (int)blockIdx.x : ((pfl & 1) ? (int)blockIdx.x - 8 : (int)blockIdx.x);   // partner slabs are indexed by the WRITER (block >= 8) - 8
-            unsigned long long* slab = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(p.sk_ws) + (own ? VLR_SK_SELF_OFF : 0)) +
-                                       ((size_t)sblk * 8 + wave) * (64 * 64) + lane;
+            const char* sb0 = reinterpret_cast<const char*>(p.sk_ws) + (own ? VLR_SK_SELF_OFF : 0) + ((size_t)sblk * 8 + wave) * 32768;
+            const char* sb1 = sb0 + 16384;
             unsigned int* flags = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(p.sk_ws) + VLR_SK_FLAG_OFF);
+            const uint32_t vo0 = (uint32_t)lane * 16, vo1 = vo0 + 4096, vo2 = vo0 + 8192, vo3 = vo0 + 12288;
             if (pfl & 5) {
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int b = 0; b < 2; ++b)
-#pragma unroll
-                            for (int j = 0; j < 2; ++j) {
-                                const int q = ((a * 4 + i) * 2 + b) * 2 + j;
-                                const f32x4 v = acc[a][i][b][j];
-                                const unsigned long long lo = (unsigned long long)__builtin_bit_cast(uint32_t, v[0]) | ((unsigned long long)__builtin_bit_cast(uint32_t, v[1]) << 32);
-                                const unsigned long long hi = (unsigned long long)__builtin_bit_cast(uint32_t, v[2]) | ((unsigned long long)__builtin_bit_cast(uint32_t, v[3]) << 32);
-                                __hip_atomic_store(slab + (2 * q) * 64, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                __hip_atomic_store(slab + (2 * q + 1) * 64, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            }
+#define SLAB_ST(vo_, vec_, sb_, imm_) asm volatile("global_store_dwordx4 %0, %1, %2 offset:" #imm_ " sc1\n\ts_nop 1" ::"v"(vo_), "v"(vec_), "s"(sb_) : "memory")
+#define SLAB_ST4(vo_, a_, i_, sb_)                                                                 \
+    SLAB_ST(vo_, acc[a_][i_][0][0], sb_, 0); SLAB_ST(vo_, acc[a_][i_][0][1], sb_, 1024);           \
+    SLAB_ST(vo_, acc[a_][i_][1][0], sb_, 2048); SLAB_ST(vo_, acc[a_][i_][1][1], sb_, 3072)
+                SLAB_ST4(vo0, 0, 0, sb0); SLAB_ST4(vo1, 0, 1, sb0); SLAB_ST4(vo2, 0, 2, sb0); SLAB_ST4(vo3, 0, 3, sb0);
+                SLAB_ST4(vo0, 1, 0, sb1); SLAB_ST4(vo1, 1, 1, sb1); SLAB_ST4(vo2, 1, 2, sb1); SLAB_ST4(vo3, 1, 3, sb1);
+#undef SLAB_ST4
+#undef SLAB_ST
                 if (pfl & 1) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the slab has reached L2 before the flag says so
                     if (lane == 0) __hip_atomic_store(flags + blockIdx.x * 8 + wave, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 piece_done = true;                                         // no epilogue: the finishing piece writes this tile
             } else {
-                if (pfl & 2) {
+                if (pfl & 2) {       // (the partner is block + 8, whose slab index is (block + 8) - 8 = this block's index: sb0 above)
                     const unsigned int* fp = flags + (blockIdx.x + 8) * 8 + wave;
                     while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch) __builtin_amdgcn_s_sleep(8);
                 }
-                // (fl & 2: the partner is block + 8, whose slab index is (block + 8) - 8 = this block's index - `slab` above)
-                const unsigned long long* rs = slab;
+#define SLAB_LD16(t_, sb_)                                                                                                              \
+    asm volatile("global_load_dwordx4 %0, %16, %20 sc1\n\tglobal_load_dwordx4 %1, %16, %20 offset:1024 sc1\n\t"                         \
+                 "global_load_dwordx4 %2, %16, %20 offset:2048 sc1\n\tglobal_load_dwordx4 %3, %16, %20 offset:3072 sc1\n\t"             \
+                 "global_load_dwordx4 %4, %17, %20 sc1\n\tglobal_load_dwordx4 %5, %17, %20 offset:1024 sc1\n\t"                         \
+                 "global_load_dwordx4 %6, %17, %20 offset:2048 sc1\n\tglobal_load_dwordx4 %7, %17, %20 offset:3072 sc1\n\t"             \
+                 "global_load_dwordx4 %8, %18, %20 sc1\n\tglobal_load_dwordx4 %9, %18, %20 offset:1024 sc1\n\t"                         \
+                 "global_load_dwordx4 %10, %18, %20 offset:2048 sc1\n\tglobal_load_dwordx4 %11, %18, %20 offset:3072 sc1\n\t"           \
+                 "global_load_dwordx4 %12, %19, %20 sc1\n\tglobal_load_dwordx4 %13, %19, %20 offset:1024 sc1\n\t"                       \
+                 "global_load_dwordx4 %14, %19, %20 offset:2048 sc1\n\tglobal_load_dwordx4 %15, %19, %20 offset:3072 sc1\n\t"           \
+                 "s_waitcnt vmcnt(0)"                                                                                                   \
+                 : "=&v"(t_[0]), "=&v"(t_[1]), "=&v"(t_[2]), "=&v"(t_[3]), "=&v"(t_[4]), "=&v"(t_[5]), "=&v"(t_[6]), "=&v"(t_[7]),      \
+                   "=&v"(t_[8]), "=&v"(t_[9]), "=&v"(t_[10]), "=&v"(t_[11]), "=&v"(t_[12]), "=&v"(t_[13]), "=&v"(t_[14]), "=&v"(t_[15]) \
+                 : "v"(vo0), "v"(vo1), "v"(vo2), "v"(vo3), "s"(sb_)                                                                     \
+                 : "memory")
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
+                for (int a = 0; a < 2; ++a) {
+                    f32x4 tq[16];
+                    if (a == 0) SLAB_LD16(tq, sb0); else SLAB_LD16(tq, sb1);
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int b = 0; b < 2; ++b)
 #pragma unroll
-                            for (int j = 0; j < 2; ++j) {
-                                const int q = ((a * 4 + i) * 2 + b) * 2 + j;
-                                const unsigned long long lo = __hip_atomic_load(rs + (2 * q) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                const unsigned long long hi = __hip_atomic_load(rs + (2 * q + 1) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                f32x4 t;
-                                t[0] = __builtin_bit_cast(float, (uint32_t)lo); t[1] = __builtin_bit_cast(float, (uint32_t)(lo >> 32));
-                                t[2] = __builtin_bit_cast(float, (uint32_t)hi); t[3] = __builtin_bit_cast(float, (uint32_t)(hi >> 32));
-                                acc[a][i][b][j] += t;                      // head (this piece) + tail (the slab): one fixed order
-                            }
+                            for (int j = 0; j < 2; ++j) acc[a][i][b][j] += tq[i * 4 + b * 2 + j];       // head (this piece) + tail (the slab): one fixed order
+                }
+#undef SLAB_LD16
             }
         }
     }
@@ -1053,16 +1071,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     }   // persistent tile loop
 }
 
-static int gemm256p_n_cu() {
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-        n_cu &= ~7;                     // whole XCD octets (256 on MI355X)
-    }
-    return n_cu;
-}
+static int gemm256p_n_cu() { return vlr_compute_cus(); }      // grid of the persistent launches (whole XCD octets; 256 on MI355X)
 static bf16_t* gemm256p_zero16() {
     static bf16_t* z = nullptr;
     static bool tried = false;
@@ -1083,6 +1092,7 @@ static void sk_prepare(GemmParams& p, int ntiles, int grid, hipStream_t stream) 
     float* ws = vlr_gemm_sk_workspace(stream, &ep);
     if (!ws) return;
     p.sched = mode; p.sk_ws = ws; p.sk_epoch = ep;
+    if (mode & 4) hipMemsetAsync((char*)ws + VLR_SK_FLAG_OFF + 32768, 0, 8 * 64, stream);      // per-XCD arrival counters of the round barrier
 }
 
 bool vlr_gemm256p_fused_try_launch(const GemmParams& p_in, hipStream_t stream) {
@@ -1244,15 +1254,9 @@ bool vlr_gemm256p_try_launch(int layout, const GemmParams& p_in, hipStream_t str
     if (!((mode >> layout) & 1)) return false;
     const int ntiles = ((p.M + PT - 1) / PT) * ((p.N + PT - 1) / PT);
     if (ntiles < 192) return false;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-        n_cu &= ~7;                     // whole XCD octets (256 on MI355X)
-        const char* e = getenv("VLR_GEMM_PERSIST");
-        if (e && e[0] == '0') n_cu = 1 << 30;
-    }
+    static int persist = -1;
+    if (persist < 0) { const char* e = getenv("VLR_GEMM_PERSIST"); persist = (e && e[0] == '0') ? 0 : 1; }
+    const int n_cu = persist ? gemm256p_n_cu() : (1 << 30);
     const int tiles = ntiles < n_cu ? ntiles : n_cu;   // grid size: persistent workgroups when there are more tiles than CUs
     // 16-byte DMA source alignment: k-contiguous operands need ld % 8 and K % 8 (checked by the caller), k-strided
     // operands ld % 8 and at least 8 columns; pointers 16-byte aligned

@@ -91,6 +91,7 @@ _SIGS = {
     "vlr_merge_index": [P, P, P, I, I, I, I, I, I, I, I, P, P, P, P, P, P, P, P],
     "vlr_merge_fwd": [P, P, P, P, P, I, I, I, I, P],
     "vlr_merge_bwd": [P, P, P, P, P, P, I, I, I, I, I, I, P],
+    "vlr_merge_fwd_f32": [P, P, P, P, I, P, I, I, I, I, P],
     "vlr_build_rows": [P, P, I, I, I, P, P, P, P],
     "vlr_logp_rows": [P, P, P, I, I, L, P, P, P],
     "vlr_dlogits_rows": [P, P, P, P, I, P, I, I, I, L, P, L, P],
@@ -118,6 +119,7 @@ _SIGS = {
     "vlr_dropout_mask": [P, L, F, U64, P],
     "vlr_layers_join": [P],
     "vlr_allreduce_bucket": [P, P, L, I, P],
+    "vlr_comm_probe": [P, P, L, I, P],
 }
 _INT_HELPERS = {
     "vlr_rmsnorm_bwd_workspace_bytes": [I],
@@ -129,6 +131,8 @@ _INT_HELPERS = {
     "vlr_prof_collect": [P, I],
     "vlr_gemm_set_splitk_workspace": [P, L],
     "vlr_gemm_set_sched": [I],
+    "vlr_set_comm_cus": [I],
+    "vlr_compute_cus": [],
     "vlr_lmhead_is_fused": [I, I, I],
     "vlr_comm_unique_id_bytes": [],
     "vlr_comm_unique_id": [P],

@@ -307,6 +307,7 @@ class VisionWeights:
 class LlavaHipEngine:
     custom_layers = False          # True: the subclass composes the decoder layer itself (_layer_forward / _hidden_backward_custom)
     supports_resid_f32 = True      # False: the subclass adds to the residual stream with bf16 primitives
+    proj_out_f32 = True            # with the fp32 stream the projector writes fp32 rows for the merge (VLR_PROJ_F32=0: bf16)
 
     def __init__(self, cfg: dict, device="cuda", max_positions: int = 4096):
         if not torch.cuda.is_available():
@@ -339,6 +340,7 @@ class LlavaHipEngine:
         # from bf16 primitives opt out (supports_resid_f32).
         self.resid_f32 = bool(c.get("resid_f32", os.environ.get("VLR_RESID_F32", "1") != "0")) and self.supports_resid_f32
         self.RDT = torch.float32 if self.resid_f32 else BF16      # dtype of the residual stream
+        self.proj_out_f32 = self.proj_out_f32 and os.environ.get("VLR_PROJ_F32", "1") != "0"
         # gradient checkpointing (reference scripts: --gradient_checkpointing True, dpo.py:99 non-reentrant): only the layer inputs
         # are kept by the forward; the backward re-runs each layer's forward into one scratch set right before its backward
         self.gradient_checkpointing = bool(c.get("gradient_checkpointing", False))
@@ -631,10 +633,12 @@ class LlavaHipEngine:
         R, H, D = vit_feat.shape[0], self.H, self.D
         z = self._buf((tag, "proj_z", R), (R, H))
         h = self._buf((tag, "proj_h", R), (R, H))
-        out = self._buf((tag, "proj_out", R, extra_rows), (R + extra_rows, H))    # LLaVA-Next appends the image_newline row
+        # fp32 residual stream: the projector's output = the image rows of the merged embeddings stays fp32 (never rounded to bf16)
+        f32 = self.resid_f32 and self.proj_out_f32
+        out = self._buf((tag, "proj_out", R, extra_rows, f32), (R + extra_rows, H), torch.float32 if f32 else BF16)    # LLaVA-Next appends the image_newline row
         _hip.call("vlr_gemm_bf16", 0, vit_feat, ws.v["proj.w1"], z, ws.v["proj.b1"], None, R, H, D, D, D, H, 0, 0, 0, 0)
         _hip.call("vlr_gelu_fwd", z, h, z.numel())
-        _hip.call("vlr_gemm_bf16", 0, h, ws.v["proj.w2"], out, ws.v["proj.b2"], None, R, H, H, H, H, H, 0, 0, 0, 0)
+        _hip.call("vlr_gemm_bf16", 0, h, ws.v["proj.w2"], out, ws.v["proj.b2"], None, R, H, H, H, H, H, 0, 0, 0, int(f32))
         return out, z, h
 
     # ------------------------------------------------------------------------------------------------ forward
@@ -670,8 +674,8 @@ class LlavaHipEngine:
                     meta["anyres"] = cached
             pack = cached["pack"]
             F = pack["F"]
-            feats = self._buf((tag, "packed", F), (F, self.H))
-            _hip.call("vlr_gather_rows", ext, pack["idx"], feats, F, self.H)
+            feats = self._buf((tag, "packed", F, ext.dtype), (F, self.H), ext.dtype)
+            _hip.call("vlr_gather_rows", ext, pack["idx"], feats, F, self.H * (2 if ext.dtype == torch.float32 else 1))   # (row copy: fp32 rows = 2H 16-bit columns)
             S = cached["S"]
             M = Bn * S
             src, mask, pos, img_map, inv = cached["src"], cached["mask"], cached["pos"], cached["img_map"], cached["inv"]
@@ -727,11 +731,12 @@ class LlavaHipEngine:
         S, M = e["S"], e["M"]
         src, mask, pos, mlabels, img_map, inv = e["src"], e["mask"], e["pos"], e["labels"], e["img_map"], e["inv"]
         feats, vit_feat, z, h, n_rows, n_feat, pack = e["feats"], e["vit_feat"], e["proj_z"], e["proj_h"], e["n_rows"], e["n_feat"], e["pack"]
-        x0 = self._buf((tag, "x0", Bn, S), (M, self.H))
-        _hip.call("vlr_merge_fwd", src, ids, ws.v["embed"], feats, x0, Bn, T, S, self.H)
-        if self.resid_f32:                 # the merged embeddings are bf16 values (table rows / projector output): exact in fp32
-            x0b, x0 = x0, self._buf((tag, "x0f", Bn, S), (M, self.H), torch.float32)
-            _hip.call("vlr_cast_bf16_to_f32", x0b, x0, M * self.H)
+        if self.resid_f32:                 # fp32 stream: embedding rows widened exactly, the projector's output rows unrounded (fp32 feats)
+            x0 = self._buf((tag, "x0f", Bn, S), (M, self.H), torch.float32)
+            _hip.call("vlr_merge_fwd_f32", src, ids, ws.v["embed"], feats, int(feats.dtype == torch.float32), x0, Bn, T, S, self.H)
+        else:
+            x0 = self._buf((tag, "x0", Bn, S), (M, self.H))
+            _hip.call("vlr_merge_fwd", src, ids, ws.v["embed"], feats, x0, Bn, T, S, self.H)
         x = x0
         acts = []
         use_lora = self.lora is not None and self.lora_active and ws is self.policy
