@@ -37,6 +37,14 @@ CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 
 
+# What the MI355X path rounds to bf16 with the fp32 residual stream (ABI v4, vlr_llama_cfg.resid_f32): weights, the operands of every
+# MFMA (norm outputs, q / k after RoPE, v, softmax probabilities, attention output, silu(gate) * up, the final hidden state) and the
+# vision tower's operands and residual stream - NOT the decoder's residual stream, NOT the projector output (the image rows of the
+# merged embeddings), NOT q / k before RoPE or gate / up (they exist only as fp32 accumulators).  emulate_bf16=HIP_ROUNDING is the
+# oracle's model of that path; emulate_bf16=True (everything the r01 / r02 path stored) remains for the bf16-stream mode.
+HIP_ROUNDING = frozenset(("w", "vit_op", "vit_resid", "xn", "rope", "v", "p", "attn", "act", "hidden", "lora_x", "lora_u"))
+
+
 def _rt(x, on, tag=None):
     """bf16 round trip.  `on`: False (fp32, reference-exact), True (every tensor the HIP path stores as bf16), or a set of
     rounding-point tags (error-budget runs, oracle/depth_parity.py): only tensors whose tag is in the set are rounded.
@@ -284,12 +292,12 @@ def lora_delta(h, lora, layer, target, r):
     dict(W={peft name: tensor}, scale=lora_alpha/r, dropout=p, seed=None|int).  With a seed the dropout mask of target
     t in layer l is dropout_mask(seed + 8*l + t) over the flattened [B*S, in] input (the HIP path's convention)."""
     na, nb = lora_names(layer, target)
-    A, B = r(lora["W"][na]), r(lora["W"][nb])
+    A, B = r(lora["W"][na], "w"), r(lora["W"][nb], "w")
     p = float(lora.get("dropout", 0.0) or 0.0)
     if p > 0 and lora.get("seed") is not None:
         m = dropout_mask(lora["seed"] + 8 * layer + LORA_TARGETS.index(target), h.numel(), p).view(h.shape).to(h.dtype)
-        h = r(h * m * (1.0 / (1.0 - p)))
-    return lora["scale"] * (r(h @ A.t()) @ B.t())
+        h = r(h * m * (1.0 / (1.0 - p)), "lora_x")
+    return lora["scale"] * (r(h @ A.t(), "lora_u") @ B.t())
 
 
 def lora_merged_weights(W, lora, cfg, prefix="language_model.model.layers."):

@@ -20,6 +20,7 @@ from tests.golden_util import load_case, t  # noqa: E402
 # vs the bf16-emulated oracle |dloss| <= 3e-3.  north_star's rtol = 1e-3 is checked where bf16 allows it: against the
 # bf16-emulated oracle on the 7B-shaped single-layer case below (test_true_width_layer_loss).
 TOL_LOSS_FP32, TOL_LOGPS_FP32, TOL_LOSS_BF16 = 6e-3, 0.25, 3e-3
+EMU = O.HIP_ROUNDING      # the oracle's model of what the fp32-residual-stream HIP path rounds to bf16 (oracle/llava_dpo_oracle.py)
 
 
 @pytest.fixture(scope="module")
@@ -134,7 +135,7 @@ def test_train_step_matches_golden(gpu):
     with torch.no_grad():
         Wp = {k: v.bfloat16().float() for k, v in W.items()}
         Wq = {k: v.bfloat16().float() for k, v in W_ref.items()}
-        l16, m16 = O.compute_loss(Wp, Wq, cfg, batch, cfg["beta"], emulate_bf16=True)
+        l16, m16 = O.compute_loss(Wp, Wq, cfg, batch, cfg["beta"], emulate_bf16=EMU)
     assert abs(float(loss) - float(l16)) < TOL_LOSS_BF16, (float(loss), float(l16))
     # the eight metrics of trl's get_batch_loss_metrics
     logs = tr.log({"loss": float(loss)})
@@ -227,7 +228,7 @@ def test_multi_head_ragged_vs_oracle(gpu):
     Wp = {k: v.bfloat16().float() for k, v in W.items()}
     Wq = {k: v.bfloat16().float() for k, v in W_ref.items()}
     with torch.no_grad():
-        l16, _ = O.compute_loss(Wp, Wq, cfg, batch, cfg["beta"], emulate_bf16=True)
+        l16, _ = O.compute_loss(Wp, Wq, cfg, batch, cfg["beta"], emulate_bf16=EMU)
     l32, m32 = O.compute_loss({k: v.clone().requires_grad_(not k.startswith("vision_tower.")) for k, v in W.items()}, W_ref, cfg, batch, cfg["beta"])
     assert abs(float(loss) - float(l16)) < TOL_LOSS_BF16, (float(loss), float(l16), float(l32))
     assert abs(float(loss) - float(l32)) < TOL_LOSS_FP32
@@ -252,7 +253,7 @@ def test_true_width_layer_loss(gpu):
     Wp = {k: v.bfloat16().float() for k, v in W.items()}
     Wq = {k: v.bfloat16().float() for k, v in W_ref.items()}
     with torch.no_grad():
-        l16, m16 = O.compute_loss(Wp, Wq, cfg, batch, cfg["beta"], emulate_bf16=True)
+        l16, m16 = O.compute_loss(Wp, Wq, cfg, batch, cfg["beta"], emulate_bf16=EMU)
         l32, _ = O.compute_loss(W, W_ref, cfg, batch, cfg["beta"])
     rel16 = abs(float(loss) - float(l16)) / abs(float(l16))
     rel32 = abs(float(loss) - float(l32)) / abs(float(l32))
@@ -306,7 +307,7 @@ def test_wrong_image_count_raises(gpu):
 PEFT = dict(r=8, lora_alpha=16, lora_dropout=0.0, target_modules="auto", bias="none")
 
 
-def _lora_oracle_grads(W, cfg, batch, lora, emulate=True):
+def _lora_oracle_grads(W, cfg, batch, lora, emulate=EMU):
     leaves = {k: v.clone().requires_grad_(True) for k, v in lora["W"].items()}
     l2 = dict(lora)
     l2["W"] = leaves
@@ -574,7 +575,7 @@ def test_training_trajectory_tracks_oracle(gpu):
         leaves = {k: master[k].bfloat16().float().requires_grad_(True) for k in names}
         Wp = {k: v.bfloat16().float() for k, v in master.items()}
         Wp.update(leaves)
-        loss, _ = O.compute_loss(Wp, Wr16, cfg, batch, cfg["beta"], emulate_bf16=True)
+        loss, _ = O.compute_loss(Wp, Wr16, cfg, batch, cfg["beta"], emulate_bf16=EMU)
         loss.backward()
         grads = {k: leaves[k].grad for k in names if leaves[k].grad is not None}
         O.clip_grad_norm_(grads, o["max_grad_norm"])

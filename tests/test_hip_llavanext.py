@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import llava_dpo_oracle as O  # noqa: E402  (checker only)
 from tests.golden_util import load_case, t  # noqa: E402
-from tests.test_hip_e2e import TOL_LOGPS_FP32, TOL_LOSS_BF16, TOL_LOSS_FP32, cosine, relmax  # noqa: E402
+from tests.test_hip_e2e import EMU, TOL_LOGPS_FP32, TOL_LOSS_BF16, TOL_LOSS_FP32, cosine, relmax  # noqa: E402
 
 
 def build():
@@ -88,7 +88,7 @@ def test_llavanext_ddpo_train_step_matches_golden_and_oracle():
     torch.cuda.synchronize()
     assert abs(float(loss) - float(z["loss_mean_ddpo"])) < TOL_LOSS_FP32, (float(loss), float(z["loss_mean_ddpo"]))
     with torch.no_grad():
-        l16, _ = O.compute_loss(W, W_ref, cfg, batch, cfg["beta"], loss_type="ddpo", emulate_bf16=True)
+        l16, _ = O.compute_loss(W, W_ref, cfg, batch, cfg["beta"], loss_type="ddpo", emulate_bf16=EMU)
     # the emulation (0.7166) and the HIP path (0.7129) sit on opposite sides of the fp32 value (0.7147): bound their distance by the
     # sum of the two fp32 budgets rather than by the LLaVA-1.5 fixture's tighter one
     assert abs(float(loss) - float(l16)) < TOL_LOSS_BF16 + 2.5e-3, (float(loss), float(l16))
@@ -141,7 +141,7 @@ def test_llavanext_lora_step_matches_oracle():
     torch.cuda.synchronize()
     leaves = {k: v.clone().requires_grad_(True) for k, v in lora["W"].items()}
     l2 = dict(lora, W=leaves)
-    l16, m16 = O.compute_loss(W, W, cfg, batch, cfg["beta"], emulate_bf16=True, lora=l2)
+    l16, m16 = O.compute_loss(W, W, cfg, batch, cfg["beta"], emulate_bf16=EMU, lora=l2)
     l16.backward()
     assert abs(float(loss) - float(l16)) < TOL_LOSS_BF16 + 2.5e-3, (float(loss), float(l16))
     named = dict(model.named_parameters())
