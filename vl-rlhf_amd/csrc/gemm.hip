@@ -620,6 +620,21 @@ static int gemm_swiglu_impl(const void* x, const void* wgu, void* gu, void* act,
         if (rc != VLR_OK) return rc;
         done = M1;
     }
+    if (done > 0 && done < M) {
+        // the peeled last tile rows take the SAME fused epilogue (one tile per workgroup): every row of the batch sees the same
+        // arithmetic - act from the fp32 accumulators - whatever the batch size
+        GemmParams p2 = fused_params((const bf16_t*)x + (size_t)done * ldx, wgu, (bf16_t*)gu + (size_t)done * 2 * I, M - done, 2 * I, K, ldx, K, 2 * I);
+        p2.fuse = 1; p2.store_c = store_gu; p2.C2 = (bf16_t*)act + (size_t)done * I; p2.ldc2 = I;
+        if (seg) { SegArgs s2 = *sg; s2.u = (const bf16_t*)sg->u + (size_t)done * sg->ldu; seg_set(p2, &s2); }
+        const int pj_ = vlr_prof_begin(VLR_K_GEMM_NT, 2.0 * (M - done) * 2 * I * K, stream);
+        const bool took2_ = seg ? vlr_gemm256p_seg_try_launch(p2, stream) : vlr_gemm256p_fused_try_launch(p2, stream);
+        vlr_prof_end(took2_ ? pj_ : -1, stream);
+        if (took2_) {
+            int rc = vlr_check_launch("vlr_gemm_swiglu(fused tail)");
+            if (rc != VLR_OK) return rc;
+            done = M;
+        }
+    }
     if (done < M) {       // remaining rows: plain GEMM (+ the adapter GEMMs) + SwiGLU kernel
         const bf16_t* xa = (const bf16_t*)x + (size_t)done * ldx;
         bf16_t* gur = (bf16_t*)gu + (size_t)done * 2 * I;
@@ -669,6 +684,20 @@ static int gemm_qkv_rope_impl(const void* x, const void* wqkv, void* qkv, const 
             int rc = vlr_check_launch("vlr_gemm_qkv_rope(fused)");
             if (rc != VLR_OK) return rc;
             done = M1;
+        }
+    }
+    if (done > 0 && done < M && head_dim == 128 && (!bias || !((uintptr_t)bias & 7))) {       // the peeled rows: same fused epilogue, one tile per workgroup
+        GemmParams p2 = fused_params((const bf16_t*)x + (size_t)done * ldx, wqkv, (bf16_t*)qkv + (size_t)done * N, M - done, N, K, ldx, K, N);
+        p2.fuse = 2; p2.pos = pos + done; p2.rope_cos = cos_t; p2.rope_sin = sin_t; p2.max_pos = max_pos; p2.rope_cols = rope_cols;
+        p2.bias = (const bf16_t*)bias;
+        if (seg) { SegArgs s2 = *sg; s2.u = (const bf16_t*)sg->u + (size_t)done * sg->ldu; seg_set(p2, &s2); }
+        const int pj_ = vlr_prof_begin(VLR_K_GEMM_NT, 2.0 * (M - done) * N * K, stream);
+        const bool took2_ = seg ? vlr_gemm256p_seg_try_launch(p2, stream) : vlr_gemm256p_fused_try_launch(p2, stream);
+        vlr_prof_end(took2_ ? pj_ : -1, stream);
+        if (took2_) {
+            int rc = vlr_check_launch("vlr_gemm_qkv_rope(fused tail)");
+            if (rc != VLR_OK) return rc;
+            done = M;
         }
     }
     if (done < M) {
@@ -801,6 +830,18 @@ extern "C" int vlr_gemm_swiglu_bwd(const void* dy, const void* wdown, void* gu, 
         int rc = vlr_check_launch("vlr_gemm_swiglu_bwd(fused)");
         if (rc != VLR_OK) return rc;
         done = M1;
+    }
+    if (done > 0 && done < M) {       // the peeled rows: same fused epilogue, one tile per workgroup
+        GemmParams p2 = fused_params((const bf16_t*)dy + (size_t)done * H, wdown, (bf16_t*)dact_ws + (size_t)done * I, M - done, I, H, H, I, I);
+        p2.fuse = 3; p2.C2 = (bf16_t*)gu + (size_t)done * 2 * I; p2.ldc2 = 2 * I;
+        const int pj_ = vlr_prof_begin(VLR_K_GEMM_NN, 2.0 * (M - done) * I * H, stream);
+        const bool took2_ = vlr_gemm256p_swiglu_bwd_try_launch(p2, stream);
+        vlr_prof_end(took2_ ? pj_ : -1, stream);
+        if (took2_) {
+            int rc = vlr_check_launch("vlr_gemm_swiglu_bwd(fused tail)");
+            if (rc != VLR_OK) return rc;
+            done = M;
+        }
     }
     if (done < M) {
         const bf16_t* dyr = (const bf16_t*)dy + (size_t)done * H;

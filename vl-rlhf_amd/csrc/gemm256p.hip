@@ -1112,14 +1112,15 @@ bool vlr_gemm256p_fused_try_launch(const GemmParams& p_in, hipStream_t stream) {
     const int tiles_m = (p.M + PT - 1) / PT;
     const int tiles_n = p.fuse == 1 ? ((p.N >> 1) + 127) / 128 : p.N / PT;
     const int ntiles = tiles_m * tiles_n;
-    if (ntiles <= n_cu || p.K < 4 * PK) return false;                      // persistent continuous pipeline only
+    if (p.K < 4 * PK) return false;
+    const int grid = ntiles > n_cu ? n_cu : ntiles;       // few tiles (small batches, the peeled last tile rows): one tile per workgroup
     if (p.fuse == 2 && (p.N % PT != 0 || p.rope_cols % PT != 0)) return false;
     if (p.fuse == 1 && ((p.N >> 1) % 8 != 0 || p.ldc2 % 8 != 0 || ((uintptr_t)p.C2 & 15))) return false;
     if ((((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.C) & 15) || p.lda % 8 != 0 || p.ldb % 8 != 0 || p.ldc % 8 != 0) return false;
-    sk_prepare(p, ntiles, n_cu, stream);
+    sk_prepare(p, ntiles, grid, stream);
     const int pi = vlr_prof_begin(VLR_K_GEMM256P, 2.0 * p.M * p.N * p.K, stream);
-    if (p.fuse == 1) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 1>), dim3(n_cu), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
-    else hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 2>), dim3(n_cu), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
+    if (p.fuse == 1) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 1>), dim3(grid), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
+    else hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 2>), dim3(grid), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
     vlr_prof_end(pi, stream);
     return true;
 }
@@ -1141,7 +1142,8 @@ bool vlr_gemm256p_seg_try_launch(const GemmParams& p, hipStream_t stream) {
     const int n_cu = gemm256p_n_cu();
     const int tiles_m = (p.M + PT - 1) / PT;
     const int tiles_n = p.fuse == 1 ? ((p.N >> 1) + 127) / 128 : (p.N + PT - 1) / PT;
-    if (tiles_m * tiles_n <= n_cu || p.K < 4 * PK || p.K % PK != 0) return false;
+    if (p.K < 4 * PK || p.K % PK != 0) return false;
+    const int grid = tiles_m * tiles_n > n_cu ? n_cu : tiles_m * tiles_n;
     if (p.K2 % 8 != 0 || p.lda2 % 8 != 0 || p.ldb2 % 8 != 0 || (((uintptr_t)p.A2 | (uintptr_t)p.B2) & 15)) return false;
     if (p.fuse != 1 && ((p.seg_b0 < p.N && p.seg_b0 % PT != 0) || (p.seg_b1 < p.N && p.seg_b1 % PT != 0))) return false;   // a tile lies in one block
     if (p.fuse == 2 && (p.N % PT != 0 || p.rope_cols % PT != 0)) return false;
@@ -1153,9 +1155,9 @@ bool vlr_gemm256p_seg_try_launch(const GemmParams& p, hipStream_t stream) {
         if (p.fuse != 0 || p.ldc % 4 != 0 || (p.residual && (!p.res_f32 || p.ldr % 4 != 0 || ((uintptr_t)p.residual & 15)))) return false;
     } else if (p.residual && (p.res_f32 || p.fuse != 0 || p.ldr % 4 != 0 || ((uintptr_t)p.residual & 7) || (const void*)p.residual == (const void*)p.C)) return false;
     const int pi = vlr_prof_begin(VLR_K_GEMM256P, 2.0 * p.M * p.N * (p.K + p.K2), stream);
-    if (p.fuse == 0) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 0, true>), dim3(n_cu), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
-    else if (p.fuse == 1) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 1, true>), dim3(n_cu), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
-    else hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 2, true>), dim3(n_cu), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
+    if (p.fuse == 0) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 0, true>), dim3(grid), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
+    else if (p.fuse == 1) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 1, true>), dim3(grid), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
+    else hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 2, true>), dim3(grid), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
     vlr_prof_end(pi, stream);
     return true;
 }
@@ -1196,11 +1198,12 @@ bool vlr_gemm256p_swiglu_bwd_try_launch(const GemmParams& p_in, hipStream_t stre
     if (!zero16) return false;
     const int n_cu = gemm256p_n_cu();
     const int ntiles = ((p.M + PT - 1) / PT) * ((p.N + PT - 1) / PT);
-    if (ntiles <= n_cu || p.K < 4 * PK) return false;
+    if (p.K < 4 * PK) return false;
+    const int grid = ntiles > n_cu ? n_cu : ntiles;
     if ((((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.C2) & 15) || p.lda % 8 != 0 || p.ldb % 8 != 0 || p.N % 8 != 0 || p.ldc2 % 8 != 0) return false;
-    sk_prepare(p, ntiles, n_cu, stream);
+    sk_prepare(p, ntiles, grid, stream);
     const int pi = vlr_prof_begin(VLR_K_GEMM256P, 2.0 * p.M * p.N * p.K, stream);
-    hipLaunchKernelGGL((gemm256p_kernel<false, true, 0, true, 3>), dim3(n_cu), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
+    hipLaunchKernelGGL((gemm256p_kernel<false, true, 0, true, 3>), dim3(grid), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
     vlr_prof_end(pi, stream);
     return true;
 }
