@@ -7,9 +7,10 @@ What is compared, per case:
   * the residual stream after EVERY decoder layer at probe positions (a layer wired to the wrong weights / offsets in the
     flat parameter buffer changes it completely; bf16 rounding moves it by a few per cent at depth 32);
   * the four per-sequence log-prob sums and the DPO loss, against the fp32 oracle AND its bf16-emulating mode.
-Tolerances are the measured bf16 budget (profiles/r02_bf16_error_budget_L32.txt): the oracle's own bf16 emulation sits
-1.2e-2 from fp32 in the loss at depth 32, so rtol 1e-3 against an fp32 reference is not reachable by any bf16 pipeline; the
-assertion is that the HIP path is no further from fp32 than ~2x that emulation."""
+Tolerances come from the oracle's own error budget (profiles/r03_bf16_error_budget_L32.txt, oracle/depth_parity.py): since round 3 the
+HIP path keeps the residual stream in fp32, so what it rounds to bf16 is what ANY bf16-MFMA pipeline must round (the MFMA operands) plus
+the vision tower; the golden files hold the oracle run with exactly that rounding (variant "f32resid+vit_f32out" = oracle.HIP_ROUNDING) and
+the HIP path is asserted to sit no further from fp32 than 1.3 x that model in the per-sequence log-probs."""
 import json
 import math
 import os
@@ -67,30 +68,46 @@ def _run_case(cfg, model, ref, tr, g):
     return got, probe
 
 
-def _compare(got, probe, g, label):
-    f32, emu = g["results"]["fp32"], g["results"]["bf16_emulated"]
+FLOOR = "f32resid+vit_f32out"      # oracle/depth_parity.py variant = oracle.HIP_ROUNDING: what the fp32-stream HIP path rounds to bf16
+
+
+def _dlogp(r, f32):
+    keys = ("policy_chosen_logps", "policy_rejected_logps", "reference_chosen_logps", "reference_rejected_logps")
+    d = [a - b for k in keys for a, b in zip(r[k], f32[k])]
+    return max(abs(x) for x in d), math.sqrt(sum(x * x for x in d) / len(d))
+
+
+def _compare(got, probe, g, label, loss_cap=None):
+    """HIP vs the fp32 oracle, judged against the oracle's own model of the path's bf16 rounding (FLOOR: bf16 MFMA operands + the vision
+    tower, fp32 residual stream - no bf16-MFMA pipeline rounds less).  The DPO loss of these random-weight models is beta / 2 times a
+    difference of four log-prob sums of -85 ... -1415, so what is asserted tightly is the per-sequence log-prob error (max and rms, at most
+    1.3 x the floor's); the loss bound follows from it: sigma_loss = beta / 2 * 2 * rms_floor / sqrt(pairs), asserted at 1.5 sigma (and at
+    the fixed cap where one is given)."""
+    f32 = g["results"]["fp32"]
+    floor = g["results"].get(FLOOR) or g["results"]["bf16_emulated"]
     L = g["layers"]
-    # ---- per-layer residual stream
+    # ---- per-layer residual stream (a mis-wired layer gives O(1); measured worst 0.011 / 0.025 / 0.029 at depth 2 / 32 / 32)
     worst = 0.0
     for l in range(L):
         want = torch.tensor(f32["layer_probe"][l])
         rel = float((probe[l] - want).norm() / want.norm())
-        emu_rel = float((torch.tensor(emu["layer_probe"][l]) - want).norm() / want.norm())
         worst = max(worst, rel)
-        assert rel < max(0.03, 3.0 * emu_rel), f"{label}: layer {l} residual stream is {rel:.3f} (relative) from the fp32 oracle (bf16 emulation: {emu_rel:.3f})"
+        assert rel < 0.04, f"{label}: layer {l} residual stream is {rel:.3f} (relative) from the fp32 oracle"
     # ---- log-probs and loss
-    keys = ("policy_chosen_logps", "policy_rejected_logps", "reference_chosen_logps", "reference_rejected_logps")
-    d_f32 = max(abs(a - b) for k in keys for a, b in zip(got[k], f32[k]))
-    d_emu = max(abs(a - b) for k in keys for a, b in zip(got[k], emu[k]))
-    e_f32 = max(abs(a - b) for k in keys for a, b in zip(emu[k], f32[k]))
-    l_f32, l_emu, le_f32 = abs(got["loss"] - f32["loss"]), abs(got["loss"] - emu["loss"]), abs(emu["loss"] - f32["loss"])
-    print(f"[depth {label}] loss HIP {got['loss']:.6f} fp32 {f32['loss']:.6f} bf16-emulated {emu['loss']:.6f} | |HIP-fp32| {l_f32:.2e} "
-          f"|HIP-emu| {l_emu:.2e} |emu-fp32| {le_f32:.2e} | max |d logp| HIP-fp32 {d_f32:.3f} HIP-emu {d_emu:.3f} emu-fp32 {e_f32:.3f} | "
+    mx, rms = _dlogp(got, f32)
+    fmx, frms = _dlogp(floor, f32)
+    l_f32, lf_f32 = abs(got["loss"] - f32["loss"]), abs(floor["loss"] - f32["loss"])
+    sigma = g["beta"] / 2 * 2 * frms / math.sqrt(g["spec"]["pairs"])
+    print(f"[depth {label}] loss HIP {got['loss']:.6f} fp32 {f32['loss']:.6f} floor model {floor['loss']:.6f} | |HIP-fp32| {l_f32:.2e} "
+          f"|floor-fp32| {lf_f32:.2e} (1.5 sigma {1.5 * sigma:.2e}) | d logp HIP-fp32 max {mx:.3f} rms {rms:.3f} floor-fp32 max {fmx:.3f} rms {frms:.3f} | "
           f"worst layer residual rel err {worst:.4f}")
     assert math.isfinite(got["loss"])
-    assert d_f32 < max(0.25, 2.5 * e_f32), (d_f32, e_f32)
-    assert l_f32 < max(5e-3, 2.5 * le_f32), (l_f32, le_f32)
-    return dict(loss=got["loss"], d_loss_fp32=l_f32, d_loss_emu=l_emu, d_logp_fp32=d_f32, worst_layer_rel=worst)
+    assert mx <= 1.3 * fmx + 0.02, (mx, fmx)
+    assert rms <= 1.3 * frms + 0.01, (rms, frms)
+    assert l_f32 <= 1.5 * sigma, (l_f32, sigma)
+    if loss_cap is not None:
+        assert l_f32 <= loss_cap, (l_f32, loss_cap)
+    return dict(loss=got["loss"], d_loss_fp32=l_f32, d_logp_max=mx, d_logp_rms=rms, worst_layer_rel=worst)
 
 
 def test_depth2_true_widths_vs_fp32_oracle():
@@ -123,7 +140,7 @@ def test_depth32_small_batch_vs_fp32_oracle(full32):
     g = _golden("llava7b_depth32_small")
     _check_weights(model, g)
     got, probe = _run_case(cfg, model, ref, tr, g)
-    _compare(got, probe, g, "L32 small")
+    _compare(got, probe, g, "L32 small", loss_cap=4e-3)     # a fixed cap at the case whose floor allows one (floor model: 1.3e-3)
 
 
 def test_depth32_configs0_shape_vs_fp32_oracle(full32):
@@ -165,8 +182,8 @@ def _check_grads(model, g, label):
         worst_cos, worst_norm = min(worst_cos, cs), max(worst_norm, nr)
         if os.environ.get("VLR_DEPTH_NOASSERT"):
             continue
-        assert cs > 0.9, f"{label} {name}: gradient probe cosine {cs:.3f} vs the fp32 oracle"
-        assert nr < 0.15, f"{label} {name}: gradient norm {norm:.4g} vs {e['norm']:.4g}"
+        assert cs > 0.99, f"{label} {name}: gradient probe cosine {cs:.3f} vs the fp32 oracle"      # measured worst 0.9999 (2 layers) / 0.9973 (32)
+        assert nr < 0.03, f"{label} {name}: gradient norm {norm:.4g} vs {e['norm']:.4g}"            # measured worst 0.1 % / 0.7 %
     print(f"[depth grads {label}] {len(g['grads'])} tensors: worst probe cosine {worst_cos:.4f}, worst norm deviation {worst_norm:.3f}")
 
 
@@ -194,7 +211,7 @@ def test_depth2_gradients_vs_fp32_oracle():
 
 def test_depth32_gradients_vs_fp32_oracle():
     """BACKWARD at full depth: the gradients that have travelled through 31, 14 and 0 further layers (layers 0, 17, 31), the final
-    norm and the lm-head, against fp32 autograd of the oracle on the same 7B model (norm within 15 %, 256-element probe cosine > 0.9)"""
+    norm and the lm-head, against fp32 autograd of the oracle on the same 7B model (norm within 3 %, 256-element probe cosine > 0.99)"""
     if torch.cuda.mem_get_info()[1] < 200 * (1 << 30):
         pytest.skip("needs a 288 GB device")
     if not os.path.exists(os.path.join(GOLDEN, "llava7b_depth32_small_grads.json")):

@@ -15,6 +15,8 @@ from oracle import qwenvl_oracle as Q  # noqa: E402  (checker only)
 from tests.golden_util import load_case, t  # noqa: E402
 from tests.test_hip_e2e import TOL_LOGPS_FP32, TOL_LOSS_BF16, TOL_LOSS_FP32, cosine, relmax  # noqa: E402
 
+EMUQ = O.HIP_ROUNDING | {"vit"}      # fp32 residual stream in the decoder; the whole Qwen vision tower + resampler (incl. its output) in bf16
+
 
 def build(lora=None, loss_type="sigmoid"):
     from vlrlhf.models.QwenVL import QwenVLDPOTrainer, QwenVLForRL
@@ -149,7 +151,7 @@ def test_qwenvl_lora_step_matches_oracle(dropout):
     lora["seed"] = (5 << 40) + (eng._lora_calls << 16)
     px = batch["img_input_dict"]["pixel_values"]
     Wl = {k: v.clone().requires_grad_(True) for k, v in lora["W"].items()}
-    l16, m16 = Q.compute_loss(W, W, cfg, dict(batch, pixel_values=px), cfg["beta"], emulate_bf16=True, lora=dict(lora, W=Wl))
+    l16, m16 = Q.compute_loss(W, W, cfg, dict(batch, pixel_values=px), cfg["beta"], emulate_bf16=EMUQ, lora=dict(lora, W=Wl))
     assert abs(float(loss) - float(l16)) < TOL_LOSS_BF16 + 1e-3, (float(loss), float(l16))      # (this fixture's weights are scaled x3)
     l16.backward()
     named = dict(model.named_parameters())
