@@ -19,7 +19,9 @@ from tests.golden_util import load_case, t  # noqa: E402
 # (relative) from the fp32 loss, so: vs fp32 golden  |dloss| <= 6e-3, |dlogps| <= 0.25 (values ~ -75..-150);
 # vs the bf16-emulated oracle |dloss| <= 3e-3.  north_star's rtol = 1e-3 is checked where bf16 allows it: against the
 # bf16-emulated oracle on the 7B-shaped single-layer case below (test_true_width_layer_loss).
-TOL_LOSS_FP32, TOL_LOGPS_FP32, TOL_LOSS_BF16 = 2e-3, 0.1, 2e-3
+# measured on the toy fixtures (round 3, fp32 residual stream): |loss - fp32 golden| <= 2.5e-3 over all model families (InternLM, on the bf16
+# stream, is the largest), per-sequence log-probs within 0.1, loss within 2e-3 of the oracle run with the path's own rounding (EMU)
+TOL_LOSS_FP32, TOL_LOGPS_FP32, TOL_LOSS_BF16 = 3e-3, 0.1, 2e-3
 EMU = O.HIP_ROUNDING      # the oracle's model of what the fp32-residual-stream HIP path rounds to bf16 (oracle/llava_dpo_oracle.py)
 
 
