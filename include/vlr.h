@@ -97,6 +97,14 @@ int vlr_gemm_swiglu_bwd(const void* dy, const void* wdown, void* gu_inout, void*
 /*  vlr_gemm_dropout_acc  : dx [M][in] += scaling / (1 - p) * mask .* (v [M][ldv] . A [r][in]) - the input-gradient term of one
  *                          target under lora_dropout; the mask is regenerated from (seed, row * in + col) as in vlr_dropout and the
  *                          product never reaches HBM (scratch [M][in] only for shapes the fused kernel does not take) */
+/*  vlr_gemm_grouped     : `groups` (<= 8) equally shaped skinny GEMMs as ONE launch - group g computes C + g gC = alpha * (A + g gA) . (B + g gB)
+ *                          (layout as vlr_gemm_bf16, strides in elements, bf16 out, optional += C) - the per-target lora_A / lora_B products of a
+ *                          fused group (q, k, v / gate, up), split along K when that fills the chip.  mask_on 1 (NT) / 2 (TN): the activation
+ *                          operand (A rows / B rows, dense [rows][mask_ld]) is multiplied by the keep mask of vlr_dropout(seed + g) while it is
+ *                          staged - lora_dropout without a dropped copy of x; the caller folds 1 / (1 - p) into alpha. */
+int vlr_gemm_grouped(int layout, const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int groups,
+                     long gA, long gB, long gC, float alpha, int accumulate, int mask_on, uint64_t seed, float p_drop, int mask_ld,
+                     vlr_stream_t stream);
 int vlr_gemm_dropout_acc(const void* v, int ldv, const void* A, void* dx, void* scratch, int M, int in, int r, float p,
                          uint64_t seed, float scale, vlr_stream_t stream);
 int vlr_gemm_lora(const void* x, int ldx, const void* W, void* y, int ldy, const void* residual, int ldr, int M, int N, int K,
@@ -283,9 +291,10 @@ int vlr_decoder_layer_bwd(const vlr_llama_cfg* cfg, const vlr_layer_weights* w, 
  * un-merged: lora_dropout works and the frozen base weights serve as the reference model (adapter disabled, trl
  * null_ref_context).  Sub-targets of a fused group are stacked: A_*: [n*r][in], B_*: [n*out][r].
  * u [M][7r] (columns qkv | o | gate,up | down) = dropout_t(x) A_t^T, written by the forward and read by the backward.
- * ws_v: scratch [M][3r]; ws_xd (dropout > 0): [M][6*hidden + inter] PER LAYER - the forward stores the seven dropped inputs
- * drop_t(x) there (q,k,v | o | gate,up | down), the backward reads them for dA and then reuses the space as scratch.  Dropout target t of the layer draws its
- * mask from vlr_dropout(seed + t), t = 0..6 in q,k,v,o,gate,up,down order. */
+ * ws_v: scratch [M][3r]; ws_xd: the forward ignores it (ABI v3 stored the seven dropped inputs there: 0.9 GB per layer at the 7B
+ * shapes); the backward with dropout > 0 needs ONE scratch [M][max(hidden, inter)] shared by all layers.  Dropout target t of the layer
+ * draws its mask from vlr_dropout(seed + t), t = 0..6 in q,k,v,o,gate,up,down order; the mask is applied to x while the skinny GEMMs
+ * stage it (vlr_gemm_grouped) and regenerated in the backward - drop(x) is never written. */
 typedef struct {
     int r;
     float scale;     /* lora_alpha / r */

@@ -296,8 +296,9 @@ def lora_delta(h, lora, layer, target, r):
     p = float(lora.get("dropout", 0.0) or 0.0)
     if p > 0 and lora.get("seed") is not None:
         m = dropout_mask(lora["seed"] + 8 * layer + LORA_TARGETS.index(target), h.numel(), p).view(h.shape).to(h.dtype)
-        h = r(h * m * (1.0 / (1.0 - p)), "lora_x")
-    return lora["scale"] * (r(h @ A.t(), "lora_u") @ B.t())
+        h = h * m                      # (exact: the HIP path zeroes the dropped elements of the staged operand; 1 / (1 - p) rides in the scale)
+        return r(lora["scale"] / (1.0 - p) * (h @ A.t()), "lora_u") @ B.t()
+    return r(lora["scale"] * (h @ A.t()), "lora_u") @ B.t()
 
 
 def lora_merged_weights(W, lora, cfg, prefix="language_model.model.layers."):

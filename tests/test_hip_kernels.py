@@ -1313,3 +1313,48 @@ def test_gemm_sched_fused_epilogues(hip):
         else:
             for t0, t1, tol in zip(base, out, (8e-3, 8e-3, 1.6e-2, 2e-5)):
                 check(t1, t0, tol, f"fused epilogue under sched {mode}")
+
+
+# ---------------------------------------------------------------------------------------------------- grouped skinny GEMMs (LoRA)
+@pytest.mark.parametrize("M,in_,r,groups", [(12792, 4096, 128, 3), (1406, 1024, 64, 2), (300, 256, 16, 1)])
+def test_gemm_grouped_masked(hip, M, in_, r, groups):
+    """vlr_gemm_grouped: (a) u_t = alpha * (mask_t . x) A_t^T for the targets of a LoRA group in one launch, the keep mask of
+    vlr_dropout(seed + t) applied to x while it is staged (NT, mask_on 1); (b) dA_t = alpha * v_t^T (mask_t . x) (TN, mask_on 2, split
+    along K = tokens); (c) v_t = dy_t B_t (NN, grouped column blocks) - against torch with the masks of vlr_dropout_mask."""
+    from vlrlhf import _hip as HH
+    HH.ensure_splitk_workspace(DEV, force=True)
+    p, seed, alpha = 0.25, 1234567, 2.0 / 0.75
+    x = rnd(M, in_, seed=1)
+    A = rnd(groups * r, in_, seed=2, scale=0.05)
+    masks = []
+    for t in range(groups):
+        mk = torch.empty(M * in_, dtype=torch.uint8, device=DEV)
+        hip.call("vlr_dropout_mask", mk, M * in_, p, seed + t)
+        masks.append(mk.view(M, in_).float())
+    # (a)
+    ldu = 7 * r
+    u = torch.full((M, ldu), float("nan"), dtype=torch.bfloat16, device=DEV)
+    hip.call("vlr_gemm_grouped", 0, x, A, u, M, r, in_, in_, in_, ldu, groups, 0, r * in_, r, alpha, 0, 1, seed, p, in_)
+    torch.cuda.synchronize()
+    for t in range(groups):
+        ref = alpha * (x.float() * masks[t]) @ A[t * r:(t + 1) * r].float().t()
+        check(u[:, t * r:(t + 1) * r], ref, 8e-3, f"grouped masked NT, target {t}")
+    assert torch.isnan(u[:, groups * r:].float()).all()
+    # (b)
+    v = rnd(M, groups * r, seed=3, scale=0.5)
+    dA = torch.full((groups * r, in_), float("nan"), dtype=torch.bfloat16, device=DEV)
+    hip.call("vlr_gemm_grouped", 2, v, x, dA, r, in_, M, groups * r, in_, in_, groups, r, 0, r * in_, alpha, 0, 2, seed, p, in_)
+    torch.cuda.synchronize()
+    for t in range(groups):
+        ref = alpha * v[:, t * r:(t + 1) * r].float().t() @ (x.float() * masks[t])
+        check(dA[t * r:(t + 1) * r], ref, 8e-3, f"grouped masked TN, target {t}")
+    # (c) + accumulate
+    out = 256
+    dy = rnd(M, groups * out, seed=4)
+    Bw = rnd(groups * out, r, seed=5, scale=0.05)
+    vv = torch.ones(M, groups * r, dtype=torch.bfloat16, device=DEV)
+    hip.call("vlr_gemm_grouped", 1, dy, Bw, vv, M, r, out, groups * out, r, groups * r, groups, out, out * r, r, 1.0, 1, 0, 0, 0.0, 0)
+    torch.cuda.synchronize()
+    for t in range(groups):
+        ref = 1.0 + dy[:, t * out:(t + 1) * out].float() @ Bw[t * out:(t + 1) * out].float()
+        check(vv[:, t * r:(t + 1) * r], ref, 8e-3, f"grouped NN accumulate, target {t}")

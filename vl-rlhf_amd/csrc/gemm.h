@@ -71,6 +71,18 @@ struct GemmParams {
     int sched;
     float* sk_ws;
     uint32_t sk_epoch;
+    // ---- 128x128 kernel only (gemm.hip): GROUPED launches and an on-the-fly lora_dropout mask.
+    // groups > 1: blockIdx.z = group g runs the same problem shape on A + g * gA, B + g * gB, C + g * gC (elements of each type) -
+    //   the skinny per-target GEMMs of a LoRA group (q, k, v / gate, up) in ONE launch that fills the chip instead of three at 39 %.
+    // mask_on: 1 = zero the dropped elements of the k-contiguous A operand (NT: x rows [M][mask_ld]) while it is staged, 2 = of the
+    //   k-strided B operand (TN: x stored [K = rows][mask_ld]); keep(row * mask_ld + col) of vlr_dropout(mask_seed + g); the 1 / (1 - p)
+    //   factor travels in alpha.  x is never copied and drop(x) never stored: the backward regenerates the same mask.
+    int groups;
+    long gA, gB, gC;
+    int mask_on;
+    uint64_t mask_seed;
+    uint32_t mask_thr;
+    int mask_ld;
 };
 #define VLR_SCHED_DEFAULT 0           // GemmParams::sched when VLR_GEMM_SCHED is not set
 #define VLR_SK_MIN_KTILES 16          // stream-K / rotation only for K >= 1024

@@ -23,15 +23,36 @@
 __device__ __forceinline__ int swz_off(int row, int chunk) { return row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 // ---- k-contiguous operand: 128 rows x 64 k, thread -> (row = t/8 + 32 i, chunk = t%8) ------------------------
+// keep bits of the 8 consecutive elements of hash group g (the mask of vlr_dropout: elementwise.hip / common.h)
+__device__ __forceinline__ uint32_t gemm_keep8(uint64_t key, long g, uint32_t thr) {
+    const uint64_t r0 = vlr_mix64(key ^ (uint64_t)(2 * g)), r1 = vlr_mix64(key ^ (uint64_t)(2 * g + 1));
+    uint32_t keep = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        keep |= (uint32_t)(((r0 >> (16 * e)) & 0xffffu) >= thr) << e;
+        keep |= (uint32_t)(((r1 >> (16 * e)) & 0xffffu) >= thr) << (4 + e);
+    }
+    return keep;
+}
+// zero the dropped ones of 8 packed bf16 (keep bit e = element e)
+__device__ __forceinline__ u32x4 mask8(u32x4 v, uint32_t keep) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] &= ((keep >> (2 * i)) & 1 ? 0x0000ffffu : 0u) | ((keep >> (2 * i + 1)) & 1 ? 0xffff0000u : 0u);
+    return v;
+}
+template <bool MASK = false>
 __device__ __forceinline__ void load_kc(const bf16_t* __restrict__ P, int ld, int row0, int nrows, int k0, int K, int t,
-                                        u32x4 (&r)[4]) {
+                                        u32x4 (&r)[4], uint64_t key = 0, uint32_t thr = 0, int mld = 0) {
     const int c = t & 7;
     const int k = k0 + c * 8;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = row0 + (t >> 3) + 32 * i;
         u32x4 v = {0u, 0u, 0u, 0u};
-        if (row < nrows && k + 8 <= K) v = *reinterpret_cast<const u32x4*>(P + (size_t)row * ld + k);
+        if (row < nrows && k + 8 <= K) {
+            v = *reinterpret_cast<const u32x4*>(P + (size_t)row * ld + k);
+            if constexpr (MASK) v = mask8(v, gemm_keep8(key, ((long)row * mld + k) >> 3, thr));     // mld % 8 == 0, k % 8 == 0: one hash group
+        }
         r[i] = v;
     }
 }
@@ -44,8 +65,9 @@ __device__ __forceinline__ void store_kc(char* lds, int t, const u32x4 (&r)[4]) 
     }
 }
 // ---- k-strided operand: stored [K][ncols]; tile 64 k x 128 cols; thread -> (k block = t/32, col quad = t%32) ----
+template <bool MASK = false>
 __device__ __forceinline__ void load_ks(const bf16_t* __restrict__ P, int ld, int col0, int ncols, int k0, int K, int t,
-                                        u32x2 (&r)[8]) {
+                                        u32x2 (&r)[8], uint64_t key = 0, uint32_t thr = 0, int mld = 0) {
     const int kb = t >> 5, nq = t & 31;
     const int col = col0 + nq * 4;
     const bool cok = col + 4 <= ncols;
@@ -53,7 +75,14 @@ __device__ __forceinline__ void load_ks(const bf16_t* __restrict__ P, int ld, in
     for (int j = 0; j < 8; ++j) {
         const int k = k0 + kb * 8 + j;
         u32x2 v = {0u, 0u};
-        if (cok && k < K) v = *reinterpret_cast<const u32x2*>(P + (size_t)k * ld + col);
+        if (cok && k < K) {
+            v = *reinterpret_cast<const u32x2*>(P + (size_t)k * ld + col);
+            if constexpr (MASK) {         // element (row k, columns col .. col + 3): half a hash group
+                const uint32_t keep = gemm_keep8(key, ((long)k * mld + col) >> 3, thr) >> (col & 4);
+                v[0] &= (keep & 1 ? 0x0000ffffu : 0u) | (keep & 2 ? 0xffff0000u : 0u);
+                v[1] &= (keep & 4 ? 0x0000ffffu : 0u) | (keep & 8 ? 0xffff0000u : 0u);
+            }
+        }
         r[j] = v;
     }
 }
@@ -72,14 +101,25 @@ __device__ __forceinline__ void store_ks(char* lds, int t, const u32x2 (&r)[8]) 
     }
 }
 
-template <bool A_KS, bool B_KS>
+template <bool A_KS, bool B_KS, int MASK = 0>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * BK * 2];  // 64 KiB
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    uint64_t mkey = 0;
+    if (p.groups > 1 || MASK) {      // grouped launch: this workgroup's problem; the mask of group g is vlr_dropout(mask_seed + g)
+        const int g = blockIdx.z;
+        p.A += (size_t)g * p.gA;
+        p.B += (size_t)g * p.gB;
+        p.C = (char*)p.C + (size_t)g * p.gC * (p.out_f32 ? 4 : 2);
+        if (p.splitk > 1) p.part += (size_t)g * p.splitk * p.M * p.N;
+        mkey = vlr_mix64(p.mask_seed + (uint64_t)g);
+    }
+    int kabs0 = 0;                   // split-K slices move p.A / p.B: the mask index uses the ABSOLUTE k
     if (p.splitk > 1) {   // split-K slice: this workgroup reduces k in [z*kchunk, (z+1)*kchunk) into its own fp32 partial
         const int z = blockIdx.y, k0 = z * p.kchunk;
+        kabs0 = k0;
         p.A += A_KS ? (size_t)k0 * p.lda : (size_t)k0;
         p.B += B_KS ? (size_t)k0 * p.ldb : (size_t)k0;
         p.K = min(p.kchunk, p.K - k0);
@@ -120,9 +160,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     auto gload = [&](int kt) {
         const int k0 = kt * BK;
         if constexpr (A_KS) load_ks(p.A, p.lda, m0, p.M, k0, p.K, t, ra_s);
-        else load_kc(p.A, p.lda, m0, p.M, k0, p.K, t, ra_c);
-        if constexpr (B_KS) load_ks(p.B, p.ldb, n0, p.N, k0, p.K, t, rb_s);
-        else load_kc(p.B, p.ldb, n0, p.N, k0, p.K, t, rb_c);
+        else if constexpr (MASK == 1) {
+            // x rows [M][mask_ld] masked while staged: the pointer already carries the split-K offset, the hash index needs it back
+            load_kc<true>(p.A - kabs0, p.lda, m0, p.M, k0 + kabs0, p.K + kabs0, t, ra_c, mkey, p.mask_thr, p.mask_ld);
+        } else load_kc(p.A, p.lda, m0, p.M, k0, p.K, t, ra_c);
+        if constexpr (B_KS) {
+            if constexpr (MASK == 2) load_ks<true>(p.B - (size_t)kabs0 * p.ldb, p.ldb, n0, p.N, k0 + kabs0, p.K + kabs0, t, rb_s, mkey, p.mask_thr, p.mask_ld);
+            else load_ks(p.B, p.ldb, n0, p.N, k0, p.K, t, rb_s);
+        } else load_kc(p.B, p.ldb, n0, p.N, k0, p.K, t, rb_c);
     };
     auto lstore = [&](int buf) {
         char* a = smem + buf * (BM + BN) * BK * 2;
@@ -269,7 +314,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, int M, int N, void* Cv,
                                                             int ldc, int out_f32, int accumulate,
                                                             const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual,
-                                                            int ldr, int act, int res_f32) {
+                                                            int ldr, int act, int res_f32, long gC) {
+    // grouped launches: blockIdx.y = group (partials [group][slice][M][N], C + group * gC elements)
+    part += (size_t)blockIdx.y * splits * M * N;
+    Cv = (char*)Cv + (size_t)blockIdx.y * gC * (out_f32 ? 4 : 2);
     const long n4 = (long)M * N / 4;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         f32x4 v = *reinterpret_cast<const f32x4*>(part + i * 4);
@@ -402,8 +450,70 @@ static bool launch_splitk128(int layout, GemmParams p, hipStream_t stream, int m
     int rg = (int)((n4 + 255) / 256);
     if (rg > 2048) rg = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, stream, ws, splits, p.M, p.N, p.C, p.ldc, p.out_f32,
-                       p.accumulate, p.bias, p.residual, p.ldr, p.act, p.res_f32);
+                       p.accumulate, p.bias, p.residual, p.ldr, p.act, p.res_f32, 0L);
     return true;
+}
+
+static GemmParams fused_params(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc);
+// The skinny per-target GEMMs of a LoRA group in ONE launch of the 128x128 kernel (GemmParams::groups): group g runs [M, N, K] on
+// A + g gA, B + g gB, C + g gC (bf16 out, C = alpha * A.B (+ C)); split along K when that fills the chip; mask_on 1 / 2 zeroes the
+// dropped elements of the activation operand while it is staged (keep mask of vlr_dropout(seed + g) over [rows][mask_ld]).
+static int gemm_grouped(int layout, const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int groups,
+                        long gA, long gB, long gC, float alpha, int accumulate, int mask_on, uint64_t seed, float p_drop, int mask_ld,
+                        hipStream_t stream) {
+    VLR_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && groups >= 1 && groups <= 8, "gemm_grouped: bad arguments");
+    VLR_REQUIRE(N % 8 == 0 && ldc % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && gC % 4 == 0, "gemm_grouped: alignment (N %d lda %d ldb %d ldc %d)", N, lda, ldb, ldc);
+    VLR_REQUIRE(!mask_on || (mask_ld % 8 == 0 && ((mask_on == 1 && layout == 0) || (mask_on == 2 && layout == 2))), "gemm_grouped: mask on the NT A / TN B operand only");
+    GemmParams p = fused_params(A, B, C, M, N, K, lda, ldb, ldc);
+    p.alpha = alpha; p.accumulate = accumulate;
+    p.groups = groups; p.gA = gA; p.gB = gB; p.gC = gC;
+    p.mask_on = mask_on; p.mask_seed = seed; p.mask_thr = vlr_dropout_thr(p_drop); p.mask_ld = mask_ld;
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    int splits = 1;
+    float* ws = nullptr;
+    if (tiles * groups < 384 && K >= 1024) {
+        splits = 512 / (tiles * groups);
+        if (splits > 16) splits = 16;
+        if (splits > K / 256) splits = K / 256;
+        ws = splits >= 2 ? splitk_slot(stream) : nullptr;
+        const long per = (long)groups * M * N * 4;
+        const long cap = g_splitk_bytes < SPLITK_SLOT_BYTES ? g_splitk_bytes : SPLITK_SLOT_BYTES;     // (the second half of a slot holds slabs)
+        if (ws && (long)splits * per > cap) splits = (int)(cap / per);
+        if (!ws || splits < 2) splits = 1;
+    }
+    if (splits > 1) {
+        const int kchunk = (((K + splits - 1) / splits) + 31) / 32 * 32;
+        splits = (K + kchunk - 1) / kchunk;
+        p.splitk = splits; p.kchunk = kchunk; p.part = ws;
+    }
+    const dim3 grid(tiles, splits, groups);
+    const int pi = vlr_prof_begin(layout, 2.0 * M * N * K * groups, stream);
+    if (layout == 0) {
+        if (mask_on) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, 1>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, dim3(256), 0, stream, p);
+    } else if (layout == 1) {
+        hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, dim3(256), 0, stream, p);
+    } else {
+        if (mask_on) hipLaunchKernelGGL((gemm_bf16_kernel<true, true, 2>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, dim3(256), 0, stream, p);
+    }
+    if (splits > 1) {
+        const long n4 = (long)M * N / 4;
+        int rg = (int)((n4 + 255) / 256);
+        if (rg > 1024) rg = 1024;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg, groups), dim3(256), 0, stream, ws, splits, M, N, C, ldc, 0, accumulate,
+                           (const bf16_t*)nullptr, (const bf16_t*)nullptr, 0, 0, 0, gC);
+    }
+    vlr_prof_end(pi, stream);
+    return vlr_check_launch("gemm_grouped");
+}
+// C-ABI face of the grouped skinny GEMM (the decoder-layer LoRA passes of layers.cpp; tests)
+extern "C" int vlr_gemm_grouped(int layout, const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                int groups, long gA, long gB, long gC, float alpha, int accumulate, int mask_on, uint64_t seed,
+                                float p_drop, int mask_ld, hipStream_t stream) {
+    VLR_REQUIRE(layout >= 0 && layout <= 2, "vlr_gemm_grouped: layout %d", layout);
+    VLR_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "vlr_gemm_grouped: 0 <= p < 1, got %g", (double)p_drop);
+    return gemm_grouped(layout, A, B, C, M, N, K, lda, ldb, ldc, groups, gA, gB, gC, alpha, accumulate, mask_on, seed, p_drop, mask_ld, stream);
 }
 
 static int gemm_impl_ex(int layout, const void* A, const void* B, void* C, const void* bias, const void* residual, int M, int N,
@@ -488,6 +598,7 @@ static int gemm_impl_ex(int layout, const void* A, const void* B, void* C, const
     p.A2 = p.B2 = nullptr; p.lda2 = p.ldb2 = p.K2 = 0; p.seg_b0 = p.seg_b1 = 0x7fffffff; p.drop_key = 0; p.drop_thr = 0; p.drop_ld = 0;
     p.res_f32 = residual ? res_f32 : 0;
     p.sched = 0; p.sk_ws = nullptr; p.sk_epoch = 0;
+    p.groups = 1; p.gA = p.gB = p.gC = 0; p.mask_on = 0; p.mask_seed = 0; p.mask_thr = 0; p.mask_ld = 0;
     const int pi = vlr_prof_begin(layout, 2.0 * M * N * K, stream);
     // ---- split-K for problems whose output is a handful of tiles but whose reduction is long: the LoRA adapter gradients
     // (TN: dB = dy^T u [out x r], dA = v^T x [r x in], reduction over all tokens) - 32..96 workgroups would leave most CUs idle
@@ -566,6 +677,7 @@ static GemmParams fused_params(const void* A, const void* B, void* C, int M, int
     p.f0 = p.f1 = nullptr;
     p.A2 = p.B2 = nullptr; p.lda2 = p.ldb2 = p.K2 = 0; p.seg_b0 = p.seg_b1 = 0x7fffffff; p.drop_key = 0; p.drop_thr = 0; p.drop_ld = 0; p.res_f32 = 0;
     p.sched = 0; p.sk_ws = nullptr; p.sk_epoch = 0;
+    p.groups = 1; p.gA = p.gB = p.gC = 0; p.mask_on = 0; p.mask_seed = 0; p.mask_thr = 0; p.mask_ld = 0;
     return p;
 }
 

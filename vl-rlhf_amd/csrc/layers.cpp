@@ -158,13 +158,12 @@ extern "C" int vlr_decoder_layer_bwd(const vlr_llama_cfg* cfg, const vlr_layer_w
 // u_t = s * dropout_t(x) A_t^T for the n sub-targets of a group (the B half rides the K loop of the base GEMM: vlr_gemm_*_lora)
 static int lora_group_a(int n, int r, int in, const void* x, int ldx, const void* A, void* u, int ldu, float scale, float p,
                         uint64_t seed, void* ws_xd, int M, hipStream_t st) {
+    (void)ws_xd;
     if (p > 0.f) {
-        for (int t = 0; t < n; ++t) {
-            void* xd_t = off(ws_xd, (size_t)t * M * in);          // kept for the backward (dA_t = s v_t^T drop_t(x))
-            CHECK(vlr_dropout(x, xd_t, (long)M * in, p, seed + t, 1.f, 0, st));
-            CHECK(vlr_gemm_bf16_scaled(0, xd_t, off(A, (size_t)t * r * in), off(u, (size_t)t * r), nullptr, nullptr, M, r, in, in, in, ldu,
-                                       0, 0, 0, 0, scale, st));
-        }
+        // ONE grouped launch for the n sub-targets: target t = group t reads the SAME x with its own keep mask (vlr_dropout(seed + t),
+        // zeroed while the operand is staged - drop(x) is never written) against its own A_t; 1 / (1 - p) rides in alpha
+        VLR_REQUIRE(ldx == in, "lora: the dropout mask is indexed over [M][in]; x must be dense (ldx %d, in %d)", ldx, in);
+        CHECK(vlr_gemm_grouped(0, x, A, u, M, r, in, ldx, in, ldu, n, 0L, (long)r * in, (long)r, scale / (1.f - p), 0, 1, seed, p, in, st));
     } else {
         CHECK(vlr_gemm_bf16_scaled(0, x, A, u, nullptr, nullptr, M, n * r, in, ldx, in, ldu, 0, 0, 0, 0, scale, st));
     }
@@ -177,22 +176,24 @@ static int lora_group_bwd(int n, int r, int in, const int* outs, const void* x, 
                           void* ws_xd, int accumulate, int M, hipStream_t st) {
     const int nr = n * r;
     size_t ofs[4] = {0, 0, 0, 0};
-    for (int t = 0; t < n; ++t) ofs[t + 1] = ofs[t] + (size_t)outs[t];
-    for (int t = 0; t < n; ++t) {
-        const void* dyt = off(dy, ofs[t]);
-        const int out = outs[t];
-        CHECK(vlr_gemm_bf16(2, dyt, off(u, (size_t)t * r), off(dB, ofs[t] * r), nullptr, nullptr, out, r, M, lddy, ldu, r,
-                            0, 0, accumulate, 0, st));                                               // dB_t = dy_t^T (s u_t): u is stored scaled
-        CHECK(vlr_gemm_bf16(1, dyt, off(B, ofs[t] * r), off(v, (size_t)t * r), nullptr, nullptr, M, r, out, lddy, r, nr,
-                            0, 0, 0, 0, st));                                                                       // v_t = dy_t B_t
+    bool same = true;
+    for (int t = 0; t < n; ++t) { ofs[t + 1] = ofs[t] + (size_t)outs[t]; same = same && outs[t] == outs[0]; }
+    // dB_t = dy_t^T (s u_t) and v_t = dy_t B_t: the n sub-targets as the groups of one launch each when their widths agree (multi-head
+    // attention; grouped-query k / v are narrower than q: one launch per target then)
+    const int ng = same ? 1 : n, gs = same ? n : 1;
+    for (int g = 0; g < ng; ++g) {
+        const int out = outs[g];
+        CHECK(vlr_gemm_grouped(2, off(dy, ofs[g]), off(u, (size_t)g * r), off(dB, ofs[g] * r), out, r, M, lddy, ldu, r, gs, (long)out, (long)r,
+                               (long)out * r, 1.f, accumulate, 0, 0, 0.f, 0, st));                       // u is stored scaled
+        CHECK(vlr_gemm_grouped(1, off(dy, ofs[g]), off(B, ofs[g] * r), off(v, (size_t)g * r), M, r, out, lddy, r, nr, gs, (long)out,
+                               (long)out * r, (long)r, 1.f, 0, 0, 0, 0.f, 0, st));
     }
     if (p > 0.f) {
-        for (int t = 0; t < n; ++t) {
-            void* xd_t = off(ws_xd, (size_t)t * M * in);          // drop_t(x) saved by the forward; dead after dA_t -> reused as scratch
-            CHECK(vlr_gemm_bf16_scaled(2, off(v, (size_t)t * r), xd_t, off(dA, (size_t)t * r * in), nullptr, nullptr, r, in, M, nr, in, in,
-                                       0, 0, accumulate, 0, scale, st));                                            // dA_t = s v_t^T drop_t(x)
-            CHECK(vlr_gemm_dropout_acc(off(v, (size_t)t * r), nr, off(A, (size_t)t * r * in), dx, xd_t, M, in, r, p, seed + t, scale, st));   // dx += s mask_t (v_t A_t)/(1-p)
-        }
+        VLR_REQUIRE(ws_xd, "lora backward: lora_dropout > 0 needs a scratch buffer [M][in]");
+        // dA_t = s / (1 - p) v_t^T (mask_t . x): the n targets as groups, x masked while it is staged (the mask of the forward, regenerated)
+        CHECK(vlr_gemm_grouped(2, v, x, dA, r, in, M, nr, in, in, n, (long)r, 0L, (long)r * in, scale / (1.f - p), accumulate, 2, seed, p, in, st));
+        for (int t = 0; t < n; ++t)
+            CHECK(vlr_gemm_dropout_acc(off(v, (size_t)t * r), nr, off(A, (size_t)t * r * in), dx, ws_xd, M, in, r, p, seed + t, scale, st));   // dx += s mask_t (v_t A_t)/(1-p)
     } else {
         CHECK(vlr_gemm_bf16_scaled(2, v, x, dA, nullptr, nullptr, nr, in, M, nr, in, in, 0, 0, accumulate, 0, scale, st));  // dA = s v^T x
         CHECK(vlr_gemm_bf16_scaled(1, v, A, dx, nullptr, nullptr, M, in, nr, nr, in, in, 0, 0, 1, 0, scale, st));     // dx += s v A
@@ -203,7 +204,7 @@ static int lora_group_bwd(int n, int r, int in, const int* outs, const void* x, 
 static int lora_check(const char* who, const vlr_lora_weights* lw, const void* ws_xd) {
     VLR_REQUIRE(lw->r > 0 && lw->r % 8 == 0, "%s: LoRA rank must be a positive multiple of 8, got %d", who, lw->r);
     VLR_REQUIRE(lw->dropout >= 0.f && lw->dropout < 1.f, "%s: lora_dropout must be in [0,1), got %g", who, (double)lw->dropout);
-    VLR_REQUIRE(lw->dropout == 0.f || ws_xd, "%s: lora_dropout > 0 needs the xd buffer [M][6*hidden + inter]", who);
+    (void)ws_xd;      // (ABI v3 kept drop(x) of the seven targets there; since v4 the mask is applied while the operand is staged)
     VLR_REQUIRE(lw->a_qkv && lw->b_qkv && lw->a_o && lw->b_o && lw->a_gu && lw->b_gu && (!lw->a_down == !lw->b_down), "%s: null adapter pointer", who);
     VLR_REQUIRE(lw->qkv_targets == 0 || lw->qkv_targets == 1 || lw->qkv_targets == 3, "%s: qkv_targets must be 1 or 3, got %d", who, lw->qkv_targets);
     return VLR_OK;
@@ -219,7 +220,7 @@ extern "C" int vlr_decoder_layer_fwd_lora(const vlr_llama_cfg* cfg, const vlr_la
     const int Nq = cfg->heads * cfg->head_dim, Nkv = kvh * cfg->head_dim, N = Nq + 2 * Nkv;
     VLR_REQUIRE(Nq == H, "vlr_decoder_layer_fwd_lora: heads*head_dim != hidden");
     const float sc = lw->scale, p = lw->dropout;
-#define XD(seg) (ws_xd ? (void*)off(ws_xd, (size_t)(seg) * M * H) : nullptr)   // segment base in units of M*H elements
+#define XD(seg) (ws_xd)      // ABI v4: one scratch [M][max(hidden, inter)] (the fallback path of vlr_gemm_dropout_acc), not per-target copies
     const int rf = cfg->resid_f32;
     CHECK(norm_fwd(rf, x_in, w->ln1, a->xn1, a->rstd1, M, H, cfg->rms_eps, st));
     const int nq = lw->qkv_targets == 1 ? 1 : 3;             // one adapter over the fused projection (Qwen c_attn) or q, k, v separately
@@ -257,7 +258,7 @@ extern "C" int vlr_decoder_layer_bwd_lora(const vlr_llama_cfg* cfg, const vlr_la
     VLR_REQUIRE(Nq == H, "vlr_decoder_layer_bwd_lora: heads*head_dim != hidden");
     const int o_qkv[3] = {Nq, Nkv, Nkv}, o_h[1] = {H}, o_gu[2] = {I, I};
     const float sc = lw->scale, p = lw->dropout;
-#define XD(seg) (ws_xd ? (void*)off(ws_xd, (size_t)(seg) * M * H) : nullptr)   // segment base in units of M*H elements
+#define XD(seg) (ws_xd)      // ABI v4: one scratch [M][max(hidden, inter)] (the fallback path of vlr_gemm_dropout_acc), not per-target copies
     // ---- MLP
     CHECK(vlr_gemm_bf16(1, dx_out, w->wdown, ws->dact, nullptr, nullptr, M, I, H, H, I, I, 0, 0, 0, 0, st));
     if (lw->a_down)

@@ -551,12 +551,9 @@ class LlavaHipEngine:
             if "u" not in sh or sh["u"].shape[1] != 7 * r:
                 sh["u"] = torch.empty(M, 7 * r, dtype=BF16, device=self.dev)
             lw, _ = self._lora_structs(l, train=True)
-            xd = None
-            if self.lora["dropout"] > 0 and self.training:     # dropped inputs of the seven targets, kept per layer for the backward
-                if "xd" not in sh:
-                    sh["xd"] = torch.empty(M, 6 * self.H + self.I, dtype=BF16, device=self.dev)
-                xd = sh["xd"]
-            _hip.call("vlr_decoder_layer_fwd_lora", self.llama_cfg, self.layer_weights(ws, l), lw, a["struct"], sh["u"], xd,
+            # (lora_dropout: the keep mask is applied to x while the adapter GEMMs stage it and regenerated in the backward - no dropped
+            # copies of the seven inputs are kept any more: 0.9 GB per layer at the 7B shapes)
+            _hip.call("vlr_decoder_layer_fwd_lora", self.llama_cfg, self.layer_weights(ws, l), lw, a["struct"], sh["u"], None,
                       lora_seed + 8 * l, x, e["pos"], e["mask"], Bn, S)
         else:
             _hip.call("vlr_decoder_layer_fwd_ex", self.llama_cfg, self.layer_weights(ws, l), a["struct"], x, e["pos"], e["mask"], Bn, S,
@@ -952,6 +949,7 @@ class LlavaHipEngine:
                               wsb["dx_mid"].data_ptr(), wsb["delta"].data_ptr(), self._norm_ws.data_ptr())
         ws_v = self._buf(("lora_v", M), (M, 3 * r))
         drop = self.lora["dropout"] > 0 and self.training
+        scratch = self._buf(("lora_scratch", M), (M, max(H, I))) if drop else None     # fallback path of the fused dropout-accumulate
         cur, nxt = dxa, dxb
         for l in range(self.L - 1, -1, -1):
             a = ctx["acts"][l]
@@ -961,7 +959,7 @@ class LlavaHipEngine:
                 self._layer_fwd_call(ws, l, a, x_in, ctx["embed"], Bn, S, True, True, ctx["lora_seed"])
             sh = a.get("shared", a)
             _hip.call("vlr_decoder_layer_bwd_lora", self.llama_cfg, self.layer_weights(ws, l), lw, lg, acc, a["struct"], sh["u"],
-                      lws, ws_v, sh["xd"] if drop else None, ctx["lora_seed"] + 8 * l, x_in, cur, nxt, ctx["pos"], ctx["mask"], Bn, S)
+                      lws, ws_v, scratch, ctx["lora_seed"] + 8 * l, x_in, cur, nxt, ctx["pos"], ctx["mask"], Bn, S)
             cur, nxt = nxt, cur
         self.grad_fresh = False
         if self.reducer is not None:
