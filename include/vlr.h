@@ -107,6 +107,15 @@ int vlr_gemm_grouped(int layout, const void* A, const void* B, void* C, int M, i
                      vlr_stream_t stream);
 int vlr_gemm_dropout_acc(const void* v, int ldv, const void* A, void* dx, void* scratch, int M, int in, int r, float p,
                          uint64_t seed, float scale, vlr_stream_t stream);
+/*  vlr_gemm_dropout_acc_multi: the same for the n targets that share dx, in ONE pass over it: dx (+)= scaling / (1 - p) * sum_t mask_t .*
+ *                          (v_t . A_t), v [M][ldv] = the n blocks of r columns side by side, A = the n stacked [r][in] matrices, mask_t of
+ *                          vlr_dropout(seed + t); accumulate = 0 WRITES dx (the adapter term alone) */
+int vlr_gemm_dropout_acc_multi(int n, const void* v, int ldv, const void* A, void* dx, int M, int in, int r, float p, uint64_t seed,
+                               float scale, int accumulate, vlr_stream_t stream);
+/*  vlr_gemm_swiglu_bwd_add: vlr_gemm_swiglu_bwd with an addend on d act before the SwiGLU backward (d act = dy . wdown + dact_add, bf16
+ *                          [M][I]; may be the dact_ws buffer) - the LoRA adapter term of down_proj */
+int vlr_gemm_swiglu_bwd_add(const void* dy, const void* wdown, void* gu_inout, void* dact_ws, const void* dact_add, int M, int I, int H,
+                            vlr_stream_t stream);
 int vlr_gemm_lora(const void* x, int ldx, const void* W, void* y, int ldy, const void* residual, int ldr, int M, int N, int K,
                   const void* u, int ldu, const void* Bl, int r, vlr_stream_t stream);
 /*  vlr_gemm_lora_f32res  : the same on the fp32 residual stream - y fp32 [M][ldy] = x W^T + u Bl^T + residual fp32 [M][ldr] */

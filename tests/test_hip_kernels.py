@@ -1358,3 +1358,49 @@ def test_gemm_grouped_masked(hip, M, in_, r, groups):
     for t in range(groups):
         ref = 1.0 + dy[:, t * out:(t + 1) * out].float() @ Bw[t * out:(t + 1) * out].float()
         check(vv[:, t * r:(t + 1) * r], ref, 8e-3, f"grouped NN accumulate, target {t}")
+
+
+@pytest.mark.parametrize("M,in_,r,n,p", [(12792, 4096, 128, 3, 0.05), (1406, 1024, 64, 2, 0.25), (300, 256, 16, 1, 0.0)])
+def test_gemm_dropout_acc_multi(hip, M, in_, r, n, p):
+    """vlr_gemm_dropout_acc_multi: dx (+)= scale / (1 - p) * sum_t mask_t . (v_t A_t) for the n targets of a group in ONE pass over dx,
+    against torch with the masks of vlr_dropout_mask; both the accumulate and the write form"""
+    seed, scale = 4242, 2.0
+    v = rnd(M, n * r, seed=1, scale=0.5)
+    A = rnd(n * r, in_, seed=2, scale=0.05)
+    dx0 = rnd(M, in_, seed=3)
+    ref = torch.zeros(M, in_, device=DEV)
+    for t in range(n):
+        if p > 0:
+            mk = torch.empty(M * in_, dtype=torch.uint8, device=DEV)
+            hip.call("vlr_dropout_mask", mk, M * in_, p, seed + t)
+            mk = mk.view(M, in_).float()
+        else:
+            mk = 1.0
+        ref += scale / (1 - p) * mk * (v[:, t * r:(t + 1) * r].float() @ A[t * r:(t + 1) * r].float())
+    dx = dx0.clone()
+    hip.call("vlr_gemm_dropout_acc_multi", n, v, n * r, A, dx, M, in_, r, p, seed, scale, 1)
+    torch.cuda.synchronize()
+    check(dx, dx0.float() + ref, 8e-3, "dropacc multi (accumulate)")
+    dx = torch.full((M, in_), float("nan"), dtype=torch.bfloat16, device=DEV)
+    hip.call("vlr_gemm_dropout_acc_multi", n, v, n * r, A, dx, M, in_, r, p, seed, scale, 0)
+    torch.cuda.synchronize()
+    check(dx, ref, 8e-3, "dropacc multi (write)")
+
+
+@pytest.mark.parametrize("shape", [(4104, 4352, 512), (300, 256, 128)])
+def test_gemm_swiglu_bwd_add(hip, shape):
+    """vlr_gemm_swiglu_bwd_add: d act = dy Wdown + addend before the SwiGLU backward (the addend buffer is also the fallback scratch)"""
+    M, I, H = shape
+    dy = rnd(M, H, seed=1)
+    w = rnd(H, I, scale=0.05, seed=2)
+    gu0 = rnd(M, 2 * I, seed=3)
+    add = rnd(M, I, seed=4, scale=0.3)
+    g, u = gu0[:, :I].float(), gu0[:, I:].float()
+    dact = dy.float() @ w.float() + add.float()
+    sg = torch.sigmoid(g)
+    ref = torch.cat([dact * u * sg * (1 + g * (1 - sg)), dact * g * sg], dim=1)
+    gu = gu0.clone()
+    ws = add.clone()
+    hip.call("vlr_gemm_swiglu_bwd_add", dy, w, gu, ws, ws, M, I, H)
+    torch.cuda.synchronize()
+    check(gu, ref, 1.6e-2, f"swiglu bwd + addend {shape}")

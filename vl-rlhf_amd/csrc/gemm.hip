@@ -310,6 +310,117 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// LoRA input gradient of the targets that share one input, in ONE pass over dx:
+//   dx [M][in] (+)= sum_t keep_t(row * in + col) ? alpha * (v_t [M][r] . A_t [r][in]) : 0,  keep_t = the mask of vlr_dropout(seed + t)
+// (q, k, v -> d xn1; gate, up -> d xn2; o -> d attn; down -> d act).  Per term: a K = r loop (two 64-deep steps at r = 128) into the
+// MFMA accumulators, through the per-wave fp32 LDS stage into row-major registers (8 rows x 8 consecutive columns per lane: one hash
+// group each), masked and summed there; then ONE read-modify-write (or write) of the bf16 tile.  GemmParams: A = v (lda = ldv, term
+// stride gA = r columns), B = A_t stack (ldb = in, term stride gB = r * in), C = dx, N = in, K = r, groups = terms.
+__global__ __launch_bounds__(256) void dropacc_multi_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[(BM + BN) * BK * 2 * 2];  // 64 KiB: operand tiles / the fp32 stage
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    int pid;
+    {
+        const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+        const int q = nwg >> 3, rem = nwg & 7;
+        pid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+    }
+    const int m0 = (pid / tiles_n) * BM, n0 = (pid % tiles_n) * BN;      // row-major walk: neighbours share the v rows
+    const int gm0 = m0 + wm * 64, gn0 = n0 + wn * 64;
+    const int cq = (lane & 7) * 8, gn = gn0 + cq;
+    float sum[8][8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum[it][e] = 0.f;
+    const int nt = (p.K + BK - 1) / BK;
+    float* stage = reinterpret_cast<float*>(smem) + wave * 64 * 64;
+    for (int term = 0; term < p.groups; ++term) {
+        const bf16_t* A = p.A + (size_t)term * p.gA;
+        const bf16_t* B = p.B + (size_t)term * p.gB;
+        const uint64_t key = vlr_mix64(p.mask_seed + (uint64_t)term);
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int kt = 0; kt < nt; ++kt) {
+            u32x4 ra[4];
+            u32x2 rb[8];
+            load_kc(A, p.lda, m0, p.M, kt * BK, p.K, t, ra);
+            load_ks(B, p.ldb, n0, p.N, kt * BK, p.K, t, rb);
+            __syncthreads();                               // the previous step's fragment reads / the previous term's stage reads are done
+            store_kc(smem, t, ra);
+            store_ks(smem + BM * BK * 2, t, rb);
+            __syncthreads();
+            const char* a = smem;
+            const char* b = smem + BM * BK * 2;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                bf16x8 fa[2], fb[2];
+                const int c = kk * 2 + (lane >> 5);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(a + swz_off(wm * 64 + i * 32 + (lane & 31), c));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(b + swz_off(wn * 64 + j * 32 + (lane & 31), c));
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    stage[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 8 + (lane >> 3);
+            const int gm = gm0 + row;
+            if (gm < p.M && gn + 8 <= p.N) {
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(stage + row * 64 + cq);
+                const f32x4 s1 = *reinterpret_cast<const f32x4*>(stage + row * 64 + cq + 4);
+                const uint32_t keep = gemm_keep8(key, ((long)gm * p.mask_ld + gn) >> 3, p.mask_thr);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if ((keep >> e) & 1) sum[it][e] += p.alpha * s0[e];
+                    if ((keep >> (4 + e)) & 1) sum[it][4 + e] += p.alpha * s1[e];
+                }
+            }
+        }
+    }
+    bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int gm = gm0 + it * 8 + (lane >> 3);
+        if (gm < p.M && gn + 8 <= p.N) {
+            bf16_t* dst = C + (size_t)gm * p.ldc + gn;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = sum[it][e];
+            if (p.accumulate) {
+                float ov[8];
+                unpack8(*reinterpret_cast<const u32x4*>(dst), ov);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += ov[e];
+            }
+            *reinterpret_cast<u32x4*>(dst) = pack8(v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // split-K epilogue: C = act(sum_z part[z] + bias) + residual (+ C), 4 columns per thread (the partials carry alpha already)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, int M, int N, void* Cv,
                                                             int ldc, int out_f32, int accumulate,
@@ -514,6 +625,27 @@ extern "C" int vlr_gemm_grouped(int layout, const void* A, const void* B, void* 
     VLR_REQUIRE(layout >= 0 && layout <= 2, "vlr_gemm_grouped: layout %d", layout);
     VLR_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "vlr_gemm_grouped: 0 <= p < 1, got %g", (double)p_drop);
     return gemm_grouped(layout, A, B, C, M, N, K, lda, ldb, ldc, groups, gA, gB, gC, alpha, accumulate, mask_on, seed, p_drop, mask_ld, stream);
+}
+
+// dx [M][in] (+)= sum over the n targets t of scale / (1 - p) * keep_t . (v_t . A_t): v [M][ldv] holds the n blocks of r columns side by
+// side, A the n stacked [r][in] lora_A matrices, keep_t = the mask of vlr_dropout(seed + t) over [M][in] (p = 0: no mask).  ONE pass
+// over dx whatever n is (the per-target vlr_gemm_dropout_acc makes n).  accumulate = 0 writes dx instead of adding to it.
+extern "C" int vlr_gemm_dropout_acc_multi(int n, const void* v, int ldv, const void* A, void* dx, int M, int in, int r, float p,
+                                          uint64_t seed, float scale, int accumulate, hipStream_t stream) {
+    VLR_REQUIRE(v && A && dx, "vlr_gemm_dropout_acc_multi: null operand");
+    VLR_REQUIRE(n >= 1 && n <= 8 && M > 0 && in > 0 && r > 0 && in % 8 == 0 && r % 8 == 0 && ldv % 8 == 0 && ldv >= n * r,
+                "vlr_gemm_dropout_acc_multi: bad shape n=%d M=%d in=%d r=%d ldv=%d", n, M, in, r, ldv);
+    VLR_REQUIRE(p >= 0.f && p < 1.f, "vlr_gemm_dropout_acc_multi: 0 <= p < 1 required, got %g", (double)p);
+    VLR_REQUIRE(!(((uintptr_t)v | (uintptr_t)A | (uintptr_t)dx) & 15), "vlr_gemm_dropout_acc_multi: 16-byte aligned operands");
+    GemmParams g = fused_params(v, A, dx, M, in, r, ldv, in, in);
+    g.alpha = scale / (1.f - p); g.accumulate = accumulate;
+    g.groups = n; g.gA = r; g.gB = (long)r * in;
+    g.mask_seed = seed; g.mask_thr = vlr_dropout_thr(p); g.mask_ld = in;
+    const int tiles = ((M + BM - 1) / BM) * ((in + BN - 1) / BN);
+    const int pi = vlr_prof_begin(VLR_K_GEMM_NN, 2.0 * M * in * r * n, stream);
+    hipLaunchKernelGGL(dropacc_multi_kernel, dim3(tiles), dim3(256), 0, stream, g);
+    vlr_prof_end(pi, stream);
+    return vlr_check_launch("vlr_gemm_dropout_acc_multi");
 }
 
 static int gemm_impl_ex(int layout, const void* A, const void* B, void* C, const void* bias, const void* residual, int M, int N,
@@ -925,7 +1057,20 @@ extern "C" int vlr_swiglu_bwd(void* gu_inout, const void* dact, int M, int I, hi
 
 // d gate | d up (in place in gu [M][2I]) = SwiGLU'(gate, up) * (dy [M][H] . wdown [H][I]): the dgrad of the down projection with
 // the SwiGLU backward in its epilogue - d act [M][I] is never written (dact_ws is only used for rows / shapes that fall back)
+static int gemm_swiglu_bwd_impl(const void* dy, const void* wdown, void* gu, void* dact_ws, const void* dact_add, int M, int I, int H,
+                                hipStream_t stream);
 extern "C" int vlr_gemm_swiglu_bwd(const void* dy, const void* wdown, void* gu, void* dact_ws, int M, int I, int H, hipStream_t stream) {
+    return gemm_swiglu_bwd_impl(dy, wdown, gu, dact_ws, nullptr, M, I, H, stream);
+}
+// the same with an addend on d act before the SwiGLU backward: d act = dy . wdown + dact_add [M][I] (bf16) - the LoRA adapter term of
+// down_proj, which must reach d act first.  dact_add may be the dact_ws buffer itself.
+extern "C" int vlr_gemm_swiglu_bwd_add(const void* dy, const void* wdown, void* gu, void* dact_ws, const void* dact_add, int M, int I,
+                                       int H, hipStream_t stream) {
+    VLR_REQUIRE(dact_add, "vlr_gemm_swiglu_bwd_add: null addend");
+    return gemm_swiglu_bwd_impl(dy, wdown, gu, dact_ws, dact_add, M, I, H, stream);
+}
+static int gemm_swiglu_bwd_impl(const void* dy, const void* wdown, void* gu, void* dact_ws, const void* dact_add, int M, int I, int H,
+                                hipStream_t stream) {
     VLR_REQUIRE(dy && wdown && gu && dact_ws, "vlr_gemm_swiglu_bwd: null operand");
     VLR_REQUIRE(M > 0 && I > 0 && H > 0 && I % 8 == 0 && H % 8 == 0, "vlr_gemm_swiglu_bwd: bad shape M=%d I=%d H=%d", M, I, H);
     const int tn = (I + 255) / 256;
@@ -934,6 +1079,7 @@ extern "C" int vlr_gemm_swiglu_bwd(const void* dy, const void* wdown, void* gu, 
     const int M1 = peel ? (tm256 - peel) * 256 : M;
     GemmParams p = fused_params(dy, wdown, dact_ws, M1, I, H, H, I, I);
     p.fuse = 3; p.C2 = gu; p.ldc2 = 2 * I;
+    p.residual = (const bf16_t*)dact_add; p.ldr = I;
     int done = 0;
     const int pi_ = vlr_prof_begin(VLR_K_GEMM_NN, 2.0 * M1 * I * H, stream);
     const bool took_ = vlr_gemm256p_swiglu_bwd_try_launch(p, stream);
@@ -946,6 +1092,7 @@ extern "C" int vlr_gemm_swiglu_bwd(const void* dy, const void* wdown, void* gu, 
     if (done > 0 && done < M) {       // the peeled rows: same fused epilogue, one tile per workgroup
         GemmParams p2 = fused_params((const bf16_t*)dy + (size_t)done * H, wdown, (bf16_t*)dact_ws + (size_t)done * I, M - done, I, H, H, I, I);
         p2.fuse = 3; p2.C2 = (bf16_t*)gu + (size_t)done * 2 * I; p2.ldc2 = 2 * I;
+        p2.residual = dact_add ? (const bf16_t*)dact_add + (size_t)done * I : nullptr; p2.ldr = I;
         const int pj_ = vlr_prof_begin(VLR_K_GEMM_NN, 2.0 * (M - done) * I * H, stream);
         const bool took2_ = vlr_gemm256p_swiglu_bwd_try_launch(p2, stream);
         vlr_prof_end(took2_ ? pj_ : -1, stream);
@@ -958,7 +1105,7 @@ extern "C" int vlr_gemm_swiglu_bwd(const void* dy, const void* wdown, void* gu, 
     if (done < M) {
         const bf16_t* dyr = (const bf16_t*)dy + (size_t)done * H;
         bf16_t* da = (bf16_t*)dact_ws + (size_t)done * I;
-        int rc = gemm_impl(1, dyr, wdown, da, nullptr, nullptr, M - done, I, H, H, I, I, 0, 0, 0, 0, 1.0f, stream);
+        int rc = gemm_impl(1, dyr, wdown, da, nullptr, dact_add ? (const bf16_t*)dact_add + (size_t)done * I : nullptr, M - done, I, H, H, I, I, I, 0, 0, 0, 1.0f, stream);
         if (rc != VLR_OK) return rc;
         return vlr_swiglu_bwd((bf16_t*)gu + (size_t)done * 2 * I, da, M - done, I, stream);
     }

@@ -789,6 +789,12 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                         d[e] = x0;
                         d[4 + e] = x1;
                     }
+                    if (p.residual && gm < p.M && gn + 8 <= I) {     // + addend on d act (the LoRA term of down_proj), same 8-column layout
+                        float ad[8];
+                        unpack8(*reinterpret_cast<const u32x4*>(p.residual + (size_t)gm * p.ldr + gn), ad);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) d[e] += ad[e];
+                    }
                     unpack8(gq[i][b], g);
                     unpack8(uq[i][b], u);
 #pragma unroll

@@ -171,9 +171,10 @@ static int lora_group_a(int n, int r, int in, const void* x, int ldx, const void
 }
 
 // dx [M][in] already holds dy W; adds the adapter path and writes the adapter gradients
+// dx_fresh = 1: dx is WRITTEN (= the adapter term alone; the caller adds dy W afterwards - the fused SwiGLU-backward GEMM of down_proj)
 static int lora_group_bwd(int n, int r, int in, const int* outs, const void* x, const void* dy, int lddy, const void* A, const void* B,
                           void* dA, void* dB, const void* u, int ldu, void* v, void* dx, float scale, float p, uint64_t seed,
-                          void* ws_xd, int accumulate, int M, hipStream_t st) {
+                          void* ws_xd, int accumulate, int M, hipStream_t st, int dx_fresh = 0) {
     const int nr = n * r;
     size_t ofs[4] = {0, 0, 0, 0};
     bool same = true;
@@ -189,14 +190,14 @@ static int lora_group_bwd(int n, int r, int in, const int* outs, const void* x, 
                                (long)out * r, (long)r, 1.f, 0, 0, 0, 0.f, 0, st));
     }
     if (p > 0.f) {
-        VLR_REQUIRE(ws_xd, "lora backward: lora_dropout > 0 needs a scratch buffer [M][in]");
+        (void)ws_xd;
         // dA_t = s / (1 - p) v_t^T (mask_t . x): the n targets as groups, x masked while it is staged (the mask of the forward, regenerated)
         CHECK(vlr_gemm_grouped(2, v, x, dA, r, in, M, nr, in, in, n, (long)r, 0L, (long)r * in, scale / (1.f - p), accumulate, 2, seed, p, in, st));
-        for (int t = 0; t < n; ++t)
-            CHECK(vlr_gemm_dropout_acc(off(v, (size_t)t * r), nr, off(A, (size_t)t * r * in), dx, ws_xd, M, in, r, p, seed + t, scale, st));   // dx += s mask_t (v_t A_t)/(1-p)
+        // dx (+)= s / (1 - p) sum_t mask_t . (v_t A_t): the n targets in ONE pass over dx
+        CHECK(vlr_gemm_dropout_acc_multi(n, v, nr, A, dx, M, in, r, p, seed, scale, dx_fresh ? 0 : 1, st));
     } else {
         CHECK(vlr_gemm_bf16_scaled(2, v, x, dA, nullptr, nullptr, nr, in, M, nr, in, in, 0, 0, accumulate, 0, scale, st));  // dA = s v^T x
-        CHECK(vlr_gemm_bf16_scaled(1, v, A, dx, nullptr, nullptr, M, in, nr, nr, in, in, 0, 0, 1, 0, scale, st));     // dx += s v A
+        CHECK(vlr_gemm_bf16_scaled(1, v, A, dx, nullptr, nullptr, M, in, nr, nr, in, in, 0, 0, dx_fresh ? 0 : 1, 0, scale, st));     // dx (+)= s v A
     }
     return VLR_OK;
 }
@@ -260,11 +261,15 @@ extern "C" int vlr_decoder_layer_bwd_lora(const vlr_llama_cfg* cfg, const vlr_la
     const float sc = lw->scale, p = lw->dropout;
 #define XD(seg) (ws_xd)      // ABI v4: one scratch [M][max(hidden, inter)] (the fallback path of vlr_gemm_dropout_acc), not per-target copies
     // ---- MLP
-    CHECK(vlr_gemm_bf16(1, dx_out, w->wdown, ws->dact, nullptr, nullptr, M, I, H, H, I, I, 0, 0, 0, 0, st));
-    if (lw->a_down)
+    if (lw->a_down) {
+        // the adapter term of down_proj FIRST, alone, into the d act scratch; the dgrad GEMM then adds it to its fp32 accumulators and runs the
+        // SwiGLU backward in its epilogue (vlr_gemm_swiglu_bwd_add): d act is never completed in HBM, no separate SwiGLU-backward pass
         CHECK(lora_group_bwd(1, r, I, o_h, a->act, dx_out, H, lw->a_down, lw->b_down, lg->a_down, lg->b_down, off(u, 6 * (size_t)r), ldu, ws_v,
-                             ws->dact, sc, p, seed + 6, XD(6), accumulate, M, st));
-    CHECK(vlr_swiglu_bwd(a->gu, ws->dact, M, I, st));   // gu now holds [dgate | dup]
+                             ws->dact, sc, p, seed + 6, XD(6), accumulate, M, st, 1));
+        CHECK(vlr_gemm_swiglu_bwd_add(dx_out, w->wdown, a->gu, ws->dact, ws->dact, M, I, H, st));   // gu now holds [dgate | dup]
+    } else {
+        CHECK(vlr_gemm_swiglu_bwd(dx_out, w->wdown, a->gu, ws->dact, M, I, H, st));
+    }
     CHECK(vlr_gemm_bf16(1, a->gu, w->wgu, ws->dxn, nullptr, nullptr, M, H, 2 * I, 2 * I, H, H, 0, 0, 0, 0, st));
     CHECK(lora_group_bwd(2, r, H, o_gu, a->xn2, a->gu, 2 * I, lw->a_gu, lw->b_gu, lg->a_gu, lg->b_gu, off(u, 4 * (size_t)r), ldu, ws_v,
                          ws->dxn, sc, p, seed + 4, XD(4), accumulate, M, st));

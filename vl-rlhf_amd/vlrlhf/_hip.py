@@ -110,6 +110,8 @@ _SIGS = {
     "vlr_gemm_lora": [P, I, P, P, I, P, I, I, I, I, P, I, P, I, P],
     "vlr_gemm_dropout_acc": [P, I, P, P, P, I, I, I, F, U64, F, P],
     "vlr_gemm_grouped": [I, P, P, P, I, I, I, I, I, I, I, L, L, L, F, I, I, U64, F, I, P],
+    "vlr_gemm_dropout_acc_multi": [I, P, I, P, P, I, I, I, F, U64, F, I, P],
+    "vlr_gemm_swiglu_bwd_add": [P, P, P, P, P, I, I, I, P],
     "vlr_gemm_swiglu_lora": [P, P, P, P, I, I, I, I, P, I, P, I, P],
     "vlr_gemm_qkv_rope_lora": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P, I, P, I, I, I, P],
     "vlr_decoder_layer_bwd": [P, P, P, I, P, P, P, P, P, P, P, I, I, P],
