@@ -190,11 +190,20 @@ static int lora_group_bwd(int n, int r, int in, const int* outs, const void* x, 
                                (long)out * r, (long)r, 1.f, 0, 0, 0, 0.f, 0, st));
     }
     if (p > 0.f) {
-        (void)ws_xd;
         // dA_t = s / (1 - p) v_t^T (mask_t . x): the n targets as groups, x masked while it is staged (the mask of the forward, regenerated)
         CHECK(vlr_gemm_grouped(2, v, x, dA, r, in, M, nr, in, in, n, (long)r, 0L, (long)r * in, scale / (1.f - p), accumulate, 2, seed, p, in, st));
-        // dx (+)= s / (1 - p) sum_t mask_t . (v_t A_t): the n targets in ONE pass over dx
-        CHECK(vlr_gemm_dropout_acc_multi(n, v, nr, A, dx, M, in, r, p, seed, scale, dx_fresh ? 0 : 1, st));
+        // dx (+)= s / (1 - p) sum_t mask_t . (v_t A_t).  One pass per target on the 128x128 GEMM kernel (its epilogue applies the mask in
+        // the coalesced copy-out); VLR_LORA_MULTI=1: ONE pass for the n targets (vlr_gemm_dropout_acc_multi) - measured NOT faster
+        // (4 x 220 us against 7 x 119 us per layer: with K = r the launch is two K steps per term, latency- not HBM-bound), so off
+        static int multi = -1;
+        if (multi < 0) { const char* e = getenv("VLR_LORA_MULTI"); multi = (e && e[0] == '1') ? 1 : 0; }
+        if (multi || dx_fresh) {
+            CHECK(vlr_gemm_dropout_acc_multi(n, v, nr, A, dx, M, in, r, p, seed, scale, dx_fresh ? 0 : 1, st));
+        } else {
+            VLR_REQUIRE(ws_xd, "lora backward: lora_dropout > 0 needs a scratch buffer [M][in]");
+            for (int t = 0; t < n; ++t)
+                CHECK(vlr_gemm_dropout_acc(off(v, (size_t)t * r), nr, off(A, (size_t)t * r * in), dx, ws_xd, M, in, r, p, seed + t, scale, st));
+        }
     } else {
         CHECK(vlr_gemm_bf16_scaled(2, v, x, dA, nullptr, nullptr, nr, in, M, nr, in, in, 0, 0, accumulate, 0, scale, st));  // dA = s v^T x
         CHECK(vlr_gemm_bf16_scaled(1, v, A, dx, nullptr, nullptr, M, in, nr, nr, in, in, 0, 0, dx_fresh ? 0 : 1, 0, scale, st));     // dx (+)= s v A
@@ -261,12 +270,19 @@ extern "C" int vlr_decoder_layer_bwd_lora(const vlr_llama_cfg* cfg, const vlr_la
     const float sc = lw->scale, p = lw->dropout;
 #define XD(seg) (ws_xd)      // ABI v4: one scratch [M][max(hidden, inter)] (the fallback path of vlr_gemm_dropout_acc), not per-target copies
     // ---- MLP
-    if (lw->a_down) {
-        // the adapter term of down_proj FIRST, alone, into the d act scratch; the dgrad GEMM then adds it to its fp32 accumulators and runs the
-        // SwiGLU backward in its epilogue (vlr_gemm_swiglu_bwd_add): d act is never completed in HBM, no separate SwiGLU-backward pass
+    static int fuse_down = -1;     // VLR_LORA_FUSE_DOWN=1: adapter term of down_proj first, then the dgrad GEMM with the SwiGLU backward in its epilogue
+    if (fuse_down < 0) { const char* e = getenv("VLR_LORA_FUSE_DOWN"); fuse_down = (e && e[0] == '1') ? 1 : 0; }
+    if (lw->a_down && fuse_down) {
+        // measured SLOWER than the three separate kernels (38.8 ms against 25.5 + 7.7 per step: the addend is a third 16-byte load stream
+        // in an epilogue that already reads gate | up) - kept behind the switch
         CHECK(lora_group_bwd(1, r, I, o_h, a->act, dx_out, H, lw->a_down, lw->b_down, lg->a_down, lg->b_down, off(u, 6 * (size_t)r), ldu, ws_v,
                              ws->dact, sc, p, seed + 6, XD(6), accumulate, M, st, 1));
         CHECK(vlr_gemm_swiglu_bwd_add(dx_out, w->wdown, a->gu, ws->dact, ws->dact, M, I, H, st));   // gu now holds [dgate | dup]
+    } else if (lw->a_down) {
+        CHECK(vlr_gemm_bf16(1, dx_out, w->wdown, ws->dact, nullptr, nullptr, M, I, H, H, I, I, 0, 0, 0, 0, st));
+        CHECK(lora_group_bwd(1, r, I, o_h, a->act, dx_out, H, lw->a_down, lw->b_down, lg->a_down, lg->b_down, off(u, 6 * (size_t)r), ldu, ws_v,
+                             ws->dact, sc, p, seed + 6, XD(6), accumulate, M, st));
+        CHECK(vlr_swiglu_bwd(a->gu, ws->dact, M, I, st));   // gu now holds [dgate | dup]
     } else {
         CHECK(vlr_gemm_swiglu_bwd(dx_out, w->wdown, a->gu, ws->dact, M, I, H, st));
     }

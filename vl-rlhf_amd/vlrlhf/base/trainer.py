@@ -548,7 +548,14 @@ class VLDPOTrainer:
             self.precompute_reference_log_probs(ds)
             self._precomputed_eval_ref_log_probs = True
         bs = int(getattr(self.args, "per_device_eval_batch_size", None) or getattr(self.args, "per_device_train_batch_size", 4))
-        rows = list(ds)[_rank()::_world()]
+        # the index list is padded by wrapping to a multiple of the world size (as _train_row_batches does): every rank runs the same
+        # number of prediction steps and reduces the same 9 scalars in log() - an eval set smaller than the world would otherwise
+        # leave ranks without metrics and hang the collective (torch DistributedSampler semantics, as HF's eval dataloader)
+        rows = list(ds)
+        w = _world()
+        if w > 1 and len(rows) % w:
+            rows = rows + rows[: w - len(rows) % w]
+        rows = rows[_rank()::w]
         was_training = self.model.training
         self.model.eval()
         losses = []
@@ -658,8 +665,9 @@ class VLDPOTrainer:
 
     def save_checkpoint(self, step: int, micro: int, epoch: int, window_len: int = 0):
         """HF Trainer._save_checkpoint for this path: `output_dir/checkpoint-<step>/` with the weights (adapters under LoRA),
-        the optimizer state (fp32 master / m / v + step), trainer_state.json (step counters, log history) and the python RNG;
-        rotated to `save_total_limit`.  Rank 0 writes (every rank holds identical state under DDP)."""
+        the optimizer state (fp32 master / m / v + step), trainer_state.json (step counters, log history, the dropout call counters
+        that seed the counter-based masks, world size / accumulation steps the counters were taken under); rotated to
+        `save_total_limit`.  Rank 0 writes (every rank holds identical state under DDP)."""
         import json
         import os
         import shutil
@@ -681,7 +689,9 @@ class VLDPOTrainer:
                 save_file({k: st[k].detach().cpu()}, os.path.join(tmp, f"optimizer_{k}.safetensors"))
         with open(os.path.join(tmp, "trainer_state.json"), "w") as f:
             json.dump(dict(global_step=step, micro_step=micro, epoch=epoch, opt_step=eng.opt_step, log_history=self.log_history,
-                           world_size=_world(), lora_calls=getattr(eng, "_lora_calls", 0)), f, indent=1)
+                           world_size=_world(), lora_calls=getattr(eng, "_lora_calls", 0), plora_calls=getattr(eng, "_plora_calls", 0),
+                           gradient_accumulation_steps=max(1, int(getattr(self.args, "gradient_accumulation_steps", 1) or 1)),
+                           per_device_train_batch_size=int(getattr(self.args, "per_device_train_batch_size", 4))), f, indent=1)
         shutil.rmtree(path, ignore_errors=True)
         os.replace(tmp, path)                        # a checkpoint directory is either complete or absent
         limit = int(getattr(self.args, "save_total_limit", 0) or 0)
@@ -697,6 +707,11 @@ class VLDPOTrainer:
         eng = self.model.engine
         with open(os.path.join(path, "trainer_state.json")) as f:
             state = json.load(f)
+        # micro_step -> (epoch, batches to skip) only means the same thing under the same sharding
+        for key, now in (("world_size", _world()), ("gradient_accumulation_steps", max(1, int(getattr(self.args, "gradient_accumulation_steps", 1) or 1))),
+                         ("per_device_train_batch_size", int(getattr(self.args, "per_device_train_batch_size", 4)))):
+            if key in state and int(state[key]) != now:
+                raise ValueError(f"resume_from_checkpoint: {path} was written with {key}={state[key]}, this run has {now}")
         if self.is_peft_model:
             self.model.load_adapter(path)
         else:
@@ -710,6 +725,8 @@ class VLDPOTrainer:
             eng.load_optimizer_state(bufs["master"], bufs["m"], bufs["v"], state["opt_step"])
         if hasattr(eng, "_lora_calls"):
             eng._lora_calls = int(state.get("lora_calls", 0))
+        if hasattr(eng, "_plora_calls"):
+            eng._plora_calls = int(state.get("plora_calls", 0))
         self.log_history = list(state.get("log_history", []))
         return state
 
@@ -777,7 +794,8 @@ class VLDPOTrainer:
                     self.save_checkpoint(step, micro, ep)
                 if step >= total:
                     break
-            if save_strategy == "epoch" and step < total:
+            # (HF saves at every epoch end incl. the last; only at an optimizer-step boundary: a partly accumulated window is not state)
+            if save_strategy == "epoch" and micro % ga == 0:
                 self.save_checkpoint(step, micro, ep)
             ep += 1
             skip = 0

@@ -104,12 +104,24 @@ class ParamLayout:
             e.append(("ap.wo", (E_, E_), [(ap + "attn.out_proj.weight", 0, E_)]))
             e.append(("ap.kv", (E_, W_), [(ap + "kv_proj.weight", 0, E_)]))
             e.append(("ap.query", (nq_, E_), [(ap + "query", 0, nq_)]))
+        # HF Trainer.get_decay_parameter_names excludes nn.LayerNorm / LlamaRMSNorm (ALL_LAYERNORM_LAYERS) and `bias` parameters from weight
+        # decay.  The RMSNorm classes VENDORED with Qwen-VL (modeling_qwen.py) and InternLM2 (modeling_internlm2.py) are not in that list:
+        # the reference decays their weights (weight_decay 0.05 / 0.1 in the shipped scripts), so for these families the norm weights
+        # sit in the decay region and only biases (and the resampler's nn.LayerNorm weights) stay outside it.
+        norms_decay = qwen or ilm
+        def _norms():
+            e.append(("norm", (H,), [(nm["norm"], 0, H)]))
+            for l in range(L - 1, -1, -1):
+                p = layer.format(l)
+                e.append((f"l{l}.ln2", (H,), [(p + nm["ln2"], 0, H)]))
+                e.append((f"l{l}.ln1", (H,), [(p + nm["ln1"], 0, H)]))
+        if norms_decay:
+            _norms()
         self.n_decay_entries = len(e)
-        e.append(("norm", (H,), [(nm["norm"], 0, H)]))
+        if not norms_decay:
+            _norms()
         for l in range(L - 1, -1, -1):
             p = layer.format(l)
-            e.append((f"l{l}.ln2", (H,), [(p + nm["ln2"], 0, H)]))
-            e.append((f"l{l}.ln1", (H,), [(p + nm["ln1"], 0, H)]))
             if qwen:
                 e.append((f"l{l}.bqkv", (Nq + 2 * Nkv,), [(p + "attn.c_attn.bias", 0, Nq + 2 * Nkv)]))
         if qwen and cfg.get("visual"):
