@@ -326,6 +326,21 @@ int vlr_decoder_layer_bwd_lora(const vlr_llama_cfg* cfg, const vlr_layer_weights
                                const vlr_layer_bwd_ws* ws, void* ws_v, void* ws_xd, uint64_t seed, const void* x_in,
                                const void* dx_out, void* dx_in, const int* pos, const int* key_mask, int batch, int S,
                                vlr_stream_t stream);
+/* The same two passes for a decoder whose linears carry adapters as BASE-MODEL weights on a row subset - PLoRA of InternLM-XComposer2
+ * (reference models/InternLMXC2/build_mlp.py:158-203: `res[im_mask] += Plora_B(Plora_A(dropout(x[im_mask])))`, r = 256): rowmask
+ * [batch * S] bytes, non-zero = image row (NULL: all rows) - the text rows of u / v are zeroed, so the dense adapter kernels compute
+ * exactly the row-restricted update; g != NULL: the base weights train too (full fine-tune: gradients as vlr_decoder_layer_bwd
+ * writes them), NULL: frozen.  The dropout mask of target t is vlr_dropout(seed + t) indexed over the FULL [batch * S][in] input. */
+int vlr_decoder_layer_fwd_lora_ex(const vlr_llama_cfg* cfg, const vlr_layer_weights* w, const vlr_lora_weights* lw,
+                                  const vlr_layer_acts* a, void* u, void* ws_xd, uint64_t seed, const unsigned char* rowmask,
+                                  const void* x_in, const int* pos, const int* key_mask, int batch, int S, vlr_stream_t stream);
+int vlr_decoder_layer_bwd_lora_ex(const vlr_llama_cfg* cfg, const vlr_layer_weights* w, const vlr_layer_grads* g,
+                                  const vlr_lora_weights* lw, const vlr_lora_grads* lg, int accumulate, const vlr_layer_acts* a,
+                                  const void* u, const vlr_layer_bwd_ws* ws, void* ws_v, void* ws_xd, uint64_t seed,
+                                  const unsigned char* rowmask, const void* x_in, const void* dx_out, void* dx_in, const int* pos,
+                                  const int* key_mask, int batch, int S, vlr_stream_t stream);
+/* rows of x [M][ld] (first `cols` columns) whose rowmask byte is 0 are zeroed */
+int vlr_rows_mask(void* x, int ld, int cols, const unsigned char* rowmask, int M, vlr_stream_t stream);
 /* counter-based dropout: out = mask * x * alpha / (1-p)  (add != 0: out += ...); the mask is a pure function of
  * (seed, element index) so the backward regenerates it.  vlr_dropout_mask writes the keep mask as bytes (tests). */
 int vlr_dropout(const void* x, void* out, long n, float p, uint64_t seed, float alpha, int add, vlr_stream_t stream);

@@ -40,10 +40,18 @@ def plora_delta(h, im_mask, W, name, r, plora):
         return out
     part = h[im_mask]
     p = float(plora.get("p", 0.0) or 0.0) if plora else 0.0
-    if p > 0 and plora.get("seed") is not None:
-        m = O.dropout_mask(plora["seed"] + 8 * plora["layer"] + TARGETS[name.split("layers.")[1].split(".", 1)[1]], part.numel(), p).view(part.shape).to(part.dtype)
-        part = r(part * m * (1.0 / (1.0 - p)))
     scale = plora.get("scale", 1.0) if plora else 1.0
+    if p > 0 and plora.get("seed") is not None:
+        seed = plora["seed"] + 8 * plora["layer"] + TARGETS[name.split("layers.")[1].split(".", 1)[1]]
+        if plora.get("index", "full") == "full":
+            # the C layer passes (vlr_decoder_layer_*_lora_ex): mask indexed over the FULL [B*S][in] input, applied exactly while the operand
+            # is staged; 1 / (1 - p) rides in the scale
+            m = O.dropout_mask(seed, h.numel(), p).view(h.shape).to(h.dtype)
+            out[im_mask] = r(scale / (1.0 - p) * ((h * m)[im_mask] @ A.t())) @ B.t()
+            return out
+        # the Python-composed layer (peft LoRA stacked on PLoRA): vlr_dropout over the COMPACT [R][in] matrix of the image rows
+        m = O.dropout_mask(seed, part.numel(), p).view(part.shape).to(part.dtype)
+        part = r(part * m * (1.0 / (1.0 - p)))
     out[im_mask] = r(scale * (part @ A.t())) @ B.t()
     return out
 

@@ -197,3 +197,22 @@ def test_internlm_gqa_two_kv_heads_vs_oracle():
     assert abs(float(loss) - float(l32)) < TOL_LOSS_FP32, (float(loss), float(l32))
     assert not torch.equal(model.engine.policy.v["l0.wqkv"].float().cpu(), W["model.layers.0.attention.wqkv.weight"])
     assert torch.equal(model.state_dict()["model.layers.0.attention.wqkv.weight"].float().cpu(), W["model.layers.0.attention.wqkv.weight"])
+
+
+def test_internlm_gradient_checkpointing_is_bit_identical():
+    """full fine-tune with PLoRA dropout under --gradient_checkpointing: the recompute re-runs the C layer pass with the pass's own dropout
+    seed - loss and every gradient (base AND PLoRA) bit-identical to the run that keeps the activations; the fp32 residual stream is on"""
+    outs = []
+    for ckpt in (False, True):
+        z, cfg, W, W_ref, batch, model, ref, tr = build(plora_dropout=0.25)
+        assert model.engine.resid_f32
+        if ckpt:
+            model.gradient_checkpointing_enable()
+        model.train()
+        loss = tr.training_step(model, batch)
+        torch.cuda.synchronize()
+        assert model._last_ctx["ckpt"] == ckpt
+        outs.append((float(loss), model.engine.grads.clone()))
+    assert outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][1].float().abs().sum()) > 0

@@ -770,3 +770,17 @@ extern "C" int vlr_comm_probe(const void* src, void* dst, long n_bytes, int wgs,
     hipLaunchKernelGGL(comm_probe_kernel, dim3(wgs), dim3(256), 0, st, (const u32x4*)src, (u32x4*)dst, n_bytes / 16);
     return vlr_check_launch("vlr_comm_probe");
 }
+
+// rows of x [M][ld] (first `cols` columns) whose mask byte is 0 are zeroed - the row restriction of InternLM-XComposer2's PLoRA
+// (`res[im_mask] += Plora_B(Plora_A(x[im_mask]))`, reference models/InternLMXC2/build_mlp.py:194-202) applied to the skinny adapter
+// tensors u = drop(x) A^T (forward) and v = dy B (backward): with their text rows zero the dense adapter kernels compute exactly it
+__global__ __launch_bounds__(256) void rows_mask_kernel(bf16_t* __restrict__ x, int ld, int cols, const unsigned char* __restrict__ mask) {
+    const size_t row = blockIdx.x;
+    if (mask[row]) return;
+    for (int c = threadIdx.x * 8; c < cols; c += 256 * 8) *reinterpret_cast<u32x4*>(x + row * ld + c) = u32x4{0u, 0u, 0u, 0u};
+}
+extern "C" int vlr_rows_mask(void* x, int ld, int cols, const unsigned char* rowmask, int M, hipStream_t st) {
+    VLR_REQUIRE(x && rowmask && M > 0 && cols > 0 && cols % 8 == 0 && ld % 8 == 0 && ld >= cols, "vlr_rows_mask: bad arguments");
+    hipLaunchKernelGGL(rows_mask_kernel, dim3(M), dim3(256), 0, st, (bf16_t*)x, ld, cols, rowmask);
+    return vlr_check_launch("vlr_rows_mask");
+}

@@ -157,8 +157,12 @@ extern "C" int vlr_decoder_layer_bwd(const vlr_llama_cfg* cfg, const vlr_layer_w
 // outs[t]: output features of sub-target t (they differ under grouped-query attention: q has heads*hd, k and v kv_heads*hd)
 // u_t = s * dropout_t(x) A_t^T for the n sub-targets of a group (the B half rides the K loop of the base GEMM: vlr_gemm_*_lora)
 static int lora_group_a(int n, int r, int in, const void* x, int ldx, const void* A, void* u, int ldu, float scale, float p,
-                        uint64_t seed, void* ws_xd, int M, hipStream_t st) {
+                        uint64_t seed, void* ws_xd, int M, hipStream_t st, const unsigned char* rowmask = nullptr) {
     (void)ws_xd;
+    struct MaskAfter {       // PLoRA: the adapter acts on the image rows only - zero the other rows of u on the way out
+        void* u; int ldu, cols, M; const unsigned char* rm; hipStream_t st;
+        int run() const { return rm ? vlr_rows_mask(u, ldu, cols, rm, M, st) : VLR_OK; }
+    } after = {u, ldu, n * r, M, rowmask, st};
     if (p > 0.f) {
         // ONE grouped launch for the n sub-targets: target t = group t reads the SAME x with its own keep mask (vlr_dropout(seed + t),
         // zeroed while the operand is staged - drop(x) is never written) against its own A_t; 1 / (1 - p) rides in alpha
@@ -167,14 +171,14 @@ static int lora_group_a(int n, int r, int in, const void* x, int ldx, const void
     } else {
         CHECK(vlr_gemm_bf16_scaled(0, x, A, u, nullptr, nullptr, M, n * r, in, ldx, in, ldu, 0, 0, 0, 0, scale, st));
     }
-    return VLR_OK;
+    return after.run();
 }
 
 // dx [M][in] already holds dy W; adds the adapter path and writes the adapter gradients
 // dx_fresh = 1: dx is WRITTEN (= the adapter term alone; the caller adds dy W afterwards - the fused SwiGLU-backward GEMM of down_proj)
 static int lora_group_bwd(int n, int r, int in, const int* outs, const void* x, const void* dy, int lddy, const void* A, const void* B,
                           void* dA, void* dB, const void* u, int ldu, void* v, void* dx, float scale, float p, uint64_t seed,
-                          void* ws_xd, int accumulate, int M, hipStream_t st, int dx_fresh = 0) {
+                          void* ws_xd, int accumulate, int M, hipStream_t st, int dx_fresh = 0, const unsigned char* rowmask = nullptr) {
     const int nr = n * r;
     size_t ofs[4] = {0, 0, 0, 0};
     bool same = true;
@@ -189,6 +193,7 @@ static int lora_group_bwd(int n, int r, int in, const int* outs, const void* x, 
         CHECK(vlr_gemm_grouped(1, off(dy, ofs[g]), off(B, ofs[g] * r), off(v, (size_t)g * r), M, r, out, lddy, r, nr, gs, (long)out,
                                (long)out * r, (long)r, 1.f, 0, 0, 0, 0.f, 0, st));
     }
+    if (rowmask) CHECK(vlr_rows_mask(v, nr, nr, rowmask, M, st));      // PLoRA: no gradient flows through the adapter on the text rows
     if (p > 0.f) {
         // dA_t = s / (1 - p) v_t^T (mask_t . x): the n targets as groups, x masked while it is staged (the mask of the forward, regenerated)
         CHECK(vlr_gemm_grouped(2, v, x, dA, r, in, M, nr, in, in, n, (long)r, 0L, (long)r * in, scale / (1.f - p), accumulate, 2, seed, p, in, st));
@@ -223,6 +228,13 @@ static int lora_check(const char* who, const vlr_lora_weights* lw, const void* w
 extern "C" int vlr_decoder_layer_fwd_lora(const vlr_llama_cfg* cfg, const vlr_layer_weights* w, const vlr_lora_weights* lw,
                                           const vlr_layer_acts* a, void* u, void* ws_xd, uint64_t seed, const void* x_in,
                                           const int* pos, const int* key_mask, int batch, int S, vlr_stream_t st) {
+    return vlr_decoder_layer_fwd_lora_ex(cfg, w, lw, a, u, ws_xd, seed, nullptr, x_in, pos, key_mask, batch, S, st);
+}
+// rowmask [batch * S] bytes (NULL: every row): the adapters act on the rows whose byte is non-zero only - PLoRA of InternLM-XComposer2
+// (reference models/InternLMXC2/build_mlp.py:158-203: im_mask = the image rows)
+extern "C" int vlr_decoder_layer_fwd_lora_ex(const vlr_llama_cfg* cfg, const vlr_layer_weights* w, const vlr_lora_weights* lw,
+                                             const vlr_layer_acts* a, void* u, void* ws_xd, uint64_t seed, const unsigned char* rowmask,
+                                             const void* x_in, const int* pos, const int* key_mask, int batch, int S, vlr_stream_t st) {
     VLR_REQUIRE(cfg && w && lw && a && u && x_in && pos, "vlr_decoder_layer_fwd_lora: null argument");
     CHECK(lora_check("vlr_decoder_layer_fwd_lora", lw, ws_xd));
     const int H = cfg->hidden, I = cfg->inter, M = batch * S, r = lw->r, ldu = 7 * r;
@@ -234,19 +246,19 @@ extern "C" int vlr_decoder_layer_fwd_lora(const vlr_llama_cfg* cfg, const vlr_la
     const int rf = cfg->resid_f32;
     CHECK(norm_fwd(rf, x_in, w->ln1, a->xn1, a->rstd1, M, H, cfg->rms_eps, st));
     const int nq = lw->qkv_targets == 1 ? 1 : 3;             // one adapter over the fused projection (Qwen c_attn) or q, k, v separately
-    CHECK(lora_group_a(nq, r, H, a->xn1, H, lw->a_qkv, u, ldu, sc, p, seed + 0, ws_xd, M, st));                    // xd segments: q,k,v | o | gate,up | down
+    CHECK(lora_group_a(nq, r, H, a->xn1, H, lw->a_qkv, u, ldu, sc, p, seed + 0, ws_xd, M, st, rowmask));
     CHECK(vlr_gemm_qkv_rope_lora(a->xn1, w->wqkv, w->bqkv, a->qkv, pos, cfg->rope_cos, cfg->rope_sin, M, N, Nq + Nkv, H, H,
                                  cfg->head_dim, cfg->max_pos, u, ldu, lw->b_qkv, r, nq == 1 ? N : Nq, nq == 1 ? 0 : Nkv, st));
     CHECK(vlr_attn_fwd_gqa(a->qkv, off(a->qkv, Nq), off(a->qkv, (size_t)Nq + Nkv), N, a->attn, Nq, a->lse, key_mask, batch, S,
                            cfg->heads, kvh, cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));
-    CHECK(lora_group_a(1, r, H, a->attn, H, lw->a_o, off(u, 3 * (size_t)r), ldu, sc, p, seed + 3, XD(3), M, st));
+    CHECK(lora_group_a(1, r, H, a->attn, H, lw->a_o, off(u, 3 * (size_t)r), ldu, sc, p, seed + 3, XD(3), M, st, rowmask));
     if (rf) CHECK(vlr_gemm_lora_f32res(a->attn, H, w->wo, (float*)a->x_mid, H, (const float*)x_in, H, M, H, H, off(u, 3 * (size_t)r), ldu, lw->b_o, r, st));
     else CHECK(vlr_gemm_lora(a->attn, H, w->wo, a->x_mid, H, x_in, H, M, H, H, off(u, 3 * (size_t)r), ldu, lw->b_o, r, st));
     CHECK(norm_fwd(rf, a->x_mid, w->ln2, a->xn2, a->rstd2, M, H, cfg->rms_eps, st));
-    CHECK(lora_group_a(2, r, H, a->xn2, H, lw->a_gu, off(u, 4 * (size_t)r), ldu, sc, p, seed + 4, XD(4), M, st));
+    CHECK(lora_group_a(2, r, H, a->xn2, H, lw->a_gu, off(u, 4 * (size_t)r), ldu, sc, p, seed + 4, XD(4), M, st, rowmask));
     CHECK(vlr_gemm_swiglu_lora(a->xn2, w->wgu, a->gu, a->act, M, I, H, H, off(u, 4 * (size_t)r), ldu, lw->b_gu, r, st));
     if (lw->a_down) {
-        CHECK(lora_group_a(1, r, I, a->act, I, lw->a_down, off(u, 6 * (size_t)r), ldu, sc, p, seed + 6, XD(6), M, st));
+        CHECK(lora_group_a(1, r, I, a->act, I, lw->a_down, off(u, 6 * (size_t)r), ldu, sc, p, seed + 6, XD(6), M, st, rowmask));
         if (rf) CHECK(vlr_gemm_lora_f32res(a->act, I, w->wdown, (float*)a->x_out, H, (const float*)a->x_mid, H, M, H, I, off(u, 6 * (size_t)r), ldu, lw->b_down, r, st));
         else CHECK(vlr_gemm_lora(a->act, I, w->wdown, a->x_out, H, a->x_mid, H, M, H, I, off(u, 6 * (size_t)r), ldu, lw->b_down, r, st));
     } else {
@@ -260,6 +272,16 @@ extern "C" int vlr_decoder_layer_bwd_lora(const vlr_llama_cfg* cfg, const vlr_la
                                           const vlr_layer_bwd_ws* ws, void* ws_v, void* ws_xd, uint64_t seed, const void* x_in,
                                           const void* dx_out, void* dx_in, const int* pos, const int* key_mask, int batch,
                                           int S, vlr_stream_t st) {
+    return vlr_decoder_layer_bwd_lora_ex(cfg, w, nullptr, lw, lg, accumulate, a, u, ws, ws_v, ws_xd, seed, nullptr, x_in, dx_out, dx_in, pos,
+                                         key_mask, batch, S, st);
+}
+// g != NULL: the base weights are trainable too (their gradients as in vlr_decoder_layer_bwd) - the FULL fine-tune of a decoder whose
+// linears carry adapters as base-model weights (InternLM-XComposer2's PLoRA); rowmask as in vlr_decoder_layer_fwd_lora_ex
+extern "C" int vlr_decoder_layer_bwd_lora_ex(const vlr_llama_cfg* cfg, const vlr_layer_weights* w, const vlr_layer_grads* g,
+                                             const vlr_lora_weights* lw, const vlr_lora_grads* lg, int accumulate, const vlr_layer_acts* a,
+                                             const void* u, const vlr_layer_bwd_ws* ws, void* ws_v, void* ws_xd, uint64_t seed,
+                                             const unsigned char* rowmask, const void* x_in, const void* dx_out, void* dx_in, const int* pos,
+                                             const int* key_mask, int batch, int S, vlr_stream_t st) {
     VLR_REQUIRE(cfg && w && lw && lg && a && u && ws && ws_v && x_in && dx_out && dx_in && pos, "vlr_decoder_layer_bwd_lora: null argument");
     CHECK(lora_check("vlr_decoder_layer_bwd_lora", lw, ws_xd));
     const int H = cfg->hidden, I = cfg->inter, M = batch * S, r = lw->r, ldu = 7 * r;
@@ -270,40 +292,44 @@ extern "C" int vlr_decoder_layer_bwd_lora(const vlr_llama_cfg* cfg, const vlr_la
     const float sc = lw->scale, p = lw->dropout;
 #define XD(seg) (ws_xd)      // ABI v4: one scratch [M][max(hidden, inter)] (the fallback path of vlr_gemm_dropout_acc), not per-target copies
     // ---- MLP
+    if (g) CHECK(vlr_gemm_bf16(2, dx_out, a->act, g->wdown, nullptr, nullptr, H, I, M, H, I, I, 0, 0, accumulate, 0, st));
     static int fuse_down = -1;     // VLR_LORA_FUSE_DOWN=1: adapter term of down_proj first, then the dgrad GEMM with the SwiGLU backward in its epilogue
     if (fuse_down < 0) { const char* e = getenv("VLR_LORA_FUSE_DOWN"); fuse_down = (e && e[0] == '1') ? 1 : 0; }
     if (lw->a_down && fuse_down) {
         // measured SLOWER than the three separate kernels (38.8 ms against 25.5 + 7.7 per step: the addend is a third 16-byte load stream
         // in an epilogue that already reads gate | up) - kept behind the switch
         CHECK(lora_group_bwd(1, r, I, o_h, a->act, dx_out, H, lw->a_down, lw->b_down, lg->a_down, lg->b_down, off(u, 6 * (size_t)r), ldu, ws_v,
-                             ws->dact, sc, p, seed + 6, XD(6), accumulate, M, st, 1));
+                             ws->dact, sc, p, seed + 6, XD(6), accumulate, M, st, 1, rowmask));
         CHECK(vlr_gemm_swiglu_bwd_add(dx_out, w->wdown, a->gu, ws->dact, ws->dact, M, I, H, st));   // gu now holds [dgate | dup]
     } else if (lw->a_down) {
         CHECK(vlr_gemm_bf16(1, dx_out, w->wdown, ws->dact, nullptr, nullptr, M, I, H, H, I, I, 0, 0, 0, 0, st));
         CHECK(lora_group_bwd(1, r, I, o_h, a->act, dx_out, H, lw->a_down, lw->b_down, lg->a_down, lg->b_down, off(u, 6 * (size_t)r), ldu, ws_v,
-                             ws->dact, sc, p, seed + 6, XD(6), accumulate, M, st));
+                             ws->dact, sc, p, seed + 6, XD(6), accumulate, M, st, 0, rowmask));
         CHECK(vlr_swiglu_bwd(a->gu, ws->dact, M, I, st));   // gu now holds [dgate | dup]
     } else {
         CHECK(vlr_gemm_swiglu_bwd(dx_out, w->wdown, a->gu, ws->dact, M, I, H, st));
     }
+    if (g) CHECK(vlr_gemm_bf16(2, a->gu, a->xn2, g->wgu, nullptr, nullptr, 2 * I, H, M, 2 * I, H, H, 0, 0, accumulate, 0, st));
     CHECK(vlr_gemm_bf16(1, a->gu, w->wgu, ws->dxn, nullptr, nullptr, M, H, 2 * I, 2 * I, H, H, 0, 0, 0, 0, st));
     CHECK(lora_group_bwd(2, r, H, o_gu, a->xn2, a->gu, 2 * I, lw->a_gu, lw->b_gu, lg->a_gu, lg->b_gu, off(u, 4 * (size_t)r), ldu, ws_v,
-                         ws->dxn, sc, p, seed + 4, XD(4), accumulate, M, st));
-    CHECK(norm_bwd(cfg->resid_f32, ws->dxn, a->x_mid, w->ln2, a->rstd2, dx_out, ws->dx_mid, nullptr, 0, ws->norm_ws, M, H, st));
+                         ws->dxn, sc, p, seed + 4, XD(4), accumulate, M, st, 0, rowmask));
+    CHECK(norm_bwd(cfg->resid_f32, ws->dxn, a->x_mid, w->ln2, a->rstd2, dx_out, ws->dx_mid, g ? g->ln2 : nullptr, g ? accumulate : 0, ws->norm_ws, M, H, st));
     // ---- attention
+    if (g) CHECK(vlr_gemm_bf16(2, ws->dx_mid, a->attn, g->wo, nullptr, nullptr, H, Nq, M, H, Nq, Nq, 0, 0, accumulate, 0, st));
     CHECK(vlr_gemm_bf16(1, ws->dx_mid, w->wo, ws->dattn, nullptr, nullptr, M, H, H, H, H, H, 0, 0, 0, 0, st));
     CHECK(lora_group_bwd(1, r, H, o_h, a->attn, ws->dx_mid, H, lw->a_o, lw->b_o, lg->a_o, lg->b_o, off(u, 3 * (size_t)r), ldu, ws_v,
-                         ws->dattn, sc, p, seed + 3, XD(3), accumulate, M, st));
+                         ws->dattn, sc, p, seed + 3, XD(3), accumulate, M, st, 0, rowmask));
     CHECK(vlr_attn_bwd_gqa(a->qkv, off(a->qkv, Nq), off(a->qkv, (size_t)Nq + Nkv), N, a->attn, ws->dattn, Nq, a->lse, ws->delta,
                            key_mask, ws->dqkv, off(ws->dqkv, Nq), off(ws->dqkv, (size_t)Nq + Nkv), N, batch, S, cfg->heads, kvh,
                            cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));
     CHECK(vlr_rope_heads(ws->dqkv, pos, cfg->rope_cos, cfg->rope_sin, M, cfg->heads + kvh, cfg->head_dim, N, cfg->max_pos, 1, st));
+    if (g) CHECK(vlr_gemm_bf16(2, ws->dqkv, a->xn1, g->wqkv, nullptr, nullptr, N, H, M, N, H, H, 0, 0, accumulate, 0, st));
     CHECK(vlr_gemm_bf16(1, ws->dqkv, w->wqkv, ws->dxn, nullptr, nullptr, M, H, N, N, H, H, 0, 0, 0, 0, st));
     const int o_all[1] = {N};
     const int nq = lw->qkv_targets == 1 ? 1 : 3;
     CHECK(lora_group_bwd(nq, r, H, nq == 1 ? o_all : o_qkv, a->xn1, ws->dqkv, N, lw->a_qkv, lw->b_qkv, lg->a_qkv, lg->b_qkv, u, ldu, ws_v, ws->dxn,
-                         sc, p, seed + 0, ws_xd, accumulate, M, st));
-    CHECK(norm_bwd(cfg->resid_f32, ws->dxn, x_in, w->ln1, a->rstd1, ws->dx_mid, dx_in, nullptr, 0, ws->norm_ws, M, H, st));
+                         sc, p, seed + 0, ws_xd, accumulate, M, st, 0, rowmask));
+    CHECK(norm_bwd(cfg->resid_f32, ws->dxn, x_in, w->ln1, a->rstd1, ws->dx_mid, dx_in, g ? g->ln1 : nullptr, g ? accumulate : 0, ws->norm_ws, M, H, st));
     return VLR_OK;
 }
 

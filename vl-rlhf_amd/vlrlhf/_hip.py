@@ -118,6 +118,9 @@ _SIGS = {
     "vlr_vit_layer_fwd": [P, P, P, P, I, I, P],
     "vlr_decoder_layer_fwd_lora": [P, P, P, P, P, P, U64, P, P, P, I, I, P],
     "vlr_decoder_layer_bwd_lora": [P, P, P, P, I, P, P, P, P, P, U64, P, P, P, P, P, I, I, P],
+    "vlr_decoder_layer_fwd_lora_ex": [P, P, P, P, P, P, U64, P, P, P, P, I, I, P],
+    "vlr_decoder_layer_bwd_lora_ex": [P, P, P, P, P, I, P, P, P, P, P, U64, P, P, P, P, P, P, I, I, P],
+    "vlr_rows_mask": [P, I, I, P, I, P],
     "vlr_dropout": [P, P, L, F, U64, F, I, P],
     "vlr_dropout_mask": [P, L, F, U64, P],
     "vlr_layers_join": [P],

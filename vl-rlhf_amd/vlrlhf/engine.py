@@ -319,6 +319,7 @@ class VisionWeights:
 class LlavaHipEngine:
     custom_layers = False          # True: the subclass composes the decoder layer itself (_layer_forward / _hidden_backward_custom)
     supports_resid_f32 = True      # False: the subclass adds to the residual stream with bf16 primitives
+    supports_ckpt = True           # False: the subclass's backward cannot re-run a layer's forward (gradient checkpointing is ignored)
     proj_out_f32 = True            # with the fp32 stream the projector writes fp32 rows for the merge (VLR_PROJ_F32=0: bf16)
 
     def __init__(self, cfg: dict, device="cuda", max_positions: int = 4096):
@@ -737,6 +738,7 @@ class LlavaHipEngine:
         lab = labels.to(self.dev).contiguous() if labels is not None else None
         e = self._embed_inputs(ws, ids, am, lab, pixel_values, image_dup, tag, image_sizes, meta)
         e["tag"] = tag               # scratch buffers of custom layers are keyed per pass (the reference pass runs on a side stream)
+        e["grad_pass"] = bool(save)  # this pass will be back-propagated (training-mode dropout applies; a checkpointed forward included)
         S, M = e["S"], e["M"]
         src, mask, pos, mlabels, img_map, inv = e["src"], e["mask"], e["pos"], e["labels"], e["img_map"], e["inv"]
         feats, vit_feat, z, h, n_rows, n_feat, pack = e["feats"], e["vit_feat"], e["proj_z"], e["proj_h"], e["n_rows"], e["n_feat"], e["pack"]
@@ -753,7 +755,7 @@ class LlavaHipEngine:
         if use_lora:
             self._lora_calls += 1
             lora_seed = (self.lora_seed << 40) + (self._lora_calls << 16)        # + 8*layer + target inside the library
-        ckpt = bool(save and self.gradient_checkpointing and not self.custom_layers)   # (composed layers keep their activations)
+        ckpt = bool(save and self.gradient_checkpointing and self.supports_ckpt)      # (layers composed in Python keep their activations)
         for l in range(self.L):
             if ckpt:
                 a = self._ckpt_acts(tag, l, Bn, S)
@@ -770,7 +772,7 @@ class LlavaHipEngine:
                     img_map=img_map.bool(), hidden=hidden, rstd_f=rstd_f, x_last=x, x0=x0, acts=acts if save else None,
                     vit_feat=vit_feat, feats=feats, proj_z=z, proj_h=h, image_dup=image_dup, n_rows=n_rows, n_feat=n_feat,
                     pack=pack, tag=tag, lora_seed=lora_seed, meta=meta, extra=e.get("extra"), ckpt=ckpt, use_lora=use_lora,
-                    embed=dict(pos=e["pos"], mask=e["mask"], extra=e.get("extra"), tag=tag, img_map=e["img_map"]))
+                    embed=dict(pos=e["pos"], mask=e["mask"], extra=e.get("extra"), tag=tag, img_map=e["img_map"], plora_seed=e.get("plora_seed"), grad_pass=bool(save)))
 
     # ------------------------------------------------------------------------------------------------ log-probs
     def logps_forward(self, ctx, labels, shared_mask=None, average=False, label_pad=-100):

@@ -29,8 +29,11 @@ PLORA_SEED_XOR = 0x2A5A5A5A5A
 
 class InternLMHipEngine(LlavaHipEngine):
     custom_layers = True
-    supports_resid_f32 = False     # the composed layer adds the adapter terms to the stream with bf16 primitives (vlr_rows_add, accumulate GEMMs)
     vision_prefix = "vit.vision_tower."
+
+    @property
+    def supports_ckpt(self):       # the C layer passes (full fine-tune / reference) can be re-run; the Python-composed peft-LoRA layer keeps its activations
+        return self.lora is None
 
     def __init__(self, cfg: dict, device="cuda", max_positions: int = 8192):
         c = dict(cfg, family="internlm_xc2")
@@ -58,7 +61,29 @@ class InternLMHipEngine(LlavaHipEngine):
                 meta["ilm"] = cached
         e["pos"] = cached["pos"]                       # rotary position = index in the merged sequence
         e["extra"] = cached
+        self._plora_calls += 1                         # one PLoRA dropout stream per forward pass (a recompute re-uses the pass's seed)
+        e["plora_seed"] = ((self.plora_seed << 40) + (self._plora_calls << 16)) ^ PLORA_SEED_XOR
         return e
+
+    def enable_lora(self, r, alpha, dropout=0.0, seed=0):
+        """peft LoRA stacked on the frozen PLoRA decoder: that layer is composed from bf16 primitives (rows_add, accumulate GEMMs), so the
+        residual stream goes back to bf16 for this configuration"""
+        super().enable_lora(r, alpha, dropout, seed)
+        if self.resid_f32:
+            self.resid_f32, self.RDT = False, BF16
+            self.llama_cfg = _hip.LlamaCfg(self.H, self.I, self.nh, self.hd, self.llama_cfg.rms_eps, self.max_pos, self.cos.data_ptr(),
+                                           self.sin.data_ptr(), self.nkv, 0)
+            self._ws = {}
+
+    def _plora_structs(self, ws, l, p):
+        """the PLoRA pairs of layer l as the adapter structs of the C layer passes (include/vlr.h vlr_lora_weights): ONE adapter over the
+        fused wqkv, wo, w1 | w3 stacked, w2; scale = alpha / r; gradients into the flat gradient buffer (full fine-tune) or nowhere"""
+        v = ws.v
+        names = ("pa_qkv", "pb_qkv", "pa_o", "pb_o", "pa_gu", "pb_gu", "pa_d", "pb_d")
+        w = _hip.LoraWeights(self.plora_r, self.plora_scale, float(p), *(v[f"l{l}.{n}"].data_ptr() for n in names), 1)
+        g = _hip.LoraGrads(*(self.gv[f"l{l}.{n}"].data_ptr() for n in names)) if self.gv is not None else None
+        return w, g
+
 
     def _embed_backward(self, ctx, cur, acc):
         """the projector is frozen with the tower: only tok_embeddings receives a gradient in front of the decoder"""
@@ -203,15 +228,21 @@ class InternLMHipEngine(LlavaHipEngine):
     def _layer_forward(self, ws, l, a, x, e, Bn, S, save, use_lora, lora_seed):
         c, H, I, N, M = self.llama_cfg, self.H, self.I, self.Nqkv, Bn * S
         ex, pos, mask = e["extra"], e["pos"], e["mask"]
-        train = self.training and ws is self.policy and save
-        if l == 0:
-            self._plora_calls += 1
-        pseed = ((self.plora_seed << 40) + (self._plora_calls << 16)) ^ PLORA_SEED_XOR
+        train = self.training and ws is self.policy and bool(e.get("grad_pass", save))     # (a checkpointed forward keeps nothing but is the same pass)
+        pseed = e["plora_seed"]
         keep_p = save and self.lora is None          # PLoRA weights are trainable only in a full fine-tune
         if not use_lora and self.fused_forward:
-            kept = self._layer_forward_fused(ws, l, a, x, e, Bn, S, save, train, pseed + 8 * l, keep_p)
+            # only PLoRA sits on the linears (reference pass; policy pass of a full fine-tune): the C layer pass with the PLoRA pairs as
+            # its adapters and the image rows as the row mask - fused qkv + RoPE / SwiGLU / residual projections, fp32 residual stream
+            M = Bn * S
+            sh = a.get("shared", a)
+            if "u" not in sh or sh["u"].shape[1] != 7 * self.plora_r:
+                sh["u"] = torch.empty(M, 7 * self.plora_r, dtype=BF16, device=self.dev)
+            pw, _ = self._plora_structs(ws, l, self.plora_p if train else 0.0)
+            _hip.call("vlr_decoder_layer_fwd_lora_ex", self.llama_cfg, self.layer_weights(ws, l), pw, a["struct"], sh["u"], None,
+                      pseed + 8 * l, e["img_map"], x, e["pos"], e["mask"], Bn, S)
             if save:
-                a["kept"], a["pseed"], a["train"] = kept, pseed + 8 * l, train
+                a["pseed"], a["train"] = pseed + 8 * l, train
             return
         kept: Dict[str, object] = {}
         tg = self._targets()
@@ -243,6 +274,40 @@ class InternLMHipEngine(LlavaHipEngine):
             a["train"] = train
 
     # ------------------------------------------------------------------------------------------------ backward
+    def _hidden_backward_full(self, ctx, dxa, dxb, acc):
+        """full fine-tune: vlr_decoder_layer_bwd_lora_ex per layer - base AND PLoRA gradients, the adapters restricted to the image rows;
+        with gradient checkpointing each layer's forward is re-run (same dropout seed) right before its backward"""
+        ws = ctx["ws"]
+        Bn, S, M, H, I, N = ctx["Bn"], ctx["S"], ctx["M"], self.H, self.I, self.Nqkv
+        Sp = _align(S, 64)
+        r = self.plora_r
+        wsb = dict(dact=self._buf(("dact", M), (M, I)), dxn=self._buf(("dxn", M), (M, H)), dattn=self._buf(("dattn", M), (M, self.Nq)),
+                   dqkv=self._buf(("dqkv", M), (M, N)), dx_mid=self._buf(("dx_mid", M), (M, H)),
+                   delta=self._buf(("delta", Bn, S), (Bn, self.nh, Sp), torch.float32))
+        lws = _hip.LayerBwdWs(wsb["dact"].data_ptr(), wsb["dxn"].data_ptr(), wsb["dattn"].data_ptr(), wsb["dqkv"].data_ptr(),
+                              wsb["dx_mid"].data_ptr(), wsb["delta"].data_ptr(), self._norm_ws.data_ptr())
+        ws_v = self._buf(("plora_v", M), (M, 3 * r))
+        scratch = self._buf(("plora_scratch", M), (M, max(H, I)))
+        e = ctx["embed"]
+        cur, nxt = dxa, dxb
+        for l in range(self.L - 1, -1, -1):
+            a = ctx["acts"][l]
+            x_in = ctx["acts"][l - 1]["x_out"] if l > 0 else ctx["x0"]
+            if ctx["ckpt"]:
+                self._layer_forward(ws, l, a, x_in, e, Bn, S, True, False, None)
+            train = a["train"]
+            pw, pg = self._plora_structs(ws, l, self.plora_p if train else 0.0)
+            sh = a.get("shared", a)
+            _hip.call("vlr_decoder_layer_bwd_lora_ex", self.llama_cfg, self.layer_weights(ws, l), self.layer_grads(l), pw, pg, acc, a["struct"],
+                      sh["u"], lws, ws_v, scratch, a["pseed"], e["img_map"], x_in, cur, nxt, ctx["pos"], ctx["mask"], Bn, S)
+            cur, nxt = nxt, cur
+            if self.reducer is not None:
+                self.reducer.bucket_ready(f"layer{l}")
+        self._embed_backward(ctx, cur, acc)
+        self.grad_fresh = False
+        if self.reducer is not None:
+            self.reducer.bucket_ready("tail")
+
     def _hidden_backward_custom(self, ctx, dhidden, dxa, dxb):
         ws = ctx["ws"]
         Bn, S, M, H, I, N = ctx["Bn"], ctx["S"], ctx["M"], self.H, self.I, self.Nqkv
@@ -250,8 +315,9 @@ class InternLMHipEngine(LlavaHipEngine):
         acc = int(not self.grad_fresh)
         Sp = _align(S, 64)
         ex = ctx["extra"]
-        _hip.call("vlr_rmsnorm_bwd", dhidden, ctx["x_last"], ws.v["norm"], ctx["rstd_f"], None, dxa, self.gv["norm"] if full else None,
-                  acc if full else 0, self._norm_ws, M, H)
+        self._norm_bwd(dhidden, ctx["x_last"], ws.v["norm"], ctx["rstd_f"], None, dxa, self.gv["norm"] if full else None, acc if full else 0, M)
+        if full and self.fused_forward:
+            return self._hidden_backward_full(ctx, dxa, dxb, acc)
         dact, dxn = self._buf(("dact", M), (M, I)), self._buf(("dxn", M), (M, H))
         dattn, dqkv = self._buf(("dattn", M), (M, self.Nq)), self._buf(("dqkv", M), (M, N))
         dx_mid = self._buf(("dx_mid", M), (M, H))
