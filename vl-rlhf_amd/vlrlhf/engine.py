@@ -1071,6 +1071,8 @@ class LlavaHipEngine:
         self.opt_step += 1
         nd = self.layout.n_decay
         for lo, hi, wd in ((0, nd, weight_decay), (nd, n, 0.0)):
+            if hi <= lo:              # (InternLM-XComposer2: no bias / nn.LayerNorm parameter is trainable - the no-decay region is empty)
+                continue
             _hip.call("vlr_adamw_step", self.master[lo:hi], self.m[lo:hi], self.v[lo:hi], self.grads[lo:hi],
                       self.policy.flat[lo:hi], hi - lo, float(lr), float(beta1), float(beta2), float(eps), float(wd),
                       self.opt_step, self.norm_out)
