@@ -116,11 +116,11 @@ def internlm_hidden(x, attention_mask, position_ids, im_mask, W, cfg, emulate_bf
         q = qkv[..., : nh * hd].reshape(B, S, nh, hd).transpose(1, 2)
         k = qkv[..., nh * hd: (nh + nkv) * hd].reshape(B, S, nkv, hd).transpose(1, 2)
         v = qkv[..., (nh + nkv) * hd:].reshape(B, S, nkv, hd).transpose(1, 2)
-        q, k = r(O.apply_rope(q, cos, sin), "rope"), r(O.apply_rope(k, cos, sin), "rope")
+        q, k, v = r(O.apply_rope(q, cos, sin), "rope"), r(O.apply_rope(k, cos, sin), "rope"), r(v, "v")
         if nkv != nh:
             k, v = (t.repeat_interleave(nh // nkv, dim=1) for t in (k, v))
         att = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd) + bias, dim=-1)
-        ctx = r((att @ v).transpose(1, 2).reshape(B, S, H), "attn")
+        ctx = r((r(att, "p") @ v).transpose(1, 2).reshape(B, S, H), "attn")
         x = r(x + lin(ctx, l, "attention.wo"), "resid")
         h = r(O.rms_norm(x, W[p + "ffn_norm.weight"], eps), "xn")
         act = r(F.silu(r(lin(h, l, "feed_forward.w1"), "gu")) * r(lin(h, l, "feed_forward.w3"), "gu"), "act")

@@ -46,7 +46,9 @@ class InternLMHipEngine(LlavaHipEngine):
         self._plora_calls = 0
         self.plora_seed = int(c.get("seed", 0))
         import os
-        self.fused_forward = os.environ.get("VLR_ILM_FUSED", "1") != "0"     # PLoRA rides the fused projections where no peft LoRA is stacked on top
+        self.fused_forward = os.environ.get("VLR_ILM_FUSED", "1") != "0"     # PLoRA-only passes on the C layer calls (0: the Python-composed layer everywhere)
+        if not self.fused_forward:
+            self._to_bf16_stream()
 
     # ------------------------------------------------------------------------------------------------ embed
     def _embed_inputs(self, ws, ids, am, lab, pixel_values, image_dup, tag, image_sizes, meta):
@@ -69,6 +71,9 @@ class InternLMHipEngine(LlavaHipEngine):
         """peft LoRA stacked on the frozen PLoRA decoder: that layer is composed from bf16 primitives (rows_add, accumulate GEMMs), so the
         residual stream goes back to bf16 for this configuration"""
         super().enable_lora(r, alpha, dropout, seed)
+        self._to_bf16_stream()
+
+    def _to_bf16_stream(self):
         if self.resid_f32:
             self.resid_f32, self.RDT = False, BF16
             self.llama_cfg = _hip.LlamaCfg(self.H, self.I, self.nh, self.hd, self.llama_cfg.rms_eps, self.max_pos, self.cos.data_ptr(),
