@@ -362,6 +362,8 @@ def main():
             "comm": {"transport": reducer.transport if reducer is not None else None,
                      "library": (reducer.transport_note if reducer is not None and reducer.transport == "native" else
                                  ("torch.distributed backend " + dist.get_backend()) if world > 1 else None),
+                     "transport_note": reducer.transport_note if reducer is not None else None,     # why the native transport was not used, when it was not
+                     "comm_cus": reducer.comm_cus if reducer is not None else 0, "compute_cus": _hip.helper("vlr_compute_cus"),
                      "exposed_ms_per_step": exposed_ms, "bytes_per_step": 2 * (eng.lora_layout.numel if a.lora else eng.layout.numel)},
             "roofline": {"bound": "mfma", "kernel": "gemm256p_kernel<A_KS,B_KS> (8-phase 256x256x64 bf16 GEMM: NT/NN/TN)", "achieved": round(achieved, 1),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),

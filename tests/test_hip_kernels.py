@@ -1404,3 +1404,43 @@ def test_gemm_swiglu_bwd_add(hip, shape):
     hip.call("vlr_gemm_swiglu_bwd_add", dy, w, gu, ws, ws, M, I, H)
     torch.cuda.synchronize()
     check(gu, ref, 1.6e-2, f"swiglu bwd + addend {shape}")
+
+
+# ---------------------------------------------------------------------------------------------------- CUs left to RCCL
+@pytest.mark.parametrize("k", [16, 40])
+def test_persistent_kernels_with_comm_cus(hip, k):
+    """vlr_set_comm_cus(k): the persistent GEMM (plain, fused SwiGLU, fp32-residual) and attention-forward launches run on (CUs - k) rounded
+    to whole XCD octets - same results as on the full chip up to summation order (the peel and the persistent grid change)"""
+    assert hip.helper("vlr_set_comm_cus", k) == 0
+    try:
+        assert hip.helper("vlr_compute_cus") == 256 - (k + 7) // 8 * 8
+        M, N, K = 12792, 4096, 1024
+        a, b = rnd(M, K, seed=1, scale=0.5), rnd(N, K, seed=2, scale=0.5)
+        c = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        hip.call("vlr_gemm_bf16", 0, a, b, c, None, None, M, N, K, K, K, N, 0, 0, 0, 0)
+        res = rnd(M, N, seed=3, dtype=torch.float32)
+        cf = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+        hip.call("vlr_gemm_bf16_f32res", 0, a, b, cf, res, M, N, K, K, K, N, N)
+        I = 2176
+        wgu = rnd(2 * I, K, scale=0.05, seed=4)
+        gu = torch.full((M, 2 * I), float("nan"), dtype=torch.bfloat16, device=DEV)
+        act = torch.full((M, I), float("nan"), dtype=torch.bfloat16, device=DEV)
+        hip.call("vlr_gemm_swiglu", a, wgu, gu, act, M, I, K, K, 1)
+        B, S, nh, hd = 8, 1599, 32, 128
+        H = nh * hd
+        qkv = rnd(B * S, 3 * H, seed=5)
+        o = torch.full((B * S, H), float("nan"), dtype=torch.bfloat16, device=DEV)
+        lse = torch.zeros(B, nh, (S + 63) // 64 * 64, dtype=torch.float32, device=DEV)
+        hip.call("vlr_attn_fwd", qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, o, H, lse, None, B, S, nh, hd, 1, 1 / math.sqrt(hd))
+        torch.cuda.synchronize()
+        ref = a.float() @ b.float().t()
+        check(c, ref, 8e-3, "gemm on a reduced grid")
+        check(cf, ref + res, 2e-5, "f32res gemm on a reduced grid")
+        g, u = (a.float() @ wgu.float().t()).split(I, dim=1)
+        check(act, F.silu(g) * u, 8e-3, "fused swiglu on a reduced grid")
+        q, kk, v = (qkv[:S, i * H:i * H + hd].float() for i in range(3))         # sequence 0, head 0
+        p = torch.softmax((q @ kk.t() / math.sqrt(hd)).masked_fill(~torch.ones(S, S, dtype=torch.bool, device=DEV).tril(), float("-inf")), -1)
+        check(o[:S, :hd], p @ v, 1.2e-2, "attention forward on a reduced grid")
+        assert torch.isfinite(o.float()).all()
+    finally:
+        hip.helper("vlr_set_comm_cus", -1)

@@ -126,6 +126,15 @@ class GradReducer:
         self._issued = False
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.native, self.transport, self.transport_note = make_transport(group, self.cuda)
+        # CUs left to the RCCL ring kernels that run beside the backward: the persistent GEMM / attention launches size their grids to
+        # (CUs - comm_cus).  Default 16 under data parallelism (2 per XCD), from the single-GPU interference bench (tools/
+        # comm_interference.py, DESIGN.md section 5: a 16-workgroup stand-in for the ring kernel cost 13 % of the step against
+        # 256-workgroup launches and 5.5 % against 240-workgroup ones); VLR_COMM_CUS overrides, 0 switches it off.
+        self.comm_cus = 0
+        if self.cuda and self.world > 1:
+            from . import _hip
+            self.comm_cus = int(os.environ.get("VLR_COMM_CUS", "16"))
+            _hip.helper("vlr_set_comm_cus", self.comm_cus)
 
     def bucket_ready(self, name: str):
         if not self.enabled or self.world == 1:
