@@ -112,6 +112,18 @@ int vlr_gemm_dropout_acc(const void* v, int ldv, const void* A, void* dx, void* 
  *                          vlr_dropout(seed + t); accumulate = 0 WRITES dx (the adapter term alone) */
 int vlr_gemm_dropout_acc_multi(int n, const void* v, int ldv, const void* A, void* dx, int M, int in, int r, float p, uint64_t seed,
                                float scale, int accumulate, vlr_stream_t stream);
+/*  ..._bits (ABI v5)     : the three calls above with the keep masks DRAWN BEFOREHAND by vlr_dropout_bits (packed, bit e of byte i =
+ *                          element 8 i + e of the dense [rows][mask_ld] operand; the mask of group / target g starts at bits + g *
+ *                          gstride bytes, seed + g as before): the forward, the dA and the dx kernels of a target all need the same mask
+ *                          and the hash (two splitmix64 per eight elements) cost more than the MFMAs of these skinny products.
+ *                          bits = NULL: hash in the kernel, exactly the calls above. */
+int vlr_gemm_grouped_bits(int layout, const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int groups,
+                          long gA, long gB, long gC, float alpha, int accumulate, int mask_on, uint64_t seed, float p_drop, int mask_ld,
+                          const void* mask_bits, long mask_gstride, vlr_stream_t stream);
+int vlr_gemm_dropout_acc_bits(const void* v, int ldv, const void* A, void* dx, void* scratch, int M, int in, int r, float p,
+                              uint64_t seed, float scale, const void* bits, vlr_stream_t stream);
+int vlr_gemm_dropout_acc_multi_bits(int n, const void* v, int ldv, const void* A, void* dx, int M, int in, int r, float p, uint64_t seed,
+                                    float scale, int accumulate, const void* bits, long bits_gstride, vlr_stream_t stream);
 /*  vlr_gemm_swiglu_bwd_add: vlr_gemm_swiglu_bwd with an addend on d act before the SwiGLU backward (d act = dy . wdown + dact_add, bf16
  *                          [M][I]; may be the dact_ws buffer) - the LoRA adapter term of down_proj */
 int vlr_gemm_swiglu_bwd_add(const void* dy, const void* wdown, void* gu_inout, void* dact_ws, const void* dact_add, int M, int I, int H,
@@ -314,7 +326,11 @@ typedef struct {
     const void* a_down; const void* b_down; /* [r][I],  [H][r]; both NULL: no adapter on the down projection */
     int qkv_targets;  /* 0 or 3: q_proj, k_proj, v_proj adapted separately (a_qkv [3r][H], u_q | u_k | u_v); 1: ONE adapter on the
                        * fused projection (Qwen c_attn: a_qkv [r][H], b_qkv [N][r]) */
+    void* mask_bits;  /* ABI v5, dropout > 0 only: vlr_lora_mask_bytes(hidden, inter, M) bytes of THIS layer, or NULL.  The forward draws
+                       * the seven packed keep masks into it (vlr_dropout_bits, target t < 6 at t * M * hidden / 8, down at 6 * M *
+                       * hidden / 8) and the adapter GEMMs of the forward AND of the backward read them; NULL: every kernel hashes */
 } vlr_lora_weights;
+long vlr_lora_mask_bytes(int hidden, int inter, int M);
 typedef struct {
     void* a_qkv; void* b_qkv; void* a_o; void* b_o; void* a_gu; void* b_gu; void* a_down; void* b_down;
 } vlr_lora_grads;
@@ -344,6 +360,8 @@ int vlr_rows_mask(void* x, int ld, int cols, const unsigned char* rowmask, int M
 /* counter-based dropout: out = mask * x * alpha / (1-p)  (add != 0: out += ...); the mask is a pure function of
  * (seed, element index) so the backward regenerates it.  vlr_dropout_mask writes the keep mask as bytes (tests). */
 int vlr_dropout(const void* x, void* out, long n, float p, uint64_t seed, float alpha, int add, vlr_stream_t stream);
+/* the keep mask of vlr_dropout(seed) over n elements (n % 32 == 0), packed: bit e of byte i = element 8 i + e */
+int vlr_dropout_bits(void* bits_u8, long n, float p, uint64_t seed, vlr_stream_t stream);
 int vlr_dropout_mask(void* mask_u8, long n, float p, uint64_t seed, vlr_stream_t stream);
 
 /* vlr_decoder_layer_bwd runs the weight-gradient GEMMs on a library-owned side stream (VLR_BWD_STREAMS=0 disables);

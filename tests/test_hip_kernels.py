@@ -1444,3 +1444,51 @@ def test_persistent_kernels_with_comm_cus(hip, k):
         assert torch.isfinite(o.float()).all()
     finally:
         hip.helper("vlr_set_comm_cus", -1)
+
+
+# ---------------------------------------------------------------------------------------------------- packed lora_dropout masks (ABI v5)
+@pytest.mark.parametrize("M,in_,r,n,p", [(1406, 1024, 64, 3, 0.25), (12792, 4096, 128, 2, 0.05)])
+def test_dropout_bits_and_masked_gemms_with_bits(hip, M, in_, r, n, p):
+    """vlr_dropout_bits packs exactly the keep mask of vlr_dropout_mask (bit e of byte i = element 8 i + e), and the three adapter kernels
+    that take the packed masks (staged NT operand, staged TN operand, dropout-accumulate epilogue: one pass per target and the one-pass
+    form) return BIT-IDENTICAL results to the same calls hashing in the kernel."""
+    from vlrlhf import _hip as HH
+    HH.ensure_splitk_workspace(DEV, force=True)
+    seed, alpha, scale = 99, 2.0 / (1 - p), 2.0
+    gstride = M * in_ // 8
+    bits = torch.zeros(n * gstride, dtype=torch.uint8, device=DEV)
+    for t in range(n):
+        hip.call("vlr_dropout_bits", bits[t * gstride:], M * in_, p, seed + t)
+        mk = torch.empty(M * in_, dtype=torch.uint8, device=DEV)
+        hip.call("vlr_dropout_mask", mk, M * in_, p, seed + t)
+        torch.cuda.synchronize()
+        b = bits[t * gstride:(t + 1) * gstride]
+        unpacked = ((b.view(-1, 1) >> torch.arange(8, device=DEV, dtype=torch.uint8)) & 1).reshape(-1)
+        assert torch.equal(unpacked, mk), f"packed mask of target {t}"
+    x = rnd(M, in_, seed=1)
+    A = rnd(n * r, in_, seed=2, scale=0.05)
+    ldu = n * r
+    u0, u1 = torch.zeros(M, ldu, dtype=torch.bfloat16, device=DEV), torch.zeros(M, ldu, dtype=torch.bfloat16, device=DEV)
+    hip.call("vlr_gemm_grouped", 0, x, A, u0, M, r, in_, in_, in_, ldu, n, 0, r * in_, r, alpha, 0, 1, seed, p, in_)
+    hip.call("vlr_gemm_grouped_bits", 0, x, A, u1, M, r, in_, in_, in_, ldu, n, 0, r * in_, r, alpha, 0, 1, seed, p, in_, bits, gstride)
+    torch.cuda.synchronize()
+    assert torch.equal(u0, u1), "masked NT (u = drop(x) A^T)"
+    v = rnd(M, n * r, seed=3, scale=0.5)
+    d0, d1 = torch.zeros(n * r, in_, dtype=torch.bfloat16, device=DEV), torch.zeros(n * r, in_, dtype=torch.bfloat16, device=DEV)
+    hip.call("vlr_gemm_grouped", 2, v, x, d0, r, in_, M, n * r, in_, in_, n, r, 0, r * in_, alpha, 0, 2, seed, p, in_)
+    hip.call("vlr_gemm_grouped_bits", 2, v, x, d1, r, in_, M, n * r, in_, in_, n, r, 0, r * in_, alpha, 0, 2, seed, p, in_, bits, gstride)
+    torch.cuda.synchronize()
+    assert torch.equal(d0, d1), "masked TN (dA = v^T drop(x))"
+    dx0 = rnd(M, in_, seed=4)
+    a0, a1, a2 = dx0.clone(), dx0.clone(), dx0.clone()
+    scratch = torch.empty(M, in_, dtype=torch.bfloat16, device=DEV)
+    for t in range(n):
+        hip.call("vlr_gemm_dropout_acc", v[:, t * r:], n * r, A[t * r:], a0, scratch, M, in_, r, p, seed + t, scale)
+        hip.call("vlr_gemm_dropout_acc_bits", v[:, t * r:], n * r, A[t * r:], a1, scratch, M, in_, r, p, seed + t, scale, bits[t * gstride:])
+    torch.cuda.synchronize()
+    assert torch.equal(a0, a1), "dropout-accumulate, one pass per target"
+    hip.call("vlr_gemm_dropout_acc_multi", n, v, n * r, A, a2, M, in_, r, p, seed, scale, 1)
+    a3 = dx0.clone()
+    hip.call("vlr_gemm_dropout_acc_multi_bits", n, v, n * r, A, a3, M, in_, r, p, seed, scale, 1, bits, gstride)
+    torch.cuda.synchronize()
+    assert torch.equal(a2, a3), "dropout-accumulate, one pass"

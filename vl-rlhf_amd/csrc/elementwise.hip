@@ -449,6 +449,17 @@ __global__ __launch_bounds__(256) void dropout_kernel(const bf16_t* __restrict__
         *reinterpret_cast<u32x4*>(out + i * 8) = pack8(v);
     }
 }
+// the same keep mask PACKED: bit e of byte g = element 8 g + e (one 32-bit store per four hash groups) - the form the LoRA adapter GEMMs read
+// (GemmParams::mask_bits): the hash costs ~300-450 cycles per wave and group pair and the forward, the dA and the dx kernels of a target
+// all need the same mask, so it is drawn ONCE per layer pass
+__global__ __launch_bounds__(256) void dropout_bits_kernel(uint32_t* __restrict__ bits, long n32, uint64_t key, uint32_t thr) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n32; i += (long)gridDim.x * 256) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w |= dropout_keep8(key, 4 * i + j, thr) << (8 * j);
+        bits[i] = w;
+    }
+}
 __global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ mask, long n8, uint64_t key, uint32_t thr) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
         const uint32_t keep = dropout_keep8(key, i, thr);
@@ -715,6 +726,13 @@ extern "C" int vlr_dropout_mask(void* mask_u8, long n, float p, uint64_t seed, h
     hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, st, (uint8_t*)mask_u8, n / 8, vlr_mix64(seed),
                        vlr_dropout_thr(p));
     return vlr_check_launch("vlr_dropout_mask");
+}
+extern "C" int vlr_dropout_bits(void* bits_u8, long n, float p, uint64_t seed, hipStream_t st) {
+    VLR_REQUIRE(bits_u8 && n > 0 && n % 32 == 0 && p >= 0.f && p < 1.f && !((uintptr_t)bits_u8 & 3),
+                "vlr_dropout_bits: n %% 32 == 0, 0 <= p < 1 and a 4-byte aligned buffer required (n=%ld p=%g)", n, (double)p);
+    hipLaunchKernelGGL(dropout_bits_kernel, dim3(grid_for(n / 32, 256)), dim3(256), 0, st, (uint32_t*)bits_u8, n / 32, vlr_mix64(seed),
+                       vlr_dropout_thr(p));
+    return vlr_check_launch("vlr_dropout_bits");
 }
 extern "C" int vlr_im2col(const float* pixel_values, void* patches, int n_img, int image_size, int patch, int Kp,
                           hipStream_t st) {

@@ -83,6 +83,12 @@ struct GemmParams {
     uint64_t mask_seed;
     uint32_t mask_thr;
     int mask_ld;
+    // packed keep masks drawn beforehand (vlr_dropout_bits: bit e of byte i = element 8 i + e of the dense [rows][mask_ld] / [M][drop_ld]
+    // operand); non-null: the kernels read them instead of hashing.  mask_bits + g * gMask bytes is the mask of group / term g
+    // (mask_on, dropacc_multi_kernel); drop_bits the one of the fuse = 6 epilogue.
+    const unsigned char* mask_bits;
+    long gMask;
+    const unsigned char* drop_bits;
 };
 #define VLR_SCHED_DEFAULT 0           // GemmParams::sched when VLR_GEMM_SCHED is not set
 #define VLR_SK_MIN_KTILES 16          // stream-K / rotation only for K >= 1024
@@ -104,9 +110,15 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // 256x256 tile, eight-phase schedule (gemm256p.hip); returns false when the problem does not qualify (fewer than 192 tiles,
 // unaligned operands, VLR_GEMM_8PHASE=0): the caller falls back to the 128x128 kernel
 bool vlr_gemm256p_try_launch(int layout, const GemmParams& p, hipStream_t stream);
+// 128x128 tile on the LDS-DMA ring (gemm128p.hip), grid = (tiles, split-K slices, groups) of gemm_bf16_kernel; false: operands it does
+// not take (alignment, masked / dropout-accumulate launches) or VLR_GEMM128P=0 - the caller launches gemm_bf16_kernel
+bool vlr_gemm128p_try_launch(int layout, const GemmParams& p, dim3 grid, hipStream_t stream);
 // fused-epilogue variants (p.fuse = 1 | 2, layout NT): false when the shape does not qualify for the persistent
 // continuous-pipeline kernel - the caller then runs the plain GEMM followed by the elementwise kernel
 bool vlr_gemm256p_dropacc_try_launch(const GemmParams& p, hipStream_t stream);
+// streaming LoRA input-gradient kernel (lora_dx.hip); false: shape not taken
+bool vlr_lora_dx_try_launch(int n, const void* v, int ldv, const void* A, void* dx, int M, int in, int r, float p_drop, uint64_t seed,
+                            float scale, int accumulate, const void* bits, long bits_gstride, hipStream_t stream);
 bool vlr_gemm256p_seg_try_launch(const GemmParams& p, hipStream_t stream);
 bool vlr_gemm256p_fused_try_launch(const GemmParams& p, hipStream_t stream);
 // fuse = 3 (NN): d act = dy . Wdown with the SwiGLU backward applied in the epilogue to gate | up in p.C2 (in place)

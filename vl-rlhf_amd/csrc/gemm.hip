@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "gemm.h"
+#include "gemm128_epilogue.h"
 
 #define BM 128
 #define BN 128
@@ -42,7 +43,7 @@ __device__ __forceinline__ u32x4 mask8(u32x4 v, uint32_t keep) {
 }
 template <bool MASK = false>
 __device__ __forceinline__ void load_kc(const bf16_t* __restrict__ P, int ld, int row0, int nrows, int k0, int K, int t,
-                                        u32x4 (&r)[4], uint64_t key = 0, uint32_t thr = 0, int mld = 0) {
+                                        u32x4 (&r)[4], uint64_t key = 0, uint32_t thr = 0, int mld = 0, const unsigned char* bits = nullptr) {
     const int c = t & 7;
     const int k = k0 + c * 8;
 #pragma unroll
@@ -51,7 +52,10 @@ __device__ __forceinline__ void load_kc(const bf16_t* __restrict__ P, int ld, in
         u32x4 v = {0u, 0u, 0u, 0u};
         if (row < nrows && k + 8 <= K) {
             v = *reinterpret_cast<const u32x4*>(P + (size_t)row * ld + k);
-            if constexpr (MASK) v = mask8(v, gemm_keep8(key, ((long)row * mld + k) >> 3, thr));     // mld % 8 == 0, k % 8 == 0: one hash group
+            if constexpr (MASK) {         // mld % 8 == 0, k % 8 == 0: one hash group = one byte of the packed mask
+                const long gq = ((long)row * mld + k) >> 3;
+                v = mask8(v, bits ? (uint32_t)bits[gq] : gemm_keep8(key, gq, thr));
+            }
         }
         r[i] = v;
     }
@@ -67,7 +71,7 @@ __device__ __forceinline__ void store_kc(char* lds, int t, const u32x4 (&r)[4]) 
 // ---- k-strided operand: stored [K][ncols]; tile 64 k x 128 cols; thread -> (k block = t/32, col quad = t%32) ----
 template <bool MASK = false>
 __device__ __forceinline__ void load_ks(const bf16_t* __restrict__ P, int ld, int col0, int ncols, int k0, int K, int t,
-                                        u32x2 (&r)[8], uint64_t key = 0, uint32_t thr = 0, int mld = 0) {
+                                        u32x2 (&r)[8], uint64_t key = 0, uint32_t thr = 0, int mld = 0, const unsigned char* bits = nullptr) {
     const int kb = t >> 5, nq = t & 31;
     const int col = col0 + nq * 4;
     const bool cok = col + 4 <= ncols;
@@ -78,7 +82,8 @@ __device__ __forceinline__ void load_ks(const bf16_t* __restrict__ P, int ld, in
         if (cok && k < K) {
             v = *reinterpret_cast<const u32x2*>(P + (size_t)k * ld + col);
             if constexpr (MASK) {         // element (row k, columns col .. col + 3): half a hash group
-                const uint32_t keep = gemm_keep8(key, ((long)k * mld + col) >> 3, thr) >> (col & 4);
+                const long gq = ((long)k * mld + col) >> 3;
+                const uint32_t keep = (bits ? (uint32_t)bits[gq] : gemm_keep8(key, gq, thr)) >> (col & 4);
                 v[0] &= (keep & 1 ? 0x0000ffffu : 0u) | (keep & 2 ? 0xffff0000u : 0u);
                 v[1] &= (keep & 4 ? 0x0000ffffu : 0u) | (keep & 8 ? 0xffff0000u : 0u);
             }
@@ -115,6 +120,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
         p.C = (char*)p.C + (size_t)g * p.gC * (p.out_f32 ? 4 : 2);
         if (p.splitk > 1) p.part += (size_t)g * p.splitk * p.M * p.N;
         mkey = vlr_mix64(p.mask_seed + (uint64_t)g);
+        if (p.mask_bits) p.mask_bits += (size_t)g * p.gMask;
     }
     int kabs0 = 0;                   // split-K slices move p.A / p.B: the mask index uses the ABSOLUTE k
     if (p.splitk > 1) {   // split-K slice: this workgroup reduces k in [z*kchunk, (z+1)*kchunk) into its own fp32 partial
@@ -162,10 +168,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
         if constexpr (A_KS) load_ks(p.A, p.lda, m0, p.M, k0, p.K, t, ra_s);
         else if constexpr (MASK == 1) {
             // x rows [M][mask_ld] masked while staged: the pointer already carries the split-K offset, the hash index needs it back
-            load_kc<true>(p.A - kabs0, p.lda, m0, p.M, k0 + kabs0, p.K + kabs0, t, ra_c, mkey, p.mask_thr, p.mask_ld);
+            load_kc<true>(p.A - kabs0, p.lda, m0, p.M, k0 + kabs0, p.K + kabs0, t, ra_c, mkey, p.mask_thr, p.mask_ld, p.mask_bits);
         } else load_kc(p.A, p.lda, m0, p.M, k0, p.K, t, ra_c);
         if constexpr (B_KS) {
-            if constexpr (MASK == 2) load_ks<true>(p.B - (size_t)kabs0 * p.ldb, p.ldb, n0, p.N, k0 + kabs0, p.K + kabs0, t, rb_s, mkey, p.mask_thr, p.mask_ld);
+            if constexpr (MASK == 2) load_ks<true>(p.B - (size_t)kabs0 * p.ldb, p.ldb, n0, p.N, k0 + kabs0, p.K + kabs0, t, rb_s, mkey, p.mask_thr, p.mask_ld, p.mask_bits);
             else load_ks(p.B, p.ldb, n0, p.N, k0, p.K, t, rb_s);
         } else load_kc(p.B, p.ldb, n0, p.N, k0, p.K, t, rb_c);
     };
@@ -223,90 +229,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
                 stage[row * 64 + col] = acc[i][j][r];
             }
     __syncthreads();
-    const int gm0 = m0 + wm * 64, gn0 = n0 + wn * 64;
-    if (!p.out_f32) {
-        bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
-        const int cq = (lane & 7) * 8;
-        const int gn = gn0 + cq;
-        float bv[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bv[e] = 0.f;
-        if (p.bias && gn + 8 <= p.N) unpack8(*reinterpret_cast<const u32x4*>(p.bias + gn), bv);
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int row = it * 8 + (lane >> 3);
-            const int gm = gm0 + row;
-            if (gm < p.M && gn + 8 <= p.N) {
-                float v[8];
-                const f32x4 s0 = *reinterpret_cast<const f32x4*>(stage + row * 64 + cq);
-                const f32x4 s1 = *reinterpret_cast<const f32x4*>(stage + row * 64 + cq + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = s0[e];
-                    v[4 + e] = s1[e];
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = apply_act(p.alpha * v[e] + bv[e], p.act);
-                if (p.fuse == 6) {      // dropout-accumulate: the keep mask of elements (gm, gn .. gn+7) - one hash group of vlr_dropout
-                    const long grp = ((long)gm * p.drop_ld + gn) >> 3;
-                    const uint64_t r0 = vlr_mix64(p.drop_key ^ (uint64_t)(2 * grp)), r1 = vlr_mix64(p.drop_key ^ (uint64_t)(2 * grp + 1));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if ((uint32_t)((r0 >> (16 * e)) & 0xffffu) < p.drop_thr) v[e] = 0.f;
-                        if ((uint32_t)((r1 >> (16 * e)) & 0xffffu) < p.drop_thr) v[4 + e] = 0.f;
-                    }
-                }
-                if (p.residual) {
-                    float rv[8];
-                    unpack8(*reinterpret_cast<const u32x4*>(p.residual + (size_t)gm * p.ldr + gn), rv);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += rv[e];
-                }
-                bf16_t* dst = C + (size_t)gm * p.ldc + gn;
-                if (p.accumulate) {
-                    float ov[8];
-                    unpack8(*reinterpret_cast<const u32x4*>(dst), ov);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += ov[e];
-                }
-                *reinterpret_cast<u32x4*>(dst) = pack8(v);
-            }
-        }
-    } else {
-        float* C = reinterpret_cast<float*>(p.C);
-        const int cq = (lane & 15) * 4;
-        const int gn = gn0 + cq;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias && gn + 4 <= p.N) {
-            const u32x2 w = *reinterpret_cast<const u32x2*>(p.bias + gn);
-            bv[0] = bf16lo(w[0]); bv[1] = bf16hi(w[0]); bv[2] = bf16lo(w[1]); bv[3] = bf16hi(w[1]);
-        }
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int row = it * 4 + (lane >> 4);
-            const int gm = gm0 + row;
-            if (gm < p.M && gn + 4 <= p.N) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * 64 + cq);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = apply_act(p.alpha * v[e] + bv[e], p.act);
-                if (p.residual) {
-                    if (p.res_f32) {
-                        v += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.residual) + (size_t)gm * p.ldr + gn);
-                    } else {
-                        const u32x2 w = *reinterpret_cast<const u32x2*>(p.residual + (size_t)gm * p.ldr + gn);
-                        v[0] += bf16lo(w[0]); v[1] += bf16hi(w[0]); v[2] += bf16lo(w[1]); v[3] += bf16hi(w[1]);
-                    }
-                }
-                float* dst = C + (size_t)gm * p.ldc + gn;
-                if (p.accumulate) {
-                    const f32x4 o = *reinterpret_cast<const f32x4*>(dst);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += o[e];
-                }
-                *reinterpret_cast<f32x4*>(dst) = v;
-            }
-        }
-    }
+    gemm128_copy_out<64>(p, stage, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -391,7 +314,8 @@ __global__ __launch_bounds__(256) void dropacc_multi_kernel(GemmParams p) {
             if (gm < p.M && gn + 8 <= p.N) {
                 const f32x4 s0 = *reinterpret_cast<const f32x4*>(stage + row * 64 + cq);
                 const f32x4 s1 = *reinterpret_cast<const f32x4*>(stage + row * 64 + cq + 4);
-                const uint32_t keep = gemm_keep8(key, ((long)gm * p.mask_ld + gn) >> 3, p.mask_thr);
+                const long gq = ((long)gm * p.mask_ld + gn) >> 3;
+                const uint32_t keep = p.mask_bits ? (uint32_t)p.mask_bits[(size_t)term * p.gMask + gq] : gemm_keep8(key, gq, p.mask_thr);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if ((keep >> e) & 1) sum[it][e] += p.alpha * s0[e];
@@ -506,11 +430,11 @@ extern "C" int vlr_gemm_set_splitk_workspace(void* ws, long bytes) {
 // Default from VLR_GEMM_SCHED (else 0 until measured - see DESIGN.md); vlr_gemm_set_sched(-1) re-reads the environment.
 static int g_sched = -1;
 int vlr_gemm_sched_mode() {
-    if (g_sched < 0) { const char* e = getenv("VLR_GEMM_SCHED"); g_sched = e ? (atoi(e) & 7) : VLR_SCHED_DEFAULT; }
+    if (g_sched < 0) { const char* e = getenv("VLR_GEMM_SCHED"); g_sched = e ? (atoi(e) & 15) : VLR_SCHED_DEFAULT; }
     return g_sched;
 }
 extern "C" int vlr_gemm_set_sched(int mode) {
-    VLR_REQUIRE(mode >= -1 && mode <= 7, "vlr_gemm_set_sched: mode 0..7 (bit 0 stream-K tail, bit 1 XCD rotation, bit 2 XCD round barrier) or -1, got %d", mode);
+    VLR_REQUIRE(mode >= -1 && mode <= 15, "vlr_gemm_set_sched: mode 0..15 (bit 0 stream-K tail, bit 1 XCD rotation, bit 2 XCD round barrier, bit 3 adapter tiles on the general path) or -1, got %d", mode);
     g_sched = mode;
     return VLR_OK;
 }
@@ -538,11 +462,20 @@ float* vlr_gemm_sk_workspace(hipStream_t stream, uint32_t* epoch) {
     return ws;
 }
 // split-K launch of the 128x128 kernel: few output tiles, long reduction.  Returns false when it does not apply.
+// one launch of the 128x128-tile GEMM: the LDS-DMA ring kernel (gemm128p.hip) when the operands qualify, else the register-staged one
+static void launch128(int layout, const GemmParams& p, dim3 grid, hipStream_t stream) {
+    if (vlr_gemm128p_try_launch(layout, p, grid, stream)) return;
+    if (layout == 0) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, dim3(256), 0, stream, p);
+    else if (layout == 1) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, dim3(256), 0, stream, p);
+}
 static bool launch_splitk128(int layout, GemmParams p, hipStream_t stream, int min_k) {
     if (p.N % 4 != 0 || p.K < min_k) return false;
     const int tiles128 = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     if (tiles128 >= 256) return false;
-    int splits = 512 / tiles128;
+    static int target = -1;       // workgroups a split launch aims at (VLR_SPLITK_TARGET; 2 per CU)
+    if (target < 0) { const char* e = getenv("VLR_SPLITK_TARGET"); target = e ? atoi(e) : 512; if (target < 64) target = 512; }
+    int splits = target / tiles128;
     if (splits > 16) splits = 16;
     if (splits > p.K / 256) splits = p.K / 256;
     if (splits < 2) return false;
@@ -551,12 +484,10 @@ static bool launch_splitk128(int layout, GemmParams p, hipStream_t stream, int m
     const long per = (long)p.M * p.N * 4;
     if ((long)splits * per > g_splitk_bytes) splits = (int)(g_splitk_bytes / per);
     if (splits < 2) return false;
-    const int kchunk = (((p.K + splits - 1) / splits) + 31) / 32 * 32;
+    const int kchunk = (((p.K + splits - 1) / splits) + 63) / 64 * 64;      // whole K tiles per slice
     splits = (p.K + kchunk - 1) / kchunk;
     p.splitk = splits; p.kchunk = kchunk; p.part = ws;
-    if (layout == 0) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), dim3(tiles128, splits), dim3(256), 0, stream, p);
-    else if (layout == 1) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), dim3(tiles128, splits), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), dim3(tiles128, splits), dim3(256), 0, stream, p);
+    launch128(layout, p, dim3(tiles128, splits), stream);
     const long n4 = (long)p.M * p.N / 4;
     int rg = (int)((n4 + 255) / 256);
     if (rg > 2048) rg = 2048;
@@ -571,7 +502,7 @@ static GemmParams fused_params(const void* A, const void* B, void* C, int M, int
 // dropped elements of the activation operand while it is staged (keep mask of vlr_dropout(seed + g) over [rows][mask_ld]).
 static int gemm_grouped(int layout, const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int groups,
                         long gA, long gB, long gC, float alpha, int accumulate, int mask_on, uint64_t seed, float p_drop, int mask_ld,
-                        hipStream_t stream) {
+                        const void* mask_bits, long mask_gstride, hipStream_t stream) {
     VLR_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && groups >= 1 && groups <= 8, "gemm_grouped: bad arguments");
     VLR_REQUIRE(N % 8 == 0 && ldc % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && gC % 4 == 0, "gemm_grouped: alignment (N %d lda %d ldb %d ldc %d)", N, lda, ldb, ldc);
     VLR_REQUIRE(!mask_on || (mask_ld % 8 == 0 && ((mask_on == 1 && layout == 0) || (mask_on == 2 && layout == 2))), "gemm_grouped: mask on the NT A / TN B operand only");
@@ -579,6 +510,7 @@ static int gemm_grouped(int layout, const void* A, const void* B, void* C, int M
     p.alpha = alpha; p.accumulate = accumulate;
     p.groups = groups; p.gA = gA; p.gB = gB; p.gC = gC;
     p.mask_on = mask_on; p.mask_seed = seed; p.mask_thr = vlr_dropout_thr(p_drop); p.mask_ld = mask_ld;
+    p.mask_bits = mask_on ? (const unsigned char*)mask_bits : nullptr; p.gMask = mask_gstride;
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     int splits = 1;
     float* ws = nullptr;
@@ -599,15 +531,9 @@ static int gemm_grouped(int layout, const void* A, const void* B, void* C, int M
     }
     const dim3 grid(tiles, splits, groups);
     const int pi = vlr_prof_begin(layout, 2.0 * M * N * K * groups, stream);
-    if (layout == 0) {
-        if (mask_on) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, 1>), grid, dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, dim3(256), 0, stream, p);
-    } else if (layout == 1) {
-        hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, dim3(256), 0, stream, p);
-    } else {
-        if (mask_on) hipLaunchKernelGGL((gemm_bf16_kernel<true, true, 2>), grid, dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, dim3(256), 0, stream, p);
-    }
+    if (mask_on && layout == 0) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, 1>), grid, dim3(256), 0, stream, p);
+    else if (mask_on) hipLaunchKernelGGL((gemm_bf16_kernel<true, true, 2>), grid, dim3(256), 0, stream, p);
+    else launch128(layout, p, grid, stream);
     if (splits > 1) {
         const long n4 = (long)M * N / 4;
         int rg = (int)((n4 + 255) / 256);
@@ -624,23 +550,49 @@ extern "C" int vlr_gemm_grouped(int layout, const void* A, const void* B, void* 
                                 float p_drop, int mask_ld, hipStream_t stream) {
     VLR_REQUIRE(layout >= 0 && layout <= 2, "vlr_gemm_grouped: layout %d", layout);
     VLR_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "vlr_gemm_grouped: 0 <= p < 1, got %g", (double)p_drop);
-    return gemm_grouped(layout, A, B, C, M, N, K, lda, ldb, ldc, groups, gA, gB, gC, alpha, accumulate, mask_on, seed, p_drop, mask_ld, stream);
+    return gemm_grouped(layout, A, B, C, M, N, K, lda, ldb, ldc, groups, gA, gB, gC, alpha, accumulate, mask_on, seed, p_drop, mask_ld, nullptr, 0, stream);
+}
+// the same with the keep masks drawn beforehand (vlr_dropout_bits(seed + g) over the [rows][mask_ld] operand, group g at mask_bits +
+// g * mask_gstride bytes): the kernels read one byte per eight elements instead of hashing
+extern "C" int vlr_gemm_grouped_bits(int layout, const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                     int groups, long gA, long gB, long gC, float alpha, int accumulate, int mask_on, uint64_t seed,
+                                     float p_drop, int mask_ld, const void* mask_bits, long mask_gstride, hipStream_t stream) {
+    VLR_REQUIRE(layout >= 0 && layout <= 2, "vlr_gemm_grouped_bits: layout %d", layout);
+    VLR_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "vlr_gemm_grouped_bits: 0 <= p < 1, got %g", (double)p_drop);
+    return gemm_grouped(layout, A, B, C, M, N, K, lda, ldb, ldc, groups, gA, gB, gC, alpha, accumulate, mask_on, seed, p_drop, mask_ld, mask_bits,
+                        mask_gstride, stream);
 }
 
 // dx [M][in] (+)= sum over the n targets t of scale / (1 - p) * keep_t . (v_t . A_t): v [M][ldv] holds the n blocks of r columns side by
 // side, A the n stacked [r][in] lora_A matrices, keep_t = the mask of vlr_dropout(seed + t) over [M][in] (p = 0: no mask).  ONE pass
 // over dx whatever n is (the per-target vlr_gemm_dropout_acc makes n).  accumulate = 0 writes dx instead of adding to it.
+extern "C" int vlr_gemm_dropout_acc_multi_bits(int n, const void* v, int ldv, const void* A, void* dx, int M, int in, int r, float p,
+                                               uint64_t seed, float scale, int accumulate, const void* bits, long bits_gstride,
+                                               hipStream_t stream);
 extern "C" int vlr_gemm_dropout_acc_multi(int n, const void* v, int ldv, const void* A, void* dx, int M, int in, int r, float p,
                                           uint64_t seed, float scale, int accumulate, hipStream_t stream) {
+    return vlr_gemm_dropout_acc_multi_bits(n, v, ldv, A, dx, M, in, r, p, seed, scale, accumulate, nullptr, 0, stream);
+}
+// bits != NULL: the packed keep masks of the n targets (vlr_dropout_bits(seed + t), target t at bits + t * bits_gstride bytes)
+extern "C" int vlr_gemm_dropout_acc_multi_bits(int n, const void* v, int ldv, const void* A, void* dx, int M, int in, int r, float p,
+                                               uint64_t seed, float scale, int accumulate, const void* bits, long bits_gstride,
+                                               hipStream_t stream) {
     VLR_REQUIRE(v && A && dx, "vlr_gemm_dropout_acc_multi: null operand");
     VLR_REQUIRE(n >= 1 && n <= 8 && M > 0 && in > 0 && r > 0 && in % 8 == 0 && r % 8 == 0 && ldv % 8 == 0 && ldv >= n * r,
                 "vlr_gemm_dropout_acc_multi: bad shape n=%d M=%d in=%d r=%d ldv=%d", n, M, in, r, ldv);
     VLR_REQUIRE(p >= 0.f && p < 1.f, "vlr_gemm_dropout_acc_multi: 0 <= p < 1 required, got %g", (double)p);
     VLR_REQUIRE(!(((uintptr_t)v | (uintptr_t)A | (uintptr_t)dx) & 15), "vlr_gemm_dropout_acc_multi: 16-byte aligned operands");
+    {   // the streaming kernel (lora_dx.hip): v rows in registers, A_t slices through LDS, one read-modify-write of dx
+        const int pj = vlr_prof_begin(VLR_K_GEMM_NN, 2.0 * M * in * r * n, stream);
+        const bool took = vlr_lora_dx_try_launch(n, v, ldv, A, dx, M, in, r, p, seed, scale, accumulate, bits, bits_gstride, stream);
+        vlr_prof_end(took ? pj : -1, stream);
+        if (took) return vlr_check_launch("vlr_gemm_dropout_acc_multi(streamed)");
+    }
     GemmParams g = fused_params(v, A, dx, M, in, r, ldv, in, in);
     g.alpha = scale / (1.f - p); g.accumulate = accumulate;
     g.groups = n; g.gA = r; g.gB = (long)r * in;
     g.mask_seed = seed; g.mask_thr = vlr_dropout_thr(p); g.mask_ld = in;
+    g.mask_bits = (const unsigned char*)bits; g.gMask = bits_gstride;
     const int tiles = ((M + BM - 1) / BM) * ((in + BN - 1) / BN);
     const int pi = vlr_prof_begin(VLR_K_GEMM_NN, 2.0 * M * in * r * n, stream);
     hipLaunchKernelGGL(dropacc_multi_kernel, dim3(tiles), dim3(256), 0, stream, g);
@@ -659,7 +611,7 @@ static int gemm_impl(int layout, const void* A, const void* B, void* C, const vo
 
 // wave quantisation (see gemm_impl): how many of the last 256-row tile rows to peel off so that the 256x256-tile part is a
 // whole number of rounds on the 256 CUs; tn = workgroup tiles per tile row
-static int choose_peel(int M, int N, int tn, int K = 0, hipStream_t stream = nullptr) {
+static int choose_peel(int M, int N, int tn, int K = 0, hipStream_t stream = nullptr, bool tail256 = false) {
     const int tm256 = (M + 255) / 256;
     int peel = 0;
     // stream-K tail (GemmParams::sched bit 0): the persistent kernel balances its last rounds itself - every row takes the same path
@@ -673,7 +625,10 @@ static int choose_peel(int M, int N, int tn, int K = 0, hipStream_t stream = nul
             const int t1 = (tm256 - r) * tn;
             const int rem_rows = M - (tm256 - r) * 256;
             const long t128 = (long)((rem_rows + 127) / 128) * ((N + 127) / 128);
-            const double est = (double)((t1 + ncu - 1) / ncu) + 0.7 * (double)((t128 + 2 * ncu - 1) / (2 * ncu));
+            // the peeled rows run on the 128x128 kernel (two workgroups per CU, ~0.7 of a 256x256 tile time per round of 2 x ncu), or -
+            // fused epilogues (tail256) - as a second launch of the same 256x256 kernel, one cold tile per workgroup
+            const double est = (double)((t1 + ncu - 1) / ncu) +
+                               (tail256 ? 1.15 * (double)((r * tn + ncu - 1) / ncu) : 0.7 * (double)((t128 + 2 * ncu - 1) / (2 * ncu)));
             if (est < best - 0.05) { best = est; peel = r; }
         }
     }
@@ -731,6 +686,7 @@ static int gemm_impl_ex(int layout, const void* A, const void* B, void* C, const
     p.res_f32 = residual ? res_f32 : 0;
     p.sched = 0; p.sk_ws = nullptr; p.sk_epoch = 0;
     p.groups = 1; p.gA = p.gB = p.gC = 0; p.mask_on = 0; p.mask_seed = 0; p.mask_thr = 0; p.mask_ld = 0;
+    p.mask_bits = nullptr; p.gMask = 0; p.drop_bits = nullptr;
     const int pi = vlr_prof_begin(layout, 2.0 * M * N * K, stream);
     // ---- split-K for problems whose output is a handful of tiles but whose reduction is long: the LoRA adapter gradients
     // (TN: dB = dy^T u [out x r], dA = v^T x [r x in], reduction over all tokens) - 32..96 workgroups would leave most CUs idle
@@ -771,9 +727,7 @@ static int gemm_impl_ex(int layout, const void* A, const void* B, void* C, const
                 vlr_prof_end(pi, stream);
                 return vlr_check_launch("vlr_gemm_bf16(256+128 split-K)");
             }
-            if (layout == 0) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), dim3(t2), dim3(256), 0, stream, p2);
-            else if (layout == 1) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), dim3(t2), dim3(256), 0, stream, p2);
-            else hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), dim3(t2), dim3(256), 0, stream, p2);
+            launch128(layout, p2, dim3(t2), stream);
             vlr_prof_end(pi, stream);
             return vlr_check_launch("vlr_gemm_bf16(256+128)");
         }
@@ -783,9 +737,12 @@ static int gemm_impl_ex(int layout, const void* A, const void* B, void* C, const
         vlr_prof_end(pi, stream);
         return vlr_check_launch("vlr_gemm_bf16(256)");
     }
-    if (layout == 0) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), dim3(tiles), dim3(256), 0, stream, p);
-    else if (layout == 1) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), dim3(tiles), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), dim3(tiles), dim3(256), 0, stream, p);
+    // few tiles with a long reduction (small batches against the decoder weights): split along K so that they fill the chip
+    if (launch_splitk128(layout, p, stream, 4096)) {
+        vlr_prof_end(pi, stream);
+        return vlr_check_launch("vlr_gemm_bf16(128 split-K)");
+    }
+    launch128(layout, p, dim3(tiles), stream);
     vlr_prof_end(pi, stream);
     return vlr_check_launch("vlr_gemm_bf16");
 }
@@ -810,6 +767,7 @@ static GemmParams fused_params(const void* A, const void* B, void* C, int M, int
     p.A2 = p.B2 = nullptr; p.lda2 = p.ldb2 = p.K2 = 0; p.seg_b0 = p.seg_b1 = 0x7fffffff; p.drop_key = 0; p.drop_thr = 0; p.drop_ld = 0; p.res_f32 = 0;
     p.sched = 0; p.sk_ws = nullptr; p.sk_epoch = 0;
     p.groups = 1; p.gA = p.gB = p.gC = 0; p.mask_on = 0; p.mask_seed = 0; p.mask_thr = 0; p.mask_ld = 0;
+    p.mask_bits = nullptr; p.gMask = 0; p.drop_bits = nullptr;
     return p;
 }
 
@@ -849,7 +807,7 @@ static int gemm_swiglu_impl(const void* x, const void* wgu, void* gu, void* act,
     { int rc = seg_check("vlr_gemm_swiglu_lora", sg); if (rc != VLR_OK) return rc; }
     const bool seg = sg && sg->u;
     const int tn = (I + 127) / 128;
-    const int peel = choose_peel(M, 2 * I, tn, seg ? 0 : K, stream);
+    const int peel = choose_peel(M, 2 * I, tn, seg ? 0 : K, stream, true);
     const int tm256 = (M + 255) / 256;
     const int M1 = peel ? (tm256 - peel) * 256 : M;
     GemmParams p = fused_params(x, wgu, gu, M1, 2 * I, K, ldx, K, 2 * I);
@@ -914,7 +872,7 @@ static int gemm_qkv_rope_impl(const void* x, const void* wqkv, void* qkv, const 
     int done = 0;
     if (head_dim == 128 && (!bias || !((uintptr_t)bias & 7))) {
         const int tn = (N + 255) / 256;
-        const int peel = choose_peel(M, N, tn, seg ? 0 : K, stream);
+        const int peel = choose_peel(M, N, tn, seg ? 0 : K, stream, true);
         const int tm256 = (M + 255) / 256;
         const int M1 = peel ? (tm256 - peel) * 256 : M;
         GemmParams p = fused_params(x, wqkv, qkv, M1, N, K, ldx, K, N);
@@ -980,14 +938,21 @@ extern "C" int vlr_dropout(const void* x, void* out, long n, float p, uint64_t s
 // dx [M][in] += scale / (1 - p) * mask_seed .* (v [M][ldv] . A [r][in]): the input-gradient term of one LoRA target with
 // lora_dropout (mask index = row * in + col, the mask the forward applied to x).  `scratch` [M][in] is used only when the fused
 // kernel does not take the shape (then: product -> scratch, vlr_dropout(add) -> dx).
+extern "C" int vlr_gemm_dropout_acc_bits(const void* v, int ldv, const void* A, void* dx, void* scratch, int M, int in, int r, float p,
+                                         uint64_t seed, float scale, const void* bits, hipStream_t stream);
 extern "C" int vlr_gemm_dropout_acc(const void* v, int ldv, const void* A, void* dx, void* scratch, int M, int in, int r, float p,
                                     uint64_t seed, float scale, hipStream_t stream) {
+    return vlr_gemm_dropout_acc_bits(v, ldv, A, dx, scratch, M, in, r, p, seed, scale, nullptr, stream);
+}
+// bits != NULL: the packed keep mask of vlr_dropout_bits(seed) over [M][in] (read by the 128x128 kernel's epilogue; the other paths hash)
+extern "C" int vlr_gemm_dropout_acc_bits(const void* v, int ldv, const void* A, void* dx, void* scratch, int M, int in, int r, float p,
+                                         uint64_t seed, float scale, const void* bits, hipStream_t stream) {
     VLR_REQUIRE(v && A && dx && scratch, "vlr_gemm_dropout_acc: null operand");
     VLR_REQUIRE(M > 0 && in > 0 && r > 0 && in % 8 == 0 && r % 8 == 0 && ldv % 8 == 0, "vlr_gemm_dropout_acc: bad shape M=%d in=%d r=%d ldv=%d", M, in, r, ldv);
     VLR_REQUIRE(p >= 0.f && p < 1.f, "vlr_gemm_dropout_acc: 0 <= p < 1 required, got %g", (double)p);
     GemmParams g = fused_params(v, A, dx, M, in, r, ldv, in, in);
     g.fuse = 6; g.accumulate = 1; g.alpha = scale / (1.f - p);
-    g.drop_key = vlr_mix64(seed); g.drop_thr = vlr_dropout_thr(p); g.drop_ld = in;
+    g.drop_key = vlr_mix64(seed); g.drop_thr = vlr_dropout_thr(p); g.drop_ld = in; g.drop_bits = (const unsigned char*)bits;
     // K is the adapter rank: the launch is one read-modify-write pass over dx with a few MFMAs per tile.  The 256x256 kernel holds one
     // tile per CU and its load - add - store of the 128 KB output tile is exposed (157 us per [12792 x 4096] launch = 1.3 TB/s);
     // the 128x128 kernel keeps several workgroups per CU in flight and adds in fp32 before the one rounding.  VLR_GEMM_DROPACC: 2 (default)
@@ -1074,7 +1039,7 @@ static int gemm_swiglu_bwd_impl(const void* dy, const void* wdown, void* gu, voi
     VLR_REQUIRE(dy && wdown && gu && dact_ws, "vlr_gemm_swiglu_bwd: null operand");
     VLR_REQUIRE(M > 0 && I > 0 && H > 0 && I % 8 == 0 && H % 8 == 0, "vlr_gemm_swiglu_bwd: bad shape M=%d I=%d H=%d", M, I, H);
     const int tn = (I + 255) / 256;
-    const int peel = choose_peel(M, I, tn, H, stream);
+    const int peel = choose_peel(M, I, tn, H, stream, true);
     const int tm256 = (M + 255) / 256;
     const int M1 = peel ? (tm256 - peel) * 256 : M;
     GemmParams p = fused_params(dy, wdown, dact_ws, M1, I, H, H, I, I);

@@ -404,6 +404,38 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                 return;
             }
         }
+        if constexpr (SEG && fast) {
+            // whole adapter tiles (K2 % 64 == 0) on the DMA path: uniform base of the segment's K tile + per-lane offsets recomputed here
+            // (a handful of VALU ops per piece; kept out of the loop-carried registers like the general form above).  SwiGLU: the half
+            // that does not own this K range streams the 16 zero bytes (every lane the same address).
+            if (kb + tile >= nt1) {
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                const uint32_t dst = lds_wave + ((tile + parb) & 1) * BUF_BYTES + h * HALF_BYTES;
+                const int s_ = kb + tile - nt1;
+                uint32_t o2[2];
+                if constexpr (h < 2) {
+                    piece_off_kc(p.lda2, m0 + h * 128, p.M, wave, ln, o2);
+                    const char* base = (const char*)(p.A2 + a2off) + (size_t)s_ * (PK * 2);
+                    lds_dma16_s(base, o2[0], dst);
+                    lds_dma16_s(base, o2[1], dst + 8192);
+                } else {
+                    const int k0 = s_ * PK - (FUSE == 1 ? (h - 2) * p.K2 : 0);
+                    if (k0 >= 0 && k0 < p.K2) {
+                        piece_off_kc_b<FUSE>(p.ldb2, n0, h - 2, p.N, wave, ln, o2);
+                        const char* base = (const char*)p.B2 + (ptrdiff_t)k0 * 2;
+                        lds_dma16_s(base, o2[0], dst);
+                        lds_dma16_s(base, o2[1], dst + 8192);
+                    } else {
+                        uint32_t z = 0;
+                        asm volatile("" : "+v"(z));
+                        lds_dma16_s((const char*)zero16, z, dst);
+                        lds_dma16_s((const char*)zero16, z, dst + 8192);
+                    }
+                }
+                return;
+            }
+        }
         if (!fast && ktail && kb + tile == nt - 1) {
             char* dst = smem + ((tile + parb) & 1) * BUF_BYTES + h * HALF_BYTES;
             const int k0 = (kb + tile) * PK;
@@ -573,8 +605,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
         flip = -flip;
     };
     // steady state: every staged tile (kt+1, kt+2) exists and is full -> no checks, no K-tail path in the hot loop
-    // (absolute K tiles kb + kt + 2 below `lim` are whole tiles of (A, B); SEG: K % 64 == 0, the adapter tiles take the general path)
-    const int lim = (SEG ? nt1 : nt) - (ktail ? 1 : 0) - kb;
+    // (absolute K tiles kb + kt + 2 below `lim` are whole tiles of (A, B); SEG: K % 64 == 0, the adapter tiles too when K2 % 64 == 0)
+    const int lim = ((SEG && ((p.K2 % PK) != 0 || (p.sched & 8))) ? nt1 : nt) - (ktail ? 1 : 0) - kb;
     const int n_fast = (ntp < lim ? ntp : lim) - 2;
     int kt = 0;
     for (; kt < n_fast; ++kt) ktile(kt, FAST{});
@@ -1092,7 +1124,7 @@ static bf16_t* gemm256p_zero16() {
 // and the caller's 128 MiB scratch slot for this stream; otherwise plain rounds
 static void sk_prepare(GemmParams& p, int ntiles, int grid, hipStream_t stream) {
     p.sched = 0; p.sk_ws = nullptr; p.sk_epoch = 0;
-    const int mode = vlr_gemm_sched_mode();
+    const int mode = vlr_gemm_sched_mode() & 7;
     if (!mode || ntiles <= grid || (grid & 7) || (p.K + PK - 1) / PK < VLR_SK_MIN_KTILES) return;
     uint32_t ep = 0;
     float* ws = vlr_gemm_sk_workspace(stream, &ep);
@@ -1133,7 +1165,9 @@ bool vlr_gemm256p_fused_try_launch(const GemmParams& p_in, hipStream_t stream) {
 
 // C = A B^T + A2 B2^T (adapter segment, GemmParams::A2...), NT, persistent continuous pipeline only: fuse 0 (plain, optional
 // residual), 1 (SwiGLU), 2 (RoPE).  false: the caller runs the base GEMM and the adapter GEMMs separately.
-bool vlr_gemm256p_seg_try_launch(const GemmParams& p, hipStream_t stream) {
+bool vlr_gemm256p_seg_try_launch(const GemmParams& p_in, hipStream_t stream) {
+    GemmParams p = p_in;
+    p.sched = vlr_gemm_sched_mode() & 8;       // bit 3 (A/B switch): adapter K tiles on the general staging path
     static int on = -1;
     if (on < 0) {
         const char* e = getenv("VLR_GEMM_SEG");

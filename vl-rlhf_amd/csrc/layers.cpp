@@ -156,8 +156,10 @@ extern "C" int vlr_decoder_layer_bwd(const vlr_llama_cfg* cfg, const vlr_layer_w
 // ---------------------------------------------------------------------------------------------------------------------
 // outs[t]: output features of sub-target t (they differ under grouped-query attention: q has heads*hd, k and v kv_heads*hd)
 // u_t = s * dropout_t(x) A_t^T for the n sub-targets of a group (the B half rides the K loop of the base GEMM: vlr_gemm_*_lora)
+// bits != NULL (vlr_lora_weights::mask_bits): the packed keep masks of the n targets are DRAWN here (target t at bits + t * M * in / 8) and
+// read by the staged-operand mask of the grouped launch - and again by the backward (lora_group_bwd)
 static int lora_group_a(int n, int r, int in, const void* x, int ldx, const void* A, void* u, int ldu, float scale, float p,
-                        uint64_t seed, void* ws_xd, int M, hipStream_t st, const unsigned char* rowmask = nullptr) {
+                        uint64_t seed, void* ws_xd, int M, hipStream_t st, const unsigned char* rowmask = nullptr, unsigned char* bits = nullptr) {
     (void)ws_xd;
     struct MaskAfter {       // PLoRA: the adapter acts on the image rows only - zero the other rows of u on the way out
         void* u; int ldu, cols, M; const unsigned char* rm; hipStream_t st;
@@ -167,7 +169,13 @@ static int lora_group_a(int n, int r, int in, const void* x, int ldx, const void
         // ONE grouped launch for the n sub-targets: target t = group t reads the SAME x with its own keep mask (vlr_dropout(seed + t),
         // zeroed while the operand is staged - drop(x) is never written) against its own A_t; 1 / (1 - p) rides in alpha
         VLR_REQUIRE(ldx == in, "lora: the dropout mask is indexed over [M][in]; x must be dense (ldx %d, in %d)", ldx, in);
-        CHECK(vlr_gemm_grouped(0, x, A, u, M, r, in, ldx, in, ldu, n, 0L, (long)r * in, (long)r, scale / (1.f - p), 0, 1, seed, p, in, st));
+        const long gstride = (long)M * in / 8;
+        if (bits) {
+            VLR_REQUIRE(((long)M * in) % 32 == 0, "lora: packed dropout masks need M * in %% 32 == 0 (M %d, in %d)", M, in);
+            for (int t = 0; t < n; ++t) CHECK(vlr_dropout_bits(bits + (size_t)t * gstride, (long)M * in, p, seed + t, st));
+        }
+        CHECK(vlr_gemm_grouped_bits(0, x, A, u, M, r, in, ldx, in, ldu, n, 0L, (long)r * in, (long)r, scale / (1.f - p), 0, 1, seed, p, in, bits,
+                                    gstride, st));
     } else {
         CHECK(vlr_gemm_bf16_scaled(0, x, A, u, nullptr, nullptr, M, n * r, in, ldx, in, ldu, 0, 0, 0, 0, scale, st));
     }
@@ -178,8 +186,10 @@ static int lora_group_a(int n, int r, int in, const void* x, int ldx, const void
 // dx_fresh = 1: dx is WRITTEN (= the adapter term alone; the caller adds dy W afterwards - the fused SwiGLU-backward GEMM of down_proj)
 static int lora_group_bwd(int n, int r, int in, const int* outs, const void* x, const void* dy, int lddy, const void* A, const void* B,
                           void* dA, void* dB, const void* u, int ldu, void* v, void* dx, float scale, float p, uint64_t seed,
-                          void* ws_xd, int accumulate, int M, hipStream_t st, int dx_fresh = 0, const unsigned char* rowmask = nullptr) {
+                          void* ws_xd, int accumulate, int M, hipStream_t st, int dx_fresh = 0, const unsigned char* rowmask = nullptr,
+                          const unsigned char* bits = nullptr) {
     const int nr = n * r;
+    const long gstride = (long)M * in / 8;       // bytes between the packed keep masks of the group's targets (the forward drew them)
     size_t ofs[4] = {0, 0, 0, 0};
     bool same = true;
     for (int t = 0; t < n; ++t) { ofs[t + 1] = ofs[t] + (size_t)outs[t]; same = same && outs[t] == outs[0]; }
@@ -196,18 +206,20 @@ static int lora_group_bwd(int n, int r, int in, const int* outs, const void* x, 
     if (rowmask) CHECK(vlr_rows_mask(v, nr, nr, rowmask, M, st));      // PLoRA: no gradient flows through the adapter on the text rows
     if (p > 0.f) {
         // dA_t = s / (1 - p) v_t^T (mask_t . x): the n targets as groups, x masked while it is staged (the mask of the forward, regenerated)
-        CHECK(vlr_gemm_grouped(2, v, x, dA, r, in, M, nr, in, in, n, (long)r, 0L, (long)r * in, scale / (1.f - p), accumulate, 2, seed, p, in, st));
-        // dx (+)= s / (1 - p) sum_t mask_t . (v_t A_t).  One pass per target on the 128x128 GEMM kernel (its epilogue applies the mask in
-        // the coalesced copy-out); VLR_LORA_MULTI=1: ONE pass for the n targets (vlr_gemm_dropout_acc_multi) - measured NOT faster
-        // (4 x 220 us against 7 x 119 us per layer: with K = r the launch is two K steps per term, latency- not HBM-bound), so off
+        CHECK(vlr_gemm_grouped_bits(2, v, x, dA, r, in, M, nr, in, in, n, (long)r, 0L, (long)r * in, scale / (1.f - p), accumulate, 2, seed, p, in,
+                                    bits, gstride, st));
+        // dx (+)= s / (1 - p) sum_t mask_t . (v_t A_t): ONE pass over dx for the n targets (vlr_gemm_dropout_acc_multi: the streaming kernel
+        // of lora_dx.hip, 222 us for q, k, v at [12792 x 4096], r = 128, against 3 x 90 us one target at a time; tools/lora_gemm_bench.py).
+        // VLR_LORA_MULTI=0: one pass per target on the 128x128 GEMM kernel (mask in its epilogue)
         static int multi = -1;
-        if (multi < 0) { const char* e = getenv("VLR_LORA_MULTI"); multi = (e && e[0] == '1') ? 1 : 0; }
+        if (multi < 0) { const char* e = getenv("VLR_LORA_MULTI"); multi = (e && e[0] == '0') ? 0 : 1; }
         if (multi || dx_fresh) {
-            CHECK(vlr_gemm_dropout_acc_multi(n, v, nr, A, dx, M, in, r, p, seed, scale, dx_fresh ? 0 : 1, st));
+            CHECK(vlr_gemm_dropout_acc_multi_bits(n, v, nr, A, dx, M, in, r, p, seed, scale, dx_fresh ? 0 : 1, bits, gstride, st));
         } else {
             VLR_REQUIRE(ws_xd, "lora backward: lora_dropout > 0 needs a scratch buffer [M][in]");
             for (int t = 0; t < n; ++t)
-                CHECK(vlr_gemm_dropout_acc(off(v, (size_t)t * r), nr, off(A, (size_t)t * r * in), dx, ws_xd, M, in, r, p, seed + t, scale, st));
+                CHECK(vlr_gemm_dropout_acc_bits(off(v, (size_t)t * r), nr, off(A, (size_t)t * r * in), dx, ws_xd, M, in, r, p, seed + t, scale,
+                                                bits ? bits + (size_t)t * gstride : nullptr, st));
         }
     } else {
         CHECK(vlr_gemm_bf16_scaled(2, v, x, dA, nullptr, nullptr, nr, in, M, nr, in, in, 0, 0, accumulate, 0, scale, st));  // dA = s v^T x
@@ -216,6 +228,7 @@ static int lora_group_bwd(int n, int r, int in, const int* outs, const void* x, 
     return VLR_OK;
 }
 
+extern "C" long vlr_lora_mask_bytes(int hidden, int inter, int M) { return ((long)M * hidden / 8) * 6 + (long)M * inter / 8; }
 static int lora_check(const char* who, const vlr_lora_weights* lw, const void* ws_xd) {
     VLR_REQUIRE(lw->r > 0 && lw->r % 8 == 0, "%s: LoRA rank must be a positive multiple of 8, got %d", who, lw->r);
     VLR_REQUIRE(lw->dropout >= 0.f && lw->dropout < 1.f, "%s: lora_dropout must be in [0,1), got %g", who, (double)lw->dropout);
@@ -243,22 +256,23 @@ extern "C" int vlr_decoder_layer_fwd_lora_ex(const vlr_llama_cfg* cfg, const vlr
     VLR_REQUIRE(Nq == H, "vlr_decoder_layer_fwd_lora: heads*head_dim != hidden");
     const float sc = lw->scale, p = lw->dropout;
 #define XD(seg) (ws_xd)      // ABI v4: one scratch [M][max(hidden, inter)] (the fallback path of vlr_gemm_dropout_acc), not per-target copies
+#define MB(t) (lw->mask_bits && p > 0.f ? (unsigned char*)lw->mask_bits + (size_t)(t) * ((size_t)M * H / 8) : nullptr)      // packed keep mask of target t
     const int rf = cfg->resid_f32;
     CHECK(norm_fwd(rf, x_in, w->ln1, a->xn1, a->rstd1, M, H, cfg->rms_eps, st));
     const int nq = lw->qkv_targets == 1 ? 1 : 3;             // one adapter over the fused projection (Qwen c_attn) or q, k, v separately
-    CHECK(lora_group_a(nq, r, H, a->xn1, H, lw->a_qkv, u, ldu, sc, p, seed + 0, ws_xd, M, st, rowmask));
+    CHECK(lora_group_a(nq, r, H, a->xn1, H, lw->a_qkv, u, ldu, sc, p, seed + 0, ws_xd, M, st, rowmask, MB(0)));
     CHECK(vlr_gemm_qkv_rope_lora(a->xn1, w->wqkv, w->bqkv, a->qkv, pos, cfg->rope_cos, cfg->rope_sin, M, N, Nq + Nkv, H, H,
                                  cfg->head_dim, cfg->max_pos, u, ldu, lw->b_qkv, r, nq == 1 ? N : Nq, nq == 1 ? 0 : Nkv, st));
     CHECK(vlr_attn_fwd_gqa(a->qkv, off(a->qkv, Nq), off(a->qkv, (size_t)Nq + Nkv), N, a->attn, Nq, a->lse, key_mask, batch, S,
                            cfg->heads, kvh, cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));
-    CHECK(lora_group_a(1, r, H, a->attn, H, lw->a_o, off(u, 3 * (size_t)r), ldu, sc, p, seed + 3, XD(3), M, st, rowmask));
+    CHECK(lora_group_a(1, r, H, a->attn, H, lw->a_o, off(u, 3 * (size_t)r), ldu, sc, p, seed + 3, XD(3), M, st, rowmask, MB(3)));
     if (rf) CHECK(vlr_gemm_lora_f32res(a->attn, H, w->wo, (float*)a->x_mid, H, (const float*)x_in, H, M, H, H, off(u, 3 * (size_t)r), ldu, lw->b_o, r, st));
     else CHECK(vlr_gemm_lora(a->attn, H, w->wo, a->x_mid, H, x_in, H, M, H, H, off(u, 3 * (size_t)r), ldu, lw->b_o, r, st));
     CHECK(norm_fwd(rf, a->x_mid, w->ln2, a->xn2, a->rstd2, M, H, cfg->rms_eps, st));
-    CHECK(lora_group_a(2, r, H, a->xn2, H, lw->a_gu, off(u, 4 * (size_t)r), ldu, sc, p, seed + 4, XD(4), M, st, rowmask));
+    CHECK(lora_group_a(2, r, H, a->xn2, H, lw->a_gu, off(u, 4 * (size_t)r), ldu, sc, p, seed + 4, XD(4), M, st, rowmask, MB(4)));
     CHECK(vlr_gemm_swiglu_lora(a->xn2, w->wgu, a->gu, a->act, M, I, H, H, off(u, 4 * (size_t)r), ldu, lw->b_gu, r, st));
     if (lw->a_down) {
-        CHECK(lora_group_a(1, r, I, a->act, I, lw->a_down, off(u, 6 * (size_t)r), ldu, sc, p, seed + 6, XD(6), M, st, rowmask));
+        CHECK(lora_group_a(1, r, I, a->act, I, lw->a_down, off(u, 6 * (size_t)r), ldu, sc, p, seed + 6, XD(6), M, st, rowmask, MB(6)));
         if (rf) CHECK(vlr_gemm_lora_f32res(a->act, I, w->wdown, (float*)a->x_out, H, (const float*)a->x_mid, H, M, H, I, off(u, 6 * (size_t)r), ldu, lw->b_down, r, st));
         else CHECK(vlr_gemm_lora(a->act, I, w->wdown, a->x_out, H, a->x_mid, H, M, H, I, off(u, 6 * (size_t)r), ldu, lw->b_down, r, st));
     } else {
@@ -291,6 +305,7 @@ extern "C" int vlr_decoder_layer_bwd_lora_ex(const vlr_llama_cfg* cfg, const vlr
     const int o_qkv[3] = {Nq, Nkv, Nkv}, o_h[1] = {H}, o_gu[2] = {I, I};
     const float sc = lw->scale, p = lw->dropout;
 #define XD(seg) (ws_xd)      // ABI v4: one scratch [M][max(hidden, inter)] (the fallback path of vlr_gemm_dropout_acc), not per-target copies
+#define MB(t) (lw->mask_bits && p > 0.f ? (unsigned char*)lw->mask_bits + (size_t)(t) * ((size_t)M * H / 8) : nullptr)      // packed keep mask of target t
     // ---- MLP
     if (g) CHECK(vlr_gemm_bf16(2, dx_out, a->act, g->wdown, nullptr, nullptr, H, I, M, H, I, I, 0, 0, accumulate, 0, st));
     static int fuse_down = -1;     // VLR_LORA_FUSE_DOWN=1: adapter term of down_proj first, then the dgrad GEMM with the SwiGLU backward in its epilogue
@@ -299,12 +314,12 @@ extern "C" int vlr_decoder_layer_bwd_lora_ex(const vlr_llama_cfg* cfg, const vlr
         // measured SLOWER than the three separate kernels (38.8 ms against 25.5 + 7.7 per step: the addend is a third 16-byte load stream
         // in an epilogue that already reads gate | up) - kept behind the switch
         CHECK(lora_group_bwd(1, r, I, o_h, a->act, dx_out, H, lw->a_down, lw->b_down, lg->a_down, lg->b_down, off(u, 6 * (size_t)r), ldu, ws_v,
-                             ws->dact, sc, p, seed + 6, XD(6), accumulate, M, st, 1, rowmask));
+                             ws->dact, sc, p, seed + 6, XD(6), accumulate, M, st, 1, rowmask, MB(6)));
         CHECK(vlr_gemm_swiglu_bwd_add(dx_out, w->wdown, a->gu, ws->dact, ws->dact, M, I, H, st));   // gu now holds [dgate | dup]
     } else if (lw->a_down) {
         CHECK(vlr_gemm_bf16(1, dx_out, w->wdown, ws->dact, nullptr, nullptr, M, I, H, H, I, I, 0, 0, 0, 0, st));
         CHECK(lora_group_bwd(1, r, I, o_h, a->act, dx_out, H, lw->a_down, lw->b_down, lg->a_down, lg->b_down, off(u, 6 * (size_t)r), ldu, ws_v,
-                             ws->dact, sc, p, seed + 6, XD(6), accumulate, M, st, 0, rowmask));
+                             ws->dact, sc, p, seed + 6, XD(6), accumulate, M, st, 0, rowmask, MB(6)));
         CHECK(vlr_swiglu_bwd(a->gu, ws->dact, M, I, st));   // gu now holds [dgate | dup]
     } else {
         CHECK(vlr_gemm_swiglu_bwd(dx_out, w->wdown, a->gu, ws->dact, M, I, H, st));
@@ -312,13 +327,13 @@ extern "C" int vlr_decoder_layer_bwd_lora_ex(const vlr_llama_cfg* cfg, const vlr
     if (g) CHECK(vlr_gemm_bf16(2, a->gu, a->xn2, g->wgu, nullptr, nullptr, 2 * I, H, M, 2 * I, H, H, 0, 0, accumulate, 0, st));
     CHECK(vlr_gemm_bf16(1, a->gu, w->wgu, ws->dxn, nullptr, nullptr, M, H, 2 * I, 2 * I, H, H, 0, 0, 0, 0, st));
     CHECK(lora_group_bwd(2, r, H, o_gu, a->xn2, a->gu, 2 * I, lw->a_gu, lw->b_gu, lg->a_gu, lg->b_gu, off(u, 4 * (size_t)r), ldu, ws_v,
-                         ws->dxn, sc, p, seed + 4, XD(4), accumulate, M, st, 0, rowmask));
+                         ws->dxn, sc, p, seed + 4, XD(4), accumulate, M, st, 0, rowmask, MB(4)));
     CHECK(norm_bwd(cfg->resid_f32, ws->dxn, a->x_mid, w->ln2, a->rstd2, dx_out, ws->dx_mid, g ? g->ln2 : nullptr, g ? accumulate : 0, ws->norm_ws, M, H, st));
     // ---- attention
     if (g) CHECK(vlr_gemm_bf16(2, ws->dx_mid, a->attn, g->wo, nullptr, nullptr, H, Nq, M, H, Nq, Nq, 0, 0, accumulate, 0, st));
     CHECK(vlr_gemm_bf16(1, ws->dx_mid, w->wo, ws->dattn, nullptr, nullptr, M, H, H, H, H, H, 0, 0, 0, 0, st));
     CHECK(lora_group_bwd(1, r, H, o_h, a->attn, ws->dx_mid, H, lw->a_o, lw->b_o, lg->a_o, lg->b_o, off(u, 3 * (size_t)r), ldu, ws_v,
-                         ws->dattn, sc, p, seed + 3, XD(3), accumulate, M, st, 0, rowmask));
+                         ws->dattn, sc, p, seed + 3, XD(3), accumulate, M, st, 0, rowmask, MB(3)));
     CHECK(vlr_attn_bwd_gqa(a->qkv, off(a->qkv, Nq), off(a->qkv, (size_t)Nq + Nkv), N, a->attn, ws->dattn, Nq, a->lse, ws->delta,
                            key_mask, ws->dqkv, off(ws->dqkv, Nq), off(ws->dqkv, (size_t)Nq + Nkv), N, batch, S, cfg->heads, kvh,
                            cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));
@@ -328,7 +343,7 @@ extern "C" int vlr_decoder_layer_bwd_lora_ex(const vlr_llama_cfg* cfg, const vlr
     const int o_all[1] = {N};
     const int nq = lw->qkv_targets == 1 ? 1 : 3;
     CHECK(lora_group_bwd(nq, r, H, nq == 1 ? o_all : o_qkv, a->xn1, ws->dqkv, N, lw->a_qkv, lw->b_qkv, lg->a_qkv, lg->b_qkv, u, ldu, ws_v, ws->dxn,
-                         sc, p, seed + 0, ws_xd, accumulate, M, st, 0, rowmask));
+                         sc, p, seed + 0, ws_xd, accumulate, M, st, 0, rowmask, MB(0)));
     CHECK(norm_bwd(cfg->resid_f32, ws->dxn, x_in, w->ln1, a->rstd1, ws->dx_mid, dx_in, g ? g->ln1 : nullptr, g ? accumulate : 0, ws->norm_ws, M, H, st));
     return VLR_OK;
 }

@@ -1,0 +1,297 @@
+// LoRA input-gradient term of the targets that share one input, streamed:  dx [M][in] (+)= alpha * sum_t keep_t . (v_t [M][r] . A_t [r][in])
+// (q, k, v -> d xn1; gate, up -> d xn2; o -> d attn; down -> d act;  keep_t = the lora_dropout mask of target t, alpha = scaling / (1 - p)).
+//
+// The reduction is the adapter rank (r = 64..256): the launch is ONE read-modify-write pass over dx with a few MFMAs per element - HBM
+// bound (210 MB at [12792 x 4096]: 27 us at 8 TB/s).  gemm.hip ran it as a 128x128-tile GEMM with the mask in the epilogue: a workgroup
+// per tile, its loads - MFMAs - read C - write C chain exposed end to end (85-120 us per target and pass, tools/lora_gemm_bench.py).
+// Here a workgroup owns 64 ROWS and walks a range of 128-column tiles:
+//   * its v rows live in REGISTERS for the whole walk, already in MFMA fragment form (NT targets x 2 row tiles x r/32 k slices);
+//   * the [r][128] slices of A_t (L2 resident: A_t is 1-3 MB) stream through a double-buffered LDS stage by global_load_lds, one
+//     (column tile, target) unit ahead of the MFMAs; the dx tile and the packed keep masks of the next unit are prefetched into
+//     registers the same way.  Every unit starts with s_waitcnt vmcnt(0) + one barrier - no counted waits (this wave's stores of the
+//     previous tile are in the same queue and stores retire out of order with loads);
+//   * per unit 16 x r/32 v_mfma_f32_16x16x32_bf16 per wave (4 waves = 2 x 2, wave tile 32 x 64); the mask is applied to the fp32
+//     accumulators (a lane holds 4 consecutive columns of a row: one nibble of the packed mask, or one hash), the targets are summed in
+//     registers and the bf16 tile is read / written once, 8 bytes per lane.
+// Grid = (row blocks, column splits): ~2 workgroups per CU, 2-4 resident per CU (LDS 2 x r/64 x 16 KiB), so one workgroup's wait is
+// another one's MFMAs.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "gemm.h"
+
+typedef __attribute__((address_space(3))) void dx_lvoid_t;
+typedef __attribute__((ext_vector_type(4))) short dx_s16x4_t;
+typedef __attribute__((address_space(3))) dx_s16x4_t dx_lds_s16x4_t;
+
+struct LoraDxParams {
+    const bf16_t* v; int ldv;
+    const bf16_t* A;             // [NT * r][in]
+    bf16_t* dx;
+    int M, in, r;
+    float alpha;
+    int accumulate;
+    const unsigned char* bits;   // packed keep masks (target t at bits + t * gbits) or null: hash (key of target t = mix64(seed + t))
+    long gbits;
+    uint64_t seed;
+    uint32_t thr;
+    int ct_per_wg;               // column tiles per workgroup (blockIdx.y walks the ranges)
+};
+
+__device__ __forceinline__ void dx_dma16_s(const char* sbase, uint32_t voff, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+}
+// K-strided operand tile [64 k][256 B] (gemm256p.hip / gemm128p.hip image): fragment of 16 columns x 32 k
+__device__ __forceinline__ bf16x8 dx_frag_ks(const char* tile, int cbase, int s, int lane) {
+    const int g = lane >> 4, pq = lane & 15;
+    const int krow = s * 32 + g * 8 + (pq >> 2);
+    const int col = cbase + (pq & 3) * 4;
+    const int swz = ((krow & 3) << 2) | (((krow >> 3) & 1) << 1);
+    const int off = krow * 256 + (((col >> 3) ^ swz) << 4) + ((col >> 2) & 1) * 8;
+    const dx_s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dx_lds_s16x4_t*)(tile + off));
+    const dx_s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dx_lds_s16x4_t*)(tile + off + 4 * 256));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+// NT targets, KT = r / 64 K tiles per target, MASK: 0 no dropout, 1 keep masks (packed bits when p.bits, else hashed)
+template <int NT, int KT, int MASK>
+__global__ __launch_bounds__(256) void lora_dx_kernel(LoraDxParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // 2 units x KT x 16 KiB
+    constexpr int KS = 2 * KT;                                        // k slices of 32 per target
+    constexpr int UNIT_BYTES = KT * 16384;
+    const int t_ = threadIdx.x;
+    const int lane = t_ & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t_ >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int lm = lane & 15, lq = lane >> 4;
+    const int m0 = blockIdx.x * 64;
+    const int tiles_n = p.in >> 7;
+    const int c_lo = blockIdx.y * p.ct_per_wg;
+    const int c_hi = min(tiles_n, c_lo + p.ct_per_wg);
+    if (c_lo >= c_hi) return;
+    const int nunits = (c_hi - c_lo) * NT;
+
+    // ---- v rows of this wave as MFMA fragments (lane: row lm of the 16-row tile, k (lane >> 4) * 8 .. + 8 of the slice)
+    bf16x8 vf[NT][2][KS];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int row = m0 + wr * 32 + i * 16 + lm;
+            row = row < p.M ? row : p.M - 1;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                vf[t][i][ks] = *reinterpret_cast<const bf16x8*>(p.v + (size_t)row * p.ldv + t * p.r + ks * 32 + lq * 8);
+        }
+    // ---- DMA of one unit = the [r][128] slice of A_t: KT tiles of [64 k][256 B], 4 wave instructions per tile and wave
+    uint32_t offB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r_ = (wave + 4 * i) * 4 + (lane >> 4);
+        const int chunk = (lane & 15) ^ (((r_ & 3) << 2) | (((r_ >> 3) & 1) << 1));
+        offB[i] = (uint32_t)(((size_t)r_ * p.in + chunk * 8) * 2);
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(dx_lvoid_t*)smem + wave * 1024;
+    auto stage_unit = [&](int u) {            // u = (c - c_lo) * NT + t
+        const int c = c_lo + u / NT, t = u % NT;
+        const uint32_t l = lds0 + (u & 1) * UNIT_BYTES;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            const char* b = reinterpret_cast<const char*>(p.A + ((size_t)(t * p.r + kt * 64)) * p.in + c * 128);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dx_dma16_s(b, offB[i], l + kt * 16384 + i * 4096);
+        }
+    };
+    // rows / first column of this lane's 2 x 4 accumulator tiles
+    int rowv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) rowv[i] = m0 + wr * 32 + i * 16 + lm;
+    const int cl = wc * 64 + 4 * lq;           // + j * 16 inside the column tile
+    // prefetched per-unit / per-tile registers
+    u32x2 dxr[2][4];                           // the dx tile of the CURRENT column tile (accumulate)
+    uint32_t kb[2][4];                         // keep nibbles of the CURRENT unit
+    auto load_dx = [&](int c, u32x2 (&d)[2][4]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                u32x2 w = {0u, 0u};
+                if (rowv[i] < p.M) w = *reinterpret_cast<const u32x2*>(p.dx + (size_t)rowv[i] * p.in + c * 128 + cl + j * 16);
+                d[i][j] = w;
+            }
+    };
+    auto load_keep = [&](int u, uint32_t (&k)[2][4]) {
+        if constexpr (MASK) {
+            const int c = c_lo + u / NT, t = u % NT;
+            if (p.bits) {
+                const unsigned char* bt = p.bits + (size_t)t * p.gbits;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int row = rowv[i] < p.M ? rowv[i] : p.M - 1;
+                        k[i][j] = bt[((size_t)row * p.in + c * 128 + cl + j * 16) >> 3];        // (the nibble is picked when it is used)
+                    }
+            } else {
+                const uint64_t key = vlr_mix64(p.seed + (uint64_t)t);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const long idx = (long)rowv[i] * p.in + c * 128 + cl + j * 16;
+                        const uint64_t rr = vlr_mix64(key ^ (uint64_t)(2 * (idx >> 3) + ((idx >> 2) & 1)));
+                        uint32_t keep = 0;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) keep |= (uint32_t)(((rr >> (16 * e)) & 0xffffu) >= p.thr) << e;
+                        k[i][j] = keep << (cl & 4);       // same position as the packed byte's nibble
+                    }
+            }
+        }
+    };
+
+    f32x4 sum[2][4];
+    stage_unit(0);
+    if (p.accumulate) load_dx(c_lo, dxr);
+    load_keep(0, kb);
+    for (int u = 0; u < nunits; ++u) {
+        const int c = c_lo + u / NT, t = u % NT;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (u + 1 < nunits) stage_unit(u + 1);
+        // prefetch for the next unit / the next column tile (used after the next vmcnt(0))
+        uint32_t kb_n[2][4];
+        u32x2 dx_n[2][4];
+        const bool last_t = t == NT - 1;
+        if (u + 1 < nunits) {
+            load_keep(u + 1, kb_n);
+            if (last_t && p.accumulate) load_dx(c + 1, dx_n);
+        }
+        if (t == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sum[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const char* tile = smem + (u & 1) * UNIT_BYTES;
+        // (static dispatch on the target: the v fragments are a register array)
+        auto run = [&](auto tc) {
+            constexpr int T = decltype(tc)::value;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8 fb[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[j] = dx_frag_ks(tile + (ks >> 1) * 16384, wc * 64 + j * 16, ks & 1, lane);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], vf[T][i][ks], acc[i][j], 0, 0, 0);
+            }
+        };
+        if constexpr (NT == 1) run(std::integral_constant<int, 0>{});
+        else if constexpr (NT == 2) { if (t == 0) run(std::integral_constant<int, 0>{}); else run(std::integral_constant<int, 1>{}); }
+        else { if (t == 0) run(std::integral_constant<int, 0>{}); else if (t == 1) run(std::integral_constant<int, 1>{}); else run(std::integral_constant<int, 2>{}); }
+        // mask + sum over the targets
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (MASK) {
+                    const uint32_t keep = kb[i][j] >> (cl & 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sum[i][j][e] += ((keep >> e) & 1) ? p.alpha * acc[i][j][e] : 0.f;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sum[i][j][e] += p.alpha * acc[i][j][e];
+                }
+            }
+        if (last_t) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 o = sum[i][j];
+                    if (p.accumulate) {
+                        const u32x2 w = dxr[i][j];
+                        o[0] += bf16lo(w[0]); o[1] += bf16hi(w[0]); o[2] += bf16lo(w[1]); o[3] += bf16hi(w[1]);
+                    }
+                    u32x2 w;
+                    w[0] = pack_bf16(o[0], o[1]);
+                    w[1] = pack_bf16(o[2], o[3]);
+                    if (rowv[i] < p.M) *reinterpret_cast<u32x2*>(p.dx + (size_t)rowv[i] * p.in + c * 128 + cl + j * 16) = w;
+                }
+        }
+        if (u + 1 < nunits) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    kb[i][j] = kb_n[i][j];
+                    if (last_t && p.accumulate) dxr[i][j] = dx_n[i][j];
+                }
+        }
+    }
+}
+
+template <int NT, int KT>
+static void dx_launch_m(const LoraDxParams& p, int mask, dim3 grid, hipStream_t stream) {
+    const int lds = 2 * KT * 16384;
+    if (mask) {
+        static bool a1 = false;
+        if (!a1) { hipFuncSetAttribute((const void*)lora_dx_kernel<NT, KT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); a1 = true; }
+        hipLaunchKernelGGL((lora_dx_kernel<NT, KT, 1>), grid, dim3(256), lds, stream, p);
+    } else {
+        static bool a0 = false;
+        if (!a0) { hipFuncSetAttribute((const void*)lora_dx_kernel<NT, KT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); a0 = true; }
+        hipLaunchKernelGGL((lora_dx_kernel<NT, KT, 0>), grid, dim3(256), lds, stream, p);
+    }
+}
+template <int NT>
+static bool dx_launch_k(const LoraDxParams& p, int mask, dim3 grid, hipStream_t stream) {
+    switch (p.r) {
+        case 64: dx_launch_m<NT, 1>(p, mask, grid, stream); return true;
+        case 128: dx_launch_m<NT, 2>(p, mask, grid, stream); return true;
+        case 256:
+            if constexpr (NT <= 2) { dx_launch_m<NT, 4>(p, mask, grid, stream); return true; }      // (3 x 2 x 8 v fragments do not fit the register file)
+            return false;
+        default: return false;
+    }
+}
+
+// dx (+)= scale / (1 - p) * sum_t keep_t . (v_t A_t) on the streaming kernel; false: a shape it does not take (the caller runs the
+// tile kernels of gemm.hip): n <= 3 targets, r in {64, 128, 256}, in % 128 == 0, 16-byte aligned operands.  VLR_LORA_DX=0 disables.
+bool vlr_lora_dx_try_launch(int n, const void* v, int ldv, const void* A, void* dx, int M, int in, int r, float p_drop, uint64_t seed,
+                            float scale, int accumulate, const void* bits, long bits_gstride, hipStream_t stream) {
+    static int on = -1, wg_per_cu = 2;
+    if (on < 0) {
+        const char* e = getenv("VLR_LORA_DX");
+        on = (e && e[0] == '0') ? 0 : 1;
+        const char* w = getenv("VLR_LORA_DX_WGS");
+        if (w && atoi(w) >= 1 && atoi(w) <= 8) wg_per_cu = atoi(w);
+    }
+    if (!on || n < 1 || n > 3 || in % 128 != 0 || (r != 64 && r != 128 && r != 256) || ldv % 8 != 0 || M < 1) return false;
+    if (((uintptr_t)v | (uintptr_t)A | (uintptr_t)dx) & 15) return false;
+    LoraDxParams q;
+    q.v = (const bf16_t*)v; q.ldv = ldv; q.A = (const bf16_t*)A; q.dx = (bf16_t*)dx; q.M = M; q.in = in; q.r = r;
+    q.alpha = scale / (1.f - p_drop); q.accumulate = accumulate;
+    q.bits = (const unsigned char*)bits; q.gbits = bits_gstride; q.seed = seed; q.thr = vlr_dropout_thr(p_drop);
+    const int rb = (M + 63) / 64, tiles_n = in / 128;
+    int splits = (wg_per_cu * vlr_compute_cus() + rb - 1) / rb;
+    if (splits < 1) splits = 1;
+    if (splits > tiles_n) splits = tiles_n;
+    q.ct_per_wg = (tiles_n + splits - 1) / splits;
+    splits = (tiles_n + q.ct_per_wg - 1) / q.ct_per_wg;
+    const dim3 grid(rb, splits);
+    const int mask = p_drop > 0.f ? 1 : 0;
+    if (n == 1) return dx_launch_k<1>(q, mask, grid, stream);
+    if (n == 2) return dx_launch_k<2>(q, mask, grid, stream);
+    return dx_launch_k<3>(q, mask, grid, stream);
+}

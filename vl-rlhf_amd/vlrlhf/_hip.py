@@ -35,7 +35,7 @@ class LayerBwdWs(C.Structure):
 
 
 class LoraWeights(C.Structure):
-    _fields_ = [("r", I), ("scale", F), ("dropout", F)] + [(n, P) for n in ("a_qkv", "b_qkv", "a_o", "b_o", "a_gu", "b_gu", "a_down", "b_down")] + [("qkv_targets", I)]
+    _fields_ = [("r", I), ("scale", F), ("dropout", F)] + [(n, P) for n in ("a_qkv", "b_qkv", "a_o", "b_o", "a_gu", "b_gu", "a_down", "b_down")] + [("qkv_targets", I), ("mask_bits", P)]
 
 
 class LoraGrads(C.Structure):
@@ -111,6 +111,9 @@ _SIGS = {
     "vlr_gemm_dropout_acc": [P, I, P, P, P, I, I, I, F, U64, F, P],
     "vlr_gemm_grouped": [I, P, P, P, I, I, I, I, I, I, I, L, L, L, F, I, I, U64, F, I, P],
     "vlr_gemm_dropout_acc_multi": [I, P, I, P, P, I, I, I, F, U64, F, I, P],
+    "vlr_gemm_grouped_bits": [I, P, P, P, I, I, I, I, I, I, I, L, L, L, F, I, I, U64, F, I, P, L, P],
+    "vlr_gemm_dropout_acc_bits": [P, I, P, P, P, I, I, I, F, U64, F, P, P],
+    "vlr_gemm_dropout_acc_multi_bits": [I, P, I, P, P, I, I, I, F, U64, F, I, P, L, P],
     "vlr_gemm_swiglu_bwd_add": [P, P, P, P, P, I, I, I, P],
     "vlr_gemm_swiglu_lora": [P, P, P, P, I, I, I, I, P, I, P, I, P],
     "vlr_gemm_qkv_rope_lora": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P, I, P, I, I, I, P],
@@ -123,6 +126,7 @@ _SIGS = {
     "vlr_rows_mask": [P, I, I, P, I, P],
     "vlr_dropout": [P, P, L, F, U64, F, I, P],
     "vlr_dropout_mask": [P, L, F, U64, P],
+    "vlr_dropout_bits": [P, L, F, U64, P],
     "vlr_layers_join": [P],
     "vlr_allreduce_bucket": [P, P, L, I, P],
     "vlr_comm_probe": [P, P, L, I, P],
@@ -165,6 +169,8 @@ def lib():
         l.vlr_comm_library.argtypes = []
         l.vlr_lmhead_workspace_bytes.restype = C.c_long
         l.vlr_lmhead_workspace_bytes.argtypes = [I, I]
+        l.vlr_lora_mask_bytes.restype = C.c_long
+        l.vlr_lora_mask_bytes.argtypes = [I, I, I]
         for name, sig in _SIGS.items():
             fn = getattr(l, name)
             fn.restype = I
@@ -178,7 +184,7 @@ def lib():
 
 
 def exported_symbols():
-    return list(_SIGS) + list(_INT_HELPERS) + ["vlr_last_error", "vlr_comm_library", "vlr_lmhead_workspace_bytes"]
+    return list(_SIGS) + list(_INT_HELPERS) + ["vlr_last_error", "vlr_comm_library", "vlr_lmhead_workspace_bytes", "vlr_lora_mask_bytes"]
 
 
 def ptr(t):
