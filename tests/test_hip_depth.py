@@ -81,7 +81,9 @@ def _compare(got, probe, g, label, loss_cap=None):
     """HIP vs the fp32 oracle, judged against the oracle's own model of the path's bf16 rounding (FLOOR: bf16 MFMA operands + the vision
     tower, fp32 residual stream - no bf16-MFMA pipeline rounds less).  The DPO loss of these random-weight models is beta / 2 times a
     difference of four log-prob sums of -85 ... -1415, so what is asserted tightly is the per-sequence log-prob error (max and rms, at most
-    1.3 x the floor's); the loss bound follows from it: sigma_loss = beta / 2 * 2 * rms_floor / sqrt(pairs), asserted at 1.5 sigma (and at
+    1.3 x the floor's); the loss bound follows from it: sigma_loss = beta / 2 * 2 * rms_floor / sqrt(pairs) (slope 1/2 of -logsigmoid at a zero logit; up to 2x that for the
+    random-weight logits of these fixtures), asserted at 3 sigma - five builds of this round landed at 0.2, 2.0, 1.2, 0.3 and 2.1 sigma with the
+    SAME log-prob errors: the loss is a sample of that distribution, the log-prob bounds above are the parity statement (and at
     the fixed cap where one is given)."""
     f32 = g["results"]["fp32"]
     floor = g["results"].get(FLOOR) or g["results"]["bf16_emulated"]
@@ -99,12 +101,12 @@ def _compare(got, probe, g, label, loss_cap=None):
     l_f32, lf_f32 = abs(got["loss"] - f32["loss"]), abs(floor["loss"] - f32["loss"])
     sigma = g["beta"] / 2 * 2 * frms / math.sqrt(g["spec"]["pairs"])
     print(f"[depth {label}] loss HIP {got['loss']:.6f} fp32 {f32['loss']:.6f} floor model {floor['loss']:.6f} | |HIP-fp32| {l_f32:.2e} "
-          f"|floor-fp32| {lf_f32:.2e} (1.5 sigma {1.5 * sigma:.2e}) | d logp HIP-fp32 max {mx:.3f} rms {rms:.3f} floor-fp32 max {fmx:.3f} rms {frms:.3f} | "
+          f"|floor-fp32| {lf_f32:.2e} (3 sigma {3 * sigma:.2e}) | d logp HIP-fp32 max {mx:.3f} rms {rms:.3f} floor-fp32 max {fmx:.3f} rms {frms:.3f} | "
           f"worst layer residual rel err {worst:.4f}")
     assert math.isfinite(got["loss"])
     assert mx <= 1.3 * fmx + 0.02, (mx, fmx)
     assert rms <= 1.3 * frms + 0.01, (rms, frms)
-    assert l_f32 <= 1.5 * sigma, (l_f32, sigma)
+    assert l_f32 <= 3 * sigma, (l_f32, sigma)
     if loss_cap is not None:
         assert l_f32 <= loss_cap, (l_f32, loss_cap)
     return dict(loss=got["loss"], d_loss_fp32=l_f32, d_logp_max=mx, d_logp_rms=rms, worst_layer_rel=worst)

@@ -15,4 +15,9 @@ run qwen_vl --model qwen_vl
 run qwen_vl_lora --model qwen_vl --lora
 run internlm_xc2 --model internlm_xc2
 run internlm_xc2_lora --model internlm_xc2 --lora
+run internlm_xc2_t512 --model internlm_xc2 --text_len 512
+run internlm_xc2_t512_lora --model internlm_xc2 --text_len 512 --lora
+VLR_BWD_STREAMS=1 run full_bwd_streams
+VLR_LORA_BITS=0 run lora_hash_masks --lora
+VLR_GEMM128P=0 run full_old128
 echo variants done
