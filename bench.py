@@ -357,7 +357,8 @@ def main():
                        "global_batch_pairs": world * a.pairs, "text_len": a.text_len, "parallelism": f"dp{world}",
                        "layers": cfg["layers"], "lr": a.lr, "resident_batches": len(batches), "loss_first_step": loss_first,
                        "loss_last_step": loss_last, "grad_norm_last_step": float(eng.norm_out[0]),
-                       "residual_stream": "fp32" if eng.resid_f32 else "bf16", "gradient_checkpointing": bool(eng.gradient_checkpointing)},
+                       "residual_stream": "fp32" if eng.resid_f32 else "bf16", "gradient_checkpointing": bool(eng.gradient_checkpointing),
+                       "peak_allocated_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},      # every device buffer of the path is a torch allocation
             "rccl_ranks": dist.get_world_size() if world > 1 else 1,
             "comm": {"transport": reducer.transport if reducer is not None else None,
                      "library": (reducer.transport_note if reducer is not None and reducer.transport == "native" else
