@@ -140,7 +140,14 @@ def make_batch(cfg, seed):
     rows = []
     for i in range(n):
         prompt = [1] + rnd(2) + [cfg["image_token"]] + rnd(cfg["prompt_len"][0] + 3 * i)
-        rows.append(dict(prompt=prompt, chosen=rnd(cfg["resp_len"][0] + 4 * i) + [2], rejected=rnd(cfg["resp_len"][1] - 5 * i) + [2]))
+        # chosen and rejected SHARE spans of >= 3 tokens (a common opening, and for the second pair a common middle), as real preference
+        # pairs do: the DDPO mask (trainer.py:161-184, min_match_size 3) then removes them and `ddpo` differs from `sigmoid`
+        lc, lr = cfg["resp_len"][0] + 4 * i, cfg["resp_len"][1] - 5 * i
+        head, mid = rnd(3), rnd(3) if i else []
+        k = len(head) + len(mid)
+        chosen = head + rnd((lc - k) // 2) + mid + rnd(lc - k - (lc - k) // 2)
+        rejected = head + rnd((lr - k) // 2) + mid + rnd(lr - k - (lr - k) // 2)
+        rows.append(dict(prompt=prompt, chosen=chosen + [2], rejected=rejected + [2]))
     batch = {}
     pad = cfg["model_pad_token_id"]
     for side in ("chosen", "rejected"):

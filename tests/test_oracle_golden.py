@@ -364,6 +364,8 @@ def test_internlm_oracle_matches_reference_golden():
         assert torch.allclose(torch.cat([rc, rr]), t(z, f"{lt}.ref_logps"), rtol=1e-4, atol=2e-3)
         losses, _, _ = O.dpo_loss(pc, pr, rc, rr, cfg["beta"], 0.0, lt, False)
         assert torch.allclose(losses, t(z, f"{lt}.losses"), rtol=2e-3, atol=2e-4)
+    # the fixture is discriminating for DDPO: chosen / rejected share >= 3-token spans, the masked log-probs lose them
+    assert float((t(z, "ddpo.logps") - t(z, "sigmoid.logps")).abs().min()) > 5.0 and abs(float(z["ddpo.loss"]) - float(z["sigmoid.loss"])) > 1e-4
     lp = O.get_batch_logps(logits, labels)
     rl = t(z, "sigmoid.ref_logps")
     losses, _, _ = O.dpo_loss(lp[:n], lp[n:], rl[:n], rl[n:], cfg["beta"], 0.0, "sigmoid", False)
