@@ -1472,7 +1472,13 @@ def test_dropout_bits_and_masked_gemms_with_bits(hip, M, in_, r, n, p):
     hip.call("vlr_gemm_grouped", 0, x, A, u0, M, r, in_, in_, in_, ldu, n, 0, r * in_, r, alpha, 0, 1, seed, p, in_)
     hip.call("vlr_gemm_grouped_bits", 0, x, A, u1, M, r, in_, in_, in_, ldu, n, 0, r * in_, r, alpha, 0, 1, seed, p, in_, bits, gstride)
     torch.cuda.synchronize()
-    assert torch.equal(u0, u1), "masked NT (u = drop(x) A^T)"
+    # (the packed-mask form runs on the LDS-DMA ring kernel, the hashing form on the register-staged one: same mask, another summation order)
+    for t in range(n):
+        mk = ((bits[t * gstride:(t + 1) * gstride].view(-1, 1) >> torch.arange(8, device=DEV, dtype=torch.uint8)) & 1).reshape(M, in_).float()
+        ref = alpha * (x.float() * mk) @ A[t * r:(t + 1) * r].float().t()
+        check(u1[:, t * r:(t + 1) * r], ref, 8e-3, f"masked NT with packed masks, target {t}")
+        check(u0[:, t * r:(t + 1) * r], ref, 8e-3, f"masked NT hashing, target {t}")
+    assert float((u0.float() - u1.float()).abs().max()) <= 0.02 * float(u0.float().abs().max())
     v = rnd(M, n * r, seed=3, scale=0.5)
     d0, d1 = torch.zeros(n * r, in_, dtype=torch.bfloat16, device=DEV), torch.zeros(n * r, in_, dtype=torch.bfloat16, device=DEV)
     hip.call("vlr_gemm_grouped", 2, v, x, d0, r, in_, M, n * r, in_, in_, n, r, 0, r * in_, alpha, 0, 2, seed, p, in_)

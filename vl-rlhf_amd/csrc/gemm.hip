@@ -525,14 +525,15 @@ static int gemm_grouped(int layout, const void* A, const void* B, void* C, int M
         if (!ws || splits < 2) splits = 1;
     }
     if (splits > 1) {
-        const int kchunk = (((K + splits - 1) / splits) + 31) / 32 * 32;
+        const int kchunk = (((K + splits - 1) / splits) + 63) / 64 * 64;      // whole K tiles per slice (the ring kernel masks whole tiles)
         splits = (K + kchunk - 1) / kchunk;
         p.splitk = splits; p.kchunk = kchunk; p.part = ws;
     }
     const dim3 grid(tiles, splits, groups);
     const int pi = vlr_prof_begin(layout, 2.0 * M * N * K * groups, stream);
-    if (mask_on && layout == 0) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, 1>), grid, dim3(256), 0, stream, p);
-    else if (mask_on) hipLaunchKernelGGL((gemm_bf16_kernel<true, true, 2>), grid, dim3(256), 0, stream, p);
+    if (mask_on && layout == 0) {       // packed masks: the LDS-DMA ring kernel masks the fragments; else staged through registers
+        if (!vlr_gemm128p_try_launch(layout, p, grid, stream)) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, 1>), grid, dim3(256), 0, stream, p);
+    } else if (mask_on) hipLaunchKernelGGL((gemm_bf16_kernel<true, true, 2>), grid, dim3(256), 0, stream, p);
     else launch128(layout, p, grid, stream);
     if (splits > 1) {
         const long n4 = (long)M * N / 4;

@@ -42,6 +42,10 @@ __device__ __forceinline__ void q_dma16(const void* g, uint32_t lds_addr) {
 __device__ __forceinline__ void q_dma16_s(const char* sbase, uint32_t voff, uint32_t lds_addr) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
 }
+// 64 lanes x 4 B -> LDS [m0 + lane * 4]
+__device__ __forceinline__ void q_dma4(const void* g, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(lds_addr) : "memory", "m0");
+}
 #define Q_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
 // fragment of v_mfma_f32_16x16x32_bf16 (16 rows x 32 k of slice s; lane l: row l & 15, k (l >> 4) * 8 .. + 8)
@@ -61,8 +65,13 @@ __device__ __forceinline__ bf16x8 q_frag_ks(const char* tile, int cbase, int s, 
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-template <bool A_KS, bool B_KS>
+// MASK = 1 (NT only): the rows of the K-contiguous A operand are x [rows][mask_ld] under lora_dropout - the packed keep mask of the K tile
+// (128 rows x 8 bytes, vlr_dropout_bits) rides the ring as a ninth DMA instruction per wave (global_load_lds_dword: 32 rows x 8 B each)
+// and a fragment (8 consecutive k of one row = ONE mask byte) is masked when it is read from LDS: no dropped copy of x, no hash, and
+// the operand still travels by LDS-DMA.  K % 64 == 0 (whole tiles), mask_ld % 64 == 0.
+template <bool A_KS, bool B_KS, int MASK = 0>
 __global__ __launch_bounds__(256) void gemm128p_kernel(GemmParams p, const bf16_t* __restrict__ zero16, int nst) {
+    static_assert(!MASK || (!A_KS && !B_KS), "masked operand: NT, A rows");
     extern __shared__ __attribute__((aligned(16))) char smem[];      // max(nst * 32 KiB, Q_EPI_BYTES)
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -74,9 +83,12 @@ __global__ __launch_bounds__(256) void gemm128p_kernel(GemmParams p, const bf16_
         p.B += (size_t)g * p.gB;
         p.C = (char*)p.C + (size_t)g * p.gC * (p.out_f32 ? 4 : 2);
         if (p.splitk > 1) p.part += (size_t)g * p.splitk * p.M * p.N;
+        if (MASK) p.mask_bits += (size_t)g * p.gMask;
     }
+    int kabs0 = 0;                 // split-K slices move p.A: the mask index needs the absolute k
     if (p.splitk > 1) {            // split-K slice z: raw alpha * acc -> its own fp32 partial
         const int z = blockIdx.y, k0 = z * p.kchunk;
+        kabs0 = k0;
         p.A += A_KS ? (size_t)k0 * p.lda : (size_t)k0;
         p.B += B_KS ? (size_t)k0 * p.ldb : (size_t)k0;
         p.K = min(p.kchunk, p.K - k0);
@@ -136,6 +148,7 @@ __global__ __launch_bounds__(256) void gemm128p_kernel(GemmParams p, const bf16_
     const size_t stepA = A_KS ? (size_t)QK * p.lda * 2 : (size_t)QK * 2;
     const size_t stepB = B_KS ? (size_t)QK * p.ldb * 2 : (size_t)QK * 2;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(q_lvoid_t*)smem + wave * 1024;
+    const uint32_t lbits = (uint32_t)(uintptr_t)(q_lvoid_t*)smem + nst * Q_STAGE_BYTES;      // mask tiles behind the operand stages
     const int nt = (p.K + QK - 1) / QK;
 
     auto stage_tile = [&](int kt, int slot) {
@@ -147,6 +160,12 @@ __global__ __launch_bounds__(256) void gemm128p_kernel(GemmParams p, const bf16_
             for (int i = 0; i < 4; ++i) q_dma16_s(ba, offA[i], la + i * 4096);
 #pragma unroll
             for (int i = 0; i < 4; ++i) q_dma16_s(bb, offB[i], lb + i * 4096);
+            if constexpr (MASK) {      // mask bytes of this K tile: lane -> (row wave*32 + lane/2, 4-byte half lane&1), LDS [128 rows][8 B]
+                int grow = m0 + wave * 32 + (lane >> 1);
+                grow = grow < p.M ? grow : p.M - 1;
+                const unsigned char* g = p.mask_bits + (((size_t)grow * p.mask_ld + kabs0 + kt * QK) >> 3) + (lane & 1) * 4;
+                q_dma4(g, lbits + slot * 1024 + wave * 256);
+            }
         } else {
             // the last, partial K tile: chunks / k-rows beyond K come from the zero buffer
             const int k0 = kt * QK;
@@ -193,9 +212,15 @@ __global__ __launch_bounds__(256) void gemm128p_kernel(GemmParams p, const bf16_
     int fill = nst - 1;                 // stage K tile kt + nst - 1 goes to
     for (int kt = 0; kt < nt; ++kt) {
         const int younger = min(nst - 2, nt - 1 - kt);     // tiles issued after kt and still allowed in flight
-        if (younger >= 2) Q_WAIT_VM(16);
-        else if (younger == 1) Q_WAIT_VM(8);
-        else Q_WAIT_VM(0);
+        if constexpr (MASK) {          // nine DMA instructions per tile and wave
+            if (younger >= 2) Q_WAIT_VM(18);
+            else if (younger == 1) Q_WAIT_VM(9);
+            else Q_WAIT_VM(0);
+        } else {
+            if (younger >= 2) Q_WAIT_VM(16);
+            else if (younger == 1) Q_WAIT_VM(8);
+            else Q_WAIT_VM(0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -203,6 +228,7 @@ __global__ __launch_bounds__(256) void gemm128p_kernel(GemmParams p, const bf16_
         if (kt + nst - 1 < nt) stage_tile(kt + nst - 1, fill);
         const char* ta = smem + slot * Q_STAGE_BYTES;
         const char* tb = ta + Q_OPER_BYTES;
+        const unsigned char* tbits = reinterpret_cast<const unsigned char*>(smem) + nst * Q_STAGE_BYTES + slot * 1024;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 fa[4], fb[4];
@@ -210,6 +236,13 @@ __global__ __launch_bounds__(256) void gemm128p_kernel(GemmParams p, const bf16_
             for (int i = 0; i < 4; ++i) {
                 if constexpr (A_KS) fa[i] = q_frag_ks(ta, wr * 64 + i * 16, ks, lane);
                 else fa[i] = q_frag_kc(ta, wr * 64 + i * 16, ks, lane);
+                if constexpr (MASK) {
+                    const uint32_t keep = tbits[(wr * 64 + i * 16 + (lane & 15)) * 8 + ks * 4 + (lane >> 4)];
+                    u32x4 w = __builtin_bit_cast(u32x4, fa[i]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] &= ((keep >> (2 * e)) & 1 ? 0x0000ffffu : 0u) | ((keep >> (2 * e + 1)) & 1 ? 0xffff0000u : 0u);
+                    fa[i] = __builtin_bit_cast(bf16x8, w);
+                }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -265,7 +298,13 @@ static int q_stages() {
 // the register-staged kernel): 16-byte alignment of every row piece, K % 8, >= 8 columns on a K-strided operand
 bool vlr_gemm128p_try_launch(int layout, const GemmParams& p, dim3 grid, hipStream_t stream) {
     const int nst = q_stages();
-    if (!nst || p.mask_on || p.fuse == 6) return false;
+    if (!nst || p.fuse == 6) return false;
+    const bool masked = p.mask_on != 0;
+    if (masked) {     // NT with the packed masks only (the TN form and the hashing form stay on the register-staged kernel)
+        if (p.mask_on != 1 || layout != 0 || !p.mask_bits || p.K % QK != 0 || p.mask_ld % QK != 0 || (p.splitk > 1 && p.kchunk % QK != 0) ||
+            ((uintptr_t)p.mask_bits & 3) || p.gMask % 4 != 0)
+            return false;
+    }
     const bool a_ks = layout == 2, b_ks = layout != 0;
     if (((uintptr_t)p.A | (uintptr_t)p.B) & 15) return false;
     if (p.lda % 8 != 0 || p.ldb % 8 != 0 || (p.groups > 1 && ((p.gA | p.gB) % 8 != 0))) return false;
@@ -279,9 +318,16 @@ bool vlr_gemm128p_try_launch(int layout, const GemmParams& p, dim3 grid, hipStre
         hipFuncSetAttribute((const void*)gemm128p_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * Q_STAGE_BYTES);
         hipFuncSetAttribute((const void*)gemm128p_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * Q_STAGE_BYTES);
         hipFuncSetAttribute((const void*)gemm128p_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * Q_STAGE_BYTES);
+        hipFuncSetAttribute((const void*)gemm128p_kernel<false, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (Q_STAGE_BYTES + 1024));
         attr = true;
     }
-    const int lds = nst * Q_STAGE_BYTES > Q_EPI_BYTES ? nst * Q_STAGE_BYTES : Q_EPI_BYTES;
+    int lds = nst * Q_STAGE_BYTES > Q_EPI_BYTES ? nst * Q_STAGE_BYTES : Q_EPI_BYTES;
+    if (masked) {
+        const int need = nst * (Q_STAGE_BYTES + 1024);
+        lds = need > Q_EPI_BYTES ? need : Q_EPI_BYTES;
+        hipLaunchKernelGGL((gemm128p_kernel<false, false, 1>), grid, dim3(256), lds, stream, p, (const bf16_t*)zero16, nst);
+        return true;
+    }
     if (layout == 0) hipLaunchKernelGGL((gemm128p_kernel<false, false>), grid, dim3(256), lds, stream, p, (const bf16_t*)zero16, nst);
     else if (layout == 1) hipLaunchKernelGGL((gemm128p_kernel<false, true>), grid, dim3(256), lds, stream, p, (const bf16_t*)zero16, nst);
     else hipLaunchKernelGGL((gemm128p_kernel<true, true>), grid, dim3(256), lds, stream, p, (const bf16_t*)zero16, nst);

@@ -13,7 +13,7 @@
 //   * per unit 16 x r/32 v_mfma_f32_16x16x32_bf16 per wave (4 waves = 2 x 2, wave tile 32 x 64); the mask is applied to the fp32
 //     accumulators (a lane holds 4 consecutive columns of a row: one nibble of the packed mask, or one hash), the targets are summed in
 //     registers and the bf16 tile is read / written once, 8 bytes per lane.
-// Grid = (row blocks, column splits): ~2 workgroups per CU, 2-4 resident per CU (LDS 2 x r/64 x 16 KiB), so one workgroup's wait is
+// Grid = (row blocks, column splits): ~4 workgroups per CU, 2-4 resident per CU (LDS 2 x r/64 x 16 KiB), so one workgroup's wait is
 // another one's MFMAs.
 #include <stdlib.h>
 
@@ -270,7 +270,7 @@ static bool dx_launch_k(const LoraDxParams& p, int mask, dim3 grid, hipStream_t 
 // tile kernels of gemm.hip): n <= 3 targets, r in {64, 128, 256}, in % 128 == 0, 16-byte aligned operands.  VLR_LORA_DX=0 disables.
 bool vlr_lora_dx_try_launch(int n, const void* v, int ldv, const void* A, void* dx, int M, int in, int r, float p_drop, uint64_t seed,
                             float scale, int accumulate, const void* bits, long bits_gstride, hipStream_t stream) {
-    static int on = -1, wg_per_cu = 2;
+    static int on = -1, wg_per_cu = 4;      // 4 workgroups per CU in the grid (2-4 resident): 196 / 88 / 123 / 255 us for the four groups at the 7B shapes against 222 / 106 / 147 / 303 at 2
     if (on < 0) {
         const char* e = getenv("VLR_LORA_DX");
         on = (e && e[0] == '0') ? 0 : 1;
