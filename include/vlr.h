@@ -115,8 +115,9 @@ int vlr_gemm_dropout_acc_multi(int n, const void* v, int ldv, const void* A, voi
 /*  ..._bits (ABI v5)     : the three calls above with the keep masks DRAWN BEFOREHAND by vlr_dropout_bits (packed, bit e of byte i =
  *                          element 8 i + e of the dense [rows][mask_ld] operand; the mask of group / target g starts at bits + g *
  *                          gstride bytes, seed + g as before): the forward, the dA and the dx kernels of a target all need the same mask
- *                          and the hash (two splitmix64 per eight elements) cost more than the MFMAs of these skinny products.
- *                          bits = NULL: hash in the kernel, exactly the calls above. */
+ *                          and the packed form lets the masked operand travel by LDS-DMA (gemm128p.hip masks the fragments it reads).
+ *                          vlr_gemm_grouped_bits: mask_on 1 / 2 read the row-major masks, mask_on 3 (layout 2) the K-tile-blocked transposed
+ *                          ones of vlr_dropout_bits2.  bits = NULL: hash in the kernel, exactly the calls above. */
 int vlr_gemm_grouped_bits(int layout, const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int groups,
                           long gA, long gB, long gC, float alpha, int accumulate, int mask_on, uint64_t seed, float p_drop, int mask_ld,
                           const void* mask_bits, long mask_gstride, vlr_stream_t stream);
@@ -327,8 +328,9 @@ typedef struct {
     int qkv_targets;  /* 0 or 3: q_proj, k_proj, v_proj adapted separately (a_qkv [3r][H], u_q | u_k | u_v); 1: ONE adapter on the
                        * fused projection (Qwen c_attn: a_qkv [r][H], b_qkv [N][r]) */
     void* mask_bits;  /* ABI v5, dropout > 0 only: vlr_lora_mask_bytes(hidden, inter, M) bytes of THIS layer, or NULL.  The forward draws
-                       * the seven packed keep masks into it (vlr_dropout_bits, target t < 6 at t * M * hidden / 8, down at 6 * M *
-                       * hidden / 8) and the adapter GEMMs of the forward AND of the backward read them; NULL: every kernel hashes */
+                       * the seven packed keep masks into it in both forms of vlr_dropout_bits2 (row-major: target t < 6 at t * M * hidden
+                       * / 8, down at 6 * M * hidden / 8; behind them, 64-byte aligned, the K-tile-blocked transposed ones) and the adapter
+                       * GEMMs of the forward AND of the backward read them; NULL: every kernel hashes */
 } vlr_lora_weights;
 long vlr_lora_mask_bytes(int hidden, int inter, int M);
 typedef struct {
@@ -362,6 +364,11 @@ int vlr_rows_mask(void* x, int ld, int cols, const unsigned char* rowmask, int M
 int vlr_dropout(const void* x, void* out, long n, float p, uint64_t seed, float alpha, int add, vlr_stream_t stream);
 /* the keep mask of vlr_dropout(seed) over n elements (n % 32 == 0), packed: bit e of byte i = element 8 i + e */
 int vlr_dropout_bits(void* bits_u8, long n, float p, uint64_t seed, vlr_stream_t stream);
+/* the same mask over a [rows][cols] operand in BOTH packed forms (either pointer may be NULL): row-major as above, and K-tile-blocked
+ * transposed - byte ((row / 64) * cols + col) * 8 + (row % 64) / 8, bit e = row + e; vlr_dropout_bits_kt_bytes(rows, cols) bytes, 8-byte
+ * aligned - which vlr_gemm_grouped_bits(layout 2, mask_on 3) reads for dA = v^T (mask . x) */
+int vlr_dropout_bits2(void* bits_u8, void* bits_kt_u8, int rows, int cols, float p, uint64_t seed, vlr_stream_t stream);
+long vlr_dropout_bits_kt_bytes(int rows, int cols);
 int vlr_dropout_mask(void* mask_u8, long n, float p, uint64_t seed, vlr_stream_t stream);
 
 /* vlr_decoder_layer_bwd runs the weight-gradient GEMMs on a library-owned side stream (VLR_BWD_STREAMS=0 disables);

@@ -1485,6 +1485,29 @@ def test_dropout_bits_and_masked_gemms_with_bits(hip, M, in_, r, n, p):
     hip.call("vlr_gemm_grouped_bits", 2, v, x, d1, r, in_, M, n * r, in_, in_, n, r, 0, r * in_, alpha, 0, 2, seed, p, in_, bits, gstride)
     torch.cuda.synchronize()
     assert torch.equal(d0, d1), "masked TN (dA = v^T drop(x))"
+    # the K-tile-blocked transposed masks (vlr_dropout_bits2) and the TN product that reads them on the LDS-DMA ring kernel (mask_on 3)
+    tstride = HH.helper("vlr_dropout_bits_kt_bytes", M, in_)
+    bits_rm = torch.zeros(n * gstride, dtype=torch.uint8, device=DEV)
+    bits_kt = torch.zeros(n * tstride, dtype=torch.uint8, device=DEV)
+    for t in range(n):
+        hip.call("vlr_dropout_bits2", bits_rm[t * gstride:], bits_kt[t * tstride:], M, in_, p, seed + t)
+    torch.cuda.synchronize()
+    assert torch.equal(bits_rm, bits), "row-major half of vlr_dropout_bits2"
+    Mp = (M + 63) // 64 * 64
+    for t in range(n):
+        mk = ((bits[t * gstride:(t + 1) * gstride].view(-1, 1) >> torch.arange(8, device=DEV, dtype=torch.uint8)) & 1).reshape(M, in_)
+        mkp = torch.zeros(Mp, in_, dtype=torch.uint8, device=DEV)
+        mkp[:M] = mk
+        # expected transposed form: [row / 64][col][(row % 64) / 8] bytes, bit = row % 8
+        w = (mkp.view(Mp // 64, 8, 8, in_).permute(0, 3, 1, 2).to(torch.int32) << torch.arange(8, device=DEV, dtype=torch.int32)).sum(-1).to(torch.uint8)
+        assert torch.equal(bits_kt[t * tstride:(t + 1) * tstride], w.reshape(-1)), f"transposed masks of target {t}"
+    d2 = torch.zeros(n * r, in_, dtype=torch.bfloat16, device=DEV)
+    hip.call("vlr_gemm_grouped_bits", 2, v, x, d2, r, in_, M, n * r, in_, in_, n, r, 0, r * in_, alpha, 0, 3, seed, p, in_, bits_kt, tstride)
+    torch.cuda.synchronize()
+    for t in range(n):
+        mk = ((bits[t * gstride:(t + 1) * gstride].view(-1, 1) >> torch.arange(8, device=DEV, dtype=torch.uint8)) & 1).reshape(M, in_).float()
+        ref = alpha * v[:, t * r:(t + 1) * r].float().t() @ (x.float() * mk)
+        check(d2[t * r:(t + 1) * r], ref, 8e-3, f"masked TN with transposed packed masks, target {t}")
     dx0 = rnd(M, in_, seed=4)
     a0, a1, a2 = dx0.clone(), dx0.clone(), dx0.clone()
     scratch = torch.empty(M, in_, dtype=torch.bfloat16, device=DEV)

@@ -81,10 +81,12 @@ def main():
         nr = n * r
         gst = M * din // 8
         bits = None if a.hash else torch.zeros(n * gst, dtype=torch.uint8, device=dev)
+        tst = _hip.helper("vlr_dropout_bits_kt_bytes", M, din)
+        bits_kt = None if a.hash else torch.zeros(n * tst, dtype=torch.uint8, device=dev)
         if bits is not None:
             def draw():
                 for t in range(n):
-                    _hip.call("vlr_dropout_bits", bits[t * gst:], M * din, p, seed + t)
+                    _hip.call("vlr_dropout_bits2", bits[t * gst:], bits_kt[t * tst:], M, din, p, seed + t)
             us = timeit(draw, a.iters)
             rec(f"{gname:8s} draw the packed masks x{n}", us, 1.0 * n * gst, 0.0)
         us = timeit(lambda: _hip.call("vlr_gemm_grouped_bits", 0, x, A, u, M, r, din, din, din, ldu, n, 0, r * din, r, sc / (1 - p), 0, 1, seed, p, din, bits, gst), a.iters)
@@ -93,7 +95,10 @@ def main():
         rec(f"{gname:8s} v = dy B         [M,{nr},{out}]", us, 2.0 * M * out * n + 2.0 * M * nr, 2.0 * M * nr * out)
         us = timeit(lambda: _hip.call("vlr_gemm_grouped", 2, dy, u, dB, out, r, M, lddy, ldu, r, n, out, r, out * r, 1.0, 0, 0, 0, 0.0, 0), a.iters)
         rec(f"{gname:8s} dB = dy^T u      [{out * n},{r},M]", us, 2.0 * M * out * n + 2.0 * M * nr, 2.0 * M * nr * out)
-        us = timeit(lambda: _hip.call("vlr_gemm_grouped_bits", 2, v, x, dA, r, din, M, nr, din, din, n, r, 0, r * din, sc / (1 - p), 0, 2, seed, p, din, bits, gst), a.iters)
+        if bits is None:
+            us = timeit(lambda: _hip.call("vlr_gemm_grouped_bits", 2, v, x, dA, r, din, M, nr, din, din, n, r, 0, r * din, sc / (1 - p), 0, 2, seed, p, din, None, 0), a.iters)
+        else:
+            us = timeit(lambda: _hip.call("vlr_gemm_grouped_bits", 2, v, x, dA, r, din, M, nr, din, din, n, r, 0, r * din, sc / (1 - p), 0, 3, seed, p, din, bits_kt, tst), a.iters)
         rec(f"{gname:8s} dA = v^T drop(x) [{nr},{din},M]", us, 2.0 * M * din + 2.0 * M * nr, 2.0 * M * nr * din)
 
         def dxall():

@@ -460,6 +460,46 @@ __global__ __launch_bounds__(256) void dropout_bits_kernel(uint32_t* __restrict_
         bits[i] = w;
     }
 }
+// Both packed forms in one draw: row-major (bit e of byte (row * cols + col) / 8 = column col + e) and K-TILE-BLOCKED TRANSPOSED
+// (byte ((row / 64) * cols + col) * 8 + (row % 64) / 8, bit e = row + e): the form the TN adapter product dA = v^T (mask . x) reads - x is
+// its K-strided operand, a fragment is 8 consecutive ROWS of one column, i.e. one byte of this layout, and the 128 columns x 8 bytes
+// of a K tile are 1 KiB contiguous (one LDS-DMA instruction per wave).  A workgroup owns 64 rows x 256 columns; a thread hashes an
+// 8 x 8 block (row group j = t / 32, column block t % 32), stores its 8 row-major bytes (32 threads = 32 consecutive bytes of a row),
+// transposes the block in a register (three masked swaps) and leaves its 8 column bytes in LDS, from where thread t writes the 8 bytes
+// of column t as one 64-bit store.
+__global__ __launch_bounds__(256) void dropout_bits2_kernel(unsigned char* __restrict__ bits, unsigned char* __restrict__ bits_kt, int rows, int cols,
+                                                            uint64_t key, uint32_t thr) {
+    __shared__ unsigned char colb[256][8];
+    const int t = threadIdx.x, j = t >> 5, cb = t & 31;
+    const int cblocks = (cols + 255) >> 8;
+    const int kt = blockIdx.x / cblocks, c0 = (blockIdx.x % cblocks) * 256;
+    const int col = c0 + cb * 8;
+    uint64_t x = 0;                                     // 8 rows x 8 columns: byte rr = row, bit e = column
+    if (col < cols) {
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int row = kt * 64 + j * 8 + rr;
+            if (row < rows) {
+                const long g = ((long)row * cols + col) >> 3;
+                const uint32_t keep = dropout_keep8(key, g, thr);
+                if (bits) bits[g] = (unsigned char)keep;
+                x |= (uint64_t)keep << (8 * rr);
+            }
+        }
+    }
+    // 8 x 8 bit-matrix transpose (bit 8 i + j <-> bit 8 j + i): byte e = column, bit rr = row
+    uint64_t w = (x ^ (x >> 7)) & 0x00AA00AA00AA00AAull;
+    x = x ^ w ^ (w << 7);
+    w = (x ^ (x >> 14)) & 0x0000CCCC0000CCCCull;
+    x = x ^ w ^ (w << 14);
+    w = (x ^ (x >> 28)) & 0x00000000F0F0F0F0ull;
+    x = x ^ w ^ (w << 28);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) colb[cb * 8 + e][j] = (unsigned char)(x >> (8 * e));
+    __syncthreads();
+    if (bits_kt && c0 + t < cols)
+        *reinterpret_cast<uint64_t*>(bits_kt + ((long)kt * cols + c0 + t) * 8) = *reinterpret_cast<const uint64_t*>(&colb[t][0]);
+}
 __global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ mask, long n8, uint64_t key, uint32_t thr) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
         const uint32_t keep = dropout_keep8(key, i, thr);
@@ -733,6 +773,16 @@ extern "C" int vlr_dropout_bits(void* bits_u8, long n, float p, uint64_t seed, h
     hipLaunchKernelGGL(dropout_bits_kernel, dim3(grid_for(n / 32, 256)), dim3(256), 0, st, (uint32_t*)bits_u8, n / 32, vlr_mix64(seed),
                        vlr_dropout_thr(p));
     return vlr_check_launch("vlr_dropout_bits");
+}
+extern "C" long vlr_dropout_bits_kt_bytes(int rows, int cols) { return (long)((rows + 63) / 64) * cols * 8; }
+extern "C" int vlr_dropout_bits2(void* bits_u8, void* bits_kt_u8, int rows, int cols, float p, uint64_t seed, hipStream_t st) {
+    VLR_REQUIRE((bits_u8 || bits_kt_u8) && rows > 0 && cols > 0 && cols % 8 == 0 && p >= 0.f && p < 1.f && !((uintptr_t)bits_kt_u8 & 7),
+                "vlr_dropout_bits2: cols %% 8 == 0, 0 <= p < 1 and an 8-byte aligned transposed buffer required (rows=%d cols=%d p=%g)", rows, cols, (double)p);
+    const long nblk = (long)((rows + 63) / 64) * ((cols + 255) / 256);
+    VLR_REQUIRE(nblk < (1L << 31), "vlr_dropout_bits2: too many blocks");
+    hipLaunchKernelGGL(dropout_bits2_kernel, dim3((unsigned)nblk), dim3(256), 0, st, (unsigned char*)bits_u8, (unsigned char*)bits_kt_u8, rows,
+                       cols, vlr_mix64(seed), vlr_dropout_thr(p));
+    return vlr_check_launch("vlr_dropout_bits2");
 }
 extern "C" int vlr_im2col(const float* pixel_values, void* patches, int n_img, int image_size, int patch, int Kp,
                           hipStream_t st) {

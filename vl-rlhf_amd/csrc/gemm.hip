@@ -505,7 +505,8 @@ static int gemm_grouped(int layout, const void* A, const void* B, void* C, int M
                         const void* mask_bits, long mask_gstride, hipStream_t stream) {
     VLR_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && groups >= 1 && groups <= 8, "gemm_grouped: bad arguments");
     VLR_REQUIRE(N % 8 == 0 && ldc % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && gC % 4 == 0, "gemm_grouped: alignment (N %d lda %d ldb %d ldc %d)", N, lda, ldb, ldc);
-    VLR_REQUIRE(!mask_on || (mask_ld % 8 == 0 && ((mask_on == 1 && layout == 0) || (mask_on == 2 && layout == 2))), "gemm_grouped: mask on the NT A / TN B operand only");
+    VLR_REQUIRE(!mask_on || (mask_ld % 8 == 0 && ((mask_on == 1 && layout == 0) || ((mask_on == 2 || mask_on == 3) && layout == 2))), "gemm_grouped: mask on the NT A / TN B operand only");
+    VLR_REQUIRE(mask_on != 3 || mask_bits, "gemm_grouped: mask_on 3 needs the K-tile-blocked transposed masks of vlr_dropout_bits2");
     GemmParams p = fused_params(A, B, C, M, N, K, lda, ldb, ldc);
     p.alpha = alpha; p.accumulate = accumulate;
     p.groups = groups; p.gA = gA; p.gB = gB; p.gC = gC;
@@ -533,6 +534,11 @@ static int gemm_grouped(int layout, const void* A, const void* B, void* C, int M
     const int pi = vlr_prof_begin(layout, 2.0 * M * N * K * groups, stream);
     if (mask_on && layout == 0) {       // packed masks: the LDS-DMA ring kernel masks the fragments; else staged through registers
         if (!vlr_gemm128p_try_launch(layout, p, grid, stream)) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, 1>), grid, dim3(256), 0, stream, p);
+    } else if (mask_on == 3) {          // TN with the transposed packed masks: ring kernel, else the register-staged kernel hashing the same mask
+        if (!vlr_gemm128p_try_launch(layout, p, grid, stream)) {
+            p.mask_on = 2; p.mask_bits = nullptr;
+            hipLaunchKernelGGL((gemm_bf16_kernel<true, true, 2>), grid, dim3(256), 0, stream, p);
+        }
     } else if (mask_on) hipLaunchKernelGGL((gemm_bf16_kernel<true, true, 2>), grid, dim3(256), 0, stream, p);
     else launch128(layout, p, grid, stream);
     if (splits > 1) {

@@ -69,9 +69,12 @@ __device__ __forceinline__ bf16x8 q_frag_ks(const char* tile, int cbase, int s, 
 // (128 rows x 8 bytes, vlr_dropout_bits) rides the ring as a ninth DMA instruction per wave (global_load_lds_dword: 32 rows x 8 B each)
 // and a fragment (8 consecutive k of one row = ONE mask byte) is masked when it is read from LDS: no dropped copy of x, no hash, and
 // the operand still travels by LDS-DMA.  K % 64 == 0 (whole tiles), mask_ld % 64 == 0.
+// MASK = 2 (TN only): the K-strided B operand is x stored [K = rows][mask_ld] (dA = v^T (mask . x)); a fragment is 8 consecutive ROWS of
+// one column = one byte of the K-tile-blocked transposed masks of vlr_dropout_bits2 ([row / 64][col][8 B]); the 128 columns x 8 B
+// of a K tile are 1 KiB contiguous: 256 B per wave by global_load_lds_dword.  N % 128 == 0, K slices start on whole tiles.
 template <bool A_KS, bool B_KS, int MASK = 0>
 __global__ __launch_bounds__(256) void gemm128p_kernel(GemmParams p, const bf16_t* __restrict__ zero16, int nst) {
-    static_assert(!MASK || (!A_KS && !B_KS), "masked operand: NT, A rows");
+    static_assert(MASK == 0 || (MASK == 1 && !A_KS && !B_KS) || (MASK == 2 && A_KS && B_KS), "masked operand: 1 = NT A rows, 2 = TN B rows");
     extern __shared__ __attribute__((aligned(16))) char smem[];      // max(nst * 32 KiB, Q_EPI_BYTES)
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -151,6 +154,17 @@ __global__ __launch_bounds__(256) void gemm128p_kernel(GemmParams p, const bf16_
     const uint32_t lbits = (uint32_t)(uintptr_t)(q_lvoid_t*)smem + nst * Q_STAGE_BYTES;      // mask tiles behind the operand stages
     const int nt = (p.K + QK - 1) / QK;
 
+    auto stage_bits = [&](int kt, int slot) {
+        if constexpr (MASK == 1) {      // lane -> (row wave*32 + lane/2, 4-byte half lane&1), LDS [128 rows][8 B]
+            int grow = m0 + wave * 32 + (lane >> 1);
+            grow = grow < p.M ? grow : p.M - 1;
+            const unsigned char* g = p.mask_bits + (((size_t)grow * p.mask_ld + kabs0 + kt * QK) >> 3) + (lane & 1) * 4;
+            q_dma4(g, lbits + slot * 1024 + wave * 256);
+        } else if constexpr (MASK == 2) {   // [128 columns][8 B] of K tile (kabs0 / 64 + kt): 1 KiB contiguous
+            const unsigned char* g = p.mask_bits + ((size_t)((kabs0 >> 6) + kt) * p.mask_ld + n0) * 8 + wave * 256 + lane * 4;
+            q_dma4(g, lbits + slot * 1024 + wave * 256);
+        }
+    };
     auto stage_tile = [&](int kt, int slot) {
         const uint32_t la = lds0 + slot * Q_STAGE_BYTES, lb = la + Q_OPER_BYTES;
         if ((kt + 1) * QK <= p.K) {
@@ -160,12 +174,7 @@ __global__ __launch_bounds__(256) void gemm128p_kernel(GemmParams p, const bf16_
             for (int i = 0; i < 4; ++i) q_dma16_s(ba, offA[i], la + i * 4096);
 #pragma unroll
             for (int i = 0; i < 4; ++i) q_dma16_s(bb, offB[i], lb + i * 4096);
-            if constexpr (MASK) {      // mask bytes of this K tile: lane -> (row wave*32 + lane/2, 4-byte half lane&1), LDS [128 rows][8 B]
-                int grow = m0 + wave * 32 + (lane >> 1);
-                grow = grow < p.M ? grow : p.M - 1;
-                const unsigned char* g = p.mask_bits + (((size_t)grow * p.mask_ld + kabs0 + kt * QK) >> 3) + (lane & 1) * 4;
-                q_dma4(g, lbits + slot * 1024 + wave * 256);
-            }
+            if constexpr (MASK) stage_bits(kt, slot);
         } else {
             // the last, partial K tile: chunks / k-rows beyond K come from the zero buffer
             const int k0 = kt * QK;
@@ -195,6 +204,7 @@ __global__ __launch_bounds__(256) void gemm128p_kernel(GemmParams p, const bf16_
                 }
                 q_dma16(g, lb + i * 4096);
             }
+            if constexpr (MASK) stage_bits(kt, slot);
         }
     };
 
@@ -236,7 +246,7 @@ __global__ __launch_bounds__(256) void gemm128p_kernel(GemmParams p, const bf16_
             for (int i = 0; i < 4; ++i) {
                 if constexpr (A_KS) fa[i] = q_frag_ks(ta, wr * 64 + i * 16, ks, lane);
                 else fa[i] = q_frag_kc(ta, wr * 64 + i * 16, ks, lane);
-                if constexpr (MASK) {
+                if constexpr (MASK == 1) {
                     const uint32_t keep = tbits[(wr * 64 + i * 16 + (lane & 15)) * 8 + ks * 4 + (lane >> 4)];
                     u32x4 w = __builtin_bit_cast(u32x4, fa[i]);
 #pragma unroll
@@ -248,6 +258,13 @@ __global__ __launch_bounds__(256) void gemm128p_kernel(GemmParams p, const bf16_
             for (int j = 0; j < 4; ++j) {
                 if constexpr (B_KS) fb[j] = q_frag_ks(tb, wc * 64 + j * 16, ks, lane);
                 else fb[j] = q_frag_kc(tb, wc * 64 + j * 16, ks, lane);
+                if constexpr (MASK == 2) {      // lane: column wc*64 + j*16 + (lane & 15), rows ks*32 + (lane >> 4)*8 .. + 7
+                    const uint32_t keep = tbits[(wc * 64 + j * 16 + (lane & 15)) * 8 + ks * 4 + (lane >> 4)];
+                    u32x4 w = __builtin_bit_cast(u32x4, fb[j]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] &= ((keep >> (2 * e)) & 1 ? 0x0000ffffu : 0u) | ((keep >> (2 * e + 1)) & 1 ? 0xffff0000u : 0u);
+                    fb[j] = __builtin_bit_cast(bf16x8, w);
+                }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -300,10 +317,11 @@ bool vlr_gemm128p_try_launch(int layout, const GemmParams& p, dim3 grid, hipStre
     const int nst = q_stages();
     if (!nst || p.fuse == 6) return false;
     const bool masked = p.mask_on != 0;
-    if (masked) {     // NT with the packed masks only (the TN form and the hashing form stay on the register-staged kernel)
-        if (p.mask_on != 1 || layout != 0 || !p.mask_bits || p.K % QK != 0 || p.mask_ld % QK != 0 || (p.splitk > 1 && p.kchunk % QK != 0) ||
-            ((uintptr_t)p.mask_bits & 3) || p.gMask % 4 != 0)
-            return false;
+    if (masked) {     // packed masks only (the hashing forms stay on the register-staged kernel): 1 = NT, row-major bits; 3 = TN, K-tile-blocked transposed bits
+        if (!p.mask_bits || ((uintptr_t)p.mask_bits & 3) || p.gMask % 4 != 0 || (p.splitk > 1 && p.kchunk % QK != 0)) return false;
+        if (p.mask_on == 1) { if (layout != 0 || p.K % QK != 0 || p.mask_ld % QK != 0) return false; }
+        else if (p.mask_on == 3) { if (layout != 2 || p.N % QT != 0 || p.mask_ld != p.N) return false; }
+        else return false;
     }
     const bool a_ks = layout == 2, b_ks = layout != 0;
     if (((uintptr_t)p.A | (uintptr_t)p.B) & 15) return false;
@@ -319,13 +337,15 @@ bool vlr_gemm128p_try_launch(int layout, const GemmParams& p, dim3 grid, hipStre
         hipFuncSetAttribute((const void*)gemm128p_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * Q_STAGE_BYTES);
         hipFuncSetAttribute((const void*)gemm128p_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * Q_STAGE_BYTES);
         hipFuncSetAttribute((const void*)gemm128p_kernel<false, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (Q_STAGE_BYTES + 1024));
+        hipFuncSetAttribute((const void*)gemm128p_kernel<true, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (Q_STAGE_BYTES + 1024));
         attr = true;
     }
     int lds = nst * Q_STAGE_BYTES > Q_EPI_BYTES ? nst * Q_STAGE_BYTES : Q_EPI_BYTES;
     if (masked) {
         const int need = nst * (Q_STAGE_BYTES + 1024);
         lds = need > Q_EPI_BYTES ? need : Q_EPI_BYTES;
-        hipLaunchKernelGGL((gemm128p_kernel<false, false, 1>), grid, dim3(256), lds, stream, p, (const bf16_t*)zero16, nst);
+        if (p.mask_on == 1) hipLaunchKernelGGL((gemm128p_kernel<false, false, 1>), grid, dim3(256), lds, stream, p, (const bf16_t*)zero16, nst);
+        else hipLaunchKernelGGL((gemm128p_kernel<true, true, 2>), grid, dim3(256), lds, stream, p, (const bf16_t*)zero16, nst);
         return true;
     }
     if (layout == 0) hipLaunchKernelGGL((gemm128p_kernel<false, false>), grid, dim3(256), lds, stream, p, (const bf16_t*)zero16, nst);

@@ -159,7 +159,8 @@ extern "C" int vlr_decoder_layer_bwd(const vlr_llama_cfg* cfg, const vlr_layer_w
 // bits != NULL (vlr_lora_weights::mask_bits): the packed keep masks of the n targets are DRAWN here (target t at bits + t * M * in / 8) and
 // read by the staged-operand mask of the grouped launch - and again by the backward (lora_group_bwd)
 static int lora_group_a(int n, int r, int in, const void* x, int ldx, const void* A, void* u, int ldu, float scale, float p,
-                        uint64_t seed, void* ws_xd, int M, hipStream_t st, const unsigned char* rowmask = nullptr, unsigned char* bits = nullptr) {
+                        uint64_t seed, void* ws_xd, int M, hipStream_t st, const unsigned char* rowmask = nullptr, unsigned char* bits = nullptr,
+                        unsigned char* bits_kt = nullptr) {
     (void)ws_xd;
     struct MaskAfter {       // PLoRA: the adapter acts on the image rows only - zero the other rows of u on the way out
         void* u; int ldu, cols, M; const unsigned char* rm; hipStream_t st;
@@ -170,9 +171,11 @@ static int lora_group_a(int n, int r, int in, const void* x, int ldx, const void
         // zeroed while the operand is staged - drop(x) is never written) against its own A_t; 1 / (1 - p) rides in alpha
         VLR_REQUIRE(ldx == in, "lora: the dropout mask is indexed over [M][in]; x must be dense (ldx %d, in %d)", ldx, in);
         const long gstride = (long)M * in / 8;
-        if (bits) {
+        if (bits) {      // row-major masks (this launch, the dx kernel) and the K-tile-blocked transposed ones (dA) in one draw per target
             VLR_REQUIRE(((long)M * in) % 32 == 0, "lora: packed dropout masks need M * in %% 32 == 0 (M %d, in %d)", M, in);
-            for (int t = 0; t < n; ++t) CHECK(vlr_dropout_bits(bits + (size_t)t * gstride, (long)M * in, p, seed + t, st));
+            const long tstride = vlr_dropout_bits_kt_bytes(M, in);
+            for (int t = 0; t < n; ++t)
+                CHECK(vlr_dropout_bits2(bits + (size_t)t * gstride, bits_kt ? bits_kt + (size_t)t * tstride : nullptr, M, in, p, seed + t, st));
         }
         CHECK(vlr_gemm_grouped_bits(0, x, A, u, M, r, in, ldx, in, ldu, n, 0L, (long)r * in, (long)r, scale / (1.f - p), 0, 1, seed, p, in, bits,
                                     gstride, st));
@@ -187,7 +190,7 @@ static int lora_group_a(int n, int r, int in, const void* x, int ldx, const void
 static int lora_group_bwd(int n, int r, int in, const int* outs, const void* x, const void* dy, int lddy, const void* A, const void* B,
                           void* dA, void* dB, const void* u, int ldu, void* v, void* dx, float scale, float p, uint64_t seed,
                           void* ws_xd, int accumulate, int M, hipStream_t st, int dx_fresh = 0, const unsigned char* rowmask = nullptr,
-                          const unsigned char* bits = nullptr) {
+                          const unsigned char* bits = nullptr, const unsigned char* bits_kt = nullptr) {
     const int nr = n * r;
     const long gstride = (long)M * in / 8;       // bytes between the packed keep masks of the group's targets (the forward drew them)
     size_t ofs[4] = {0, 0, 0, 0};
@@ -206,8 +209,10 @@ static int lora_group_bwd(int n, int r, int in, const int* outs, const void* x, 
     if (rowmask) CHECK(vlr_rows_mask(v, nr, nr, rowmask, M, st));      // PLoRA: no gradient flows through the adapter on the text rows
     if (p > 0.f) {
         // dA_t = s / (1 - p) v_t^T (mask_t . x): the n targets as groups, x masked while it is staged (the mask of the forward, regenerated)
-        CHECK(vlr_gemm_grouped_bits(2, v, x, dA, r, in, M, nr, in, in, n, (long)r, 0L, (long)r * in, scale / (1.f - p), accumulate, 2, seed, p, in,
-                                    bits, gstride, st));
+        if (bits_kt) CHECK(vlr_gemm_grouped_bits(2, v, x, dA, r, in, M, nr, in, in, n, (long)r, 0L, (long)r * in, scale / (1.f - p), accumulate, 3, seed, p,
+                                                 in, bits_kt, vlr_dropout_bits_kt_bytes(M, in), st));
+        else CHECK(vlr_gemm_grouped_bits(2, v, x, dA, r, in, M, nr, in, in, n, (long)r, 0L, (long)r * in, scale / (1.f - p), accumulate, 2, seed, p, in,
+                                         bits, gstride, st));
         // dx (+)= s / (1 - p) sum_t mask_t . (v_t A_t): ONE pass over dx for the n targets (vlr_gemm_dropout_acc_multi: the streaming kernel
         // of lora_dx.hip, 222 us for q, k, v at [12792 x 4096], r = 128, against 3 x 90 us one target at a time; tools/lora_gemm_bench.py).
         // VLR_LORA_MULTI=0: one pass per target on the 128x128 GEMM kernel (mask in its epilogue)
@@ -228,7 +233,10 @@ static int lora_group_bwd(int n, int r, int in, const int* outs, const void* x, 
     return VLR_OK;
 }
 
-extern "C" long vlr_lora_mask_bytes(int hidden, int inter, int M) { return ((long)M * hidden / 8) * 6 + (long)M * inter / 8; }
+static long lora_rowmajor_bytes(int hidden, int inter, int M) { return (((long)M * hidden / 8) * 6 + (long)M * inter / 8 + 63) / 64 * 64; }
+extern "C" long vlr_lora_mask_bytes(int hidden, int inter, int M) {
+    return lora_rowmajor_bytes(hidden, inter, M) + 6 * vlr_dropout_bits_kt_bytes(M, hidden) + vlr_dropout_bits_kt_bytes(M, inter);
+}
 static int lora_check(const char* who, const vlr_lora_weights* lw, const void* ws_xd) {
     VLR_REQUIRE(lw->r > 0 && lw->r % 8 == 0, "%s: LoRA rank must be a positive multiple of 8, got %d", who, lw->r);
     VLR_REQUIRE(lw->dropout >= 0.f && lw->dropout < 1.f, "%s: lora_dropout must be in [0,1), got %g", who, (double)lw->dropout);
@@ -257,22 +265,23 @@ extern "C" int vlr_decoder_layer_fwd_lora_ex(const vlr_llama_cfg* cfg, const vlr
     const float sc = lw->scale, p = lw->dropout;
 #define XD(seg) (ws_xd)      // ABI v4: one scratch [M][max(hidden, inter)] (the fallback path of vlr_gemm_dropout_acc), not per-target copies
 #define MB(t) (lw->mask_bits && p > 0.f ? (unsigned char*)lw->mask_bits + (size_t)(t) * ((size_t)M * H / 8) : nullptr)      // packed keep mask of target t
+#define MT(t) (lw->mask_bits && p > 0.f ? (unsigned char*)lw->mask_bits + lora_rowmajor_bytes(H, I, M) + (size_t)(t) * (size_t)vlr_dropout_bits_kt_bytes(M, H) : nullptr)   // ... K-tile-blocked transposed
     const int rf = cfg->resid_f32;
     CHECK(norm_fwd(rf, x_in, w->ln1, a->xn1, a->rstd1, M, H, cfg->rms_eps, st));
     const int nq = lw->qkv_targets == 1 ? 1 : 3;             // one adapter over the fused projection (Qwen c_attn) or q, k, v separately
-    CHECK(lora_group_a(nq, r, H, a->xn1, H, lw->a_qkv, u, ldu, sc, p, seed + 0, ws_xd, M, st, rowmask, MB(0)));
+    CHECK(lora_group_a(nq, r, H, a->xn1, H, lw->a_qkv, u, ldu, sc, p, seed + 0, ws_xd, M, st, rowmask, MB(0), MT(0)));
     CHECK(vlr_gemm_qkv_rope_lora(a->xn1, w->wqkv, w->bqkv, a->qkv, pos, cfg->rope_cos, cfg->rope_sin, M, N, Nq + Nkv, H, H,
                                  cfg->head_dim, cfg->max_pos, u, ldu, lw->b_qkv, r, nq == 1 ? N : Nq, nq == 1 ? 0 : Nkv, st));
     CHECK(vlr_attn_fwd_gqa(a->qkv, off(a->qkv, Nq), off(a->qkv, (size_t)Nq + Nkv), N, a->attn, Nq, a->lse, key_mask, batch, S,
                            cfg->heads, kvh, cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));
-    CHECK(lora_group_a(1, r, H, a->attn, H, lw->a_o, off(u, 3 * (size_t)r), ldu, sc, p, seed + 3, XD(3), M, st, rowmask, MB(3)));
+    CHECK(lora_group_a(1, r, H, a->attn, H, lw->a_o, off(u, 3 * (size_t)r), ldu, sc, p, seed + 3, XD(3), M, st, rowmask, MB(3), MT(3)));
     if (rf) CHECK(vlr_gemm_lora_f32res(a->attn, H, w->wo, (float*)a->x_mid, H, (const float*)x_in, H, M, H, H, off(u, 3 * (size_t)r), ldu, lw->b_o, r, st));
     else CHECK(vlr_gemm_lora(a->attn, H, w->wo, a->x_mid, H, x_in, H, M, H, H, off(u, 3 * (size_t)r), ldu, lw->b_o, r, st));
     CHECK(norm_fwd(rf, a->x_mid, w->ln2, a->xn2, a->rstd2, M, H, cfg->rms_eps, st));
-    CHECK(lora_group_a(2, r, H, a->xn2, H, lw->a_gu, off(u, 4 * (size_t)r), ldu, sc, p, seed + 4, XD(4), M, st, rowmask, MB(4)));
+    CHECK(lora_group_a(2, r, H, a->xn2, H, lw->a_gu, off(u, 4 * (size_t)r), ldu, sc, p, seed + 4, XD(4), M, st, rowmask, MB(4), MT(4)));
     CHECK(vlr_gemm_swiglu_lora(a->xn2, w->wgu, a->gu, a->act, M, I, H, H, off(u, 4 * (size_t)r), ldu, lw->b_gu, r, st));
     if (lw->a_down) {
-        CHECK(lora_group_a(1, r, I, a->act, I, lw->a_down, off(u, 6 * (size_t)r), ldu, sc, p, seed + 6, XD(6), M, st, rowmask, MB(6)));
+        CHECK(lora_group_a(1, r, I, a->act, I, lw->a_down, off(u, 6 * (size_t)r), ldu, sc, p, seed + 6, XD(6), M, st, rowmask, MB(6), MT(6)));
         if (rf) CHECK(vlr_gemm_lora_f32res(a->act, I, w->wdown, (float*)a->x_out, H, (const float*)a->x_mid, H, M, H, I, off(u, 6 * (size_t)r), ldu, lw->b_down, r, st));
         else CHECK(vlr_gemm_lora(a->act, I, w->wdown, a->x_out, H, a->x_mid, H, M, H, I, off(u, 6 * (size_t)r), ldu, lw->b_down, r, st));
     } else {
@@ -306,6 +315,7 @@ extern "C" int vlr_decoder_layer_bwd_lora_ex(const vlr_llama_cfg* cfg, const vlr
     const float sc = lw->scale, p = lw->dropout;
 #define XD(seg) (ws_xd)      // ABI v4: one scratch [M][max(hidden, inter)] (the fallback path of vlr_gemm_dropout_acc), not per-target copies
 #define MB(t) (lw->mask_bits && p > 0.f ? (unsigned char*)lw->mask_bits + (size_t)(t) * ((size_t)M * H / 8) : nullptr)      // packed keep mask of target t
+#define MT(t) (lw->mask_bits && p > 0.f ? (unsigned char*)lw->mask_bits + lora_rowmajor_bytes(H, I, M) + (size_t)(t) * (size_t)vlr_dropout_bits_kt_bytes(M, H) : nullptr)   // ... K-tile-blocked transposed
     // ---- MLP
     if (g) CHECK(vlr_gemm_bf16(2, dx_out, a->act, g->wdown, nullptr, nullptr, H, I, M, H, I, I, 0, 0, accumulate, 0, st));
     static int fuse_down = -1;     // VLR_LORA_FUSE_DOWN=1: adapter term of down_proj first, then the dgrad GEMM with the SwiGLU backward in its epilogue
@@ -314,12 +324,12 @@ extern "C" int vlr_decoder_layer_bwd_lora_ex(const vlr_llama_cfg* cfg, const vlr
         // measured SLOWER than the three separate kernels (38.8 ms against 25.5 + 7.7 per step: the addend is a third 16-byte load stream
         // in an epilogue that already reads gate | up) - kept behind the switch
         CHECK(lora_group_bwd(1, r, I, o_h, a->act, dx_out, H, lw->a_down, lw->b_down, lg->a_down, lg->b_down, off(u, 6 * (size_t)r), ldu, ws_v,
-                             ws->dact, sc, p, seed + 6, XD(6), accumulate, M, st, 1, rowmask, MB(6)));
+                             ws->dact, sc, p, seed + 6, XD(6), accumulate, M, st, 1, rowmask, MB(6), MT(6)));
         CHECK(vlr_gemm_swiglu_bwd_add(dx_out, w->wdown, a->gu, ws->dact, ws->dact, M, I, H, st));   // gu now holds [dgate | dup]
     } else if (lw->a_down) {
         CHECK(vlr_gemm_bf16(1, dx_out, w->wdown, ws->dact, nullptr, nullptr, M, I, H, H, I, I, 0, 0, 0, 0, st));
         CHECK(lora_group_bwd(1, r, I, o_h, a->act, dx_out, H, lw->a_down, lw->b_down, lg->a_down, lg->b_down, off(u, 6 * (size_t)r), ldu, ws_v,
-                             ws->dact, sc, p, seed + 6, XD(6), accumulate, M, st, 0, rowmask, MB(6)));
+                             ws->dact, sc, p, seed + 6, XD(6), accumulate, M, st, 0, rowmask, MB(6), MT(6)));
         CHECK(vlr_swiglu_bwd(a->gu, ws->dact, M, I, st));   // gu now holds [dgate | dup]
     } else {
         CHECK(vlr_gemm_swiglu_bwd(dx_out, w->wdown, a->gu, ws->dact, M, I, H, st));
@@ -327,13 +337,13 @@ extern "C" int vlr_decoder_layer_bwd_lora_ex(const vlr_llama_cfg* cfg, const vlr
     if (g) CHECK(vlr_gemm_bf16(2, a->gu, a->xn2, g->wgu, nullptr, nullptr, 2 * I, H, M, 2 * I, H, H, 0, 0, accumulate, 0, st));
     CHECK(vlr_gemm_bf16(1, a->gu, w->wgu, ws->dxn, nullptr, nullptr, M, H, 2 * I, 2 * I, H, H, 0, 0, 0, 0, st));
     CHECK(lora_group_bwd(2, r, H, o_gu, a->xn2, a->gu, 2 * I, lw->a_gu, lw->b_gu, lg->a_gu, lg->b_gu, off(u, 4 * (size_t)r), ldu, ws_v,
-                         ws->dxn, sc, p, seed + 4, XD(4), accumulate, M, st, 0, rowmask, MB(4)));
+                         ws->dxn, sc, p, seed + 4, XD(4), accumulate, M, st, 0, rowmask, MB(4), MT(4)));
     CHECK(norm_bwd(cfg->resid_f32, ws->dxn, a->x_mid, w->ln2, a->rstd2, dx_out, ws->dx_mid, g ? g->ln2 : nullptr, g ? accumulate : 0, ws->norm_ws, M, H, st));
     // ---- attention
     if (g) CHECK(vlr_gemm_bf16(2, ws->dx_mid, a->attn, g->wo, nullptr, nullptr, H, Nq, M, H, Nq, Nq, 0, 0, accumulate, 0, st));
     CHECK(vlr_gemm_bf16(1, ws->dx_mid, w->wo, ws->dattn, nullptr, nullptr, M, H, H, H, H, H, 0, 0, 0, 0, st));
     CHECK(lora_group_bwd(1, r, H, o_h, a->attn, ws->dx_mid, H, lw->a_o, lw->b_o, lg->a_o, lg->b_o, off(u, 3 * (size_t)r), ldu, ws_v,
-                         ws->dattn, sc, p, seed + 3, XD(3), accumulate, M, st, 0, rowmask, MB(3)));
+                         ws->dattn, sc, p, seed + 3, XD(3), accumulate, M, st, 0, rowmask, MB(3), MT(3)));
     CHECK(vlr_attn_bwd_gqa(a->qkv, off(a->qkv, Nq), off(a->qkv, (size_t)Nq + Nkv), N, a->attn, ws->dattn, Nq, a->lse, ws->delta,
                            key_mask, ws->dqkv, off(ws->dqkv, Nq), off(ws->dqkv, (size_t)Nq + Nkv), N, batch, S, cfg->heads, kvh,
                            cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));
@@ -343,7 +353,7 @@ extern "C" int vlr_decoder_layer_bwd_lora_ex(const vlr_llama_cfg* cfg, const vlr
     const int o_all[1] = {N};
     const int nq = lw->qkv_targets == 1 ? 1 : 3;
     CHECK(lora_group_bwd(nq, r, H, nq == 1 ? o_all : o_qkv, a->xn1, ws->dqkv, N, lw->a_qkv, lw->b_qkv, lg->a_qkv, lg->b_qkv, u, ldu, ws_v, ws->dxn,
-                         sc, p, seed + 0, ws_xd, accumulate, M, st, 0, rowmask, MB(0)));
+                         sc, p, seed + 0, ws_xd, accumulate, M, st, 0, rowmask, MB(0), MT(0)));
     CHECK(norm_bwd(cfg->resid_f32, ws->dxn, x_in, w->ln1, a->rstd1, ws->dx_mid, dx_in, g ? g->ln1 : nullptr, g ? accumulate : 0, ws->norm_ws, M, H, st));
     return VLR_OK;
 }

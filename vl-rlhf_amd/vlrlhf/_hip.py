@@ -127,6 +127,7 @@ _SIGS = {
     "vlr_dropout": [P, P, L, F, U64, F, I, P],
     "vlr_dropout_mask": [P, L, F, U64, P],
     "vlr_dropout_bits": [P, L, F, U64, P],
+    "vlr_dropout_bits2": [P, P, I, I, F, U64, P],
     "vlr_layers_join": [P],
     "vlr_allreduce_bucket": [P, P, L, I, P],
     "vlr_comm_probe": [P, P, L, I, P],
@@ -171,6 +172,8 @@ def lib():
         l.vlr_lmhead_workspace_bytes.argtypes = [I, I]
         l.vlr_lora_mask_bytes.restype = C.c_long
         l.vlr_lora_mask_bytes.argtypes = [I, I, I]
+        l.vlr_dropout_bits_kt_bytes.restype = C.c_long
+        l.vlr_dropout_bits_kt_bytes.argtypes = [I, I]
         for name, sig in _SIGS.items():
             fn = getattr(l, name)
             fn.restype = I
@@ -184,7 +187,7 @@ def lib():
 
 
 def exported_symbols():
-    return list(_SIGS) + list(_INT_HELPERS) + ["vlr_last_error", "vlr_comm_library", "vlr_lmhead_workspace_bytes", "vlr_lora_mask_bytes"]
+    return list(_SIGS) + list(_INT_HELPERS) + ["vlr_last_error", "vlr_comm_library", "vlr_lmhead_workspace_bytes", "vlr_lora_mask_bytes", "vlr_dropout_bits_kt_bytes"]
 
 
 def ptr(t):
