@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--seg_ab", action="store_true", help="also time the adapter-carrying projections with the adapter K tiles on the general staging path")
     ap.add_argument("--M", type=int, default=None)
+    ap.add_argument("--dx_ablate", action="store_true", help="extra rows: the streaming dx kernel without its dx read / without the mask")
     ap.add_argument("--hash", action="store_true", help="the masked kernels hash in the kernel (ABI v4 behaviour) instead of reading packed masks")
     a = ap.parse_args()
     dev = "cuda"
@@ -108,6 +109,11 @@ def main():
         rec(f"{gname:8s} dx += mask.(v A) x{n} [M,{din},{r}]", us, 4.0 * M * din + 2.0 * M * nr, 2.0 * M * nr * din)
         us = timeit(lambda: _hip.call("vlr_gemm_dropout_acc_multi_bits", n, v, nr, A, dx, M, din, r, p, seed, sc, 1, bits, gst), a.iters)
         rec(f"{gname:8s} dx (one pass, multi)", us, 4.0 * M * din + 2.0 * M * nr, 2.0 * M * nr * din)
+        if a.dx_ablate:
+            us = timeit(lambda: _hip.call("vlr_gemm_dropout_acc_multi_bits", n, v, nr, A, dx, M, din, r, p, seed, sc, 0, bits, gst), a.iters)
+            rec(f"{gname:8s} dx multi, WRITE only (no dx read)", us, 2.0 * M * din, 0.0)
+            us = timeit(lambda: _hip.call("vlr_gemm_dropout_acc_multi_bits", n, v, nr, A, dx, M, din, r, 0.0, seed, sc, 1, None, 0), a.iters)
+            rec(f"{gname:8s} dx multi, no mask", us, 4.0 * M * din, 0.0)
 
     # the projections with / without the adapter K tiles
     wqkv, wo, wgu, wdown = rn(3 * H, H), rn(H, H), rn(2 * I, H), rn(H, I)

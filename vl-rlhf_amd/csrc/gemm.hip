@@ -515,8 +515,10 @@ static int gemm_grouped(int layout, const void* A, const void* B, void* C, int M
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     int splits = 1;
     float* ws = nullptr;
-    if (tiles * groups < 384 && K >= 1024) {
-        splits = 512 / (tiles * groups);
+    static int gtarget = -1;      // workgroups a grouped launch aims at when it splits along K (VLR_GROUPED_TARGET)
+    if (gtarget < 0) { const char* e = getenv("VLR_GROUPED_TARGET"); gtarget = e ? atoi(e) : 512; if (gtarget < 64) gtarget = 512; }
+    if (tiles * groups < gtarget * 3 / 4 && K >= 1024) {
+        splits = gtarget / (tiles * groups);       // (rounded down on purpose: 2 x 300 workgroups of half the depth measured slower than 300 whole ones)
         if (splits > 16) splits = 16;
         if (splits > K / 256) splits = K / 256;
         ws = splits >= 2 ? splitk_slot(stream) : nullptr;

@@ -57,7 +57,7 @@ __device__ __forceinline__ bf16x8 dx_frag_ks(const char* tile, int cbase, int s,
 // NT targets, KT = r / 64 K tiles per target, MASK: 0 no dropout, 1 keep masks (packed bits when p.bits, else hashed)
 template <int NT, int KT, int MASK>
 __global__ __launch_bounds__(256) void lora_dx_kernel(LoraDxParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // 2 units x KT x 16 KiB
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // 2 units x KT x 16 KiB | 2 x 1 KiB packed-mask tiles
     constexpr int KS = 2 * KT;                                        // k slices of 32 per target
     constexpr int UNIT_BYTES = KT * 16384;
     const int t_ = threadIdx.x;
@@ -121,19 +121,26 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(LoraDxParams p) {
                 d[i][j] = w;
             }
     };
-    auto load_keep = [&](int u, uint32_t (&k)[2][4]) {
+    // keep masks of unit u.  Packed bits: wave 0 moves the [64 rows][16 B] tile of (column tile, target) into LDS with ONE LDS-DMA
+    // instruction (lane = row) a unit ahead - visible to every wave after the next vmcnt(0) + barrier - and a lane reads its eight nibbles
+    // from there (the first version loaded them as 8 scattered global bytes per lane: 86 us of the 196 us of the q, k, v launch).
+    // Hash form: computed into registers a unit ahead.
+    const uint32_t lbits = (uint32_t)(uintptr_t)(dx_lvoid_t*)smem + 2 * UNIT_BYTES;
+    auto stage_keep = [&](int u) {
         if constexpr (MASK) {
-            const int c = c_lo + u / NT, t = u % NT;
-            if (p.bits) {
-                const unsigned char* bt = p.bits + (size_t)t * p.gbits;
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int row = rowv[i] < p.M ? rowv[i] : p.M - 1;
-                        k[i][j] = bt[((size_t)row * p.in + c * 128 + cl + j * 16) >> 3];        // (the nibble is picked when it is used)
-                    }
-            } else {
+            if (p.bits && wave == 0) {
+                const int c = c_lo + u / NT, t = u % NT;
+                int row = m0 + lane;
+                row = row < p.M ? row : p.M - 1;
+                const unsigned char* g = p.bits + (size_t)t * p.gbits + (((size_t)row * p.in + c * 128) >> 3);
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lbits + (u & 1) * 1024) : "memory", "m0");
+            }
+        }
+    };
+    auto hash_keep = [&](int u, uint32_t (&k)[2][4]) {
+        if constexpr (MASK) {
+            if (!p.bits) {
+                const int c = c_lo + u / NT, t = u % NT;
                 const uint64_t key = vlr_mix64(p.seed + (uint64_t)t);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -149,11 +156,11 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(LoraDxParams p) {
             }
         }
     };
-
     f32x4 sum[2][4];
     stage_unit(0);
     if (p.accumulate) load_dx(c_lo, dxr);
-    load_keep(0, kb);
+    stage_keep(0);
+    hash_keep(0, kb);
     for (int u = 0; u < nunits; ++u) {
         const int c = c_lo + u / NT, t = u % NT;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -167,7 +174,8 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(LoraDxParams p) {
         u32x2 dx_n[2][4];
         const bool last_t = t == NT - 1;
         if (u + 1 < nunits) {
-            load_keep(u + 1, kb_n);
+            stage_keep(u + 1);
+            hash_keep(u + 1, kb_n);
             if (last_t && p.accumulate) load_dx(c + 1, dx_n);
         }
         if (t == 0) {
@@ -182,6 +190,7 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(LoraDxParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         const char* tile = smem + (u & 1) * UNIT_BYTES;
+        const unsigned char* bt_lds = reinterpret_cast<const unsigned char*>(smem) + 2 * UNIT_BYTES + (u & 1) * 1024;
         // (static dispatch on the target: the v fragments are a register array)
         auto run = [&](auto tc) {
             constexpr int T = decltype(tc)::value;
@@ -205,7 +214,8 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(LoraDxParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if constexpr (MASK) {
-                    const uint32_t keep = kb[i][j] >> (cl & 4);
+                    const uint32_t kbyte = p.bits ? (uint32_t)bt_lds[(wr * 32 + i * 16 + lm) * 16 + ((cl + j * 16) >> 3)] : kb[i][j];
+                    const uint32_t keep = kbyte >> (cl & 4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) sum[i][j][e] += ((keep >> e) & 1) ? p.alpha * acc[i][j][e] : 0.f;
                 } else {
@@ -243,7 +253,7 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(LoraDxParams p) {
 
 template <int NT, int KT>
 static void dx_launch_m(const LoraDxParams& p, int mask, dim3 grid, hipStream_t stream) {
-    const int lds = 2 * KT * 16384;
+    const int lds = 2 * KT * 16384 + 2048;
     if (mask) {
         static bool a1 = false;
         if (!a1) { hipFuncSetAttribute((const void*)lora_dx_kernel<NT, KT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); a1 = true; }
