@@ -6,7 +6,7 @@ as extra K tiles (against the same projection without it).
     python tools/lora_gemm_bench.py [--shape llava|internlm] [--iters 10] [--seg_ab]
 
 llava:    M = 12792 rows, r = 128, q / k / v separately adapted, lora_dropout 0.05 (scripts/ddpo_llava.sh)
-internlm: M = 13888 rows (4 pairs x S = 1736), r = 256, ONE adapter over wqkv (PLoRA), dropout 0.05
+internlm: M = 13888 rows (4 pairs x S = 1736), r = 256, intermediate 14336, ONE adapter over wqkv (PLoRA), dropout 0.05
 """
 import argparse
 import os
@@ -51,7 +51,7 @@ def main():
     if a.shape == "llava":
         M, r, nq, hd = a.M or 12792, 128, 3, 128
     else:
-        M, r, nq, hd = a.M or 13888, 256, 1, 128
+        M, r, nq, hd, I = a.M or 13888, 256, 1, 128, 14336        # InternLM2-7B: intermediate 14336 (its grouped-query wqkv is 6144 wide; the qkv rows below keep 12288)
     p, seed, sc = 0.05, 1234, 2.0
     g = torch.Generator(device=dev).manual_seed(0)
     rn = lambda *s: (torch.randn(*s, device=dev, generator=g) * 0.05).bfloat16()      # noqa: E731
