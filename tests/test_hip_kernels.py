@@ -1360,7 +1360,7 @@ def test_gemm_grouped_masked(hip, M, in_, r, groups):
         check(vv[:, t * r:(t + 1) * r], ref, 8e-3, f"grouped NN accumulate, target {t}")
 
 
-@pytest.mark.parametrize("M,in_,r,n,p", [(12792, 4096, 128, 3, 0.05), (1406, 1024, 64, 2, 0.25), (300, 256, 16, 1, 0.0)])
+@pytest.mark.parametrize("M,in_,r,n,p", [(12792, 4096, 128, 3, 0.05), (1406, 1024, 64, 2, 0.25), (300, 256, 16, 1, 0.0), (2248, 2048, 256, 2, 0.05), (1000, 1024, 256, 1, 0.0)])
 def test_gemm_dropout_acc_multi(hip, M, in_, r, n, p):
     """vlr_gemm_dropout_acc_multi: dx (+)= scale / (1 - p) * sum_t mask_t . (v_t A_t) for the n targets of a group in ONE pass over dx,
     against torch with the masks of vlr_dropout_mask; both the accumulate and the write form"""
