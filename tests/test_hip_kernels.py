@@ -1521,3 +1521,43 @@ def test_dropout_bits_and_masked_gemms_with_bits(hip, M, in_, r, n, p):
     hip.call("vlr_gemm_dropout_acc_multi_bits", n, v, n * r, A, a3, M, in_, r, p, seed, scale, 1, bits, gstride)
     torch.cuda.synchronize()
     assert torch.equal(a2, a3), "dropout-accumulate, one pass"
+
+
+# ---------------------------------------------------------------------------------------------------- 128x128 ring kernel, other ring depths
+_RING_PROBE = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+from vlrlhf import _hip
+_hip.ensure_splitk_workspace("cuda", force=True)
+g = torch.Generator().manual_seed(0)
+rn = lambda *s: (torch.randn(*s, generator=g) * 0.5).bfloat16().cuda()
+worst = 0.0
+for layout, (M, N, K) in [(0, (504, 1024, 4096)), (1, (504, 1024, 4096)), (2, (1024, 512, 5000)), (0, (200, 136, 72)), (1, (300, 264, 1000)), (2, (136, 200, 777 * 4))]:
+    a = rn(M, K) if layout != 2 else rn(K, M)
+    b = rn(N, K) if layout == 0 else rn(K, N)
+    c = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    lda = K if layout != 2 else M
+    ldb = K if layout == 0 else N
+    _hip.call("vlr_gemm_bf16", layout, a, b, c, None, None, M, N, K, lda, ldb, N, 0, 0, 0, 0)
+    A = a.float() if layout != 2 else a.float().t()
+    B = b.float().t() if layout == 0 else b.float()
+    ref = A @ B
+    torch.cuda.synchronize()
+    worst = max(worst, float((c.float() - ref).abs().max()) / float(ref.abs().max()))
+print("WORST", worst)
+"""
+
+
+@pytest.mark.parametrize("depth", ["3", "4", "0"])
+def test_gemm128_ring_depths(depth):
+    """VLR_GEMM128P is read once per process: the ring depths the default (2) does not use, and the register-staged kernel (0), in a child
+    process each - NT / NN / TN, split along K and not, ragged edges and a K tail."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VLR_GEMM128P=depth)
+    r = subprocess.run([sys.executable, "-c", _RING_PROBE, root, os.path.join(root, "vl-rlhf_amd")], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    worst = float(r.stdout.strip().splitlines()[-1].split()[1])
+    assert worst < 8e-3, (depth, worst)
