@@ -57,6 +57,12 @@ int vlr_gemm_bf16_f32res(int layout, const void* A, const void* B, float* C, con
  * K >= 1024; otherwise a launch runs plain rounds.  -1 = back to the default (environment VLR_GEMM_SCHED, else the built-in one).
  * Results are bit-identical run to run for a given mode; different modes sum K in different orders (last-bit differences). */
 int vlr_gemm_set_sched(int mode);
+/* Diagnostics only: the tile timeline of the persistent GEMM launches.  With a non-NULL buffer of >= 256 KiB every later launch of the
+ * 256x256 continuous-pipeline kernel leaves, for each workgroup b, words [b*256 + 4*i .. +3] = {tile id, and the 100 MHz clock after the
+ * first K tile / after the K loop / after the epilogue's stores were issued} of its i-th tile, and [b*256 + 252 ..] = {tiles, start
+ * clock, K tiles per tile}.  Recorded only by the library built with -DVLR_GEMM_TRACE (`build_hip.py --trace`,
+ * tools/gemm_tile_trace.py); the production build returns VLR_ERR_ARG.  (NULL, 0) switches it off. */
+int vlr_gemm_set_trace(void* buf, long bytes);
 /* Optional fp32 scratch for split-K: problems with few output tiles and a long reduction (the LoRA adapter gradients;
  * the ragged last tile rows of the decoder GEMMs) are split along K into fp32 partials and reduced by a second kernel
  * that applies the epilogue.  Without it they run un-split.  The buffer is cut in 128 MiB slots (at most eight; below 256 MiB in

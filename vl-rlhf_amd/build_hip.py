@@ -28,10 +28,15 @@ def _digest():
     return h.hexdigest()
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, defines=(), tag=""):
+    """defines / tag: a diagnostics variant of the library (e.g. defines=("VLR_GEMM_TRACE",), tag="_trace" -> libvlr_hip_trace.so with
+    its own object directory), loaded through VLR_LIB; the product build is the one with neither."""
+    OBJ = os.path.join(HERE, "build" + tag)
+    LIB = os.path.join(HERE, f"libvlr_hip{tag}.so")
+    FLAGS = globals()["FLAGS"] + [f"-D{d}" for d in defines]
     os.makedirs(OBJ, exist_ok=True)
     stamp = os.path.join(OBJ, "stamp")
-    dg = _digest()
+    dg = _digest() + "".join(defines)
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dg:
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -65,4 +70,7 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--trace" in sys.argv:      # tile-timeline diagnostics of the persistent GEMM (tools/gemm_tile_trace.py)
+        build(force="--force" in sys.argv, defines=("VLR_GEMM_TRACE",), tag="_trace")
+    else:
+        build(force="--force" in sys.argv)

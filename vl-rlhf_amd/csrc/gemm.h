@@ -89,6 +89,9 @@ struct GemmParams {
     const unsigned char* mask_bits;
     long gMask;
     const unsigned char* drop_bits;
+#ifdef VLR_GEMM_TRACE
+    uint32_t* trace;         // diagnostics build only: set by the launchers of gemm256p.hip (vlr_gemm_set_trace), never by callers
+#endif
 };
 #define VLR_SCHED_DEFAULT 0           // GemmParams::sched when VLR_GEMM_SCHED is not set
 #define VLR_SK_MIN_KTILES 16          // stream-K / rotation only for K >= 1024

@@ -209,6 +209,28 @@ __device__ __forceinline__ int widen_col(int lq) { return (lq & 1) * 16 + (lq >>
 #define PWAIT_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
 #define PWAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
+// Diagnostics build only (-DVLR_GEMM_TRACE, build_hip.py --trace -> libvlr_hip_trace.so; tools/gemm_tile_trace.py): wave 0 of every
+// workgroup stamps s_memrealtime (100 MHz) after the first K tile, after the K loop and after the epilogue's last store has been
+// ISSUED of every piece into the free words of its piece-table entry and copies them out at the end - the timeline of the tiles of a
+// persistent launch (are the epilogues of the 256 workgroups in phase?  what does an epilogue cost?  does the next tile's first
+// counted wait stall behind the stores?).  SMEM returns out of order with LDS reads on lgkmcnt, hence the full wait after it.
+#ifdef VLR_GEMM_TRACE
+static uint32_t* g_trace = nullptr;
+#define TSTAMP(slot_)                                                                  \
+    do {                                                                               \
+        if (p.trace && wave == 0) {                                                    \
+            const uint64_t t__ = __builtin_amdgcn_s_memrealtime();                     \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                         \
+            if (lane0 == 0) ptab[(slot_)] = (int)(uint32_t)t__;                        \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                         \
+        }                                                                              \
+    } while (0)
+#define TRACE_SET(p_) (p_).trace = g_trace
+#else
+#define TSTAMP(slot_) do { } while (0)
+#define TRACE_SET(p_) do { } while (0)
+#endif
+
 // CONT = true: continuous pipeline across the output tiles of a persistent workgroup (plain bf16 epilogue only): the last K tiles
 // of tile i stage the first K tiles of tile i+1 (same slots, same counted wait), the epilogue stores straight from the
 // accumulator registers (8 bytes per lane, no LDS, no barrier) and the K loop of tile i+1 starts with its data resident.
@@ -313,6 +335,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     }
     __syncthreads();
     if (npieces <= 0) return;
+    TSTAMP(511 * 8 + 5);
     int parb = 0;                 // CONT: buffer parity of the current piece's K tile 0 (K tiles keep alternating across pieces)
     for (int titer = 0;; ++titer) {
     // per-tile opaque copy of the lane id: keeps hipcc from hoisting every lane-derived address out of the tile loop (it did,
@@ -609,8 +632,12 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     const int lim = ((SEG && ((p.K2 % PK) != 0 || (p.sched & 8))) ? nt1 : nt) - (ktail ? 1 : 0) - kb;
     const int n_fast = (ntp < lim ? ntp : lim) - 2;
     int kt = 0;
+#ifdef VLR_GEMM_TRACE
+    if (n_fast > 0) { ktile(0, FAST{}); kt = 1; TSTAMP(titer * 8 + 5); }
+#endif
     for (; kt < n_fast; ++kt) ktile(kt, FAST{});
     for (; kt < ntp; ++kt) ktile(kt, SLOW{});
+    TSTAMP(titer * 8 + 6);
 #undef PMFMA
     // ---- stream-K / rotation hand-off of the fp32 accumulators (GemmParams::sched).  Slab = this wave's 128 accumulator registers as
     // 64 x (64 lanes x 8 B): fully coalesced, agent-scope write-through stores / loads (sc1) - no fence, no barrier: wave w of the
@@ -957,6 +984,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
       }
     }
     if constexpr (CONT) {
+        TSTAMP(titer * 8 + 7);
         parb = (parb + ntp) & 1;
         if (!has_next) {
             if (wr == 0) PBAR();  // balance the extra barrier of waves 4-7
@@ -1107,6 +1135,19 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     __syncthreads();              // every wave is done with the LDS image / patches before the next tile's DMA lands
     if (titer + 1 >= npieces) break;            // (per-tile kernels: whole tiles only)
     }   // persistent tile loop
+#ifdef VLR_GEMM_TRACE
+    if (CONT && p.trace && wave == 0) {          // [block][64 pieces][4] = {m0 / 256 << 16 | n0 / 128, first K tile, K loop, epilogue}; [block][63] = {npieces, start, nt, 0}
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        uint32_t* out = p.trace + (size_t)blockIdx.x * 256;
+        for (int i = lane0; i < npieces && i < 63; i += 64) {
+            out[i * 4 + 0] = ((uint32_t)(ptab[i * 8 + 0] / PT) << 16) | (uint32_t)(ptab[i * 8 + 1] / 128);
+            out[i * 4 + 1] = (uint32_t)ptab[i * 8 + 5];
+            out[i * 4 + 2] = (uint32_t)ptab[i * 8 + 6];
+            out[i * 4 + 3] = (uint32_t)ptab[i * 8 + 7];
+        }
+        if (lane0 == 0) { out[252] = (uint32_t)npieces; out[253] = (uint32_t)ptab[511 * 8 + 5]; out[254] = (uint32_t)nt; out[255] = 0; }
+    }
+#endif
 }
 
 static int gemm256p_n_cu() { return vlr_compute_cus(); }      // grid of the persistent launches (whole XCD octets; 256 on MI355X)
@@ -1156,6 +1197,7 @@ bool vlr_gemm256p_fused_try_launch(const GemmParams& p_in, hipStream_t stream) {
     if (p.fuse == 1 && ((p.N >> 1) % 8 != 0 || p.ldc2 % 8 != 0 || ((uintptr_t)p.C2 & 15))) return false;
     if ((((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.C) & 15) || p.lda % 8 != 0 || p.ldb % 8 != 0 || p.ldc % 8 != 0) return false;
     sk_prepare(p, ntiles, grid, stream);
+    TRACE_SET(p);
     const int pi = vlr_prof_begin(VLR_K_GEMM256P, 2.0 * p.M * p.N * p.K, stream);
     if (p.fuse == 1) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 1>), dim3(grid), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
     else hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 2>), dim3(grid), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
@@ -1194,6 +1236,7 @@ bool vlr_gemm256p_seg_try_launch(const GemmParams& p_in, hipStream_t stream) {
     if (p.out_f32) {          // fp32 residual stream: y fp32 = x W^T + u Bl^T + residual fp32 (register-direct 16-byte accesses)
         if (p.fuse != 0 || p.ldc % 4 != 0 || (p.residual && (!p.res_f32 || p.ldr % 4 != 0 || ((uintptr_t)p.residual & 15)))) return false;
     } else if (p.residual && (p.res_f32 || p.fuse != 0 || p.ldr % 4 != 0 || ((uintptr_t)p.residual & 7) || (const void*)p.residual == (const void*)p.C)) return false;
+    TRACE_SET(p);
     const int pi = vlr_prof_begin(VLR_K_GEMM256P, 2.0 * p.M * p.N * (p.K + p.K2), stream);
     if (p.fuse == 0) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 0, true>), dim3(grid), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
     else if (p.fuse == 1) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 1, true>), dim3(grid), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
@@ -1204,7 +1247,9 @@ bool vlr_gemm256p_seg_try_launch(const GemmParams& p_in, hipStream_t stream) {
 
 // dx [M][N] += keep ? alpha * (A [M][K] . B [K][N]) : 0 (NN; fuse 6).  Any tile count >= 192 (K is the adapter rank: the launch is
 // store-bound, no peeling); false -> the caller materialises the product and runs the dropout-accumulate kernel.
-bool vlr_gemm256p_dropacc_try_launch(const GemmParams& p, hipStream_t stream) {
+bool vlr_gemm256p_dropacc_try_launch(const GemmParams& p_in, hipStream_t stream) {
+    GemmParams p = p_in;
+    TRACE_SET(p);
     static int on = -1;
     if (on < 0) {
         const char* e = getenv("VLR_GEMM_DROPACC");
@@ -1242,10 +1287,23 @@ bool vlr_gemm256p_swiglu_bwd_try_launch(const GemmParams& p_in, hipStream_t stre
     const int grid = ntiles > n_cu ? n_cu : ntiles;
     if ((((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.C2) & 15) || p.lda % 8 != 0 || p.ldb % 8 != 0 || p.N % 8 != 0 || p.ldc2 % 8 != 0) return false;
     sk_prepare(p, ntiles, grid, stream);
+    TRACE_SET(p);
     const int pi = vlr_prof_begin(VLR_K_GEMM256P, 2.0 * p.M * p.N * p.K, stream);
     hipLaunchKernelGGL((gemm256p_kernel<false, true, 0, true, 3>), dim3(grid), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
     vlr_prof_end(pi, stream);
     return true;
+}
+
+// diagnostics (include/vlr.h): tile timeline of the persistent launches; only the -DVLR_GEMM_TRACE build records anything
+extern "C" int vlr_gemm_set_trace(void* buf, long bytes) {
+#ifdef VLR_GEMM_TRACE
+    VLR_REQUIRE(!buf || bytes >= 256L * 1024, "vlr_gemm_set_trace: the buffer holds 256 words for each of 256 workgroups (256 KiB), got %ld bytes", bytes);
+    g_trace = (uint32_t*)buf;
+    return VLR_OK;
+#else
+    (void)buf; (void)bytes;
+    VLR_REQUIRE(false, "vlr_gemm_set_trace: this library was built without -DVLR_GEMM_TRACE (python vl-rlhf_amd/build_hip.py --trace)");
+#endif
 }
 
 int vlr_gemm256p_lmhead_parts(int V) { return ((V + PT - 1) / PT) * 4; }
@@ -1268,6 +1326,7 @@ bool vlr_gemm256p_lmhead_try_launch(const GemmParams& p_in, hipStream_t stream) 
     if ((((uintptr_t)p.A | (uintptr_t)p.B) & 15) || p.lda % 8 != 0 || p.ldb % 8 != 0 || p.N % 8 != 0) return false;
     if (p.fuse == 5 && (p.ldc % 8 != 0 || ((uintptr_t)p.C & 15))) return false;
     sk_prepare(p, ntiles, n_cu, stream);
+    TRACE_SET(p);
     const int pi = vlr_prof_begin(VLR_K_GEMM256P, 2.0 * p.M * p.N * p.K, stream);
     if (p.fuse == 4) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 4>), dim3(n_cu), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
     else hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 5>), dim3(n_cu), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
@@ -1279,6 +1338,7 @@ bool vlr_gemm256p_lmhead_try_launch(const GemmParams& p_in, hipStream_t stream) 
 bool vlr_gemm256p_try_launch(int layout, const GemmParams& p_in, hipStream_t stream) {
     GemmParams p = p_in;
     p.sched = 0; p.sk_ws = nullptr; p.sk_epoch = 0;
+    TRACE_SET(p);
     static int mode = -1;
     static bf16_t* zero16 = nullptr;
     if (mode < 0) {

@@ -142,6 +142,7 @@ _INT_HELPERS = {
     "vlr_prof_collect": [P, I],
     "vlr_gemm_set_splitk_workspace": [P, L],
     "vlr_gemm_set_sched": [I],
+    "vlr_gemm_set_trace": [P, L],
     "vlr_set_comm_cus": [I],
     "vlr_compute_cus": [],
     "vlr_lmhead_is_fused": [I, I, I],
