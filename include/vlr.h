@@ -50,12 +50,10 @@ int vlr_gemm_bf16_scaled(int layout, const void* A, const void* B, void* C, cons
  * LlamaDecoderLayer.forward (call site src/vlrlhf/models/Llava/__init__.py:232) without the bf16 rounding of the sum. */
 int vlr_gemm_bf16_f32res(int layout, const void* A, const void* B, float* C, const float* residual, int M, int N, int K,
                          int lda, int ldb, int ldc, int ldr, vlr_stream_t stream);
-/* Tile schedule of the persistent (continuous-pipeline) GEMM launches: bit 0 = stream-K tail (the last 1.x rounds of an XCD's tiles
- * are cut into equal K ranges per workgroup; a tile shared by two workgroups is finished by one of them from the other's fp32
- * accumulator slab - fixed order, deterministic), bit 1 = XCD rotation (the eight XCDs' tile boundaries are offset by 1/8 of a tile so
- * that their output-store bursts do not coincide).  Both need the 128 MiB-per-stream scratch of vlr_gemm_set_splitk_workspace and
- * K >= 1024; otherwise a launch runs plain rounds.  -1 = back to the default (environment VLR_GEMM_SCHED, else the built-in one).
- * Results are bit-identical run to run for a given mode; different modes sum K in different orders (last-bit differences). */
+/* A/B switches of the persistent (continuous-pipeline) GEMM launches, 0 in production: 8 = the adapter-segment K tiles take the general
+ * staging path, 16 = the two wave groups of a workgroup run their epilogues one after the other (the order before round 4; results are
+ * bit-identical to 0).  -1 = back to the default (environment VLR_GEMM_SCHED, else 0).  The tile schedules 1-7 of ABI v5 (stream-K tail,
+ * XCD rotation, XCD round barrier) measured slower or neutral and are rejected with VLR_ERR_ARG. */
 int vlr_gemm_set_sched(int mode);
 /* Diagnostics only: the tile timeline of the persistent GEMM launches.  With a non-NULL buffer of >= 256 KiB every later launch of the
  * 256x256 continuous-pipeline kernel leaves, for each workgroup b, words [b*256 + 4*i .. +3] = {tile id, and the 100 MHz clock after the
@@ -66,7 +64,7 @@ int vlr_gemm_set_trace(void* buf, long bytes);
 /* Optional fp32 scratch for split-K: problems with few output tiles and a long reduction (the LoRA adapter gradients;
  * the ragged last tile rows of the decoder GEMMs) are split along K into fp32 partials and reduced by a second kernel
  * that applies the epilogue.  Without it they run un-split.  The buffer is cut in 128 MiB slots (at most eight; below 256 MiB in
- * total: 64 MiB slots, which cover the split-K partials of the 7B shapes but not the stream-K slabs of vlr_gemm_set_sched), one per
+ * total: 64 MiB slots, which cover the split-K partials of the 7B shapes), one per
  * distinct stream that launches such a GEMM (policy pass, reference pass on a side stream, ...); further streams run un-split.
  * Registering again forgets the stream assignment.  (NULL, 0) unregisters. */
 int vlr_gemm_set_splitk_workspace(void* workspace, long bytes);

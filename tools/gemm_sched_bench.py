@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Within-process A/B of the persistent-GEMM tile schedules (vlr_gemm_set_sched: 0 plain rounds, 1 stream-K tail, 2 XCD rotation,
-3 both) on the GEMM shapes of the LLaVA-1.5-7B DPO step (M = 12792 token rows): interleaved rounds, median and min per mode.
+"""Within-process A/B of the persistent GEMM's switches (vlr_gemm_set_sched: 0 default, 16 serial epilogue order; round 3 used it for the
+stream-K / rotation schedules 1-3, since removed) on the GEMM shapes of the LLaVA-1.5-7B DPO step (M = 12792 token rows): interleaved
+rounds, median and min per mode.  With one mode it is the per-layer GEMM microbenchmark (A/B two builds of the library through VLR_LIB).
 
-    python tools/gemm_sched_bench.py [--rounds 5] [--modes 0,1,2,3]
+    python tools/gemm_sched_bench.py [--rounds 5] [--modes 0,16]
 """
 import argparse
 import os
@@ -21,7 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=8)
-    ap.add_argument("--modes", default="0,1,2,3")
+    ap.add_argument("--modes", default="0")
     ap.add_argument("--M", type=int, default=12792)
     a = ap.parse_args()
     modes = [int(m) for m in a.modes.split(",")]

@@ -62,15 +62,9 @@ struct GemmParams {
     // ---- fp32 residual stream (vlr_llama_cfg::resid_f32): residual is read as fp32 [M][ldr]; with out_f32 the o_proj / down_proj
     // launches are C fp32 = acc + residual fp32 (no rounding of the stream at all)
     int res_f32;
-    // ---- persistent schedule of the continuous-pipeline kernels (gemm256p.hip "pieces"): sched bit 0 = stream-K tail (the last
-    // 1.x rounds of an XCD's tiles are cut into equal K ranges per workgroup; a tile shared by two workgroups is finished by the one
-    // that holds its head, the other leaves its fp32 accumulators in a slab), bit 1 = XCD rotation (the workgroups of XCD x start their
-    // first tile at K offset x/8 and finish its head last, through their own slab: the eight XCDs' epilogue store bursts no longer
-    // coincide).  sk_ws: 128 MiB of the caller's registered scratch (one per stream): partner slabs [0, 62 MiB), per-wave flags at
-    // 62 MiB, self slabs at 64 MiB; sk_epoch: launch counter (a flag equal to it = slab published).  sched = 0: plain rounds.
+    // ---- A/B switches of the continuous-pipeline kernels (vlr_gemm_set_sched): bit 3 = adapter K tiles on the general staging path,
+    // bit 4 = the two wave groups run their epilogues one after the other (the order before round 4).  0 in production.
     int sched;
-    float* sk_ws;
-    uint32_t sk_epoch;
     // ---- 128x128 kernel only (gemm.hip): GROUPED launches and an on-the-fly lora_dropout mask.
     // groups > 1: blockIdx.z = group g runs the same problem shape on A + g * gA, B + g * gB, C + g * gC (elements of each type) -
     //   the skinny per-target GEMMs of a LoRA group (q, k, v / gate, up) in ONE launch that fills the chip instead of three at 39 %.
@@ -91,16 +85,10 @@ struct GemmParams {
     const unsigned char* drop_bits;
 #ifdef VLR_GEMM_TRACE
     uint32_t* trace;         // diagnostics build only: set by the launchers of gemm256p.hip (vlr_gemm_set_trace), never by callers
+    int dephase_p, dephase_ticks;
 #endif
 };
 #define VLR_SCHED_DEFAULT 0           // GemmParams::sched when VLR_GEMM_SCHED is not set
-#define VLR_SK_MIN_KTILES 16          // stream-K / rotation only for K >= 1024
-#define VLR_SK_SLAB_FLOATS 65536      // 256 x 256 fp32 accumulators of one workgroup
-#define VLR_SK_FLAG_OFF (62L << 20)   // byte offsets inside sk_ws
-#define VLR_SK_SELF_OFF (64L << 20)
-#define VLR_SK_WS_BYTES (128L << 20)
-// scratch slot of `stream` when it is at least VLR_SK_WS_BYTES (gemm.hip: vlr_gemm_set_splitk_workspace), else null; bumps the epoch
-float* vlr_gemm_sk_workspace(hipStream_t stream, uint32_t* epoch);
 int vlr_gemm_sched_mode();
 
 __device__ __forceinline__ float apply_act(float v, int act) {

@@ -408,15 +408,12 @@ static int g_splitk_nstream = 0;
 extern "C" int vlr_gemm_set_splitk_workspace(void* ws, long bytes) {
     VLR_REQUIRE((ws && bytes > 0) || (!ws && bytes == 0), "vlr_gemm_set_splitk_workspace: (ptr, bytes) or (NULL, 0)");
     g_splitk_ws = (float*)ws;
-    // slots of 128 MiB (split-K partials of the 7B shapes in the first 64 MiB; the stream-K / rotation slabs of the persistent GEMM
-    // kernels - gemm.h, GemmParams::sched - use all of it), one per stream, at most 8; below 256 MiB: 64 MiB slots (no slabs: the
-    // persistent kernels then run plain rounds); a still smaller buffer is cut in two
-    int n = (int)(bytes / VLR_SK_WS_BYTES);
+    // slots of 128 MiB, one per stream, at most 8; below 256 MiB: 64 MiB slots (the split-K partials of the 7B shapes fit those); a still
+    // smaller buffer is cut in two.  (Round 3 kept per-wave flags and accumulator slabs of the stream-K experiments in these slots; gone.)
+    int n = (int)(bytes / (128L << 20));
     if (n > SPLITK_MAX_SLOTS) n = SPLITK_MAX_SLOTS;
     if (n >= 2) {
-        g_splitk_nslots = n; g_splitk_bytes = VLR_SK_WS_BYTES;
-        for (int i = 0; i < n; ++i)        // flags = "published at launch epoch e"; epochs start at 1 and never repeat
-            if (hipMemset((char*)ws + (size_t)i * VLR_SK_WS_BYTES + VLR_SK_FLAG_OFF, 0, 64 << 10) != hipSuccess) { g_splitk_nslots = 0; break; }
+        g_splitk_nslots = n; g_splitk_bytes = 128L << 20;
     } else {
         n = (int)(bytes / SPLITK_SLOT_BYTES);
         if (n > SPLITK_MAX_SLOTS) n = SPLITK_MAX_SLOTS;
@@ -426,19 +423,22 @@ extern "C" int vlr_gemm_set_splitk_workspace(void* ws, long bytes) {
     g_splitk_nstream = 0;
     return VLR_OK;
 }
-// persistent schedule of the continuous-pipeline GEMM kernels (GemmParams::sched): bit 0 stream-K tail, bit 1 XCD rotation.
-// Default from VLR_GEMM_SCHED (else 0 until measured - see DESIGN.md); vlr_gemm_set_sched(-1) re-reads the environment.
+// A/B switches of the continuous-pipeline GEMM kernels (GemmParams::sched): bit 3 (8) adapter K tiles on the general staging path,
+// bit 4 (16) the two wave groups of a workgroup run their epilogues one after the other (the order before round 4).  Default from
+// VLR_GEMM_SCHED (else 0); vlr_gemm_set_sched(-1) re-reads the environment.  The tile schedules of round 3 (bits 0-2: stream-K tail, XCD
+// rotation, XCD round barrier) measured slower or neutral and were removed.
 static int g_sched = -1;
 int vlr_gemm_sched_mode() {
-    if (g_sched < 0) { const char* e = getenv("VLR_GEMM_SCHED"); g_sched = e ? (atoi(e) & 15) : VLR_SCHED_DEFAULT; }
+    if (g_sched < 0) { const char* e = getenv("VLR_GEMM_SCHED"); g_sched = e ? (atoi(e) & 24) : VLR_SCHED_DEFAULT; }
     return g_sched;
 }
 extern "C" int vlr_gemm_set_sched(int mode) {
-    VLR_REQUIRE(mode >= -1 && mode <= 15, "vlr_gemm_set_sched: mode 0..15 (bit 0 stream-K tail, bit 1 XCD rotation, bit 2 XCD round barrier, bit 3 adapter tiles on the general path) or -1, got %d", mode);
+    VLR_REQUIRE(mode == -1 || (mode >= 0 && (mode & ~24) == 0),
+                "vlr_gemm_set_sched: 0, 8 (adapter tiles on the general staging path), 16 (serial epilogue order), 24 or -1, got %d "
+                "(the stream-K / rotation / round-barrier schedules 1-7 of round 3 were removed: measured slower)", mode);
     g_sched = mode;
     return VLR_OK;
 }
-static uint32_t g_sk_epoch = 0;
 // Which split a GEMM takes must not depend on which OTHER streams happened to run split-K GEMMs earlier in the process: the
 // reference pass (side stream) and the policy pass (main stream) of one step have to produce bit-identical results for
 // identical weights (policy == reference => loss == ln 2 exactly).  With two slots, a third stream - e.g. a new trainer's side
@@ -454,12 +454,6 @@ static float* splitk_slot(hipStream_t st) {
         return (float*)((char*)g_splitk_ws + (size_t)(g_splitk_nstream++) * g_splitk_bytes);
     }
     return nullptr;
-}
-float* vlr_gemm_sk_workspace(hipStream_t stream, uint32_t* epoch) {
-    if (g_splitk_bytes < VLR_SK_WS_BYTES) return nullptr;
-    float* ws = splitk_slot(stream);
-    if (ws) *epoch = ++g_sk_epoch;
-    return ws;
 }
 // split-K launch of the 128x128 kernel: few output tiles, long reduction.  Returns false when it does not apply.
 // one launch of the 128x128-tile GEMM: the LDS-DMA ring kernel (gemm128p.hip) when the operands qualify, else the register-staged one
@@ -623,8 +617,6 @@ static int gemm_impl(int layout, const void* A, const void* B, void* C, const vo
 static int choose_peel(int M, int N, int tn, int K = 0, hipStream_t stream = nullptr, bool tail256 = false) {
     const int tm256 = (M + 255) / 256;
     int peel = 0;
-    // stream-K tail (GemmParams::sched bit 0): the persistent kernel balances its last rounds itself - every row takes the same path
-    if ((vlr_gemm_sched_mode() & 1) && K >= VLR_SK_MIN_KTILES * 64 && g_splitk_bytes >= VLR_SK_WS_BYTES && splitk_slot(stream)) return 0;
     const int ncu = vlr_compute_cus();          // workgroups of a persistent round (256 on MI355X; fewer when CUs are left to RCCL)
     if ((long)tm256 * tn >= 2 * ncu) {
         const int full = tm256 * tn;
@@ -693,7 +685,7 @@ static int gemm_impl_ex(int layout, const void* A, const void* B, void* C, const
     p.f0 = p.f1 = nullptr;
     p.A2 = p.B2 = nullptr; p.lda2 = p.ldb2 = p.K2 = 0; p.seg_b0 = p.seg_b1 = 0x7fffffff; p.drop_key = 0; p.drop_thr = 0; p.drop_ld = 0;
     p.res_f32 = residual ? res_f32 : 0;
-    p.sched = 0; p.sk_ws = nullptr; p.sk_epoch = 0;
+    p.sched = 0;
     p.groups = 1; p.gA = p.gB = p.gC = 0; p.mask_on = 0; p.mask_seed = 0; p.mask_thr = 0; p.mask_ld = 0;
     p.mask_bits = nullptr; p.gMask = 0; p.drop_bits = nullptr;
     const int pi = vlr_prof_begin(layout, 2.0 * M * N * K, stream);
@@ -774,7 +766,7 @@ static GemmParams fused_params(const void* A, const void* B, void* C, int M, int
     p.fuse = 0; p.store_c = 1; p.C2 = nullptr; p.ldc2 = 0; p.pos = nullptr; p.rope_cos = p.rope_sin = nullptr; p.max_pos = 0; p.rope_cols = 0;
     p.f0 = p.f1 = nullptr;
     p.A2 = p.B2 = nullptr; p.lda2 = p.ldb2 = p.K2 = 0; p.seg_b0 = p.seg_b1 = 0x7fffffff; p.drop_key = 0; p.drop_thr = 0; p.drop_ld = 0; p.res_f32 = 0;
-    p.sched = 0; p.sk_ws = nullptr; p.sk_epoch = 0;
+    p.sched = 0;
     p.groups = 1; p.gA = p.gB = p.gC = 0; p.mask_on = 0; p.mask_seed = 0; p.mask_thr = 0; p.mask_ld = 0;
     p.mask_bits = nullptr; p.gMask = 0; p.drop_bits = nullptr;
     return p;

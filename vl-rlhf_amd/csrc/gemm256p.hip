@@ -23,6 +23,7 @@
 // SOURCE address of the DMA, same XOR on the ds_read_b128).  K-strided operands (stored [K][cols]): LDS image [64 k][256 B],
 // chunk c of k-row r stored at c ^ (((r&3)<<2) | (((r>>3)&1)<<1)), fragments by two ds_read_b64_tr_b16.  M/N edges: rows/columns clamped on the
 // source side, never stored.  K tail: chunks beyond K read a 16-byte zero buffer.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -35,15 +36,26 @@
 #define BUF_BYTES (4 * HALF_BYTES)   // A-lo | A-hi | B-lo | B-hi
 #define C_STRIDE 528                 // bytes per row of the bf16 C image (256 cols + 16 B pad: conflict-free 8-byte writes)
 #define P_LDS_BYTES (256 * C_STRIDE)  // 132 KiB: the two K-tile buffers (128 KiB) / the epilogue's C image
-#define PTAB_PIECES 512                // capacity of the piece table behind them (8 ints per piece)
+#define PTAB_PIECES 384                // capacity of the piece table behind them (8 ints per piece); persist_grid() keeps launches below it
 #define PTAB_BYTES (PTAB_PIECES * 32)
-#define CONT_LDS_BYTES (2 * BUF_BYTES + PTAB_BYTES)      // dynamic LDS of the continuous-pipeline kernels
+#define EPATCH_STRIDE 144              // bytes per row of a wave's epilogue patch: 32 fp32 columns + 16 B (conflict-free 16-byte row-per-lane writes)
+#define EPATCH_BYTES (16 * EPATCH_STRIDE)                // one 16-row x 32-column fp32 chunk (two accumulator tiles) per wave
+#define CONT_LDS_BYTES (2 * BUF_BYTES + PTAB_BYTES + 8 * EPATCH_BYTES)      // dynamic LDS of the continuous-pipeline kernels (158 KiB)
 #define TILE_LDS_BYTES (P_LDS_BYTES + PTAB_BYTES)        // ... of the per-tile kernels
 
 typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+
+// compile-time loop: f(std::integral_constant<int, B>{}) ... f(<E - 1>) - software-pipelined epilogues index their register windows statically
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
 
 // One LDS-DMA wave instruction (64 lanes x 16 B -> LDS [m0 + lane*16]) issued through inline asm ON PURPOSE: when hipcc sees
 // the builtin it tracks an outstanding "LDS store through VMEM" and puts s_waitcnt vmcnt(0) in front of every
@@ -206,6 +218,9 @@ __device__ __forceinline__ int widen_col(int lq) { return (lq & 1) * 16 + (lq >>
         asm volatile("" ::: "memory");       \
         __builtin_amdgcn_sched_barrier(0);   \
     } while (0)
+// waves 4-7 of the workgroup?  Recomputed from threadIdx at every use: as a value carried through the tile loop hipcc kept it in a VGPR,
+// spilled that to scratch and reloaded it - behind an s_waitcnt vmcnt(0) that drained the LDS-DMA queue - at the top of every tile.
+#define WAVES_HI() (__builtin_amdgcn_readfirstlane((int)threadIdx.x) >= 256)
 #define PWAIT_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
 #define PWAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
@@ -225,11 +240,48 @@ static uint32_t* g_trace = nullptr;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                         \
         }                                                                              \
     } while (0)
-#define TRACE_SET(p_) (p_).trace = g_trace
+// VLR_GEMM_DEPHASE="P,D" (trace build only): workgroup b idles ((b * 7) % P) * D / P microseconds before its first tile - an experiment
+// on whether the epilogue bursts of workgroups that run in phase are what an epilogue costs
+static int g_dephase_p = -1, g_dephase_ticks = 0;
+static void trace_set(GemmParams& p) {
+    if (g_dephase_p < 0) {
+        g_dephase_p = 0;
+        const char* e = getenv("VLR_GEMM_DEPHASE");
+        int a = 0, b = 0;
+        if (e && sscanf(e, "%d,%d", &a, &b) == 2 && a > 0 && b > 0) { g_dephase_p = a; g_dephase_ticks = b * 100; }
+    }
+    p.trace = g_trace; p.dephase_p = g_dephase_p; p.dephase_ticks = g_dephase_ticks;
+}
+#define TRACE_SET(p_) trace_set(p_)
 #else
 #define TSTAMP(slot_) do { } while (0)
 #define TRACE_SET(p_) do { } while (0)
 #endif
+
+// ---- epilogue staging of the continuous-pipeline kernels: a wave-private LDS patch (EPATCH_BYTES behind the piece table) turns the
+// accumulator layout (lane (lm, lq): row lm, 4 columns at 4 lq of a 16 x 16 tile) into row-contiguous registers.  LDS instructions of
+// one wave execute in order, so write -> read -> next write need no wait, only a compiler barrier (`epatch`, `lane` of the kernel).
+#define EPI_SYNC() do { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+// fp32: the tiles j = 0, 1 (16 rows x 32 columns) -> o_[k] = row (lane >> 3) + 8 k, columns (lane & 7) * 4 .. + 3
+#define EPI_XPOSE_F32(t0_, t1_, o_)                                                                                   \
+    do {                                                                                                              \
+        EPI_SYNC();                                                                                                   \
+        *reinterpret_cast<f32x4*>(epatch + (lane & 15) * EPATCH_STRIDE + (lane >> 4) * 16) = (t0_);                   \
+        *reinterpret_cast<f32x4*>(epatch + (lane & 15) * EPATCH_STRIDE + 64 + (lane >> 4) * 16) = (t1_);              \
+        EPI_SYNC();                                                                                                   \
+        (o_)[0] = *reinterpret_cast<const f32x4*>(epatch + (lane >> 3) * EPATCH_STRIDE + (lane & 7) * 16);            \
+        (o_)[1] = *reinterpret_cast<const f32x4*>(epatch + ((lane >> 3) + 8) * EPATCH_STRIDE + (lane & 7) * 16);      \
+    } while (0)
+// bf16: w_in_ = widen_pair(tile 0, tile 1) (row lane & 15, 8 columns at widen_col(lane >> 4)) -> w_out_ = row lane >> 2, columns
+// (lane & 3) * 8 .. + 7 of the 32-column strip
+#define EPI_XPOSE_BF16(w_in_, w_out_)                                                                                 \
+    do {                                                                                                              \
+        const u32x4 w__ = (w_in_);                                                                                    \
+        EPI_SYNC();                                                                                                   \
+        *reinterpret_cast<u32x4*>(epatch + (lane & 15) * 80 + widen_col(lane >> 4) * 2) = w__;                        \
+        EPI_SYNC();                                                                                                   \
+        (w_out_) = *reinterpret_cast<const u32x4*>(epatch + (lane >> 2) * 80 + (lane & 3) * 16);                      \
+    } while (0)
 
 // CONT = true: continuous pipeline across the output tiles of a persistent workgroup (plain bf16 epilogue only): the last K tiles
 // of tile i stage the first K tiles of tile i+1 (same slots, same counted wait), the epilogue stores straight from the
@@ -259,83 +311,39 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     const int nt1 = (p.K + PK - 1) / PK;
     const int k2t = !SEG ? 0 : (FUSE == 1 ? 2 * p.K2 : p.K2);
     const int nt = nt1 + (k2t + PK - 1) / PK;
-    // ---- the workgroup's list of PIECES: a piece = K tiles [kb, ke) of one output tile.  Plain rounds: piece i = tile (j + i * G8) of
-    // this XCD's tiles, whole K (j = blockIdx / 8, G8 = gridDim / 8).  GemmParams::sched adds (continuous pipeline only, K >= 1024):
-    //  bit 0, stream-K tail: the XCD's last T = G8 + (tiles % G8) tiles are not run as 1 full + 1 nearly empty round; their T * nt K
-    //         tiles are cut into G8 equal contiguous ranges (boundaries snapped off the first / last 4 K tiles of a tile), one per
-    //         workgroup, i.e. 1.x tile-times each.  A tile that straddles two ranges is FINISHED by workgroup j, which holds its head
-    //         [0, k) at the end of its range; workgroup j + 1 computed the tail [k, nt) at the start of its range, long before, and left
-    //         its fp32 accumulators in its slab (write-through stores, then a per-wave flag = launch epoch).  Fixed summation order:
-    //         head + tail - deterministic.
-    //  bit 1, XCD rotation: the workgroups of XCD x != 0 start their first tile at K tile x * nt / 8 (accumulators -> own slab) and run
-    //         its head [0, x * nt / 8) as their LAST piece: every later tile boundary of XCD x is shifted by x / 8 of a tile, so the
-    //         eight XCDs' C-store bursts are spread over the tile time instead of hitting the fabric together.
+    // ---- the workgroup's list of PIECES (a piece = one output tile, whole K): piece i = tile (j + i * G8) of this XCD's tiles
+    // (j = blockIdx / 8, G8 = gridDim / 8), written ONCE into LDS behind the K-tile buffers (lane l of wave 0 computes pieces l, l + 64,
+    // ...): an iteration reads its own and the next piece with two broadcast ds_reads - the scalars of the enumeration, kept live
+    // across the K loop, pushed the kernel into scratch.  (Round 3 also cut pieces along K across workgroups - a stream-K tail, an
+    // XCD rotation, an XCD round barrier, accumulators handed over through fp32 slabs: all measured slower or neutral, DESIGN.md
+    // section 4, and removed in round 4.)
     const int G8 = (int)gridDim.x >> 3, xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
     const bool persistent = (int)gridDim.x < nwg;                  // else: one tile per workgroup, gridDim == nwg (any count)
     const int n_x = (nwg >> 3) + (xcd < (nwg & 7) ? 1 : 0);       // tiles of this XCD
-    const bool sk_ok = CONT && persistent && nt >= VLR_SK_MIN_KTILES && p.sk_ws != nullptr && n_x >= G8;
-    const bool sk_tail = sk_ok && (p.sched & 1) && (n_x % G8) != 0;
-    const int r_dp = sk_tail ? n_x / G8 - 1 : (persistent ? (n_x - jx + G8 - 1) / G8 : 1);   // whole-K tiles this workgroup runs first
-    int kr = 0;                                                    // rotation offset (K tiles); 0 = none
-    if (sk_ok && (p.sched & 2) && xcd != 0 && r_dp >= 1) {
-        kr = (xcd * nt) >> 3;
-        kr = kr < 4 ? 4 : (kr > nt - 4 ? nt - 4 : kr);
-    }
-    int tb[4] = {0, 0, 0, 0};                                     // boundaries of the tail pieces in (tail tile, K tile) units
-    int n_tp = 0, tail0 = 0;
-    if (sk_tail) {
-        tail0 = r_dp * G8;                                         // first local tile of the stream-K tail
-        const int U = (n_x - tail0) * nt;
-        int bb[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {                              // range [bound(jx), bound(jx + 1)) of this workgroup
-            const int i = jx + e;
-            int b = (i * U) / G8;                                  // < 2^31: at most 32 x (64 tiles x 1000 K tiles)
-            const int r = b % nt;
-            if (r < 4) b -= r; else if (nt - r < 4) b += nt - r;
-            bb[e] = i >= G8 ? U : b;
-        }
-        tb[0] = bb[0];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const int s_ = tb[c];
-            int e_ = (s_ / nt + 1) * nt;
-            e_ = e_ < bb[1] ? e_ : bb[1];
-            tb[c + 1] = e_;
-            if (s_ < bb[1]) n_tp = c + 1;
-        }
-    }
-    // The piece list is written ONCE into LDS behind the K-tile buffers (lane l of wave 0 computes pieces l, l + 64, ...): the ~25
-    // scalars of the enumeration are dead before the K loop starts, an iteration reads its own and the next piece (two broadcast
-    // ds_reads) - kept live in SGPRs across the K loop they pushed the kernel into scratch.
-    const int npieces = __builtin_amdgcn_readfirstlane(r_dp + n_tp + (kr ? 1 : 0));
+    const int npieces = __builtin_amdgcn_readfirstlane(persistent ? (n_x - jx + G8 - 1) / G8 : 1);
     int* ptab = reinterpret_cast<int*>(smem + (CONT ? 2 * BUF_BYTES : P_LDS_BYTES));
     if (t < 64) {
         for (int i = t; i < npieces; i += 64) {
-            // piece i: whole-K tiles first (the first one rotated), then the stream-K tail pieces, then the head of the rotated tile
-            const int c = i - r_dp;
-            const int kind = i < r_dp ? 0 : (c < n_tp ? 1 : 2);
-            const int s_ = c <= 0 ? tb[0] : (c == 1 ? tb[1] : tb[2]), e_ = c <= 0 ? tb[1] : (c == 1 ? tb[2] : tb[3]);
-            const int tt = s_ / nt;
-            const int idx = kind == 0 ? jx + i * G8 : (kind == 1 ? tail0 + tt : jx);
+            const int idx = jx + i * G8;
             const int q = nwg >> 3, rem = nwg & 7;
-            const int pid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+            const int pid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;      // XCD x owns a contiguous range of tile ids (bijective)
             const int GROUP = 8;
             const int per_group = GROUP * tiles_n;
             const int first_m = (pid / per_group) * GROUP;
             const int gsz = min(tiles_m - first_m, GROUP);
-            const int kb_ = kind == 0 ? (i == 0 ? kr : 0) : (kind == 1 ? s_ - tt * nt : 0);
-            const int ke_ = kind == 1 ? e_ - tt * nt : (kind == 2 ? kr : nt);
             ptab[i * 8 + 0] = (first_m + (pid % per_group) % gsz) * PT;
             ptab[i * 8 + 1] = ((pid % per_group) / gsz) * NW;
-            ptab[i * 8 + 2] = kb_;
-            ptab[i * 8 + 3] = ke_;
-            ptab[i * 8 + 4] = kind == 0 ? ((i == 0 && kr) ? 4 : 0) : (kind == 1 ? ((kb_ > 0 ? 1 : 0) | (ke_ < nt ? 2 : 0)) : 8);
         }
     }
     __syncthreads();
     if (npieces <= 0) return;
-    TSTAMP(511 * 8 + 5);
+#ifdef VLR_GEMM_TRACE
+    if (CONT && p.dephase_p > 0) {
+        const uint64_t until = __builtin_amdgcn_s_memrealtime() + (uint64_t)(((int)blockIdx.x * 7) % p.dephase_p) * p.dephase_ticks / p.dephase_p;
+        while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(16);
+    }
+#endif
+    TSTAMP((PTAB_PIECES - 1) * 8 + 5);
     int parb = 0;                 // CONT: buffer parity of the current piece's K tile 0 (K tiles keep alternating across pieces)
     for (int titer = 0;; ++titer) {
     // per-tile opaque copy of the lane id: keeps hipcc from hoisting every lane-derived address out of the tile loop (it did,
@@ -343,24 +351,15 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     int lane = lane0;
     asm volatile("" : "+v"(lane));
 #define RFL(x) __builtin_amdgcn_readfirstlane(x)
-    const int m0 = RFL(ptab[titer * 8 + 0]), n0 = RFL(ptab[titer * 8 + 1]), kb = RFL(ptab[titer * 8 + 2]);
-    const int ntp = RFL(ptab[titer * 8 + 3]) - kb, pfl = RFL(ptab[titer * 8 + 4]);
+    const int m0 = RFL(ptab[titer * 8 + 0]), n0 = RFL(ptab[titer * 8 + 1]);
+    const int kb = 0, ntp = nt;                    // a piece is a whole tile: K tiles [0, nt)
     const bool has_next = CONT && titer + 1 < npieces;
     const int tnx = has_next ? titer + 1 : titer;
-    const int m0n = RFL(ptab[tnx * 8 + 0]), n0n = RFL(ptab[tnx * 8 + 1]), kbn = RFL(ptab[tnx * 8 + 2]);
+    const int m0n = RFL(ptab[tnx * 8 + 0]), n0n = RFL(ptab[tnx * 8 + 1]);
+    const int kbn = 0;
     const bool first = !CONT || titer == 0;
+    const bool epi_par = CONT && !(p.sched & 16);      // both wave groups in the epilogue at once (sched bit 4 = the old serial order, A/B)
     parb = RFL(parb);
-    if constexpr (CONT) {
-        // sched bit 2 (experiment): the workgroups of an XCD start every whole-K round together (one arrival counter per XCD, zeroed by
-        // the host before the launch; rounds that every workgroup of the XCD runs) - tests whether drift between the workgroups that
-        // share A / B panels in the XCD's L2 costs anything
-        if ((p.sched & 4) && p.sk_ws && titer > 0 && titer < n_x / G8 && pfl == 0) {
-            unsigned int* ctr = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(p.sk_ws) + VLR_SK_FLAG_OFF + 32768) + xcd * 16;
-            if (t == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned int want = (unsigned int)(G8 * titer);
-            while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(2);
-        }
-    }
 
     f32x4 acc[2][4][2][2];   // [A half a][16-row tile i][B half b][16-col tile j]
 #pragma unroll
@@ -391,7 +390,6 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     }
     const size_t stepA = A_KS ? (size_t)PK * p.lda * 2 : (size_t)PK * 2;
     const size_t stepB = B_KS ? (size_t)PK * p.ldb * 2 : (size_t)PK * 2;
-    const bool ktail = (p.K % PK) != 0;          // only the last K tile can be partial: it takes the general (zero-filling) path
     const uint32_t lds_wave = (uint32_t)(uintptr_t)(lvoid_t*)smem + wave * 1024;
     // fastc = true: the caller guarantees tile < nt and that the tile is a full one (steady-state loop): no checks at all
     // `tile` is relative to the piece: K tile kb + tile of this output tile; tile >= ntp: K tile kbn + (tile - ntp) of the NEXT piece
@@ -459,7 +457,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                 return;
             }
         }
-        if (!fast && ktail && kb + tile == nt - 1) {
+        if (!fast && (p.K & (PK - 1)) != 0 && kb + tile == nt - 1) {      // only the last K tile can be partial: it takes the general (zero-filling) path
             char* dst = smem + ((tile + parb) & 1) * BUF_BYTES + h * HALF_BYTES;
             const int k0 = (kb + tile) * PK;
             if constexpr (h < 2) {
@@ -491,12 +489,16 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     using SLOW = std::false_type;
     using FAST = std::true_type;
     if (first) {
-        stage(0, H_BLO{}, SLOW{}); stage(0, H_ALO{}, SLOW{}); stage(0, H_BHI{}, SLOW{}); stage(0, H_AHI{}, SLOW{});
-        stage(1, H_BLO{}, SLOW{}); stage(1, H_ALO{}, SLOW{}); stage(1, H_BHI{}, SLOW{});
+        // (continuous pipeline: K >= 256 is a launch condition, so K tiles 0 and 1 are whole tiles of (A, B) - the unchecked path)
+        using PRO = std::integral_constant<bool, CONT>;
+        stage(0, H_BLO{}, PRO{}); stage(0, H_ALO{}, PRO{}); stage(0, H_BHI{}, PRO{}); stage(0, H_AHI{}, PRO{});
+        stage(1, H_BLO{}, PRO{}); stage(1, H_ALO{}, PRO{}); stage(1, H_BHI{}, PRO{});
         // (from the second tile on the previous tile's stores are still in flight and vmcnt counts them too: wait for everything)
         if (titer == 0 && ntp >= 2) PWAIT_VM(6); else PWAIT_VM(0);
         PBAR();
-        if (wr == 1) PBAR();      // waves 4-7 run one barrier behind waves 0-3
+        if (WAVES_HI()) PBAR();      // waves 4-7 run one barrier behind waves 0-3
+    } else if (epi_par) {
+        if (WAVES_HI()) PBAR();      // ... again after an epilogue that both wave groups ran side by side (below)
     }
 
     bf16x8 fa0[4][2], fa1[4][2], fb0[2][2], fb1[2][2];   // [16-row/col tile][k slice of 32]
@@ -629,7 +631,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     };
     // steady state: every staged tile (kt+1, kt+2) exists and is full -> no checks, no K-tail path in the hot loop
     // (absolute K tiles kb + kt + 2 below `lim` are whole tiles of (A, B); SEG: K % 64 == 0, the adapter tiles too when K2 % 64 == 0)
-    const int lim = ((SEG && ((p.K2 % PK) != 0 || (p.sched & 8))) ? nt1 : nt) - (ktail ? 1 : 0) - kb;
+    const int lim = ((SEG && ((p.K2 % PK) != 0 || (p.sched & 8))) ? nt1 : nt) - ((p.K & (PK - 1)) != 0 ? 1 : 0) - kb;
     const int n_fast = (ntp < lim ? ntp : lim) - 2;
     int kt = 0;
 #ifdef VLR_GEMM_TRACE
@@ -638,85 +640,32 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     for (; kt < n_fast; ++kt) ktile(kt, FAST{});
     for (; kt < ntp; ++kt) ktile(kt, SLOW{});
     TSTAMP(titer * 8 + 6);
+    // Waves 4-7 are one barrier behind: when waves 0-3 leave the K loop, waves 4-7 still owe their last barrier - and found its partner
+    // only in waves 0-3's FIRST barrier of the next tile, i.e. after waves 0-3's epilogue; then waves 0-3 waited in their second barrier
+    // for the epilogue of waves 4-7.  The two halves of the workgroup ran their epilogues one after the other, each with the other half
+    // idle (tile timeline, tools/gemm_tile_trace.py: "first K tile of the next tile" = one epilogue longer than a K tile, for every
+    // epilogue; 22 - 30 us per tile for the fp32-residual, RoPE and SwiGLU-backward ones).  So: waves 0-3 pay the barrier here, both
+    // halves run their epilogues side by side, and waves 4-7 drop back by one barrier before the next tile's first phase.
+    if (epi_par) { if (!WAVES_HI()) PBAR(); }
+    char* const epatch = smem + 2 * BUF_BYTES + PTAB_BYTES + wave * EPATCH_BYTES;      // CONT only (the per-tile kernels own the K-tile buffers here)
 #undef PMFMA
-    // ---- stream-K / rotation hand-off of the fp32 accumulators (GemmParams::sched).  Slab = this wave's 128 accumulator registers as
-    // 64 x (64 lanes x 8 B): fully coalesced, agent-scope write-through stores / loads (sc1) - no fence, no barrier: wave w of the
-    // finishing workgroup needs only what wave w of its partner wrote, so the flag is per wave.
-    bool piece_done = false;
-    if constexpr (CONT) {
-        if (pfl) {
-            // Slab of this wave: its 32 accumulator quads as [q][lane] x 16 B (1 KiB per q, fully coalesced), moved by inline-asm
-            // dwordx4 accesses with sc1 (agent-scope write-through / L1 bypass: the partner sits on another CU of the same XCD) straight
-            // from / into the accumulator registers.  No element reads of the accumulator vectors: hipcc 7.2 folds them (all four
-            // stored values came out as element 0 - seen in the ISA of the first version of this loop, the miscompile of the
-            // SwiGLU-backward epilogue below).  Loads: 16 per statement with their own s_waitcnt (the compiler does not count asm loads).
-            const bool own = (pfl & 12) != 0;
-            const int sblk = own ? (int)blockIdx.x : ((pfl & 1) ? (int)blockIdx.x - 8 : (int)blockIdx.x);   // partner slabs are indexed by the WRITER (block >= 8) - 8
-            const char* sb0 = reinterpret_cast<const char*>(p.sk_ws) + (own ? VLR_SK_SELF_OFF : 0) + ((size_t)sblk * 8 + wave) * 32768;
-            const char* sb1 = sb0 + 16384;
-            unsigned int* flags = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(p.sk_ws) + VLR_SK_FLAG_OFF);
-            const uint32_t vo0 = (uint32_t)lane * 16, vo1 = vo0 + 4096, vo2 = vo0 + 8192, vo3 = vo0 + 12288;
-            if (pfl & 5) {
-#define SLAB_ST(vo_, vec_, sb_, imm_) asm volatile("global_store_dwordx4 %0, %1, %2 offset:" #imm_ " sc1\n\ts_nop 1" ::"v"(vo_), "v"(vec_), "s"(sb_) : "memory")
-#define SLAB_ST4(vo_, a_, i_, sb_)                                                                 \
-    SLAB_ST(vo_, acc[a_][i_][0][0], sb_, 0); SLAB_ST(vo_, acc[a_][i_][0][1], sb_, 1024);           \
-    SLAB_ST(vo_, acc[a_][i_][1][0], sb_, 2048); SLAB_ST(vo_, acc[a_][i_][1][1], sb_, 3072)
-                SLAB_ST4(vo0, 0, 0, sb0); SLAB_ST4(vo1, 0, 1, sb0); SLAB_ST4(vo2, 0, 2, sb0); SLAB_ST4(vo3, 0, 3, sb0);
-                SLAB_ST4(vo0, 1, 0, sb1); SLAB_ST4(vo1, 1, 1, sb1); SLAB_ST4(vo2, 1, 2, sb1); SLAB_ST4(vo3, 1, 3, sb1);
-#undef SLAB_ST4
-#undef SLAB_ST
-                if (pfl & 1) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the slab has reached L2 before the flag says so
-                    if (lane == 0) __hip_atomic_store(flags + blockIdx.x * 8 + wave, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                piece_done = true;                                         // no epilogue: the finishing piece writes this tile
-            } else {
-                if (pfl & 2) {       // (the partner is block + 8, whose slab index is (block + 8) - 8 = this block's index: sb0 above)
-                    const unsigned int* fp = flags + (blockIdx.x + 8) * 8 + wave;
-                    while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch) __builtin_amdgcn_s_sleep(8);
-                }
-#define SLAB_LD16(t_, sb_)                                                                                                              \
-    asm volatile("global_load_dwordx4 %0, %16, %20 sc1\n\tglobal_load_dwordx4 %1, %16, %20 offset:1024 sc1\n\t"                         \
-                 "global_load_dwordx4 %2, %16, %20 offset:2048 sc1\n\tglobal_load_dwordx4 %3, %16, %20 offset:3072 sc1\n\t"             \
-                 "global_load_dwordx4 %4, %17, %20 sc1\n\tglobal_load_dwordx4 %5, %17, %20 offset:1024 sc1\n\t"                         \
-                 "global_load_dwordx4 %6, %17, %20 offset:2048 sc1\n\tglobal_load_dwordx4 %7, %17, %20 offset:3072 sc1\n\t"             \
-                 "global_load_dwordx4 %8, %18, %20 sc1\n\tglobal_load_dwordx4 %9, %18, %20 offset:1024 sc1\n\t"                         \
-                 "global_load_dwordx4 %10, %18, %20 offset:2048 sc1\n\tglobal_load_dwordx4 %11, %18, %20 offset:3072 sc1\n\t"           \
-                 "global_load_dwordx4 %12, %19, %20 sc1\n\tglobal_load_dwordx4 %13, %19, %20 offset:1024 sc1\n\t"                       \
-                 "global_load_dwordx4 %14, %19, %20 offset:2048 sc1\n\tglobal_load_dwordx4 %15, %19, %20 offset:3072 sc1\n\t"           \
-                 "s_waitcnt vmcnt(0)"                                                                                                   \
-                 : "=&v"(t_[0]), "=&v"(t_[1]), "=&v"(t_[2]), "=&v"(t_[3]), "=&v"(t_[4]), "=&v"(t_[5]), "=&v"(t_[6]), "=&v"(t_[7]),      \
-                   "=&v"(t_[8]), "=&v"(t_[9]), "=&v"(t_[10]), "=&v"(t_[11]), "=&v"(t_[12]), "=&v"(t_[13]), "=&v"(t_[14]), "=&v"(t_[15]) \
-                 : "v"(vo0), "v"(vo1), "v"(vo2), "v"(vo3), "s"(sb_)                                                                     \
-                 : "memory")
-#pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    f32x4 tq[16];
-                    if (a == 0) SLAB_LD16(tq, sb0); else SLAB_LD16(tq, sb1);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int b = 0; b < 2; ++b)
-#pragma unroll
-                            for (int j = 0; j < 2; ++j) acc[a][i][b][j] += tq[i * 4 + b * 2 + j];       // head (this piece) + tail (the slab): one fixed order
-                }
-#undef SLAB_LD16
-            }
-        }
-    }
-    if (piece_done) {
-    } else if constexpr (CONT && FUSE == 1) {
+    if constexpr (CONT && FUSE == 1) {
         // SwiGLU epilogue: acc[a][i][0][j] = gate, acc[a][i][1][j] = the matching up columns; act = silu(gate) * up from the fp32
-        // accumulators (one rounding), gate | up stored for the backward only when asked
+        // accumulators (one rounding), gate | up stored for the backward only when asked.  The arithmetic runs in the accumulator
+        // layout (gate and up of an element sit in one lane); the rounded 16 x 32 chunks go through the patch and leave as 16-byte
+        // stores, 4 lanes = 64 B per row (see the plain epilogue below).
         bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
         bf16_t* C2 = reinterpret_cast<bf16_t*>(p.C2);
         const int I = p.N >> 1;
-        const int lm_ = lane & 15, lq_ = lane >> 4;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int gm = m0 + a * 128 + wr * 64 + i * 16 + lm_;
+                int ln = lane;                       // opaque per chunk row: keeps hipcc from carrying 24 hoisted store addresses (it spilled)
+                asm volatile("" : "+v"(ln));
+                const int gm = m0 + a * 128 + wr * 64 + i * 16 + (ln >> 2);
+                const int gn = n0 + wc * 32 + (ln & 3) * 8;
+                const bool ok = gm < p.M && gn + 8 <= I;
                 f32x4 h[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -724,18 +673,16 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
 #pragma unroll
                     for (int e = 0; e < 4; ++e) h[j][e] = g[e] / (1.f + __expf(-g[e])) * u[e];
                 }
-                const int gn = n0 + wc * 32 + widen_col(lq_);
-                const bool ok = gm < p.M && gn + 8 <= I;
-                if (p.store_c) {
-                    const u32x4 wg = widen_pair(acc[a][i][0][0], acc[a][i][0][1]);
-                    const u32x4 wu = widen_pair(acc[a][i][1][0], acc[a][i][1][1]);
-                    if (ok) {
-                        *reinterpret_cast<u32x4*>(C + (size_t)gm * p.ldc + gn) = wg;
-                        *reinterpret_cast<u32x4*>(C + (size_t)gm * p.ldc + I + gn) = wu;
-                    }
-                }
-                const u32x4 wh = widen_pair(h[0], h[1]);
+                u32x4 wh;
+                EPI_XPOSE_BF16(widen_pair(h[0], h[1]), wh);
                 if (ok) *reinterpret_cast<u32x4*>(C2 + (size_t)gm * p.ldc2 + gn) = wh;
+                if (p.store_c) {
+                    u32x4 wg, wu;
+                    EPI_XPOSE_BF16(widen_pair(acc[a][i][0][0], acc[a][i][0][1]), wg);
+                    if (ok) *reinterpret_cast<u32x4*>(C + (size_t)gm * p.ldc + gn) = wg;
+                    EPI_XPOSE_BF16(widen_pair(acc[a][i][1][0], acc[a][i][1][1]), wu);
+                    if (ok) *reinterpret_cast<u32x4*>(C + (size_t)gm * p.ldc + I + gn) = wu;
+                }
             }
     } else if constexpr (CONT && FUSE == 4) {
         // lm-head forward: per row, this wave's 64 columns (wc*32..+32 of both B halves) -> (max, sum exp) partial + the target logit
@@ -811,188 +758,264 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
             }
     } else if constexpr (CONT && FUSE == 3) {
         // SwiGLU backward epilogue (dgrad of the down projection, NN): acc = d act [rows][cols of I]; gate | up of the forward sit in
-        // C2 [M][2I] and are overwritten IN PLACE with d gate | d up (each element is read and written by the same lane)
+        // C2 [M][2I] and are overwritten IN PLACE with d gate | d up (each element is read and written by the same lane).  The fp32
+        // d act chunks go through the patch (row-contiguous: lane -> rows er, er + 8, 4 columns), gate | up are read and d gate | d up
+        // written as 8-byte accesses, 8 lanes = 64 B per row; the loads of an A half are issued together before its arithmetic.
+        // (History: the first version regrouped d act with v_permlane16_swap to the layout of 16-byte row-per-lane loads - hipcc 7.2
+        // folded the four swaps on one accumulator into one)
         bf16_t* GU = reinterpret_cast<bf16_t*>(p.C2);
         const int I = p.N;
-        const int lm_ = lane & 15, lq_ = lane >> 4;
+        const int ec = (lane & 7) * 4, er = lane >> 3;
+        // per A half: the gate | up loads of its 8 chunks together, then transposition, arithmetic and stores chunk by chunk
+        static_for<0, 2>([&](auto ac) {
+            constexpr int a = decltype(ac)::value;
+            u32x2 gq[8][2], uq[8][2];
+            static_for<0, 8>([&](auto cc) {      // unpredicated, clamped at the edges
+                constexpr int c = decltype(cc)::value;
+                constexpr int i = c >> 1, b = c & 1;
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            // one batch of loads per A half: 8 x (gate, up) x 16 bytes in flight, then the arithmetic, then the stores
-            u32x4 gq[4][2], uq[4][2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int gm = m0 + a * 128 + wr * 64 + i * 16 + lm_;
-                const int gmc = gm < p.M ? gm : p.M - 1;
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    int gn = n0 + b * 128 + wc * 32 + widen_col(lq_);
-                    gn = gn + 8 <= I ? gn : I - 8;
-                    gq[i][b] = *reinterpret_cast<const u32x4*>(GU + (size_t)gmc * p.ldc2 + gn);
-                    uq[i][b] = *reinterpret_cast<const u32x4*>(GU + (size_t)gmc * p.ldc2 + I + gn);
+                for (int k = 0; k < 2; ++k) {
+                    int gm = m0 + a * 128 + wr * 64 + i * 16 + er + 8 * k;
+                    int gn = n0 + b * 128 + wc * 32 + ec;
+                    gm = gm < p.M ? gm : p.M - 1;
+                    gn = gn + 4 <= I ? gn : I - 4;
+                    gq[c][k] = *reinterpret_cast<const u32x2*>(GU + (size_t)gm * p.ldc2 + gn);
+                    uq[c][k] = *reinterpret_cast<const u32x2*>(GU + (size_t)gm * p.ldc2 + I + gn);
                 }
-            }
+            });
+            static_for<0, 8>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                constexpr int i = c >> 1, b = c & 1;
+                f32x4 o[2];
+                EPI_XPOSE_F32(acc[a][i][b][0], acc[a][i][b][1], o);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int gm = m0 + a * 128 + wr * 64 + i * 16 + lm_;
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const int gn = n0 + b * 128 + wc * 32 + widen_col(lq_);
-                    // bring d act into the same 8-consecutive-column layout as the 16-byte gate / up loads (fp32 bits through the swap)
-                    float d[8], g[8], u[8], dg[8], du[8];
+                for (int k = 0; k < 2; ++k) {
+                    const int gm = m0 + a * 128 + wr * 64 + i * 16 + er + 8 * k;
+                    const int gn = n0 + b * 128 + wc * 32 + ec;
+                    const bool ok = gm < p.M && gn + 4 <= I;
+                    f32x4 d = o[k];
+                    if (p.residual && ok) {     // + addend on d act (the LoRA term of down_proj)
+                        const u32x2 w = *reinterpret_cast<const u32x2*>(p.residual + (size_t)gm * p.ldr + gn);
+                        d[0] += bf16lo(w[0]); d[1] += bf16hi(w[0]); d[2] += bf16lo(w[1]); d[3] += bf16hi(w[1]);
+                    }
+                    const u32x2 gw = gq[c][k], uw = uq[c][k];
+                    const float g[4] = {bf16lo(gw[0]), bf16hi(gw[0]), bf16lo(gw[1]), bf16hi(gw[1])};
+                    const float u[4] = {bf16lo(uw[0]), bf16hi(uw[0]), bf16lo(uw[1]), bf16hi(uw[1])};
+                    float dg[4], du[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        // inline asm, one swap per element: the builtin on the four fp32 lanes of an accumulator was folded into a
-                        // single swap by hipcc 7.2 (all eight values came out equal to element 0)
-                        float x0 = acc[a][i][b][0][e], x1 = acc[a][i][b][1][e];
-                        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x0), "+v"(x1));   // nops: VALU-write -> swap-read and swap-write -> VALU-read hazards are not tracked through inline asm
-                        d[e] = x0;
-                        d[4 + e] = x1;
-                    }
-                    if (p.residual && gm < p.M && gn + 8 <= I) {     // + addend on d act (the LoRA term of down_proj), same 8-column layout
-                        float ad[8];
-                        unpack8(*reinterpret_cast<const u32x4*>(p.residual + (size_t)gm * p.ldr + gn), ad);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) d[e] += ad[e];
-                    }
-                    unpack8(gq[i][b], g);
-                    unpack8(uq[i][b], u);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
                         const float sg = 1.f / (1.f + __expf(-g[e]));
                         du[e] = d[e] * g[e] * sg;
                         dg[e] = d[e] * u[e] * sg * (1.f + g[e] * (1.f - sg));
                     }
-                    if (gm < p.M && gn + 8 <= I) {
-                        *reinterpret_cast<u32x4*>(GU + (size_t)gm * p.ldc2 + gn) = pack8(dg);
-                        *reinterpret_cast<u32x4*>(GU + (size_t)gm * p.ldc2 + I + gn) = pack8(du);
+                    if (ok) {
+                        u32x2 qg, qu;
+                        qg[0] = pack_bf16(dg[0], dg[1]); qg[1] = pack_bf16(dg[2], dg[3]);
+                        qu[0] = pack_bf16(du[0], du[1]); qu[1] = pack_bf16(du[2], du[3]);
+                        *reinterpret_cast<u32x2*>(GU + (size_t)gm * p.ldc2 + gn) = qg;
+                        *reinterpret_cast<u32x2*>(GU + (size_t)gm * p.ldc2 + I + gn) = qu;
                     }
                 }
-            }
-        }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
     } else if constexpr (CONT && FUSE == 2) {
-        // RoPE epilogue: acc[a][i][0][j] / acc[a][i][1][j] = features d / d + 64 of one head (rotate-half partners)
+        // RoPE epilogue: acc[a][i][0][j] / acc[a][i][1][j] = features d / d + 64 of one head (rotate-half partners).  Both fp32 chunks go
+        // through the patch (row-contiguous: lane -> rows er, er + 8; features fc .. fc + 3 of the head's first / second 64), so that the
+        // cos / sin rows of the positions are read as whole 128-byte lines (8 lanes x 16 B) and the rotated values leave as 8-byte
+        // stores, 64 B per row; the positions of all 16 rows of the lane first, then the table rows of one (a, i) ahead of its arithmetic.
         bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
-        const int lm_ = lane & 15, lq_ = lane >> 4;
         const bool rot = n0 < p.rope_cols;            // q and k tiles; v tiles pass through
+        const int ec = (lane & 7) * 4, er = lane >> 3;
+        const int fc = (wc & 1) * 32 + ec;            // feature inside the 64-wide half
+        const int hc = n0 + (wc >> 1) * 128 + fc;     // output column of the first-half feature (second half: + 64)
+        float b1[4] = {0.f, 0.f, 0.f, 0.f}, b2[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {                                  // biased fused projection (Qwen c_attn): added before the rotation
+            const u32x2 w1 = *reinterpret_cast<const u32x2*>(p.bias + hc), w2 = *reinterpret_cast<const u32x2*>(p.bias + hc + 64);
+            b1[0] = bf16lo(w1[0]); b1[1] = bf16hi(w1[0]); b1[2] = bf16lo(w1[1]); b1[3] = bf16hi(w1[1]);
+            b2[0] = bf16lo(w2[0]); b2[1] = bf16hi(w2[0]); b2[2] = bf16lo(w2[1]); b2[3] = bf16hi(w2[1]);
+        }
+        // per A half: the positions of the lane's 8 rows, the cos / sin rows of its 4 row blocks (i), then transposition, rotation and
+        // stores block by block
+        auto body = [&](auto rotc) {
+            constexpr bool ROT = decltype(rotc)::value;
+            static_for<0, 2>([&](auto ac) {
+                constexpr int a = decltype(ac)::value;
+                f32x4 cs[4][2], sn[4][2];
+                if constexpr (ROT) {
+                    int ps[4][2];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+                    for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int gm = m0 + a * 128 + wr * 64 + i * 16 + lm_;
-                int ps = 0;
-                if (rot && gm < p.M) {
-                    ps = p.pos[gm];
-                    ps = ps < 0 ? 0 : (ps >= p.max_pos ? p.max_pos - 1 : ps);
+                        for (int k = 0; k < 2; ++k) {
+                            int gm = m0 + a * 128 + wr * 64 + i * 16 + er + 8 * k;
+                            gm = gm < p.M ? gm : p.M - 1;          // rows past the edge take the last row's position, and are not stored
+                            int q = p.pos[gm];
+                            q = q < 0 ? 0 : (q >= p.max_pos ? p.max_pos - 1 : q);
+                            ps[i][k] = q;
+                        }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            cs[i][k] = *reinterpret_cast<const f32x4*>(p.rope_cos + (size_t)(ps[i][k] * 64 + fc));
+                            sn[i][k] = *reinterpret_cast<const f32x4*>(p.rope_sin + (size_t)(ps[i][k] * 64 + fc));
+                        }
                 }
-                f32x4 x1[2], x2[2];
+                static_for<0, 4>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    f32x4 o1[2], o2[2];
+                    EPI_XPOSE_F32(acc[a][i][0][0], acc[a][i][0][1], o1);
+                    EPI_XPOSE_F32(acc[a][i][1][0], acc[a][i][1][1], o2);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int c = wc * 32 + j * 16 + 4 * lq_;          // column of the 128-wide half: head c >> 6, feature c & 63
-                    x1[j] = acc[a][i][0][j];
-                    x2[j] = acc[a][i][1][j];
-                    if (p.bias) {                                      // biased fused projection (Qwen c_attn): added before the rotation
-                        const bf16_t* bp = p.bias + n0 + (c >> 6) * 128 + (c & 63);
-                        const u32x2 b1 = *reinterpret_cast<const u32x2*>(bp), b2 = *reinterpret_cast<const u32x2*>(bp + 64);
-                        x1[j][0] += bf16lo(b1[0]); x1[j][1] += bf16hi(b1[0]); x1[j][2] += bf16lo(b1[1]); x1[j][3] += bf16hi(b1[1]);
-                        x2[j][0] += bf16lo(b2[0]); x2[j][1] += bf16hi(b2[0]); x2[j][2] += bf16lo(b2[1]); x2[j][3] += bf16hi(b2[1]);
-                    }
-                    if (rot) {
-                        const f32x4 cs = *reinterpret_cast<const f32x4*>(p.rope_cos + (size_t)ps * 64 + (c & 63));
-                        const f32x4 sn = *reinterpret_cast<const f32x4*>(p.rope_sin + (size_t)ps * 64 + (c & 63));
-                        const f32x4 y1 = x1[j], y2 = x2[j];
+                    for (int k = 0; k < 2; ++k) {
+                        const int gm = m0 + a * 128 + wr * 64 + i * 16 + er + 8 * k;
+                        float y1[4], y2[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            x1[j][e] = y1[e] * cs[e] - y2[e] * sn[e];
-                            x2[j][e] = y2[e] * cs[e] + y1[e] * sn[e];
+                            const float x1 = o1[k][e] + b1[e], x2 = o2[k][e] + b2[e];
+                            if constexpr (ROT) {
+                                y1[e] = x1 * cs[i][k][e] - x2 * sn[i][k][e];
+                                y2[e] = x2 * cs[i][k][e] + x1 * sn[i][k][e];
+                            } else {
+                                y1[e] = x1;
+                                y2[e] = x2;
+                            }
+                        }
+                        if (gm < p.M) {
+                            u32x2 q1, q2;
+                            q1[0] = pack_bf16(y1[0], y1[1]); q1[1] = pack_bf16(y1[2], y1[3]);
+                            q2[0] = pack_bf16(y2[0], y2[1]); q2[1] = pack_bf16(y2[2], y2[3]);
+                            *reinterpret_cast<u32x2*>(C + (size_t)gm * p.ldc + hc) = q1;
+                            *reinterpret_cast<u32x2*>(C + (size_t)gm * p.ldc + hc + 64) = q2;
                         }
                     }
-                }
-                const u32x4 w1 = widen_pair(x1[0], x1[1]), w2 = widen_pair(x2[0], x2[1]);
-                const int c8 = wc * 32 + widen_col(lq_);
-                const int gn = n0 + (c8 >> 6) * 128 + (c8 & 63);
-                if (gm < p.M) {
-                    *reinterpret_cast<u32x4*>(C + (size_t)gm * p.ldc + gn) = w1;
-                    *reinterpret_cast<u32x4*>(C + (size_t)gm * p.ldc + gn + 64) = w2;
-                }
-            }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+        };
+        if (rot) body(std::true_type{}); else body(std::false_type{});        // (N % 256 == 0 is a launch condition of this epilogue)
     } else if constexpr (CONT) {
+      // Staged through a wave-private LDS patch (EPI_* above): a lane of the accumulator layout holds 4 columns of ONE row per 16-lane
+      // group, so a 16-byte access per lane straight from that layout is 16 different cache lines per group - 64 requests of 16 bytes per
+      // wave instruction, and the texture path takes about one request per clock (tile timeline: 23 us per tile for the fp32-residual
+      // epilogue, the same whether the two wave groups run it one after the other or side by side, and whether or not the other CUs
+      // are in their epilogues at that moment).  A 16-row x 32-column chunk (the two accumulator tiles j = 0, 1) goes through the patch
+      // and comes back row-contiguous: 8 lanes x 16 B = one 128-byte line per row (fp32), 4 lanes x 16 B = 64 B per row (bf16) -
+      // 8 / 16 requests per instruction.  The patch lives behind the piece table, outside the K-tile buffers: the next tile's first K
+      // tiles keep arriving by LDS-DMA underneath.
       if (p.out_f32) {
-        // fp32 output (fp32 residual stream: x_new = x + attn Wo^T / x + act Wdown^T): a lane's four consecutive columns are one
-        // 16-byte access - residual read and store straight from / to the accumulator layout, nothing is rounded.  The 16 residual
-        // loads of an A half are issued together (the fragment registers of the K loop are dead here), then added and stored.
+        // fp32 output (fp32 residual stream: x_new = x + attn Wo^T / x + act Wdown^T), nothing is rounded
         float* C = reinterpret_cast<float*>(p.C);
         const float* R = reinterpret_cast<const float*>(p.residual);
-        const int lm_ = lane & 15, lq_ = lane >> 4;
+        const int ec = (lane & 7) * 4, er = lane >> 3;
+        // Per A half: its 16 residual loads (rows er, er + 8 of the 8 chunks (i, b): whole 128-byte lines) are issued together - the
+        // fragment registers of the K loop are dead here - then each chunk is transposed, added and stored.  (Loads of later chunks
+        // cannot run ahead under stores: with loads AND stores pending hipcc treats vmcnt as unordered and waits vmcnt(0) for every
+        // value; parking the sums in the accumulator registers until all loads are in - two passes - made hipcc spill them.)
+        auto body = [&]() {
+            static_for<0, 2>([&](auto ac) {
+                constexpr int a = decltype(ac)::value;
+                f32x4 rv[8][2];
+                static_for<0, 8>([&](auto cc) {      // unpredicated (rows / columns past the edge re-read the last valid ones)
+                    constexpr int c = decltype(cc)::value;
+                    constexpr int i = c >> 1, b = c & 1;
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            f32x4 rv[4][2][2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int gm = m0 + a * 128 + wr * 64 + i * 16 + lm_;
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int gn = n0 + b * 128 + wc * 32 + j * 16 + 4 * lq_;
-                        f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                        if (R && gm < p.M && gn + 4 <= p.N) z = *reinterpret_cast<const f32x4*>(R + (size_t)gm * p.ldr + gn);
-                        rv[i][b][j] = z;
+                    for (int k = 0; k < 2; ++k) {
+                        int gm = m0 + a * 128 + wr * 64 + i * 16 + er + 8 * k;
+                        int gn = n0 + b * 128 + wc * 32 + ec;
+                        gm = gm < p.M ? gm : p.M - 1;
+                        gn = gn + 4 <= p.N ? gn : p.N - 4;
+                        rv[c][k] = *reinterpret_cast<const f32x4*>(R + (size_t)gm * p.ldr + gn);
                     }
-            }
+                });
+                static_for<0, 8>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    constexpr int i = c >> 1, b = c & 1;
+                    f32x4 o[2];
+                    EPI_XPOSE_F32(acc[a][i][b][0], acc[a][i][b][1], o);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int gm = m0 + a * 128 + wr * 64 + i * 16 + lm_;
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int gn = n0 + b * 128 + wc * 32 + j * 16 + 4 * lq_;
-                        const f32x4 v = p.alpha * acc[a][i][b][j] + rv[i][b][j];
+                    for (int k = 0; k < 2; ++k) {
+                        const int gm = m0 + a * 128 + wr * 64 + i * 16 + er + 8 * k;
+                        const int gn = n0 + b * 128 + wc * 32 + ec;
+                        const f32x4 v = p.alpha * o[k] + rv[c][k];
                         if (gm < p.M && gn + 4 <= p.N) *reinterpret_cast<f32x4*>(C + (size_t)gm * p.ldc + gn) = v;
                     }
-            }
-        }
-      } else {
-        // plain bf16 epilogue straight from the registers: lane (lm, lq) of tile (i, j) holds C[row lm][cols 4 lq .. +3]
+                    __builtin_amdgcn_sched_barrier(0);      // one chunk's addresses at a time
+                });
+            });
+        };
+        auto body_nores = [&]() {      // no residual (not on the 7B path): transposition and store per chunk
+            static_for<0, 16>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                constexpr int a = c >> 3, i = (c >> 1) & 3, b = c & 1;
+                f32x4 o[2];
+                EPI_XPOSE_F32(acc[a][i][b][0], acc[a][i][b][1], o);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int gm = m0 + a * 128 + wr * 64 + i * 16 + er + 8 * k;
+                    const int gn = n0 + b * 128 + wc * 32 + ec;
+                    if (gm < p.M && gn + 4 <= p.N) *reinterpret_cast<f32x4*>(C + (size_t)gm * p.ldc + gn) = p.alpha * o[k];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        if (R) body(); else body_nores();
+      } else if (p.residual) {
+        // bf16 output with a bf16 residual (adapter-segment launches on the bf16 stream): fp32 chunks through the patch, residual added
+        // in fp32 before the single rounding, 8-byte accesses (8 lanes = 64 B per row)
         bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
-        const int lm_ = lane & 15, lq_ = lane >> 4;
+        const int ec = (lane & 7) * 4, er = lane >> 3;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int gm = m0 + a * 128 + wr * 64 + i * 16 + lm_;
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    const int gn = n0 + b * 128 + wc * 32 + widen_col(lq_);
-                    f32x4 v[2] = {p.alpha * acc[a][i][b][0], p.alpha * acc[a][i][b][1]};
-                    if (p.residual) {
-                        // residual add in fp32 before the single rounding: 8-byte reads in the accumulator layout (4 consecutive
-                        // columns of tile j), then the same widening as the plain store
+                    f32x4 o[2];
+                    EPI_XPOSE_F32(acc[a][i][b][0], acc[a][i][b][1], o);
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const int gr = n0 + b * 128 + wc * 32 + j * 16 + 4 * lq_;
-                            if (gm < p.M && gr + 4 <= p.N) {
-                                const u32x2 w = *reinterpret_cast<const u32x2*>(p.residual + (size_t)gm * p.ldr + gr);
-                                v[j][0] += bf16lo(w[0]); v[j][1] += bf16hi(w[0]); v[j][2] += bf16lo(w[1]); v[j][3] += bf16hi(w[1]);
-                            }
+                    for (int k = 0; k < 2; ++k) {
+                        const int gm = m0 + a * 128 + wr * 64 + i * 16 + er + 8 * k;
+                        const int gn = n0 + b * 128 + wc * 32 + ec;
+                        if (gm < p.M && gn + 4 <= p.N) {
+                            f32x4 v = p.alpha * o[k];
+                            const u32x2 w = *reinterpret_cast<const u32x2*>(p.residual + (size_t)gm * p.ldr + gn);
+                            v[0] += bf16lo(w[0]); v[1] += bf16hi(w[0]); v[2] += bf16lo(w[1]); v[3] += bf16hi(w[1]);
+                            u32x2 q;
+                            q[0] = pack_bf16(v[0], v[1]); q[1] = pack_bf16(v[2], v[3]);
+                            *reinterpret_cast<u32x2*>(C + (size_t)gm * p.ldc + gn) = q;
                         }
                     }
-                    const u32x4 w = widen_pair(v[0], v[1]);
+                }
+      } else {
+        // plain bf16 epilogue: rounded in the accumulator layout, the packed 16-row x 32-column chunk (1 KiB) through the patch, ONE
+        // 16-byte store per lane and chunk (lane -> row lane >> 2, columns (lane & 3) * 8 .. + 7)
+        bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    u32x4 w;
+                    EPI_XPOSE_BF16(widen_pair(p.alpha * acc[a][i][b][0], p.alpha * acc[a][i][b][1]), w);
+                    const int gm = m0 + a * 128 + wr * 64 + i * 16 + (lane >> 2);
+                    const int gn = n0 + b * 128 + wc * 32 + (lane & 3) * 8;
                     if (gm < p.M && gn + 8 <= p.N) *reinterpret_cast<u32x4*>(C + (size_t)gm * p.ldc + gn) = w;
                 }
-            }
       }
     }
     if constexpr (CONT) {
         TSTAMP(titer * 8 + 7);
         parb = (parb + ntp) & 1;
         if (!has_next) {
-            if (wr == 0) PBAR();  // balance the extra barrier of waves 4-7
+            if (!WAVES_HI() && !epi_par) PBAR();  // balance the extra barrier of waves 4-7
             break;
         }
         continue;
     }
-    if (wr == 0) PBAR();          // balance the extra barrier of waves 4-7
+    if (!WAVES_HI()) PBAR();          // balance the extra barrier of waves 4-7
     __syncthreads();
 
     // ---- epilogue.  The MFMAs were issued as (B fragment, A fragment), i.e. they accumulated C^T tiles: lane l of a 16x16
@@ -1145,12 +1168,14 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
             out[i * 4 + 2] = (uint32_t)ptab[i * 8 + 6];
             out[i * 4 + 3] = (uint32_t)ptab[i * 8 + 7];
         }
-        if (lane0 == 0) { out[252] = (uint32_t)npieces; out[253] = (uint32_t)ptab[511 * 8 + 5]; out[254] = (uint32_t)nt; out[255] = 0; }
+        if (lane0 == 0) { out[252] = (uint32_t)npieces; out[253] = (uint32_t)ptab[(PTAB_PIECES - 1) * 8 + 5]; out[254] = (uint32_t)nt; out[255] = 0; }
     }
 #endif
 }
 
 static int gemm256p_n_cu() { return vlr_compute_cus(); }      // grid of the persistent launches (whole XCD octets; 256 on MI355X)
+// grid of a launch over `ntiles` output tiles: the CUs (persistent workgroups, a piece list each) unless the list would not fit the table
+static int persist_grid(int ntiles, int n_cu) { return (ntiles > n_cu && ntiles / n_cu + 8 <= PTAB_PIECES) ? n_cu : ntiles; }
 static bf16_t* gemm256p_zero16() {
     static bf16_t* z = nullptr;
     static bool tried = false;
@@ -1161,18 +1186,9 @@ static bf16_t* gemm256p_zero16() {
     return z;
 }
 
-// stream-K tail / XCD rotation of a persistent continuous-pipeline launch (GemmParams::sched): needs more tiles than workgroups, K >= 1024
-// and the caller's 128 MiB scratch slot for this stream; otherwise plain rounds
-static void sk_prepare(GemmParams& p, int ntiles, int grid, hipStream_t stream) {
-    p.sched = 0; p.sk_ws = nullptr; p.sk_epoch = 0;
-    const int mode = vlr_gemm_sched_mode() & 7;
-    if (!mode || ntiles <= grid || (grid & 7) || (p.K + PK - 1) / PK < VLR_SK_MIN_KTILES) return;
-    uint32_t ep = 0;
-    float* ws = vlr_gemm_sk_workspace(stream, &ep);
-    if (!ws) return;
-    p.sched = mode; p.sk_ws = ws; p.sk_epoch = ep;
-    if (mode & 4) hipMemsetAsync((char*)ws + VLR_SK_FLAG_OFF + 32768, 0, 8 * 64, stream);      // per-XCD arrival counters of the round barrier
-}
+// GemmParams::sched of a launch: bit 3 = adapter K tiles on the general staging path, bit 4 = serial epilogue order (both A/B switches,
+// vlr_gemm_set_sched / VLR_GEMM_SCHED; 0 in production)
+static void sched_prepare(GemmParams& p) { p.sched = vlr_gemm_sched_mode() & 24; }
 
 bool vlr_gemm256p_fused_try_launch(const GemmParams& p_in, hipStream_t stream) {
     GemmParams p = p_in;
@@ -1192,11 +1208,11 @@ bool vlr_gemm256p_fused_try_launch(const GemmParams& p_in, hipStream_t stream) {
     const int tiles_n = p.fuse == 1 ? ((p.N >> 1) + 127) / 128 : p.N / PT;
     const int ntiles = tiles_m * tiles_n;
     if (p.K < 4 * PK) return false;
-    const int grid = ntiles > n_cu ? n_cu : ntiles;       // few tiles (small batches, the peeled last tile rows): one tile per workgroup
+    const int grid = persist_grid(ntiles, n_cu);       // few tiles (small batches, the peeled last tile rows): one tile per workgroup
     if (p.fuse == 2 && (p.N % PT != 0 || p.rope_cols % PT != 0)) return false;
     if (p.fuse == 1 && ((p.N >> 1) % 8 != 0 || p.ldc2 % 8 != 0 || ((uintptr_t)p.C2 & 15))) return false;
     if ((((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.C) & 15) || p.lda % 8 != 0 || p.ldb % 8 != 0 || p.ldc % 8 != 0) return false;
-    sk_prepare(p, ntiles, grid, stream);
+    sched_prepare(p);
     TRACE_SET(p);
     const int pi = vlr_prof_begin(VLR_K_GEMM256P, 2.0 * p.M * p.N * p.K, stream);
     if (p.fuse == 1) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 1>), dim3(grid), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
@@ -1209,7 +1225,7 @@ bool vlr_gemm256p_fused_try_launch(const GemmParams& p_in, hipStream_t stream) {
 // residual), 1 (SwiGLU), 2 (RoPE).  false: the caller runs the base GEMM and the adapter GEMMs separately.
 bool vlr_gemm256p_seg_try_launch(const GemmParams& p_in, hipStream_t stream) {
     GemmParams p = p_in;
-    p.sched = vlr_gemm_sched_mode() & 8;       // bit 3 (A/B switch): adapter K tiles on the general staging path
+    sched_prepare(p);
     static int on = -1;
     if (on < 0) {
         const char* e = getenv("VLR_GEMM_SEG");
@@ -1225,7 +1241,7 @@ bool vlr_gemm256p_seg_try_launch(const GemmParams& p_in, hipStream_t stream) {
     const int tiles_m = (p.M + PT - 1) / PT;
     const int tiles_n = p.fuse == 1 ? ((p.N >> 1) + 127) / 128 : (p.N + PT - 1) / PT;
     if (p.K < 4 * PK || p.K % PK != 0) return false;
-    const int grid = tiles_m * tiles_n > n_cu ? n_cu : tiles_m * tiles_n;
+    const int grid = persist_grid(tiles_m * tiles_n, n_cu);
     if (p.K2 % 8 != 0 || p.lda2 % 8 != 0 || p.ldb2 % 8 != 0 || (((uintptr_t)p.A2 | (uintptr_t)p.B2) & 15)) return false;
     if (p.fuse != 1 && ((p.seg_b0 < p.N && p.seg_b0 % PT != 0) || (p.seg_b1 < p.N && p.seg_b1 % PT != 0))) return false;   // a tile lies in one block
     if (p.fuse == 2 && (p.N % PT != 0 || p.rope_cols % PT != 0)) return false;
@@ -1284,9 +1300,9 @@ bool vlr_gemm256p_swiglu_bwd_try_launch(const GemmParams& p_in, hipStream_t stre
     const int n_cu = gemm256p_n_cu();
     const int ntiles = ((p.M + PT - 1) / PT) * ((p.N + PT - 1) / PT);
     if (p.K < 4 * PK) return false;
-    const int grid = ntiles > n_cu ? n_cu : ntiles;
+    const int grid = persist_grid(ntiles, n_cu);
     if ((((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.C2) & 15) || p.lda % 8 != 0 || p.ldb % 8 != 0 || p.N % 8 != 0 || p.ldc2 % 8 != 0) return false;
-    sk_prepare(p, ntiles, grid, stream);
+    sched_prepare(p);
     TRACE_SET(p);
     const int pi = vlr_prof_begin(VLR_K_GEMM256P, 2.0 * p.M * p.N * p.K, stream);
     hipLaunchKernelGGL((gemm256p_kernel<false, true, 0, true, 3>), dim3(grid), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
@@ -1322,10 +1338,10 @@ bool vlr_gemm256p_lmhead_try_launch(const GemmParams& p_in, hipStream_t stream) 
     if (!zero16) return false;
     const int n_cu = gemm256p_n_cu();
     const int ntiles = ((p.M + PT - 1) / PT) * ((p.N + PT - 1) / PT);
-    if (ntiles <= n_cu || p.K < 4 * PK) return false;
+    if (ntiles <= n_cu || persist_grid(ntiles, n_cu) != n_cu || p.K < 4 * PK) return false;
     if ((((uintptr_t)p.A | (uintptr_t)p.B) & 15) || p.lda % 8 != 0 || p.ldb % 8 != 0 || p.N % 8 != 0) return false;
     if (p.fuse == 5 && (p.ldc % 8 != 0 || ((uintptr_t)p.C & 15))) return false;
-    sk_prepare(p, ntiles, n_cu, stream);
+    sched_prepare(p);
     TRACE_SET(p);
     const int pi = vlr_prof_begin(VLR_K_GEMM256P, 2.0 * p.M * p.N * p.K, stream);
     if (p.fuse == 4) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true, 4>), dim3(n_cu), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
@@ -1337,7 +1353,7 @@ bool vlr_gemm256p_lmhead_try_launch(const GemmParams& p_in, hipStream_t stream) 
 // returns false when the problem does not qualify (caller falls back to the staggered / 128x128 kernels)
 bool vlr_gemm256p_try_launch(int layout, const GemmParams& p_in, hipStream_t stream) {
     GemmParams p = p_in;
-    p.sched = 0; p.sk_ws = nullptr; p.sk_epoch = 0;
+    sched_prepare(p);
     TRACE_SET(p);
     static int mode = -1;
     static bf16_t* zero16 = nullptr;
@@ -1360,7 +1376,7 @@ bool vlr_gemm256p_try_launch(int layout, const GemmParams& p_in, hipStream_t str
     static int persist = -1;
     if (persist < 0) { const char* e = getenv("VLR_GEMM_PERSIST"); persist = (e && e[0] == '0') ? 0 : 1; }
     const int n_cu = persist ? gemm256p_n_cu() : (1 << 30);
-    const int tiles = ntiles < n_cu ? ntiles : n_cu;   // grid size: persistent workgroups when there are more tiles than CUs
+    const int tiles = persist_grid(ntiles, n_cu);   // grid size: persistent workgroups when there are more tiles than CUs
     // 16-byte DMA source alignment: k-contiguous operands need ld % 8 and K % 8 (checked by the caller), k-strided
     // operands ld % 8 and at least 8 columns; pointers 16-byte aligned
     const bool a_ks = layout == 2, b_ks = layout != 0;
@@ -1397,7 +1413,7 @@ bool vlr_gemm256p_try_launch(int layout, const GemmParams& p_in, hipStream_t str
     const bool f32_ok = p.out_f32 && f32_cont && (!p.residual || (p.res_f32 && p.ldr % 4 == 0 && !((uintptr_t)p.residual & 15))) && p.ldc % 4 == 0 && p.N % 4 == 0;
     if (cont && ntiles > tiles && !p.bias && (p.out_f32 ? f32_ok : (res_ok && !p.res_f32)) && !p.accumulate && p.act == ACT_NONE && p.K >= 4 * PK &&
         (p.out_f32 || (p.ldc % 8 == 0 && p.N % 8 == 0)) && !((uintptr_t)p.C & 15)) {
-        sk_prepare(p, ntiles, tiles, stream);
+        sched_prepare(p);
         if (layout == 0) hipLaunchKernelGGL((gemm256p_kernel<false, false, 0, true>), dim3(tiles), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
         else if (layout == 1) hipLaunchKernelGGL((gemm256p_kernel<false, true, 0, true>), dim3(tiles), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
         else hipLaunchKernelGGL((gemm256p_kernel<true, true, 0, true>), dim3(tiles), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
