@@ -28,6 +28,37 @@ def _digest():
     return h.hexdigest()
 
 
+def check_kloop_isa(asm_path):
+    """gemm256p.hip: the steady-state K loop of every kernel (the branch-free innermost loop with exactly 64 v_mfma: 4 phases x 16)
+    must hold ONE vector-memory wait, the hand-written counted vmcnt(6).  Any other s_waitcnt vmcnt in there is hipcc guarding a
+    register against an epilogue load it believes pending - it drains the LDS-DMA queue every K tile (-7 % on the TN kernel when it
+    happened).  Raises with the kernel name and the offending waits."""
+    import re
+    text = open(asm_path).read()
+    bad, seen = [], 0
+    for m in re.finditer(r"^(_Z15gemm256p_kernel\w+):[^\n]*\n(.*?)\.end_amdhsa_kernel", text, re.S | re.M):
+        name, body = m.group(1), m.group(2).split("\n")
+        targs = re.match(r"_Z15gemm256p_kernelILb(\d)ELb(\d)ELi(\d+)ELb(\d)ELi(\d+)ELb(\d)E", name)
+        if targs and int(targs.group(3)) != 0:
+            continue                                   # timing-ablation instantiations (VLR_GEMM_ABLATE)
+        labels = {l.split(":")[0]: i for i, l in enumerate(body) if l.startswith(".LBB")}
+        for i, l in enumerate(body):
+            t = re.match(r"\s+s_cbranch_\w+\s+(\.LBB\w+)", l)
+            if not t or t.group(1) not in labels or labels[t.group(1)] >= i:
+                continue
+            loop = body[labels[t.group(1)]:i]
+            if sum("v_mfma" in x for x in loop) != 64 or any(x.startswith(".LBB") for x in loop[1:]):
+                continue
+            seen += 1
+            waits = [x.strip() for x in loop if "s_waitcnt" in x and "vmcnt" in x]
+            if waits != ["s_waitcnt vmcnt(6)"]:
+                bad.append((name, waits))
+    if bad:
+        raise RuntimeError("gemm256p.hip: stray vector-memory waits in the steady-state K loop:\n" + "\n".join(f"  {n}: {w}" for n, w in bad))
+    if seen < 12:
+        raise RuntimeError(f"gemm256p.hip: the ISA check found only {seen} steady-state K loops (expected one per kernel) - update check_kloop_isa")
+
+
 def build(force=False, verbose=True, defines=(), tag=""):
     """defines / tag: a diagnostics variant of the library (e.g. defines=("VLR_GEMM_TRACE",), tag="_trace" -> libvlr_hip_trace.so with
     its own object directory), loaded through VLR_LIB; the product build is the one with neither."""
@@ -46,7 +77,9 @@ def build(force=False, verbose=True, defines=(), tag=""):
         cmd = [hipcc] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if src.endswith(".hip"):
             cmd.append("-Rpass-analysis=kernel-resource-usage")
-        r = subprocess.run(cmd, capture_output=True, text=True)
+        if src == "gemm256p.hip":
+            cmd.append("-save-temps")          # keeps the gfx950 assembly (in OBJ) for check_kloop_isa
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=OBJ)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-4000:]}")
         # a kernel that touches scratch (spill, or a register array the compiler could not keep in VGPRs) is a 10-20x
@@ -55,6 +88,8 @@ def build(force=False, verbose=True, defines=(), tag=""):
         for m in re.finditer(r"Function Name: (\S+).*?ScratchSize \[bytes/lane\]: (\d+)", r.stderr, re.S):
             if int(m.group(2)) > 0 and not tag:      # (diagnostics variants may: they are not what is measured or shipped)
                 raise RuntimeError(f"{src}: kernel {m.group(1)} uses {m.group(2)} B/lane of scratch")
+        if src == "gemm256p.hip":
+            check_kloop_isa(os.path.join(OBJ, "gemm256p-hip-amdgcn-amd-amdhsa-gfx950.s"))
         return obj
 
     with ThreadPoolExecutor(max_workers=6) as ex:

@@ -85,7 +85,7 @@ struct GemmParams {
     const unsigned char* drop_bits;
 #ifdef VLR_GEMM_TRACE
     uint32_t* trace;         // diagnostics build only: set by the launchers of gemm256p.hip (vlr_gemm_set_trace), never by callers
-    int dephase_p, dephase_ticks;
+    int dephase_p, dephase_ticks, epi_abl;
 #endif
 };
 #define VLR_SCHED_DEFAULT 0           // GemmParams::sched when VLR_GEMM_SCHED is not set

@@ -250,18 +250,29 @@ static void trace_set(GemmParams& p) {
         int a = 0, b = 0;
         if (e && sscanf(e, "%d,%d", &a, &b) == 2 && a > 0 && b > 0) { g_dephase_p = a; g_dephase_ticks = b * 100; }
     }
-    p.trace = g_trace; p.dephase_p = g_dephase_p; p.dephase_ticks = g_dephase_ticks;
+    static int abl = -1;
+    if (abl < 0) { const char* e = getenv("VLR_EPI_ABLATE"); abl = e ? atoi(e) : 0; }      // timing only (wrong results): 1 no epilogue loads, 2 no epilogue stores
+    p.trace = g_trace; p.dephase_p = g_dephase_p; p.dephase_ticks = g_dephase_ticks; p.epi_abl = abl;
 }
 #define TRACE_SET(p_) trace_set(p_)
+#define EPI_LD_ON (!(p.epi_abl & 1))
+#define EPI_ST_ON (!(p.epi_abl & 2))
 #else
 #define TSTAMP(slot_) do { } while (0)
 #define TRACE_SET(p_) do { } while (0)
+#define EPI_LD_ON true
+#define EPI_ST_ON true
 #endif
 
 // ---- epilogue staging of the continuous-pipeline kernels: a wave-private LDS patch (EPATCH_BYTES behind the piece table) turns the
 // accumulator layout (lane (lm, lq): row lm, 4 columns at 4 lq of a 16 x 16 tile) into row-contiguous registers.  LDS instructions of
 // one wave execute in order, so write -> read -> next write need no wait, only a compiler barrier (`epatch`, `lane` of the kernel).
 #define EPI_SYNC() do { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+// An epilogue load whose value is only used under a predicate (an edge-tile store) is waited for inside that branch; on the other path
+// it stays "pending" for hipcc, which then guards the next write of that register - a fragment read at the TOP OF THE K LOOP - with
+// s_waitcnt vmcnt(0..1) and drains the LDS-DMA queue every K tile (the TN kernel lost 7 % that way; build_hip.py now checks the ISA of
+// the K loops for stray vmcnt waits).  EPI_USE consumes the value unconditionally, i.e. puts the wait where the value arrives.
+#define EPI_USE(x_) asm volatile("" ::"v"(x_))
 // fp32: the tiles j = 0, 1 (16 rows x 32 columns) -> o_[k] = row (lane >> 3) + 8 k, columns (lane & 7) * 4 .. + 3
 #define EPI_XPOSE_F32(t0_, t1_, o_)                                                                                   \
     do {                                                                                                              \
@@ -271,6 +282,17 @@ static void trace_set(GemmParams& p) {
         EPI_SYNC();                                                                                                   \
         (o_)[0] = *reinterpret_cast<const f32x4*>(epatch + (lane >> 3) * EPATCH_STRIDE + (lane & 7) * 16);            \
         (o_)[1] = *reinterpret_cast<const f32x4*>(epatch + ((lane >> 3) + 8) * EPATCH_STRIDE + (lane & 7) * 16);      \
+    } while (0)
+// fp32, 8 columns per lane: o_[0], o_[1] = row lane >> 2, columns (lane & 3) * 8 .. + 3 / + 4 .. + 7 (for epilogues whose global accesses are
+// bf16: 8 columns = 16 bytes per lane, 4 lanes = 64 B per row, 16 rows per instruction - half the instructions of the 4-column form)
+#define EPI_XPOSE_F32_8(t0_, t1_, o_)                                                                                 \
+    do {                                                                                                              \
+        EPI_SYNC();                                                                                                   \
+        *reinterpret_cast<f32x4*>(epatch + (lane & 15) * EPATCH_STRIDE + (lane >> 4) * 16) = (t0_);                   \
+        *reinterpret_cast<f32x4*>(epatch + (lane & 15) * EPATCH_STRIDE + 64 + (lane >> 4) * 16) = (t1_);              \
+        EPI_SYNC();                                                                                                   \
+        (o_)[0] = *reinterpret_cast<const f32x4*>(epatch + (lane >> 2) * EPATCH_STRIDE + (lane & 3) * 32);            \
+        (o_)[1] = *reinterpret_cast<const f32x4*>(epatch + (lane >> 2) * EPATCH_STRIDE + (lane & 3) * 32 + 16);       \
     } while (0)
 // bf16: w_in_ = widen_pair(tile 0, tile 1) (row lane & 15, 8 columns at widen_col(lane >> 4)) -> w_out_ = row lane >> 2, columns
 // (lane & 3) * 8 .. + 7 of the 32-column strip
@@ -765,56 +787,54 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
         // folded the four swaps on one accumulator into one)
         bf16_t* GU = reinterpret_cast<bf16_t*>(p.C2);
         const int I = p.N;
-        const int ec = (lane & 7) * 4, er = lane >> 3;
-        // per A half: the gate | up loads of its 8 chunks together, then transposition, arithmetic and stores chunk by chunk
+        // per A half: the gate | up loads of its 8 chunks together (16 bytes = 8 columns per lane: row lane >> 2), then transposition,
+        // arithmetic and two 16-byte stores chunk by chunk
+        const int ec8 = (lane & 3) * 8, er8 = lane >> 2;
         static_for<0, 2>([&](auto ac) {
             constexpr int a = decltype(ac)::value;
-            u32x2 gq[8][2], uq[8][2];
+            u32x4 gq[8], uq[8];
             static_for<0, 8>([&](auto cc) {      // unpredicated, clamped at the edges
                 constexpr int c = decltype(cc)::value;
                 constexpr int i = c >> 1, b = c & 1;
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    int gm = m0 + a * 128 + wr * 64 + i * 16 + er + 8 * k;
-                    int gn = n0 + b * 128 + wc * 32 + ec;
-                    gm = gm < p.M ? gm : p.M - 1;
-                    gn = gn + 4 <= I ? gn : I - 4;
-                    gq[c][k] = *reinterpret_cast<const u32x2*>(GU + (size_t)gm * p.ldc2 + gn);
-                    uq[c][k] = *reinterpret_cast<const u32x2*>(GU + (size_t)gm * p.ldc2 + I + gn);
+                int gm = m0 + a * 128 + wr * 64 + i * 16 + er8;
+                int gn = n0 + b * 128 + wc * 32 + ec8;
+                gm = gm < p.M ? gm : p.M - 1;
+                gn = gn + 8 <= I ? gn : I - 8;
+                gq[c] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+                uq[c] = gq[c];
+                if (EPI_LD_ON) {
+                    gq[c] = *reinterpret_cast<const u32x4*>(GU + (size_t)gm * p.ldc2 + gn);
+                    uq[c] = *reinterpret_cast<const u32x4*>(GU + (size_t)gm * p.ldc2 + I + gn);
                 }
             });
             static_for<0, 8>([&](auto cc) {
                 constexpr int c = decltype(cc)::value;
                 constexpr int i = c >> 1, b = c & 1;
                 f32x4 o[2];
-                EPI_XPOSE_F32(acc[a][i][b][0], acc[a][i][b][1], o);
+                EPI_XPOSE_F32_8(acc[a][i][b][0], acc[a][i][b][1], o);
+                EPI_USE(gq[c]); EPI_USE(uq[c]);
+                const int gm = m0 + a * 128 + wr * 64 + i * 16 + er8;
+                const int gn = n0 + b * 128 + wc * 32 + ec8;
+                const bool ok = gm < p.M && gn + 8 <= I;
+                float d[8] = {o[0][0], o[0][1], o[0][2], o[0][3], o[1][0], o[1][1], o[1][2], o[1][3]};
+                if (p.residual && ok) {     // + addend on d act (the LoRA term of down_proj)
+                    float ad[8];
+                    unpack8(*reinterpret_cast<const u32x4*>(p.residual + (size_t)gm * p.ldr + gn), ad);
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int gm = m0 + a * 128 + wr * 64 + i * 16 + er + 8 * k;
-                    const int gn = n0 + b * 128 + wc * 32 + ec;
-                    const bool ok = gm < p.M && gn + 4 <= I;
-                    f32x4 d = o[k];
-                    if (p.residual && ok) {     // + addend on d act (the LoRA term of down_proj)
-                        const u32x2 w = *reinterpret_cast<const u32x2*>(p.residual + (size_t)gm * p.ldr + gn);
-                        d[0] += bf16lo(w[0]); d[1] += bf16hi(w[0]); d[2] += bf16lo(w[1]); d[3] += bf16hi(w[1]);
-                    }
-                    const u32x2 gw = gq[c][k], uw = uq[c][k];
-                    const float g[4] = {bf16lo(gw[0]), bf16hi(gw[0]), bf16lo(gw[1]), bf16hi(gw[1])};
-                    const float u[4] = {bf16lo(uw[0]), bf16hi(uw[0]), bf16lo(uw[1]), bf16hi(uw[1])};
-                    float dg[4], du[4];
+                    for (int e = 0; e < 8; ++e) d[e] += ad[e];
+                }
+                float g[8], u[8], dg[8], du[8];
+                unpack8(gq[c], g);
+                unpack8(uq[c], u);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float sg = 1.f / (1.f + __expf(-g[e]));
-                        du[e] = d[e] * g[e] * sg;
-                        dg[e] = d[e] * u[e] * sg * (1.f + g[e] * (1.f - sg));
-                    }
-                    if (ok) {
-                        u32x2 qg, qu;
-                        qg[0] = pack_bf16(dg[0], dg[1]); qg[1] = pack_bf16(dg[2], dg[3]);
-                        qu[0] = pack_bf16(du[0], du[1]); qu[1] = pack_bf16(du[2], du[3]);
-                        *reinterpret_cast<u32x2*>(GU + (size_t)gm * p.ldc2 + gn) = qg;
-                        *reinterpret_cast<u32x2*>(GU + (size_t)gm * p.ldc2 + I + gn) = qu;
-                    }
+                for (int e = 0; e < 8; ++e) {
+                    const float sg = 1.f / (1.f + __expf(-g[e]));
+                    du[e] = d[e] * g[e] * sg;
+                    dg[e] = d[e] * u[e] * sg * (1.f + g[e] * (1.f - sg));
+                }
+                if (EPI_ST_ON && ok) {
+                    *reinterpret_cast<u32x4*>(GU + (size_t)gm * p.ldc2 + gn) = pack8(dg);
+                    *reinterpret_cast<u32x4*>(GU + (size_t)gm * p.ldc2 + I + gn) = pack8(du);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
@@ -826,69 +846,66 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
         // stores, 64 B per row; the positions of all 16 rows of the lane first, then the table rows of one (a, i) ahead of its arithmetic.
         bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
         const bool rot = n0 < p.rope_cols;            // q and k tiles; v tiles pass through
-        const int ec = (lane & 7) * 4, er = lane >> 3;
-        const int fc = (wc & 1) * 32 + ec;            // feature inside the 64-wide half
-        const int hc = n0 + (wc >> 1) * 128 + fc;     // output column of the first-half feature (second half: + 64)
-        float b1[4] = {0.f, 0.f, 0.f, 0.f}, b2[4] = {0.f, 0.f, 0.f, 0.f};
+        const int ec8 = (lane & 3) * 8, er8 = lane >> 2;
+        const int fc = (wc & 1) * 32 + ec8;           // feature inside the 64-wide half (8 of them per lane)
+        const int hc = n0 + (wc >> 1) * 128 + fc;     // output column of the first-half features (second half: + 64)
+        float b1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, b2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (p.bias) {                                  // biased fused projection (Qwen c_attn): added before the rotation
-            const u32x2 w1 = *reinterpret_cast<const u32x2*>(p.bias + hc), w2 = *reinterpret_cast<const u32x2*>(p.bias + hc + 64);
-            b1[0] = bf16lo(w1[0]); b1[1] = bf16hi(w1[0]); b1[2] = bf16lo(w1[1]); b1[3] = bf16hi(w1[1]);
-            b2[0] = bf16lo(w2[0]); b2[1] = bf16hi(w2[0]); b2[2] = bf16lo(w2[1]); b2[3] = bf16hi(w2[1]);
+            const u32x4 w1 = *reinterpret_cast<const u32x4*>(p.bias + hc), w2 = *reinterpret_cast<const u32x4*>(p.bias + hc + 64);
+            EPI_USE(w1); EPI_USE(w2);
+            unpack8(w1, b1);
+            unpack8(w2, b2);
         }
-        // per A half: the positions of the lane's 8 rows, the cos / sin rows of its 4 row blocks (i), then transposition, rotation and
-        // stores block by block
+        // per A half: the positions of the lane's 4 rows (one per row block i), the cos / sin rows of those blocks (two 16-byte loads
+        // each: 4 lanes read the 128-byte line of a position's features), then transposition (8 columns per lane), rotation and the two
+        // 16-byte stores block by block
         auto body = [&](auto rotc) {
             constexpr bool ROT = decltype(rotc)::value;
             static_for<0, 2>([&](auto ac) {
                 constexpr int a = decltype(ac)::value;
                 f32x4 cs[4][2], sn[4][2];
                 if constexpr (ROT) {
-                    int ps[4][2];
+                    int ps[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        int gm = m0 + a * 128 + wr * 64 + i * 16 + er8;
+                        gm = gm < p.M ? gm : p.M - 1;          // rows past the edge take the last row's position, and are not stored
+                        int q = p.pos[gm];
+                        q = q < 0 ? 0 : (q >= p.max_pos ? p.max_pos - 1 : q);
+                        ps[i] = q;
+                    }
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int k = 0; k < 2; ++k) {
-                            int gm = m0 + a * 128 + wr * 64 + i * 16 + er + 8 * k;
-                            gm = gm < p.M ? gm : p.M - 1;          // rows past the edge take the last row's position, and are not stored
-                            int q = p.pos[gm];
-                            q = q < 0 ? 0 : (q >= p.max_pos ? p.max_pos - 1 : q);
-                            ps[i][k] = q;
-                        }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int k = 0; k < 2; ++k) {
-                            cs[i][k] = *reinterpret_cast<const f32x4*>(p.rope_cos + (size_t)(ps[i][k] * 64 + fc));
-                            sn[i][k] = *reinterpret_cast<const f32x4*>(p.rope_sin + (size_t)(ps[i][k] * 64 + fc));
+                            cs[i][k] = *reinterpret_cast<const f32x4*>(p.rope_cos + (size_t)(ps[i] * 64 + fc + 4 * k));
+                            sn[i][k] = *reinterpret_cast<const f32x4*>(p.rope_sin + (size_t)(ps[i] * 64 + fc + 4 * k));
                         }
                 }
                 static_for<0, 4>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
                     f32x4 o1[2], o2[2];
-                    EPI_XPOSE_F32(acc[a][i][0][0], acc[a][i][0][1], o1);
-                    EPI_XPOSE_F32(acc[a][i][1][0], acc[a][i][1][1], o2);
+                    EPI_XPOSE_F32_8(acc[a][i][0][0], acc[a][i][0][1], o1);
+                    EPI_XPOSE_F32_8(acc[a][i][1][0], acc[a][i][1][1], o2);
+                    if constexpr (ROT) { EPI_USE(cs[i][0]); EPI_USE(cs[i][1]); EPI_USE(sn[i][0]); EPI_USE(sn[i][1]); }
+                    const int gm = m0 + a * 128 + wr * 64 + i * 16 + er8;
+                    float y1[8], y2[8];
 #pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const int gm = m0 + a * 128 + wr * 64 + i * 16 + er + 8 * k;
-                        float y1[4], y2[4];
+                    for (int k = 0; k < 2; ++k)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float x1 = o1[k][e] + b1[e], x2 = o2[k][e] + b2[e];
+                            const float x1 = o1[k][e] + b1[4 * k + e], x2 = o2[k][e] + b2[4 * k + e];
                             if constexpr (ROT) {
-                                y1[e] = x1 * cs[i][k][e] - x2 * sn[i][k][e];
-                                y2[e] = x2 * cs[i][k][e] + x1 * sn[i][k][e];
+                                y1[4 * k + e] = x1 * cs[i][k][e] - x2 * sn[i][k][e];
+                                y2[4 * k + e] = x2 * cs[i][k][e] + x1 * sn[i][k][e];
                             } else {
-                                y1[e] = x1;
-                                y2[e] = x2;
+                                y1[4 * k + e] = x1;
+                                y2[4 * k + e] = x2;
                             }
                         }
-                        if (gm < p.M) {
-                            u32x2 q1, q2;
-                            q1[0] = pack_bf16(y1[0], y1[1]); q1[1] = pack_bf16(y1[2], y1[3]);
-                            q2[0] = pack_bf16(y2[0], y2[1]); q2[1] = pack_bf16(y2[2], y2[3]);
-                            *reinterpret_cast<u32x2*>(C + (size_t)gm * p.ldc + hc) = q1;
-                            *reinterpret_cast<u32x2*>(C + (size_t)gm * p.ldc + hc + 64) = q2;
-                        }
+                    if (gm < p.M) {
+                        *reinterpret_cast<u32x4*>(C + (size_t)gm * p.ldc + hc) = pack8(y1);
+                        *reinterpret_cast<u32x4*>(C + (size_t)gm * p.ldc + hc + 64) = pack8(y2);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });
@@ -926,7 +943,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                         int gn = n0 + b * 128 + wc * 32 + ec;
                         gm = gm < p.M ? gm : p.M - 1;
                         gn = gn + 4 <= p.N ? gn : p.N - 4;
-                        rv[c][k] = *reinterpret_cast<const f32x4*>(R + (size_t)gm * p.ldr + gn);
+                        rv[c][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (EPI_LD_ON) rv[c][k] = *reinterpret_cast<const f32x4*>(R + (size_t)gm * p.ldr + gn);
                     }
                 });
                 static_for<0, 8>([&](auto cc) {
@@ -934,12 +952,13 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                     constexpr int i = c >> 1, b = c & 1;
                     f32x4 o[2];
                     EPI_XPOSE_F32(acc[a][i][b][0], acc[a][i][b][1], o);
+                    EPI_USE(rv[c][0]); EPI_USE(rv[c][1]);
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
                         const int gm = m0 + a * 128 + wr * 64 + i * 16 + er + 8 * k;
                         const int gn = n0 + b * 128 + wc * 32 + ec;
                         const f32x4 v = p.alpha * o[k] + rv[c][k];
-                        if (gm < p.M && gn + 4 <= p.N) *reinterpret_cast<f32x4*>(C + (size_t)gm * p.ldc + gn) = v;
+                        if (EPI_ST_ON && gm < p.M && gn + 4 <= p.N) *reinterpret_cast<f32x4*>(C + (size_t)gm * p.ldc + gn) = v;
                     }
                     __builtin_amdgcn_sched_barrier(0);      // one chunk's addresses at a time
                 });

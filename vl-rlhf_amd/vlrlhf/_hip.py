@@ -180,6 +180,8 @@ def lib():
             fn.restype = I
             fn.argtypes = sig
         for name, sig in _INT_HELPERS.items():
+            if os.environ.get("VLR_LIB") and not hasattr(l, name):      # A/B against an older build of the library: newer diagnostics entries may be absent
+                continue
             fn = getattr(l, name)
             fn.restype = I
             fn.argtypes = sig
