@@ -45,6 +45,15 @@ int vlr_gemm_bf16(int layout, const void* A, const void* B, void* C, const void*
 int vlr_gemm_bf16_scaled(int layout, const void* A, const void* B, void* C, const void* bias, const void* residual, int M,
                          int N, int K, int lda, int ldb, int ldc, int ldr, int act, int accumulate, int out_f32,
                          float alpha, vlr_stream_t stream);
+/* Two weight-gradient GEMMs of one decoder layer in one launch (layout 2 of vlr_gemm_bf16, both over the same K token rows):
+ * C0 [M0][N0] = A0^T B0 and C1 [M1][N1] = A1^T B1 (A_i [K][lda_i], B_i [K][ldb_i], bf16; accumulate as in vlr_gemm_bf16).  The output tiles
+ * of both problems form ONE persistent grid, so their tile counts add up before they are rounded to whole rounds of the CUs - the
+ * dW of gate|up and of down_proj of LLaMA-7B are 6 + 3 rounds apart and 8 together.  Same arithmetic and results as two vlr_gemm_bf16
+ * calls (which it falls back to when the shapes do not qualify).  Replaces two of the cuBLAS wgrad calls under autograd's backward of
+ * transformers LlamaMLP (call site src/vlrlhf/models/Llava/__init__.py:232-243). */
+int vlr_gemm_bf16_tn_pair(const void* A0, const void* B0, void* C0, int M0, int N0, int lda0, int ldb0, int ldc0, const void* A1,
+                          const void* B1, void* C1, int M1, int N1, int lda1, int ldb1, int ldc1, int K, int accumulate,
+                          vlr_stream_t stream);
 /* fp32 residual stream (vlr_llama_cfg.resid_f32): C fp32 [M][ldc] = A . B (layout as above) + residual fp32 [M][ldr] (NULL: none);
  * in place (C == residual) is allowed.  Replaces the `hidden_states = residual + hidden_states` adds of transformers
  * LlamaDecoderLayer.forward (call site src/vlrlhf/models/Llava/__init__.py:232) without the bf16 rounding of the sum. */

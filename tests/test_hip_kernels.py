@@ -1317,6 +1317,41 @@ def test_gemm_sched_fused_epilogues(hip):
                 assert torch.equal(t0, t1), f"fused epilogue under sched {mode}"
 
 
+@pytest.mark.parametrize("shape", [((22016, 4096), (4096, 11008), 1064),      # the dW_gate|up + dW_down pair of the 7B layer: one tile row peeled
+                                   ((4096, 4096), (4096, 11008), 520),       # 256 + 688 tiles: no peel
+                                   ((2048, 1024), (1024, 2816), 300)])       # 32 + 44 tiles: fewer than the CUs -> two plain calls
+def test_gemm_tn_pair(hip, shape):
+    """vlr_gemm_bf16_tn_pair: two weight-gradient GEMMs as one persistent launch - against fp32 torch, and bit-identical to two
+    vlr_gemm_bf16 calls on every row the 256x256 kernel computes in both (the peeled tile row runs split along K: tolerance only);
+    NaN-filled outputs prove every element is written; accumulate = 1 takes the two-call path and adds."""
+    (M0, N0), (M1, N1), K = shape
+    a0, b0 = rnd(K, M0, seed=1, scale=0.5), rnd(K, N0, seed=2, scale=0.5)
+    a1, b1 = rnd(K, M1, seed=3, scale=0.5), rnd(K, N1, seed=4, scale=0.5)
+    c0 = torch.full((M0, N0), float("nan"), dtype=torch.bfloat16, device=DEV)
+    c1 = torch.full((M1, N1), float("nan"), dtype=torch.bfloat16, device=DEV)
+    hip.call("vlr_gemm_bf16_tn_pair", a0, b0, c0, M0, N0, M0, N0, N0, a1, b1, c1, M1, N1, M1, N1, N1, K, 0)
+    torch.cuda.synchronize()
+    r0, r1 = a0.float().t() @ b0.float(), a1.float().t() @ b1.float()
+    check(c0, r0, 8e-3, f"tn pair, problem 0 {shape}")
+    check(c1, r1, 8e-3, f"tn pair, problem 1 {shape}")
+    s0, s1 = torch.empty_like(c0), torch.empty_like(c1)
+    hip.call("vlr_gemm_bf16", 2, a0, b0, s0, None, None, M0, N0, K, M0, N0, N0, 0, 0, 0, 0)
+    hip.call("vlr_gemm_bf16", 2, a1, b1, s1, None, None, M1, N1, K, M1, N1, N1, 0, 0, 0, 0)
+    torch.cuda.synchronize()
+    # rows that the 256x256 kernel computes in the separate launches AND in the pair (the separate launches peel nothing at these shapes
+    # or other rows): identical K order -> identical bits on the overwhelming majority of rows; everything within the GEMM tolerance
+    same0 = (c0 == s0).all(dim=1).float().mean().item()
+    same1 = (c1 == s1).all(dim=1).float().mean().item()
+    assert same0 > 0.9 and same1 > 0.9, (same0, same1)
+    check(c0, s0, 8e-3, "pair vs single, problem 0")
+    check(c1, s1, 8e-3, "pair vs single, problem 1")
+    c0b, c1b = c0.clone(), c1.clone()
+    hip.call("vlr_gemm_bf16_tn_pair", a0, b0, c0b, M0, N0, M0, N0, N0, a1, b1, c1b, M1, N1, M1, N1, N1, K, 1)
+    torch.cuda.synchronize()
+    check(c0b, 2 * r0, 1.2e-2, "tn pair accumulate 0")
+    check(c1b, 2 * r1, 1.2e-2, "tn pair accumulate 1")
+
+
 # ---------------------------------------------------------------------------------------------------- grouped skinny GEMMs (LoRA)
 @pytest.mark.parametrize("M,in_,r,groups", [(12792, 4096, 128, 3), (1406, 1024, 64, 2), (300, 256, 16, 1)])
 def test_gemm_grouped_masked(hip, M, in_, r, groups):

@@ -56,7 +56,10 @@ def main():
         "wgrad o TN   [4096,4096,M]": (lambda: _hip.call("vlr_gemm_bf16", 2, dyH, x, go, None, None, H, H, M, H, H, H, 0, 0, 0, 0), 2.0 * M * H * H),
         "wgrad gu TN  [22016,4096,M]": (lambda: _hip.call("vlr_gemm_bf16", 2, dgu, x, ggu, None, None, 2 * I, H, M, 2 * I, H, H, 0, 0, 0, 0), 2.0 * M * 2 * I * H),
         "wgrad down TN [4096,11008,M]": (lambda: _hip.call("vlr_gemm_bf16", 2, dyH, xi, gd, None, None, H, I, M, H, I, I, 0, 0, 0, 0), 2.0 * M * H * I),
+        "wgrad gu + down, one launch": (lambda: _hip.call("vlr_gemm_bf16_tn_pair", dgu, x, ggu, 2 * I, H, 2 * I, H, H, dyH, xi, gd, H, I, H, I, I, M, 0), 2.0 * M * 3 * I * H),
     }
+    if not hasattr(_hip.lib(), "vlr_gemm_bf16_tn_pair"):      # an older build of the library through VLR_LIB
+        del cases["wgrad gu + down, one launch"]
     times = {k: {m: [] for m in modes} for k in cases}
     for name, (fn, _) in cases.items():
         for m in modes:
@@ -76,6 +79,8 @@ def main():
                 times[name][m].append(s.elapsed_time(e) / a.iters)
     _hip.helper("vlr_gemm_set_sched", -1)
     per_layer = {"qkv+rope NT  [M,12288,4096]": 2, "o_proj f32res NT [M,4096,4096]": 2, "swiglu NT   [M,22016,4096]": 2, "down f32res NT [M,4096,11008]": 2}
+    if "wgrad gu + down, one launch" in cases:                # what the layer backward calls; the two single rows are then for comparison only
+        per_layer.update({"wgrad gu TN  [22016,4096,M]": 0, "wgrad down TN [4096,11008,M]": 0})
     tot = {m: 0.0 for m in modes}
     print(f"{'shape':34s} " + " ".join(f"{'mode ' + str(m) + ' ms (TF/s)':>22s}" for m in modes))
     for name, (fn, fl) in cases.items():

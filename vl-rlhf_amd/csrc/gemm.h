@@ -62,6 +62,12 @@ struct GemmParams {
     // ---- fp32 residual stream (vlr_llama_cfg::resid_f32): residual is read as fp32 [M][ldr]; with out_f32 the o_proj / down_proj
     // launches are C fp32 = acc + residual fp32 (no rounding of the stream at all)
     int res_f32;
+    // ---- second problem of a GROUPED launch of the 256x256 TN continuous-pipeline kernel (gemm256p.hip, template GRP; same K, alpha 1, plain
+    // bf16 epilogue): C1 [M1][ldc1] = A1^T B1.  Set by vlr_gemm256p_tn_pair_try_launch only.
+    const bf16_t* A1;
+    const bf16_t* B1;
+    void* C1;
+    int M1, N1, lda1, ldb1, ldc1;
     // ---- A/B switches of the continuous-pipeline kernels (vlr_gemm_set_sched): bit 3 = adapter K tiles on the general staging path,
     // bit 4 = the two wave groups run their epilogues one after the other (the order before round 4).  0 in production.
     int sched;
@@ -112,6 +118,8 @@ bool vlr_lora_dx_try_launch(int n, const void* v, int ldv, const void* A, void* 
                             float scale, int accumulate, const void* bits, long bits_gstride, hipStream_t stream);
 bool vlr_gemm256p_seg_try_launch(const GemmParams& p, hipStream_t stream);
 bool vlr_gemm256p_fused_try_launch(const GemmParams& p, hipStream_t stream);
+// two TN problems of equal K (the weight gradients of two linears of one layer) as ONE persistent launch; false: shapes it does not take
+bool vlr_gemm256p_tn_pair_try_launch(const GemmParams& p0, const GemmParams& p1, hipStream_t stream);
 // fuse = 3 (NN): d act = dy . Wdown with the SwiGLU backward applied in the epilogue to gate | up in p.C2 (in place)
 bool vlr_gemm256p_swiglu_bwd_try_launch(const GemmParams& p, hipStream_t stream);
 // fuse = 4 | 5: the lm-head GEMM with the log-softmax statistics / the logits gradient in its epilogue

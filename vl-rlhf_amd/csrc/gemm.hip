@@ -648,6 +648,54 @@ extern "C" int vlr_gemm_bf16_scaled(int layout, const void* A, const void* B, vo
     return gemm_impl(layout, A, B, C, bias, residual, M, N, K, lda, ldb, ldc, ldr, act, accumulate, out_f32, alpha, stream);
 }
 
+// Two weight-gradient GEMMs of one layer (TN: C_i [M_i][N_i] = A_i^T B_i over the same K token rows) as ONE persistent launch: their tile
+// counts add up before they are rounded to whole rounds of the CUs (LLaVA-1.5-7B: dW_gate|up 1376 tiles + dW_down 688 = 8.06 rounds
+// instead of 6 + 3; one tile row of 16 tiles goes to the 128x128 kernel split along K and 8 rounds remain).  Falls back to two calls.
+extern "C" int vlr_gemm_bf16_tn_pair(const void* A0, const void* B0, void* C0, int M0, int N0, int lda0, int ldb0, int ldc0,
+                                     const void* A1, const void* B1, void* C1, int M1, int N1, int lda1, int ldb1, int ldc1, int K,
+                                     int accumulate, hipStream_t stream) {
+    VLR_REQUIRE(A0 && B0 && C0 && A1 && B1 && C1 && M0 > 0 && N0 > 0 && M1 > 0 && N1 > 0 && K > 0, "vlr_gemm_bf16_tn_pair: bad arguments");
+    const int ncu = vlr_compute_cus();
+    const int tm[2] = {(M0 + 255) / 256, (M1 + 255) / 256}, tn[2] = {(N0 + 255) / 256, (N1 + 255) / 256};
+    const int Ms[2] = {M0, M1}, Ns[2] = {N0, N1};
+    const int sep = (tm[0] * tn[0] + ncu - 1) / ncu + (tm[1] * tn[1] + ncu - 1) / ncu;       // rounds of two launches
+    // best (problem, tile rows peeled to the 128x128 kernel) for the joint launch, priced like choose_peel
+    double best = 1e30;
+    int bq = -1, br = 0;
+    for (int q = 0; q < 2; ++q)
+        for (int r = 0; r <= 3 && tm[q] - r >= 1; ++r) {
+            const int t = tm[0] * tn[0] + tm[1] * tn[1] - r * tn[q];
+            const int rem_rows = r ? Ms[q] - (tm[q] - r) * 256 : 0;
+            const long t128 = (long)((rem_rows + 127) / 128) * ((Ns[q] + 127) / 128);
+            const double est = (double)((t + ncu - 1) / ncu) + 0.7 * (double)((t128 + 2 * ncu - 1) / (2 * ncu));
+            if (est < best - 1e-9) { best = est; bq = q; br = r; }
+        }
+    static int pair_on = -1;
+    if (pair_on < 0) { const char* e = getenv("VLR_GEMM_PAIR"); pair_on = (e && e[0] == '0') ? 0 : 1; }
+    if (pair_on && !accumulate && best < (double)sep - 0.25 && K % 8 == 0) {
+        GemmParams p[2] = {fused_params(A0, B0, C0, M0, N0, K, lda0, ldb0, ldc0), fused_params(A1, B1, C1, M1, N1, K, lda1, ldb1, ldc1)};
+        GemmParams rest = p[bq];
+        if (br) {
+            const int keep = (tm[bq] - br) * 256;
+            p[bq].M = keep;
+            rest.M = Ms[bq] - keep;
+            rest.A = p[bq].A + keep;                                  // TN: the output rows are columns of A [K][lda]
+            rest.C = (bf16_t*)p[bq].C + (size_t)keep * p[bq].ldc;
+        }
+        const int pi = vlr_prof_begin(2, 2.0 * K * ((double)M0 * N0 + (double)M1 * N1), stream);
+        if (vlr_gemm256p_tn_pair_try_launch(p[0], p[1], stream)) {
+            if (br && !launch_splitk128(2, rest, stream, 4096))
+                launch128(2, rest, dim3(((rest.M + BM - 1) / BM) * ((rest.N + BN - 1) / BN)), stream);
+            vlr_prof_end(pi, stream);
+            return vlr_check_launch("vlr_gemm_bf16_tn_pair");
+        }
+        vlr_prof_end(-1, stream);
+    }
+    int rc = vlr_gemm_bf16(2, A0, B0, C0, nullptr, nullptr, M0, N0, K, lda0, ldb0, ldc0, 0, 0, accumulate, 0, stream);
+    if (rc != VLR_OK) return rc;
+    return vlr_gemm_bf16(2, A1, B1, C1, nullptr, nullptr, M1, N1, K, lda1, ldb1, ldc1, 0, 0, accumulate, 0, stream);
+}
+
 // fp32 residual stream (vlr_llama_cfg::resid_f32; o_proj / down_proj of the decoder layer): C fp32 [M][ldc] = A . B + residual
 // fp32 [M][ldr] (NULL: none) - the stream is never rounded.  Same layouts and dispatch as vlr_gemm_bf16.
 extern "C" int vlr_gemm_bf16_f32res(int layout, const void* A, const void* B, float* C, const float* residual, int M, int N, int K,
@@ -686,6 +734,7 @@ static int gemm_impl_ex(int layout, const void* A, const void* B, void* C, const
     p.A2 = p.B2 = nullptr; p.lda2 = p.ldb2 = p.K2 = 0; p.seg_b0 = p.seg_b1 = 0x7fffffff; p.drop_key = 0; p.drop_thr = 0; p.drop_ld = 0;
     p.res_f32 = residual ? res_f32 : 0;
     p.sched = 0;
+    p.A1 = p.B1 = nullptr; p.C1 = nullptr; p.M1 = p.N1 = p.lda1 = p.ldb1 = p.ldc1 = 0;
     p.groups = 1; p.gA = p.gB = p.gC = 0; p.mask_on = 0; p.mask_seed = 0; p.mask_thr = 0; p.mask_ld = 0;
     p.mask_bits = nullptr; p.gMask = 0; p.drop_bits = nullptr;
     const int pi = vlr_prof_begin(layout, 2.0 * M * N * K, stream);
@@ -767,6 +816,7 @@ static GemmParams fused_params(const void* A, const void* B, void* C, int M, int
     p.f0 = p.f1 = nullptr;
     p.A2 = p.B2 = nullptr; p.lda2 = p.ldb2 = p.K2 = 0; p.seg_b0 = p.seg_b1 = 0x7fffffff; p.drop_key = 0; p.drop_thr = 0; p.drop_ld = 0; p.res_f32 = 0;
     p.sched = 0;
+    p.A1 = p.B1 = nullptr; p.C1 = nullptr; p.M1 = p.N1 = p.lda1 = p.ldb1 = p.ldc1 = 0;
     p.groups = 1; p.gA = p.gB = p.gC = 0; p.mask_on = 0; p.mask_seed = 0; p.mask_thr = 0; p.mask_ld = 0;
     p.mask_bits = nullptr; p.gMask = 0; p.drop_bits = nullptr;
     return p;

@@ -308,8 +308,13 @@ static void trace_set(GemmParams& p) {
 // CONT = true: continuous pipeline across the output tiles of a persistent workgroup (plain bf16 epilogue only): the last K tiles
 // of tile i stage the first K tiles of tile i+1 (same slots, same counted wait), the epilogue stores straight from the
 // accumulator registers (8 bytes per lane, no LDS, no barrier) and the K loop of tile i+1 starts with its data resident.
-template <bool A_KS, bool B_KS, int ABL = 0, bool CONT = false, int FUSE = 0, bool SEG = false>
+struct TileProb { const bf16_t* A; const bf16_t* B; void* C; int M, N, lda, ldb, ldc; };
+// GRP = true (TN continuous pipeline only): the launch covers TWO problems of equal K - (A, B, C, M, N, ld*) and (A1, ... ) of GemmParams -
+// as one list of output tiles, the first problem's tiles first: the weight gradients of gate|up and down_proj are 5.375 + 2.69 rounds
+// of 256 tiles as two launches (6 + 3) and 8.06 as one (the host peels one tile row to the 128x128 kernel: 8).
+template <bool A_KS, bool B_KS, int ABL = 0, bool CONT = false, int FUSE = 0, bool SEG = false, bool GRP = false>
 __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_t* __restrict__ zero16) {
+    static_assert(!GRP || (A_KS && B_KS && CONT && FUSE == 0 && !SEG), "grouped launches: TN, plain epilogue");
     static_assert(FUSE == 0 || (FUSE == 6 && !CONT && !A_KS && B_KS) || (FUSE != 6 && CONT && !A_KS && (FUSE == 3 ? B_KS : !B_KS)),
                   "fused epilogues: continuous pipeline; 1, 2, 4, 5 NT, 3 NN; 6 (dropout-accumulate) NN on the LDS-image epilogue");
     static_assert(!SEG || (!A_KS && !B_KS && FUSE <= 2), "adapter segment: NT, plain / SwiGLU / RoPE epilogues");
@@ -328,7 +333,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     // fetched; a workgroup that ends instead holds its CU (LDS) until the stores have landed and the next one starts cold:
     // 10-12 us per tile, measured (K sweep: 0.23 ms of fixed cost per 2304-tile launch).
     const int tiles_m = (p.M + PT - 1) / PT, tiles_n = FUSE == 1 ? ((p.N >> 1) + NW - 1) / NW : (p.N + PT - 1) / PT;
-    const int nwg = tiles_m * tiles_n;
+    const int tiles_m1 = GRP ? (p.M1 + PT - 1) / PT : 0, tiles_n1 = GRP ? (p.N1 + PT - 1) / PT : 0;
+    const int nwg0 = tiles_m * tiles_n;
+    const int nwg = nwg0 + tiles_m1 * tiles_n1;
     // SEG: K tiles [0, nt1) come from (A, B), [nt1, nt) from the adapter pair (A2 columns of this tile's output block, B2)
     const int nt1 = (p.K + PK - 1) / PK;
     const int k2t = !SEG ? 0 : (FUSE == 1 ? 2 * p.K2 : p.K2);
@@ -349,12 +356,15 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
             const int idx = jx + i * G8;
             const int q = nwg >> 3, rem = nwg & 7;
             const int pid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;      // XCD x owns a contiguous range of tile ids (bijective)
+            const bool g1 = GRP && pid >= nwg0;
+            const int pl = g1 ? pid - nwg0 : pid, tm = g1 ? tiles_m1 : tiles_m, tn_ = g1 ? tiles_n1 : tiles_n;
             const int GROUP = 8;
-            const int per_group = GROUP * tiles_n;
-            const int first_m = (pid / per_group) * GROUP;
-            const int gsz = min(tiles_m - first_m, GROUP);
-            ptab[i * 8 + 0] = (first_m + (pid % per_group) % gsz) * PT;
-            ptab[i * 8 + 1] = ((pid % per_group) / gsz) * NW;
+            const int per_group = GROUP * tn_;
+            const int first_m = (pl / per_group) * GROUP;
+            const int gsz = min(tm - first_m, GROUP);
+            ptab[i * 8 + 0] = (first_m + (pl % per_group) % gsz) * PT;
+            ptab[i * 8 + 1] = ((pl % per_group) / gsz) * NW;
+            ptab[i * 8 + 2] = g1 ? 1 : 0;
         }
     }
     __syncthreads();
@@ -376,9 +386,17 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     const int m0 = RFL(ptab[titer * 8 + 0]), n0 = RFL(ptab[titer * 8 + 1]);
     const int kb = 0, ntp = nt;                    // a piece is a whole tile: K tiles [0, nt)
     const bool has_next = CONT && titer + 1 < npieces;
-    const int tnx = has_next ? titer + 1 : titer;
-    const int m0n = RFL(ptab[tnx * 8 + 0]), n0n = RFL(ptab[tnx * 8 + 1]);
+    const int tni = has_next ? titer + 1 : titer;
+    const int m0n = RFL(ptab[tni * 8 + 0]), n0n = RFL(ptab[tni * 8 + 1]);
     const int kbn = 0;
+    // operands of this piece and of the next one: the launch's (A, B, C), or - GRP, two problems of equal K in one launch - those of
+    // the problem the piece belongs to (piece-table word 2)
+    TileProb tp = {p.A, p.B, p.C, p.M, p.N, p.lda, p.ldb, p.ldc}, tnx = tp;
+    if constexpr (GRP) {
+        const TileProb t1 = {p.A1, p.B1, p.C1, p.M1, p.N1, p.lda1, p.ldb1, p.ldc1};
+        if (RFL(ptab[titer * 8 + 2])) tp = t1;
+        if (RFL(ptab[tni * 8 + 2])) tnx = t1;
+    }
     const bool first = !CONT || titer == 0;
     const bool epi_par = CONT && !(p.sched & 16);      // both wave groups in the epilogue at once (sched bit 4 = the old serial order, A/B)
     parb = RFL(parb);
@@ -405,13 +423,13 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     uint32_t offA[2][2], offB[2][2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        if constexpr (A_KS) piece_off_ks(p.lda, m0 + h * 128, p.M, wave, lane, offA[h]);
-        else piece_off_kc(p.lda, m0 + h * 128, p.M, wave, lane, offA[h]);
-        if constexpr (B_KS) piece_off_ks(p.ldb, n0 + h * 128, p.N, wave, lane, offB[h]);
-        else piece_off_kc_b<FUSE>(p.ldb, n0, h, p.N, wave, lane, offB[h]);
+        if constexpr (A_KS) piece_off_ks(tp.lda, m0 + h * 128, tp.M, wave, lane, offA[h]);
+        else piece_off_kc(tp.lda, m0 + h * 128, tp.M, wave, lane, offA[h]);
+        if constexpr (B_KS) piece_off_ks(tp.ldb, n0 + h * 128, tp.N, wave, lane, offB[h]);
+        else piece_off_kc_b<FUSE>(tp.ldb, n0, h, tp.N, wave, lane, offB[h]);
     }
-    const size_t stepA = A_KS ? (size_t)PK * p.lda * 2 : (size_t)PK * 2;
-    const size_t stepB = B_KS ? (size_t)PK * p.ldb * 2 : (size_t)PK * 2;
+    const size_t stepA = A_KS ? (size_t)PK * tp.lda * 2 : (size_t)PK * 2;
+    const size_t stepB = B_KS ? (size_t)PK * tp.ldb * 2 : (size_t)PK * 2;
     const uint32_t lds_wave = (uint32_t)(uintptr_t)(lvoid_t*)smem + wave * 1024;
     // fastc = true: the caller guarantees tile < nt and that the tile is a full one (steady-state loop): no checks at all
     // `tile` is relative to the piece: K tile kb + tile of this output tile; tile >= ntp: K tile kbn + (tile - ntp) of the NEXT piece
@@ -426,11 +444,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                     char* dst = smem + ((tile + parb) & 1) * BUF_BYTES + h * HALF_BYTES;
                     const int k0 = (kbn + tile - ntp) * PK;
                     if constexpr (h < 2) {
-                        if constexpr (A_KS) stage_ks(p.A, p.lda, m0n + h * 128, p.M, k0, p.K, zero16, dst, wave, lane);
-                        else stage_kc(p.A, p.lda, m0n + h * 128, p.M, k0, p.K, zero16, dst, wave, lane);
+                        if constexpr (A_KS) stage_ks(tnx.A, tnx.lda, m0n + h * 128, tnx.M, k0, p.K, zero16, dst, wave, lane);
+                        else stage_kc(tnx.A, tnx.lda, m0n + h * 128, tnx.M, k0, p.K, zero16, dst, wave, lane);
                     } else {
-                        if constexpr (B_KS) stage_ks(p.B, p.ldb, n0n + (h - 2) * 128, p.N, k0, p.K, zero16, dst, wave, lane);
-                        else stage_kc_b<FUSE>(p.B, p.ldb, n0n, h - 2, p.N, k0, p.K, zero16, dst, wave, lane);
+                        if constexpr (B_KS) stage_ks(tnx.B, tnx.ldb, n0n + (h - 2) * 128, tnx.N, k0, p.K, zero16, dst, wave, lane);
+                        else stage_kc_b<FUSE>(tnx.B, tnx.ldb, n0n, h - 2, tnx.N, k0, p.K, zero16, dst, wave, lane);
                     }
                 }
                 return;
@@ -442,8 +460,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                 asm volatile("" : "+v"(ln));         // set hipcc would otherwise carry (and spill) through the whole K loop
                 char* dst = smem + ((tile + parb) & 1) * BUF_BYTES + h * HALF_BYTES;
                 const int k0 = (kb + tile - nt1) * PK;
-                if constexpr (h < 2) stage_kc(p.A2 + a2off, p.lda2, m0 + h * 128, p.M, k0, k2t, zero16, dst, wave, ln);
-                else stage_seg_b<FUSE>(p.B2, p.ldb2, n0, h - 2, p.N, k0, p.K2, zero16, dst, wave, ln);
+                if constexpr (h < 2) stage_kc(p.A2 + a2off, p.lda2, m0 + h * 128, tp.M, k0, k2t, zero16, dst, wave, ln);
+                else stage_seg_b<FUSE>(p.B2, p.ldb2, n0, h - 2, tp.N, k0, p.K2, zero16, dst, wave, ln);
                 return;
             }
         }
@@ -458,14 +476,14 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                 const int s_ = kb + tile - nt1;
                 uint32_t o2[2];
                 if constexpr (h < 2) {
-                    piece_off_kc(p.lda2, m0 + h * 128, p.M, wave, ln, o2);
+                    piece_off_kc(p.lda2, m0 + h * 128, tp.M, wave, ln, o2);
                     const char* base = (const char*)(p.A2 + a2off) + (size_t)s_ * (PK * 2);
                     lds_dma16_s(base, o2[0], dst);
                     lds_dma16_s(base, o2[1], dst + 8192);
                 } else {
                     const int k0 = s_ * PK - (FUSE == 1 ? (h - 2) * p.K2 : 0);
                     if (k0 >= 0 && k0 < p.K2) {
-                        piece_off_kc_b<FUSE>(p.ldb2, n0, h - 2, p.N, wave, ln, o2);
+                        piece_off_kc_b<FUSE>(p.ldb2, n0, h - 2, tp.N, wave, ln, o2);
                         const char* base = (const char*)p.B2 + (ptrdiff_t)k0 * 2;
                         lds_dma16_s(base, o2[0], dst);
                         lds_dma16_s(base, o2[1], dst + 8192);
@@ -483,21 +501,21 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
             char* dst = smem + ((tile + parb) & 1) * BUF_BYTES + h * HALF_BYTES;
             const int k0 = (kb + tile) * PK;
             if constexpr (h < 2) {
-                if constexpr (A_KS) stage_ks(p.A, p.lda, m0 + h * 128, p.M, k0, p.K, zero16, dst, wave, lane);
-                else stage_kc(p.A, p.lda, m0 + h * 128, p.M, k0, p.K, zero16, dst, wave, lane);
+                if constexpr (A_KS) stage_ks(tp.A, tp.lda, m0 + h * 128, tp.M, k0, p.K, zero16, dst, wave, lane);
+                else stage_kc(tp.A, tp.lda, m0 + h * 128, tp.M, k0, p.K, zero16, dst, wave, lane);
             } else {
-                if constexpr (B_KS) stage_ks(p.B, p.ldb, n0 + (h - 2) * 128, p.N, k0, p.K, zero16, dst, wave, lane);
-                else stage_kc_b<FUSE>(p.B, p.ldb, n0, h - 2, p.N, k0, p.K, zero16, dst, wave, lane);
+                if constexpr (B_KS) stage_ks(tp.B, tp.ldb, n0 + (h - 2) * 128, tp.N, k0, p.K, zero16, dst, wave, lane);
+                else stage_kc_b<FUSE>(tp.B, tp.ldb, n0, h - 2, tp.N, k0, p.K, zero16, dst, wave, lane);
             }
             return;
         }
         const uint32_t dst = lds_wave + ((tile + parb) & 1) * BUF_BYTES + h * HALF_BYTES;
         if constexpr (h < 2) {
-            const char* base = (const char*)p.A + (size_t)(kb + tile) * stepA;
+            const char* base = (const char*)tp.A + (size_t)(kb + tile) * stepA;
             lds_dma16_s(base, offA[h][0], dst);
             lds_dma16_s(base, offA[h][1], dst + 8192);
         } else {
-            const char* base = (const char*)p.B + (size_t)(kb + tile) * stepB;
+            const char* base = (const char*)tp.B + (size_t)(kb + tile) * stepB;
             lds_dma16_s(base, offB[h - 2][0], dst);
             lds_dma16_s(base, offB[h - 2][1], dst + 8192);
         }
@@ -676,9 +694,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
         // accumulators (one rounding), gate | up stored for the backward only when asked.  The arithmetic runs in the accumulator
         // layout (gate and up of an element sit in one lane); the rounded 16 x 32 chunks go through the patch and leave as 16-byte
         // stores, 4 lanes = 64 B per row (see the plain epilogue below).
-        bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+        bf16_t* C = reinterpret_cast<bf16_t*>(tp.C);
         bf16_t* C2 = reinterpret_cast<bf16_t*>(p.C2);
-        const int I = p.N >> 1;
+        const int I = tp.N >> 1;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -687,7 +705,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                 asm volatile("" : "+v"(ln));
                 const int gm = m0 + a * 128 + wr * 64 + i * 16 + (ln >> 2);
                 const int gn = n0 + wc * 32 + (ln & 3) * 8;
-                const bool ok = gm < p.M && gn + 8 <= I;
+                const bool ok = gm < tp.M && gn + 8 <= I;
                 f32x4 h[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -701,9 +719,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                 if (p.store_c) {
                     u32x4 wg, wu;
                     EPI_XPOSE_BF16(widen_pair(acc[a][i][0][0], acc[a][i][0][1]), wg);
-                    if (ok) *reinterpret_cast<u32x4*>(C + (size_t)gm * p.ldc + gn) = wg;
+                    if (ok) *reinterpret_cast<u32x4*>(C + (size_t)gm * tp.ldc + gn) = wg;
                     EPI_XPOSE_BF16(widen_pair(acc[a][i][1][0], acc[a][i][1][1]), wu);
-                    if (ok) *reinterpret_cast<u32x4*>(C + (size_t)gm * p.ldc + I + gn) = wu;
+                    if (ok) *reinterpret_cast<u32x4*>(C + (size_t)gm * tp.ldc + I + gn) = wu;
                 }
             }
     } else if constexpr (CONT && FUSE == 4) {
@@ -717,7 +735,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int gm = m0 + a * 128 + wr * 64 + i * 16 + lm_;
-                const int tg = gm < p.M ? p.pos[gm] : -1;
+                const int tg = gm < tp.M ? p.pos[gm] : -1;
                 float mx = -INFINITY;
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
@@ -727,7 +745,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const float v = acc[a][i][b][j][e];
-                            if (gn + e < p.N) mx = fmaxf(mx, v);
+                            if (gn + e < tp.N) mx = fmaxf(mx, v);
                             if (gn + e == tg) p.f1[gm] = v;               // exactly one lane of one workgroup owns the target column
                         }
                     }
@@ -742,26 +760,26 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                             const int gn = n0 + b * 128 + wc * 32 + j * 16 + 4 * lq_;
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
-                                if (gn + e < p.N) sm += __expf(acc[a][i][b][j][e] - mx);
+                                if (gn + e < tp.N) sm += __expf(acc[a][i][b][j][e] - mx);
                         }
                 }
                 sm += __shfl_xor(sm, 16);
                 sm += __shfl_xor(sm, 32);
-                if (lq_ == 0 && gm < p.M) {
+                if (lq_ == 0 && gm < tp.M) {
                     f32x2 o = {mx, sm};
                     *reinterpret_cast<f32x2*>(parts + ((size_t)gm * nparts + part) * 2) = o;
                 }
             }
     } else if constexpr (CONT && FUSE == 5) {
         // lm-head backward: d logits = g_row * ([col == target] - exp(logit - lse_row)), rounded once, 16-byte stores
-        bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+        bf16_t* C = reinterpret_cast<bf16_t*>(tp.C);
         const int lm_ = lane & 15, lq_ = lane >> 4;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int gm = m0 + a * 128 + wr * 64 + i * 16 + lm_;
-                const int gmc = gm < p.M ? gm : p.M - 1;
+                const int gmc = gm < tp.M ? gm : tp.M - 1;
                 const int tg = p.pos[gmc];
                 const float z = p.f0[gmc], g = p.f1[gmc];
 #pragma unroll
@@ -775,7 +793,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                     }
                     const int gn = n0 + b * 128 + wc * 32 + widen_col(lq_);
                     const u32x4 w = widen_pair(d[0], d[1]);
-                    if (gm < p.M && gn + 8 <= p.N) *reinterpret_cast<u32x4*>(C + (size_t)gm * p.ldc + gn) = w;
+                    if (gm < tp.M && gn + 8 <= tp.N) *reinterpret_cast<u32x4*>(C + (size_t)gm * tp.ldc + gn) = w;
                 }
             }
     } else if constexpr (CONT && FUSE == 3) {
@@ -786,7 +804,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
         // (History: the first version regrouped d act with v_permlane16_swap to the layout of 16-byte row-per-lane loads - hipcc 7.2
         // folded the four swaps on one accumulator into one)
         bf16_t* GU = reinterpret_cast<bf16_t*>(p.C2);
-        const int I = p.N;
+        const int I = tp.N;
         // per A half: the gate | up loads of its 8 chunks together (16 bytes = 8 columns per lane: row lane >> 2), then transposition,
         // arithmetic and two 16-byte stores chunk by chunk
         const int ec8 = (lane & 3) * 8, er8 = lane >> 2;
@@ -798,7 +816,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                 constexpr int i = c >> 1, b = c & 1;
                 int gm = m0 + a * 128 + wr * 64 + i * 16 + er8;
                 int gn = n0 + b * 128 + wc * 32 + ec8;
-                gm = gm < p.M ? gm : p.M - 1;
+                gm = gm < tp.M ? gm : tp.M - 1;
                 gn = gn + 8 <= I ? gn : I - 8;
                 gq[c] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
                 uq[c] = gq[c];
@@ -815,7 +833,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                 EPI_USE(gq[c]); EPI_USE(uq[c]);
                 const int gm = m0 + a * 128 + wr * 64 + i * 16 + er8;
                 const int gn = n0 + b * 128 + wc * 32 + ec8;
-                const bool ok = gm < p.M && gn + 8 <= I;
+                const bool ok = gm < tp.M && gn + 8 <= I;
                 float d[8] = {o[0][0], o[0][1], o[0][2], o[0][3], o[1][0], o[1][1], o[1][2], o[1][3]};
                 if (p.residual && ok) {     // + addend on d act (the LoRA term of down_proj)
                     float ad[8];
@@ -844,7 +862,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
         // through the patch (row-contiguous: lane -> rows er, er + 8; features fc .. fc + 3 of the head's first / second 64), so that the
         // cos / sin rows of the positions are read as whole 128-byte lines (8 lanes x 16 B) and the rotated values leave as 8-byte
         // stores, 64 B per row; the positions of all 16 rows of the lane first, then the table rows of one (a, i) ahead of its arithmetic.
-        bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+        bf16_t* C = reinterpret_cast<bf16_t*>(tp.C);
         const bool rot = n0 < p.rope_cols;            // q and k tiles; v tiles pass through
         const int ec8 = (lane & 3) * 8, er8 = lane >> 2;
         const int fc = (wc & 1) * 32 + ec8;           // feature inside the 64-wide half (8 of them per lane)
@@ -869,7 +887,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         int gm = m0 + a * 128 + wr * 64 + i * 16 + er8;
-                        gm = gm < p.M ? gm : p.M - 1;          // rows past the edge take the last row's position, and are not stored
+                        gm = gm < tp.M ? gm : tp.M - 1;          // rows past the edge take the last row's position, and are not stored
                         int q = p.pos[gm];
                         q = q < 0 ? 0 : (q >= p.max_pos ? p.max_pos - 1 : q);
                         ps[i] = q;
@@ -903,9 +921,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                                 y2[4 * k + e] = x2;
                             }
                         }
-                    if (gm < p.M) {
-                        *reinterpret_cast<u32x4*>(C + (size_t)gm * p.ldc + hc) = pack8(y1);
-                        *reinterpret_cast<u32x4*>(C + (size_t)gm * p.ldc + hc + 64) = pack8(y2);
+                    if (gm < tp.M) {
+                        *reinterpret_cast<u32x4*>(C + (size_t)gm * tp.ldc + hc) = pack8(y1);
+                        *reinterpret_cast<u32x4*>(C + (size_t)gm * tp.ldc + hc + 64) = pack8(y2);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });
@@ -923,7 +941,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
       // tiles keep arriving by LDS-DMA underneath.
       if (p.out_f32) {
         // fp32 output (fp32 residual stream: x_new = x + attn Wo^T / x + act Wdown^T), nothing is rounded
-        float* C = reinterpret_cast<float*>(p.C);
+        float* C = reinterpret_cast<float*>(tp.C);
         const float* R = reinterpret_cast<const float*>(p.residual);
         const int ec = (lane & 7) * 4, er = lane >> 3;
         // Per A half: its 16 residual loads (rows er, er + 8 of the 8 chunks (i, b): whole 128-byte lines) are issued together - the
@@ -941,8 +959,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                     for (int k = 0; k < 2; ++k) {
                         int gm = m0 + a * 128 + wr * 64 + i * 16 + er + 8 * k;
                         int gn = n0 + b * 128 + wc * 32 + ec;
-                        gm = gm < p.M ? gm : p.M - 1;
-                        gn = gn + 4 <= p.N ? gn : p.N - 4;
+                        gm = gm < tp.M ? gm : tp.M - 1;
+                        gn = gn + 4 <= tp.N ? gn : tp.N - 4;
                         rv[c][k] = f32x4{0.f, 0.f, 0.f, 0.f};
                         if (EPI_LD_ON) rv[c][k] = *reinterpret_cast<const f32x4*>(R + (size_t)gm * p.ldr + gn);
                     }
@@ -958,7 +976,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                         const int gm = m0 + a * 128 + wr * 64 + i * 16 + er + 8 * k;
                         const int gn = n0 + b * 128 + wc * 32 + ec;
                         const f32x4 v = p.alpha * o[k] + rv[c][k];
-                        if (EPI_ST_ON && gm < p.M && gn + 4 <= p.N) *reinterpret_cast<f32x4*>(C + (size_t)gm * p.ldc + gn) = v;
+                        if (EPI_ST_ON && gm < tp.M && gn + 4 <= tp.N) *reinterpret_cast<f32x4*>(C + (size_t)gm * tp.ldc + gn) = v;
                     }
                     __builtin_amdgcn_sched_barrier(0);      // one chunk's addresses at a time
                 });
@@ -974,7 +992,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                 for (int k = 0; k < 2; ++k) {
                     const int gm = m0 + a * 128 + wr * 64 + i * 16 + er + 8 * k;
                     const int gn = n0 + b * 128 + wc * 32 + ec;
-                    if (gm < p.M && gn + 4 <= p.N) *reinterpret_cast<f32x4*>(C + (size_t)gm * p.ldc + gn) = p.alpha * o[k];
+                    if (gm < tp.M && gn + 4 <= tp.N) *reinterpret_cast<f32x4*>(C + (size_t)gm * tp.ldc + gn) = p.alpha * o[k];
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
@@ -983,7 +1001,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
       } else if (p.residual) {
         // bf16 output with a bf16 residual (adapter-segment launches on the bf16 stream): fp32 chunks through the patch, residual added
         // in fp32 before the single rounding, 8-byte accesses (8 lanes = 64 B per row)
-        bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+        bf16_t* C = reinterpret_cast<bf16_t*>(tp.C);
         const int ec = (lane & 7) * 4, er = lane >> 3;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -997,20 +1015,20 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                     for (int k = 0; k < 2; ++k) {
                         const int gm = m0 + a * 128 + wr * 64 + i * 16 + er + 8 * k;
                         const int gn = n0 + b * 128 + wc * 32 + ec;
-                        if (gm < p.M && gn + 4 <= p.N) {
+                        if (gm < tp.M && gn + 4 <= tp.N) {
                             f32x4 v = p.alpha * o[k];
                             const u32x2 w = *reinterpret_cast<const u32x2*>(p.residual + (size_t)gm * p.ldr + gn);
                             v[0] += bf16lo(w[0]); v[1] += bf16hi(w[0]); v[2] += bf16lo(w[1]); v[3] += bf16hi(w[1]);
                             u32x2 q;
                             q[0] = pack_bf16(v[0], v[1]); q[1] = pack_bf16(v[2], v[3]);
-                            *reinterpret_cast<u32x2*>(C + (size_t)gm * p.ldc + gn) = q;
+                            *reinterpret_cast<u32x2*>(C + (size_t)gm * tp.ldc + gn) = q;
                         }
                     }
                 }
       } else {
         // plain bf16 epilogue: rounded in the accumulator layout, the packed 16-row x 32-column chunk (1 KiB) through the patch, ONE
         // 16-byte store per lane and chunk (lane -> row lane >> 2, columns (lane & 3) * 8 .. + 7)
-        bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+        bf16_t* C = reinterpret_cast<bf16_t*>(tp.C);
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -1021,7 +1039,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                     EPI_XPOSE_BF16(widen_pair(p.alpha * acc[a][i][b][0], p.alpha * acc[a][i][b][1]), w);
                     const int gm = m0 + a * 128 + wr * 64 + i * 16 + (lane >> 2);
                     const int gn = n0 + b * 128 + wc * 32 + (lane & 3) * 8;
-                    if (gm < p.M && gn + 8 <= p.N) *reinterpret_cast<u32x4*>(C + (size_t)gm * p.ldc + gn) = w;
+                    if (gm < tp.M && gn + 8 <= tp.N) *reinterpret_cast<u32x4*>(C + (size_t)gm * tp.ldc + gn) = w;
                 }
       }
     }
@@ -1047,7 +1065,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
         // 8-byte global reads), rounds ONCE and writes 8-byte pieces of a bf16 image of the whole 256x256 C tile in LDS; after a
         // barrier the block copies the image out as full 512-byte rows (two rows per wave instruction, 16 B per lane).
         // (The per-quadrant version wrote 64-byte row pieces straight from each wave: 12 us per tile, measured by ablation.)
-        const bf16_t* Cold = reinterpret_cast<const bf16_t*>(p.C);
+        const bf16_t* Cold = reinterpret_cast<const bf16_t*>(tp.C);
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -1056,7 +1074,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                 for (int j = 0; j < 2; ++j) {
                     const int tn_ = b * 128 + wc * 32 + j * 16 + 4 * lq;      // column inside the tile
                     const int gn = n0 + tn_;
-                    const bool nok = gn + 4 <= p.N;
+                    const bool nok = gn + 4 <= tp.N;
                     float bv[4] = {0.f, 0.f, 0.f, 0.f};
                     if (p.bias && nok) {
                         const u32x2 w = *reinterpret_cast<const u32x2*>(p.bias + gn);
@@ -1077,13 +1095,13 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                             for (int e = 0; e < 4; ++e)
                                 if ((uint32_t)((rr >> (16 * e)) & 0xffffu) < p.drop_thr) v[e] = 0.f;
                         }
-                        if (gm < p.M && nok) {
+                        if (gm < tp.M && nok) {
                             if (p.residual) {
                                 const u32x2 w = *reinterpret_cast<const u32x2*>(p.residual + (size_t)gm * p.ldr + gn);
                                 v[0] += bf16lo(w[0]); v[1] += bf16hi(w[0]); v[2] += bf16lo(w[1]); v[3] += bf16hi(w[1]);
                             }
                             if (FUSE != 6 && p.accumulate) {      // fuse 6 accumulates in the coalesced copy-out below
-                                const u32x2 w = *reinterpret_cast<const u32x2*>(Cold + (size_t)gm * p.ldc + gn);
+                                const u32x2 w = *reinterpret_cast<const u32x2*>(Cold + (size_t)gm * tp.ldc + gn);
                                 v[0] += bf16lo(w[0]); v[1] += bf16hi(w[0]); v[2] += bf16lo(w[1]); v[3] += bf16hi(w[1]);
                             }
                         }
@@ -1095,26 +1113,26 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                 }
             }
         __syncthreads();
-        bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+        bf16_t* C = reinterpret_cast<bf16_t*>(tp.C);
         const int cch = lane & 31;                     // 16-byte chunk of the 512-byte row
         const int gn = n0 + cch * 8;
 #pragma unroll 4
         for (int it = 0; it < 16; ++it) {
             const int row = it * 16 + wave * 2 + (lane >> 5);
             const int gm = m0 + row;
-            if (gm < p.M && gn + 8 <= p.N) {
+            if (gm < tp.M && gn + 8 <= tp.N) {
                 u32x4 w = *reinterpret_cast<const u32x4*>(smem + row * C_STRIDE + cch * 16);
                 if constexpr (FUSE == 6) {
                     // C += (rounded masked product): full 512-byte rows read and written once, 16 B per lane (the K loop is two
                     // tiles long - this read-modify-write IS the kernel); same two roundings as product -> scratch -> add
                     float o[8], d[8];
-                    unpack8(*reinterpret_cast<const u32x4*>(C + (size_t)gm * p.ldc + gn), o);
+                    unpack8(*reinterpret_cast<const u32x4*>(C + (size_t)gm * tp.ldc + gn), o);
                     unpack8(w, d);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] += d[e];
                     w = pack8(o);
                 }
-                *reinterpret_cast<u32x4*>(C + (size_t)gm * p.ldc + gn) = w;
+                *reinterpret_cast<u32x4*>(C + (size_t)gm * tp.ldc + gn) = w;
             }
         }
     } else {
@@ -1131,11 +1149,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const int gm0 = m0 + a * 128 + wr * 64, gn0 = n0 + b * 128 + wc * 32;
-        float* C = reinterpret_cast<float*>(p.C);
+        float* C = reinterpret_cast<float*>(tp.C);
         const int cq = (lane & 7) * 4;
         const int gn = gn0 + cq;
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias && gn + 4 <= p.N) {
+        if (p.bias && gn + 4 <= tp.N) {
             const u32x2 w = *reinterpret_cast<const u32x2*>(p.bias + gn);
             bv[0] = bf16lo(w[0]); bv[1] = bf16hi(w[0]); bv[2] = bf16lo(w[1]); bv[3] = bf16hi(w[1]);
         }
@@ -1143,7 +1161,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
         for (int it = 0; it < 8; ++it) {
             const int row = it * 8 + (lane >> 3);
             const int gm = gm0 + row;
-            if (gm < p.M && gn + 4 <= p.N) {
+            if (gm < tp.M && gn + 4 <= tp.N) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(patch + row * PS + cq);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = apply_act(p.alpha * v[e] + bv[e], p.act);
@@ -1155,7 +1173,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                         v[0] += bf16lo(w[0]); v[1] += bf16hi(w[0]); v[2] += bf16lo(w[1]); v[3] += bf16hi(w[1]);
                     }
                 }
-                float* dst = C + (size_t)gm * p.ldc + gn;
+                float* dst = C + (size_t)gm * tp.ldc + gn;
                 if (p.accumulate) {
                     const f32x4 o = *reinterpret_cast<const f32x4*>(dst);
 #pragma unroll
@@ -1339,6 +1357,35 @@ extern "C" int vlr_gemm_set_trace(void* buf, long bytes) {
     (void)buf; (void)bytes;
     VLR_REQUIRE(false, "vlr_gemm_set_trace: this library was built without -DVLR_GEMM_TRACE (python vl-rlhf_amd/build_hip.py --trace)");
 #endif
+}
+
+// Two TN problems of equal K as ONE persistent launch of the grouped continuous-pipeline kernel (template GRP): C0 = A0^T B0 and
+// C1 = A1^T B1, plain bf16 outputs.  false: the caller launches them one by one.
+bool vlr_gemm256p_tn_pair_try_launch(const GemmParams& p0, const GemmParams& p1, hipStream_t stream) {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("VLR_GEMM_PAIR");
+        on = (e && e[0] == '0') ? 0 : 1;
+        hipFuncSetAttribute((const void*)gemm256p_kernel<true, true, 0, true, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CONT_LDS_BYTES);
+    }
+    if (!on || p0.K != p1.K || p0.K < 4 * PK) return false;
+    bf16_t* zero16 = gemm256p_zero16();
+    if (!zero16) return false;
+    for (const GemmParams* q : {&p0, &p1}) {
+        if (q->bias || q->residual || q->accumulate || q->act != ACT_NONE || q->out_f32 || q->alpha != 1.f || q->fuse) return false;
+        if ((((uintptr_t)q->A | (uintptr_t)q->B | (uintptr_t)q->C) & 15) || q->lda % 8 != 0 || q->M % 8 != 0 || q->ldb % 8 != 0 || q->N % 8 != 0 || q->ldc % 8 != 0) return false;
+    }
+    const int n_cu = gemm256p_n_cu();
+    const int ntiles = ((p0.M + PT - 1) / PT) * ((p0.N + PT - 1) / PT) + ((p1.M + PT - 1) / PT) * ((p1.N + PT - 1) / PT);
+    if (ntiles <= n_cu || persist_grid(ntiles, n_cu) != n_cu) return false;
+    GemmParams p = p0;
+    p.A1 = p1.A; p.B1 = p1.B; p.C1 = p1.C; p.M1 = p1.M; p.N1 = p1.N; p.lda1 = p1.lda; p.ldb1 = p1.ldb; p.ldc1 = p1.ldc;
+    sched_prepare(p);
+    TRACE_SET(p);
+    const int pi = vlr_prof_begin(VLR_K_GEMM256P, 2.0 * p.K * ((double)p0.M * p0.N + (double)p1.M * p1.N), stream);
+    hipLaunchKernelGGL((gemm256p_kernel<true, true, 0, true, 0, false, true>), dim3(n_cu), dim3(512), CONT_LDS_BYTES, stream, p, (const bf16_t*)zero16);
+    vlr_prof_end(pi, stream);
+    return true;
 }
 
 int vlr_gemm256p_lmhead_parts(int V) { return ((V + PT - 1) / PT) * 4; }

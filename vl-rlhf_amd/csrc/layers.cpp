@@ -116,13 +116,20 @@ extern "C" int vlr_decoder_layer_bwd(const vlr_llama_cfg* cfg, const vlr_layer_w
     const bool two = two_streams();
     hipStream_t sd = st;
     // ---- MLP
-    if (two) { sd = fork_side(st); }
-    CHECK(vlr_gemm_bf16(2, dx_out, a->act, g->wdown, nullptr, nullptr, H, I, M, H, I, I, 0, 0, accumulate, 0, sd));
-    if (two) side_done(0);
+    if (two) {
+        sd = fork_side(st);
+        CHECK(vlr_gemm_bf16(2, dx_out, a->act, g->wdown, nullptr, nullptr, H, I, M, H, I, I, 0, 0, accumulate, 0, sd));
+        side_done(0);
+    }
     CHECK(vlr_gemm_swiglu_bwd(dx_out, w->wdown, a->gu, ws->dact, M, I, H, st));   // gu now holds [dgate | dup]; d act is not materialised
-    if (two) { sd = fork_side(st); }
-    CHECK(vlr_gemm_bf16(2, a->gu, a->xn2, g->wgu, nullptr, nullptr, 2 * I, H, M, 2 * I, H, H, 0, 0, accumulate, 0, sd));
-    if (two) side_done(1);
+    if (two) {
+        sd = fork_side(st);
+        CHECK(vlr_gemm_bf16(2, a->gu, a->xn2, g->wgu, nullptr, nullptr, 2 * I, H, M, 2 * I, H, H, 0, 0, accumulate, 0, sd));
+        side_done(1);
+    } else {
+        // dW_gate|up and dW_down as ONE persistent launch: 1376 + 688 output tiles are 8.06 rounds of 256 CUs together, 6 + 3 apart
+        CHECK(vlr_gemm_bf16_tn_pair(a->gu, a->xn2, g->wgu, 2 * I, H, 2 * I, H, H, dx_out, a->act, g->wdown, H, I, H, I, I, M, accumulate, st));
+    }
     CHECK(vlr_gemm_bf16(1, a->gu, w->wgu, ws->dxn, nullptr, nullptr, M, H, 2 * I, 2 * I, H, H, 0, 0, 0, 0, st));
     if (two) wait_side(2, st);                           // previous layer's dWo GEMM still reads ws->dx_mid
     CHECK(norm_bwd(cfg->resid_f32, ws->dxn, a->x_mid, w->ln2, a->rstd2, dx_out, ws->dx_mid, g->ln2, accumulate, ws->norm_ws, M, H, st));
@@ -317,7 +324,6 @@ extern "C" int vlr_decoder_layer_bwd_lora_ex(const vlr_llama_cfg* cfg, const vlr
 #define MB(t) (lw->mask_bits && p > 0.f ? (unsigned char*)lw->mask_bits + (size_t)(t) * ((size_t)M * H / 8) : nullptr)      // packed keep mask of target t
 #define MT(t) (lw->mask_bits && p > 0.f ? (unsigned char*)lw->mask_bits + lora_rowmajor_bytes(H, I, M) + (size_t)(t) * (size_t)vlr_dropout_bits_kt_bytes(M, H) : nullptr)   // ... K-tile-blocked transposed
     // ---- MLP
-    if (g) CHECK(vlr_gemm_bf16(2, dx_out, a->act, g->wdown, nullptr, nullptr, H, I, M, H, I, I, 0, 0, accumulate, 0, st));
     static int fuse_down = -1;     // VLR_LORA_FUSE_DOWN=1: adapter term of down_proj first, then the dgrad GEMM with the SwiGLU backward in its epilogue
     if (fuse_down < 0) { const char* e = getenv("VLR_LORA_FUSE_DOWN"); fuse_down = (e && e[0] == '1') ? 1 : 0; }
     if (lw->a_down && fuse_down) {
@@ -334,7 +340,7 @@ extern "C" int vlr_decoder_layer_bwd_lora_ex(const vlr_llama_cfg* cfg, const vlr
     } else {
         CHECK(vlr_gemm_swiglu_bwd(dx_out, w->wdown, a->gu, ws->dact, M, I, H, st));
     }
-    if (g) CHECK(vlr_gemm_bf16(2, a->gu, a->xn2, g->wgu, nullptr, nullptr, 2 * I, H, M, 2 * I, H, H, 0, 0, accumulate, 0, st));
+    if (g) CHECK(vlr_gemm_bf16_tn_pair(a->gu, a->xn2, g->wgu, 2 * I, H, 2 * I, H, H, dx_out, a->act, g->wdown, H, I, H, I, I, M, accumulate, st));
     CHECK(vlr_gemm_bf16(1, a->gu, w->wgu, ws->dxn, nullptr, nullptr, M, H, 2 * I, 2 * I, H, H, 0, 0, 0, 0, st));
     CHECK(lora_group_bwd(2, r, H, o_gu, a->xn2, a->gu, 2 * I, lw->a_gu, lw->b_gu, lg->a_gu, lg->b_gu, off(u, 4 * (size_t)r), ldu, ws_v,
                          ws->dxn, sc, p, seed + 4, XD(4), accumulate, M, st, 0, rowmask, MB(4), MT(4)));

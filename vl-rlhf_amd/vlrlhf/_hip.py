@@ -58,6 +58,7 @@ class VitWs(C.Structure):
 _SIGS = {
     "vlr_gemm_bf16": [I, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "vlr_gemm_bf16_scaled": [I, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, F, P],
+    "vlr_gemm_bf16_tn_pair": [P, P, P, I, I, I, I, I, P, P, P, I, I, I, I, I, I, I, P],
     "vlr_rmsnorm_fwd": [P, P, P, P, I, I, F, P],
     "vlr_rmsnorm_bwd": [P, P, P, P, P, P, P, I, P, I, I, P],
     "vlr_rmsnorm_fwd_f32": [P, P, P, P, I, I, F, P],
@@ -176,6 +177,8 @@ def lib():
         l.vlr_dropout_bits_kt_bytes.restype = C.c_long
         l.vlr_dropout_bits_kt_bytes.argtypes = [I, I]
         for name, sig in _SIGS.items():
+            if os.environ.get("VLR_LIB") and not hasattr(l, name):      # A/B against an older build of the library: newer entries may be absent
+                continue
             fn = getattr(l, name)
             fn.restype = I
             fn.argtypes = sig
