@@ -3,6 +3,8 @@
 
     python oracle/depth_parity.py small      # 1 pair, T = 128 (S = 703), ragged: fp32 + bf16 error budget
     python oracle/depth_parity.py configs0   # BASELINE.json configs[0]: 4 pairs, T = 256 (S = 831): fp32 + bf16-emulated
+    python oracle/depth_parity.py grads | grads_sharp   # fp32 autograd of the `small` case (VLR_DEPTH_LAYERS=2|32); _sharp: q / k weights x 2
+    python oracle/depth_parity.py seeds      # (round 4) the `small` case under 8 hashed models / batches: fp32 + the floor model
 
 The weights are the machine-independent hashed weights of oracle.llava_dpo_oracle.HashedWeights (reference = seed 0,
 policy = reference + 1e-3 * n'), so the GPU test regenerates the SAME 7B model on the MI355X from (seed, name) alone and
@@ -94,6 +96,7 @@ def run(case, variants, cfg, log):
 
 
 GRAD_LAYERS = (0, 17, 31)
+SHARP_QK = 2.0          # `grads_sharp`: scale of the q_proj / k_proj weights of the sharp-softmax fixture
 
 
 class _Leaves:
@@ -113,13 +116,52 @@ class _Leaves:
         return self.base.keys()
 
 
-def run_grads(cfg, log):
+SEED_SWEEP = 8          # `seeds`: weight seeds 1 .. SEED_SWEEP (reference = seed s, policy delta seed 100 + s), batch seed 20 + s
+FLOOR_TAGS = ("f32resid+vit_f32out",)
+
+
+def run_seeds(cfg, log):
+    """The `small` case under SEED_SWEEP different hashed models and batches: fp32 and the floor model of the HIP path's rounding
+    (oracle.HIP_ROUNDING) -> tests/golden/llava7b_depth<L>_seeds.json.  The GPU test (tests/test_hip_depth.py::test_depth32_seed_sweep)
+    rebuilds each model and asserts that the SIGNED loss / log-prob errors of the HIP path average to zero within 2 sigma / sqrt(n) - the
+    statistic a systematic offset cannot pass (a single draw at <= 3 sigma can hide a bias of a full sigma)."""
+    L = cfg["layers"]
+    path = os.path.join(ROOT, "tests", "golden", f"llava7b_depth{L}_seeds.json")
+    done = json.load(open(path))["seeds"] if os.path.exists(path) else []
+    floor = [v for v in VARIANTS if v[0] in FLOOR_TAGS][0]
+    for s in range(1 + len(done), SEED_SWEEP + 1):
+        spec = dict(CASES["small"], seed=20 + s)
+        batch = O.synthetic_batch(spec["pairs"], spec["text_len"], cfg["image_token"], 32000, cfg["image_size"], spec["seed"], ragged=spec["ragged"])
+        Wr = O.HashedWeights(cfg, seed=s, cache=True)
+        Wp = O.HashedWeights(cfg, seed=s, delta=1e-3, seed_delta=100 + s, cache=True)
+        rec = dict(seed=s, seed_delta=100 + s, spec=spec)
+        for tag, emu in (("fp32", False), ("floor", floor[1])):
+            t0 = time.time()
+            with torch.no_grad():
+                pc, pr, _, _ = O.concatenated_forward(Wp, cfg, batch, "sigmoid", emu)
+                rc, rr, _, _ = O.concatenated_forward(Wr, cfg, batch, "sigmoid", emu)
+                losses, _, _ = O.dpo_loss(pc, pr, rc, rr, 0.1)
+            rec[tag] = dict(loss=float(losses.mean()), policy_chosen_logps=pc.tolist(), policy_rejected_logps=pr.tolist(),
+                            reference_chosen_logps=rc.tolist(), reference_rejected_logps=rr.tolist())
+            log(f"seeds L{L} s={s} {tag}: loss {rec[tag]['loss']:.7f} [{time.time() - t0:.0f} s]")
+        rec["weight_probe"] = {k: Wp[k].double().sum().item() for k in ("language_model.model.layers.0.self_attn.q_proj.weight",
+                                                                          f"language_model.model.layers.{L - 1}.mlp.down_proj.weight")}
+        done.append(rec)
+        with open(path, "w") as f:      # after every seed: the sweep can be interrupted and resumed
+            json.dump(dict(layers=L, cfg="LLAVA_1_5_7B", beta=0.1, floor=FLOOR_TAGS[0],
+                           weights="HashedWeights(seed=s) reference; policy delta=1e-3 seed_delta=100+s; batch seed 20+s", seeds=done), f)
+        del Wr, Wp
+
+
+def run_grads(cfg, log, qk_scale=1.0):
     """fp32 gradients of the DPO loss of the `small` case w.r.t. every weight of decoder layers 0, 17, 31, the final norm and the
-    lm-head: per tensor the Frobenius norm and a 256-element probe -> tests/golden/llava7b_depth<L>_small_grads.json"""
+    lm-head: per tensor the Frobenius norm and a 256-element probe -> tests/golden/llava7b_depth<L>_small_grads.json
+    (qk_scale != 1: the "sharp" fixture - q_proj / k_proj drawn qk_scale times larger, so that the softmax is peaked and dq, dk are
+    first-order quantities whose DIRECTION can be asserted -> ..._sharp_grads.json)"""
     spec = CASES["small"]
     batch = O.synthetic_batch(spec["pairs"], spec["text_len"], cfg["image_token"], 32000, cfg["image_size"], spec["seed"], ragged=spec["ragged"])
-    Wr = O.HashedWeights(cfg, seed=0)
-    Wp = O.HashedWeights(cfg, seed=0, delta=1e-3, seed_delta=1)
+    Wr = O.HashedWeights(cfg, seed=0, qk_scale=qk_scale)
+    Wp = O.HashedWeights(cfg, seed=0, delta=1e-3, seed_delta=1, qk_scale=qk_scale)
     L = cfg["layers"]
     names = ["language_model.model.norm.weight", "language_model.lm_head.weight"]
     for l in sorted(set(min(x, L - 1) for x in GRAD_LAYERS)):
@@ -139,17 +181,20 @@ def run_grads(cfg, log):
         stride = max(1, flat.numel() // 256)
         out[n] = dict(norm=float(g.double().norm()), stride=stride, probe=flat[::stride][:256].tolist())
     log(f"grads: backward done [{time.time() - t0:.0f} s]")
-    path = os.path.join(ROOT, "tests", "golden", f"llava7b_depth{L}_small_grads.json")
+    path = os.path.join(ROOT, "tests", "golden", f"llava7b_depth{L}_{'small' if qk_scale == 1.0 else 'sharp'}_grads.json")
     with open(path, "w") as f:
-        json.dump(dict(layers=L, spec=spec, loss=float(loss), grads=out), f)
+        json.dump(dict(layers=L, spec=spec, loss=float(loss), qk_scale=qk_scale, grads=out), f)
     log(f"grads -> {path}")
 
 
 def main():
     case = sys.argv[1] if len(sys.argv) > 1 else "small"
-    if case == "grads":
+    if case in ("grads", "grads_sharp"):
         layers = int(os.environ.get("VLR_DEPTH_LAYERS", "32"))
-        return run_grads(dict(O.LLAVA_1_5_7B, layers=layers), lambda s_: print(s_, flush=True))
+        return run_grads(dict(O.LLAVA_1_5_7B, layers=layers), lambda s_: print(s_, flush=True), qk_scale=SHARP_QK if case == "grads_sharp" else 1.0)
+    if case == "seeds":
+        layers = int(os.environ.get("VLR_DEPTH_LAYERS", "32"))
+        return run_seeds(dict(O.LLAVA_1_5_7B, layers=layers), lambda s_: print(s_, flush=True))
     layers = int(os.environ.get("VLR_DEPTH_LAYERS", "32"))
     cfg = dict(O.LLAVA_1_5_7B, layers=layers)
     variants = VARIANTS if case == "small" else VARIANTS[:2]

@@ -866,8 +866,10 @@ class HashedWeights:
     """Lazy mapping name -> fp32 tensor with transformers==4.41.0 LLaVA checkpoint names; nothing is stored.
     `delta` > 0: value = bf16(base(seed) + delta * n(seed_delta)) - a policy that differs from the reference `base`."""
 
-    def __init__(self, cfg, seed=0, std=0.02, delta=0.0, seed_delta=1, device="cpu", cache=False):
+    def __init__(self, cfg, seed=0, std=0.02, delta=0.0, seed_delta=1, device="cpu", cache=False, qk_scale=1.0):
         self.cfg, self.seed, self.std, self.delta, self.seed_delta, self.device = cfg, seed, std, delta, seed_delta, device
+        self.qk_scale = qk_scale     # > 1: the decoder's q_proj / k_proj weights are drawn qk_scale times larger (sharper softmax: the
+                                     # "sharp" depth fixtures, whose q / k gradients are large enough to be compared by direction)
         self._cache = {} if cache else None          # bf16 copies (2 B / parameter) for multi-pass runs
         D, P, H, I, V = cfg["vit_hidden"], cfg["patch_size"], cfg["hidden"], cfg["inter"], cfg["vocab"]
         nkv = cfg.get("kv_heads", cfg["heads"])
@@ -922,7 +924,8 @@ class HashedWeights:
     def _make(self, name):
         shape = self.shapes[name]
         gain = name.endswith("norm.weight") or name.endswith("norm1.weight") or name.endswith("norm2.weight") or name.endswith("layrnorm.weight")
-        t = hashed_tensor(shape, self.seed, name, self.std, gain, self.device)
+        qk = self.qk_scale != 1.0 and name.startswith("language_model.") and name.endswith(("q_proj.weight", "k_proj.weight"))
+        t = hashed_tensor(shape, self.seed, name, self.std * (self.qk_scale if qk else 1.0), gain, self.device)
         if self.delta > 0 and not name.startswith("vision_tower."):
             t = (t + hashed_normal(t.numel(), self.seed_delta, name, self.device).view(*shape) * self.delta).to(torch.bfloat16).to(torch.float32)
         return t

@@ -39,7 +39,7 @@ def hashed_normal(n, seed, name, device):
     return out
 
 
-def init_hashed_model(model, seed=0, std=0.02, policy_delta=1e-3, seed_delta=1):
+def init_hashed_model(model, seed=0, std=0.02, policy_delta=1e-3, seed_delta=1, qk_scale=1.0, ref=None):
     """Weights named by their HF checkpoint keys and drawn by hashed_normal: reference = bf16(std * n) (norm gains
     1 + 0.05 n), policy = bf16(reference + policy_delta * n').  Returns the reference model."""
     from ..engine import VisionWeights
@@ -52,12 +52,14 @@ def init_hashed_model(model, seed=0, std=0.02, policy_delta=1e-3, seed_delta=1):
             numel *= s_
         n = hashed_normal(numel, seed, name, dev).view(*shape)
         gain = name.endswith(("norm.weight", "norm1.weight", "norm2.weight", "layrnorm.weight"))
-        t = ((n * 0.05 + 1.0) if gain else n * std).to(torch.bfloat16)
+        qk = qk_scale != 1.0 and name.startswith("language_model.") and name.endswith(("q_proj.weight", "k_proj.weight"))
+        t = ((n * 0.05 + 1.0) if gain else n * (std * qk_scale if qk else std)).to(torch.bfloat16)      # (qk_scale: oracle.HashedWeights)
         if delta > 0 and not name.startswith(("vision_tower.", "vit.", "vision_proj.")):
             t = (t.float() + hashed_normal(numel, seed_delta, name, dev).view(*shape) * delta).to(torch.bfloat16)
         return t
 
-    ref = model.create_reference_model()
+    if ref is None:
+        ref = model.create_reference_model()
     for ws, delta in ((ref.weights, 0.0), (eng.policy, policy_delta)):
         for hf, name, r0, rows in eng.layout.hf_names():
             dst = ws.v[name]
@@ -211,7 +213,8 @@ def init_hashed_qwen(model, seed=0, std=0.02, policy_delta=1e-3, seed_delta=1, w
             numel *= s_
         n = hashed_normal(numel, seed, name, dev).view(*shape)
         gain = name.endswith((".weight",)) and (".ln_" in name or "ln_f" in name or "ln_pre" in name or "ln_post" in name)
-        t = ((n * 0.05 + 1.0) if gain else n * std).to(torch.bfloat16)
+        qk = qk_scale != 1.0 and name.startswith("language_model.") and name.endswith(("q_proj.weight", "k_proj.weight"))
+        t = ((n * 0.05 + 1.0) if gain else n * (std * qk_scale if qk else std)).to(torch.bfloat16)      # (qk_scale: oracle.HashedWeights)
         if delta > 0 and not name.startswith("transformer.visual."):
             t = (t.float() + hashed_normal(numel, seed_delta, name, dev).view(*shape) * delta).to(torch.bfloat16)
         return t
