@@ -365,6 +365,7 @@ def main():
                                  ("torch.distributed backend " + dist.get_backend()) if world > 1 else None),
                      "transport_note": reducer.transport_note if reducer is not None else None,     # why the native transport was not used, when it was not
                      "comm_cus": reducer.comm_cus if reducer is not None else 0, "compute_cus": _hip.helper("vlr_compute_cus"),
+                     "rccl_max_min_nchannels": list(reducer.rccl_channels) if reducer is not None else None,     # NCCL_MAX / MIN_NCHANNELS := comm_cus (parallel.rccl_channel_env)
                      "exposed_ms_per_step": exposed_ms, "bytes_per_step": 2 * (eng.lora_layout.numel if a.lora else eng.layout.numel)},
             "roofline": {"bound": "mfma", "kernel": "gemm256p_kernel<A_KS,B_KS> (8-phase 256x256x64 bf16 GEMM: NT/NN/TN)", "achieved": round(achieved, 1),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),

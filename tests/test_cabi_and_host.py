@@ -294,3 +294,20 @@ def test_vlfeedback_pair_mining_matches_reference(tmp_path):
     assert len(rows) == len(g["results"]["-1"]["prompt"]) and rows[0]["img_path"].startswith("/imgs/")
     with pytest.raises(RuntimeError, match="no network"):
         DATASET_MAP["vlfeedback_paired"](SimpleNamespace(data_path=None, score_margin=-1))
+
+
+def test_rccl_channel_bounds_follow_the_cu_reservation(monkeypatch):
+    """parallel.rccl_channel_env: NCCL_MAX_NCHANNELS = NCCL_MIN_NCHANNELS = VLR_COMM_CUS (default 16) in the environment the ranks are
+    launched with, unless the user set them; VLR_COMM_CUS=0 leaves RCCL alone"""
+    from vlrlhf import parallel as P
+    monkeypatch.delenv("VLR_COMM_CUS", raising=False)
+    e = {}
+    assert P.rccl_channel_env(e) == ("16", "16") and e == {"NCCL_MAX_NCHANNELS": "16", "NCCL_MIN_NCHANNELS": "16"}
+    e = {"NCCL_MAX_NCHANNELS": "8"}
+    assert P.rccl_channel_env(e) == ("8", "8")                      # the user's bound wins, the minimum never exceeds it
+    monkeypatch.setenv("VLR_COMM_CUS", "24")
+    e = {}
+    assert P.rccl_channel_env(e) == ("24", "24")
+    monkeypatch.setenv("VLR_COMM_CUS", "0")
+    e = {}
+    assert P.rccl_channel_env(e) == (None, None) and e == {}

@@ -9,7 +9,14 @@ Two transports for the same buckets:
                 stream; the unique id travels through torch.distributed once at start-up.  It is verified with a known
                 all-reduce before it is trusted; if RCCL cannot be loaded / initialised the reducer says so and uses
   * "torch"   - torch.distributed all_reduce (backend "nccl" IS RCCL on ROCm; "gloo" for the CPU tests).
-VLR_COMM=native|torch forces one of them (native then raises instead of falling back)."""
+VLR_COMM=torch selects torch.distributed; with any other value a native transport that cannot be initialised RAISES on every rank (round 4:
+no silent fallback - a multi-GPU run whose transport is not the one that was measured should not produce a number).
+
+CUs for RCCL: the ring kernels of RCCL run one workgroup per CHANNEL beside the backward.  The persistent GEMM / attention launches leave
+`comm_cus` CUs free (vlr_set_comm_cus; VLR_COMM_CUS, default 16 = two per XCD), and rccl_channel_env() bounds RCCL to exactly that many
+channels (NCCL_MAX_NCHANNELS = NCCL_MIN_NCHANNELS = comm_cus, set before any communicator - torch's or ours - is created), so that the
+ring kernels fit the reservation instead of displacing persistent workgroups (which cost 13 % of the step in the single-GPU
+interference bench, profiles/r03_comm_cus_interference_1gpu.txt)."""
 import ctypes as C
 import os
 import subprocess
@@ -18,6 +25,21 @@ from typing import Dict, Optional, Tuple
 
 import torch
 import torch.distributed as dist
+
+
+def comm_cus_default() -> int:
+    return int(os.environ.get("VLR_COMM_CUS", "16"))
+
+
+def rccl_channel_env(env=None, comm_cus=None):
+    """NCCL_MAX_NCHANNELS / NCCL_MIN_NCHANNELS := comm_cus (unless the user set them) in `env` (default os.environ).  Must run before
+    the first RCCL communicator of the process is created.  Returns the (max, min) strings in effect."""
+    e = os.environ if env is None else env
+    k = comm_cus_default() if comm_cus is None else comm_cus
+    if k > 0:
+        e.setdefault("NCCL_MAX_NCHANNELS", str(k))
+        e.setdefault("NCCL_MIN_NCHANNELS", str(min(k, int(e["NCCL_MAX_NCHANNELS"]))))
+    return e.get("NCCL_MAX_NCHANNELS"), e.get("NCCL_MIN_NCHANNELS")
 
 
 def _all_ok(ok: bool, group=None) -> bool:
@@ -101,15 +123,8 @@ def make_transport(group=None, cuda=True):
         return None, "torch", f"process group backend is {dist.get_backend(group)}"
     # NativeComm's stages are collective and agree on success / failure among themselves: every rank either returns a working
     # communicator or raises
-    try:
-        comm = NativeComm(group)
-    except Exception as e:          # noqa: BLE001 - any failure of the native transport is reported, not swallowed
-        if want == "native":
-            raise
-        note = f"{type(e).__name__}: {e}"
-        if dist.get_rank(group) == 0:
-            print(f"[vlrlhf.parallel] native RCCL transport unavailable ({note}); using torch.distributed all_reduce", file=sys.stderr, flush=True)
-        return None, "torch", note
+    # communicator or raises - and a failure is FATAL (set VLR_COMM=torch to run on torch.distributed's RCCL communicator instead)
+    comm = NativeComm(group)
     return comm, "native", comm.library
 
 
@@ -131,9 +146,10 @@ class GradReducer:
         # comm_interference.py, DESIGN.md section 5: a 16-workgroup stand-in for the ring kernel cost 13 % of the step against
         # 256-workgroup launches and 5.5 % against 240-workgroup ones); VLR_COMM_CUS overrides, 0 switches it off.
         self.comm_cus = 0
+        self.rccl_channels = (os.environ.get("NCCL_MAX_NCHANNELS"), os.environ.get("NCCL_MIN_NCHANNELS"))      # what RCCL was bounded to
         if self.cuda and self.world > 1:
             from . import _hip
-            self.comm_cus = int(os.environ.get("VLR_COMM_CUS", "16"))
+            self.comm_cus = comm_cus_default()
             _hip.helper("vlr_set_comm_cus", self.comm_cus)
 
     def bucket_ready(self, name: str):
@@ -195,6 +211,7 @@ def init_distributed_from_env(backend: Optional[str] = None):
     rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     if torch.cuda.is_available():
         torch.cuda.set_device(local)
+        rccl_channel_env()               # before the first communicator (torch's process group, then NativeComm)
     if not dist.is_initialized():
         dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank, world_size=world)
     return rank, local, world
@@ -214,6 +231,8 @@ def relaunch_under_torchrun(script: str, argv, nproc: int, env=None) -> int:
     e = dict(os.environ if env is None else env)
     e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # the host driver only supports dmabuf IPC (RCCL needs it)
     e.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, nproc))))
+    if nproc > 1:
+        rccl_channel_env(e)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), script] + list(argv)
     return subprocess.call(cmd, env=e)
