@@ -55,6 +55,11 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
 }
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16(f, 0.f) & 0xffffu); }
 
+// sigmoid with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of an IEEE division (v_div_scale / v_rcp / 4 v_fma / v_div_fmas /
+// v_div_fixup: ~10 VALU instructions per element - a third of the SwiGLU epilogues' arithmetic, which runs with the matrix pipe idle);
+// the SAME function in the fused GEMM epilogues (gemm256p.hip) and in the elementwise kernels, so every row sees the same arithmetic
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+
 __device__ __forceinline__ void unpack8(const u32x4& w, float* f) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restric
         unpack8(*reinterpret_cast<const u32x4*>(gu + row * 2 * I + c), g);
         unpack8(*reinterpret_cast<const u32x4*>(gu + row * 2 * I + I + c), u);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = g[e] / (1.f + __expf(-g[e])) * u[e];
+        for (int e = 0; e < 8; ++e) o[e] = g[e] * fast_sigmoid(g[e]) * u[e];
         *reinterpret_cast<u32x4*>(act + row * I + c) = pack8(o);
     }
 }
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(bf16_t* __restrict__ gu
         unpack8(*reinterpret_cast<const u32x4*>(dact + row * I + c), d);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float sg = 1.f / (1.f + __expf(-g[e]));
+            const float sg = fast_sigmoid(g[e]);
             du[e] = d[e] * g[e] * sg;
             dg[e] = d[e] * u[e] * sg * (1.f + g[e] * (1.f - sg));
         }

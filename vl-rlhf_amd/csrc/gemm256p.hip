@@ -711,7 +711,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                 for (int j = 0; j < 2; ++j) {
                     const f32x4 g = acc[a][i][0][j], u = acc[a][i][1][j];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) h[j][e] = g[e] / (1.f + __expf(-g[e])) * u[e];
+                    for (int e = 0; e < 4; ++e) h[j][e] = g[e] * fast_sigmoid(g[e]) * u[e];
                 }
                 u32x4 wh;
                 EPI_XPOSE_BF16(widen_pair(h[0], h[1]), wh);
@@ -846,7 +846,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                 unpack8(uq[c], u);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float sg = 1.f / (1.f + __expf(-g[e]));
+                    const float sg = fast_sigmoid(g[e]);
                     du[e] = d[e] * g[e] * sg;
                     dg[e] = d[e] * u[e] * sg * (1.f + g[e] * (1.f - sg));
                 }
