@@ -26,6 +26,16 @@ extern "C" int vlr_compute_cus(void);      // CUs the persistent kernels may fil
 int vlr_prof_begin(int kernel, double work, hipStream_t st);
 void vlr_prof_end(int idx, hipStream_t st);
 
+// ---- internal (not part of the C ABI): the ragged last tile rows of a decoder GEMM ("peel": 504 of 12792 rows on the 128x128 kernel, split
+// along K, + its reduction) leave most CUs idle for 50 - 125 us, and the kernel that follows on the stream is an HBM-bound RMSNorm pass over
+// the same rows.  A caller that can consume the rows in two parts hands the next vlr_gemm_bf16* call a VlrGemmTail: the peeled rows are
+// then launched on `side` (after the main part), `done` is recorded behind them and M1 = rows of the main part; the caller runs its
+// consumer on rows [0, M1) at once, waits for `done`, and finishes rows [M1, M).  used = 0: the call did not peel (consume all rows).
+struct VlrGemmTail { hipStream_t side; hipEvent_t fork, done; int M1; int used; };
+void vlr_internal_set_gemm_tail(VlrGemmTail* t);      // applies to the NEXT vlr_gemm_bf16 / _f32res call of this thread only
+int vlr_internal_rmsnorm_bwd_split(const void* dy, const void* x, int x_f32, const void* w, const float* rstd, const void* dres, void* dx,
+                                   void* dw, int dw_accumulate, void* workspace, int M, int H, int M1, hipEvent_t tail_done, hipStream_t st);
+
 #define VLR_REQUIRE(cond, ...)                 \
     do {                                       \
         if (!(cond)) {                         \

@@ -46,7 +46,8 @@ template <typename XT>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const XT* __restrict__ x,
                                                           const bf16_t* __restrict__ w, const float* __restrict__ rstd,
                                                           const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
-                                                          float* __restrict__ dw_part, int M, int H) {
+                                                          float* __restrict__ dw_part, int M, int H, int row0, int part0) {
+    // rows [row0, M); the workgroup's dw partial goes to row part0 + blockIdx.x of dw_part (two launches over two row ranges share one reduction)
     __shared__ float red[16];
     constexpr int MAXC = 4;  // H <= 256*8*MAXC = 8192
     float dwacc[MAXC][8];
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
     for (int i = 0; i < MAXC; ++i)
 #pragma unroll
         for (int e = 0; e < 8; ++e) dwacc[i][e] = 0.f;
-    for (int row = blockIdx.x; row < M; row += gridDim.x) {
+    for (int row = row0 + blockIdx.x; row < M; row += gridDim.x) {
         const size_t off = (size_t)row * H;
         const float rs = rstd[row];
         float dot = 0.f;
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
     for (int i = 0; i < MAXC; ++i) {
         const int c = (i * 256 + threadIdx.x) * 8;
         if (c < H) {
-            float* d = dw_part + (size_t)blockIdx.x * H + c;
+            float* d = dw_part + (size_t)(part0 + blockIdx.x) * H + c;
             *reinterpret_cast<f32x4*>(d) = f32x4{dwacc[i][0], dwacc[i][1], dwacc[i][2], dwacc[i][3]};
             *reinterpret_cast<f32x4*>(d + 4) = f32x4{dwacc[i][4], dwacc[i][5], dwacc[i][6], dwacc[i][7]};
         }
@@ -620,7 +621,8 @@ extern "C" int vlr_rmsnorm_fwd_f32(const float* x, const void* w, void* y, float
 extern "C" int vlr_rmsnorm_bwd_workspace_bytes(int H) { return (VLR_NORM_BWD_BLOCKS + VLR_NORM_BWD_STAGE2) * H * 4; }
 
 static int rmsnorm_bwd_impl(const void* dy, const void* x, int x_f32, const void* w, const float* rstd, const void* dres,
-                            void* dx, void* dw, int dw_accumulate, void* workspace, int M, int H, hipStream_t st);
+                            void* dx, void* dw, int dw_accumulate, void* workspace, int M, int H, hipStream_t st, int M1 = 0,
+                            hipEvent_t tail_done = nullptr);
 extern "C" int vlr_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres,
                                void* dx, void* dw, int dw_accumulate, void* workspace, int M, int H, hipStream_t st) {
     return rmsnorm_bwd_impl(dy, x, 0, w, rstd, dres, dx, dw, dw_accumulate, workspace, M, H, st);
@@ -630,18 +632,34 @@ extern "C" int vlr_rmsnorm_bwd_f32(const void* dy, const float* x, const void* w
                                    void* dx, void* dw, int dw_accumulate, void* workspace, int M, int H, hipStream_t st) {
     return rmsnorm_bwd_impl(dy, x, 1, w, rstd, dres, dx, dw, dw_accumulate, workspace, M, H, st);
 }
+// M1 > 0 (vlr_internal_rmsnorm_bwd_split, common.h: VlrGemmTail): rows [0, M1) now, rows [M1, M) once `tail_done` has fired on the
+// stream - the producer's peeled rows were still being computed on a side stream - and ONE reduction of the dw partials of both launches
 static int rmsnorm_bwd_impl(const void* dy, const void* x, int x_f32, const void* w, const float* rstd, const void* dres,
-                            void* dx, void* dw, int dw_accumulate, void* workspace, int M, int H, hipStream_t st) {
+                            void* dx, void* dw, int dw_accumulate, void* workspace, int M, int H, hipStream_t st, int M1,
+                            hipEvent_t tail_done) {
     VLR_REQUIRE(dy && x && w && rstd && dx, "vlr_rmsnorm_bwd: null argument");
     VLR_REQUIRE(M > 0 && H % 8 == 0 && H <= 8192, "vlr_rmsnorm_bwd: bad shape M=%d H=%d (H<=8192)", M, H);
     VLR_REQUIRE(workspace, "vlr_rmsnorm_bwd: workspace of vlr_rmsnorm_bwd_workspace_bytes(H) required");
-    const int G = M < VLR_NORM_BWD_BLOCKS ? M : VLR_NORM_BWD_BLOCKS;
-    if (x_f32)
-        hipLaunchKernelGGL(rmsnorm_bwd_kernel<float>, dim3(G), dim3(256), 0, st, (const bf16_t*)dy, (const float*)x,
-                           (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, (float*)workspace, M, H);
-    else
-        hipLaunchKernelGGL(rmsnorm_bwd_kernel<bf16_t>, dim3(G), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x,
-                           (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, (float*)workspace, M, H);
+    VLR_REQUIRE(M1 >= 0 && M1 < M, "vlr_rmsnorm_bwd: split row %d outside [0, %d)", M1, M);
+    auto launch = [&](int row0, int rows_end, int G, int part0) {
+        if (x_f32)
+            hipLaunchKernelGGL(rmsnorm_bwd_kernel<float>, dim3(G), dim3(256), 0, st, (const bf16_t*)dy, (const float*)x,
+                               (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, (float*)workspace, rows_end, H, row0, part0);
+        else
+            hipLaunchKernelGGL(rmsnorm_bwd_kernel<bf16_t>, dim3(G), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x,
+                               (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, (float*)workspace, rows_end, H, row0, part0);
+    };
+    int G = M < VLR_NORM_BWD_BLOCKS ? M : VLR_NORM_BWD_BLOCKS;
+    if (M1 > 0) {
+        const int GB = (M - M1) < 64 ? (M - M1) : 64;
+        const int GA = M1 < VLR_NORM_BWD_BLOCKS - GB ? M1 : VLR_NORM_BWD_BLOCKS - GB;
+        launch(0, M1, GA, 0);
+        if (tail_done) hipStreamWaitEvent(st, tail_done, 0);
+        launch(M1, M, GB, GA);
+        G = GA + GB;
+    } else {
+        launch(0, M, G, 0);
+    }
     if (dw) {
         float* part2 = (float*)workspace + (size_t)VLR_NORM_BWD_BLOCKS * H;
         const int S2 = G < VLR_NORM_BWD_STAGE2 ? 1 : VLR_NORM_BWD_STAGE2;
@@ -650,6 +668,10 @@ static int rmsnorm_bwd_impl(const void* dy, const void* x, int x_f32, const void
                            (bf16_t*)dw, dw_accumulate);
     }
     return vlr_check_launch("vlr_rmsnorm_bwd");
+}
+int vlr_internal_rmsnorm_bwd_split(const void* dy, const void* x, int x_f32, const void* w, const float* rstd, const void* dres, void* dx,
+                                   void* dw, int dw_accumulate, void* workspace, int M, int H, int M1, hipEvent_t tail_done, hipStream_t st) {
+    return rmsnorm_bwd_impl(dy, x, x_f32, w, rstd, dres, dx, dw, dw_accumulate, workspace, M, H, st, M1, tail_done);
 }
 
 #define VLR_COLSUM_ROWS 64

@@ -703,9 +703,14 @@ extern "C" int vlr_gemm_bf16_f32res(int layout, const void* A, const void* B, fl
     return gemm_impl_ex(layout, A, B, C, nullptr, residual, M, N, K, lda, ldb, ldc, ldr, 0, 0, 1, 1.0f, 1, stream);
 }
 
+static VlrGemmTail* g_gemm_tail = nullptr;
+void vlr_internal_set_gemm_tail(VlrGemmTail* t) { g_gemm_tail = t; if (t) { t->used = 0; t->M1 = 0; } }
+
 static int gemm_impl_ex(int layout, const void* A, const void* B, void* C, const void* bias, const void* residual, int M, int N,
                         int K, int lda, int ldb, int ldc, int ldr, int act, int accumulate, int out_f32, float alpha, int res_f32,
                         hipStream_t stream) {
+    VlrGemmTail* tail = g_gemm_tail;      // (common.h) consumed by this call whatever path it takes
+    g_gemm_tail = nullptr;
     VLR_REQUIRE(!res_f32 || out_f32, "vlr_gemm_bf16: an fp32 residual needs an fp32 output");
     VLR_REQUIRE(layout >= 0 && layout <= 2, "vlr_gemm_bf16: layout must be 0 (NT), 1 (NN) or 2 (TN), got %d", layout);
     VLR_REQUIRE(M > 0 && N > 0 && K > 0, "vlr_gemm_bf16: empty problem M=%d N=%d K=%d", M, N, K);
@@ -771,13 +776,21 @@ static int gemm_impl_ex(int layout, const void* A, const void* B, void* C, const
         if (p.residual) p2.residual = (const bf16_t*)((const char*)p.residual + (size_t)M1 * ldr * (p.res_f32 ? 4 : 2));
         if (vlr_gemm256p_try_launch(layout, p1, stream)) {
             const int t2 = ((p2.M + BM - 1) / BM) * ((N + BN - 1) / BN);
+            // the peeled rows on the caller's side stream (VlrGemmTail, common.h): behind the main part, beside the caller's next kernel
+            hipStream_t ps = stream;
+            if (tail) {
+                hipEventRecord(tail->fork, stream);
+                hipStreamWaitEvent(tail->side, tail->fork, 0);
+                ps = tail->side;
+            }
             // the peeled rows are few tiles with the full reduction depth (e.g. 504 x 4096 x 22016 = 128 tiles x 688 k-steps):
             // split them along K so that they fill the chip
-            if (launch_splitk128(layout, p2, stream, 4096)) {
-                vlr_prof_end(pi, stream);
-                return vlr_check_launch("vlr_gemm_bf16(256+128 split-K)");
+            if (!launch_splitk128(layout, p2, ps, 4096)) launch128(layout, p2, dim3(t2), ps);
+            if (tail) {
+                hipEventRecord(tail->done, ps);
+                tail->M1 = M1;
+                tail->used = 1;
             }
-            launch128(layout, p2, dim3(t2), stream);
             vlr_prof_end(pi, stream);
             return vlr_check_launch("vlr_gemm_bf16(256+128)");
         }

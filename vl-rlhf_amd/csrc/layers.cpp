@@ -49,6 +49,30 @@ extern "C" int vlr_layers_join(vlr_stream_t stream) {
     return VLR_OK;
 }
 
+// ---- side streams for the peeled rows of the decoder GEMMs (VlrGemmTail, common.h): one per main stream (the policy and the reference
+// pass run on different streams), created on first use.  VLR_GEMM_TAIL=0 switches the overlap off (the peel then runs on the main
+// stream as before round 4).
+static int g_tail_on = -1;
+static struct TailSlot { hipStream_t main, side; hipEvent_t fork, done; } g_tails[4];
+static int g_ntails = 0;
+static VlrGemmTail* tail_for(hipStream_t main, VlrGemmTail* t) {
+    if (g_tail_on < 0) { const char* e = getenv("VLR_GEMM_TAIL"); g_tail_on = (e && e[0] == '1') ? 1 : 0; }
+    if (!g_tail_on) return nullptr;
+    TailSlot* sl = nullptr;
+    for (int i = 0; i < g_ntails; ++i)
+        if (g_tails[i].main == main) sl = &g_tails[i];
+    if (!sl) {
+        if (g_ntails == 4) return nullptr;
+        sl = &g_tails[g_ntails];
+        sl->main = main;
+        if (hipStreamCreateWithFlags(&sl->side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&sl->fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&sl->done, hipEventDisableTiming) != hipSuccess) return nullptr;
+        ++g_ntails;
+    }
+    t->side = sl->side; t->fork = sl->fork; t->done = sl->done; t->M1 = 0; t->used = 0;
+    return t;
+}
+
 #define CHECK(call)                     \
     do {                                \
         int rc_ = (call);               \
@@ -92,8 +116,20 @@ extern "C" int vlr_decoder_layer_fwd_ex(const vlr_llama_cfg* cfg, const vlr_laye
                                  cfg->max_pos, st));
     CHECK(vlr_attn_fwd_gqa(a->qkv, off(a->qkv, Nq), off(a->qkv, (size_t)Nq + Nkv), N, a->attn, Nq, a->lse, key_mask, batch, S,
                            cfg->heads, kvh, cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));
+    // o_proj: its peeled last tile rows run on a side stream beside the RMSNorm of the rows that are already there (tail_for above)
+    VlrGemmTail tl_, *tl = tail_for(st, &tl_);
+    vlr_internal_set_gemm_tail(tl);
     CHECK(proj_res(rf, a->attn, w->wo, a->x_mid, x_in, M, H, Nq, st));
-    CHECK(norm_fwd(rf, a->x_mid, w->ln2, a->xn2, a->rstd2, M, H, cfg->rms_eps, st));
+    vlr_internal_set_gemm_tail(nullptr);
+    if (tl && tl->used) {
+        const size_t xs = rf ? 4 : 2;
+        CHECK(norm_fwd(rf, a->x_mid, w->ln2, a->xn2, a->rstd2, tl->M1, H, cfg->rms_eps, st));
+        hipStreamWaitEvent(st, tl->done, 0);
+        CHECK(norm_fwd(rf, (const char*)a->x_mid + (size_t)tl->M1 * H * xs, w->ln2, off(a->xn2, (size_t)tl->M1 * H), a->rstd2 + tl->M1, M - tl->M1, H,
+                       cfg->rms_eps, st));
+    } else {
+        CHECK(norm_fwd(rf, a->x_mid, w->ln2, a->xn2, a->rstd2, M, H, cfg->rms_eps, st));
+    }
     // gate|up projection with act = silu(gate) * up computed in the epilogue
     CHECK(vlr_gemm_swiglu(a->xn2, w->wgu, a->gu, a->act, M, I, H, H, keep_for_backward, st));
     CHECK(proj_res(rf, a->act, w->wdown, a->x_out, a->x_mid, M, H, I, st));
@@ -130,9 +166,17 @@ extern "C" int vlr_decoder_layer_bwd(const vlr_llama_cfg* cfg, const vlr_layer_w
         // dW_gate|up and dW_down as ONE persistent launch: 1376 + 688 output tiles are 8.06 rounds of 256 CUs together, 6 + 3 apart
         CHECK(vlr_gemm_bf16_tn_pair(a->gu, a->xn2, g->wgu, 2 * I, H, 2 * I, H, H, dx_out, a->act, g->wdown, H, I, H, I, I, M, accumulate, st));
     }
+    // the data-gradient GEMMs in front of the two RMSNorm backward passes: peeled rows on the side stream, the norm in two row ranges
+    VlrGemmTail tl_, *tl = two ? nullptr : tail_for(st, &tl_);
+    vlr_internal_set_gemm_tail(tl);
     CHECK(vlr_gemm_bf16(1, a->gu, w->wgu, ws->dxn, nullptr, nullptr, M, H, 2 * I, 2 * I, H, H, 0, 0, 0, 0, st));
+    vlr_internal_set_gemm_tail(nullptr);
     if (two) wait_side(2, st);                           // previous layer's dWo GEMM still reads ws->dx_mid
-    CHECK(norm_bwd(cfg->resid_f32, ws->dxn, a->x_mid, w->ln2, a->rstd2, dx_out, ws->dx_mid, g->ln2, accumulate, ws->norm_ws, M, H, st));
+    if (tl && tl->used)
+        CHECK(vlr_internal_rmsnorm_bwd_split(ws->dxn, a->x_mid, cfg->resid_f32, w->ln2, a->rstd2, dx_out, ws->dx_mid, g->ln2, accumulate, ws->norm_ws, M, H,
+                                             tl->M1, tl->done, st));
+    else
+        CHECK(norm_bwd(cfg->resid_f32, ws->dxn, a->x_mid, w->ln2, a->rstd2, dx_out, ws->dx_mid, g->ln2, accumulate, ws->norm_ws, M, H, st));
     // ---- attention
     if (two) { sd = fork_side(st); }
     CHECK(vlr_gemm_bf16(2, ws->dx_mid, a->attn, g->wo, nullptr, nullptr, H, Nq, M, H, Nq, Nq, 0, 0, accumulate, 0, sd));
@@ -147,10 +191,17 @@ extern "C" int vlr_decoder_layer_bwd(const vlr_llama_cfg* cfg, const vlr_layer_w
     if (two) { sd = fork_side(st); }
     CHECK(vlr_gemm_bf16(2, ws->dqkv, a->xn1, g->wqkv, nullptr, nullptr, N, H, M, N, H, H, 0, 0, accumulate, 0, sd));
     if (two) side_done(3);
+    tl = two ? nullptr : tail_for(st, &tl_);
+    vlr_internal_set_gemm_tail(tl);
     CHECK(vlr_gemm_bf16(1, ws->dqkv, w->wqkv, ws->dxn, nullptr, nullptr, M, H, N, N, H, H, 0, 0, 0, 0, st));
+    vlr_internal_set_gemm_tail(nullptr);
     if (two) { wait_side(0, st); wait_side(1, st); }     // this layer's dWdown / dWgu read dx_out / gu: done before dx_in (the
                                                          // buffer the NEXT layer overwrites dx_out with) is produced
-    CHECK(norm_bwd(cfg->resid_f32, ws->dxn, x_in, w->ln1, a->rstd1, ws->dx_mid, dx_in, g->ln1, accumulate, ws->norm_ws, M, H, st));
+    if (tl && tl->used)
+        CHECK(vlr_internal_rmsnorm_bwd_split(ws->dxn, x_in, cfg->resid_f32, w->ln1, a->rstd1, ws->dx_mid, dx_in, g->ln1, accumulate, ws->norm_ws, M, H,
+                                             tl->M1, tl->done, st));
+    else
+        CHECK(norm_bwd(cfg->resid_f32, ws->dxn, x_in, w->ln1, a->rstd1, ws->dx_mid, dx_in, g->ln1, accumulate, ws->norm_ws, M, H, st));
     return VLR_OK;
 }
 

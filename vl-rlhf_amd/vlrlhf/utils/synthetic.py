@@ -213,8 +213,7 @@ def init_hashed_qwen(model, seed=0, std=0.02, policy_delta=1e-3, seed_delta=1, w
             numel *= s_
         n = hashed_normal(numel, seed, name, dev).view(*shape)
         gain = name.endswith((".weight",)) and (".ln_" in name or "ln_f" in name or "ln_pre" in name or "ln_post" in name)
-        qk = qk_scale != 1.0 and name.startswith("language_model.") and name.endswith(("q_proj.weight", "k_proj.weight"))
-        t = ((n * 0.05 + 1.0) if gain else n * (std * qk_scale if qk else std)).to(torch.bfloat16)      # (qk_scale: oracle.HashedWeights)
+        t = ((n * 0.05 + 1.0) if gain else n * std).to(torch.bfloat16)
         if delta > 0 and not name.startswith("transformer.visual."):
             t = (t.float() + hashed_normal(numel, seed_delta, name, dev).view(*shape) * delta).to(torch.bfloat16)
         return t
