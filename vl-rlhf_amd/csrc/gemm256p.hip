@@ -39,8 +39,9 @@
 #define PTAB_PIECES 384                // capacity of the piece table behind them (8 ints per piece); persist_grid() keeps launches below it
 #define PTAB_BYTES (PTAB_PIECES * 32)
 #define EPATCH_STRIDE 144              // bytes per row of a wave's epilogue patch: 32 fp32 columns + 16 B (conflict-free 16-byte row-per-lane writes)
-#define EPATCH_BYTES (16 * EPATCH_STRIDE)                // one 16-row x 32-column fp32 chunk (two accumulator tiles) per wave
-#define CONT_LDS_BYTES (2 * BUF_BYTES + PTAB_BYTES + 8 * EPATCH_BYTES)      // dynamic LDS of the continuous-pipeline kernels (158 KiB)
+#define EPATCH_BF16 1280               // image of a packed bf16 chunk: 16 rows x (64 B + 16 B)
+#define EPATCH_BYTES (2 * EPATCH_BF16)                   // per wave: one 16-row x 32-column fp32 chunk (16 * EPATCH_STRIDE = 2304 B) or TWO bf16 chunk images
+#define CONT_LDS_BYTES (2 * BUF_BYTES + PTAB_BYTES + 8 * EPATCH_BYTES)      // dynamic LDS of the continuous-pipeline kernels (all 160 KiB)
 #define TILE_LDS_BYTES (P_LDS_BYTES + PTAB_BYTES)        // ... of the per-tile kernels
 
 typedef __attribute__((address_space(1))) const void gvoid_t;
@@ -303,6 +304,18 @@ static void trace_set(GemmParams& p) {
         *reinterpret_cast<u32x4*>(epatch + (lane & 15) * 80 + widen_col(lane >> 4) * 2) = w__;                        \
         EPI_SYNC();                                                                                                   \
         (w_out_) = *reinterpret_cast<const u32x4*>(epatch + (lane >> 2) * 80 + (lane & 3) * 16);                      \
+    } while (0)
+
+// pipelined form for runs of bf16 chunks: EPI_BF16_PUT writes chunk image `buf_` (0 | 1: the patch holds two) and requests it back
+// row-contiguous into w_out_ WITHOUT waiting; the caller stores chunk n - 1 after putting chunk n, so that the LDS round trip of a
+// chunk hides under the packing of the next one (hipcc waits with a counted lgkmcnt at the store).
+#define EPI_BF16_PUT(buf_, w_in_, w_out_)                                                                                                \
+    do {                                                                                                                                 \
+        const u32x4 w__ = (w_in_);                                                                                                       \
+        EPI_SYNC();                                                                                                                      \
+        *reinterpret_cast<u32x4*>(epatch + (buf_) * EPATCH_BF16 + (lane & 15) * 80 + widen_col(lane >> 4) * 2) = w__;                    \
+        EPI_SYNC();                                                                                                                      \
+        (w_out_) = *reinterpret_cast<const u32x4*>(epatch + (buf_) * EPATCH_BF16 + (lane >> 2) * 80 + (lane & 3) * 16);                  \
     } while (0)
 
 // CONT = true: continuous pipeline across the output tiles of a persistent workgroup (plain bf16 epilogue only): the last K tiles
@@ -697,33 +710,42 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
         bf16_t* C = reinterpret_cast<bf16_t*>(tp.C);
         bf16_t* C2 = reinterpret_cast<bf16_t*>(p.C2);
         const int I = tp.N >> 1;
+        // chunk n = (row block r = (a, i), kind): kind 0 act, 1 gate, 2 up (NK = 1: act only - the no-grad passes); chunk n is put while
+        // chunk n - 1 comes back from the patch (EPI_BF16_PUT)
+        auto body = [&](auto nkc) {
+            constexpr int NK = decltype(nkc)::value;
+            u32x4 pend[2];
+            static_for<0, 8 * NK + 1>([&](auto nc) {
+                constexpr int n = decltype(nc)::value;
+                if constexpr (n < 8 * NK) {
+                    constexpr int r = n / NK, kind = n % NK, a = r >> 2, i = r & 3;
+                    if constexpr (kind == 0) {
+                        f32x4 h[2];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+                        for (int j = 0; j < 2; ++j) {
+                            const f32x4 g = acc[a][i][0][j], u = acc[a][i][1][j];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int ln = lane;                       // opaque per chunk row: keeps hipcc from carrying 24 hoisted store addresses (it spilled)
-                asm volatile("" : "+v"(ln));
-                const int gm = m0 + a * 128 + wr * 64 + i * 16 + (ln >> 2);
-                const int gn = n0 + wc * 32 + (ln & 3) * 8;
-                const bool ok = gm < tp.M && gn + 8 <= I;
-                f32x4 h[2];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const f32x4 g = acc[a][i][0][j], u = acc[a][i][1][j];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) h[j][e] = g[e] * fast_sigmoid(g[e]) * u[e];
+                            for (int e = 0; e < 4; ++e) h[j][e] = g[e] * fast_sigmoid(g[e]) * u[e];
+                        }
+                        EPI_BF16_PUT(n & 1, widen_pair(h[0], h[1]), pend[n & 1]);
+                    } else {
+                        EPI_BF16_PUT(n & 1, widen_pair(acc[a][i][kind - 1][0], acc[a][i][kind - 1][1]), pend[n & 1]);
+                    }
                 }
-                u32x4 wh;
-                EPI_XPOSE_BF16(widen_pair(h[0], h[1]), wh);
-                if (ok) *reinterpret_cast<u32x4*>(C2 + (size_t)gm * p.ldc2 + gn) = wh;
-                if (p.store_c) {
-                    u32x4 wg, wu;
-                    EPI_XPOSE_BF16(widen_pair(acc[a][i][0][0], acc[a][i][0][1]), wg);
-                    if (ok) *reinterpret_cast<u32x4*>(C + (size_t)gm * tp.ldc + gn) = wg;
-                    EPI_XPOSE_BF16(widen_pair(acc[a][i][1][0], acc[a][i][1][1]), wu);
-                    if (ok) *reinterpret_cast<u32x4*>(C + (size_t)gm * tp.ldc + I + gn) = wu;
+                if constexpr (n >= 1) {
+                    constexpr int c = n - 1, r = c / NK, kind = c % NK, a = r >> 2, i = r & 3;
+                    int ln = lane;                       // opaque per chunk: keeps hipcc from carrying 24 hoisted store addresses (it spilled)
+                    asm volatile("" : "+v"(ln));
+                    const int gm = m0 + a * 128 + wr * 64 + i * 16 + (ln >> 2);
+                    const int gn = n0 + wc * 32 + (ln & 3) * 8;
+                    if (gm < tp.M && gn + 8 <= I) {
+                        if constexpr (kind == 0) *reinterpret_cast<u32x4*>(C2 + (size_t)gm * p.ldc2 + gn) = pend[c & 1];
+                        else *reinterpret_cast<u32x4*>(C + (size_t)gm * tp.ldc + (kind - 1) * I + gn) = pend[c & 1];
+                    }
                 }
-            }
+            });
+        };
+        if (p.store_c) body(std::integral_constant<int, 3>{}); else body(std::integral_constant<int, 1>{});
     } else if constexpr (CONT && FUSE == 4) {
         // lm-head forward: per row, this wave's 64 columns (wc*32..+32 of both B halves) -> (max, sum exp) partial + the target logit
         const int lm_ = lane & 15, lq_ = lane >> 4;
@@ -1026,21 +1048,23 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                     }
                 }
       } else {
-        // plain bf16 epilogue: rounded in the accumulator layout, the packed 16-row x 32-column chunk (1 KiB) through the patch, ONE
-        // 16-byte store per lane and chunk (lane -> row lane >> 2, columns (lane & 3) * 8 .. + 7)
+        // plain bf16 epilogue: rounded in the accumulator layout, the packed 16-row x 32-column chunks (1 KiB) through the patch, ONE
+        // 16-byte store per lane and chunk (lane -> row lane >> 2, columns (lane & 3) * 8 .. + 7); chunk n is put while chunk n - 1 returns
         bf16_t* C = reinterpret_cast<bf16_t*>(tp.C);
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    u32x4 w;
-                    EPI_XPOSE_BF16(widen_pair(p.alpha * acc[a][i][b][0], p.alpha * acc[a][i][b][1]), w);
-                    const int gm = m0 + a * 128 + wr * 64 + i * 16 + (lane >> 2);
-                    const int gn = n0 + b * 128 + wc * 32 + (lane & 3) * 8;
-                    if (gm < tp.M && gn + 8 <= tp.N) *reinterpret_cast<u32x4*>(C + (size_t)gm * tp.ldc + gn) = w;
-                }
+        u32x4 pend[2];
+        static_for<0, 17>([&](auto nc) {
+            constexpr int n = decltype(nc)::value;
+            if constexpr (n < 16) {
+                constexpr int a = n >> 3, i = (n >> 1) & 3, b = n & 1;
+                EPI_BF16_PUT(n & 1, widen_pair(p.alpha * acc[a][i][b][0], p.alpha * acc[a][i][b][1]), pend[n & 1]);
+            }
+            if constexpr (n >= 1) {
+                constexpr int c = n - 1, a = c >> 3, i = (c >> 1) & 3, b = c & 1;
+                const int gm = m0 + a * 128 + wr * 64 + i * 16 + (lane >> 2);
+                const int gn = n0 + b * 128 + wc * 32 + (lane & 3) * 8;
+                if (gm < tp.M && gn + 8 <= tp.N) *reinterpret_cast<u32x4*>(C + (size_t)gm * tp.ldc + gn) = pend[c & 1];
+            }
+        });
       }
     }
     if constexpr (CONT) {
