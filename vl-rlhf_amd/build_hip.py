@@ -30,7 +30,7 @@ def _digest():
 
 def check_kloop_isa(asm_path):
     """gemm256p.hip: the steady-state K loop of every kernel (the branch-free innermost loop with exactly 64 v_mfma: 4 phases x 16)
-    must hold ONE vector-memory wait, the hand-written counted vmcnt(6).  Any other s_waitcnt vmcnt in there is hipcc guarding a
+    must hold only the hand-written counted waits: vmcnt(6) (classic body) or vmcnt(8) + vmcnt(6) (balanced phases).  Any other s_waitcnt vmcnt in there is hipcc guarding a
     register against an epilogue load it believes pending - it drains the LDS-DMA queue every K tile (-7 % on the TN kernel when it
     happened).  Raises with the kernel name and the offending waits."""
     import re
@@ -51,7 +51,7 @@ def check_kloop_isa(asm_path):
                 continue
             seen += 1
             waits = [x.strip() for x in loop if "s_waitcnt" in x and "vmcnt" in x]
-            if waits != ["s_waitcnt vmcnt(6)"]:
+            if waits not in (["s_waitcnt vmcnt(6)"], ["s_waitcnt vmcnt(8)", "s_waitcnt vmcnt(6)"]):      # classic / balanced-phase K loop
                 bad.append((name, waits))
     if bad:
         raise RuntimeError("gemm256p.hip: stray vector-memory waits in the steady-state K loop:\n" + "\n".join(f"  {n}: {w}" for n, w in bad))
@@ -107,5 +107,7 @@ def build(force=False, verbose=True, defines=(), tag=""):
 if __name__ == "__main__":
     if "--trace" in sys.argv:      # tile-timeline diagnostics of the persistent GEMM (tools/gemm_tile_trace.py)
         build(force="--force" in sys.argv, defines=("VLR_GEMM_TRACE",), tag="_trace")
+    elif "--classic" in sys.argv:  # the round-3 K loop of the persistent GEMM (12 / 4 / 8 / 0 fragment reads per phase), for A/B through VLR_LIB
+        build(force="--force" in sys.argv, defines=("VLR_KLOOP_BAL=0",), tag="_classic")
     else:
         build(force="--force" in sys.argv)

@@ -30,6 +30,9 @@
 
 #include "gemm.h"
 
+#ifndef VLR_KLOOP_BAL
+#define VLR_KLOOP_BAL 1        // balanced fragment reads per phase (6 / 6 / 6 / 6 instead of the template's 12 / 4 / 8 / 0); 0: the round-3 K loop (A/B builds)
+#endif
 #define PT 256
 #define PK 64
 #define HALF_BYTES (128 * PK * 2)    // 16 KiB
@@ -454,6 +457,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
             if (tile >= ntp) {
                 if constexpr (CONT) {      // the K loop runs on into the next piece: its first K tiles, general path
                     if (!has_next) return;
+                    int lane = lane0;                    // opaque per call (shadows the tile's copy): hipcc hoisted the general path's 64-bit
+                    asm volatile("" : "+v"(lane));       // source addresses out of the slow K loop and spilled them around it
                     char* dst = smem + ((tile + parb) & 1) * BUF_BYTES + h * HALF_BYTES;
                     const int k0 = (kbn + tile - ntp) * PK;
                     if constexpr (h < 2) {
@@ -511,6 +516,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
             }
         }
         if (!fast && (p.K & (PK - 1)) != 0 && kb + tile == nt - 1) {      // only the last K tile can be partial: it takes the general (zero-filling) path
+            int lane = lane0;
+            asm volatile("" : "+v"(lane));
             char* dst = smem + ((tile + parb) & 1) * BUF_BYTES + h * HALF_BYTES;
             const int k0 = (kb + tile) * PK;
             if constexpr (h < 2) {
@@ -629,6 +636,23 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     };
     using LO = std::integral_constant<int, 0>;
     using HI = std::integral_constant<int, 1>;
+#if VLR_KLOOP_BAL
+    // 16-row tiles [I0, I1) of an A half; boff = 0: the current K-tile buffer, `flip`: the other one (the NEXT K tile's)
+    auto rdAr = [&](auto hic, auto i0c, auto i1c, bf16x8 (&f)[4][2], int boff) {
+        constexpr int ho = decltype(hic)::value * HALF_BYTES, I0 = decltype(i0c)::value, I1 = decltype(i1c)::value;
+#pragma unroll
+        for (int i = I0; i < I1; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if constexpr (A_KS) f[i][ks] = tr2(pa[i] + boff + ho + ks * 8192);
+                else f[i][ks] = *reinterpret_cast<const bf16x8*>(pa[ks] + boff + ho + i * 2048);
+            }
+    };
+    using I0_ = std::integral_constant<int, 0>;
+    using I1_ = std::integral_constant<int, 1>;
+    using I2_ = std::integral_constant<int, 2>;
+    using I4_ = std::integral_constant<int, 4>;
+#endif
 #define PMFMA(A_, B_, a_, b_)                                                                                            \
     do {                                                                                                                 \
         __builtin_amdgcn_s_setprio(1);                                                                                   \
@@ -640,7 +664,78 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     } while (0)
 
 #define LBAR() do { if (!abl_bar) PBAR(); } while (0)
+    // steady state: absolute K tiles kb + kt + 2 below `lim` are whole tiles of (A, B); SEG: K % 64 == 0, the adapter tiles too when K2 % 64 == 0
+    const int lim = ((SEG && ((p.K2 % PK) != 0 || (p.sched & 8))) ? nt1 : nt) - ((p.K & (PK - 1)) != 0 ? 1 : 0) - kb;
+    const int n_fast = (ntp < lim ? ntp : lim) - 2;
+#if VLR_KLOOP_BAL
+    if (n_fast > 0) rdAr(LO{}, I0_{}, I2_{}, fa0, 0);      // first half of A-lo of K tile 0 (inside the steady state phase 4 reads the next K tile's)
+#endif
     in_loop = true;
+#if VLR_KLOOP_BAL
+    // Balanced phases (round 4).  The template's 12 / 4 / 8 / 0 fragment reads per phase make phase 1 the long pole: its load section
+    // (12 reads + one half tile of LDS-DMA) outlasts the 16 MFMAs of the partner wave group, and every phase lasts max(load section,
+    // MFMA section) because the two groups swap roles at the barriers (SQ_VALU_MFMA_BUSY_CYCLES: 84 % of the CU-busy cycles in the
+    // longest-K launches).  Here the first two 16-row tiles of the NEXT K tile's A-lo are read in phase 4 (which read nothing), into the
+    // registers phase 2 released: 8 / 4 / 8 / 4.  No more than 16 fragments are ever live (as before) - reading further ahead (6 / 6 / 6 / 6)
+    // needs 32 more registers and spilled inside the K loop.
+    //   phase 1  B0 (4, retired first), A0[2..3] (4) | stage A-hi(kt+1)                 | MFMA A0 x B0
+    //   phase 2  B1 (4)                              | stage B-lo(kt+2)                 | MFMA A0 x B1
+    //   phase 3  A1 (8)                              | stage A-lo(kt+2); vmcnt(8)        | MFMA A1 x B1
+    //   phase 4  A0(kt+1)[0..1] (4)                  | stage B-hi(kt+2); vmcnt(6)        | MFMA A1 x B0
+    // RAW: A-lo of tile kt+1 was issued in phase 3 of tile kt-1; the phase-3 wait (newest 8 = B-hi(kt+1), A-hi(kt+1), B-lo(kt+2),
+    // A-lo(kt+2) may stay in flight) precedes phase 3's first barrier, the reads start in phase 4.  WAR: A-lo(kt) is re-staged in
+    // phase 3 of tile kt: its last reads are now in phase 1 of tile kt (retired before that phase's MFMAs, two barriers earlier).
+    // Steady-state iterations only (every staged tile exists and is whole); the last two K tiles of a tile and ragged cases take the
+    // classic 12 / 4 / 8 / 0 body below, which reads all of A0 itself - so nothing read ahead is live when the slow path (or the
+    // epilogue) needs registers.
+    auto ktile_bal = [&](int kt, auto prec) {      // prec: read the next K tile's A0[0..1] in phase 4 (all but the last steady-state iteration)
+        using fastc_t = FAST;
+        const fastc_t fastc{};
+        const bool rd = !abl_rd || kt == 0;
+        constexpr bool more = true;
+        // ---------------- phase 1
+        if (rd) rdB(LO{}, fb0);
+        PFENCE();
+        if (rd) rdAr(LO{}, I2_{}, I4_{}, fa0, 0);
+        PFENCE();
+        stage(kt + 1, H_AHI{}, fastc);
+        PFENCE();
+        if constexpr (A_KS) PWAIT_LGKM(8); else PWAIT_LGKM(4);      // the B reads are retired (B-lo is re-staged in phase 2); the A reads may be in flight
+        LBAR();
+        PMFMA(fa0, fb0, 0, 0);
+        LBAR();
+        // ---------------- phase 2
+        if (rd) rdB(HI{}, fb1);
+        PFENCE();
+        stage(kt + 2, H_BLO{}, fastc);
+        LBAR();
+        PMFMA(fa0, fb1, 0, 1);
+        LBAR();
+        // ---------------- phase 3
+        if (rd) rdA(HI{}, fa1);
+        PFENCE();
+        stage(kt + 2, H_ALO{}, fastc);
+        PFENCE();
+        if (more) PWAIT_VM(8); else PWAIT_VM(0);                    // A-lo (and B-lo) of tile kt+1 have landed
+        LBAR();
+        PMFMA(fa1, fb1, 1, 1);
+        LBAR();
+        // ---------------- phase 4
+        if constexpr (decltype(prec)::value) { if (rd) rdAr(LO{}, I0_{}, I2_{}, fa0, flip); }      // (not in the last steady-state iteration: the classic body that follows reads A0 itself)
+        PFENCE();
+        stage(kt + 2, H_BHI{}, fastc);
+        PFENCE();
+        if (more) PWAIT_VM(6); else PWAIT_VM(0);
+        LBAR();
+        PMFMA(fa1, fb0, 1, 0);
+        LBAR();
+#pragma unroll
+        for (int q = 0; q < NPA; ++q) pa[q] += flip;
+#pragma unroll
+        for (int q = 0; q < NPB; ++q) pb[q] += flip;
+        flip = -flip;
+    };
+#endif
     auto ktile = [&](int kt, auto fastc) {
         const bool rd = !abl_rd || kt == 0;
         // ---------------- phase 1: B0 (4 reads, retired first), A0 (8 reads); stage A-hi of tile kt+1
@@ -684,13 +779,19 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     };
     // steady state: every staged tile (kt+1, kt+2) exists and is full -> no checks, no K-tail path in the hot loop
     // (absolute K tiles kb + kt + 2 below `lim` are whole tiles of (A, B); SEG: K % 64 == 0, the adapter tiles too when K2 % 64 == 0)
-    const int lim = ((SEG && ((p.K2 % PK) != 0 || (p.sched & 8))) ? nt1 : nt) - ((p.K & (PK - 1)) != 0 ? 1 : 0) - kb;
-    const int n_fast = (ntp < lim ? ntp : lim) - 2;
     int kt = 0;
+#if VLR_KLOOP_BAL
+#ifdef VLR_GEMM_TRACE
+    if (n_fast > 1) { ktile_bal(0, std::true_type{}); kt = 1; TSTAMP(titer * 8 + 5); }
+#endif
+    for (; kt < n_fast - 1; ++kt) ktile_bal(kt, std::true_type{});
+    if (kt < n_fast) { ktile_bal(kt, std::false_type{}); ++kt; }
+#else
 #ifdef VLR_GEMM_TRACE
     if (n_fast > 0) { ktile(0, FAST{}); kt = 1; TSTAMP(titer * 8 + 5); }
 #endif
     for (; kt < n_fast; ++kt) ktile(kt, FAST{});
+#endif
     for (; kt < ntp; ++kt) ktile(kt, SLOW{});
     TSTAMP(titer * 8 + 6);
     // Waves 4-7 are one barrier behind: when waves 0-3 leave the K loop, waves 4-7 still owe their last barrier - and found its partner
