@@ -35,7 +35,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2516.6          # 256 CU x 4096 FLOP/clk/CU x 2.4 GHz (MI355X_MICROARCH.md: ~2.5 PF dense)
-PROFILE_FILE = "profiles/r03_rocprofv3_kernel_stats_bench.csv"   # rocprofv3 --kernel-trace --stats of this command; `frac` can be recomputed from it
+PROFILE_FILE = "profiles/r04_rocprofv3_kernel_stats_bench.csv"   # rocprofv3 --kernel-trace --stats of this command; `frac` can be recomputed from it
 TFLOP_PER_PAIR = {"ref_in_step": 174.87, "ref_precomputed": 131.24}
 
 
@@ -311,15 +311,20 @@ def main():
         exposed_ms = round((dt / a.steps - float(t2)) * 1e3, 2)
         reducer.enabled = True
     # HBM traffic of the dominant kernel: PMC passes cannot run inside the timed region; the committed rocprofv3 --pmc
-    # result (profiles/r02_pmc_hbm_traffic.*, tools/pmc_traffic.sh) is quoted when present
+    # result (tools/pmc_traffic.sh -> profiles/r04_pmc_hbm_traffic.json) is quoted ONLY when it was taken with the library
+    # built from the sources this run uses (source digest of build_hip.py recorded in the file) - a stale file is refused
+    import build_hip as _bh
+    lib_digest = _bh._digest()[:16]
     traffic = None
     traffic_file = None
-    for name in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic_8phase.json"):
-        tf = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(tf):
-            traffic = round(json.load(open(tf))["gemm_hbm_bytes_per_launch"])
-            traffic_file = "profiles/" + name
-            break
+    tf = os.path.join(ROOT, "profiles", "r04_pmc_hbm_traffic.json")
+    if os.path.exists(tf):
+        tj = json.load(open(tf))
+        if tj.get("source_digest") == lib_digest:
+            traffic = round(tj["gemm_hbm_bytes_per_launch"])
+            traffic_file = "profiles/r04_pmc_hbm_traffic.json"
+        else:
+            traffic_file = f"profiles/r04_pmc_hbm_traffic.json REFUSED: taken with source digest {tj.get('source_digest')}, this library is {lib_digest}"
     # roofline of the DOMINANT kernel: the 8-phase 256x256 GEMM alone (its launches are timed under their own id; the
     # gemm_nt/nn/tn entries of per_kernel are whole vlr_gemm_bf16 calls incl. peeled rows and split-K reduces)
     g_n, g_ms, g_flop = prof["gemm256p"]
@@ -332,6 +337,8 @@ def main():
     Nqkv_ = eng.Nqkv
     for m_, n_, k_ in ((M_, Nqkv_, H_), (M_, H_, eng.Nq), (M_, 2 * I_, H_), (M_, H_, I_)):
         g_bytes += per_shape * (m_ * k_ + n_ * k_ + m_ * n_)
+    if eng.resid_f32:     # o_proj / down_proj forward launches read the fp32 residual and write the fp32 stream (8 bytes per element instead of a 2-byte store)
+        g_bytes += 2 * cfg["layers"] * a.steps * (1 if a.precomputed_ref else 2) * (M_ * H_ * 3)       # in 2-byte elements: + 6 bytes per element
     # every entry with its own fraction of the nominal bf16 MFMA peak (attention included: the kernels furthest below it)
     per_kernel = {k: {"launches": n, "ms": round(ms, 2), "tflops": round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else 0.0,
                       "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if ms > 0 else 0.0}
@@ -371,7 +378,7 @@ def main():
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                          "traffic": traffic, "traffic_source": traffic_file, "traffic_unit": "bytes/launch leaving L2 (2*FETCH_SIZE+WRITE_SIZE, rocprofv3 --pmc, OFFLINE pass of tools/pmc_traffic.sh with the same binary - counters cannot be collected inside the timed region; A+B of a decoder GEMM fit the 256 MB Infinity Cache, so most of the re-reads never reach HBM)",
                          "algorithmic_bytes_per_launch": round(2.0 * g_bytes / max(1, g_dec)), "launches": g_n, "avg_launch_ms": round(g_ms / max(1, g_n), 4), "event_sampling": f"one launch in {max(1, a.prof_sample)} bracketed by HIP events (pseudo-random per kernel id); launches and FLOPs exact, ms = sampled mean x launches", "per_kernel": per_kernel,
-                         "profile_file": PROFILE_FILE,
+                         "profile_file": PROFILE_FILE, "library_source_digest": lib_digest,
                          "kernel_share_of_step": round(g_ms * 1e-3 / dt, 3), "all_gemm_share_of_step": round(all_ms * 1e-3 / dt, 3),
                          "share_note": "kernel_share = the 256x256 kernel's launches alone; all_gemm_share = every vlr_gemm_* call by layout (fused launches, peeled rows and split-K reduces included), so all_gemm_share >= kernel_share",
                          "step_frac": round(pairs_per_s / world * per_pair / PEAK_BF16_TFLOPS, 4),
@@ -394,7 +401,7 @@ def main():
                                           + (f"LoRA r={lora_r} alpha={lora_alpha} dropout={a.lora_dropout} on wqkv / wo / w1 / w2 / w3 over the frozen PLoRA decoder "
                                              "(scripts/dpo_internlmxc2vl7b.sh), reference = adapters disabled" if a.lora else
                                              "full fine-tune of the decoder incl. its PLoRA pairs, reference forward inside the step")
-                                          + ", frozen ViT + projector; decoder layer composed from the library's primitives (un-fused)")
+                                          + ", frozen ViT + projector; PLoRA on the fused C layer calls (vlr_decoder_layer_*_lora_ex)" + ("; the peft-LoRA layer is composed from the library's primitives" if a.lora else ""))
             line["config"]["variant"] = "internlm_xc2" + ("+lora" if a.lora else "") + " (not the headline configuration)"
             line["config"]["tflop_per_pair"] = round(per_pair_i, 2)
             line["roofline"]["step_frac"] = None if a.lora else round(pairs_per_s / world * per_pair_i / PEAK_BF16_TFLOPS, 4)

@@ -9,7 +9,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -o r -f csv -- python bench.py --steps 1 --warmup 0 --no_side_stream --no_cpu_baseline > /tmp/pmc_$c.log 2>&1
 done
 python - <<'PY'
-import csv, glob, collections, json
+import csv, glob, collections, json, sys
+sys.path.insert(0, "vl-rlhf_amd")
+import build_hip
 def load(c):
     f = glob.glob(f"/tmp/pmc_{c}/**/*counter_collection.csv", recursive=True)[0]
     acc, n = collections.defaultdict(float), collections.Counter()
@@ -32,7 +34,7 @@ for k, n, f, w, mb in rows[:40]:
 open("gpurun_out/pmc_hbm_traffic.txt", "w").write("\n".join(out) + "\n")
 g = [r for r in rows if r[0].startswith("gemm256p_kernel")]
 nl = sum(r[1] for r in g)
-json.dump({"gemm_launches": nl, "gemm_hbm_bytes_per_launch": sum(r[1] * r[4] * 1e6 for r in g) / max(1, nl),
+json.dump({"source_digest": build_hip._digest()[:16], "gemm_launches": nl, "gemm_hbm_bytes_per_launch": sum(r[1] * r[4] * 1e6 for r in g) / max(1, nl),
            "note": "2*FETCH_SIZE+WRITE_SIZE, KiB->bytes, averaged over the gemm256p (8-phase 256x256 tile) launches of one DPO step"},
           open("gpurun_out/pmc_hbm_traffic.json", "w"))
 print("\n".join(out[:16]))
