@@ -1195,7 +1195,7 @@ static unsigned* attn_counters(hipStream_t st) {
         on = (e && e[0] == '0') ? 0 : 1;
         if (on && (hipGetDevice(&buf_dev) != hipSuccess ||
                    hipMalloc((void**)&buf, ATTN_CTR_SLOTS * 8 * 32 * sizeof(unsigned)) != hipSuccess ||
-                   hipMemset(buf, 0, ATTN_CTR_SLOTS * 8 * 32 * sizeof(unsigned)) != hipSuccess)) on = 0;
+                   hipMemset(buf, 0, ATTN_CTR_SLOTS * 8 * 32 * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) on = 0;
     }
     if (!on) return nullptr;
     int dev = -1;

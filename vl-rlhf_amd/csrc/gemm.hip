@@ -476,7 +476,8 @@ static bool launch_splitk128(int layout, GemmParams p, hipStream_t stream, int m
     float* ws = splitk_slot(stream);
     if (!ws) return false;
     const long per = (long)p.M * p.N * 4;
-    if ((long)splits * per > g_splitk_bytes) splits = (int)(g_splitk_bytes / per);
+    const long cap = g_splitk_bytes < SPLITK_SLOT_BYTES ? g_splitk_bytes : SPLITK_SLOT_BYTES;     // one bound for every user of a slot (gemm_grouped has the same)
+    if ((long)splits * per > cap) splits = (int)(cap / per);
     if (splits < 2) return false;
     const int kchunk = (((p.K + splits - 1) / splits) + 63) / 64 * 64;      // whole K tiles per slice
     splits = (p.K + kchunk - 1) / kchunk;
@@ -517,7 +518,7 @@ static int gemm_grouped(int layout, const void* A, const void* B, void* C, int M
         if (splits > K / 256) splits = K / 256;
         ws = splits >= 2 ? splitk_slot(stream) : nullptr;
         const long per = (long)groups * M * N * 4;
-        const long cap = g_splitk_bytes < SPLITK_SLOT_BYTES ? g_splitk_bytes : SPLITK_SLOT_BYTES;     // (the second half of a slot holds slabs)
+        const long cap = g_splitk_bytes < SPLITK_SLOT_BYTES ? g_splitk_bytes : SPLITK_SLOT_BYTES;
         if (ws && (long)splits * per > cap) splits = (int)(cap / per);
         if (!ws || splits < 2) splits = 1;
     }

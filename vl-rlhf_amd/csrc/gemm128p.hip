@@ -294,6 +294,7 @@ static bf16_t* q_zero16() {
     if (!z) {
         if (hipMalloc((void**)&z, 256) != hipSuccess) return nullptr;
         hipMemset(z, 0, 256);
+        hipDeviceSynchronize();      // one-time: the first launch may be on a non-blocking stream that does not order behind the null stream
     }
     return z;
 }

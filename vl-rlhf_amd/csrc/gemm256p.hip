@@ -1343,7 +1343,7 @@ static bf16_t* gemm256p_zero16() {
     static bool tried = false;
     if (!tried) {
         tried = true;
-        if (hipMalloc((void**)&z, 256) != hipSuccess || hipMemset(z, 0, 256) != hipSuccess) z = nullptr;
+        if (hipMalloc((void**)&z, 256) != hipSuccess || hipMemset(z, 0, 256) != hipSuccess || hipDeviceSynchronize() != hipSuccess) z = nullptr;
     }
     return z;
 }
@@ -1558,7 +1558,7 @@ bool vlr_gemm256p_try_launch(int layout, const GemmParams& p_in, hipStream_t str
             hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CONT_LDS_BYTES);
             hipFuncSetAttribute((const void*)gemm256p_kernel<false, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CONT_LDS_BYTES);
             hipFuncSetAttribute((const void*)gemm256p_kernel<true, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CONT_LDS_BYTES);
-            if (hipMalloc((void**)&zero16, 256) != hipSuccess || hipMemset(zero16, 0, 256) != hipSuccess) mode = 0;
+            if (hipMalloc((void**)&zero16, 256) != hipSuccess || hipMemset(zero16, 0, 256) != hipSuccess || hipDeviceSynchronize() != hipSuccess) mode = 0;
         }
     }
     if (!((mode >> layout) & 1)) return false;

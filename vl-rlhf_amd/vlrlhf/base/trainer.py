@@ -554,7 +554,8 @@ class VLDPOTrainer:
         rows = list(ds)
         w = _world()
         if w > 1 and len(rows) % w:
-            rows = rows + rows[: w - len(rows) % w]
+            pad = (-len(rows)) % w                      # cycled: an eval set smaller than the padding still fills every rank
+            rows = rows + (rows * (pad // len(rows) + 1))[:pad]
         rows = rows[_rank()::w]
         was_training = self.model.training
         self.model.eval()
@@ -761,6 +762,7 @@ class VLDPOTrainer:
             ep, skip = divmod(micro, n_batches)
             self.state.global_step = step
         window = []           # device scalars; only read back at logging time (no per-step host sync)
+        epoch_save_due = False
         while step < total:
             it = iter(self.get_train_batches(ep, skip=skip))
             nxt = next(it, None)
@@ -792,13 +794,27 @@ class VLDPOTrainer:
                     self.evaluate()
                 if save_strategy == "steps" and step % save_steps == 0:
                     self.save_checkpoint(step, micro, ep)
+                elif epoch_save_due:                    # the epoch ended inside an accumulation window: saved at the first optimizer step after it
+                    self.save_checkpoint(step, micro, ep)
+                epoch_save_due = False
                 if step >= total:
                     break
-            # (HF saves at every epoch end incl. the last; only at an optimizer-step boundary: a partly accumulated window is not state)
-            if save_strategy == "epoch" and micro % ga == 0:
+            # HF saves at every epoch end incl. the last.  A checkpoint is only state at an optimizer-step boundary (a partly accumulated
+            # window is not): when the epoch ends inside a window the save is deferred to the next optimizer step (logged), and an epoch
+            # cut short by max_steps is not an epoch end
+            if save_strategy == "epoch" and step < total:
+                if micro % ga == 0:
+                    self.save_checkpoint(step, micro, ep)
+                else:
+                    epoch_save_due = True
+                    if _rank() == 0:
+                        print(f"[vlrlhf] epoch {ep} ended inside an accumulation window ({micro % ga} of {ga} micro-batches): its checkpoint is written at optimizer step {step + 1}", flush=True)
+            elif save_strategy == "epoch" and micro % ga == 0 and micro == (ep + 1) * n_batches:      # the last epoch, fully consumed (not a max_steps break)
                 self.save_checkpoint(step, micro, ep)
             ep += 1
             skip = 0
+        if epoch_save_due and _rank() == 0:
+            print("[vlrlhf] warning: the last epoch ended inside an accumulation window; no checkpoint holds its partial window", flush=True)
         return self.state
 
     def save_state(self):

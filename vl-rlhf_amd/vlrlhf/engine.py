@@ -484,19 +484,29 @@ class LlavaHipEngine:
         if self.master is not None:
             self.init_optimizer()
 
-    def _mask_bits(self, l, M, p):
+    def _mask_bits(self, l, M, p, acts=None):
         """packed lora_dropout keep masks of layer l (include/vlr.h vlr_lora_weights::mask_bits): drawn by the layer's forward, read by
-        its adapter GEMMs and again by its backward - 57 MB per layer at the 7B shapes.  VLR_LORA_BITS=0: every kernel hashes instead."""
+        its adapter GEMMs and again by its backward - 57 MB per layer at the 7B shapes.  The buffer lives IN the activation set of the
+        pass that drew it (`acts`: per tag and layer, or the one shared set of a checkpointed pass), so a second training-mode forward
+        of the same size cannot overwrite masks a pending backward will read, and checkpointing keeps one buffer instead of one per
+        layer.  VLR_LORA_BITS=0: every kernel hashes instead."""
         if p <= 0.0 or os.environ.get("VLR_LORA_BITS", "1") == "0" or (M * self.H) % 32 or (M * self.I) % 32:
             return None
-        return self._buf(("lora_bits", l, M), (_hip.helper("vlr_lora_mask_bytes", self.H, self.I, M),), torch.uint8).data_ptr()
+        n = _hip.helper("vlr_lora_mask_bytes", self.H, self.I, M)
+        if acts is None:
+            return self._buf(("lora_bits", l, M), (n,), torch.uint8).data_ptr()
+        sh = acts.get("shared", acts)
+        t = sh.get("lora_bits")
+        if t is None or t.numel() != n:
+            t = sh["lora_bits"] = torch.empty(n, dtype=torch.uint8, device=self.dev)
+        return t.data_ptr()
 
-    def _lora_structs(self, l, train, M=None):
+    def _lora_structs(self, l, train, M=None, acts=None):
         lo = self.lora
         p = lo["dropout"] if (train and self.training) else 0.0
         ptr = lambda views, k: views[f"l{l}.{k}"].data_ptr() if f"l{l}.{k}" in views else None   # noqa: E731  (no down adapter: NULL)
         w = _hip.LoraWeights(lo["r"], lo["scale"], p, *(ptr(self.lv, k) for k in LORA_KEYS), self.lora_layout.qkv_targets,
-                             self._mask_bits(l, M, p) if M else None)
+                             self._mask_bits(l, M, p, acts) if M else None)
         g = _hip.LoraGrads(*(ptr(self.lgv, k) for k in LORA_KEYS))
         return w, g
 
@@ -571,7 +581,7 @@ class LlavaHipEngine:
             sh = a.get("shared", a)
             if "u" not in sh or sh["u"].shape[1] != 7 * r:
                 sh["u"] = torch.empty(M, 7 * r, dtype=BF16, device=self.dev)
-            lw, _ = self._lora_structs(l, train=True, M=M)
+            lw, _ = self._lora_structs(l, train=True, M=M, acts=a)
             # (lora_dropout: the keep mask is applied to x while the adapter GEMMs stage it and regenerated in the backward - no dropped
             # copies of the seven inputs are kept any more: 0.9 GB per layer at the 7B shapes)
             _hip.call("vlr_decoder_layer_fwd_lora", self.llama_cfg, self.layer_weights(ws, l), lw, a["struct"], sh["u"], None,
@@ -976,7 +986,7 @@ class LlavaHipEngine:
         for l in range(self.L - 1, -1, -1):
             a = ctx["acts"][l]
             x_in = ctx["acts"][l - 1]["x_out"] if l > 0 else ctx["x0"]
-            lw, lg = self._lora_structs(l, train=True, M=M)
+            lw, lg = self._lora_structs(l, train=True, M=M, acts=a)
             if ctx["ckpt"]:
                 self._layer_fwd_call(ws, l, a, x_in, ctx["embed"], Bn, S, True, True, ctx["lora_seed"])
             sh = a.get("shared", a)

@@ -33,7 +33,7 @@ class InternLMHipEngine(LlavaHipEngine):
 
     @property
     def supports_ckpt(self):       # the C layer passes (full fine-tune / reference) can be re-run; the Python-composed peft-LoRA layer keeps its activations
-        return self.lora is None
+        return self.lora is None and bool(getattr(self, "fused_forward", True))
 
     def __init__(self, cfg: dict, device="cuda", max_positions: int = 8192):
         c = dict(cfg, family="internlm_xc2")
@@ -80,13 +80,13 @@ class InternLMHipEngine(LlavaHipEngine):
                                            self.sin.data_ptr(), self.nkv, 0)
             self._ws = {}
 
-    def _plora_structs(self, ws, l, p, M=None):
+    def _plora_structs(self, ws, l, p, M=None, acts=None):
         """the PLoRA pairs of layer l as the adapter structs of the C layer passes (include/vlr.h vlr_lora_weights): ONE adapter over the
         fused wqkv, wo, w1 | w3 stacked, w2; scale = alpha / r; gradients into the flat gradient buffer (full fine-tune) or nowhere"""
         v = ws.v
         names = ("pa_qkv", "pb_qkv", "pa_o", "pb_o", "pa_gu", "pb_gu", "pa_d", "pb_d")
         w = _hip.LoraWeights(self.plora_r, self.plora_scale, float(p), *(v[f"l{l}.{n}"].data_ptr() for n in names), 1,
-                             self._mask_bits(l, M, float(p)) if M else None)
+                             self._mask_bits(l, M, float(p), acts) if M else None)
         g = _hip.LoraGrads(*(self.gv[f"l{l}.{n}"].data_ptr() for n in names)) if self.gv is not None else None
         return w, g
 
@@ -244,7 +244,7 @@ class InternLMHipEngine(LlavaHipEngine):
             sh = a.get("shared", a)
             if "u" not in sh or sh["u"].shape[1] != 7 * self.plora_r:
                 sh["u"] = torch.empty(M, 7 * self.plora_r, dtype=BF16, device=self.dev)
-            pw, _ = self._plora_structs(ws, l, self.plora_p if train else 0.0, M)
+            pw, _ = self._plora_structs(ws, l, self.plora_p if train else 0.0, M, a)
             _hip.call("vlr_decoder_layer_fwd_lora_ex", self.llama_cfg, self.layer_weights(ws, l), pw, a["struct"], sh["u"], None,
                       pseed + 8 * l, e["img_map"], x, e["pos"], e["mask"], Bn, S)
             if save:
@@ -302,7 +302,7 @@ class InternLMHipEngine(LlavaHipEngine):
             if ctx["ckpt"]:
                 self._layer_forward(ws, l, a, x_in, e, Bn, S, True, False, None)
             train = a["train"]
-            pw, pg = self._plora_structs(ws, l, self.plora_p if train else 0.0, M)
+            pw, pg = self._plora_structs(ws, l, self.plora_p if train else 0.0, M, a)
             sh = a.get("shared", a)
             _hip.call("vlr_decoder_layer_bwd_lora_ex", self.llama_cfg, self.layer_weights(ws, l), self.layer_grads(l), pw, pg, acc, a["struct"],
                       sh["u"], lws, ws_v, scratch, a["pseed"], e["img_map"], x_in, cur, nxt, ctx["pos"], ctx["mask"], Bn, S)
