@@ -312,9 +312,9 @@ def main():
         reducer.enabled = True
     # HBM traffic of the dominant kernel: PMC passes cannot run inside the timed region; the committed rocprofv3 --pmc
     # result (tools/pmc_traffic.sh -> profiles/r04_pmc_hbm_traffic.json) is quoted ONLY when it was taken with the library
-    # built from the sources this run uses (source digest of build_hip.py recorded in the file) - a stale file is refused
+    # built from the GEMM sources this run uses (build_hip.kernel_digest() recorded in the file) - a stale file is refused
     import build_hip as _bh
-    lib_digest = _bh._digest()[:16]
+    lib_digest = _bh.kernel_digest()[:16]       # gemm256p.hip + gemm.h + common.h + flags
     traffic = None
     traffic_file = None
     tf = os.path.join(ROOT, "profiles", "r04_pmc_hbm_traffic.json")
@@ -378,7 +378,7 @@ def main():
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                          "traffic": traffic, "traffic_source": traffic_file, "traffic_unit": "bytes/launch leaving L2 (2*FETCH_SIZE+WRITE_SIZE, rocprofv3 --pmc, OFFLINE pass of tools/pmc_traffic.sh with the same binary - counters cannot be collected inside the timed region; A+B of a decoder GEMM fit the 256 MB Infinity Cache, so most of the re-reads never reach HBM)",
                          "algorithmic_bytes_per_launch": round(2.0 * g_bytes / max(1, g_dec)), "launches": g_n, "avg_launch_ms": round(g_ms / max(1, g_n), 4), "event_sampling": f"one launch in {max(1, a.prof_sample)} bracketed by HIP events (pseudo-random per kernel id); launches and FLOPs exact, ms = sampled mean x launches", "per_kernel": per_kernel,
-                         "profile_file": PROFILE_FILE, "library_source_digest": lib_digest,
+                         "profile_file": PROFILE_FILE, "gemm_source_digest": lib_digest,
                          "kernel_share_of_step": round(g_ms * 1e-3 / dt, 3), "all_gemm_share_of_step": round(all_ms * 1e-3 / dt, 3),
                          "share_note": "kernel_share = the 256x256 kernel's launches alone; all_gemm_share = every vlr_gemm_* call by layout (fused launches, peeled rows and split-K reduces included), so all_gemm_share >= kernel_share",
                          "step_frac": round(pairs_per_s / world * per_pair / PEAK_BF16_TFLOPS, 4),

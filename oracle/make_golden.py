@@ -444,6 +444,17 @@ def gen_processor_answers():
         out["rows"].append(dict(row=r, formatted_prompt=prompt, conv=conv, prompt_raw_str=pr["raw_str"][0],
                                 prompt_full=pr["full"], chosen_full=full["full"], chosen_raw_str=full["raw_str"][0],
                                 valid=proc.is_multimodal_prompt_valid(prompt), stripped=proc.remove_image_placeholder(prompt)))
+    # VLProcessor.__call__ (base/processor.py:95-164; the base method, so no image file is opened): raw texts are wrapped in a single-turn
+    # conversation and run through process_batch_conv - a text without the placeholder gets it prepended - then padded on either side
+    from vlrlhf.base.processor import VLProcessor as RefVLProcessor
+    texts = ["What is shown in this picture?", "<image>\nIs there a cat in the photo?", "How many apples are on the table"]
+    paths = ["a.jpg", ["b.jpg"], "c.jpg"]
+    convs = [proc.make_single_turn_conv(proc.format_multimodal_prompt(r["prompt"], r["img_path"]), r["chosen"]) for r in rows]
+    out["call"] = []
+    for kw in (dict(texts=list(texts), images_path=paths), dict(texts=list(texts), images_path=paths, padding_side="right"),
+               dict(texts=list(texts)), dict(convs=convs), dict(convs=convs, padding_side="right")):
+        enc = RefVLProcessor.__call__(proc, **json.loads(json.dumps(kw)))       # (the reference formats `texts` in place: hand it a copy)
+        out["call"].append(dict(kwargs=kw, **{k: enc[k].tolist() for k in ("input_ids", "attention_mask", "labels")}))
     path = os.path.join(OUT_DIR, "processor_answers.json")
     with open(path, "w") as f:
         json.dump(out, f)

@@ -32,6 +32,17 @@ def t(z, k):
     return torch.from_numpy(z[k])
 
 
+def within(name, measured, tol):
+    """assert measured < tol; with VLR_MARGINS=<file> the (name, measured, tol) triple is appended to that file first - the tolerances of
+    the per-pair loss tests are 1.5 x what an MI355X run of the committed binary measured (profiles/r04_parity_margins.txt)"""
+    measured = float(measured)
+    f = os.environ.get("VLR_MARGINS")
+    if f:
+        with open(f, "a") as fh:
+            fh.write(f"{name:60s} measured {measured:.3e}  tolerance {tol:.3e}  ratio {measured / tol:.2f}\n")
+    assert measured < tol, (name, measured, tol)
+
+
 TINY_PROCESSOR = os.path.join(GOLDEN, "tiny_llava_processor")
 # a checkpoint-shaped tiny LLaVA whose vocabulary matches tests/golden/tiny_llava_processor (385 tokens -> 392)
 TINY_CKPT_CFG = dict(vit_hidden=128, vit_mlp=256, vit_layers=3, vit_heads=2, image_size=28, patch_size=14, hidden=256, inter=512,

@@ -12,7 +12,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import llava_dpo_oracle as O  # noqa: E402  (checker only)
-from tests.golden_util import load_case, t  # noqa: E402
+from tests.golden_util import load_case, t, within  # noqa: E402
 
 # Tolerances.  The HIP path stores weights/activations/gradients in bf16 (fp32 accumulation, fp32 softmax / norms /
 # log-softmax / loss); the golden vectors are fp32.  On the toy fixture the bf16-emulated ORACLE itself sits 2.3e-3
@@ -115,8 +115,8 @@ def test_losses_match_golden(gpu, loss_type):
     losses, cr, rw = tr.dpo_loss(pc, pr, rc, rr)
     exp = t(z, f"loss_{loss_type}")
     tol = 6e-2 * float(exp.abs().max()) + 2e-2 if loss_type in ("ipo", "hinge") else 1.2e-2
-    assert float((losses.cpu() - exp).abs().max()) < tol, (losses.cpu(), exp)
-    assert float((cr.cpu() - t(z, f"chosen_rewards_{loss_type}")).abs().max()) < 2.5e-2
+    within(f"llava.losses.{loss_type}", (losses.cpu() - exp).abs().max(), tol)
+    within(f"llava.chosen_rewards.{loss_type}", (cr.cpu() - t(z, f"chosen_rewards_{loss_type}")).abs().max(), 2.5e-2)
     tr2 = make_trainer(model, ref, cfg, "nope")
     with pytest.raises(ValueError, match="Unknown loss type"):
         tr2.dpo_loss(pc, pr, rc, rr)

@@ -10,7 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import llava_dpo_oracle as O  # noqa: E402  (checker only)
-from tests.golden_util import load_case, t  # noqa: E402
+from tests.golden_util import load_case, t, within  # noqa: E402
 from tests.test_hip_e2e import EMU, TOL_LOGPS_FP32, TOL_LOSS_BF16, TOL_LOSS_FP32, cosine, relmax  # noqa: E402
 
 
@@ -75,8 +75,8 @@ def test_llavanext_losses_match_golden(loss_type):
     losses, cr, rw = tr.dpo_loss(pc, pr, rc, rr)
     exp = t(z, f"loss_{loss_type}")
     tol = 6e-2 * float(exp.abs().max()) + 2e-2 if loss_type == "ipo" else 1.2e-2
-    assert float((losses.cpu() - exp).abs().max()) < tol, (losses.cpu(), exp)
-    assert float((cr.cpu() - t(z, f"chosen_rewards_{loss_type}")).abs().max()) < 2.5e-2
+    within(f"llavanext.losses.{loss_type}", (losses.cpu() - exp).abs().max(), tol)
+    within(f"llavanext.chosen_rewards.{loss_type}", (cr.cpu() - t(z, f"chosen_rewards_{loss_type}")).abs().max(), 2.5e-2)
 
 
 def test_llavanext_ddpo_train_step_matches_golden_and_oracle():

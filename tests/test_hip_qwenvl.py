@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import llava_dpo_oracle as O  # noqa: E402  (checker only)
 from oracle import qwenvl_oracle as Q  # noqa: E402  (checker only)
-from tests.golden_util import load_case, t  # noqa: E402
+from tests.golden_util import load_case, t, within  # noqa: E402
 from tests.test_hip_e2e import TOL_LOGPS_FP32, TOL_LOSS_BF16, TOL_LOSS_FP32, cosine, relmax  # noqa: E402
 
 EMUQ = O.HIP_ROUNDING | {"vit"}      # fp32 residual stream in the decoder; the whole Qwen vision tower + resampler (incl. its output) in bf16
@@ -86,9 +86,9 @@ def test_qwenvl_losses_match_reference_golden(loss_type):
     # vs the fp32 reference: the log-probs of this fixture (-48 .. -87, weights scaled x3, policy 40 % away from the reference) carry
     # up to TOL_LOGPS_FP32 = 0.25 of bf16 noise each, i.e. beta * 0.25 = 2.5e-2 on a sigmoid-type loss
     if loss_type == "ipo":       # (log-ratio - 1/(2 beta))^2: compare the roots - the log-ratio is a sum of four log-probs, each within ~0.15
-        assert float((losses.cpu().sqrt() - exp.sqrt()).abs().max()) < 0.6, (losses.cpu(), exp)
+        within("qwenvl.losses.ipo.sqrt", (losses.cpu().sqrt() - exp.sqrt()).abs().max(), 0.6)
     else:
-        assert float((losses.cpu() - exp).abs().max()) < 2.5e-2, (losses.cpu(), exp)
+        within(f"qwenvl.losses.{loss_type}", (losses.cpu() - exp).abs().max(), 2.5e-2)
 
 
 def test_qwenvl_train_step_gradients_match_reference_autograd():

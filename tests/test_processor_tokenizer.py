@@ -43,6 +43,25 @@ def test_processor_matches_the_reference_processor(proc):
         assert proc.is_multimodal_prompt_valid(prompt) == a["valid"] and proc.remove_image_placeholder(prompt) == a["stripped"]
 
 
+def test_processor_call_matches_the_reference_call(proc):
+    """VLProcessor.__call__(texts= / convs=, images_path, padding_side) against the reference's own base method on the same tokenizer files
+    (reference base/processor.py:95-164): texts ride make_single_turn_conv -> process_batch_conv, un-formatted prompts get the placeholder"""
+    import warnings
+    from vlrlhf.base.processor import VLProcessor
+    ans = json.load(open(os.path.join(GOLDEN, "processor_answers.json")))
+    assert len(ans["call"]) == 5
+    for c in ans["call"]:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            enc = VLProcessor.__call__(proc, **c["kwargs"])
+        for k in ("input_ids", "attention_mask", "labels"):
+            assert enc[k].tolist() == c[k], (c["kwargs"].keys(), k)
+        if "texts" in c["kwargs"] and "images_path" in c["kwargs"]:
+            assert any("multimodal format" in str(x.message) for x in w)
+    with pytest.raises(AssertionError):
+        VLProcessor.__call__(proc, texts=["a"], convs=[[]])
+
+
 def test_tokenize_row_on_a_real_tokenizer(proc):
     ans = json.load(open(os.path.join(GOLDEN, "processor_answers.json")))
     tok = proc.tokenizer

@@ -34,7 +34,7 @@ for k, n, f, w, mb in rows[:40]:
 open("gpurun_out/pmc_hbm_traffic.txt", "w").write("\n".join(out) + "\n")
 g = [r for r in rows if r[0].startswith("gemm256p_kernel")]
 nl = sum(r[1] for r in g)
-json.dump({"source_digest": build_hip._digest()[:16], "gemm_launches": nl, "gemm_hbm_bytes_per_launch": sum(r[1] * r[4] * 1e6 for r in g) / max(1, nl),
+json.dump({"source_digest": build_hip.kernel_digest()[:16], "gemm_launches": nl, "gemm_hbm_bytes_per_launch": sum(r[1] * r[4] * 1e6 for r in g) / max(1, nl),
            "note": "2*FETCH_SIZE+WRITE_SIZE, KiB->bytes, averaged over the gemm256p (8-phase 256x256 tile) launches of one DPO step"},
           open("gpurun_out/pmc_hbm_traffic.json", "w"))
 print("\n".join(out[:16]))

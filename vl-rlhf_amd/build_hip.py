@@ -28,6 +28,18 @@ def _digest():
     return h.hexdigest()
 
 
+def kernel_digest(sources=("gemm256p.hip", "gemm.h", "common.h")):
+    """digest of the translation unit of ONE kernel family (default: the dominant 256x256 GEMM, gemm256p.hip and the two headers it
+    includes) + the compiler flags: what tools/pmc_traffic.sh records next to the counters it collects and bench.py compares before it
+    quotes them - a change to another kernel's source does not make the GEMM's counters stale, a change to the GEMM's does."""
+    h = hashlib.sha256()
+    for name in sources:
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(name.encode() + f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
 def check_kloop_isa(asm_path):
     """gemm256p.hip: the steady-state K loop of every kernel (the branch-free innermost loop with exactly 64 v_mfma: 4 phases x 16)
     must hold only the hand-written counted waits: vmcnt(6) (classic body) or vmcnt(8) + vmcnt(6) (balanced phases).  Any other s_waitcnt vmcnt in there is hipcc guarding a

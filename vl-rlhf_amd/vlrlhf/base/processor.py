@@ -72,37 +72,37 @@ class VLProcessor(ABC):
 
     def __call__(self, texts=None, convs=None, images_path=None, padding: bool = True,
                  padding_side: Literal["right", "left"] = "left", check_format: bool = True):
-        """tokenize texts or conversations into (optionally padded) tensors (reference :95-164)."""
-        if texts is None and convs is None:
-            raise ValueError("texts and convs cannot be both None")
-        if texts is not None and convs is not None:
-            raise ValueError("texts and convs cannot be both set")
+        """raw texts or formatted conversations -> padded input_ids / attention_mask / labels (reference base/processor.py:95-164): a text
+        becomes the single-turn conversation [user: text, assistant: ""] and goes through process_batch_conv like a conversation does; when
+        images are passed, a text without the image placeholder gets it through format_multimodal_prompt (with the reference's warning).
+        Pinned by tests/golden/processor_answers.json["call"] (the reference's own method on the same tokenizer files).  Beyond the
+        reference: a single string is accepted for `texts`, and padding=False returns the un-padded lists (the reference leaves its
+        result unbound there)."""
+        assert texts is None or convs is None, "You can only pass texts or convs, not both."
         if isinstance(texts, str):
             texts = [texts]
-        if texts is not None:
-            if images_path is not None:
-                texts = [self.format_multimodal_prompt(t, p) for t, p in zip(texts, images_path)]
-            if check_format and images_path is not None:
-                for t in texts:
-                    if not self.is_multimodal_prompt_valid(t):
-                        raise ValueError(f"invalid multimodal prompt: {t}")
-            enc = [self.tokenizer(t) for t in texts]
-            ids = [e["input_ids"] for e in enc]
-            masks = [e["attention_mask"] for e in enc]
-            labels = None
-        else:
-            full = self.process_batch_conv(convs)["full"]
-            ids, masks, labels = full["input_ids"], full["attention_mask"], full["labels"]
+        if texts:
+            texts = list(texts)
+            if images_path is not None and check_format:
+                all_valid = True
+                for i in range(len(texts)):
+                    if not self.is_multimodal_prompt_valid(texts[i]):
+                        all_valid = False
+                        texts[i] = self.format_multimodal_prompt(texts[i], images_path[i])
+                if not all_valid:
+                    import warnings
+                    warnings.warn("You passed images, but your prompts are not in multimodal format. The image placeholder is added to "
+                                  "them automatically; prepare multimodal prompts in advance.")
+        batch_conv = [self.make_single_turn_conv(text) for text in texts] if texts else convs
+        if batch_conv is None:
+            raise ValueError("texts and convs cannot be both None")
+        full = self.process_batch_conv(batch_conv)["full"]
+        ids, masks, labels = full["input_ids"], full["attention_mask"], full["labels"]
         if not padding:
             return dict(input_ids=ids, attention_mask=masks, labels=labels)
         n = max(len(i) for i in ids)
-        pad_id = self.tokenizer.pad_token_id
 
         def pad(rows, value):
-            return torch.stack([pad_to_length(torch.tensor(r, dtype=torch.long), n, value, padding_side=padding_side)
-                                for r in rows])
+            return torch.stack([pad_to_length(torch.tensor(r, dtype=torch.long), n, value, padding_side=padding_side) for r in rows])
 
-        out = dict(input_ids=pad(ids, pad_id), attention_mask=pad(masks, 0))
-        if labels is not None:
-            out["labels"] = pad(labels, -100)
-        return out
+        return dict(input_ids=pad(ids, self.tokenizer.pad_token_id), attention_mask=pad(masks, 0), labels=pad(labels, -100))
