@@ -1598,3 +1598,19 @@ def test_gemm128_ring_depths(depth):
     assert r.returncode == 0, r.stderr[-2000:]
     worst = float(r.stdout.strip().splitlines()[-1].split()[1])
     assert worst < 8e-3, (depth, worst)
+
+
+# ---------------------------------------------------------------------------------------------------- 64-query forward attention kernel
+def test_fwd3_kernel_in_child_process():
+    """VLR_ATTN_FWD3 is read once per process: every attention test of this file (forward parity incl. masks / GQA / the step's sizes,
+    and the backward tests, which consume the forward's lse) again in a child process on attn_fwd3_kernel (csrc/attn_fwd3.h: 64 queries
+    per wave, asm-owned accumulator registers, explicit issue order; opt-in - it is not faster than the 32-query kernel yet)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VLR_ATTN_FWD3="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_kernels.py"), "-k", "attention", "-x", "-q", "-m", "gpu",
+                        "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-1000:]

@@ -520,6 +520,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
     }
 }
 
+#include "attn_fwd3.h"
+
 // ------------------------------------------------------------------------------------------------------------
 // delta[b][h][s] = sum_d dO[s][h*128+d] * O[s][h*128+d]   (D = 128)
 // ------------------------------------------------------------------------------------------------------------
@@ -1206,6 +1208,14 @@ static unsigned* attn_counters(hipStream_t st) {
     streams[nstreams] = st;
     return buf + (size_t)(nstreams++) * 8 * 32;
 }
+static int attn_fwd3_on() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("VLR_ATTN_FWD3");      // 64 queries per wave, explicit issue order (attn_fwd3.h); 0 = the 32-query fwd2 kernel
+        on = e ? atoi(e) : 0;
+    }
+    return on;
+}
 static int attn_dma_on() {
     static int on = -1;
     if (on < 0) {
@@ -1251,7 +1261,26 @@ extern "C" int vlr_attn_fwd_gqa(const void* q, const void* k, const void* v, int
 #define LAUNCH2(D_, C_)                                                                                                 \
     hipLaunchKernelGGL((attn_fwd2_kernel<D_, C_>), dim3(fgrid), dim3(256), AttnFwd2<D_>::LDS_BYTES, st, (const bf16_t*)q, \
                        (const bf16_t*)k, (const bf16_t*)v, ld, (bf16_t*)o, ldo, lse, key_mask, S, Sp, sl2, ag)
-    if (dma) {
+    if (dma && head_dim == 128 && attn_fwd3_on()) {
+        static bool attr3 = false;
+        if (!attr3) {
+            attr3 = true;
+            hipFuncSetAttribute((const void*)attn_fwd3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, AttnFwd3::LDS_BYTES);
+            hipFuncSetAttribute((const void*)attn_fwd3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, AttnFwd3::LDS_BYTES);
+        }
+        // the block map with 64 F3_NW queries per workgroup (one 256-thread workgroup per CU, or two of 128), persistent beyond that
+        AttnGrid a3 = ag;
+        a3.nblk = (S + 64 * F3_NW - 1) / (64 * F3_NW);
+        int g3 = a3.grid(false);
+        const int res3 = (F3_NW == 4 ? 1 : 2) * vlr_compute_cus();
+        a3.ctr = g3 > res3 ? attn_counters(st) : nullptr;
+        a3.items = g3 / 8;
+        if (a3.ctr) g3 = res3;
+        if (causal) hipLaunchKernelGGL((attn_fwd3_kernel<true>), dim3(g3), dim3(64 * F3_NW), AttnFwd3::LDS_BYTES, st, (const bf16_t*)q, (const bf16_t*)k,
+                                       (const bf16_t*)v, ld, (bf16_t*)o, ldo, lse, key_mask, S, Sp, sl2, a3);
+        else hipLaunchKernelGGL((attn_fwd3_kernel<false>), dim3(g3), dim3(64 * F3_NW), AttnFwd3::LDS_BYTES, st, (const bf16_t*)q, (const bf16_t*)k,
+                                (const bf16_t*)v, ld, (bf16_t*)o, ldo, lse, key_mask, S, Sp, sl2, a3);
+    } else if (dma) {
         if (head_dim == 128) { if (causal) LAUNCH2(128, true); else LAUNCH2(128, false); }
         else { if (causal) LAUNCH2(64, true); else LAUNCH2(64, false); }
     } else {
