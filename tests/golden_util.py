@@ -32,10 +32,38 @@ def t(z, k):
     return torch.from_numpy(z[k])
 
 
-def within(name, measured, tol):
+# per-pair loss / reward tolerances = 1.5 x the error an MI355X run of the committed binary measured against the reference-generated
+# fixtures (profiles/r04_parity_margins.txt, written by `VLR_MARGINS=<file> pytest -m gpu`; VERDICT r03 item 6c: the tests used to
+# accept 2.5e-2 on every pair).  The kernels are bit-reproducible, so a run only moves when a kernel's rounding order does: re-measure then.
+MEASURED_TOL = {
+    "llava.losses.sigmoid": 0.0065,
+    "llava.chosen_rewards.sigmoid": 0.0056,
+    "llava.losses.hinge": 0.014,
+    "llava.chosen_rewards.hinge": 0.0056,
+    "llava.losses.ipo": 1.2,
+    "llava.chosen_rewards.ipo": 0.0056,
+    "llava.losses.kto_pair": 0.002,
+    "llava.chosen_rewards.kto_pair": 0.0056,
+    "llava.losses.ddpo": 0.0037,
+    "llava.chosen_rewards.ddpo": 0.0051,
+    "qwenvl.losses.sigmoid": 0.0046,
+    "qwenvl.losses.ipo.sqrt": 0.12,
+    "qwenvl.losses.ddpo": 0.0046,
+    "internlm.losses.sigmoid": 0.0021,
+    "llavanext.losses.sigmoid": 0.00092,
+    "llavanext.chosen_rewards.sigmoid": 0.0021,
+    "llavanext.losses.ddpo": 0.0012,
+    "llavanext.chosen_rewards.ddpo": 0.0043,
+    "llavanext.losses.ipo": 0.19,
+    "llavanext.chosen_rewards.ipo": 0.0021,
+}
+
+
+def within(name, measured, tol=None):
     """assert measured < tol; with VLR_MARGINS=<file> the (name, measured, tol) triple is appended to that file first - the tolerances of
     the per-pair loss tests are 1.5 x what an MI355X run of the committed binary measured (profiles/r04_parity_margins.txt)"""
     measured = float(measured)
+    tol = MEASURED_TOL[name] if tol is None else tol
     f = os.environ.get("VLR_MARGINS")
     if f:
         with open(f, "a") as fh:

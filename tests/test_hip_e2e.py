@@ -114,9 +114,8 @@ def test_losses_match_golden(gpu, loss_type):
     assert float((torch.cat([rc, rr]).cpu() - t(z, key)).abs().max()) < TOL_LOGPS_FP32
     losses, cr, rw = tr.dpo_loss(pc, pr, rc, rr)
     exp = t(z, f"loss_{loss_type}")
-    tol = 6e-2 * float(exp.abs().max()) + 2e-2 if loss_type in ("ipo", "hinge") else 1.2e-2
-    within(f"llava.losses.{loss_type}", (losses.cpu() - exp).abs().max(), tol)
-    within(f"llava.chosen_rewards.{loss_type}", (cr.cpu() - t(z, f"chosen_rewards_{loss_type}")).abs().max(), 2.5e-2)
+    within(f"llava.losses.{loss_type}", (losses.cpu() - exp).abs().max())
+    within(f"llava.chosen_rewards.{loss_type}", (cr.cpu() - t(z, f"chosen_rewards_{loss_type}")).abs().max())
     tr2 = make_trainer(model, ref, cfg, "nope")
     with pytest.raises(ValueError, match="Unknown loss type"):
         tr2.dpo_loss(pc, pr, rc, rr)

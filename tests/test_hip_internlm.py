@@ -54,7 +54,7 @@ def test_internlm_forward_matches_reference_golden():
         pc, pr, _, _ = tr.concatenated_forward(model, batch)
     assert float((torch.cat([rc, rr]).cpu() - t(z, "sigmoid.ref_logps")).abs().max()) < TOL_LOGPS_FP32
     losses, _, _ = tr.dpo_loss(pc, pr, rc, rr)
-    within("internlm.losses.sigmoid", (losses.cpu() - t(z, "sigmoid.losses")).abs().max(), 2.5e-2)
+    within("internlm.losses.sigmoid", (losses.cpu() - t(z, "sigmoid.losses")).abs().max())
     bad = cb["concatenated_input_ids"].clone()
     bad[0, 1] = cfg["image_token"]                                   # one more <ImageHere> than images
     with pytest.raises(ValueError, match="image tokens"):
