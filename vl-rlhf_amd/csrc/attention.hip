@@ -1225,6 +1225,11 @@ static int attn_dma_on() {
     return on;
 }
 
+#ifdef F3_TRACE
+extern "C" int vlr_attn_fwd3_trace(unsigned long long* host, int n) {      // diagnostics build: the s_memtime stamps of attn_fwd3.h
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(f3_trace_buf), (size_t)n * 8) == hipSuccess ? 0 : 1;
+}
+#endif
 extern "C" int vlr_attn_fwd_gqa(const void* q, const void* k, const void* v, int ld, void* o, int ldo, float* lse,
                                 const int* key_mask, int batch, int S, int heads, int kv_heads, int head_dim, int causal,
                                 float scale, hipStream_t st) {

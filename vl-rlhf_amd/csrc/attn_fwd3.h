@@ -22,35 +22,52 @@
 #pragma once
 
 #define F3_TAU 8.0f
-#ifndef F3_SWAP
-#define F3_SWAP 0
-#endif
 #ifndef F3_NW
 #define F3_NW 4          // waves per workgroup: 4 = 256 queries per workgroup, one per CU; 2 = 128 queries, two per CU
 #endif
+#ifndef F3_ABLATE
+#define F3_ABLATE 0      // timing experiments (wrong results): 1 no softmax pairs, 2 no MFMAs, 4 no fragment reads, 8 no per-tile barrier
+#endif
 #define F3_PF 3            // fragments requested this many slots ahead of their MFMAs
+
+#ifdef F3_TRACE
+// timing probe (diagnostics build only): wave 0 of workgroup 0 stamps s_memtime at fixed points of its first tiles
+__device__ unsigned long long f3_trace_buf[4096];
+#define F3_STAMP(slot) do { if (f3_tr_on && f3_tr_n < 4000) { f3_trace_buf[f3_tr_n++] = ((unsigned long long)(slot) << 56) | (__builtin_amdgcn_s_memtime() & 0xffffffffffffffull); } } while (0)
+#else
+#define F3_STAMP(slot) do {} while (0)
+#endif
 
 struct AttnFwd3 {
     static constexpr int TILE_BYTES = KV_TILE * 128 * 2;
-    static constexpr int LDS_BYTES = 4 * TILE_BYTES + ATTN_MAX_TILES * 8;
+    static constexpr int LDS_BYTES = 4 * TILE_BYTES + ATTN_MAX_TILES * 8 + 16;      // K / V stages, tile masks, one any-mask word per wave
 };
 
-// key-validity words of the first nkv tiles with TWO waves per workgroup (attn_tile_masks assumes four): wave w takes tiles w, w+2, ...
-__device__ __forceinline__ void attn_tile_masks2(unsigned long long* tilemask, const int* __restrict__ kmask, size_t tok0, int S, int nkv,
-                                                 int wave, int lane) {
-    for (int base = wave; base < nkv; base += 8) {
+// key-validity words of the first nkv tiles (bit = key is padded or past S), NW waves per workgroup: wave w takes tiles w, w + NW, ...,
+// four tiles' loads in flight per ballot (attn_tile_masks of attention.hip for any NW).  Returns whether ANY of this wave's words is
+// non-zero: the workgroup ORs that (one LDS word per wave) and the tile loop only reads mask words when there is a masked key at all -
+// the per-tile ds_read_b64 + wait cost 120 cycles in front of every tile (tools/attn_fwd3_trace.py).
+template <int NW>
+__device__ __forceinline__ bool f3_tile_masks(unsigned long long* tilemask, const int* __restrict__ kmask, size_t tok0, int S, int nkv,
+                                              int wave, int lane) {
+    unsigned long long any = 0ull;
+    for (int base = wave; base < nkv; base += 4 * NW) {
         int ok[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int key = (base + 2 * u) * KV_TILE + lane;
+            const int key = (base + NW * u) * KV_TILE + lane;
             ok[u] = key < S ? (kmask ? kmask[tok0 + key] : 1) : 0;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const unsigned long long bad = __builtin_amdgcn_ballot_w64(ok[u] == 0);
-            if (lane == 0 && base + 2 * u < nkv) tilemask[base + 2 * u] = bad;
+            if (base + NW * u < nkv) {
+                any |= bad;
+                if (lane == 0) tilemask[base + NW * u] = bad;
+            }
         }
     }
+    return any != 0ull;
 }
 
 // LDS fragment reads from explicit per-lane byte addresses: the lane part (row, swizzled chunk) is computed ONCE per workgroup - 8
@@ -73,15 +90,15 @@ __device__ __forceinline__ bf16x8 f3_vfrag(const F3Addr& a, int db, int ks, int 
 }
 
 __device__ __forceinline__ float f3_pair_max(float x) {
-    // max over the lane pair (l, l ^ 32)
-#if F3_SWAP
-    // without the LDS crossbar: v_permlane32_swap exchanges the upper half of one register with the lower half of the other
-    const unsigned u = __builtin_bit_cast(unsigned, x);
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
-#else
-    return fmaxf(x, __shfl_xor(x, 32));
-#endif
+    // max over the lane pair (l, l ^ 32) without the LDS crossbar (ds_bpermute + lgkmcnt(0): 140 cycles per query half, measured):
+    // v_permlane32_swap exchanges lanes 32..63 of its first register with lanes 0..31 of its second; with the row's value in both,
+    // one register then holds the lower lane's value in every lane and the other the upper lane's.  By inline asm: through
+    // __builtin_amdgcn_permlane32_swap hipcc (ROCm 7.2) folds fmaxf(r[0], r[1]) of a swap whose operands carry the same value to r[0]
+    // - the swap is emitted, the max is not (tools/probe_permlane32_swap.hip) - and every lane is left with the LOWER lane's value.
+    // s_nop 1: the two wait states between a VALU write of an operand and the swap; hipcc pads the reader behind the statement.
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
 }
 
 // scores of one 64-key tile for the wave's two query halves: keys that are padded / past S (mk) or in the query's future -> -inf.
@@ -173,6 +190,7 @@ __device__ __forceinline__ float f3_rowmax32(const f32x16& a, const f32x16& b) {
 template <int J>
 __device__ __forceinline__ void f3_pair(const f32x16 (&Sc)[2][2], float c, const float (&negm)[2], float (&l)[2][2], u32x4 (&pw)[2][4]) {
     constexpr int ks = J >> 3, qh = (J >> 2) & 1, i = J & 3, kb = ks >> 1, r = 8 * (ks & 1) + 2 * i;
+    if constexpr (F3_ABLATE & 1) { pw[qh][ks][i] = 0x3f803f80u; return; }
     // ONE asm statement, seven VALU instructions in this order:  fma fma exp exp add add cvt_pk.
     //  * scalar on purpose: v_pk_fma_f32 / v_pk_add_f32 beside MFMAs cost +22..26 cycles per gap (MI355X_MICROARCH.md), and left to
     //    itself hipcc packs the two query halves' row sums into v_pk_add_f32 chains that it sinks behind the last MFMA of the tile
@@ -190,29 +208,71 @@ __device__ __forceinline__ void f3_pair(const f32x16 (&Sc)[2][2], float c, const
         : "v"(Sc[qh][kb][r]), "v"(Sc[qh][kb][r + 1]), "s"(c), "v"(negm[qh]));
     pw[qh][ks][i] = w;
 }
+// The same pair in two statements, for the steady-state slots: A (fma fma exp) goes behind the slot's FIRST MFMA, B (exp add add cvt_pk)
+// behind the second.  One wave per SIMD issues in order: two MFMAs back to back leave the wave stalled at the second one until the
+// matrix pipe is free (~28 cycles in which nothing issues), and the whole pair (~48 cycles) then runs behind a 32-cycle MFMA - 101-112
+// cycles per slot measured (tools/attn_fwd3_trace.py) against 64 of matrix work.  With half a pair behind each MFMA the next MFMA reaches
+// the head of the queue about when the pipe frees.  volatile: hipcc must not regroup them around the (volatile) MFMA statements.
+template <int J>
+__device__ __forceinline__ void f3_pair_a(const f32x16 (&Sc)[2][2], float c, const float (&negm)[2], float& x0, float& x1) {
+    constexpr int ks = J >> 3, qh = (J >> 2) & 1, i = J & 3, kb = ks >> 1, r = 8 * (ks & 1) + 2 * i;
+    if constexpr (F3_ABLATE & 1) return;
+    asm volatile("v_fma_f32 %0, %2, %4, %5\n\tv_fma_f32 %1, %3, %4, %5\n\tv_exp_f32 %0, %0"
+                 : "=&v"(x0), "=&v"(x1)
+                 : "v"(Sc[qh][kb][r]), "v"(Sc[qh][kb][r + 1]), "s"(c), "v"(negm[qh]));
+}
+template <int J>
+__device__ __forceinline__ void f3_pair_b(float (&l)[2][2], u32x4 (&pw)[2][4], float& x0, float& x1) {
+    constexpr int ks = J >> 3, qh = (J >> 2) & 1, i = J & 3;
+    if constexpr (F3_ABLATE & 1) { pw[qh][ks][i] = 0x3f803f80u; return; }
+    uint32_t w;
+    asm volatile("v_exp_f32 %1, %1\n\tv_add_f32 %2, %2, %0\n\tv_add_f32 %3, %3, %1\n\tv_cvt_pk_bf16_f32 %4, %0, %1"
+                 : "+v"(x0), "+v"(x1), "+v"(l[qh][0]), "+v"(l[qh][1]), "=v"(w));
+    pw[qh][ks][i] = w;
+}
 
-// the running maxima: move them only where the tile's maximum is more than 2^TAU above (lazy rescale); negm = -m for the exponent
-__device__ __forceinline__ void f3_running_max(float (&m_used)[2], float (&l)[2][2], const float (&mx)[2], float c, float (&negm)[2]) {
-    float alpha[2];
-    bool any = false;
+// The running maxima: a query's exponentials are taken against m_used, which only moves when the tile's maximum is more than 2^TAU above
+// it (lazy rescale).  DECIDED beside the last MFMAs of the previous tile (f3_decide: pure VALU, slots 14 / 15 of phase 2) and APPLIED in
+// front of the next tile's first pair (f3_rescale: a wave-uniform branch that is not taken in the steady state) - computed at the top
+// of the tile these ~25 instructions ran with the matrix pipe idle (236 cycles per tile, tools/attn_fwd3_trace.py).
+struct F3Next {
+    float negm[2];      // -m for the exponent of the tile to come
+    float alpha[2];     // factor for O and l where the maximum moved, 1 elsewhere
+    bool any;           // some lane of this wave moved
+};
+__device__ __forceinline__ void f3_decide(float (&m_used)[2], const float (&mx)[2], float c, F3Next& nx) {
+    nx.any = false;
 #pragma unroll
     for (int qh = 0; qh < 2; ++qh) {
         const float ms = mx[qh] * c;
         const bool grow = ms > m_used[qh] + F3_TAU;
         const float m_new = grow ? ms : m_used[qh];
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        alpha[qh] = grow ? __builtin_amdgcn_exp2f(m_used[qh] - m_use) : 1.f;
+        nx.alpha[qh] = grow ? __builtin_amdgcn_exp2f(m_used[qh] - m_use) : 1.f;
         m_used[qh] = m_new;
-        negm[qh] = -m_use;
-        any = any || grow;
+        nx.negm[qh] = -m_use;
+        nx.any = nx.any || grow;
     }
-    if (__builtin_amdgcn_ballot_w64(any)) {       // rare after the first tiles: O passes through two VGPRs, in place
-        l[0][0] *= alpha[0];
-        l[0][1] *= alpha[0];
-        l[1][0] *= alpha[1];
-        l[1][1] *= alpha[1];
-        f3_o_scale<0>(alpha[0]);
-        f3_o_scale<1>(alpha[1]);
+}
+__device__ __forceinline__ void f3_rescale(const F3Next& nx, float (&l)[2][2]) {
+    if (__builtin_amdgcn_ballot_w64(nx.any)) {       // rare after the first tiles: O passes through two VGPRs, in place
+        l[0][0] *= nx.alpha[0];
+        l[0][1] *= nx.alpha[0];
+        l[1][0] *= nx.alpha[1];
+        l[1][1] *= nx.alpha[1];
+        f3_o_scale<0>(nx.alpha[0]);
+        f3_o_scale<1>(nx.alpha[1]);
+    }
+}
+
+// the NP pieces a wave contributes to one K or V tile (see `issue` in attn_fwd3_block)
+template <int STAGE_OFF, int I, int NP, int NW>
+__device__ __forceinline__ void f3_dma_tile(const bf16_t* tb, const uint32_t (&voff)[NP], uint32_t ldsw) {
+    if constexpr (I < NP) {
+        asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff[I]), "s"(tb), "s"(ldsw),
+                     "i"(STAGE_OFF + NW * I * 1024)
+                     : "memory", "scc");
+        f3_dma_tile<STAGE_OFF, I + 1, NP, NW>(tb, voff, ldsw);
     }
 }
 
@@ -221,60 +281,87 @@ __device__ __forceinline__ void f3_running_max(float (&m_used)[2], float (&l)[2]
 // of Sn.  diag_next / mk_next (wave-uniform, rare): tile t+1 is the diagonal tile or holds padded keys - masked after the slots,
 // maxima taken again.
 template <bool CAUSAL, int KST, int VST>
-__device__ __forceinline__ void f3_tile(f32x16 (&Sc)[2][2], f32x16 (&Sn)[2][2], float (&m_used)[2], float (&l)[2][2], float (&mx)[2],
+__device__ __forceinline__ void f3_tile(f32x16 (&Sc)[2][2], f32x16 (&Sn)[2][2], float (&m_used)[2], float (&l)[2][2], F3Next& nx,
                                         const F3Addr& fa, float c, int lane, bool diag_next, unsigned long long mk_next, int k0_next,
-                                        int qi0) {
-    float negm[2];
+                                        int qi0, bool f3_tr_on, int& f3_tr_n) {
     u32x4 pw[2][4];
     bf16x8 kf[16], vf[16];
+    F3_STAMP(1);
     f3_for<0, F3_PF>([&](auto ic) { constexpr int i = ic; kf[i] = f3_kfrag(fa, i & 7, i >> 3, KST); });
-    f3_running_max(m_used, l, mx, c, negm);
+    f3_rescale(nx, l);
+    const float negm[2] = {nx.negm[0], nx.negm[1]};
     __builtin_amdgcn_sched_barrier(0);
+    F3_STAMP(2);
     // ---- phase 1: S(t+1) = K(t+1) Q^T beside the pairs of the first two P fragments (keys 0..31)
     f3_for<0, 16>([&](auto ic) {
         constexpr int i = ic, kb = i >> 3, st = i & 7, n = i + F3_PF;
-        if constexpr (n < 16) kf[n] = f3_kfrag(fa, n & 7, n >> 3, KST);
-        else vf[n - 16] = f3_vfrag(fa, (n - 16) & 3, (n - 16) >> 2, VST);
-        f3_mma_s<st, st == 0>(Sn[0][kb], kf[i]);
-        f3_mma_s<8 + st, st == 0>(Sn[1][kb], kf[i]);
-        f3_pair<i>(Sc, c, negm, l, pw);
+        if constexpr (F3_ABLATE & 4) {
+            if constexpr (n < 16) kf[n] = kf[0];
+            else vf[n - 16] = kf[0];
+        } else {
+            if constexpr (n < 16) kf[n] = f3_kfrag(fa, n & 7, n >> 3, KST);
+            else vf[n - 16] = f3_vfrag(fa, (n - 16) & 3, (n - 16) >> 2, VST);
+        }
+        float x0, x1;
+        if constexpr (!(F3_ABLATE & 2)) f3_mma_s<st, st == 0>(Sn[0][kb], kf[i]);
+        f3_pair_a<i>(Sc, c, negm, x0, x1);
+        if constexpr (!(F3_ABLATE & 2)) f3_mma_s<8 + st, st == 0>(Sn[1][kb], kf[i]);
+        else if constexpr (st == 0) {
+            Sn[0][kb] = Sc[0][kb];
+            Sn[1][kb] = Sc[1][kb];
+        }
+        f3_pair_b<i>(l, pw, x0, x1);
         __builtin_amdgcn_sched_barrier(0);
     });
+    F3_STAMP(3);
     // ---- phase 2: O += V(t) P(t) beside the pairs of keys 32..63 (slots 0..11: 16 pairs, slots 0 / 3 / 6 / 9 take two) and the row
     // maxima of S(t+1) (slots 12..15)
+    // slots 0..11: the 16 pairs of keys 32..63 (slots 0 / 3 / 6 / 9 take two); then Sn - complete since the end of phase 1 - is masked
+    // if tile t+1 needs it (rare branch), slots 12 / 13 take its row maxima (two interleaved v_max3 chains per query half), slot 14
+    // the exchange with the partner lane, slot 15 the decision about the running maxima
     float mxa[2][2] = {{-INFINITY, -INFINITY}, {-INFINITY, -INFINITY}};
-    f3_for<0, 16>([&](auto jc) {
+    float mxp[2];
+    auto slot2 = [&](auto jc) {
         constexpr int j = jc, ks = j >> 2, db = j & 3, n = j + F3_PF;
-        if constexpr (n < 16) vf[n] = f3_vfrag(fa, n & 3, n >> 2, VST);
-        f3_mma_o<db, db == 0>(vf[j], pw[0][ks]);
-        f3_mma_o<4 + db, db == 0>(vf[j], pw[1][ks]);
-        if constexpr (j < 12) {
-            constexpr int first = 16 + j + (j + 2) / 3;        // slots 0,3,6,9 carry two pairs: 16,17 | 18 | 19 | 20,21 | ...
-            f3_pair<first>(Sc, c, negm, l, pw);
-            if constexpr (j % 3 == 0) f3_pair<first + 1>(Sc, c, negm, l, pw);
-        } else {
-            constexpr int qh = (j - 12) >> 1, kb = (j - 12) & 1;
-            f3_rowmax16(Sn[qh][kb], mxa[qh]);
+        if constexpr (n < 16) {
+            if constexpr (F3_ABLATE & 4) vf[n] = vf[0];
+            else vf[n] = f3_vfrag(fa, n & 3, n >> 2, VST);
         }
+        constexpr int first = 16 + j + (j + 2) / 3;            // slots 0,3,6,9 carry two pairs: 16,17 | 18 | 19 | 20,21 | ...
+        float x0, x1;
+        if constexpr (!(F3_ABLATE & 2)) f3_mma_o<db, db == 0>(vf[j], pw[0][ks]);
+        if constexpr (j < 12) f3_pair_a<first>(Sc, c, negm, x0, x1);
+        if constexpr (j == 12) f3_rowmax16(Sn[0][0], mxa[0]);
+        if constexpr (j == 13) f3_rowmax16(Sn[1][0], mxa[1]);
+        if constexpr (j == 14) mxp[0] = f3_pair_max(fmaxf(mxa[0][0], mxa[0][1]));
+        if constexpr (!(F3_ABLATE & 2)) f3_mma_o<4 + db, db == 0>(vf[j], pw[1][ks]);
+        else asm volatile("" ::"v"(vf[j]), "v"(pw[0][ks]), "v"(pw[1][ks]));
+        if constexpr (j < 12) {
+            f3_pair_b<first>(l, pw, x0, x1);
+            if constexpr (j % 3 == 0) f3_pair<first + 1>(Sc, c, negm, l, pw);
+        }
+        if constexpr (j == 12) f3_rowmax16(Sn[0][1], mxa[0]);
+        if constexpr (j == 13) f3_rowmax16(Sn[1][1], mxa[1]);
+        if constexpr (j == 14) mxp[1] = f3_pair_max(fmaxf(mxa[1][0], mxa[1][1]));
+        if constexpr (j == 15) f3_decide(m_used, mxp, c, nx);
         __builtin_amdgcn_sched_barrier(0);
-    });
-    float m0 = fmaxf(mxa[0][0], mxa[0][1]), m1 = fmaxf(mxa[1][0], mxa[1][1]);
+    };
+    f3_for<0, 12>(slot2);
     if (diag_next || mk_next != 0ull) {
         f3_mask<CAUSAL>(Sn, mk_next, k0_next, qi0, lane >> 5);
-        m0 = f3_rowmax32(Sn[0][0], Sn[0][1]);
-        m1 = f3_rowmax32(Sn[1][0], Sn[1][1]);
+        __builtin_amdgcn_sched_barrier(0);
     }
-    mx[0] = f3_pair_max(m0);
-    mx[1] = f3_pair_max(m1);
+    f3_for<12, 16>(slot2);
+    F3_STAMP(4);
+    F3_STAMP(5);
 }
 
 // The wave's LAST tile: no next tile to overlap with - softmax, then O += V P, in program order (once per 128-query block and wave).
 template <int VST>
-__device__ __forceinline__ void f3_tail(f32x16 (&Sc)[2][2], float (&m_used)[2], float (&l)[2][2], const float (&mx)[2], const F3Addr& fa,
-                                        float c) {
-    float negm[2];
+__device__ __forceinline__ void f3_tail(f32x16 (&Sc)[2][2], float (&l)[2][2], const F3Next& nx, const F3Addr& fa, float c) {
     u32x4 pw[2][4];
-    f3_running_max(m_used, l, mx, c, negm);
+    f3_rescale(nx, l);
+    const float negm[2] = {nx.negm[0], nx.negm[1]};
     f3_for<0, 4>([&](auto kc) {
         constexpr int ks = kc;
         f3_for<0, 8>([&](auto jc) { f3_pair<8 * ks + decltype(jc)::value>(Sc, c, negm, l, pw); });
@@ -328,15 +415,19 @@ __device__ __forceinline__ unsigned attn_fwd3_block(const bf16_t* __restrict__ q
         const int swz = (tile_off<D>(r, 0) - r * (D * 2)) >> 4;
         voff[i] = (uint32_t)(((size_t)r * ld + ((ppos ^ swz) * 8)) * 2);
     }
-    auto issue = [&](const bf16_t* base, int it, uint32_t dst) {
+    const uint32_t ldsw = lds0 + (uint32_t)wave * 1024u;       // scalar: this wave's first piece of stage 0 / K
+    // STAGE_OFF: byte offset of the destination tile in LDS (a constant at every call site).  One piece = {s_add_u32 m0, ldsw, constant;
+    // s_nop 0; global_load_lds_dwordx4}: the per-piece destination is an immediate added straight into m0 (92 cycles per piece went
+    // into seven scalar instructions and spilled-SGPR reloads before, tools/attn_fwd3_trace.py)
+    auto issue = [&](const bf16_t* base, int it, auto stage_c) {
+        constexpr int STAGE_OFF = decltype(stage_c)::value;
         const int k0 = it * KV_TILE;
 #ifdef F3_NODMA          // timing experiment (wrong results): only the first two tiles are fetched, the others reuse what is in LDS
         if (it >= 2) return;
 #endif
         if (k0 + KV_TILE <= S) {
             const bf16_t* tb = base + (size_t)k0 * ld;          // scalar: the tile's first row
-#pragma unroll
-            for (int i = 0; i < NP; ++i) attn_dma16(tb, voff[i], dst + (wave + NW * i) * 1024);
+            f3_dma_tile<STAGE_OFF, 0, NP, NW>(tb, voff, ldsw);
         } else {
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
@@ -346,10 +437,14 @@ __device__ __forceinline__ unsigned attn_fwd3_block(const bf16_t* __restrict__ q
                 const int cc = ppos ^ swz;
                 int row = k0 + r;
                 row = row < S ? row : S - 1;
-                attn_dma16(base, (uint32_t)(((size_t)row * ld + cc * 8) * 2), dst + pc * 1024);
+                attn_dma16(base, (uint32_t)(((size_t)row * ld + cc * 8) * 2), lds0 + STAGE_OFF + pc * 1024);
             }
         }
     };
+    using KS0 = std::integral_constant<int, 0>;
+    using VS0 = std::integral_constant<int, AttnFwd3::TILE_BYTES>;
+    using KS1 = std::integral_constant<int, 2 * AttnFwd3::TILE_BYTES>;
+    using VS1 = std::integral_constant<int, 3 * AttnFwd3::TILE_BYTES>;
     F3Addr fa;
     {
         const int l31 = lane & 31;
@@ -365,12 +460,13 @@ __device__ __forceinline__ unsigned attn_fwd3_block(const bf16_t* __restrict__ q
             fa.v[db][1] = lds0 + (uint32_t)(TB + tile_off<D>(row + 8, col >> 3) + sub);
         }
     }
-    auto k_stage = [&](int it) { return (uint32_t)((it & 1) * 2 * TB); };
-    auto v_stage = [&](int it) { return (uint32_t)((it & 1) * 2 * TB + TB); };
-    issue(kh, 0, lds0 + k_stage(0));
+    issue(kh, 0, KS0{});
 
-    if constexpr (NW == 4) attn_tile_masks(tilemask, kmask, tok0, S, nkv, wave, lane);
-    else attn_tile_masks2(tilemask, kmask, tok0, S, nkv, wave, lane);
+    uint32_t* wflag = reinterpret_cast<uint32_t*>(smem + 4 * TB + ATTN_MAX_TILES * 8);
+    {
+        const bool wany = f3_tile_masks<NW>(tilemask, kmask, tok0, S, nkv, wave, lane);
+        if (lane == 0) wflag[wave] = wany ? 1u : 0u;
+    }
 
     // the wave's Q fragments -> a[128:191] (B operands of the S MFMAs), O = a[0:127] = 0
     f3_for<0, 16>([&](auto ic) {
@@ -382,16 +478,21 @@ __device__ __forceinline__ unsigned attn_fwd3_block(const bf16_t* __restrict__ q
     f3_o_zero();
     float m_used[2] = {-INFINITY, -INFINITY};
     float l[2][2] = {{0.f, 0.f}, {0.f, 0.f}};       // this lane's half of the row sums, two chains each (its 32 of every 64 keys); the lane pair is added at the end
-    float mx[2];                    // row maxima of the scores whose softmax comes next, per query half
+    F3Next nx;                      // the running-maximum decision for the tile whose softmax comes next
+    nx.any = false;
     f32x16 Sx[2][2][2];             // [tile parity][query half][key block]: raw scores, double buffered across the pipeline
     // K(0) has landed (vmcnt also retires the Q fragments and the mask words' loads); V(0) and K(1) go out under S(0) = K(0) Q^T
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (lgkmcnt: the tile-mask words written above)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    issue(vh, 0, lds0 + v_stage(0));
-    if (nkv > 1) issue(kh, 1, lds0 + k_stage(1));
-    auto need_mask = [&](int it) { return tilemask[it] != 0ull || (CAUSAL && it * KV_TILE + KV_TILE - 1 > qw0); };
+    issue(vh, 0, VS0{});
+    if (nkv > 1) issue(kh, 1, KS1{});
+    bool has_masks = false;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) has_masks = has_masks || wflag[w] != 0u;
+    has_masks = __builtin_amdgcn_readfirstlane((int)has_masks) != 0;
+    auto mask_word = [&](int it) { return has_masks ? tilemask[it] : 0ull; };
     if (nt_w > 0) {
         f3_for<0, 16>([&](auto ic) {
             constexpr int i = ic, kb = i >> 3, st = i & 7;
@@ -400,31 +501,42 @@ __device__ __forceinline__ unsigned attn_fwd3_block(const bf16_t* __restrict__ q
             f3_mma_s<8 + st, st == 0>(Sx[0][1][kb], kf);
         });
         f3_settle_s(Sx[0]);
-        if (need_mask(0)) f3_mask<CAUSAL>(Sx[0], tilemask[0], 0, qi0, g);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) mx[h] = f3_pair_max(f3_rowmax32(Sx[0][h][0], Sx[0][h][1]));
+        {
+            const unsigned long long mk0 = mask_word(0);
+            if (mk0 != 0ull || (CAUSAL && KV_TILE - 1 > qw0)) f3_mask<CAUSAL>(Sx[0], mk0, 0, qi0, g);
+        }
+        float mx[2];
+        mx[0] = f3_pair_max(f3_rowmax32(Sx[0][0][0], Sx[0][0][1]));
+        mx[1] = f3_pair_max(f3_rowmax32(Sx[0][1][0], Sx[0][1][1]));
+        f3_decide(m_used, mx, scale_log2, nx);
     }
 
 #define F3_ITER(P_)                                                                                                              \
     {                                                                                                                            \
         const int it_ = it + (P_);                                                                                               \
+        F3_STAMP(6);                                                                                                             \
         /* K(it+1) and V(it) have landed; nobody still reads K(it) / V(it-1) */                                                  \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                                       \
-        __builtin_amdgcn_s_barrier();                                                                                            \
+        if (!(F3_ABLATE & 8)) __builtin_amdgcn_s_barrier();                                                                      \
         asm volatile("" ::: "memory");                                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                                                       \
-        if (it_ + 2 < nkv) issue(kh, it_ + 2, lds0 + k_stage(P_));                                                               \
-        if (it_ + 1 < nkv) issue(vh, it_ + 1, lds0 + v_stage((P_) ^ 1));                                                         \
+        F3_STAMP(7);                                                                                                             \
+        if (it_ + 2 < nkv) issue(kh, it_ + 2, std::integral_constant<int, (P_)*2 * AttnFwd3::TILE_BYTES>{});                     \
+        if (it_ + 1 < nkv) issue(vh, it_ + 1, std::integral_constant<int, (((P_) ^ 1) * 2 + 1) * AttnFwd3::TILE_BYTES>{});       \
         else if (ctr && t == 0) nxt = atomicAdd(ctr, 1u);                                                                        \
         if (it_ + 1 < nt_w) {                                                                                                    \
             const bool dn = CAUSAL && (it_ + 1) * KV_TILE + KV_TILE - 1 > qw0;                                                   \
-            f3_tile<CAUSAL, (P_) ^ 1, P_>(Sx[P_], Sx[(P_) ^ 1], m_used, l, mx, fa, scale_log2, lane, dn, tilemask[it_ + 1],       \
-                                          (it_ + 1) * KV_TILE, qi0);                                                             \
+            F3_STAMP(8);                                                                                                         \
+            f3_tile<CAUSAL, (P_) ^ 1, P_>(Sx[P_], Sx[(P_) ^ 1], m_used, l, nx, fa, scale_log2, lane, dn, mask_word(it_ + 1),      \
+                                          (it_ + 1) * KV_TILE, qi0, f3_tr_on, f3_tr_n);                                          \
         } else if (it_ < nt_w) {                                                                                                 \
-            f3_tail<P_>(Sx[P_], m_used, l, mx, fa, scale_log2);                                                                  \
+            f3_tail<P_>(Sx[P_], l, nx, fa, scale_log2);                                                                          \
         }                                                                                                                        \
     }
+    const bool f3_tr_on = (L == 0) && wave == 0;          // (diagnostics builds: the first workgroup's wave 0; item 0 = the heaviest block)
+    int f3_tr_n = 0;
+    F3_STAMP(9);
     for (int it = 0; it < nkv; it += 2) {
         F3_ITER(0)
         if (it + 1 < nkv) F3_ITER(1)
