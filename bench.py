@@ -129,7 +129,15 @@ def cpu_baseline(budget_s=30.0):
     t_vit = time.time() - t0
     n_params = 32 * n_layer + 2 * V * H
     step_s = 32 * (t_layer + t_fwd) + (t_head + t_head_f) + 23 * t_vit + t_adam * n_params / n_layer
-    return dict(value=4.0 / step_s, unit="pairs/s", cores=n_thr, kind="port",
+    # the sample is checked against ONE full 32-layer step of the same oracle on the GPU box's host (tools/cpu_baseline_full_step.py, offline:
+    # ~11 minutes of CPU work, profiles/r04_cpu_baseline_full_step.json)
+    check = None
+    fp = os.path.join(ROOT, "profiles", "r04_cpu_baseline_full_step.json")
+    if os.path.exists(fp):
+        full = json.load(open(fp))
+        check = dict(full_step_s=full["seconds"]["step"], full_step_threads=full["threads"], full_step_pairs_per_s=full["pairs_per_s"],
+                     sample_extrapolation_over_full_step=round(step_s / full["seconds"]["step"], 3), file="profiles/r04_cpu_baseline_full_step.json")
+    return dict(value=4.0 / step_s, unit="pairs/s", cores=n_thr, kind="port", checked_against=check,
                 sample=f"configs[0] shape (4 pairs, T=256, S=831), fp32, {time.time() - t_start:.0f} s of CPU work: one LLaMA-7B decoder layer "
                        f"fwd+bwd {t_layer:.2f} s and reference fwd {t_fwd:.2f} s (x32); lm-head + log-probs over all 8x831 positions "
                        f"fwd+bwd {t_head:.2f} s + reference fwd {t_head_f:.2f} s (x1); one ViT layer on 4 images {t_vit:.2f} s (x23); AdamW on "
