@@ -288,6 +288,31 @@ __device__ __forceinline__ void attn_dma16(const bf16_t* sbase, uint32_t voff, u
 __device__ __forceinline__ void attn_dma4(const float* sbase, uint32_t voff, uint32_t lds_addr) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
 }
+// value of the partner lane l ^ 32 without the LDS crossbar: v_permlane32_swap exchanges lanes 32..63 of its first register with lanes
+// 0..31 of its second; with x in both, one register then holds the lower lane's x everywhere and the other the upper lane's.  Inline asm:
+// hipcc (ROCm 7.2) folds fmaxf(r[0], r[1]) of __builtin_amdgcn_permlane32_swap(u, u) to r[0] (tools/probe_permlane32_swap.hip).  s_nop 1 =
+// the two wait states between a VALU write of an operand and the swap.  VLR_ATTN_SWAP=0 (compile time: ATTN_SWAP) keeps ds_bpermute.
+#ifndef ATTN_SWAP
+#define ATTN_SWAP 1
+#endif
+__device__ __forceinline__ float attn_pair_max(float x) {
+#if ATTN_SWAP
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+#else
+    return fmaxf(x, __shfl_xor(x, 32));
+#endif
+}
+// dS = P (dP - delta) as two scalar VALU instructions: left to hipcc, the SLP vectoriser packs adjacent elements into v_pk_add_f32 /
+// v_pk_mul_f32, which beside MFMAs cost +22..26 cycles per gap (MI355X_MICROARCH.md).  p usually comes straight out of v_exp_f32: the
+// v_sub in front of the v_mul that reads it is the wait state gfx950 needs between a transcendental and a VALU reader (hipcc does not
+// pad asm consumers).
+__device__ __forceinline__ float attn_ds(float p, float dp, float delta) {
+    float d;
+    asm("v_sub_f32 %0, %1, %2\n\tv_mul_f32 %0, %0, %3" : "=&v"(d) : "v"(dp), "v"(delta), "v"(p));
+    return d;
+}
 // key-validity masks of the first nkv KV tiles, one 64-bit word per tile (bit = key is masked or past S).  Wave w takes tiles
 // w, w+4, ...; four tiles' loads are issued before the first ballot (one load latency per four tiles instead of one per tile:
 // this runs before the first MFMA of every workgroup)
@@ -441,7 +466,7 @@ __device__ __forceinline__ unsigned attn_fwd2_block(const bf16_t* __restrict__ q
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = attn_pair_max(mx);
         const float m_new = fmaxf(m, mx * scale_log2);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
         const float alpha = __builtin_amdgcn_exp2f(m - m_use);
@@ -454,8 +479,12 @@ __device__ __forceinline__ unsigned attn_fwd2_block(const bf16_t* __restrict__ q
                 s[kb][r] = pp;
                 rs += pp;
             }
+#if ATTN_SWAP
+        l = l * alpha + rs;            // this lane's 32 of the tile's 64 keys: the lane pair shares m, its sums are added once, after the loop
+#else
         rs += __shfl_xor(rs, 32);
         l = l * alpha + rs;
+#endif
         m = m_new;
         if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {   // the running max moved for some query of this wave
 #pragma unroll
@@ -471,6 +500,9 @@ __device__ __forceinline__ unsigned attn_fwd2_block(const bf16_t* __restrict__ q
                 acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(v_lds, db * 32, ks, lane), pf, acc[db], 0, 0, 0);
         }
     }
+#if ATTN_SWAP
+    l += __shfl_xor(l, 32);
+#endif
     {
         const float inv = l > 0.f ? 1.f / l : 0.f;
         if (ag.epi) {
@@ -856,16 +888,22 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 1) void attn_bwd_dq2_kernel(const
             }
             ATTN_PRIO(0);
             if (need_mask) {
+                // a REAL branch: hipcc if-converted this wave-uniform block into 80 predicated instructions per key block that every
+                // tile executed (v_and / v_cmp_ne_u64 / v_cmp_gt / s_or / v_cndmask per score: a third of the steady-state tile, found in
+                // the round-4 ISA census); an asm statement cannot be speculated.  Only the diagonal tiles and tiles with padded keys come here.
+                asm volatile("" ::: "memory");
+                const uint32_t m32 = (uint32_t)(mk >> (32 * kb)) >> (4 * g);
+                const int thr = qi - k0 - 32 * kb - 4 * g;          // key e (this lane's keys are e + 4 g) is in the query's future iff e > thr
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int kk = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-                    if (((mk >> kk) & 1ull) || (CAUSAL && k0 + kk > qi)) s[r] = -INFINITY;
+                    const int e = (r & 3) + 8 * (r >> 2);
+                    if (((m32 >> e) & 1u) || (CAUSAL && e > thr)) s[r] = -INFINITY;
                 }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float pp = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], scale_log2, -L2));   // masked / L2=+inf -> 0
-                s[r] = pp * (dp[r] - dl);          // x scale: once, on dQ in the epilogue
+                s[r] = attn_ds(pp, dp[r], dl);     // x scale: once, on dQ in the epilogue
             }
             ATTN_PRIO(1);
 #pragma unroll
@@ -885,6 +923,55 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 1) void attn_bwd_dq2_kernel(const
     } else if (qi < S) {
         write_rows<D>(acc, scale, dq + (tok0 + qi) * (size_t)lddq + head * D, g);
     }
+}
+
+// Round 4, dK,dV kernel (one wave per SIMD, 423 registers): two things the 64-query forward kernel (attn_fwd3.h) taught.
+//  * With 512 registers per wave hipcc selects the AGPR form for EVERY v_mfma, so the scores S and dP landed in AGPRs and were read
+//    back one register at a time for the exp / dS arithmetic: 64 v_accvgpr_read per tile.  The S / dP products are inline-asm MFMAs with
+//    VGPR destinations now (dkv_mma_v); dK / dV stay builtin MFMAs (AGPR accumulators, which is where they belong).  hipcc pads no
+//    hazard of an asm statement: the first reader of S / dP (pds) runs four MFMAs after the last one that wrote them (>= 128 cycles;
+//    12 wait states are needed).
+//  * The ~40 lane-derived LDS addresses were recomputed per tile from an opaque copy of the lane id (held across the loop they
+//    spilled): ~110 address instructions per tile.  The swizzle does not depend on the query block / k step / tile, so 16 per-lane
+//    base addresses (8 row-fragment chunks, 4 d blocks x {rows 0-7, rows 8-15} for the transposing reads) + 16 v_add of the stage
+//    offset per tile + immediates cover every fragment (DkvAddr).
+// VLR_ATTN_DKV_ASM=0 (compile time: ATTN_DKV_ASM) keeps the round-3 body for A/B.
+#ifndef ATTN_DKV_ASM
+#define ATTN_DKV_ASM 1
+#endif
+typedef __attribute__((address_space(3))) const bf16x8 attn_lds_bf16x8_t;
+struct DkvAddr {
+    uint32_t row[8];        // byte address of chunk 2 st + (lane >> 5) of row lane & 31 (tile at LDS offset 0)
+    uint32_t tr[4][2];      // transposing reads: d block db, low / high row group, 16-key step 0
+};
+__device__ __forceinline__ void dkv_addr_init(DkvAddr& a, uint32_t lds0, int lane) {
+    const int l31 = lane & 31, g = lane >> 5;
+#pragma unroll
+    for (int st = 0; st < 8; ++st) a.row[st] = lds0 + (uint32_t)tile_off<128>(l31, 2 * st + g);
+    const int q4 = lane >> 4, pq = lane & 15;
+    const int row = 4 * (q4 >> 1) + (pq >> 2);
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+        const int col = db * 32 + 16 * (q4 & 1) + (pq & 3) * 4;
+        const int sub = ((col >> 2) & 1) * 8;
+        a.tr[db][0] = lds0 + (uint32_t)(tile_off<128>(row, col >> 3) + sub);
+        a.tr[db][1] = lds0 + (uint32_t)(tile_off<128>(row + 8, col >> 3) + sub);
+    }
+}
+// 32 x 16 row fragment: rows rb .. rb + 31 (rb = 0 | 32), chunk pair st, of the tile at byte offset `off` behind the bases
+__device__ __forceinline__ bf16x8 dkv_frag_row(const uint32_t (&row)[8], int st, int rb, int off) {
+    return *(attn_lds_bf16x8_t*)(uintptr_t)(row[st] + (uint32_t)(rb * 256 + off));
+}
+__device__ __forceinline__ bf16x8 dkv_frag_tr(const uint32_t (&tr)[4][2], int db, int ks, int off) {
+    const uint32_t o = (uint32_t)(ks * 16 * 256 + off);
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(uintptr_t)(tr[db][0] + o));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(uintptr_t)(tr[db][1] + o));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+template <bool FIRST>
+__device__ __forceinline__ void dkv_mma_v(f32x16& d, const bf16x8& a, const bf16x8& b) {
+    if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
 }
 
 // PIPE: the tile body as fenced half-units so that every LDS fragment is requested two half-units (8 MFMAs, 256 cycles) before
@@ -940,6 +1027,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(const bf16_t* __rest
         kf[st] = *reinterpret_cast<const bf16x8*>(kh + (size_t)krow * ld + 16 * st + 8 * g);
         vf[st] = *reinterpret_cast<const bf16x8*>(vh + (size_t)krow * ld + 16 * st + 8 * g);
     }
+    DkvAddr fa0;
+    dkv_addr_init(fa0, lds0, lane);
     f32x16 adk[4], adv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -967,9 +1056,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(const bf16_t* __rest
                 constexpr bool MASK = decltype(mask_c)::value;
                 // per-tile opaque copy of the lane id: the ~40 lane-derived LDS addresses are recomputed per tile instead of being held
                 // (and spilled) across the loop
+#if ATTN_DKV_ASM
+                const int gl = g;
+                uint32_t arow[8], atr[4][2];         // this tile's fragment bases: the per-lane bases + the stage's offset
+                {
+                    const uint32_t so = (uint32_t)((j & 1) * 2 * TB);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) arow[i] = fa0.row[i] + so;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { atr[i][0] = fa0.tr[i][0] + so; atr[i][1] = fa0.tr[i][1] + so; }
+                }
+#else
                 int ln = lane;
                 asm volatile("" : "+v"(ln));
                 const int gl = ln >> 5;
+#endif
                 // sixteen half-units of 4 MFMAs, each fed by 4 LDS fragments (16 registers) requested AHEAD half-units earlier:
                 //   x = 0..7   S / dP:  qb = x >> 2, k-slots {2 (x & 3), 2 (x & 3) + 1}
                 //   x = 8..15  dV / dK: qb = (x - 8) >> 2, h = ((x - 8) >> 1) & 1, d blocks {2 (x & 1), 2 (x & 1) + 1}
@@ -987,15 +1088,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(const bf16_t* __rest
                         constexpr int qb = X >> 2;
 #pragma unroll
                         for (int i = 0; i < 2; ++i) {
+#if ATTN_DKV_ASM
+                            u[X][2 * i] = dkv_frag_row(arow, 2 * (X & 3) + i, qb * 32, 0);
+                            u[X][2 * i + 1] = dkv_frag_row(arow, 2 * (X & 3) + i, qb * 32, TB);
+#else
                             u[X][2 * i] = frag_row<D>(q_lds, qb * 32, 2 * (2 * (X & 3) + i), ln);
                             u[X][2 * i + 1] = frag_row<D>(do_lds, qb * 32, 2 * (2 * (X & 3) + i), ln);
+#endif
                         }
                     } else {
                         constexpr int qb = (X - 8) >> 2, h = ((X - 8) >> 1) & 1;
 #pragma unroll
                         for (int i = 0; i < 2; ++i) {
+#if ATTN_DKV_ASM
+                            u[X][2 * i] = dkv_frag_tr(atr, 2 * (X & 1) + i, qb * 2 + h, TB);
+                            u[X][2 * i + 1] = dkv_frag_tr(atr, 2 * (X & 1) + i, qb * 2 + h, 0);
+#else
                             u[X][2 * i] = frag_tr<D>(do_lds, (2 * (X & 1) + i) * 32, qb * 2 + h, ln);
                             u[X][2 * i + 1] = frag_tr<D>(q_lds, (2 * (X & 1) + i) * 32, qb * 2 + h, ln);
+#endif
                         }
                     }
                 };
@@ -1008,6 +1119,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(const bf16_t* __rest
                     constexpr int X = decltype(xc)::value;
                     if constexpr (X < 8) {
                         constexpr int qb = X >> 2;
+#if ATTN_DKV_ASM
+                        dkv_mma_v<(X & 3) == 0>(sc[qb], u[X][0], kf[2 * (X & 3)]);
+                        dkv_mma_v<(X & 3) == 0>(dpc[qb], u[X][1], vf[2 * (X & 3)]);
+                        dkv_mma_v<false>(sc[qb], u[X][2], kf[2 * (X & 3) + 1]);
+                        dkv_mma_v<false>(dpc[qb], u[X][3], vf[2 * (X & 3) + 1]);
+#else
                         if constexpr ((X & 3) == 0) {
 #pragma unroll
                             for (int r = 0; r < 16; ++r) { sc[qb][r] = 0.f; dpc[qb][r] = 0.f; }
@@ -1017,6 +1134,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(const bf16_t* __rest
                             sc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[X][2 * i], kf[2 * (X & 3) + i], sc[qb], 0, 0, 0);
                             dpc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[X][2 * i + 1], vf[2 * (X & 3) + i], dpc[qb], 0, 0, 0);
                         }
+#endif
                     } else {
                         constexpr int qb = (X - 8) >> 2, h = ((X - 8) >> 1) & 1;
 #pragma unroll
@@ -1042,7 +1160,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(const bf16_t* __rest
                         float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[qb][r], scale_log2, -l2v[P][e]));   // l2 = +inf past S -> 0
                         if constexpr (MASK) pv = (bad & (1u << (8 * rq + e))) ? 0.f : pv;
                         pmq[P][e] = pv;
-                        sc[qb][r] = pv * (dpc[qb][r] - dlv[P][e]);   // x scale: once, on dK in the epilogue; delta is finite on padded rows
+                        sc[qb][r] = attn_ds(pv, dpc[qb][r], dlv[P][e]);   // x scale: once, on dK in the epilogue; delta is finite on padded rows
                     }
                     if constexpr (rq & 1) {                  // rows 8h .. 8h+7 done: the bf16 operands of dV / dK (pack_frag order)
                         constexpr int h = rq >> 1;
@@ -1061,11 +1179,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(const bf16_t* __rest
                 auto step = [&](auto xc) {
                     constexpr int X = decltype(xc)::value;
                     if constexpr (X + AHEAD < 16) ldh(std::integral_constant<int, X + AHEAD>{});
+#if ATTN_DKV_ASM
+                    // P / dS slice p rides half-unit p + 5 (one later than with builtin MFMAs): hipcc pads no hazard of the asm S / dP
+                    // products, and inside a half-unit it may order the slice's VALU reads in front of the unit's MFMAs - a whole
+                    // half-unit (4 MFMAs, >= 128 cycles) now lies between the last write of S / dP of a query block and their first
+                    // read, whatever that order.  Deadlines hold: P / dS of (qb, h) are packed in unit 6 + 4 qb + 2 h, read in 8 + 4 qb + 2 h.
+                    if constexpr (X >= 4 && X < 12) ldl(std::integral_constant<int, X - 4>{});
+                    DKV_FENCE();
+                    mmh(xc);
+                    if constexpr (X >= 5 && X < 13) pds(std::integral_constant<int, X - 5>{});
+                    DKV_FENCE();
+#else
                     if constexpr (X + 1 >= 4 && X + 1 < 12) ldl(std::integral_constant<int, X + 1 - 4>{});
                     DKV_FENCE();
                     mmh(xc);
                     if constexpr (X >= 4 && X < 12) pds(std::integral_constant<int, X - 4>{});
                     DKV_FENCE();
+#endif
                 };
                 ldh(std::integral_constant<int, 0>{});
                 if constexpr (AHEAD > 1) ldh(std::integral_constant<int, 1>{});
