@@ -1,6 +1,6 @@
 #!/bin/bash
-# the variant bench lines quoted in DESIGN.md section 6 (one JSON line each): tools/round_variants.sh r03
-tag=${1:-r03}
+# the variant bench lines quoted in DESIGN.md section 6 (one JSON line each): tools/round_variants.sh r04
+tag=${1:-r04}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 mkdir -p gpurun_out
@@ -17,7 +17,6 @@ run internlm_xc2 --model internlm_xc2
 run internlm_xc2_lora --model internlm_xc2 --lora
 run internlm_xc2_t512 --model internlm_xc2 --text_len 512
 run internlm_xc2_t512_lora --model internlm_xc2 --text_len 512 --lora
-VLR_BWD_STREAMS=1 run full_bwd_streams
-VLR_LORA_BITS=0 run lora_hash_masks --lora
-VLR_GEMM128P=0 run full_old128
+VLR_ATTN_FWD3=1 run full_attn_fwd3
+VLR_ATTN_FWD3=1 run llava_next_2x1024_attn_fwd3 --model llava_next --pairs 2
 echo variants done

@@ -471,6 +471,7 @@ __global__ __launch_bounds__(256) void dropout_bits_kernel(uint32_t* __restrict_
 __global__ __launch_bounds__(256) void dropout_bits2_kernel(unsigned char* __restrict__ bits, unsigned char* __restrict__ bits_kt, int rows, int cols,
                                                             uint64_t key, uint32_t thr) {
     __shared__ unsigned char colb[256][8];
+    __shared__ __attribute__((aligned(16))) unsigned char rowb[64][32];       // the block's 64 rows x 256 columns, row-major bits
     const int t = threadIdx.x, j = t >> 5, cb = t & 31;
     const int cblocks = (cols + 255) >> 8;
     const int kt = blockIdx.x / cblocks, c0 = (blockIdx.x % cblocks) * 256;
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(256) void dropout_bits2_kernel(unsigned char* __res
             if (row < rows) {
                 const long g = ((long)row * cols + col) >> 3;
                 const uint32_t keep = dropout_keep8(key, g, thr);
-                if (bits) bits[g] = (unsigned char)keep;
+                rowb[j * 8 + rr][cb] = (unsigned char)keep;
                 x |= (uint64_t)keep << (8 * rr);
             }
         }
@@ -500,6 +501,18 @@ __global__ __launch_bounds__(256) void dropout_bits2_kernel(unsigned char* __res
     __syncthreads();
     if (bits_kt && c0 + t < cols)
         *reinterpret_cast<uint64_t*>(bits_kt + ((long)kt * cols + c0 + t) * 8) = *reinterpret_cast<const uint64_t*>(&colb[t][0]);
+    // row-major bits: 16 bytes per thread (a row of the block = 32 bytes = two stores) instead of one byte per thread and row -
+    // the byte stores made this draw run at 300 GB/s (26 x its HBM floor, profiles/r03_lora_gemm_microbench_llava.txt)
+    if (bits && t < 128) {
+        const int r = t >> 1, h = t & 1;
+        const int row = kt * 64 + r, cbyte = (c0 >> 3) + h * 16;       // byte column inside the row
+        if (row < rows && c0 + h * 128 < cols) {
+            unsigned char* dst = bits + (((long)row * cols) >> 3) + cbyte;
+            const int nb = min(16, ((cols + 7) >> 3) - cbyte);
+            if (nb == 16 && (((uintptr_t)dst) & 15) == 0) *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(&rowb[r][h * 16]);
+            else for (int i = 0; i < nb; ++i) dst[i] = rowb[r][h * 16 + i];
+        }
+    }
 }
 __global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ mask, long n8, uint64_t key, uint32_t thr) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
