@@ -118,7 +118,12 @@ def cpu_baseline(budget_s=30.0):
     t0 = time.time()
     O.adamw_step(Wp, {"w": torch.ones(n_layer)}, st, 1e-6, step=1)
     t_adam = time.time() - t0
-    del Wp, st
+    # (3b) clip_grad_norm_ over one layer's gradients (the full step spends 37 s of its 673 s there: profiles/r04_cpu_baseline_full_step.json)
+    gr = {"w": torch.ones(n_layer)}
+    t0 = time.time()
+    O.clip_grad_norm_(gr, 1.0)
+    t_clip = time.time() - t0
+    del Wp, st, gr
     # (4) one CLIP ViT-L/14-336 layer on the 4 distinct images (the oracle dedupes like the HIP path)
     vcfg = dict(vit_hidden=1024, vit_mlp=4096, vit_layers=2, vit_heads=16, image_size=336, patch_size=14)
     Wv = O.random_weights(dict(vcfg, hidden=8, inter=8, vocab=8, layers=0, heads=1), seed=0)
@@ -128,7 +133,7 @@ def cpu_baseline(budget_s=30.0):
         O.clip_vit_features(px, Wv, vcfg)
     t_vit = time.time() - t0
     n_params = 32 * n_layer + 2 * V * H
-    step_s = 32 * (t_layer + t_fwd) + (t_head + t_head_f) + 23 * t_vit + t_adam * n_params / n_layer
+    step_s = 32 * (t_layer + t_fwd) + (t_head + t_head_f) + 23 * t_vit + (t_adam + t_clip) * n_params / n_layer
     # the sample is checked against ONE full 32-layer step of the same oracle on the GPU box's host (tools/cpu_baseline_full_step.py, offline:
     # ~11 minutes of CPU work, profiles/r04_cpu_baseline_full_step.json)
     check = None
@@ -141,7 +146,7 @@ def cpu_baseline(budget_s=30.0):
                 sample=f"configs[0] shape (4 pairs, T=256, S=831), fp32, {time.time() - t_start:.0f} s of CPU work: one LLaMA-7B decoder layer "
                        f"fwd+bwd {t_layer:.2f} s and reference fwd {t_fwd:.2f} s (x32); lm-head + log-probs over all 8x831 positions "
                        f"fwd+bwd {t_head:.2f} s + reference fwd {t_head_f:.2f} s (x1); one ViT layer on 4 images {t_vit:.2f} s (x23); AdamW on "
-                       f"one layer's {n_layer / 1e6:.0f} M parameters {t_adam:.2f} s (x{n_params / n_layer:.1f}); "
+                       f"one layer's {n_layer / 1e6:.0f} M parameters {t_adam:.2f} s + gradient clipping {t_clip:.2f} s (x{n_params / n_layer:.1f}); "
                        f"extrapolated full step {step_s:.0f} s")
 
 
