@@ -883,8 +883,10 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 1) void attn_bwd_dq2_kernel(const
             ATTN_PRIO(1);
 #pragma unroll
             for (int st = 0; st < 8; ++st) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(k_lds, kb * 32, 2 * st, lane), qf[st], s, 0, 0, 0);
+                // dP first, S last: the asm dS arithmetic below (attn_ds) reads dP without hipcc's MFMA -> VALU hazard padding (it pads
+                // nothing for an asm reader), but it pads the exp's read of S - whose last MFMA now issues AFTER dP's last one
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(v_lds, kb * 32, 2 * st, lane), dof[st], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(k_lds, kb * 32, 2 * st, lane), qf[st], s, 0, 0, 0);
             }
             ATTN_PRIO(0);
             if (need_mask) {
