@@ -370,6 +370,25 @@ int vlr_decoder_layer_bwd_lora_ex(const vlr_llama_cfg* cfg, const vlr_layer_weig
                                   const void* u, const vlr_layer_bwd_ws* ws, void* ws_v, void* ws_xd, uint64_t seed,
                                   const unsigned char* rowmask, const void* x_in, const void* dx_out, void* dx_in, const int* pos,
                                   const int* key_mask, int batch, int S, vlr_stream_t stream);
+/* ---- ABI v7: TWO adapters per linear - peft LoRA (trainable, every row) stacked on PLoRA (frozen base-model weights, image rows only):
+ * what reference scripts/dpo_internlmxc2vl7b.sh trains (--use_lora True over the PLoRA decoder of models/InternLMXC2/build_mlp.py:158-203,
+ * LoraConfig from utils/auto_load.py:559-571).  y = W x + s_l B_l A_l drop_l(x) + [image rows] s_p B_p A_p drop_p(x) is ONE adapter segment
+ * of rank R = lw->r + pw->r in the K loop of the fused projections: u [M][7R], per sub-target [u_lora (r_l) | u_plora (r_p)], and `bc` holds
+ * the groups' row-wise concatenations [B_lora | B_plora] ([n*out][R], vlr_lora_concat_b; rebuilt by the caller when B_lora has moved).  The
+ * two adapters draw independent dropout masks (seed_l + t / seed_p + t, their own mask_bits), both indexed over the full [batch*S][in]
+ * operand; rowmask applies to the PLoRA half.  Backward: gradients for the LoRA pairs only (lg), input gradients through both; ws_v
+ * [M][2R] at least (3R when q, k, v are adapted separately). */
+typedef struct { const void* qkv; const void* o; const void* gu; const void* down; } vlr_lora_bcomb;
+int vlr_lora_concat_b(const void* b1, int r1, const void* b2, int r2, void* out, long rows, vlr_stream_t stream);
+int vlr_decoder_layer_fwd_lora2(const vlr_llama_cfg* cfg, const vlr_layer_weights* w, const vlr_lora_weights* lw,
+                                const vlr_lora_weights* pw, const vlr_lora_bcomb* bc, const vlr_layer_acts* a, void* u,
+                                uint64_t seed_l, uint64_t seed_p, const unsigned char* rowmask, const void* x_in, const int* pos,
+                                const int* key_mask, int batch, int S, vlr_stream_t stream);
+int vlr_decoder_layer_bwd_lora2(const vlr_llama_cfg* cfg, const vlr_layer_weights* w, const vlr_lora_weights* lw,
+                                const vlr_lora_grads* lg, const vlr_lora_weights* pw, const vlr_lora_bcomb* bc, int accumulate,
+                                const vlr_layer_acts* a, const void* u, const vlr_layer_bwd_ws* ws, void* ws_v, uint64_t seed_l,
+                                uint64_t seed_p, const unsigned char* rowmask, const void* x_in, const void* dx_out, void* dx_in,
+                                const int* pos, const int* key_mask, int batch, int S, vlr_stream_t stream);
 /* rows of x [M][ld] (first `cols` columns) whose rowmask byte is 0 are zeroed */
 int vlr_rows_mask(void* x, int ld, int cols, const unsigned char* rowmask, int M, vlr_stream_t stream);
 /* counter-based dropout: out = mask * x * alpha / (1-p)  (add != 0: out += ...); the mask is a pure function of

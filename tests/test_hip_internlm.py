@@ -126,13 +126,17 @@ def test_internlm_plora_dropout_step_matches_oracle():
     assert err < 0.15 and effect > 5 * err, (err, effect)
 
 
-@pytest.mark.parametrize("dropout", [0.0, 0.25])
-def test_internlm_lora_step_matches_oracle(dropout):
+@pytest.mark.parametrize("dropout,plora_dropout,fused", [(0.0, 0.0, 1), (0.25, 0.0, 1), (0.25, 0.5, 1), (0.25, 0.0, 0)])
+def test_internlm_lora_step_matches_oracle(dropout, plora_dropout, fused, monkeypatch):
     """scripts/dpo_internlmxc2vl7b.sh: peft LoRA on the five PLoRA linears (one adapter over the fused wqkv, lora_B rows in the
-    checkpoint's per-K/V-head order), base + PLoRA frozen but active, reference = adapters disabled"""
+    checkpoint's per-K/V-head order), base + PLoRA frozen but active, reference = adapters disabled.  fused = 1: the two-adapter C
+    layer passes (vlr_decoder_layer_fwd_lora2 / bwd_lora2, fp32 residual stream), with lora_dropout and with PLoRA's own dropout on the
+    image rows under it; fused = 0: the layer composed from bf16 primitives (VLR_ILM_LORA_FUSED=0), the cross-check."""
+    monkeypatch.setenv("VLR_ILM_LORA_FUSED", str(fused))
     pc = dict(r=8, lora_alpha=8, lora_dropout=dropout, target_modules="auto", bias="none", seed=5)
-    z, cfg, W, W_ref, batch, model, ref, tr = build(lora=pc, plora_dropout=0.0)
+    z, cfg, W, W_ref, batch, model, ref, tr = build(lora=pc, plora_dropout=plora_dropout)
     assert tr.ref_model is None and tr.is_peft_model
+    assert model.engine.lora_fused == bool(fused) and model.engine.resid_f32 == bool(fused)
     lora = IL.random_lora(cfg, r=8, alpha=8, seed=3, b_std=0.05, dropout=dropout)
     lora["W"] = {k: v.bfloat16().float() for k, v in lora["W"].items()}
     eng = model.engine
@@ -141,11 +145,31 @@ def test_internlm_lora_step_matches_oracle(dropout):
     assert len(names) == 2 * 5 * cfg["layers"] and all(".lora_" in n for n in names)
     base_before = eng.policy.flat.clone()
     eng.init_optimizer()
+    calls0 = eng._plora_calls
     loss = tr.training_step(model, batch)
     torch.cuda.synchronize()
     lora["seed"] = (5 << 40) + (eng._lora_calls << 16)
     Wl = {k: v.clone().requires_grad_(True) for k, v in lora["W"].items()}
-    l16, _ = IL.compute_loss(W, W, cfg, batch, cfg["beta"], emulate_bf16=True, lora=dict(lora, W=Wl))
+    from vlrlhf.engine_internlm import PLORA_SEED_XOR
+    pl = None
+    if plora_dropout > 0:                       # the seed of the policy pass (the adapters-off reference pass is a forward of the same engine)
+        assert eng.last_train_plora_seed in [((eng.plora_seed << 40) + ((calls0 + i) << 16)) ^ PLORA_SEED_XOR for i in (1, 2)]
+        pl = dict(seed=eng.last_train_plora_seed, p=plora_dropout, index="full")
+    l16, a16 = IL.compute_loss(W, W, cfg, batch, cfg["beta"], emulate_bf16=O.HIP_ROUNDING if fused else True, lora=dict(lora, W=Wl), plora=pl)
+    m = tr._stored_metrics["train"]
+    hip_lp = torch.tensor([float(m["logps/chosen"][-1]), float(m["logps/rejected"][-1])])
+    with_mask = torch.tensor([float(a16["pc"].mean()), float(a16["pr"].mean())])
+    err = float((hip_lp - with_mask).abs().max())
+    print(f"lora {dropout} plora {plora_dropout} fused {fused}: loss hip {float(loss):.6f} oracle {float(l16):.6f}; mean policy log-probs hip "
+          f"{hip_lp.tolist()} oracle {with_mask.tolist()}")
+    assert err < 0.15, err
+    if pl is not None:                          # and the PLoRA mask is a visible part of the answer (judged on the log-probs, as above)
+        with torch.no_grad():
+            l_nd, a_nd = IL.compute_loss(W, W, cfg, batch, cfg["beta"], emulate_bf16=O.HIP_ROUNDING, lora=dict(lora, W=lora["W"]))
+        without = torch.tensor([float(a_nd["pc"].mean()), float(a_nd["pr"].mean())])
+        effect = float((with_mask - without).abs().min())
+        print(f"    without the PLoRA mask: loss {float(l_nd):.6f} log-probs {without.tolist()}")
+        assert effect > 3 * err, (err, effect)
     assert abs(float(loss) - float(l16)) < TOL_LOSS_BF16 + 2e-3, (float(loss), float(l16))
     l16.backward()
     # adapter gradients under checkpoint names / row order

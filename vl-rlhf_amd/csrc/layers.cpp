@@ -216,14 +216,21 @@ extern "C" int vlr_decoder_layer_bwd(const vlr_llama_cfg* cfg, const vlr_layer_w
 // u_t = s * dropout_t(x) A_t^T for the n sub-targets of a group (the B half rides the K loop of the base GEMM: vlr_gemm_*_lora)
 // bits != NULL (vlr_lora_weights::mask_bits): the packed keep masks of the n targets are DRAWN here (target t at bits + t * M * in / 8) and
 // read by the staged-operand mask of the grouped launch - and again by the backward (lora_group_bwd)
+// ustride (0 = r): elements between the u blocks of consecutive sub-targets - the two-adapter layout [u_lora | u_plora] per sub-target
 static int lora_group_a(int n, int r, int in, const void* x, int ldx, const void* A, void* u, int ldu, float scale, float p,
                         uint64_t seed, void* ws_xd, int M, hipStream_t st, const unsigned char* rowmask = nullptr, unsigned char* bits = nullptr,
-                        unsigned char* bits_kt = nullptr) {
+                        unsigned char* bits_kt = nullptr, int ustride = 0) {
     (void)ws_xd;
+    if (ustride == 0) ustride = r;
     struct MaskAfter {       // PLoRA: the adapter acts on the image rows only - zero the other rows of u on the way out
-        void* u; int ldu, cols, M; const unsigned char* rm; hipStream_t st;
-        int run() const { return rm ? vlr_rows_mask(u, ldu, cols, rm, M, st) : VLR_OK; }
-    } after = {u, ldu, n * r, M, rowmask, st};
+        void* u; int ldu, n, r, us, M; const unsigned char* rm; hipStream_t st;
+        int run() const {
+            if (!rm) return VLR_OK;
+            if (us == r) return vlr_rows_mask(u, ldu, n * r, rm, M, st);
+            for (int t = 0; t < n; ++t) { const int e = vlr_rows_mask((char*)u + (size_t)t * us * 2, ldu, r, rm, M, st); if (e) return e; }
+            return VLR_OK;
+        }
+    } after = {u, ldu, n, r, ustride, M, rowmask, st};
     if (p > 0.f) {
         // ONE grouped launch for the n sub-targets: target t = group t reads the SAME x with its own keep mask (vlr_dropout(seed + t),
         // zeroed while the operand is staged - drop(x) is never written) against its own A_t; 1 / (1 - p) rides in alpha
@@ -235,10 +242,12 @@ static int lora_group_a(int n, int r, int in, const void* x, int ldx, const void
             for (int t = 0; t < n; ++t)
                 CHECK(vlr_dropout_bits2(bits + (size_t)t * gstride, bits_kt ? bits_kt + (size_t)t * tstride : nullptr, M, in, p, seed + t, st));
         }
-        CHECK(vlr_gemm_grouped_bits(0, x, A, u, M, r, in, ldx, in, ldu, n, 0L, (long)r * in, (long)r, scale / (1.f - p), 0, 1, seed, p, in, bits,
+        CHECK(vlr_gemm_grouped_bits(0, x, A, u, M, r, in, ldx, in, ldu, n, 0L, (long)r * in, (long)ustride, scale / (1.f - p), 0, 1, seed, p, in, bits,
                                     gstride, st));
-    } else {
+    } else if (ustride == r) {
         CHECK(vlr_gemm_bf16_scaled(0, x, A, u, nullptr, nullptr, M, n * r, in, ldx, in, ldu, 0, 0, 0, 0, scale, st));
+    } else {
+        CHECK(vlr_gemm_grouped(0, x, A, u, M, r, in, ldx, in, ldu, n, 0L, (long)r * in, (long)ustride, scale, 0, 0, 0, 0.f, 0, st));
     }
     return after.run();
 }
@@ -412,6 +421,181 @@ extern "C" int vlr_decoder_layer_bwd_lora_ex(const vlr_llama_cfg* cfg, const vlr
     CHECK(lora_group_bwd(nq, r, H, nq == 1 ? o_all : o_qkv, a->xn1, ws->dqkv, N, lw->a_qkv, lw->b_qkv, lg->a_qkv, lg->b_qkv, u, ldu, ws_v, ws->dxn,
                          sc, p, seed + 0, ws_xd, accumulate, M, st, 0, rowmask, MB(0), MT(0)));
     CHECK(norm_bwd(cfg->resid_f32, ws->dxn, x_in, w->ln1, a->rstd1, ws->dx_mid, dx_in, g ? g->ln1 : nullptr, g ? accumulate : 0, ws->norm_ws, M, H, st));
+    return VLR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// TWO adapters per linear: peft LoRA (trainable, every row) stacked on PLoRA (base-model weights, frozen here, image rows only) - the
+// configuration reference scripts/dpo_internlmxc2vl7b.sh ships (--use_lora True over the PLoRA decoder of
+// models/InternLMXC2/build_mlp.py:158-203; LoraConfig from utils/auto_load.py:559-571).
+//   y = W x + s_l B_l A_l drop_l(x) + [image rows] s_p B_p A_p drop_p(x)  =  [x | u_l | u_p] . [W | B_l | B_p]^T
+// i.e. ONE adapter segment of rank R = r_l + r_p in the K loop of the fused projections: per sub-target the u block is [u_lora | u_plora]
+// (u [M][7R]) and the B operand is the row-wise concatenation [B_lora | B_plora] (vlr_lora_concat_b, built by the caller once per
+// optimizer step: B_plora is frozen, B_lora moves).  Dropout: the two adapters draw independent masks (their own seed and packed-mask
+// buffer), both indexed over the full [M][in] operand.  Backward: v = dy . [B_l | B_p] in one grouped product; the LoRA half feeds
+// dA_l / dB_l and its input-gradient term, the PLoRA half (text rows zeroed) only its input-gradient term.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lora_concat_b_kernel(const bf16_t* __restrict__ b1, int r1, const bf16_t* __restrict__ b2, int r2,
+                                                            bf16_t* __restrict__ out, long rows) {
+    const int R = r1 + r2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows * R; i += (long)gridDim.x * 256) {
+        const long row = i / R;
+        const int c = (int)(i % R);
+        out[i] = c < r1 ? b1[row * r1 + c] : b2[row * r2 + (c - r1)];
+    }
+}
+extern "C" int vlr_lora_concat_b(const void* b1, int r1, const void* b2, int r2, void* out, long rows, vlr_stream_t st) {
+    VLR_REQUIRE(b1 && b2 && out && r1 > 0 && r2 > 0 && rows > 0, "vlr_lora_concat_b: bad arguments");
+    long blocks = (rows * (r1 + r2) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(lora_concat_b_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)st, (const bf16_t*)b1, r1, (const bf16_t*)b2, r2,
+                       (bf16_t*)out, rows);
+    return vlr_check_launch("vlr_lora_concat_b");
+}
+
+struct Lora2Side {          // one adapter's view of a group
+    int r; float scale, p; uint64_t seed; const void* A; void* dA; void* dB; const unsigned char* bits; const unsigned char* bits_kt;
+};
+// dx [M][in] already holds dy W.  L: the trainable adapter (dA / dB written), P: the frozen row-masked one (dA = dB = NULL).
+static int lora2_group_bwd(int n, int in, const int* outs, const void* x, const void* dy, int lddy, const Lora2Side& L, const Lora2Side& P,
+                           const void* Bcomb, const void* u, int ldu, void* v, void* dx, int accumulate, int M, const unsigned char* rowmask,
+                           hipStream_t st) {
+    const int R = L.r + P.r, nR = n * R;
+    const long gstride = (long)M * in / 8;
+    size_t ofs[4] = {0, 0, 0, 0};
+    bool same = true;
+    for (int t = 0; t < n; ++t) { ofs[t + 1] = ofs[t] + (size_t)outs[t]; same = same && outs[t] == outs[0]; }
+    const int ng = same ? 1 : n, gs = same ? n : 1;
+    for (int g = 0; g < ng; ++g) {
+        const int out = outs[g];
+        // v_t = dy_t [B_l | B_p]_t  ([M][R] per sub-target, sub-targets R apart)
+        CHECK(vlr_gemm_grouped(1, off(dy, ofs[g]), off(Bcomb, ofs[g] * R), off(v, (size_t)g * R), M, R, out, lddy, R, nR, gs, (long)out,
+                               (long)out * R, (long)R, 1.f, 0, 0, 0, 0.f, 0, st));
+        // dB_l,t = dy_t^T u_l,t   (u is stored scaled; the LoRA block is the first r_l columns of the sub-target's u block)
+        CHECK(vlr_gemm_grouped(2, off(dy, ofs[g]), off(u, (size_t)g * R), off(L.dB, ofs[g] * L.r), out, L.r, M, lddy, ldu, L.r, gs, (long)out,
+                               (long)R, (long)out * L.r, 1.f, accumulate, 0, 0, 0.f, 0, st));
+    }
+    if (rowmask)
+        for (int t = 0; t < n; ++t) CHECK(vlr_rows_mask(off(v, (size_t)t * R + L.r), nR, P.r, rowmask, M, st));      // no gradient through PLoRA on the text rows
+    for (int side = 0; side < 2; ++side) {
+        const Lora2Side& a = side == 0 ? L : P;
+        const size_t c0 = side == 0 ? 0 : (size_t)L.r;                 // column of this adapter's block inside a sub-target's [R]
+        for (int t = 0; t < n; ++t) {
+            const void* vt = off(v, (size_t)t * R + c0);
+            const void* At = off(a.A, (size_t)t * a.r * in);
+            if (a.p > 0.f) {
+                const unsigned char* bt = a.bits ? a.bits + (size_t)t * gstride : nullptr;
+                if (a.dA) {
+                    if (a.bits_kt) CHECK(vlr_gemm_grouped_bits(2, vt, x, off(a.dA, (size_t)t * a.r * in), a.r, in, M, nR, in, in, 1, 0L, 0L, 0L,
+                                                               a.scale / (1.f - a.p), accumulate, 3, a.seed + t, a.p, in,
+                                                               a.bits_kt + (size_t)t * vlr_dropout_bits_kt_bytes(M, in), 0L, st));
+                    else CHECK(vlr_gemm_grouped_bits(2, vt, x, off(a.dA, (size_t)t * a.r * in), a.r, in, M, nR, in, in, 1, 0L, 0L, 0L,
+                                                     a.scale / (1.f - a.p), accumulate, 2, a.seed + t, a.p, in, bt, 0L, st));
+                }
+                CHECK(vlr_gemm_dropout_acc_multi_bits(1, vt, nR, At, dx, M, in, a.r, a.p, a.seed + t, a.scale, 1, bt, gstride, st));
+            } else {
+                if (a.dA) CHECK(vlr_gemm_bf16_scaled(2, vt, x, off(a.dA, (size_t)t * a.r * in), nullptr, nullptr, a.r, in, M, nR, in, in, 0, 0,
+                                                     accumulate, 0, a.scale, st));
+                CHECK(vlr_gemm_bf16_scaled(1, vt, At, dx, nullptr, nullptr, M, in, a.r, nR, in, in, 0, 0, 1, 0, a.scale, st));
+            }
+        }
+    }
+    return VLR_OK;
+}
+
+static int lora2_check(const char* who, const vlr_lora_weights* lw, const vlr_lora_weights* pw, const vlr_lora_bcomb* bc) {
+    CHECK(lora_check(who, lw, nullptr));
+    CHECK(lora_check(who, pw, nullptr));
+    VLR_REQUIRE(bc && bc->qkv && bc->o && bc->gu, "%s: null concatenated B", who);
+    VLR_REQUIRE((lw->qkv_targets == 1) == (pw->qkv_targets == 1), "%s: the two adapters must split the qkv projection the same way", who);
+    VLR_REQUIRE(!lw->a_down == !pw->a_down && (!lw->a_down || bc->down), "%s: down-projection adapters must be both present or both absent", who);
+    return VLR_OK;
+}
+#define MB2(w_, t) ((w_)->mask_bits && (w_)->dropout > 0.f ? (unsigned char*)(w_)->mask_bits + (size_t)(t) * ((size_t)M * H / 8) : nullptr)
+#define MT2(w_, t) ((w_)->mask_bits && (w_)->dropout > 0.f ? (unsigned char*)(w_)->mask_bits + lora_rowmajor_bytes(H, I, M) + (size_t)(t) * (size_t)vlr_dropout_bits_kt_bytes(M, H) : nullptr)
+
+extern "C" int vlr_decoder_layer_fwd_lora2(const vlr_llama_cfg* cfg, const vlr_layer_weights* w, const vlr_lora_weights* lw,
+                                           const vlr_lora_weights* pw, const vlr_lora_bcomb* bc, const vlr_layer_acts* a, void* u,
+                                           uint64_t seed_l, uint64_t seed_p, const unsigned char* rowmask, const void* x_in, const int* pos,
+                                           const int* key_mask, int batch, int S, vlr_stream_t st) {
+    VLR_REQUIRE(cfg && w && lw && pw && a && u && x_in && pos, "vlr_decoder_layer_fwd_lora2: null argument");
+    CHECK(lora2_check("vlr_decoder_layer_fwd_lora2", lw, pw, bc));
+    const int H = cfg->hidden, I = cfg->inter, M = batch * S, rl = lw->r, rp = pw->r, R = rl + rp, ldu = 7 * R;
+    const int kvh = cfg->kv_heads > 0 ? cfg->kv_heads : cfg->heads;
+    const int Nq = cfg->heads * cfg->head_dim, Nkv = kvh * cfg->head_dim, N = Nq + 2 * Nkv;
+    VLR_REQUIRE(Nq == H, "vlr_decoder_layer_fwd_lora2: heads*head_dim != hidden");
+    const int rf = cfg->resid_f32;
+    const int nq = lw->qkv_targets == 1 ? 1 : 3;
+    // group g of the layer: u columns [c, c + n R); LoRA block first, PLoRA block behind it (row-masked)
+    auto both = [&](int n, int in, const void* x, const void* Al, const void* Ap, size_t c, int t0) -> int {
+        CHECK(lora_group_a(n, rl, in, x, in, Al, off(u, c), ldu, lw->scale, lw->dropout, seed_l + t0, nullptr, M, st, nullptr, MB2(lw, t0), MT2(lw, t0), R));
+        CHECK(lora_group_a(n, rp, in, x, in, Ap, off(u, c + rl), ldu, pw->scale, pw->dropout, seed_p + t0, nullptr, M, st, rowmask, MB2(pw, t0), MT2(pw, t0), R));
+        return VLR_OK;
+    };
+    CHECK(norm_fwd(rf, x_in, w->ln1, a->xn1, a->rstd1, M, H, cfg->rms_eps, st));
+    CHECK(both(nq, H, a->xn1, lw->a_qkv, pw->a_qkv, 0, 0));
+    CHECK(vlr_gemm_qkv_rope_lora(a->xn1, w->wqkv, w->bqkv, a->qkv, pos, cfg->rope_cos, cfg->rope_sin, M, N, Nq + Nkv, H, H,
+                                 cfg->head_dim, cfg->max_pos, u, ldu, bc->qkv, R, nq == 1 ? N : Nq, nq == 1 ? 0 : Nkv, st));
+    CHECK(vlr_attn_fwd_gqa(a->qkv, off(a->qkv, Nq), off(a->qkv, (size_t)Nq + Nkv), N, a->attn, Nq, a->lse, key_mask, batch, S,
+                           cfg->heads, kvh, cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));
+    CHECK(both(1, H, a->attn, lw->a_o, pw->a_o, 3 * (size_t)R, 3));
+    if (rf) CHECK(vlr_gemm_lora_f32res(a->attn, H, w->wo, (float*)a->x_mid, H, (const float*)x_in, H, M, H, H, off(u, 3 * (size_t)R), ldu, bc->o, R, st));
+    else CHECK(vlr_gemm_lora(a->attn, H, w->wo, a->x_mid, H, x_in, H, M, H, H, off(u, 3 * (size_t)R), ldu, bc->o, R, st));
+    CHECK(norm_fwd(rf, a->x_mid, w->ln2, a->xn2, a->rstd2, M, H, cfg->rms_eps, st));
+    CHECK(both(2, H, a->xn2, lw->a_gu, pw->a_gu, 4 * (size_t)R, 4));
+    CHECK(vlr_gemm_swiglu_lora(a->xn2, w->wgu, a->gu, a->act, M, I, H, H, off(u, 4 * (size_t)R), ldu, bc->gu, R, st));
+    if (lw->a_down) {
+        CHECK(both(1, I, a->act, lw->a_down, pw->a_down, 6 * (size_t)R, 6));
+        if (rf) CHECK(vlr_gemm_lora_f32res(a->act, I, w->wdown, (float*)a->x_out, H, (const float*)a->x_mid, H, M, H, I, off(u, 6 * (size_t)R), ldu, bc->down, R, st));
+        else CHECK(vlr_gemm_lora(a->act, I, w->wdown, a->x_out, H, a->x_mid, H, M, H, I, off(u, 6 * (size_t)R), ldu, bc->down, R, st));
+    } else {
+        CHECK(proj_res(rf, a->act, w->wdown, a->x_out, a->x_mid, M, H, I, st));
+    }
+    return VLR_OK;
+}
+
+extern "C" int vlr_decoder_layer_bwd_lora2(const vlr_llama_cfg* cfg, const vlr_layer_weights* w, const vlr_lora_weights* lw,
+                                           const vlr_lora_grads* lg, const vlr_lora_weights* pw, const vlr_lora_bcomb* bc, int accumulate,
+                                           const vlr_layer_acts* a, const void* u, const vlr_layer_bwd_ws* ws, void* ws_v, uint64_t seed_l,
+                                           uint64_t seed_p, const unsigned char* rowmask, const void* x_in, const void* dx_out, void* dx_in,
+                                           const int* pos, const int* key_mask, int batch, int S, vlr_stream_t st) {
+    VLR_REQUIRE(cfg && w && lw && lg && pw && a && u && ws && ws_v && x_in && dx_out && dx_in && pos, "vlr_decoder_layer_bwd_lora2: null argument");
+    CHECK(lora2_check("vlr_decoder_layer_bwd_lora2", lw, pw, bc));
+    const int H = cfg->hidden, I = cfg->inter, M = batch * S, rl = lw->r, rp = pw->r, R = rl + rp, ldu = 7 * R;
+    const int kvh = cfg->kv_heads > 0 ? cfg->kv_heads : cfg->heads;
+    const int Nq = cfg->heads * cfg->head_dim, Nkv = kvh * cfg->head_dim, N = Nq + 2 * Nkv;
+    VLR_REQUIRE(Nq == H, "vlr_decoder_layer_bwd_lora2: heads*head_dim != hidden");
+    const int o_qkv[3] = {Nq, Nkv, Nkv}, o_h[1] = {H}, o_gu[2] = {I, I}, o_all[1] = {N};
+    const int nq = lw->qkv_targets == 1 ? 1 : 3;
+    auto side = [&](const vlr_lora_weights* x_, const void* A, void* dA, void* dB, uint64_t seed, int t0) {
+        return Lora2Side{x_->r, x_->scale, x_->dropout, seed + (uint64_t)t0, A, dA, dB, MB2(x_, t0), MT2(x_, t0)};
+    };
+    // ---- MLP
+    if (lw->a_down) {
+        CHECK(vlr_gemm_bf16(1, dx_out, w->wdown, ws->dact, nullptr, nullptr, M, I, H, H, I, I, 0, 0, 0, 0, st));
+        CHECK(lora2_group_bwd(1, I, o_h, a->act, dx_out, H, side(lw, lw->a_down, lg->a_down, lg->b_down, seed_l, 6),
+                              side(pw, pw->a_down, nullptr, nullptr, seed_p, 6), bc->down, off(u, 6 * (size_t)R), ldu, ws_v, ws->dact, accumulate, M,
+                              rowmask, st));
+        CHECK(vlr_swiglu_bwd(a->gu, ws->dact, M, I, st));   // gu now holds [dgate | dup]
+    } else {
+        CHECK(vlr_gemm_swiglu_bwd(dx_out, w->wdown, a->gu, ws->dact, M, I, H, st));
+    }
+    CHECK(vlr_gemm_bf16(1, a->gu, w->wgu, ws->dxn, nullptr, nullptr, M, H, 2 * I, 2 * I, H, H, 0, 0, 0, 0, st));
+    CHECK(lora2_group_bwd(2, H, o_gu, a->xn2, a->gu, 2 * I, side(lw, lw->a_gu, lg->a_gu, lg->b_gu, seed_l, 4), side(pw, pw->a_gu, nullptr, nullptr, seed_p, 4),
+                          bc->gu, off(u, 4 * (size_t)R), ldu, ws_v, ws->dxn, accumulate, M, rowmask, st));
+    CHECK(norm_bwd(cfg->resid_f32, ws->dxn, a->x_mid, w->ln2, a->rstd2, dx_out, ws->dx_mid, nullptr, 0, ws->norm_ws, M, H, st));
+    // ---- attention
+    CHECK(vlr_gemm_bf16(1, ws->dx_mid, w->wo, ws->dattn, nullptr, nullptr, M, H, H, H, H, H, 0, 0, 0, 0, st));
+    CHECK(lora2_group_bwd(1, H, o_h, a->attn, ws->dx_mid, H, side(lw, lw->a_o, lg->a_o, lg->b_o, seed_l, 3), side(pw, pw->a_o, nullptr, nullptr, seed_p, 3),
+                          bc->o, off(u, 3 * (size_t)R), ldu, ws_v, ws->dattn, accumulate, M, rowmask, st));
+    CHECK(vlr_attn_bwd_gqa(a->qkv, off(a->qkv, Nq), off(a->qkv, (size_t)Nq + Nkv), N, a->attn, ws->dattn, Nq, a->lse, ws->delta,
+                           key_mask, ws->dqkv, off(ws->dqkv, Nq), off(ws->dqkv, (size_t)Nq + Nkv), N, batch, S, cfg->heads, kvh,
+                           cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));
+    CHECK(vlr_rope_heads(ws->dqkv, pos, cfg->rope_cos, cfg->rope_sin, M, cfg->heads + kvh, cfg->head_dim, N, cfg->max_pos, 1, st));
+    CHECK(vlr_gemm_bf16(1, ws->dqkv, w->wqkv, ws->dxn, nullptr, nullptr, M, H, N, N, H, H, 0, 0, 0, 0, st));
+    CHECK(lora2_group_bwd(nq, H, nq == 1 ? o_all : o_qkv, a->xn1, ws->dqkv, N, side(lw, lw->a_qkv, lg->a_qkv, lg->b_qkv, seed_l, 0),
+                          side(pw, pw->a_qkv, nullptr, nullptr, seed_p, 0), bc->qkv, u, ldu, ws_v, ws->dxn, accumulate, M, rowmask, st));
+    CHECK(norm_bwd(cfg->resid_f32, ws->dxn, x_in, w->ln1, a->rstd1, ws->dx_mid, dx_in, nullptr, 0, ws->norm_ws, M, H, st));
     return VLR_OK;
 }
 

@@ -42,6 +42,10 @@ class LoraGrads(C.Structure):
     _fields_ = [(n, P) for n in ("a_qkv", "b_qkv", "a_o", "b_o", "a_gu", "b_gu", "a_down", "b_down")]
 
 
+class LoraBcomb(C.Structure):      # vlr_lora_bcomb: the groups' [B_lora | B_plora] of the two-adapter layer passes (ABI v7)
+    _fields_ = [(n, P) for n in ("qkv", "o", "gu", "down")]
+
+
 class VitCfg(C.Structure):
     _fields_ = [("hidden", I), ("mlp", I), ("heads", I), ("head_dim", I), ("ln_eps", F), ("act", I), ("head_dim_pad", I), ("attn_scale", F)]
 
@@ -124,6 +128,9 @@ _SIGS = {
     "vlr_decoder_layer_bwd_lora": [P, P, P, P, I, P, P, P, P, P, U64, P, P, P, P, P, I, I, P],
     "vlr_decoder_layer_fwd_lora_ex": [P, P, P, P, P, P, U64, P, P, P, P, I, I, P],
     "vlr_decoder_layer_bwd_lora_ex": [P, P, P, P, P, I, P, P, P, P, P, U64, P, P, P, P, P, P, I, I, P],
+    "vlr_lora_concat_b": [P, I, P, I, P, L, P],
+    "vlr_decoder_layer_fwd_lora2": [P, P, P, P, P, P, P, U64, U64, P, P, P, P, I, I, P],
+    "vlr_decoder_layer_bwd_lora2": [P, P, P, P, P, P, I, P, P, P, P, U64, U64, P, P, P, P, P, P, I, I, P],
     "vlr_rows_mask": [P, I, I, P, I, P],
     "vlr_dropout": [P, P, L, F, U64, F, I, P],
     "vlr_dropout_mask": [P, L, F, U64, P],

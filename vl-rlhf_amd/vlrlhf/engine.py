@@ -484,7 +484,7 @@ class LlavaHipEngine:
         if self.master is not None:
             self.init_optimizer()
 
-    def _mask_bits(self, l, M, p, acts=None):
+    def _mask_bits(self, l, M, p, acts=None, key="lora_bits"):
         """packed lora_dropout keep masks of layer l (include/vlr.h vlr_lora_weights::mask_bits): drawn by the layer's forward, read by
         its adapter GEMMs and again by its backward - 57 MB per layer at the 7B shapes.  The buffer lives IN the activation set of the
         pass that drew it (`acts`: per tag and layer, or the one shared set of a checkpointed pass), so a second training-mode forward
@@ -494,11 +494,11 @@ class LlavaHipEngine:
             return None
         n = _hip.helper("vlr_lora_mask_bytes", self.H, self.I, M)
         if acts is None:
-            return self._buf(("lora_bits", l, M), (n,), torch.uint8).data_ptr()
+            return self._buf((key, l, M), (n,), torch.uint8).data_ptr()
         sh = acts.get("shared", acts)
-        t = sh.get("lora_bits")
+        t = sh.get(key)
         if t is None or t.numel() != n:
-            t = sh["lora_bits"] = torch.empty(n, dtype=torch.uint8, device=self.dev)
+            t = sh[key] = torch.empty(n, dtype=torch.uint8, device=self.dev)
         return t.data_ptr()
 
     def _lora_structs(self, l, train, M=None, acts=None):

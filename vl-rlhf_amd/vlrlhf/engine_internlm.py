@@ -16,6 +16,7 @@ needs (a row-masked adapter segment in the GEMM K loop).
 Dropout convention (the reference draws from torch's RNG): target t of layer l masks the compact [R, in] matrix with the counter-based
 mask of vlr_dropout(seed + 8 l + t), t = 0 wqkv, 3 wo, 4 w1, 5 w3, 6 w2; PLoRA and LoRA use different seed bases."""
 import math
+import os
 from typing import Dict
 
 import torch
@@ -68,10 +69,27 @@ class InternLMHipEngine(LlavaHipEngine):
         return e
 
     def enable_lora(self, r, alpha, dropout=0.0, seed=0):
-        """peft LoRA stacked on the frozen PLoRA decoder: that layer is composed from bf16 primitives (rows_add, accumulate GEMMs), so the
-        residual stream goes back to bf16 for this configuration"""
+        """peft LoRA stacked on the frozen PLoRA decoder (the configuration the reference ships for this family).  Default: the C layer
+        passes with TWO adapters per projection (vlr_decoder_layer_fwd_lora2 / bwd_lora2, include/vlr.h) - fused qkv + RoPE / SwiGLU /
+        residual projections, one adapter segment [B_lora | B_plora] in the K loop, fp32 residual stream.  VLR_ILM_LORA_FUSED=0 composes
+        the layer from bf16 primitives instead (rows_add, accumulate GEMMs; bf16 residual stream) - the cross-check of the fused path."""
         super().enable_lora(r, alpha, dropout, seed)
-        self._to_bf16_stream()
+        self.lora_fused = bool(self.fused_forward) and os.environ.get("VLR_ILM_LORA_FUSED", "1") != "0"
+        if not self.lora_fused:
+            self._to_bf16_stream()
+
+    def _bcomb(self, ws, l):
+        """[B_lora | B_plora] of layer l for the four fused projections (vlr_lora_bcomb): rebuilt from the live adapter weights in front
+        of every layer pass (4 copies of 26 MB at the 7B shapes, ~10 us) so an optimizer step or a loaded adapter is never stale"""
+        rl, rp = self.lora["r"], self.plora_r
+        ptrs = []
+        for grp, pk in (("qkv", "pb_qkv"), ("o", "pb_o"), ("gu", "pb_gu"), ("down", "pb_d")):
+            Bl, Bp = self.lv[f"l{l}.b_{grp}"], ws.v[f"l{l}.{pk}"]
+            rows = Bl.shape[0]
+            out = self._buf(("bcomb", grp), (rows, rl + rp))
+            _hip.call("vlr_lora_concat_b", Bl, rl, Bp, rp, out, rows)
+            ptrs.append(out.data_ptr())
+        return _hip.LoraBcomb(*ptrs)
 
     def _to_bf16_stream(self):
         if self.resid_f32:
@@ -86,7 +104,7 @@ class InternLMHipEngine(LlavaHipEngine):
         v = ws.v
         names = ("pa_qkv", "pb_qkv", "pa_o", "pb_o", "pa_gu", "pb_gu", "pa_d", "pb_d")
         w = _hip.LoraWeights(self.plora_r, self.plora_scale, float(p), *(v[f"l{l}.{n}"].data_ptr() for n in names), 1,
-                             self._mask_bits(l, M, float(p), acts) if M else None)
+                             self._mask_bits(l, M, float(p), acts, "plora_bits") if M else None)
         g = _hip.LoraGrads(*(self.gv[f"l{l}.{n}"].data_ptr() for n in names)) if self.gv is not None else None
         return w, g
 
@@ -237,6 +255,8 @@ class InternLMHipEngine(LlavaHipEngine):
         train = self.training and ws is self.policy and bool(e.get("grad_pass", save))     # (a checkpointed forward keeps nothing but is the same pass)
         pseed = e["plora_seed"]
         keep_p = save and self.lora is None          # PLoRA weights are trainable only in a full fine-tune
+        if train and l == 0:
+            self.last_train_plora_seed = pseed       # (tests: the oracle regenerates the pass's masks from it)
         if not use_lora and self.fused_forward:
             # only PLoRA sits on the linears (reference pass; policy pass of a full fine-tune): the C layer pass with the PLoRA pairs as
             # its adapters and the image rows as the row mask - fused qkv + RoPE / SwiGLU / residual projections, fp32 residual stream
@@ -247,6 +267,19 @@ class InternLMHipEngine(LlavaHipEngine):
             pw, _ = self._plora_structs(ws, l, self.plora_p if train else 0.0, M, a)
             _hip.call("vlr_decoder_layer_fwd_lora_ex", self.llama_cfg, self.layer_weights(ws, l), pw, a["struct"], sh["u"], None,
                       pseed + 8 * l, e["img_map"], x, e["pos"], e["mask"], Bn, S)
+            if save:
+                a["pseed"], a["train"] = pseed + 8 * l, train
+            return
+        if use_lora and self.lora_fused:
+            R = self.lora["r"] + self.plora_r
+            sh = a.get("shared", a)
+            if "u2" not in sh or sh["u2"].shape[1] != 7 * R:
+                sh["u2"] = torch.empty(M, 7 * R, dtype=BF16, device=self.dev)
+            lw, _ = self._lora_structs(l, train=True, M=M, acts=a)
+            pw, _ = self._plora_structs(ws, l, self.plora_p if train else 0.0, M, a)
+            bc = self._bcomb(ws, l)
+            _hip.call("vlr_decoder_layer_fwd_lora2", self.llama_cfg, self.layer_weights(ws, l), lw, pw, bc, a["struct"], sh["u2"],
+                      lora_seed + 8 * l, pseed + 8 * l, e["img_map"], x, e["pos"], e["mask"], Bn, S)
             if save:
                 a["pseed"], a["train"] = pseed + 8 * l, train
             return
@@ -314,6 +347,35 @@ class InternLMHipEngine(LlavaHipEngine):
         if self.reducer is not None:
             self.reducer.bucket_ready("tail")
 
+    def _hidden_backward_lora2(self, ctx, dxa, dxb, acc):
+        """peft LoRA over the frozen PLoRA decoder: vlr_decoder_layer_bwd_lora2 per layer - gradients of the LoRA pairs only, dx through the
+        base projections and BOTH adapters (PLoRA on the image rows, its own dropout stream)"""
+        ws = ctx["ws"]
+        Bn, S, M, H, I, N = ctx["Bn"], ctx["S"], ctx["M"], self.H, self.I, self.Nqkv
+        Sp = _align(S, 64)
+        R = self.lora["r"] + self.plora_r
+        wsb = dict(dact=self._buf(("dact", M), (M, I)), dxn=self._buf(("dxn", M), (M, H)), dattn=self._buf(("dattn", M), (M, self.Nq)),
+                   dqkv=self._buf(("dqkv", M), (M, N)), dx_mid=self._buf(("dx_mid", M), (M, H)),
+                   delta=self._buf(("delta", Bn, S), (Bn, self.nh, Sp), torch.float32))
+        lws = _hip.LayerBwdWs(wsb["dact"].data_ptr(), wsb["dxn"].data_ptr(), wsb["dattn"].data_ptr(), wsb["dqkv"].data_ptr(),
+                              wsb["dx_mid"].data_ptr(), wsb["delta"].data_ptr(), self._norm_ws.data_ptr())
+        ws_v = self._buf(("lora2_v", M), (M, 3 * R))
+        e = ctx["embed"]
+        cur, nxt = dxa, dxb
+        for l in range(self.L - 1, -1, -1):
+            a = ctx["acts"][l]
+            x_in = ctx["acts"][l - 1]["x_out"] if l > 0 else ctx["x0"]
+            lw, lg = self._lora_structs(l, train=True, M=M, acts=a)
+            pw, _ = self._plora_structs(ws, l, self.plora_p if a["train"] else 0.0, M, a)
+            bc = self._bcomb(ws, l)
+            sh = a.get("shared", a)
+            _hip.call("vlr_decoder_layer_bwd_lora2", self.llama_cfg, self.layer_weights(ws, l), lw, lg, pw, bc, acc, a["struct"], sh["u2"], lws,
+                      ws_v, ctx["lora_seed"] + 8 * l, a["pseed"], e["img_map"], x_in, cur, nxt, ctx["pos"], ctx["mask"], Bn, S)
+            cur, nxt = nxt, cur
+        self.grad_fresh = False
+        if self.reducer is not None:
+            self.reducer.bucket_ready("lora")
+
     def _hidden_backward_custom(self, ctx, dhidden, dxa, dxb):
         ws = ctx["ws"]
         Bn, S, M, H, I, N = ctx["Bn"], ctx["S"], ctx["M"], self.H, self.I, self.Nqkv
@@ -324,6 +386,8 @@ class InternLMHipEngine(LlavaHipEngine):
         self._norm_bwd(dhidden, ctx["x_last"], ws.v["norm"], ctx["rstd_f"], None, dxa, self.gv["norm"] if full else None, acc if full else 0, M)
         if full and self.fused_forward:
             return self._hidden_backward_full(ctx, dxa, dxb, acc)
+        if not full and self.lora_fused:
+            return self._hidden_backward_lora2(ctx, dxa, dxb, acc)
         dact, dxn = self._buf(("dact", M), (M, I)), self._buf(("dxn", M), (M, H))
         dattn, dqkv = self._buf(("dattn", M), (M, self.Nq)), self._buf(("dqkv", M), (M, N))
         dx_mid = self._buf(("dx_mid", M), (M, H))
