@@ -138,6 +138,18 @@ int vlr_gemm_dropout_acc_bits(const void* v, int ldv, const void* A, void* dx, v
                               uint64_t seed, float scale, const void* bits, vlr_stream_t stream);
 int vlr_gemm_dropout_acc_multi_bits(int n, const void* v, int ldv, const void* A, void* dx, int M, int in, int r, float p, uint64_t seed,
                                     float scale, int accumulate, const void* bits, long bits_gstride, vlr_stream_t stream);
+/*  ..._rows (ABI v7)     : the adapter restricted to a ROW SET (InternLM-XComposer2's PLoRA acts on the image rows only, reference
+ *                          models/InternLMXC2/build_mlp.py:194-202).  rowmask [M] bytes, 1 = the row takes part.
+ *                          vlr_gemm_grouped_bits_rows (layouts 0 / 1, accumulate 0): 128-row output tiles without a marked row are not
+ *                          computed - the caller zeroes the unmarked rows afterwards (vlr_rows_mask), which it does anyway.
+ *                          vlr_gemm_dropout_acc_multi_rows: the caller guarantees zero v rows on the unmarked rows; with accumulate = 1
+ *                          every 64-row slab without a marked row is skipped (dx += 0).  rowmask = NULL: the calls above. */
+int vlr_gemm_grouped_bits_rows(int layout, const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int groups,
+                               long gA, long gB, long gC, float alpha, int accumulate, int mask_on, uint64_t seed, float p_drop,
+                               int mask_ld, const void* mask_bits, long mask_gstride, const unsigned char* rowmask, vlr_stream_t stream);
+int vlr_gemm_dropout_acc_multi_rows(int n, const void* v, int ldv, const void* A, void* dx, int M, int in, int r, float p, uint64_t seed,
+                                    float scale, int accumulate, const void* bits, long bits_gstride, const unsigned char* rowmask,
+                                    vlr_stream_t stream);
 /*  vlr_gemm_swiglu_bwd_add: vlr_gemm_swiglu_bwd with an addend on d act before the SwiGLU backward (d act = dy . wdown + dact_add, bf16
  *                          [M][I]; may be the dact_ws buffer) - the LoRA adapter term of down_proj */
 int vlr_gemm_swiglu_bwd_add(const void* dy, const void* wdown, void* gu_inout, void* dact_ws, const void* dact_add, int M, int I, int H,

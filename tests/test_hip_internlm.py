@@ -249,3 +249,25 @@ def test_internlm_gradient_checkpointing_is_bit_identical():
     assert outs[0][0] == outs[1][0]
     assert torch.equal(outs[0][1], outs[1][1])
     assert float(outs[0][1].float().abs().sum()) > 0
+
+
+def test_internlm_lora_gradient_checkpointing_is_bit_identical():
+    """peft LoRA over PLoRA (both dropouts on) under --gradient_checkpointing: the recompute re-runs vlr_decoder_layer_fwd_lora2 with the
+    pass's two dropout seeds - loss and every adapter gradient bit-identical to the run that keeps the activations"""
+    outs = []
+    for ckpt in (False, True):
+        pc = dict(r=8, lora_alpha=8, lora_dropout=0.25, target_modules="auto", bias="none", seed=5)
+        z, cfg, W, W_ref, batch, model, ref, tr = build(lora=pc, plora_dropout=0.25)
+        lora = IL.random_lora(cfg, r=8, alpha=8, seed=3, b_std=0.05, dropout=0.25)
+        model.engine.load_lora_state_dict({k: v.bfloat16().float() for k, v in lora["W"].items()})
+        assert model.engine.lora_fused and model.engine.resid_f32
+        if ckpt:
+            model.gradient_checkpointing_enable()
+        model.train()
+        loss = tr.training_step(model, batch)
+        torch.cuda.synchronize()
+        assert model._last_ctx["ckpt"] == ckpt
+        outs.append((float(loss), model.engine.lora_grads.clone()))
+    assert outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][1].float().abs().sum()) > 0

@@ -1560,6 +1560,60 @@ def test_dropout_bits_and_masked_gemms_with_bits(hip, M, in_, r, n, p):
     assert torch.equal(a2, a3), "dropout-accumulate, one pass"
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,in_,r,n,p", [(1000, 512, 64, 2, 0.25), (1353, 1024, 256, 1, 0.05)])
+def test_adapter_products_restricted_to_a_row_set(hip, M, in_, r, n, p):
+    """PLoRA acts on the image rows only: the row-set forms (vlr_gemm_grouped_bits_rows, vlr_gemm_dropout_acc_multi_rows) skip the 128-row
+    tiles / 64-row slabs without a marked row and are BIT-IDENTICAL to the dense calls followed by vlr_rows_mask.  The row set has marked
+    runs that start and end inside tiles, whole unmarked tiles (skipped) and a ragged last tile."""
+    from vlrlhf import _hip as HH
+    HH.ensure_splitk_workspace(DEV, force=True)
+    seed, alpha, scale = 7, 2.0 / (1 - p), 2.0
+    rowmask = torch.zeros(M, dtype=torch.uint8, device=DEV)
+    rowmask[70:200] = 1
+    rowmask[640:705] = 1
+    rowmask[M - 3:] = 1
+    gstride = M * in_ // 8
+    bits = torch.zeros(n * gstride, dtype=torch.uint8, device=DEV)
+    for t in range(n):
+        hip.call("vlr_dropout_bits", bits[t * gstride:], M * in_, p, seed + t)
+    x = rnd(M, in_, seed=1)
+    A = rnd(n * r, in_, seed=2, scale=0.05)
+    ldu = n * r
+    poison = lambda: torch.full((M, ldu), float("nan"), dtype=torch.bfloat16, device=DEV)      # noqa: E731  (a skipped tile keeps what was there)
+    u0, u1 = poison(), poison()
+    hip.call("vlr_gemm_grouped_bits", 0, x, A, u0, M, r, in_, in_, in_, ldu, n, 0, r * in_, r, alpha, 0, 1, seed, p, in_, bits, gstride)
+    hip.call("vlr_gemm_grouped_bits_rows", 0, x, A, u1, M, r, in_, in_, in_, ldu, n, 0, r * in_, r, alpha, 0, 1, seed, p, in_, bits, gstride, rowmask)
+    torch.cuda.synchronize()
+    if in_ < 1024:          # (K >= 1024 splits along K: the reduction then writes the skipped tile's rows from untouched partials)
+        assert bool(torch.isnan(u1[256:384].float()).all()), "rows 256..383 hold no marked row: the tile must not have been computed"
+    for u in (u0, u1):
+        hip.call("vlr_rows_mask", u, ldu, ldu, rowmask, M)
+    torch.cuda.synchronize()
+    assert torch.equal(u0, u1) and float(u1.float().abs().sum()) > 0, "u = drop(x) A^T on the row set"
+    # v = dy B (layout 1) on the row set
+    out = 384
+    dy, B = rnd(M, out, seed=5), rnd(out, r, seed=6, scale=0.05)
+    v0 = torch.full((M, r), float("nan"), dtype=torch.bfloat16, device=DEV)
+    v1 = v0.clone()
+    hip.call("vlr_gemm_grouped", 1, dy, B, v0, M, r, out, out, r, r, 1, 0, 0, 0, 1.0, 0, 0, 0, 0.0, 0)
+    hip.call("vlr_gemm_grouped_bits_rows", 1, dy, B, v1, M, r, out, out, r, r, 1, 0, 0, 0, 1.0, 0, 0, 0, 0.0, 0, None, 0, rowmask)
+    for v_ in (v0, v1):
+        hip.call("vlr_rows_mask", v_, r, r, rowmask, M)
+    torch.cuda.synchronize()
+    assert torch.equal(v0, v1) and float(v1.float().abs().sum()) > 0, "v = dy B on the row set"
+    # dx += mask . (v A) with zero v rows outside the row set
+    v = rnd(M, n * r, seed=3, scale=0.5)
+    hip.call("vlr_rows_mask", v, n * r, n * r, rowmask, M)
+    dx0 = rnd(M, in_, seed=4)
+    a0, a1 = dx0.clone(), dx0.clone()
+    hip.call("vlr_gemm_dropout_acc_multi_bits", n, v, n * r, A, a0, M, in_, r, p, seed, scale, 1, bits, gstride)
+    hip.call("vlr_gemm_dropout_acc_multi_rows", n, v, n * r, A, a1, M, in_, r, p, seed, scale, 1, bits, gstride, rowmask)
+    torch.cuda.synchronize()
+    assert torch.equal(a0, a1), "dx += mask . (v A) on the row set"
+    assert torch.equal(a1[rowmask == 0], dx0[rowmask == 0]) and not torch.equal(a1, dx0)
+
+
 # ---------------------------------------------------------------------------------------------------- 128x128 ring kernel, other ring depths
 _RING_PROBE = r"""
 import sys, torch

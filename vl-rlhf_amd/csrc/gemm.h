@@ -89,6 +89,9 @@ struct GemmParams {
     const unsigned char* mask_bits;
     long gMask;
     const unsigned char* drop_bits;
+    // [M] bytes or null (128x128 ring kernel, row-major A only): an output tile whose 128 rows all carry 0 is not computed - the caller
+    // zeroes those rows afterwards (vlr_rows_mask: the text rows of InternLM-XComposer2's PLoRA, 46 % of the rows at 490 x 490 / 1024)
+    const unsigned char* rowskip;
 #ifdef VLR_GEMM_TRACE
     uint32_t* trace;         // diagnostics build only: set by the launchers of gemm256p.hip (vlr_gemm_set_trace), never by callers
     int dephase_p, dephase_ticks, epi_abl;
@@ -115,7 +118,7 @@ bool vlr_gemm128p_try_launch(int layout, const GemmParams& p, dim3 grid, hipStre
 bool vlr_gemm256p_dropacc_try_launch(const GemmParams& p, hipStream_t stream);
 // streaming LoRA input-gradient kernel (lora_dx.hip); false: shape not taken
 bool vlr_lora_dx_try_launch(int n, const void* v, int ldv, const void* A, void* dx, int M, int in, int r, float p_drop, uint64_t seed,
-                            float scale, int accumulate, const void* bits, long bits_gstride, hipStream_t stream);
+                            float scale, int accumulate, const void* bits, long bits_gstride, hipStream_t stream, const unsigned char* rowskip = nullptr);
 bool vlr_gemm256p_seg_try_launch(const GemmParams& p, hipStream_t stream);
 bool vlr_gemm256p_fused_try_launch(const GemmParams& p, hipStream_t stream);
 // two TN problems of equal K (the weight gradients of two linears of one layer) as ONE persistent launch; false: shapes it does not take

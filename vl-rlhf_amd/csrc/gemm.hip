@@ -497,13 +497,14 @@ static GemmParams fused_params(const void* A, const void* B, void* C, int M, int
 // dropped elements of the activation operand while it is staged (keep mask of vlr_dropout(seed + g) over [rows][mask_ld]).
 static int gemm_grouped(int layout, const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int groups,
                         long gA, long gB, long gC, float alpha, int accumulate, int mask_on, uint64_t seed, float p_drop, int mask_ld,
-                        const void* mask_bits, long mask_gstride, hipStream_t stream) {
+                        const void* mask_bits, long mask_gstride, hipStream_t stream, const unsigned char* rowskip = nullptr) {
     VLR_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && groups >= 1 && groups <= 8, "gemm_grouped: bad arguments");
     VLR_REQUIRE(N % 8 == 0 && ldc % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && gC % 4 == 0, "gemm_grouped: alignment (N %d lda %d ldb %d ldc %d)", N, lda, ldb, ldc);
     VLR_REQUIRE(!mask_on || (mask_ld % 8 == 0 && ((mask_on == 1 && layout == 0) || ((mask_on == 2 || mask_on == 3) && layout == 2))), "gemm_grouped: mask on the NT A / TN B operand only");
     VLR_REQUIRE(mask_on != 3 || mask_bits, "gemm_grouped: mask_on 3 needs the K-tile-blocked transposed masks of vlr_dropout_bits2");
     GemmParams p = fused_params(A, B, C, M, N, K, lda, ldb, ldc);
     p.alpha = alpha; p.accumulate = accumulate;
+    p.rowskip = (layout != 2 && !accumulate) ? rowskip : nullptr;      // A row-major: its rows are the output rows
     p.groups = groups; p.gA = gA; p.gB = gB; p.gC = gC;
     p.mask_on = mask_on; p.mask_seed = seed; p.mask_thr = vlr_dropout_thr(p_drop); p.mask_ld = mask_ld;
     p.mask_bits = mask_on ? (const unsigned char*)mask_bits : nullptr; p.gMask = mask_gstride;
@@ -567,6 +568,18 @@ extern "C" int vlr_gemm_grouped_bits(int layout, const void* A, const void* B, v
                         mask_gstride, stream);
 }
 
+// ... and with a row mask [M] (1 = the row takes part): layouts 0 / 1 (A row-major); 128-row output tiles without a marked row are NOT computed, the
+// caller zeroes the unmarked rows afterwards (vlr_rows_mask) - the u GEMMs of InternLM-XComposer2's PLoRA skip the all-text tiles
+extern "C" int vlr_gemm_grouped_bits_rows(int layout, const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                          int groups, long gA, long gB, long gC, float alpha, int accumulate, int mask_on, uint64_t seed,
+                                          float p_drop, int mask_ld, const void* mask_bits, long mask_gstride, const unsigned char* rowmask,
+                                          hipStream_t stream) {
+    VLR_REQUIRE((layout == 0 || layout == 1) && !accumulate, "vlr_gemm_grouped_bits_rows: layout 0 / 1, accumulate 0 only (layout %d accumulate %d)", layout, accumulate);
+    VLR_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "vlr_gemm_grouped_bits_rows: 0 <= p < 1, got %g", (double)p_drop);
+    return gemm_grouped(layout, A, B, C, M, N, K, lda, ldb, ldc, groups, gA, gB, gC, alpha, accumulate, mask_on, seed, p_drop, mask_ld, mask_bits,
+                        mask_gstride, stream, rowmask);
+}
+
 // dx [M][in] (+)= sum over the n targets t of scale / (1 - p) * keep_t . (v_t . A_t): v [M][ldv] holds the n blocks of r columns side by
 // side, A the n stacked [r][in] lora_A matrices, keep_t = the mask of vlr_dropout(seed + t) over [M][in] (p = 0: no mask).  ONE pass
 // over dx whatever n is (the per-target vlr_gemm_dropout_acc makes n).  accumulate = 0 writes dx instead of adding to it.
@@ -578,9 +591,19 @@ extern "C" int vlr_gemm_dropout_acc_multi(int n, const void* v, int ldv, const v
     return vlr_gemm_dropout_acc_multi_bits(n, v, ldv, A, dx, M, in, r, p, seed, scale, accumulate, nullptr, 0, stream);
 }
 // bits != NULL: the packed keep masks of the n targets (vlr_dropout_bits(seed + t), target t at bits + t * bits_gstride bytes)
+extern "C" int vlr_gemm_dropout_acc_multi_rows(int n, const void* v, int ldv, const void* A, void* dx, int M, int in, int r, float p,
+                                               uint64_t seed, float scale, int accumulate, const void* bits, long bits_gstride,
+                                               const unsigned char* rowmask, hipStream_t stream);
 extern "C" int vlr_gemm_dropout_acc_multi_bits(int n, const void* v, int ldv, const void* A, void* dx, int M, int in, int r, float p,
                                                uint64_t seed, float scale, int accumulate, const void* bits, long bits_gstride,
                                                hipStream_t stream) {
+    return vlr_gemm_dropout_acc_multi_rows(n, v, ldv, A, dx, M, in, r, p, seed, scale, accumulate, bits, bits_gstride, nullptr, stream);
+}
+// rowmask [M] (or NULL): the caller guarantees that the v rows of unmarked rows are ZERO (vlr_rows_mask) - with accumulate = 1 the
+// streaming kernel then skips every 64-row slab without a marked row (dx += 0)
+extern "C" int vlr_gemm_dropout_acc_multi_rows(int n, const void* v, int ldv, const void* A, void* dx, int M, int in, int r, float p,
+                                               uint64_t seed, float scale, int accumulate, const void* bits, long bits_gstride,
+                                               const unsigned char* rowmask, hipStream_t stream) {
     VLR_REQUIRE(v && A && dx, "vlr_gemm_dropout_acc_multi: null operand");
     VLR_REQUIRE(n >= 1 && n <= 8 && M > 0 && in > 0 && r > 0 && in % 8 == 0 && r % 8 == 0 && ldv % 8 == 0 && ldv >= n * r,
                 "vlr_gemm_dropout_acc_multi: bad shape n=%d M=%d in=%d r=%d ldv=%d", n, M, in, r, ldv);
@@ -588,7 +611,7 @@ extern "C" int vlr_gemm_dropout_acc_multi_bits(int n, const void* v, int ldv, co
     VLR_REQUIRE(!(((uintptr_t)v | (uintptr_t)A | (uintptr_t)dx) & 15), "vlr_gemm_dropout_acc_multi: 16-byte aligned operands");
     {   // the streaming kernel (lora_dx.hip): v rows in registers, A_t slices through LDS, one read-modify-write of dx
         const int pj = vlr_prof_begin(VLR_K_GEMM_NN, 2.0 * M * in * r * n, stream);
-        const bool took = vlr_lora_dx_try_launch(n, v, ldv, A, dx, M, in, r, p, seed, scale, accumulate, bits, bits_gstride, stream);
+        const bool took = vlr_lora_dx_try_launch(n, v, ldv, A, dx, M, in, r, p, seed, scale, accumulate, bits, bits_gstride, stream, rowmask);
         vlr_prof_end(took ? pj : -1, stream);
         if (took) return vlr_check_launch("vlr_gemm_dropout_acc_multi(streamed)");
     }
@@ -742,7 +765,7 @@ static int gemm_impl_ex(int layout, const void* A, const void* B, void* C, const
     p.sched = 0;
     p.A1 = p.B1 = nullptr; p.C1 = nullptr; p.M1 = p.N1 = p.lda1 = p.ldb1 = p.ldc1 = 0;
     p.groups = 1; p.gA = p.gB = p.gC = 0; p.mask_on = 0; p.mask_seed = 0; p.mask_thr = 0; p.mask_ld = 0;
-    p.mask_bits = nullptr; p.gMask = 0; p.drop_bits = nullptr;
+    p.mask_bits = nullptr; p.gMask = 0; p.drop_bits = nullptr; p.rowskip = nullptr;
     const int pi = vlr_prof_begin(layout, 2.0 * M * N * K, stream);
     // ---- split-K for problems whose output is a handful of tiles but whose reduction is long: the LoRA adapter gradients
     // (TN: dB = dy^T u [out x r], dA = v^T x [r x in], reduction over all tokens) - 32..96 workgroups would leave most CUs idle
@@ -832,7 +855,7 @@ static GemmParams fused_params(const void* A, const void* B, void* C, int M, int
     p.sched = 0;
     p.A1 = p.B1 = nullptr; p.C1 = nullptr; p.M1 = p.N1 = p.lda1 = p.ldb1 = p.ldc1 = 0;
     p.groups = 1; p.gA = p.gB = p.gC = 0; p.mask_on = 0; p.mask_seed = 0; p.mask_thr = 0; p.mask_ld = 0;
-    p.mask_bits = nullptr; p.gMask = 0; p.drop_bits = nullptr;
+    p.mask_bits = nullptr; p.gMask = 0; p.drop_bits = nullptr; p.rowskip = nullptr;
     return p;
 }
 

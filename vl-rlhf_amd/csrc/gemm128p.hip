@@ -113,6 +113,11 @@ __global__ __launch_bounds__(256) void gemm128p_kernel(GemmParams p, const bf16_
     const int gsz = min(tiles_m - first_m, GROUP);
     const int m0 = (first_m + (pid % per_group) % gsz) * QT;
     const int n0 = ((pid % per_group) / gsz) * QT;
+    if (!A_KS && p.rowskip) {      // no marked row in this tile's 128 rows: the caller zeroes them (GemmParams::rowskip)
+        const int r0 = m0 + lane, r1 = m0 + 64 + lane;
+        const bool any = (r0 < p.M && p.rowskip[r0] != 0) || (r1 < p.M && p.rowskip[r1] != 0);
+        if (__ballot(any) == 0) return;
+    }
 
     // ---- per-lane source offsets (bytes) of this wave's four DMA pieces of each operand tile, relative to the K tile's base
     uint32_t offA[4], offB[4];

@@ -242,8 +242,10 @@ static int lora_group_a(int n, int r, int in, const void* x, int ldx, const void
             for (int t = 0; t < n; ++t)
                 CHECK(vlr_dropout_bits2(bits + (size_t)t * gstride, bits_kt ? bits_kt + (size_t)t * tstride : nullptr, M, in, p, seed + t, st));
         }
-        CHECK(vlr_gemm_grouped_bits(0, x, A, u, M, r, in, ldx, in, ldu, n, 0L, (long)r * in, (long)ustride, scale / (1.f - p), 0, 1, seed, p, in, bits,
-                                    gstride, st));
+        if (rowmask) CHECK(vlr_gemm_grouped_bits_rows(0, x, A, u, M, r, in, ldx, in, ldu, n, 0L, (long)r * in, (long)ustride, scale / (1.f - p), 0, 1, seed, p,
+                                                      in, bits, gstride, rowmask, st));      // all-text tiles are skipped; `after` zeroes the text rows
+        else CHECK(vlr_gemm_grouped_bits(0, x, A, u, M, r, in, ldx, in, ldu, n, 0L, (long)r * in, (long)ustride, scale / (1.f - p), 0, 1, seed, p, in, bits,
+                                         gstride, st));
     } else if (ustride == r) {
         CHECK(vlr_gemm_bf16_scaled(0, x, A, u, nullptr, nullptr, M, n * r, in, ldx, in, ldu, 0, 0, 0, 0, scale, st));
     } else {
@@ -270,8 +272,10 @@ static int lora_group_bwd(int n, int r, int in, const int* outs, const void* x, 
         const int out = outs[g];
         CHECK(vlr_gemm_grouped(2, off(dy, ofs[g]), off(u, (size_t)g * r), off(dB, ofs[g] * r), out, r, M, lddy, ldu, r, gs, (long)out, (long)r,
                                (long)out * r, 1.f, accumulate, 0, 0, 0.f, 0, st));                       // u is stored scaled
-        CHECK(vlr_gemm_grouped(1, off(dy, ofs[g]), off(B, ofs[g] * r), off(v, (size_t)g * r), M, r, out, lddy, r, nr, gs, (long)out,
-                               (long)out * r, (long)r, 1.f, 0, 0, 0, 0.f, 0, st));
+        if (rowmask) CHECK(vlr_gemm_grouped_bits_rows(1, off(dy, ofs[g]), off(B, ofs[g] * r), off(v, (size_t)g * r), M, r, out, lddy, r, nr, gs, (long)out,
+                                                      (long)out * r, (long)r, 1.f, 0, 0, 0, 0.f, 0, nullptr, 0L, rowmask, st));
+        else CHECK(vlr_gemm_grouped(1, off(dy, ofs[g]), off(B, ofs[g] * r), off(v, (size_t)g * r), M, r, out, lddy, r, nr, gs, (long)out,
+                                    (long)out * r, (long)r, 1.f, 0, 0, 0, 0.f, 0, st));
     }
     if (rowmask) CHECK(vlr_rows_mask(v, nr, nr, rowmask, M, st));      // PLoRA: no gradient flows through the adapter on the text rows
     if (p > 0.f) {
@@ -286,7 +290,7 @@ static int lora_group_bwd(int n, int r, int in, const int* outs, const void* x, 
         static int multi = -1;
         if (multi < 0) { const char* e = getenv("VLR_LORA_MULTI"); multi = (e && e[0] == '0') ? 0 : 1; }
         if (multi || dx_fresh) {
-            CHECK(vlr_gemm_dropout_acc_multi_bits(n, v, nr, A, dx, M, in, r, p, seed, scale, dx_fresh ? 0 : 1, bits, gstride, st));
+            CHECK(vlr_gemm_dropout_acc_multi_rows(n, v, nr, A, dx, M, in, r, p, seed, scale, dx_fresh ? 0 : 1, bits, gstride, rowmask, st));
         } else {
             VLR_REQUIRE(ws_xd, "lora backward: lora_dropout > 0 needs a scratch buffer [M][in]");
             for (int t = 0; t < n; ++t)
@@ -492,7 +496,7 @@ static int lora2_group_bwd(int n, int in, const int* outs, const void* x, const 
                     else CHECK(vlr_gemm_grouped_bits(2, vt, x, off(a.dA, (size_t)t * a.r * in), a.r, in, M, nR, in, in, 1, 0L, 0L, 0L,
                                                      a.scale / (1.f - a.p), accumulate, 2, a.seed + t, a.p, in, bt, 0L, st));
                 }
-                CHECK(vlr_gemm_dropout_acc_multi_bits(1, vt, nR, At, dx, M, in, a.r, a.p, a.seed + t, a.scale, 1, bt, gstride, st));
+                CHECK(vlr_gemm_dropout_acc_multi_rows(1, vt, nR, At, dx, M, in, a.r, a.p, a.seed + t, a.scale, 1, bt, gstride, side == 1 ? rowmask : nullptr, st));
             } else {
                 if (a.dA) CHECK(vlr_gemm_bf16_scaled(2, vt, x, off(a.dA, (size_t)t * a.r * in), nullptr, nullptr, a.r, in, M, nR, in, in, 0, 0,
                                                      accumulate, 0, a.scale, st));

@@ -38,6 +38,7 @@ struct LoraDxParams {
     uint64_t seed;
     uint32_t thr;
     int ct_per_wg;               // column tiles per workgroup (blockIdx.y walks the ranges)
+    const unsigned char* rowskip; // [M] or null: a 64-row slab whose bytes are all 0 holds zero v rows (PLoRA: text rows) - dx += 0, nothing to do
 };
 
 __device__ __forceinline__ void dx_dma16_s(const char* sbase, uint32_t voff, uint32_t lds_addr) {
@@ -71,6 +72,11 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(LoraDxParams p) {
     const int c_lo = blockIdx.y * p.ct_per_wg;
     const int c_hi = min(tiles_n, c_lo + p.ct_per_wg);
     if (c_lo >= c_hi) return;
+    if (p.rowskip) {              // (accumulate launches only: the host passes it with accumulate = 1)
+        const int row = m0 + lane;
+        const bool any = row < p.M && p.rowskip[row] != 0;
+        if (__ballot(any) == 0) return;
+    }
     const int nunits = (c_hi - c_lo) * NT;
 
     // ---- v rows of this wave as MFMA fragments (lane: row lm of the 16-row tile, k (lane >> 4) * 8 .. + 8 of the slice)
@@ -280,7 +286,7 @@ static bool dx_launch_k(const LoraDxParams& p, int mask, dim3 grid, hipStream_t 
 // dx (+)= scale / (1 - p) * sum_t keep_t . (v_t A_t) on the streaming kernel; false: a shape it does not take (the caller runs the
 // tile kernels of gemm.hip): n <= 3 targets, r in {64, 128, 256}, in % 128 == 0, 16-byte aligned operands.  VLR_LORA_DX=0 disables.
 bool vlr_lora_dx_try_launch(int n, const void* v, int ldv, const void* A, void* dx, int M, int in, int r, float p_drop, uint64_t seed,
-                            float scale, int accumulate, const void* bits, long bits_gstride, hipStream_t stream) {
+                            float scale, int accumulate, const void* bits, long bits_gstride, hipStream_t stream, const unsigned char* rowskip) {
     static int on = -1, wg_per_cu = 4;      // 4 workgroups per CU in the grid (2-4 resident): 196 / 88 / 123 / 255 us for the four groups at the 7B shapes against 222 / 106 / 147 / 303 at 2
     if (on < 0) {
         const char* e = getenv("VLR_LORA_DX");
@@ -294,6 +300,7 @@ bool vlr_lora_dx_try_launch(int n, const void* v, int ldv, const void* A, void* 
     q.v = (const bf16_t*)v; q.ldv = ldv; q.A = (const bf16_t*)A; q.dx = (bf16_t*)dx; q.M = M; q.in = in; q.r = r;
     q.alpha = scale / (1.f - p_drop); q.accumulate = accumulate;
     q.bits = (const unsigned char*)bits; q.gbits = bits_gstride; q.seed = seed; q.thr = vlr_dropout_thr(p_drop);
+    q.rowskip = accumulate ? rowskip : nullptr;
     const int rb = (M + 63) / 64, tiles_n = in / 128;
     int splits = (wg_per_cu * vlr_compute_cus() + rb - 1) / rb;
     if (splits < 1) splits = 1;

@@ -33,8 +33,8 @@ class InternLMHipEngine(LlavaHipEngine):
     vision_prefix = "vit.vision_tower."
 
     @property
-    def supports_ckpt(self):       # the C layer passes (full fine-tune / reference) can be re-run; the Python-composed peft-LoRA layer keeps its activations
-        return self.lora is None and bool(getattr(self, "fused_forward", True))
+    def supports_ckpt(self):       # the C layer passes (full fine-tune / reference / LoRA over PLoRA) can be re-run; the Python-composed peft-LoRA layer keeps its activations
+        return (self.lora is None or bool(getattr(self, "lora_fused", False))) and bool(getattr(self, "fused_forward", True))
 
     def __init__(self, cfg: dict, device="cuda", max_positions: int = 8192):
         c = dict(cfg, family="internlm_xc2")
@@ -365,6 +365,8 @@ class InternLMHipEngine(LlavaHipEngine):
         for l in range(self.L - 1, -1, -1):
             a = ctx["acts"][l]
             x_in = ctx["acts"][l - 1]["x_out"] if l > 0 else ctx["x0"]
+            if ctx["ckpt"]:
+                self._layer_forward(ws, l, a, x_in, e, Bn, S, True, True, ctx["lora_seed"])
             lw, lg = self._lora_structs(l, train=True, M=M, acts=a)
             pw, _ = self._plora_structs(ws, l, self.plora_p if a["train"] else 0.0, M, a)
             bc = self._bcomb(ws, l)
