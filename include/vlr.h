@@ -147,6 +147,14 @@ int vlr_gemm_dropout_acc_multi_bits(int n, const void* v, int ldv, const void* A
 int vlr_gemm_grouped_bits_rows(int layout, const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int groups,
                                long gA, long gB, long gC, float alpha, int accumulate, int mask_on, uint64_t seed, float p_drop,
                                int mask_ld, const void* mask_bits, long mask_gstride, const unsigned char* rowmask, vlr_stream_t stream);
+/*  vlr_rows_tile_list    : out[0] = n, out[1 .. n] = the 64-row tiles of [0, M) with a marked row, ascending (out: M / 64 + 2 ints).
+ *  vlr_gemm_grouped_bits_ktiles (layout 2, C = A^T B over K = token rows, K % 64 == 0): contracts only over the listed K tiles - the
+ *                          caller guarantees that every other row contributes zero (PLoRA's dB = dy^T u, dA = v^T drop(x)).  The list
+ *                          is read on the device; split-K slices cut the LIST, so the summation order differs from the dense call. */
+int vlr_rows_tile_list(const unsigned char* rowmask, int M, int* out, vlr_stream_t stream);
+int vlr_gemm_grouped_bits_ktiles(int layout, const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int groups,
+                                 long gA, long gB, long gC, float alpha, int accumulate, int mask_on, uint64_t seed, float p_drop,
+                                 int mask_ld, const void* mask_bits, long mask_gstride, const int* ktlist, vlr_stream_t stream);
 int vlr_gemm_dropout_acc_multi_rows(int n, const void* v, int ldv, const void* A, void* dx, int M, int in, int r, float p, uint64_t seed,
                                     float scale, int accumulate, const void* bits, long bits_gstride, const unsigned char* rowmask,
                                     vlr_stream_t stream);

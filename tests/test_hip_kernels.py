@@ -1614,6 +1614,65 @@ def test_adapter_products_restricted_to_a_row_set(hip, M, in_, r, n, p):
     assert torch.equal(a1[rowmask == 0], dx0[rowmask == 0]) and not torch.equal(a1, dx0)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,in_,r,out,p", [(1024, 512, 64, 384, 0.25), (4096, 1024, 256, 512, 0.05)])
+def test_adapter_gradient_reductions_over_a_k_tile_list(hip, M, in_, r, out, p):
+    """PLoRA's dB = dy^T u and dA = v^T drop(x) contract over the token rows; u and v are zero outside the image rows, so
+    vlr_gemm_grouped_bits_ktiles reads only the 64-row K tiles of vlr_rows_tile_list.  Same product as the dense call (fp32 accumulation,
+    another split-K partition: compared at rounding level) - and NaN-poisoned operand rows in the unlisted tiles prove they are not read."""
+    from vlrlhf import _hip as HH
+    HH.ensure_splitk_workspace(DEV, force=True)
+    rowmask = torch.zeros(M, dtype=torch.uint8, device=DEV)
+    rowmask[70:200] = 1
+    rowmask[640:705] = 1
+    rowmask[M - 3:] = 1
+    tl = torch.full((M // 64 + 2,), -1, dtype=torch.int32, device=DEV)
+    hip.call("vlr_rows_tile_list", rowmask, M, tl)
+    torch.cuda.synchronize()
+    want = rowmask.view(-1, 64).any(1).nonzero().flatten().to(torch.int32)
+    assert int(tl[0]) == want.numel() and torch.equal(tl[1:1 + want.numel()], want), tl[:8]
+    listed = torch.zeros(M, dtype=torch.bool, device=DEV)
+    listed.view(-1, 64)[want.long()] = True
+    seed, alpha = 11, 2.0 / (1 - p)
+    dy, u = rnd(M, out, seed=1), rnd(M, r, seed=2, scale=0.5)
+    hip.call("vlr_rows_mask", u, r, r, rowmask, M)
+    dB0 = torch.zeros(out, r, dtype=torch.bfloat16, device=DEV)
+    hip.call("vlr_gemm_grouped", 2, dy, u, dB0, out, r, M, out, r, r, 1, 0, 0, 0, 1.0, 0, 0, 0, 0.0, 0)
+    dyp, up = dy.clone(), u.clone()
+    dyp[~listed] = float("nan")
+    up[~listed] = float("nan")
+    dB1 = torch.zeros(out, r, dtype=torch.bfloat16, device=DEV)
+    hip.call("vlr_gemm_grouped_bits_ktiles", 2, dyp, up, dB1, out, r, M, out, r, r, 1, 0, 0, 0, 1.0, 0, 0, 0, 0.0, 0, None, 0, tl)
+    torch.cuda.synchronize()
+    ref = dy.float().t() @ u.float()
+    check(dB1, ref, 8e-3, "dB over the K-tile list")
+    assert float((dB0.float() - dB1.float()).abs().max()) <= 0.01 * float(ref.abs().max())
+    # dA with the K-tile-blocked transposed masks
+    gstride, tstride = M * in_ // 8, HH.helper("vlr_dropout_bits_kt_bytes", M, in_)
+    bits_rm = torch.zeros(gstride, dtype=torch.uint8, device=DEV)
+    bits_kt = torch.zeros(tstride, dtype=torch.uint8, device=DEV)
+    hip.call("vlr_dropout_bits2", bits_rm, bits_kt, M, in_, p, seed)
+    x, v = rnd(M, in_, seed=3), rnd(M, r, seed=4, scale=0.5)
+    hip.call("vlr_rows_mask", v, r, r, rowmask, M)
+    xp, vp = x.clone(), v.clone()
+    xp[~listed] = float("nan")
+    vp[~listed] = float("nan")
+    dA0, dA1 = (torch.zeros(r, in_, dtype=torch.bfloat16, device=DEV) for _ in range(2))
+    hip.call("vlr_gemm_grouped_bits", 2, v, x, dA0, r, in_, M, r, in_, in_, 1, 0, 0, 0, alpha, 0, 3, seed, p, in_, bits_kt, tstride)
+    hip.call("vlr_gemm_grouped_bits_ktiles", 2, vp, xp, dA1, r, in_, M, r, in_, in_, 1, 0, 0, 0, alpha, 0, 3, seed, p, in_, bits_kt, tstride, tl)
+    torch.cuda.synchronize()
+    mk = ((bits_rm.view(-1, 1) >> torch.arange(8, device=DEV, dtype=torch.uint8)) & 1).reshape(M, in_).float()
+    ref = alpha * v.float().t() @ (x.float() * mk)
+    check(dA1, ref, 8e-3, "dA over the K-tile list")
+    assert float((dA0.float() - dA1.float()).abs().max()) <= 0.01 * float(ref.abs().max())
+    # an empty list writes zeros
+    hip.call("vlr_rows_tile_list", torch.zeros(M, dtype=torch.uint8, device=DEV), M, tl)
+    dB1.fill_(1.0)
+    hip.call("vlr_gemm_grouped_bits_ktiles", 2, dyp, up, dB1, out, r, M, out, r, r, 1, 0, 0, 0, 1.0, 0, 0, 0, 0.0, 0, None, 0, tl)
+    torch.cuda.synchronize()
+    assert int(tl[0]) == 0 and float(dB1.float().abs().max()) == 0.0
+
+
 # ---------------------------------------------------------------------------------------------------- 128x128 ring kernel, other ring depths
 _RING_PROBE = r"""
 import sys, torch

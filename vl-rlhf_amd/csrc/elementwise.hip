@@ -882,6 +882,28 @@ __global__ __launch_bounds__(256) void rows_mask_kernel(bf16_t* __restrict__ x, 
     if (mask[row]) return;
     for (int c = threadIdx.x * 8; c < cols; c += 256 * 8) *reinterpret_cast<u32x4*>(x + row * ld + c) = u32x4{0u, 0u, 0u, 0u};
 }
+// out[0] = n, out[1 .. n] = the 64-row tiles of [0, M) that hold a marked row, ascending (one wave: ballot + prefix count per 64 tiles)
+__global__ __launch_bounds__(64) void rows_tile_list_kernel(const unsigned char* __restrict__ mask, int M, int* __restrict__ out) {
+    const int lane = threadIdx.x, nt = (M + 63) / 64;
+    int cnt = 0;
+    for (int c = 0; c < nt; c += 64) {
+        const int t = c + lane;
+        bool any = false;
+        if (t < nt) {
+            const int r1 = min(M, t * 64 + 64);
+            for (int r = t * 64; r < r1; ++r) any = any || mask[r] != 0;
+        }
+        const unsigned long long b = __ballot(any);
+        if (any) out[1 + cnt + __popcll(b & ((1ull << lane) - 1ull))] = t;
+        cnt += __popcll(b);
+    }
+    if (lane == 0) out[0] = cnt;
+}
+extern "C" int vlr_rows_tile_list(const unsigned char* rowmask, int M, int* out, hipStream_t st) {
+    VLR_REQUIRE(rowmask && out && M > 0, "vlr_rows_tile_list: bad arguments");
+    hipLaunchKernelGGL(rows_tile_list_kernel, dim3(1), dim3(64), 0, st, rowmask, M, out);
+    return vlr_check_launch("vlr_rows_tile_list");
+}
 extern "C" int vlr_rows_mask(void* x, int ld, int cols, const unsigned char* rowmask, int M, hipStream_t st) {
     VLR_REQUIRE(x && rowmask && M > 0 && cols > 0 && cols % 8 == 0 && ld % 8 == 0 && ld >= cols, "vlr_rows_mask: bad arguments");
     hipLaunchKernelGGL(rows_mask_kernel, dim3(M), dim3(256), 0, st, (bf16_t*)x, ld, cols, rowmask);

@@ -92,6 +92,10 @@ struct GemmParams {
     // [M] bytes or null (128x128 ring kernel, row-major A only): an output tile whose 128 rows all carry 0 is not computed - the caller
     // zeroes those rows afterwards (vlr_rows_mask: the text rows of InternLM-XComposer2's PLoRA, 46 % of the rows at 490 x 490 / 1024)
     const unsigned char* rowskip;
+    // TN launches of the 128x128 ring kernel (K = token rows, K % 64 == 0): ktlist[0] = n, ktlist[1 .. n] = the K tiles (of 64 rows) to
+    // contract over, ascending - the tiles that hold an image row (vlr_rows_tile_list); every other row of both operands' product is zero
+    // by construction (PLoRA's u / v on the text rows).  The count is read on the device: split-K slices cut the LIST into equal runs.
+    const int* ktlist;
 #ifdef VLR_GEMM_TRACE
     uint32_t* trace;         // diagnostics build only: set by the launchers of gemm256p.hip (vlr_gemm_set_trace), never by callers
     int dephase_p, dephase_ticks, epi_abl;

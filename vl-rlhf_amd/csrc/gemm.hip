@@ -497,7 +497,8 @@ static GemmParams fused_params(const void* A, const void* B, void* C, int M, int
 // dropped elements of the activation operand while it is staged (keep mask of vlr_dropout(seed + g) over [rows][mask_ld]).
 static int gemm_grouped(int layout, const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int groups,
                         long gA, long gB, long gC, float alpha, int accumulate, int mask_on, uint64_t seed, float p_drop, int mask_ld,
-                        const void* mask_bits, long mask_gstride, hipStream_t stream, const unsigned char* rowskip = nullptr) {
+                        const void* mask_bits, long mask_gstride, hipStream_t stream, const unsigned char* rowskip = nullptr,
+                        const int* ktlist = nullptr) {
     VLR_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && groups >= 1 && groups <= 8, "gemm_grouped: bad arguments");
     VLR_REQUIRE(N % 8 == 0 && ldc % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && gC % 4 == 0, "gemm_grouped: alignment (N %d lda %d ldb %d ldc %d)", N, lda, ldb, ldc);
     VLR_REQUIRE(!mask_on || (mask_ld % 8 == 0 && ((mask_on == 1 && layout == 0) || ((mask_on == 2 || mask_on == 3) && layout == 2))), "gemm_grouped: mask on the NT A / TN B operand only");
@@ -505,6 +506,7 @@ static int gemm_grouped(int layout, const void* A, const void* B, void* C, int M
     GemmParams p = fused_params(A, B, C, M, N, K, lda, ldb, ldc);
     p.alpha = alpha; p.accumulate = accumulate;
     p.rowskip = (layout != 2 && !accumulate) ? rowskip : nullptr;      // A row-major: its rows are the output rows
+    p.ktlist = (layout == 2 && K % 64 == 0) ? ktlist : nullptr;        // (only the ring kernel reads it; any other kernel contracts over all of K: same product)
     p.groups = groups; p.gA = gA; p.gB = gB; p.gC = gC;
     p.mask_on = mask_on; p.mask_seed = seed; p.mask_thr = vlr_dropout_thr(p_drop); p.mask_ld = mask_ld;
     p.mask_bits = mask_on ? (const unsigned char*)mask_bits : nullptr; p.gMask = mask_gstride;
@@ -568,6 +570,18 @@ extern "C" int vlr_gemm_grouped_bits(int layout, const void* A, const void* B, v
                         mask_gstride, stream);
 }
 
+// ... layout 2 (C = A^T B, K = token rows) contracting only over the K tiles of `ktlist` (vlr_rows_tile_list: the 64-row tiles that hold a
+// marked row; the caller guarantees that the product of every other row is zero - PLoRA's dB = dy^T u and dA = v^T drop(x), u / v zero on
+// the text rows).  K % 64 != 0 or a kernel other than the 128x128 ring kernel: the list is ignored (same result, all of K read).
+extern "C" int vlr_gemm_grouped_bits_ktiles(int layout, const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                            int groups, long gA, long gB, long gC, float alpha, int accumulate, int mask_on, uint64_t seed,
+                                            float p_drop, int mask_ld, const void* mask_bits, long mask_gstride, const int* ktlist,
+                                            hipStream_t stream) {
+    VLR_REQUIRE(layout == 2, "vlr_gemm_grouped_bits_ktiles: layout 2 only, got %d", layout);
+    VLR_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "vlr_gemm_grouped_bits_ktiles: 0 <= p < 1, got %g", (double)p_drop);
+    return gemm_grouped(layout, A, B, C, M, N, K, lda, ldb, ldc, groups, gA, gB, gC, alpha, accumulate, mask_on, seed, p_drop, mask_ld, mask_bits,
+                        mask_gstride, stream, nullptr, ktlist);
+}
 // ... and with a row mask [M] (1 = the row takes part): layouts 0 / 1 (A row-major); 128-row output tiles without a marked row are NOT computed, the
 // caller zeroes the unmarked rows afterwards (vlr_rows_mask) - the u GEMMs of InternLM-XComposer2's PLoRA skip the all-text tiles
 extern "C" int vlr_gemm_grouped_bits_rows(int layout, const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
@@ -765,7 +779,7 @@ static int gemm_impl_ex(int layout, const void* A, const void* B, void* C, const
     p.sched = 0;
     p.A1 = p.B1 = nullptr; p.C1 = nullptr; p.M1 = p.N1 = p.lda1 = p.ldb1 = p.ldc1 = 0;
     p.groups = 1; p.gA = p.gB = p.gC = 0; p.mask_on = 0; p.mask_seed = 0; p.mask_thr = 0; p.mask_ld = 0;
-    p.mask_bits = nullptr; p.gMask = 0; p.drop_bits = nullptr; p.rowskip = nullptr;
+    p.mask_bits = nullptr; p.gMask = 0; p.drop_bits = nullptr; p.rowskip = nullptr; p.ktlist = nullptr;
     const int pi = vlr_prof_begin(layout, 2.0 * M * N * K, stream);
     // ---- split-K for problems whose output is a handful of tiles but whose reduction is long: the LoRA adapter gradients
     // (TN: dB = dy^T u [out x r], dA = v^T x [r x in], reduction over all tokens) - 32..96 workgroups would leave most CUs idle
@@ -855,7 +869,7 @@ static GemmParams fused_params(const void* A, const void* B, void* C, int M, int
     p.sched = 0;
     p.A1 = p.B1 = nullptr; p.C1 = nullptr; p.M1 = p.N1 = p.lda1 = p.ldb1 = p.ldc1 = 0;
     p.groups = 1; p.gA = p.gB = p.gC = 0; p.mask_on = 0; p.mask_seed = 0; p.mask_thr = 0; p.mask_ld = 0;
-    p.mask_bits = nullptr; p.gMask = 0; p.drop_bits = nullptr; p.rowskip = nullptr;
+    p.mask_bits = nullptr; p.gMask = 0; p.drop_bits = nullptr; p.rowskip = nullptr; p.ktlist = nullptr;
     return p;
 }
 

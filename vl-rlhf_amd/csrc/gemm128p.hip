@@ -89,12 +89,29 @@ __global__ __launch_bounds__(256) void gemm128p_kernel(GemmParams p, const bf16_
         if (MASK) p.mask_bits += (size_t)g * p.gMask;
     }
     int kabs0 = 0;                 // split-K slices move p.A: the mask index needs the absolute k
+    // TN with a K-tile list (GemmParams::ktlist): the K loop walks list entries [kt0, kt0 + K / 64) instead of consecutive tiles
+    const int* ktl = nullptr;
+    int kt0 = 0;
+    if constexpr (A_KS && B_KS) ktl = p.ktlist;
+    if (ktl) {
+        const int nall = ktl[0];
+        int n = nall;
+        if (p.splitk > 1) {
+            const int per = (nall + p.splitk - 1) / p.splitk;
+            kt0 = (int)blockIdx.y * per;
+            n = min(per, nall - kt0);
+            n = n > 0 ? n : 0;      // (an empty slice still writes its zero partial)
+        }
+        p.K = n * QK;
+    }
     if (p.splitk > 1) {            // split-K slice z: raw alpha * acc -> its own fp32 partial
         const int z = blockIdx.y, k0 = z * p.kchunk;
-        kabs0 = k0;
-        p.A += A_KS ? (size_t)k0 * p.lda : (size_t)k0;
-        p.B += B_KS ? (size_t)k0 * p.ldb : (size_t)k0;
-        p.K = min(p.kchunk, p.K - k0);
+        if (!ktl) {
+            kabs0 = k0;
+            p.A += A_KS ? (size_t)k0 * p.lda : (size_t)k0;
+            p.B += B_KS ? (size_t)k0 * p.ldb : (size_t)k0;
+            p.K = min(p.kchunk, p.K - k0);
+        }
         p.C = p.part + (size_t)z * p.M * p.N;
         p.ldc = p.N; p.out_f32 = 1; p.bias = nullptr; p.residual = nullptr; p.accumulate = 0; p.act = 0;
     }
@@ -159,27 +176,28 @@ __global__ __launch_bounds__(256) void gemm128p_kernel(GemmParams p, const bf16_
     const uint32_t lbits = (uint32_t)(uintptr_t)(q_lvoid_t*)smem + nst * Q_STAGE_BYTES;      // mask tiles behind the operand stages
     const int nt = (p.K + QK - 1) / QK;
 
-    auto stage_bits = [&](int kt, int slot) {
+    auto stage_bits = [&](int kt, int slot, int ka) {
         if constexpr (MASK == 1) {      // lane -> (row wave*32 + lane/2, 4-byte half lane&1), LDS [128 rows][8 B]
             int grow = m0 + wave * 32 + (lane >> 1);
             grow = grow < p.M ? grow : p.M - 1;
             const unsigned char* g = p.mask_bits + (((size_t)grow * p.mask_ld + kabs0 + kt * QK) >> 3) + (lane & 1) * 4;
             q_dma4(g, lbits + slot * 1024 + wave * 256);
         } else if constexpr (MASK == 2) {   // [128 columns][8 B] of K tile (kabs0 / 64 + kt): 1 KiB contiguous
-            const unsigned char* g = p.mask_bits + ((size_t)((kabs0 >> 6) + kt) * p.mask_ld + n0) * 8 + wave * 256 + lane * 4;
+            const unsigned char* g = p.mask_bits + ((size_t)(ktl ? ka : (kabs0 >> 6) + kt) * p.mask_ld + n0) * 8 + wave * 256 + lane * 4;
             q_dma4(g, lbits + slot * 1024 + wave * 256);
         }
     };
     auto stage_tile = [&](int kt, int slot) {
         const uint32_t la = lds0 + slot * Q_STAGE_BYTES, lb = la + Q_OPER_BYTES;
+        const int ka = ktl ? __builtin_amdgcn_readfirstlane(ktl[1 + kt0 + kt]) : kt;      // the K tile this ring entry holds
         if ((kt + 1) * QK <= p.K) {
-            const char* ba = baseA + (size_t)kt * stepA;
-            const char* bb = baseB + (size_t)kt * stepB;
+            const char* ba = baseA + (size_t)ka * stepA;
+            const char* bb = baseB + (size_t)ka * stepB;
 #pragma unroll
             for (int i = 0; i < 4; ++i) q_dma16_s(ba, offA[i], la + i * 4096);
 #pragma unroll
             for (int i = 0; i < 4; ++i) q_dma16_s(bb, offB[i], lb + i * 4096);
-            if constexpr (MASK) stage_bits(kt, slot);
+            if constexpr (MASK) stage_bits(kt, slot, ka);
         } else {
             // the last, partial K tile: chunks / k-rows beyond K come from the zero buffer
             const int k0 = kt * QK;
@@ -209,7 +227,7 @@ __global__ __launch_bounds__(256) void gemm128p_kernel(GemmParams p, const bf16_
                 }
                 q_dma16(g, lb + i * 4096);
             }
-            if constexpr (MASK) stage_bits(kt, slot);
+            if constexpr (MASK) stage_bits(kt, slot, ka);
         }
     };
 

@@ -217,6 +217,28 @@ extern "C" int vlr_decoder_layer_bwd(const vlr_llama_cfg* cfg, const vlr_layer_w
 // bits != NULL (vlr_lora_weights::mask_bits): the packed keep masks of the n targets are DRAWN here (target t at bits + t * M * in / 8) and
 // read by the staged-operand mask of the grouped launch - and again by the backward (lora_group_bwd)
 // ustride (0 = r): elements between the u blocks of consecutive sub-targets - the two-adapter layout [u_lora | u_plora] per sub-target
+// per-stream device buffer for vlr_rows_tile_list (count + tile indices), grown on demand; NULL: no memory (the dense reductions run)
+static int* row_tiles_buf(hipStream_t st, int ints) {
+    struct Slot { hipStream_t st; int* p; int cap; };
+    static Slot slots[8];
+    static int nslots = 0;
+    Slot* s = nullptr;
+    for (int i = 0; i < nslots; ++i) if (slots[i].st == st) s = &slots[i];
+    if (!s) { if (nslots == 8) return nullptr; s = &slots[nslots++]; *s = Slot{st, nullptr, 0}; }
+    if (s->cap < ints) {
+        if (s->p) { hipStreamSynchronize(st); hipFree(s->p); s->p = nullptr; s->cap = 0; }
+        const int cap = ints < 16384 ? 16384 : ints;
+        if (hipMalloc((void**)&s->p, (size_t)cap * 4) != hipSuccess) { s->p = nullptr; return nullptr; }
+        s->cap = cap;
+    }
+    return s->p;
+}
+static bool row_tiles_on() {      // VLR_ROW_TILES=0: the K reductions of a row-restricted adapter read all token rows (A/B)
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("VLR_ROW_TILES"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on != 0;
+}
+
 static int lora_group_a(int n, int r, int in, const void* x, int ldx, const void* A, void* u, int ldu, float scale, float p,
                         uint64_t seed, void* ws_xd, int M, hipStream_t st, const unsigned char* rowmask = nullptr, unsigned char* bits = nullptr,
                         unsigned char* bits_kt = nullptr, int ustride = 0) {
@@ -259,7 +281,7 @@ static int lora_group_a(int n, int r, int in, const void* x, int ldx, const void
 static int lora_group_bwd(int n, int r, int in, const int* outs, const void* x, const void* dy, int lddy, const void* A, const void* B,
                           void* dA, void* dB, const void* u, int ldu, void* v, void* dx, float scale, float p, uint64_t seed,
                           void* ws_xd, int accumulate, int M, hipStream_t st, int dx_fresh = 0, const unsigned char* rowmask = nullptr,
-                          const unsigned char* bits = nullptr, const unsigned char* bits_kt = nullptr) {
+                          const unsigned char* bits = nullptr, const unsigned char* bits_kt = nullptr, const int* ktl = nullptr) {
     const int nr = n * r;
     const long gstride = (long)M * in / 8;       // bytes between the packed keep masks of the group's targets (the forward drew them)
     size_t ofs[4] = {0, 0, 0, 0};
@@ -270,8 +292,11 @@ static int lora_group_bwd(int n, int r, int in, const int* outs, const void* x, 
     const int ng = same ? 1 : n, gs = same ? n : 1;
     for (int g = 0; g < ng; ++g) {
         const int out = outs[g];
-        CHECK(vlr_gemm_grouped(2, off(dy, ofs[g]), off(u, (size_t)g * r), off(dB, ofs[g] * r), out, r, M, lddy, ldu, r, gs, (long)out, (long)r,
-                               (long)out * r, 1.f, accumulate, 0, 0, 0.f, 0, st));                       // u is stored scaled
+        // (ktl: PLoRA - u and v are zero on the text rows, the K reductions over the token rows read only the 64-row tiles with an image row)
+        if (ktl) CHECK(vlr_gemm_grouped_bits_ktiles(2, off(dy, ofs[g]), off(u, (size_t)g * r), off(dB, ofs[g] * r), out, r, M, lddy, ldu, r, gs, (long)out,
+                                                    (long)r, (long)out * r, 1.f, accumulate, 0, 0, 0.f, 0, nullptr, 0L, ktl, st));
+        else CHECK(vlr_gemm_grouped(2, off(dy, ofs[g]), off(u, (size_t)g * r), off(dB, ofs[g] * r), out, r, M, lddy, ldu, r, gs, (long)out, (long)r,
+                                    (long)out * r, 1.f, accumulate, 0, 0, 0.f, 0, st));                  // u is stored scaled
         if (rowmask) CHECK(vlr_gemm_grouped_bits_rows(1, off(dy, ofs[g]), off(B, ofs[g] * r), off(v, (size_t)g * r), M, r, out, lddy, r, nr, gs, (long)out,
                                                       (long)out * r, (long)r, 1.f, 0, 0, 0, 0.f, 0, nullptr, 0L, rowmask, st));
         else CHECK(vlr_gemm_grouped(1, off(dy, ofs[g]), off(B, ofs[g] * r), off(v, (size_t)g * r), M, r, out, lddy, r, nr, gs, (long)out,
@@ -280,8 +305,10 @@ static int lora_group_bwd(int n, int r, int in, const int* outs, const void* x, 
     if (rowmask) CHECK(vlr_rows_mask(v, nr, nr, rowmask, M, st));      // PLoRA: no gradient flows through the adapter on the text rows
     if (p > 0.f) {
         // dA_t = s / (1 - p) v_t^T (mask_t . x): the n targets as groups, x masked while it is staged (the mask of the forward, regenerated)
-        if (bits_kt) CHECK(vlr_gemm_grouped_bits(2, v, x, dA, r, in, M, nr, in, in, n, (long)r, 0L, (long)r * in, scale / (1.f - p), accumulate, 3, seed, p,
-                                                 in, bits_kt, vlr_dropout_bits_kt_bytes(M, in), st));
+        if (bits_kt && ktl) CHECK(vlr_gemm_grouped_bits_ktiles(2, v, x, dA, r, in, M, nr, in, in, n, (long)r, 0L, (long)r * in, scale / (1.f - p), accumulate, 3,
+                                                               seed, p, in, bits_kt, vlr_dropout_bits_kt_bytes(M, in), ktl, st));
+        else if (bits_kt) CHECK(vlr_gemm_grouped_bits(2, v, x, dA, r, in, M, nr, in, in, n, (long)r, 0L, (long)r * in, scale / (1.f - p), accumulate, 3, seed, p,
+                                                      in, bits_kt, vlr_dropout_bits_kt_bytes(M, in), st));
         else CHECK(vlr_gemm_grouped_bits(2, v, x, dA, r, in, M, nr, in, in, n, (long)r, 0L, (long)r * in, scale / (1.f - p), accumulate, 2, seed, p, in,
                                          bits, gstride, st));
         // dx (+)= s / (1 - p) sum_t mask_t . (v_t A_t): ONE pass over dx for the n targets (vlr_gemm_dropout_acc_multi: the streaming kernel
@@ -384,6 +411,11 @@ extern "C" int vlr_decoder_layer_bwd_lora_ex(const vlr_llama_cfg* cfg, const vlr
     VLR_REQUIRE(Nq == H, "vlr_decoder_layer_bwd_lora: heads*head_dim != hidden");
     const int o_qkv[3] = {Nq, Nkv, Nkv}, o_h[1] = {H}, o_gu[2] = {I, I};
     const float sc = lw->scale, p = lw->dropout;
+    const int* ktl = nullptr;         // PLoRA: the 64-row K tiles with an image row, for the adapter-gradient reductions over the token rows
+    if (rowmask && M % 64 == 0 && lg->a_qkv && row_tiles_on()) {
+        int* buf = row_tiles_buf(st, M / 64 + 1);
+        if (buf) { CHECK(vlr_rows_tile_list(rowmask, M, buf, st)); ktl = buf; }
+    }
 #define XD(seg) (ws_xd)      // ABI v4: one scratch [M][max(hidden, inter)] (the fallback path of vlr_gemm_dropout_acc), not per-target copies
 #define MB(t) (lw->mask_bits && p > 0.f ? (unsigned char*)lw->mask_bits + (size_t)(t) * ((size_t)M * H / 8) : nullptr)      // packed keep mask of target t
 #define MT(t) (lw->mask_bits && p > 0.f ? (unsigned char*)lw->mask_bits + lora_rowmajor_bytes(H, I, M) + (size_t)(t) * (size_t)vlr_dropout_bits_kt_bytes(M, H) : nullptr)   // ... K-tile-blocked transposed
@@ -394,12 +426,12 @@ extern "C" int vlr_decoder_layer_bwd_lora_ex(const vlr_llama_cfg* cfg, const vlr
         // measured SLOWER than the three separate kernels (38.8 ms against 25.5 + 7.7 per step: the addend is a third 16-byte load stream
         // in an epilogue that already reads gate | up) - kept behind the switch
         CHECK(lora_group_bwd(1, r, I, o_h, a->act, dx_out, H, lw->a_down, lw->b_down, lg->a_down, lg->b_down, off(u, 6 * (size_t)r), ldu, ws_v,
-                             ws->dact, sc, p, seed + 6, XD(6), accumulate, M, st, 1, rowmask, MB(6), MT(6)));
+                             ws->dact, sc, p, seed + 6, XD(6), accumulate, M, st, 1, rowmask, MB(6), MT(6), ktl));
         CHECK(vlr_gemm_swiglu_bwd_add(dx_out, w->wdown, a->gu, ws->dact, ws->dact, M, I, H, st));   // gu now holds [dgate | dup]
     } else if (lw->a_down) {
         CHECK(vlr_gemm_bf16(1, dx_out, w->wdown, ws->dact, nullptr, nullptr, M, I, H, H, I, I, 0, 0, 0, 0, st));
         CHECK(lora_group_bwd(1, r, I, o_h, a->act, dx_out, H, lw->a_down, lw->b_down, lg->a_down, lg->b_down, off(u, 6 * (size_t)r), ldu, ws_v,
-                             ws->dact, sc, p, seed + 6, XD(6), accumulate, M, st, 0, rowmask, MB(6), MT(6)));
+                             ws->dact, sc, p, seed + 6, XD(6), accumulate, M, st, 0, rowmask, MB(6), MT(6), ktl));
         CHECK(vlr_swiglu_bwd(a->gu, ws->dact, M, I, st));   // gu now holds [dgate | dup]
     } else {
         CHECK(vlr_gemm_swiglu_bwd(dx_out, w->wdown, a->gu, ws->dact, M, I, H, st));
@@ -407,13 +439,13 @@ extern "C" int vlr_decoder_layer_bwd_lora_ex(const vlr_llama_cfg* cfg, const vlr
     if (g) CHECK(vlr_gemm_bf16_tn_pair(a->gu, a->xn2, g->wgu, 2 * I, H, 2 * I, H, H, dx_out, a->act, g->wdown, H, I, H, I, I, M, accumulate, st));
     CHECK(vlr_gemm_bf16(1, a->gu, w->wgu, ws->dxn, nullptr, nullptr, M, H, 2 * I, 2 * I, H, H, 0, 0, 0, 0, st));
     CHECK(lora_group_bwd(2, r, H, o_gu, a->xn2, a->gu, 2 * I, lw->a_gu, lw->b_gu, lg->a_gu, lg->b_gu, off(u, 4 * (size_t)r), ldu, ws_v,
-                         ws->dxn, sc, p, seed + 4, XD(4), accumulate, M, st, 0, rowmask, MB(4), MT(4)));
+                         ws->dxn, sc, p, seed + 4, XD(4), accumulate, M, st, 0, rowmask, MB(4), MT(4), ktl));
     CHECK(norm_bwd(cfg->resid_f32, ws->dxn, a->x_mid, w->ln2, a->rstd2, dx_out, ws->dx_mid, g ? g->ln2 : nullptr, g ? accumulate : 0, ws->norm_ws, M, H, st));
     // ---- attention
     if (g) CHECK(vlr_gemm_bf16(2, ws->dx_mid, a->attn, g->wo, nullptr, nullptr, H, Nq, M, H, Nq, Nq, 0, 0, accumulate, 0, st));
     CHECK(vlr_gemm_bf16(1, ws->dx_mid, w->wo, ws->dattn, nullptr, nullptr, M, H, H, H, H, H, 0, 0, 0, 0, st));
     CHECK(lora_group_bwd(1, r, H, o_h, a->attn, ws->dx_mid, H, lw->a_o, lw->b_o, lg->a_o, lg->b_o, off(u, 3 * (size_t)r), ldu, ws_v,
-                         ws->dattn, sc, p, seed + 3, XD(3), accumulate, M, st, 0, rowmask, MB(3), MT(3)));
+                         ws->dattn, sc, p, seed + 3, XD(3), accumulate, M, st, 0, rowmask, MB(3), MT(3), ktl));
     CHECK(vlr_attn_bwd_gqa(a->qkv, off(a->qkv, Nq), off(a->qkv, (size_t)Nq + Nkv), N, a->attn, ws->dattn, Nq, a->lse, ws->delta,
                            key_mask, ws->dqkv, off(ws->dqkv, Nq), off(ws->dqkv, (size_t)Nq + Nkv), N, batch, S, cfg->heads, kvh,
                            cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));
@@ -423,7 +455,7 @@ extern "C" int vlr_decoder_layer_bwd_lora_ex(const vlr_llama_cfg* cfg, const vlr
     const int o_all[1] = {N};
     const int nq = lw->qkv_targets == 1 ? 1 : 3;
     CHECK(lora_group_bwd(nq, r, H, nq == 1 ? o_all : o_qkv, a->xn1, ws->dqkv, N, lw->a_qkv, lw->b_qkv, lg->a_qkv, lg->b_qkv, u, ldu, ws_v, ws->dxn,
-                         sc, p, seed + 0, ws_xd, accumulate, M, st, 0, rowmask, MB(0), MT(0)));
+                         sc, p, seed + 0, ws_xd, accumulate, M, st, 0, rowmask, MB(0), MT(0), ktl));
     CHECK(norm_bwd(cfg->resid_f32, ws->dxn, x_in, w->ln1, a->rstd1, ws->dx_mid, dx_in, g ? g->ln1 : nullptr, g ? accumulate : 0, ws->norm_ws, M, H, st));
     return VLR_OK;
 }
