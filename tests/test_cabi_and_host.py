@@ -39,6 +39,15 @@ def test_argument_errors_without_gpu():
     assert l.vlr_attn_fwd(None, None, None, 8, None, 8, None, None, 1, 8, 1, 96, 1, 1.0, None) == 1
     assert b"head_dim" in l.vlr_last_error()
     assert _hip.helper("vlr_rmsnorm_bwd_workspace_bytes", 4096) >= 256 * 4096 * 4
+    # ABI v7: the two-adapter layer passes and the row-set products validate before they launch
+    assert l.vlr_decoder_layer_fwd_lora2(None, None, None, None, None, None, None, 0, 0, None, None, None, None, 1, 8, None) == 1
+    assert b"vlr_decoder_layer_fwd_lora2: null argument" in l.vlr_last_error()
+    assert l.vlr_gemm_grouped_bits_rows(2, None, None, None, 8, 8, 8, 8, 8, 8, 1, 0, 0, 0, 1.0, 0, 0, 0, 0.0, 0, None, 0, None, None) == 1
+    assert b"layout 0 / 1" in l.vlr_last_error()
+    assert l.vlr_gemm_grouped_bits_ktiles(0, None, None, None, 8, 8, 8, 8, 8, 8, 1, 0, 0, 0, 1.0, 0, 0, 0, 0.0, 0, None, 0, None, None) == 1
+    assert b"layout 2 only" in l.vlr_last_error()
+    assert l.vlr_rows_tile_list(None, 8, None, None) == 1
+    assert b"vlr_rows_tile_list" in l.vlr_last_error()
 
 
 def test_product_refuses_to_run_without_gpu():
