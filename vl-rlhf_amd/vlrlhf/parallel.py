@@ -209,6 +209,7 @@ def init_distributed_from_env(backend: Optional[str] = None):
     if world <= 1:
         return 0, 0, 1
     rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (a launcher that did not export it: read when the HSA runtime starts, i.e. below)
     if torch.cuda.is_available():
         torch.cuda.set_device(local)
         rccl_channel_env()               # before the first communicator (torch's process group, then NativeComm)
