@@ -2,13 +2,11 @@
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 mkdir -p gpurun_out
-out=gpurun_out/r04_bench_1gpu_internlm_variants_final.json
-: > $out
-for v in "--model internlm_xc2" "--model internlm_xc2 --lora" "--model internlm_xc2 --text_len 512" "--model internlm_xc2 --text_len 512 --lora"; do
-  timeout 300 python bench.py $v --steps 6 --warmup 2 --no_cpu_baseline 2>/dev/null | tail -1 >> $out
+for m in "full:" "lora:--lora"; do
+  tag=${m%%:*}; flag=${m#*:}
+  rm -rf /tmp/prof_ilm
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ilm -o r -- python bench.py --model internlm_xc2 $flag --steps 3 --warmup 2 --no_cpu_baseline > gpurun_out/ilm_${tag}_under_rocprof.json 2>/dev/null
+  f=$(find /tmp/prof_ilm -name "*kernel_trace.csv" | head -1)
+  python tools/step_trace.py $f 2 3 gpurun_out/r04_steady_state_kernel_breakdown_internlm_${tag}_final.txt > /dev/null
+  head -3 gpurun_out/r04_steady_state_kernel_breakdown_internlm_${tag}_final.txt | cut -c1-120
 done
-python - <<'PY'
-import json
-for l in open("gpurun_out/r04_bench_1gpu_internlm_variants_final.json"):
-    d=json.loads(l); print(d["config"].get("variant"), d["config"].get("text_len"), d["ms_per_step"], d["value"])
-PY
