@@ -13,7 +13,9 @@ __device__ __forceinline__ void load8(const float* p, float* v) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
 }
-template <typename XT>
+// REG (H <= 8192): the row stays in registers between the sum of squares and the scaling - x is read ONCE (the two-pass form reads it a
+// second time out of the L2: the same values, the same order of additions, a longer dependent chain per workgroup)
+template <typename XT, bool REG>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const XT* __restrict__ x, const bf16_t* __restrict__ w,
                                                           bf16_t* __restrict__ y, float* __restrict__ rstd_out, int H,
                                                           float eps) {
@@ -21,6 +23,34 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const XT* __restrict__
     const size_t row = blockIdx.x;
     const XT* xr = x + row * H;
     float ss = 0.f;
+    if constexpr (REG) {
+        constexpr int MAXC = 4;
+        float v[MAXC][8];
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = threadIdx.x * 8 + i * 2048;
+            if (c < H) {
+                load8(xr + c, v[i]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ss += v[i][e] * v[i][e];
+            }
+        }
+        ss = block_sum(ss, red);
+        const float rstd = rsqrtf(ss / (float)H + eps);
+        if (threadIdx.x == 0 && rstd_out) rstd_out[row] = rstd;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = threadIdx.x * 8 + i * 2048;
+            if (c < H) {
+                float g[8], o[8];
+                unpack8(*reinterpret_cast<const u32x4*>(w + c), g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = g[e] * (v[i][e] * rstd);
+                *reinterpret_cast<u32x4*>(y + row * H + c) = pack8(o);
+            }
+        }
+        return;
+    }
     for (int c = threadIdx.x * 8; c < H; c += 256 * 8) {
         float v[8];
         load8(xr + c, v);
@@ -612,18 +642,28 @@ static inline int grid_for(long n, int per_block, int cap = 256 * 16) {
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
+static bool norm_fwd_reg() {      // VLR_NORM_FWD_REG=0: the two-pass kernel (A/B; bit-identical)
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("VLR_NORM_FWD_REG"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on != 0;
+}
 extern "C" int vlr_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int M, int H, float eps,
                                hipStream_t st) {
     VLR_REQUIRE(M > 0 && H > 0 && H % 8 == 0, "vlr_rmsnorm_fwd: bad shape M=%d H=%d", M, H);
-    hipLaunchKernelGGL(rmsnorm_fwd_kernel<bf16_t>, dim3(M), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y,
-                       rstd, H, eps);
+    if (H <= 8192 && norm_fwd_reg())
+        hipLaunchKernelGGL((rmsnorm_fwd_kernel<bf16_t, true>), dim3(M), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, H, eps);
+    else
+        hipLaunchKernelGGL((rmsnorm_fwd_kernel<bf16_t, false>), dim3(M), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, H, eps);
     return vlr_check_launch("vlr_rmsnorm_fwd");
 }
 // the same on an fp32 residual stream x [M][H]: y stays bf16 (the A operand of the projection that follows), rounded once
 extern "C" int vlr_rmsnorm_fwd_f32(const float* x, const void* w, void* y, float* rstd, int M, int H, float eps, hipStream_t st) {
     VLR_REQUIRE(x && w && y, "vlr_rmsnorm_fwd_f32: null argument");
     VLR_REQUIRE(M > 0 && H > 0 && H % 8 == 0, "vlr_rmsnorm_fwd_f32: bad shape M=%d H=%d", M, H);
-    hipLaunchKernelGGL(rmsnorm_fwd_kernel<float>, dim3(M), dim3(256), 0, st, x, (const bf16_t*)w, (bf16_t*)y, rstd, H, eps);
+    if (H <= 8192 && norm_fwd_reg())
+        hipLaunchKernelGGL((rmsnorm_fwd_kernel<float, true>), dim3(M), dim3(256), 0, st, x, (const bf16_t*)w, (bf16_t*)y, rstd, H, eps);
+    else
+        hipLaunchKernelGGL((rmsnorm_fwd_kernel<float, false>), dim3(M), dim3(256), 0, st, x, (const bf16_t*)w, (bf16_t*)y, rstd, H, eps);
     return vlr_check_launch("vlr_rmsnorm_fwd_f32");
 }
 
