@@ -72,7 +72,9 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const XT* __restrict__
 
 // RMSNorm backward.  dx = rstd * (dy*w - xhat * mean(dy*w*xhat)) (+ dres), dw partial[j] += dy*xhat.
 // Workgroup b walks rows b, b+G, ...; its dw partial goes to dw_part[b][H] (reduced by reduce_partials_kernel).
-template <typename XT>
+// EARLY: the residual-gradient addend of a row is loaded with dy / x, in front of the block reduction, instead of behind it (one exposed
+// memory latency per row less; the same values in the same operations)
+template <typename XT, bool EARLY>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const XT* __restrict__ x,
                                                           const bf16_t* __restrict__ w, const float* __restrict__ rstd,
                                                           const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
@@ -90,11 +92,13 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
         const float rs = rstd[row];
         float dot = 0.f;
         float gx[MAXC][8], xh[MAXC][8];
+        u32x4 rraw[MAXC];
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
             const int c = (i * 256 + threadIdx.x) * 8;
             if (c < H) {
                 float a[8], b[8], g[8];
+                if constexpr (EARLY) { if (dres) rraw[i] = *reinterpret_cast<const u32x4*>(dres + off + c); }
                 unpack8(*reinterpret_cast<const u32x4*>(dy + off + c), a);
                 load8(x + off + c, b);
                 unpack8(*reinterpret_cast<const u32x4*>(w + c), g);
@@ -117,7 +121,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
                 for (int e = 0; e < 8; ++e) o[e] = rs * (gx[i][e] - xh[i][e] * dot);
                 if (dres) {
                     float r[8];
-                    unpack8(*reinterpret_cast<const u32x4*>(dres + off + c), r);
+                    if constexpr (EARLY) unpack8(rraw[i], r);
+                    else unpack8(*reinterpret_cast<const u32x4*>(dres + off + c), r);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] += r[e];
                 }
@@ -695,12 +700,14 @@ static int rmsnorm_bwd_impl(const void* dy, const void* x, int x_f32, const void
     VLR_REQUIRE(workspace, "vlr_rmsnorm_bwd: workspace of vlr_rmsnorm_bwd_workspace_bytes(H) required");
     VLR_REQUIRE(M1 >= 0 && M1 < M, "vlr_rmsnorm_bwd: split row %d outside [0, %d)", M1, M);
     auto launch = [&](int row0, int rows_end, int G, int part0) {
-        if (x_f32)
-            hipLaunchKernelGGL(rmsnorm_bwd_kernel<float>, dim3(G), dim3(256), 0, st, (const bf16_t*)dy, (const float*)x,
-                               (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, (float*)workspace, rows_end, H, row0, part0);
-        else
-            hipLaunchKernelGGL(rmsnorm_bwd_kernel<bf16_t>, dim3(G), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x,
-                               (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, (float*)workspace, rows_end, H, row0, part0);
+        static int early = -1;      // VLR_NORM_BWD_EARLY=0: the addend loaded behind the reduction (A/B; bit-identical)
+        if (early < 0) { const char* e = getenv("VLR_NORM_BWD_EARLY"); early = (e && e[0] == '0') ? 0 : 1; }
+#define NORM_BWD_LAUNCH(XT_, E_)                                                                                                       \
+    hipLaunchKernelGGL((rmsnorm_bwd_kernel<XT_, E_>), dim3(G), dim3(256), 0, st, (const bf16_t*)dy, (const XT_*)x, (const bf16_t*)w, rstd, \
+                       (const bf16_t*)dres, (bf16_t*)dx, (float*)workspace, rows_end, H, row0, part0)
+        if (x_f32) { if (early) NORM_BWD_LAUNCH(float, true); else NORM_BWD_LAUNCH(float, false); }
+        else { if (early) NORM_BWD_LAUNCH(bf16_t, true); else NORM_BWD_LAUNCH(bf16_t, false); }
+#undef NORM_BWD_LAUNCH
     };
     int G = M < VLR_NORM_BWD_BLOCKS ? M : VLR_NORM_BWD_BLOCKS;
     if (M1 > 0) {
