@@ -614,3 +614,47 @@ def test_evaluate_reports_eval_metrics(gpu):
               "logits/chosen", "logits/rejected"):
         assert f"eval_{k}" in out, k
     assert torch.equal(before, model.engine.policy.flat) and model.training
+
+
+def test_generate_and_get_batch_samples(gpu):
+    """reference base/trainer.py:310-360 (`generate_during_eval`): `model.generate` on the left-padded prompts of the batch - greedy tokens
+    judged against the fp32 oracle's next-token logits on the SAME prefix (teacher-forced with the HIP tokens: the chosen token is the
+    oracle's argmax up to bf16 noise), sampling is reproducible under a generator, finished rows keep receiving the pad id, and
+    `get_batch_samples` returns decoded policy / reference strings padded to max_length."""
+    z, cfg, W, W_ref, batch, rows = load_case("llava_hipsmall")
+    model, ref = build(cfg, W, W_ref)
+    pix = batch["img_input_dict"]["pixel_values"]
+    ids0, m0 = batch["prompt_input_ids"], batch["prompt_attention_mask"]
+    assert int(m0[1, 0]) == 0 and int(m0[1, -1]) == 1                         # the fixture's prompts are left-padded
+    new = 5
+    out = model.generate(input_ids=ids0.to(gpu), attention_mask=m0.to(gpu), max_new_tokens=new, do_sample=False, pad_token_id=0,
+                         eos_token_id=10 ** 6, pixel_values=pix.to(gpu)).cpu()
+    assert out.shape == (2, ids0.shape[1] + new) and torch.equal(out[:, :ids0.shape[1]], ids0)
+    ids, mask = ids0.clone(), m0.clone()
+    for k in range(new):
+        logits, _, aux = O.llava_forward(W, cfg, ids, mask, torch.full_like(ids, -100), pix, dedupe_images=False)
+        for b in range(2):
+            last = int(torch.nonzero(aux["mask"][b]).max())
+            row = logits[b, last]
+            tok = int(out[b, ids0.shape[1] + k])
+            assert float(row.max() - row[tok]) <= 0.06 * float(row.max() - row.min()), (k, b, tok, int(row.argmax()))
+        ids = torch.cat([ids, out[:, ids0.shape[1] + k: ids0.shape[1] + k + 1]], 1)
+        mask = torch.cat([mask, torch.ones(2, 1, dtype=mask.dtype)], 1)
+    # sampling: reproducible under a generator, every sampled token inside the top-k set of the step
+    g = lambda: torch.Generator(device=gpu).manual_seed(7)      # noqa: E731
+    kw = dict(input_ids=ids0.to(gpu), attention_mask=m0.to(gpu), max_length=ids0.shape[1] + 4, do_sample=True, top_k=5, pad_token_id=0,
+              eos_token_id=10 ** 6, pixel_values=pix.to(gpu))
+    s1, s2 = model.generate(generator=g(), **kw).cpu(), model.generate(generator=g(), **kw).cpu()
+    assert torch.equal(s1, s2) and s1.shape[1] == ids0.shape[1] + 4
+    # eos: a row that emits it is finished and receives the pad id from then on
+    first = int(out[0, ids0.shape[1]])
+    e = model.generate(input_ids=ids0.to(gpu), attention_mask=m0.to(gpu), max_new_tokens=4, do_sample=False, pad_token_id=191,
+                       eos_token_id=first, pixel_values=pix.to(gpu)).cpu()
+    assert int(e[0, ids0.shape[1]]) == first and bool((e[0, ids0.shape[1] + 1:] == 191).all())
+    # the trainer's wrapper
+    tr = make_trainer(model, ref, cfg)
+    tr.max_length = ids0.shape[1] + 3
+    tr.tokenizer = SimpleNamespace(pad_token_id=0, batch_decode=lambda t_, skip_special_tokens=True: [" ".join(map(str, r.tolist())) for r in t_])
+    pol, refs = tr.get_batch_samples(model, {k: (v.to(gpu) if isinstance(v, torch.Tensor) else v) for k, v in batch.items() if k != "img_input_dict"}
+                                     | dict(img_input_dict=dict(pixel_values=pix.to(gpu))))
+    assert len(pol) == len(refs) == 2 and all(len(p_.split()) == tr.max_length for p_ in pol + refs)

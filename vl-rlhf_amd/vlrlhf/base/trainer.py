@@ -832,9 +832,26 @@ class VLDPOTrainer:
         self.callbacks.append(cb)
 
     def get_batch_samples(self, model, batch):
-        """reference base/trainer.py:310-360 samples text from the policy and the reference during evaluation; that is
-        autoregressive generation, outside the DPO training step."""
-        raise NotImplementedError("generate_during_eval is outside the MI355X DPO hot path (SURVEY.md section 8)")
+        """reference base/trainer.py:310-360: sample a continuation of every prompt from the policy and from the reference (the batch's
+        `reference_output`, else the reference model, else the policy with its adapters disabled), pad to max_length, decode.
+        Evaluation-time only (`generate_during_eval`; the reference CLI never switches it on): `model.generate` re-runs the HIP forward
+        per token, no KV cache."""
+        others = dict(batch.get("img_input_dict", {}))
+        kw = dict(input_ids=batch["prompt_input_ids"], attention_mask=batch["prompt_attention_mask"], max_length=self.max_length,
+                  do_sample=True, pad_token_id=self.tokenizer.pad_token_id, **others)
+        policy_output = model.generate(**kw)
+        if "reference_output" in batch:
+            reference_output = batch["reference_output"]
+        elif self.ref_model is None:
+            with self.null_ref_context():
+                reference_output = self.model.generate(**kw)
+        else:
+            reference_output = self.ref_model.generate(**kw)
+        pad = self.tokenizer.pad_token_id
+        policy_output = pad_to_length(policy_output, self.max_length, pad)
+        reference_output = pad_to_length(reference_output, self.max_length, pad)
+        return (self.tokenizer.batch_decode(policy_output, skip_special_tokens=True),
+                self.tokenizer.batch_decode(reference_output, skip_special_tokens=True))
 
 
 class _State:

@@ -387,6 +387,81 @@ class LlavaForRL(nn.Module):
         generation_config.do_sample = False
         return dict(generation_config=generation_config)
 
+    @torch.no_grad()
+    def generate(self, input_ids=None, attention_mask=None, max_length=None, max_new_tokens=None, do_sample=False, temperature=1.0,
+                 top_k=50, top_p=1.0, pad_token_id=None, eos_token_id=None, generation_config=None, generator=None, **img):
+        """What the reference trainer's `get_batch_samples` calls (base/trainer.py:310-360: `model.generate(input_ids, attention_mask,
+        max_length, do_sample=True, pad_token_id, **img_input_dict)`, transformers GenerationMixin defaults: temperature 1, top_k 50,
+        top_p 1).  Evaluation-time sampling only and outside the DPO step, so there is NO KV cache: every new token re-runs the forward
+        of the whole sequence on the HIP path (the vision features of the batch are cached by the engine) and the lm-head is evaluated
+        on the last row of each sequence alone.  Prompts are LEFT-padded (trl's collator; the merge of the reference end-aligns such
+        rows); the running batch is left-padded further to a multiple of 32 tokens so that the engine sees a new shape every 32 steps,
+        not every step.  Finished rows keep receiving `pad_token_id` as in transformers.  Returns prompt + continuation ids."""
+        if generation_config is not None:
+            max_new_tokens = max_new_tokens if max_new_tokens is not None else getattr(generation_config, "max_new_tokens", None)
+            do_sample = bool(getattr(generation_config, "do_sample", do_sample))
+        if input_ids is None:
+            raise ValueError("generate needs input_ids")
+        dev = self.engine.dev
+        ids = input_ids.to(dev).long()
+        mask = (torch.ones_like(ids) if attention_mask is None else attention_mask.to(dev).long())
+        B, T0 = ids.shape
+        if max_new_tokens is not None:
+            limit = T0 + int(max_new_tokens)
+        elif max_length is not None:
+            limit = int(max_length)
+        else:
+            limit = T0 + 20                       # transformers' default max_length is 20 NEW tokens when nothing is given
+        eos = eos_token_id if eos_token_id is not None else self.config.get("eos_token_id", 2)
+        eos = set(eos) if isinstance(eos, (list, tuple)) else {int(eos)}
+        pad = int(pad_token_id if pad_token_id is not None else 0)
+        img = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in img.items()}
+        was_training = self.training
+        self.eval()
+        unfinished = torch.ones(B, dtype=torch.bool, device=dev)
+        lm_head = self.weights.v["lm_head"]
+        try:
+            while ids.shape[1] < limit and bool(unfinished.any()):
+                T = ids.shape[1]
+                Tp = (T + 31) // 32 * 32
+                if Tp != T:                   # left padding: masked out, and the merged rows stay end-aligned
+                    fill = torch.full((B, Tp - T), pad, dtype=ids.dtype, device=dev)
+                    run_ids, run_mask = torch.cat([fill, ids], 1), torch.cat([torch.zeros_like(fill), mask], 1)
+                else:
+                    run_ids, run_mask = ids, mask
+                out = self(input_ids=run_ids, attention_mask=run_mask, labels=None, use_cache=False, **img)
+                c = out.logits.c
+                S, H = c["S"], self.engine.H
+                valid = c["mask"].view(B, S) != 0
+                last = S - 1 - torch.flip(valid, dims=[1]).float().argmax(1)           # last attended position of every row
+                rows = max(8, B)
+                h_last = torch.zeros(rows, H, dtype=torch.bfloat16, device=dev)
+                h_last[:B] = c["hidden"].view(B, S, H)[torch.arange(B, device=dev), last]
+                logits = torch.empty(rows, self.engine.V, dtype=torch.float32, device=dev)
+                _hip.call("vlr_gemm_bf16", 0, h_last, lm_head, logits, None, None, rows, self.engine.V, H, H, H, self.engine.V, 0, 0, 0, 1)
+                logits = logits[:B]
+                if do_sample:
+                    logits = logits / max(float(temperature), 1e-6)
+                    if top_k and top_k > 0:
+                        kth = torch.topk(logits, min(int(top_k), logits.shape[-1]), dim=-1).values[:, -1:]
+                        logits = logits.masked_fill(logits < kth, float("-inf"))
+                    if top_p < 1.0:
+                        srt, idx = torch.sort(logits, dim=-1, descending=False)
+                        drop = srt.softmax(-1).cumsum(-1) <= (1.0 - float(top_p))
+                        drop[:, -1] = False
+                        logits = logits.masked_fill(drop.scatter(1, idx, drop), float("-inf"))
+                    nxt = torch.multinomial(logits.softmax(-1), 1, generator=generator).squeeze(1)
+                else:
+                    nxt = logits.argmax(-1)
+                nxt = torch.where(unfinished, nxt, torch.full_like(nxt, pad))
+                ids = torch.cat([ids, nxt[:, None]], 1)
+                mask = torch.cat([mask, torch.ones(B, 1, dtype=mask.dtype, device=dev)], 1)
+                for e in eos:
+                    unfinished = unfinished & (nxt != e)
+        finally:
+            self.train(was_training)
+        return ids
+
     def zero_grad(self, set_to_none: bool = True):
         self.engine.zero_grad()
 
