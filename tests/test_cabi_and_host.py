@@ -320,3 +320,24 @@ def test_rccl_channel_bounds_follow_the_cu_reservation(monkeypatch):
     monkeypatch.setenv("VLR_COMM_CUS", "0")
     e = {}
     assert P.rccl_channel_env(e) == (None, None) and e == {}
+
+
+def test_sampling_filter_follows_the_logits_warpers():
+    """LlavaForRL.generate's temperature / top-k / top-p filter against a plain restatement of transformers' warpers"""
+    from vlrlhf.models.Llava import sampling_filter
+    g = torch.Generator().manual_seed(0)
+    logits = torch.randn(5, 40, generator=g) * 3
+    out = sampling_filter(logits, 0.7, 7, 1.0)
+    assert bool(((out > float("-inf")).sum(-1) == 7).all())
+    keep = (logits / 0.7).topk(7, dim=-1).indices
+    assert bool(torch.isfinite(out.gather(1, keep)).all())
+    out = sampling_filter(logits, 1.0, 0, 0.8)
+    for b in range(5):
+        p = logits[b].softmax(-1)
+        order = p.argsort(descending=True)
+        csum = p[order].cumsum(0)
+        n_keep = int((csum < 0.8).sum()) + 1                       # the smallest prefix whose mass reaches top_p
+        want = torch.zeros(40, dtype=torch.bool)
+        want[order[:n_keep]] = True
+        assert torch.equal(torch.isfinite(out[b]), want), b
+    assert bool(torch.isfinite(sampling_filter(logits, 1.0, 1, 0.01)).sum(-1).eq(1).all())       # one token always survives

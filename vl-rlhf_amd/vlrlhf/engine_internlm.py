@@ -34,7 +34,7 @@ class InternLMHipEngine(LlavaHipEngine):
 
     @property
     def supports_ckpt(self):       # the C layer passes (full fine-tune / reference / LoRA over PLoRA) can be re-run; the Python-composed peft-LoRA layer keeps its activations
-        return (self.lora is None or bool(getattr(self, "lora_fused", False))) and bool(getattr(self, "fused_forward", True))
+        return (self.lora is None or bool(getattr(self, "lora_fused", False))) and bool(getattr(self, "fused_forward", True))      # (getattr: read by the base __init__)
 
     def __init__(self, cfg: dict, device="cuda", max_positions: int = 8192):
         c = dict(cfg, family="internlm_xc2")
@@ -46,8 +46,9 @@ class InternLMHipEngine(LlavaHipEngine):
         self.plora_p = float(c.get("plora_dropout", 0.05))
         self._plora_calls = 0
         self.plora_seed = int(c.get("seed", 0))
-        import os
         self.fused_forward = os.environ.get("VLR_ILM_FUSED", "1") != "0"     # PLoRA-only passes on the C layer calls (0: the Python-composed layer everywhere)
+        self.lora_fused = False                  # set by enable_lora: peft LoRA over PLoRA on vlr_decoder_layer_*_lora2
+        self.last_train_plora_seed = None        # PLoRA dropout seed of the last training-mode policy pass
         if not self.fused_forward:
             self._to_bf16_stream()
 

@@ -170,6 +170,21 @@ def _hf_from_cfg(c: dict) -> dict:
                            patch_size=c["patch_size"], layer_norm_eps=c.get("vit_ln_eps", 1e-5)))
 
 
+def sampling_filter(logits, temperature=1.0, top_k=50, top_p=1.0):
+    """transformers' logits warpers in their order (TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper): the filtered-out entries
+    become -inf; at least one token always survives"""
+    logits = logits / max(float(temperature), 1e-6)
+    if top_k and top_k > 0:
+        kth = torch.topk(logits, min(int(top_k), logits.shape[-1]), dim=-1).values[:, -1:]
+        logits = logits.masked_fill(logits < kth, float("-inf"))
+    if top_p < 1.0:
+        srt, idx = torch.sort(logits, dim=-1, descending=False)
+        drop = srt.softmax(-1).cumsum(-1) <= (1.0 - float(top_p))
+        drop[:, -1] = False
+        logits = logits.masked_fill(drop.scatter(1, idx, drop), float("-inf"))
+    return logits
+
+
 class LlavaForRL(nn.Module):
     engine_cls = LlavaHipEngine
 
@@ -441,16 +456,7 @@ class LlavaForRL(nn.Module):
                 _hip.call("vlr_gemm_bf16", 0, h_last, lm_head, logits, None, None, rows, self.engine.V, H, H, H, self.engine.V, 0, 0, 0, 1)
                 logits = logits[:B]
                 if do_sample:
-                    logits = logits / max(float(temperature), 1e-6)
-                    if top_k and top_k > 0:
-                        kth = torch.topk(logits, min(int(top_k), logits.shape[-1]), dim=-1).values[:, -1:]
-                        logits = logits.masked_fill(logits < kth, float("-inf"))
-                    if top_p < 1.0:
-                        srt, idx = torch.sort(logits, dim=-1, descending=False)
-                        drop = srt.softmax(-1).cumsum(-1) <= (1.0 - float(top_p))
-                        drop[:, -1] = False
-                        logits = logits.masked_fill(drop.scatter(1, idx, drop), float("-inf"))
-                    nxt = torch.multinomial(logits.softmax(-1), 1, generator=generator).squeeze(1)
+                    nxt = torch.multinomial(sampling_filter(logits, temperature, top_k, top_p).softmax(-1), 1, generator=generator).squeeze(1)
                 else:
                     nxt = logits.argmax(-1)
                 nxt = torch.where(unfinished, nxt, torch.full_like(nxt, pad))
