@@ -59,10 +59,12 @@ int vlr_gemm_bf16_tn_pair(const void* A0, const void* B0, void* C0, int M0, int 
  * LlamaDecoderLayer.forward (call site src/vlrlhf/models/Llava/__init__.py:232) without the bf16 rounding of the sum. */
 int vlr_gemm_bf16_f32res(int layout, const void* A, const void* B, float* C, const float* residual, int M, int N, int K,
                          int lda, int ldb, int ldc, int ldr, vlr_stream_t stream);
-/* A/B switches of the persistent (continuous-pipeline) GEMM launches, 0 in production: 8 = the adapter-segment K tiles take the general
- * staging path, 16 = the two wave groups of a workgroup run their epilogues one after the other (the order before round 4; results are
- * bit-identical to 0).  -1 = back to the default (environment VLR_GEMM_SCHED, else 0).  The tile schedules 1-7 of ABI v5 (stream-K tail,
- * XCD rotation, XCD round barrier) measured slower or neutral and are rejected with VLR_ERR_ARG. */
+/* Switches of the persistent (continuous-pipeline) GEMM launches, a sum of: 8 = the adapter-segment K tiles take the general staging
+ * path, 16 = the two wave groups of a workgroup run their epilogues one after the other (the order before round 4; bit-identical
+ * results), 32 = the shared-panel tile map (csrc/gemm_tilemap.h, round 5: the XCD blocks of a round are stacked into one super-block so
+ * that the eight XCDs share panels through the Infinity Cache; same results, other order of the output tiles).  Production = 32.
+ * -1 = back to the default (environment VLR_GEMM_SCHED, else 32).  The tile schedules 1-7 of ABI v5 (stream-K tail, XCD rotation, XCD
+ * round barrier) measured slower or neutral and are rejected with VLR_ERR_ARG. */
 int vlr_gemm_set_sched(int mode);
 /* Diagnostics only: the tile timeline of the persistent GEMM launches.  With a non-NULL buffer of >= 256 KiB every later launch of the
  * 256x256 continuous-pipeline kernel leaves, for each workgroup b, words [b*256 + 4*i .. +3] = {tile id, and the 100 MHz clock after the

@@ -4,7 +4,7 @@
     python oracle/depth_parity.py small      # 1 pair, T = 128 (S = 703), ragged: fp32 + bf16 error budget
     python oracle/depth_parity.py configs0   # BASELINE.json configs[0]: 4 pairs, T = 256 (S = 831): fp32 + bf16-emulated
     python oracle/depth_parity.py grads | grads_sharp   # fp32 autograd of the `small` case (VLR_DEPTH_LAYERS=2|32); _sharp: q / k weights x 2
-    python oracle/depth_parity.py seeds      # (round 4) the `small` case under 8 hashed models / batches: fp32 + the floor model
+    python oracle/depth_parity.py seeds      # (round 4) the `small` case under 16 (round 4: 8) hashed models / batches: fp32 + the floor model
 
 The weights are the machine-independent hashed weights of oracle.llava_dpo_oracle.HashedWeights (reference = seed 0,
 policy = reference + 1e-3 * n'), so the GPU test regenerates the SAME 7B model on the MI355X from (seed, name) alone and
@@ -116,7 +116,7 @@ class _Leaves:
         return self.base.keys()
 
 
-SEED_SWEEP = 8          # `seeds`: weight seeds 1 .. SEED_SWEEP (reference = seed s, policy delta seed 100 + s), batch seed 20 + s
+SEED_SWEEP = int(os.environ.get("VLR_SEED_SWEEP", "16"))   # `seeds`: weight seeds 1 .. SEED_SWEEP (reference = seed s, policy delta seed 100 + s), batch seed 20 + s (round 4: 8; round 5: 16)
 FLOOR_TAGS = ("f32resid+vit_f32out",)
 
 

@@ -1253,9 +1253,10 @@ SCHED_SHAPES = [(12792, 4096, 1024), (4096, 11008, 1088), (5000, 4360, 2048)]
 @pytest.mark.parametrize("layout", [0, 1, 2])
 @pytest.mark.parametrize("shape", SCHED_SHAPES)
 def test_gemm_sched_modes(hip, layout, shape):
-    """vlr_gemm_set_sched: the serial epilogue order (16: the two wave groups one after the other, as before round 4) against the default
-    (0: side by side) - the same arithmetic, so bit-identical; each mode twice, and a NaN-filled output proves every tile is written.
-    The removed tile schedules (1-7) are rejected."""
+    """vlr_gemm_set_sched: the serial epilogue order (16: the two wave groups one after the other, as before round 4) and the tile maps
+    (32: the shared-panel map of gemm_tilemap.h, the default since round 5; without it the per-XCD contiguous ranges of rounds 1-4) - the
+    same arithmetic per output tile in another order of the tiles, so bit-identical; each mode twice, and a NaN-filled output proves
+    every tile is written.  The removed tile schedules (1-7) are rejected."""
     M, N, K = shape
     if layout == 2:
         K = K + 40
@@ -1266,7 +1267,7 @@ def test_gemm_sched_modes(hip, layout, shape):
     lda = K if layout != 2 else M
     ldb = K if layout == 0 else N
     outs = {}
-    for mode in (0, 16):
+    for mode in (0, 16, 32, 48):
         def run():
             res = []
             for _ in range(2):
@@ -1279,21 +1280,22 @@ def test_gemm_sched_modes(hip, layout, shape):
         assert torch.equal(c1, c2), f"mode {mode}: not reproducible"
         check(c1, ref, 8e-3, f"gemm sched {mode} layout {layout} {shape}")
         outs[mode] = c1
-    assert torch.equal(outs[0], outs[16])
-    for mode in (1, 2, 3, 4, 7):
+    assert torch.equal(outs[0], outs[16]) and torch.equal(outs[0], outs[32]) and torch.equal(outs[0], outs[48])
+    for mode in (1, 2, 3, 4, 7, 64):
         assert hip.helper("vlr_gemm_set_sched", mode) != 0
     assert hip.helper("vlr_gemm_set_sched", -1) == 0
 
 
 def test_gemm_sched_fused_epilogues(hip):
-    """the fused SwiGLU / RoPE-free / SwiGLU-backward / fp32-residual launches with the serial epilogue order: bit-identical to the default"""
+    """the fused SwiGLU / RoPE-free / SwiGLU-backward / fp32-residual launches with the serial epilogue order and with either tile map:
+    bit-identical"""
     M, I, H = 6648, 2176, 1024                                   # 26 x 17 = 442 SwiGLU tiles; 26 x 9 o_proj-like tiles
     x, wgu = rnd(M, H, seed=1), rnd(2 * I, H, scale=0.05, seed=2)
     dy, wdown = rnd(M, H, seed=3), rnd(H, I, scale=0.05, seed=4)
     res = rnd(M, 4352, seed=5, dtype=torch.float32)
     wo = rnd(4352, H, scale=0.05, seed=6)
     base = {}
-    for mode in (0, 16):
+    for mode in (0, 16, 32):
         def run():
             gu = torch.full((M, 2 * I), float("nan"), dtype=torch.bfloat16, device=DEV)
             act = torch.full((M, I), float("nan"), dtype=torch.bfloat16, device=DEV)

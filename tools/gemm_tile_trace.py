@@ -65,49 +65,54 @@ def main():
     for name, fn in cases.items():
         if a.only and a.only not in name:
             continue
-        for _ in range(3):
-            fn()
-        torch.cuda.synchronize()
-        trace.zero_()
-        assert _hip.helper("vlr_gemm_set_trace", trace.data_ptr(), trace.numel() * 4) == 0, _hip.lib().vlr_last_error()
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
+        measure(name, fn, trace, a.dump)
+
+
+def measure(name, fn, trace, dump="", warm=3):
+    """one traced launch of `fn` (after `warm` warm-up calls) -> the timeline line of the module docstring"""
+    for _ in range(warm):
         fn()
-        e.record()
-        torch.cuda.synchronize()
-        _hip.helper("vlr_gemm_set_trace", None, 0)
-        t = trace.cpu().numpy().astype(np.uint32).reshape(256, 64, 4)
-        if a.dump:
-            np.save(os.path.join(a.dump, name.split()[0].replace("+", "_") + "_" + name.split()[1] + ".npy"), t)
-        npc = t[:, 63, 0].astype(int)
-        act_b = np.nonzero(npc)[0]
-        if len(act_b) == 0:
-            print(f"{name:34s} no persistent continuous-pipeline launch recorded")
-            continue
-        nt = int(t[act_b[0], 63, 2])
-        t0 = t[act_b, 63, 1].astype(np.int64)
-        kt, first, epi, tile = [], [], [], []
-        ends = {}
-        for bi, b in enumerate(act_b):
-            prev = int(t0[bi])
-            for i in range(min(npc[b], 63)):
-                f, k, ep = (int(v) for v in t[b, i, 1:4])
-                if f == 0:      # a tile with fewer than 3 K tiles on the fast path: no first-tile stamp
-                    f = prev
-                kt.append((k - f) / max(nt - 1, 1) / 100.0)
-                first.append((f - prev) / 100.0)
-                epi.append((ep - k) / 100.0)
-                tile.append((ep - prev) / 100.0)
-                ends.setdefault(i, []).append(ep - int(t0.min()))
-                prev = ep
-        kt, first, epi, tile = (np.array(v) for v in (kt, first, epi, tile))
-        # tiles after the first of a workgroup (the first one has the cold prologue in its "first K tile")
-        later = np.concatenate([np.arange(sum(min(npc[b], 63) for b in act_b[:bi]) + 1, sum(min(npc[b], 63) for b in act_b[:bi + 1])) for bi in range(len(act_b))]) if npc.max() > 1 else np.arange(0)
-        fl = first[later] if len(later) else first
-        phase = " ".join(f"{(max(v) - min(v)) / 100.0:.0f}" for i, v in sorted(ends.items()) if len(v) > 128)
-        print(f"{name:34s} {s.elapsed_time(e) * 1e3:7.0f} us  nt {nt:3d}  k-tile {np.median(kt):5.2f}  first (later tiles) med {np.median(fl):5.2f} p90 {np.percentile(fl, 90):5.2f}"
-              f"  epi med {np.median(epi):5.2f} p90 {np.percentile(epi, 90):5.2f}  tile med {np.median(tile):6.1f} (overhead {100 * (1 - np.median(kt) * nt / np.median(tile)):.1f} %)"
-              f"  rounds' end spread [{phase}] us")
+    torch.cuda.synchronize()
+    trace.zero_()
+    assert _hip.helper("vlr_gemm_set_trace", trace.data_ptr(), trace.numel() * 4) == 0, _hip.lib().vlr_last_error()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    fn()
+    e.record()
+    torch.cuda.synchronize()
+    _hip.helper("vlr_gemm_set_trace", None, 0)
+    t = trace.cpu().numpy().astype(np.uint32).reshape(256, 64, 4)
+    if dump:
+        np.save(os.path.join(dump, name.split()[0].replace("+", "_") + "_" + name.split()[1] + ".npy"), t)
+    npc = t[:, 63, 0].astype(int)
+    act_b = np.nonzero(npc)[0]
+    if len(act_b) == 0:
+        print(f"{name:34s} no persistent continuous-pipeline launch recorded")
+        return
+    nt = int(t[act_b[0], 63, 2])
+    t0 = t[act_b, 63, 1].astype(np.int64)
+    kt, first, epi, tile = [], [], [], []
+    ends = {}
+    for bi, b in enumerate(act_b):
+        prev = int(t0[bi])
+        for i in range(min(npc[b], 63)):
+            f, k, ep = (int(v) for v in t[b, i, 1:4])
+            if f == 0:      # a tile with fewer than 3 K tiles on the fast path: no first-tile stamp
+                f = prev
+            kt.append((k - f) / max(nt - 1, 1) / 100.0)
+            first.append((f - prev) / 100.0)
+            epi.append((ep - k) / 100.0)
+            tile.append((ep - prev) / 100.0)
+            ends.setdefault(i, []).append(ep - int(t0.min()))
+            prev = ep
+    kt, first, epi, tile = (np.array(v) for v in (kt, first, epi, tile))
+    # tiles after the first of a workgroup (the first one has the cold prologue in its "first K tile")
+    later = np.concatenate([np.arange(sum(min(npc[b], 63) for b in act_b[:bi]) + 1, sum(min(npc[b], 63) for b in act_b[:bi + 1])) for bi in range(len(act_b))]) if npc.max() > 1 else np.arange(0)
+    fl = first[later] if len(later) else first
+    phase = " ".join(f"{(max(v) - min(v)) / 100.0:.0f}" for i, v in sorted(ends.items()) if len(v) > 128)
+    print(f"{name:34s} {s.elapsed_time(e) * 1e3:7.0f} us  nt {nt:3d}  k-tile {np.median(kt):5.2f} (p10 {np.percentile(kt, 10):4.2f} p90 {np.percentile(kt, 90):4.2f})  first (later tiles) med {np.median(fl):5.2f} p90 {np.percentile(fl, 90):5.2f}"
+          f"  epi med {np.median(epi):5.2f} p90 {np.percentile(epi, 90):5.2f}  tile med {np.median(tile):6.1f} (overhead {100 * (1 - np.median(kt) * nt / np.median(tile)):.1f} %)"
+          f"  rounds' end spread [{phase}] us", flush=True)
 
 
 if __name__ == "__main__":

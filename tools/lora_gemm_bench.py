@@ -150,9 +150,9 @@ def main():
         t0, t1 = timeit(f0, a.iters), timeit(f1, a.iters)
         line = f"{name:14s} {t0:9.1f} {t1:12.1f} {t1 / t0:6.3f}"
         if a.seg_ab:
-            _hip.helper("vlr_gemm_set_sched", 8)
+            _hip.helper("vlr_gemm_set_sched", 8 | 32)
             t2 = timeit(f1, a.iters)
-            _hip.helper("vlr_gemm_set_sched", 0)
+            _hip.helper("vlr_gemm_set_sched", -1)
             line += f"   {t2:15.1f} {t2 / t0:6.3f}"
         print(line)
 

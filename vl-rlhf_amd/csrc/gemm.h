@@ -69,7 +69,8 @@ struct GemmParams {
     void* C1;
     int M1, N1, lda1, ldb1, ldc1;
     // ---- A/B switches of the continuous-pipeline kernels (vlr_gemm_set_sched): bit 3 = adapter K tiles on the general staging path,
-    // bit 4 = the two wave groups run their epilogues one after the other (the order before round 4).  0 in production.
+    // bit 4 = the two wave groups run their epilogues one after the other (the order before round 4), bit 5 (32) = the shared-panel tile
+    // map of gemm_tilemap.h (round 5; off = the per-XCD contiguous tile ranges of rounds 1-4).  32 in production.
     int sched;
     // ---- 128x128 kernel only (gemm.hip): GROUPED launches and an on-the-fly lora_dropout mask.
     // groups > 1: blockIdx.z = group g runs the same problem shape on A + g * gA, B + g * gB, C + g * gC (elements of each type) -
@@ -98,10 +99,10 @@ struct GemmParams {
     const int* ktlist;
 #ifdef VLR_GEMM_TRACE
     uint32_t* trace;         // diagnostics build only: set by the launchers of gemm256p.hip (vlr_gemm_set_trace), never by callers
-    int dephase_p, dephase_ticks, epi_abl;
+    int dephase_p, dephase_ticks, epi_abl, trace_clk;
 #endif
 };
-#define VLR_SCHED_DEFAULT 0           // GemmParams::sched when VLR_GEMM_SCHED is not set
+#define VLR_SCHED_DEFAULT 32          // GemmParams::sched when VLR_GEMM_SCHED is not set: the shared-panel tile map (gemm_tilemap.h, round 5)
 int vlr_gemm_sched_mode();
 
 __device__ __forceinline__ float apply_act(float v, int act) {

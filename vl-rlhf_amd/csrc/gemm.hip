@@ -424,17 +424,18 @@ extern "C" int vlr_gemm_set_splitk_workspace(void* ws, long bytes) {
     return VLR_OK;
 }
 // A/B switches of the continuous-pipeline GEMM kernels (GemmParams::sched): bit 3 (8) adapter K tiles on the general staging path,
-// bit 4 (16) the two wave groups of a workgroup run their epilogues one after the other (the order before round 4).  Default from
-// VLR_GEMM_SCHED (else 0); vlr_gemm_set_sched(-1) re-reads the environment.  The tile schedules of round 3 (bits 0-2: stream-K tail, XCD
+// bit 4 (16) the two wave groups of a workgroup run their epilogues one after the other (the order before round 4), bit 5 (32) the
+// shared-panel tile map (gemm_tilemap.h; the production default since round 5).  Default from VLR_GEMM_SCHED (else 32);
+// vlr_gemm_set_sched(-1) re-reads the environment.  The tile schedules of round 3 (bits 0-2: stream-K tail, XCD
 // rotation, XCD round barrier) measured slower or neutral and were removed.
 static int g_sched = -1;
 int vlr_gemm_sched_mode() {
-    if (g_sched < 0) { const char* e = getenv("VLR_GEMM_SCHED"); g_sched = e ? (atoi(e) & 24) : VLR_SCHED_DEFAULT; }
+    if (g_sched < 0) { const char* e = getenv("VLR_GEMM_SCHED"); g_sched = e ? (atoi(e) & 56) : VLR_SCHED_DEFAULT; }
     return g_sched;
 }
 extern "C" int vlr_gemm_set_sched(int mode) {
-    VLR_REQUIRE(mode == -1 || (mode >= 0 && (mode & ~24) == 0),
-                "vlr_gemm_set_sched: 0, 8 (adapter tiles on the general staging path), 16 (serial epilogue order), 24 or -1, got %d "
+    VLR_REQUIRE(mode == -1 || (mode >= 0 && (mode & ~56) == 0),
+                "vlr_gemm_set_sched: a sum of 8 (adapter tiles on the general staging path), 16 (serial epilogue order), 32 (shared-panel tile map), or -1, got %d "
                 "(the stream-K / rotation / round-barrier schedules 1-7 of round 3 were removed: measured slower)", mode);
     g_sched = mode;
     return VLR_OK;

@@ -29,6 +29,7 @@
 #include <type_traits>
 
 #include "gemm.h"
+#include "gemm_tilemap.h"
 
 #ifndef VLR_KLOOP_BAL
 #define VLR_KLOOP_BAL 1        // balanced fragment reads per phase (6 / 6 / 6 / 6 instead of the template's 12 / 4 / 8 / 0); 0: the round-3 K loop (A/B builds)
@@ -238,7 +239,7 @@ static uint32_t* g_trace = nullptr;
 #define TSTAMP(slot_)                                                                  \
     do {                                                                               \
         if (p.trace && wave == 0) {                                                    \
-            const uint64_t t__ = __builtin_amdgcn_s_memrealtime();                     \
+            const uint64_t t__ = p.trace_clk ? __builtin_amdgcn_s_memtime() : __builtin_amdgcn_s_memrealtime(); \
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                         \
             if (lane0 == 0) ptab[(slot_)] = (int)(uint32_t)t__;                        \
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                         \
@@ -256,7 +257,9 @@ static void trace_set(GemmParams& p) {
     }
     static int abl = -1;
     if (abl < 0) { const char* e = getenv("VLR_EPI_ABLATE"); abl = e ? atoi(e) : 0; }      // timing only (wrong results): 1 no epilogue loads, 2 no epilogue stores
-    p.trace = g_trace; p.dephase_p = g_dephase_p; p.dephase_ticks = g_dephase_ticks; p.epi_abl = abl;
+    static int clk = -1;
+    if (clk < 0) { const char* e = getenv("VLR_GEMM_TRACE_CLK"); clk = (e && e[0] == '1') ? 1 : 0; }      // 1: stamps of the SHADER clock (s_memtime) - cycles instead of 10 ns ticks
+    p.trace = g_trace; p.dephase_p = g_dephase_p; p.dephase_ticks = g_dephase_ticks; p.epi_abl = abl; p.trace_clk = clk;
 }
 #define TRACE_SET(p_) trace_set(p_)
 #define EPI_LD_ON (!(p.epi_abl & 1))
@@ -365,21 +368,39 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     const int G8 = (int)gridDim.x >> 3, xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
     const bool persistent = (int)gridDim.x < nwg;                  // else: one tile per workgroup, gridDim == nwg (any count)
     const int n_x = (nwg >> 3) + (xcd < (nwg & 7) ? 1 : 0);       // tiles of this XCD
-    const int npieces = __builtin_amdgcn_readfirstlane(persistent ? (n_x - jx + G8 - 1) / G8 : 1);
+    // sched bit 5 (VLR_SCHED_SHARED, gemm_tilemap.h): round i of the launch is tiles [i * gridDim, (i + 1) * gridDim) of a list in which the
+    // XCD blocks of a round are stacked into one super-block (shared B panels, A panels re-read one round later: Infinity-Cache distances)
+    // - XCD x takes the x-th run of gridDim / 8 tiles of the round; persistent launches with whole XCD octets only
+    const bool shared_map = persistent && (p.sched & 32) && ((int)gridDim.x & 7) == 0;
+    const int l_first = xcd * G8 + jx;
+    const int npieces = __builtin_amdgcn_readfirstlane(!persistent ? 1 : shared_map ? (nwg - l_first + (int)gridDim.x - 1) / (int)gridDim.x
+                                                                                    : (n_x - jx + G8 - 1) / G8);
     int* ptab = reinterpret_cast<int*>(smem + (CONT ? 2 * BUF_BYTES : P_LDS_BYTES));
     if (t < 64) {
         for (int i = t; i < npieces; i += 64) {
-            const int idx = jx + i * G8;
-            const int q = nwg >> 3, rem = nwg & 7;
-            const int pid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;      // XCD x owns a contiguous range of tile ids (bijective)
+            int pid;
+            if (shared_map) {
+                pid = i * (int)gridDim.x + l_first;
+            } else {
+                const int idx = jx + i * G8;
+                const int q = nwg >> 3, rem = nwg & 7;
+                pid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;      // XCD x owns a contiguous range of tile ids (bijective)
+            }
             const bool g1 = GRP && pid >= nwg0;
             const int pl = g1 ? pid - nwg0 : pid, tm = g1 ? tiles_m1 : tiles_m, tn_ = g1 ? tiles_n1 : tiles_n;
-            const int GROUP = 8;
-            const int per_group = GROUP * tn_;
-            const int first_m = (pl / per_group) * GROUP;
-            const int gsz = min(tm - first_m, GROUP);
-            ptab[i * 8 + 0] = (first_m + (pl % per_group) % gsz) * PT;
-            ptab[i * 8 + 1] = ((pl % per_group) / gsz) * NW;
+            int trow, tcol;
+            if (shared_map) {
+                vlr_tile_of_shared(pl, tm, tn_, &trow, &tcol);
+            } else {
+                const int GROUP = 8;
+                const int per_group = GROUP * tn_;
+                const int first_m = (pl / per_group) * GROUP;
+                const int gsz = min(tm - first_m, GROUP);
+                trow = first_m + (pl % per_group) % gsz;
+                tcol = (pl % per_group) / gsz;
+            }
+            ptab[i * 8 + 0] = trow * PT;
+            ptab[i * 8 + 1] = tcol * NW;
             ptab[i * 8 + 2] = g1 ? 1 : 0;
         }
     }
@@ -1348,9 +1369,9 @@ static bf16_t* gemm256p_zero16() {
     return z;
 }
 
-// GemmParams::sched of a launch: bit 3 = adapter K tiles on the general staging path, bit 4 = serial epilogue order (both A/B switches,
-// vlr_gemm_set_sched / VLR_GEMM_SCHED; 0 in production)
-static void sched_prepare(GemmParams& p) { p.sched = vlr_gemm_sched_mode() & 24; }
+// GemmParams::sched of a launch: bit 3 = adapter K tiles on the general staging path, bit 4 = serial epilogue order (both A/B switches),
+// bit 5 = the shared-panel tile map (vlr_gemm_set_sched / VLR_GEMM_SCHED; 32 in production)
+static void sched_prepare(GemmParams& p) { p.sched = vlr_gemm_sched_mode() & (24 | 32); }
 
 bool vlr_gemm256p_fused_try_launch(const GemmParams& p_in, hipStream_t stream) {
     GemmParams p = p_in;

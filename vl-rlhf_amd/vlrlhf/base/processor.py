@@ -78,21 +78,17 @@ class VLProcessor(ABC):
         Pinned by tests/golden/processor_answers.json["call"] (the reference's own method on the same tokenizer files).  Beyond the
         reference: a single string is accepted for `texts`, and padding=False returns the un-padded lists (the reference leaves its
         result unbound there)."""
-        assert texts is None or convs is None, "You can only pass texts or convs, not both."
-        if isinstance(texts, str):
-            texts = [texts]
-        if texts:
-            texts = list(texts)
-            if images_path is not None and check_format:
-                all_valid = True
-                for i in range(len(texts)):
-                    if not self.is_multimodal_prompt_valid(texts[i]):
-                        all_valid = False
-                        texts[i] = self.format_multimodal_prompt(texts[i], images_path[i])
-                if not all_valid:
-                    import warnings
-                    warnings.warn("You passed images, but your prompts are not in multimodal format. The image placeholder is added to "
-                                  "them automatically; prepare multimodal prompts in advance.")
+        if texts is not None and convs is not None:
+            raise AssertionError("You can only pass texts or convs, not both.")
+        texts = [texts] if isinstance(texts, str) else (list(texts) if texts else None)
+        if texts and images_path is not None and check_format:
+            # prompts that lack the image placeholder get it; one warning for the batch
+            lacking = [not self.is_multimodal_prompt_valid(t) for t in texts]
+            if any(lacking):
+                import warnings
+                texts = [self.format_multimodal_prompt(t, img) if bad else t for t, img, bad in zip(texts, images_path, lacking)]
+                warnings.warn("You passed images, but your prompts are not in multimodal format. The image placeholder is added to "
+                              "them automatically; prepare multimodal prompts in advance.")
         batch_conv = [self.make_single_turn_conv(text) for text in texts] if texts else convs
         if batch_conv is None:
             raise ValueError("texts and convs cannot be both None")

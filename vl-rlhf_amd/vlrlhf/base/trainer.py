@@ -559,6 +559,19 @@ class VLDPOTrainer:
         rows = rows[_rank()::w]
         was_training = self.model.training
         self.model.eval()
+        if self.generate_during_eval and rows:
+            # trl==0.8.1 DPOTrainer.evaluation_loop: ONE random eval batch is sampled from the policy and the reference and logged as a
+            # (prompt, policy, reference) table (wandb.Table there; a "game_log" entry of log_history + a rank-0 print here).  Every rank
+            # draws its own batch from its shard - no collective is involved.
+            import random
+            pick = random.sample(range(len(rows)), k=min(bs, len(rows)))
+            sample = self._prepare_inputs(self.data_collator([rows[i] for i in pick]))
+            policy_txt, ref_txt = self.get_batch_samples(self.model, sample)
+            table = [[pr, po[len(pr):], rf[len(pr):]] for pr, po, rf in zip(sample["prompt"], policy_txt, ref_txt)]
+            if _rank() == 0:
+                self.log_history.append({"game_log": {"columns": ["Prompt", "Policy", "Ref Model"], "rows": table}, "step": self.state.global_step})
+                for row in table:
+                    print({"prompt": row[0], "policy": row[1], "ref_model": row[2]}, flush=True)
         losses = []
         for i in range(0, len(rows), bs):
             loss, _, _ = self.prediction_step(self.model, self.data_collator(rows[i:i + bs]))
@@ -761,6 +774,12 @@ class VLDPOTrainer:
             step, micro = int(st["global_step"]), int(st["micro_step"])
             ep, skip = divmod(micro, n_batches)
             self.state.global_step = step
+        last_saved = [-1]
+
+        def save(step_, micro_, ep_):
+            last_saved[0] = step_
+            return self.save_checkpoint(step_, micro_, ep_)
+
         window = []           # device scalars; only read back at logging time (no per-step host sync)
         epoch_save_due = False
         while step < total:
@@ -793,28 +812,27 @@ class VLDPOTrainer:
                 if ev == "steps" and self.eval_dataset and step % max(1, int(getattr(a, "eval_steps", None) or logging_steps)) == 0:
                     self.evaluate()
                 if save_strategy == "steps" and step % save_steps == 0:
-                    self.save_checkpoint(step, micro, ep)
+                    save(step, micro, ep)
                 elif epoch_save_due:                    # the epoch ended inside an accumulation window: saved at the first optimizer step after it
-                    self.save_checkpoint(step, micro, ep)
+                    save(step, micro, ep)
                 epoch_save_due = False
                 if step >= total:
                     break
-            # HF saves at every epoch end incl. the last.  A checkpoint is only state at an optimizer-step boundary (a partly accumulated
-            # window is not): when the epoch ends inside a window the save is deferred to the next optimizer step (logged), and an epoch
-            # cut short by max_steps is not an epoch end
-            if save_strategy == "epoch" and step < total:
-                if micro % ga == 0:
-                    self.save_checkpoint(step, micro, ep)
+            # HF fires on_epoch_end - and with save_strategy="epoch" saves - at every epoch end INCLUDING the one training stops in, whether
+            # the epoch was consumed or max_steps cut it short (the loop leaves on an optimizer-step boundary in both cases).  A checkpoint is
+            # only state at such a boundary: an epoch that ends inside an accumulation window defers its save to the next optimizer step.
+            if save_strategy == "epoch":
+                if step >= total:
+                    if last_saved[0] != step:
+                        save(step, micro, ep)
+                elif micro % ga == 0:
+                    save(step, micro, ep)
                 else:
                     epoch_save_due = True
                     if _rank() == 0:
                         print(f"[vlrlhf] epoch {ep} ended inside an accumulation window ({micro % ga} of {ga} micro-batches): its checkpoint is written at optimizer step {step + 1}", flush=True)
-            elif save_strategy == "epoch" and micro % ga == 0 and micro == (ep + 1) * n_batches:      # the last epoch, fully consumed (not a max_steps break)
-                self.save_checkpoint(step, micro, ep)
             ep += 1
             skip = 0
-        if epoch_save_due and _rank() == 0:
-            print("[vlrlhf] warning: the last epoch ended inside an accumulation window; no checkpoint holds its partial window", flush=True)
         return self.state
 
     def save_state(self):
@@ -839,6 +857,13 @@ class VLDPOTrainer:
         others = dict(batch.get("img_input_dict", {}))
         kw = dict(input_ids=batch["prompt_input_ids"], attention_mask=batch["prompt_attention_mask"], max_length=self.max_length,
                   do_sample=True, pad_token_id=self.tokenizer.pad_token_id, **others)
+        # the stop token is the TOKENIZER's (Qwen-VL's HF config has no eos_token_id: its end token is tokenizer.eod_id; the model-side
+        # default of `generate` is LLaMA's id 2)
+        eos = getattr(self.tokenizer, "eos_token_id", None)
+        if eos is None:
+            eos = getattr(self.tokenizer, "eod_id", None)
+        if eos is not None:
+            kw["eos_token_id"] = eos
         policy_output = model.generate(**kw)
         if "reference_output" in batch:
             reference_output = batch["reference_output"]

@@ -56,14 +56,18 @@ class MyAutoDPOTrainer:
 
 
 def auto_load_rlmodel(script_args, training_args, lora_args):
-    """-> (model, ref_model=None, lora_config); vision tower frozen (reference :554-555).  With use_lora the LoraConfig of
+    """-> (model, ref_model=None, lora_config); vision tower frozen (reference :554-555; freeze_vision_tower=False raises).  With use_lora the LoraConfig of
     reference :559-571 is returned as a plain dict (peft itself is not needed: the trainer hands it to
     LlavaForRL.apply_lora); q_lora (GPTQ, reference :520-548) is not on the MI355X path."""
     if getattr(training_args, "use_lora", False) and getattr(lora_args, "q_lora", False):
         raise NotImplementedError("q_lora (GPTQ 4-bit base weights) is outside the MI355X DPO path")
+    if not getattr(script_args, "freeze_vision_tower", True):
+        # reference :554-555 would train the tower (dpo.py:54 --freeze_vision_tower False); the MI355X path has no ViT backward:
+        # refuse instead of silently training with a frozen tower
+        raise NotImplementedError("--freeze_vision_tower False: the MI355X DPO path has no vision-tower backward; the tower is frozen "
+                                  "in every shipped script of the reference (scripts/dpo_*.sh)")
     model = MyAutoModel.from_pretrained(script_args.model_name_or_path)
-    if getattr(script_args, "freeze_vision_tower", True):
-        model.freeze_vision_tower()
+    model.freeze_vision_tower()
     model.config.label_pad_token_id = script_args.label_pad_token_id
     model.config.use_cache = False
     lora_config = None
