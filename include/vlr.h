@@ -465,6 +465,14 @@ int vlr_comm_unique_id_bytes(void);
 const char* vlr_comm_library(void);   /* path of the RCCL library in use ("" + vlr_last_error() when none loads) */
 int vlr_comm_unique_id(void* id_host);
 int vlr_comm_init(const void* id_host, int rank, int world, void** comm_out);
+/* (ABI v8) ... with a PER-COMMUNICATOR bound on RCCL's channels (one channel = one workgroup of the ring kernel): ncclCommInitRankConfig
+ * with minCTAs / maxCTAs, so that the ring kernels fit the CUs vlr_set_comm_cus reserved without the process-wide NCCL_*_NCHANNELS
+ * environment (two communicators of one process may differ: bench.py measures one bucket bounded and unbounded).  max_ctas <= 0 = no
+ * bound (vlr_comm_init).  VLR_ERR_HIP when the loaded RCCL has no ncclCommInitRankConfig or rejects the configuration - the caller
+ * (vlrlhf/parallel.py NativeComm) then agrees with the other ranks and falls back to vlr_comm_init under the environment bound.
+ * vlr_comm_rccl_version: ncclGetVersion of the library in use (major * 10000 + minor * 100 + patch; 0: unknown). */
+int vlr_comm_init_cfg(const void* id_host, int rank, int world, int min_ctas, int max_ctas, void** comm_out);
+int vlr_comm_rccl_version(void);
 int vlr_comm_destroy(void* comm);
 int vlr_allreduce_bucket(void* comm, void* buf, long n, int dtype, vlr_stream_t stream);
 

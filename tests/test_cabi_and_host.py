@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(l, name), f"{name} declared in include/vlr.h but not exported by libvlr_hip.so"
     for name in _hip.exported_symbols():
         assert name in declared, f"{name} bound in _hip.py but not declared in include/vlr.h"
-    assert _hip.helper("vlr_abi_version") == 7
+    assert _hip.helper("vlr_abi_version") == 8
 
 
 def test_argument_errors_without_gpu():
@@ -306,17 +306,18 @@ def test_vlfeedback_pair_mining_matches_reference(tmp_path):
 
 
 def test_rccl_channel_bounds_follow_the_cu_reservation(monkeypatch):
-    """parallel.rccl_channel_env: NCCL_MAX_NCHANNELS = NCCL_MIN_NCHANNELS = VLR_COMM_CUS (default 16) in the environment the ranks are
-    launched with, unless the user set them; VLR_COMM_CUS=0 leaves RCCL alone"""
+    """parallel.rccl_channel_env: NCCL_MAX_NCHANNELS = VLR_COMM_CUS (default 16) in the environment the ranks are launched with, unless
+    the user set it (no floor is forced: NCCL_MIN_NCHANNELS stays the user's); VLR_COMM_CUS=0 leaves RCCL alone.  (The library's own
+    communicator carries the bound in its configuration - vlr_comm_init_cfg - and does not depend on this environment.)"""
     from vlrlhf import parallel as P
     monkeypatch.delenv("VLR_COMM_CUS", raising=False)
     e = {}
-    assert P.rccl_channel_env(e) == ("16", "16") and e == {"NCCL_MAX_NCHANNELS": "16", "NCCL_MIN_NCHANNELS": "16"}
-    e = {"NCCL_MAX_NCHANNELS": "8"}
-    assert P.rccl_channel_env(e) == ("8", "8")                      # the user's bound wins, the minimum never exceeds it
+    assert P.rccl_channel_env(e) == ("16", None) and e == {"NCCL_MAX_NCHANNELS": "16"}
+    e = {"NCCL_MAX_NCHANNELS": "8", "NCCL_MIN_NCHANNELS": "junk"}
+    assert P.rccl_channel_env(e) == ("8", "junk")                   # the user's values win and are never parsed
     monkeypatch.setenv("VLR_COMM_CUS", "24")
     e = {}
-    assert P.rccl_channel_env(e) == ("24", "24")
+    assert P.rccl_channel_env(e) == ("24", None)
     monkeypatch.setenv("VLR_COMM_CUS", "0")
     e = {}
     assert P.rccl_channel_env(e) == (None, None) and e == {}
@@ -341,3 +342,19 @@ def test_sampling_filter_follows_the_logits_warpers():
         want[order[:n_keep]] = True
         assert torch.equal(torch.isfinite(out[b]), want), b
     assert bool(torch.isfinite(sampling_filter(logits, 1.0, 1, 0.01)).sum(-1).eq(1).all())       # one token always survives
+
+
+def test_sampling_filter_matches_the_hf_warpers():
+    """... and against transformers' OWN TemperatureLogitsWarper / TopKLogitsWarper / TopPLogitsWarper run in the build container
+    (oracle/make_golden_sampling.py -> tests/golden/sampling_warpers.json): the same tokens survive (ties included) with the same scores"""
+    import json
+    from vlrlhf.models.Llava import sampling_filter
+    G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "sampling_warpers.json")))
+    logits = torch.tensor(G["logits"], dtype=torch.float32)
+    assert len(G["cases"]) >= 8
+    for c in G["cases"]:
+        out = sampling_filter(logits.clone(), c["temperature"], c["top_k"], c["top_p"])
+        kept = torch.tensor(c["kept"], dtype=torch.bool)
+        assert torch.equal(torch.isfinite(out), kept), (c["temperature"], c["top_k"], c["top_p"])
+        want = torch.tensor([[v if v is not None else 0.0 for v in row] for row in c["scores"]], dtype=torch.float32)
+        assert torch.allclose(out[kept], want[kept], rtol=1e-6, atol=1e-6), (c["temperature"], c["top_k"], c["top_p"])

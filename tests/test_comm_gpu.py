@@ -20,6 +20,8 @@ def test_comm_entry_points_report_argument_errors_without_gpu():
     assert l.vlr_comm_init(buf, 3, 2, C.byref(comm)) == 1 and b"outside world" in l.vlr_last_error()
     assert l.vlr_allreduce_bucket(None, None, 8, 0, None) == 1 and b"communicator" in l.vlr_last_error()
     assert l.vlr_comm_destroy(None) == 0
+    assert l.vlr_comm_init_cfg(None, 0, 1, 0, 16, None) == 1
+    assert l.vlr_comm_init_cfg(buf, 0, 1, 20, 16, C.byref(comm)) == 1 and b"min_ctas" in l.vlr_last_error()
 
 
 @pytest.mark.gpu
@@ -46,6 +48,27 @@ def test_single_rank_allreduce_through_the_c_abi():
 
 
 @pytest.mark.gpu
+def test_channel_bounded_communicator_through_the_c_abi():
+    """vlr_comm_init_cfg (ABI v8): the communicator takes its channel bound (ncclConfig_t maxCTAs, NCCL 2.18 layout) from the call, not
+    from the process environment - the RCCL loaded at run time (PyTorch's) accepts the configuration, and an all-reduce on it works"""
+    from vlrlhf import _hip
+    l = _hip.lib()
+    ver = _hip.helper("vlr_comm_rccl_version")
+    assert ver >= 21700, ver
+    buf = (C.c_ubyte * 128)()
+    assert l.vlr_comm_unique_id(buf) == 0, l.vlr_last_error()
+    comm = C.c_void_p()
+    assert l.vlr_comm_init_cfg(buf, 0, 1, 0, 16, C.byref(comm)) == 0, l.vlr_last_error()
+    x = torch.randn(1 << 20, device="cuda").bfloat16()
+    want = x.clone()
+    assert l.vlr_allreduce_bucket(comm, x.data_ptr(), x.numel(), 0, torch.cuda.current_stream().cuda_stream) == 0, l.vlr_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(x, want)
+    assert l.vlr_comm_destroy(comm) == 0
+    print(f"[comm] RCCL version {ver}: ncclCommInitRankConfig(maxCTAs = 16) accepted")
+
+
+@pytest.mark.gpu
 def test_native_comm_staged_construction_one_rank_nccl():
     """parallel.NativeComm on a real RCCL process group of one rank: the staged, collective construction (library check ->
     unique id with its ok flag -> join -> self-check) and an in-place bucket reduction on a side stream."""
@@ -58,6 +81,7 @@ def test_native_comm_staged_construction_one_rank_nccl():
     try:
         nc = NativeComm()
         assert "rccl" in nc.library and nc.world == 1
+        assert nc.channel_bound == "config" and nc.channels == 16, (nc.channel_bound, getattr(nc, "config_error", ""))
         g = torch.randn(1 << 22, device="cuda").bfloat16()
         want = g.clone()
         side = torch.cuda.Stream()

@@ -19,6 +19,8 @@ struct Api {
     void* handle = nullptr;
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitRankConfig)(ncclComm_t*, int, ncclUniqueId, int, void*) = nullptr;      // optional (NCCL >= 2.17)
+    ncclResult_t (*GetVersion)(int*) = nullptr;                                                    // optional
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -64,6 +66,8 @@ int load_api() {
     SYM(AllReduce, "ncclAllReduce");
     SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
+    g_api.CommInitRankConfig = (decltype(g_api.CommInitRankConfig))dlsym(h, "ncclCommInitRankConfig");
+    g_api.GetVersion = (decltype(g_api.GetVersion))dlsym(h, "ncclGetVersion");
     g_api.handle = h;
     return VLR_OK;
 }
@@ -101,6 +105,42 @@ extern "C" int vlr_comm_init(const void* id_host, int rank, int world, void** co
     if (r != ncclSuccess) return nccl_fail("vlr_comm_init", r);
     *comm_out = (void*)c;
     return VLR_OK;
+}
+
+// The same with a PER-COMMUNICATOR bound on the channels (= workgroups of the ring kernel; ncclConfig_t::minCTAs / maxCTAs, NCCL >= 2.17):
+// the DPO step leaves `comm_cus` CUs to the ring kernels (vlr_set_comm_cus) and the communicator is told to use exactly that many - without
+// the process-wide NCCL_MAX_NCHANNELS / NCCL_MIN_NCHANNELS environment, so that two communicators of one process (bench.py's bucket probe:
+// bounded and unbounded side by side) can differ.  max_ctas <= 0: no bound (= vlr_comm_init).  The configuration is passed in the layout
+// of NCCL 2.18 (size / magic / version header + blocking, cgaClusterSize, minCTAs, maxCTAs, netName, splitShare), which every later
+// library accepts by its version field - the RCCL that is loaded at run time (PyTorch's) need not be the one whose header was compiled
+// against.  VLR_ERR_HIP with "no ncclCommInitRankConfig" when the loaded library has no such entry: the caller falls back to the environment.
+extern "C" int vlr_comm_init_cfg(const void* id_host, int rank, int world, int min_ctas, int max_ctas, void** comm_out) {
+    if (max_ctas <= 0) return vlr_comm_init(id_host, rank, world, comm_out);
+    VLR_REQUIRE(id_host && comm_out, "vlr_comm_init_cfg: null argument");
+    VLR_REQUIRE(world >= 1 && rank >= 0 && rank < world, "vlr_comm_init_cfg: rank %d outside world %d", rank, world);
+    VLR_REQUIRE(min_ctas >= 0 && min_ctas <= max_ctas, "vlr_comm_init_cfg: min_ctas %d max_ctas %d", min_ctas, max_ctas);
+    int rc = load_api();
+    if (rc != VLR_OK) return rc;
+    if (!g_api.CommInitRankConfig) {
+        vlr_set_error("vlr_comm_init_cfg: %s has no ncclCommInitRankConfig", g_api.path);
+        return VLR_ERR_HIP;
+    }
+    struct Cfg218 { size_t size; unsigned int magic; unsigned int version; int blocking; int cgaClusterSize; int minCTAs; int maxCTAs; const char* netName; int splitShare; };
+    const int UNDEF = (int)0x80000000;       // NCCL_CONFIG_UNDEF_INT (INT_MIN)
+    Cfg218 cfg = {sizeof(Cfg218), 0xcafebeefu, 21800u, UNDEF, UNDEF, min_ctas > 0 ? min_ctas : UNDEF, max_ctas, nullptr, UNDEF};
+    ncclUniqueId id;
+    memcpy(&id, id_host, sizeof(id));
+    ncclComm_t c = nullptr;
+    ncclResult_t r = g_api.CommInitRankConfig(&c, world, id, rank, &cfg);
+    if (r != ncclSuccess) return nccl_fail("vlr_comm_init_cfg", r);
+    *comm_out = (void*)c;
+    return VLR_OK;
+}
+// version code of the RCCL library in use (ncclGetVersion: major * 10000 + minor * 100 + patch), 0 when it cannot be asked
+extern "C" int vlr_comm_rccl_version(void) {
+    int v = 0;
+    if (load_api() != VLR_OK || !g_api.GetVersion || g_api.GetVersion(&v) != ncclSuccess) return 0;
+    return v;
 }
 
 extern "C" int vlr_comm_destroy(void* comm) {

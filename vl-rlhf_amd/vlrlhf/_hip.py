@@ -161,6 +161,8 @@ _INT_HELPERS = {
     "vlr_comm_unique_id_bytes": [],
     "vlr_comm_unique_id": [P],
     "vlr_comm_init": [P, I, I, P],
+    "vlr_comm_init_cfg": [P, I, I, I, I, P],
+    "vlr_comm_rccl_version": [],
     "vlr_comm_destroy": [P],
 }
 

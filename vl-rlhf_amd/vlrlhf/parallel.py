@@ -6,17 +6,19 @@ all-reduce; the 1/world_size is folded into the optimizer's gradient scale, so n
 
 Two transports for the same buckets:
   * "native"  - vlr_allreduce_bucket of libvlr_hip.so (include/vlr.h): RCCL called straight from the C ABI on our comm
-                stream; the unique id travels through torch.distributed once at start-up.  It is verified with a known
-                all-reduce before it is trusted; if RCCL cannot be loaded / initialised the reducer says so and uses
-  * "torch"   - torch.distributed all_reduce (backend "nccl" IS RCCL on ROCm; "gloo" for the CPU tests).
-VLR_COMM=torch selects torch.distributed; with any other value a native transport that cannot be initialised RAISES on every rank (round 4:
-no silent fallback - a multi-GPU run whose transport is not the one that was measured should not produce a number).
+                stream; the unique id travels through torch.distributed once at start-up, and the communicator is verified
+                with a known all-reduce before it is trusted.  The default.
+  * "torch"   - torch.distributed all_reduce (backend "nccl" IS RCCL on ROCm; "gloo" for the CPU tests).  VLR_COMM=torch.
+A native transport that cannot be initialised RAISES on every rank (the stages of NativeComm agree on success / failure among the
+ranks, so nobody is left inside a collective): a multi-GPU run whose transport is not the one that was asked for should not silently
+produce a number.  bench.py catches that error, says so in its JSON line and measures on the "torch" transport instead.
 
 CUs for RCCL: the ring kernels of RCCL run one workgroup per CHANNEL beside the backward.  The persistent GEMM / attention launches leave
-`comm_cus` CUs free (vlr_set_comm_cus; VLR_COMM_CUS, default 16 = two per XCD), and rccl_channel_env() bounds RCCL to exactly that many
-channels (NCCL_MAX_NCHANNELS = NCCL_MIN_NCHANNELS = comm_cus, set before any communicator - torch's or ours - is created), so that the
-ring kernels fit the reservation instead of displacing persistent workgroups (which cost 13 % of the step in the single-GPU
-interference bench, profiles/r03_comm_cus_interference_1gpu.txt)."""
+`comm_cus` CUs free (vlr_set_comm_cus; VLR_COMM_CUS, default 16 = two per XCD) and RCCL is bounded to that many channels so that the ring
+kernels fit the reservation instead of displacing persistent workgroups (13 % of the step in the single-GPU interference bench,
+profiles/r03_comm_cus_interference_1gpu.txt): our own communicator PER COMMUNICATOR (vlr_comm_init_cfg: ncclConfig_t maxCTAs / minCTAs,
+ABI v8), torch's through the process-wide NCCL_MAX_NCHANNELS (rccl_channel_env(), set before the first communicator exists; only the
+maximum is forced - a floor would take CUs the reservation does not cover)."""
 import ctypes as C
 import os
 import subprocess
@@ -32,13 +34,13 @@ def comm_cus_default() -> int:
 
 
 def rccl_channel_env(env=None, comm_cus=None):
-    """NCCL_MAX_NCHANNELS / NCCL_MIN_NCHANNELS := comm_cus (unless the user set them) in `env` (default os.environ).  Must run before
-    the first RCCL communicator of the process is created.  Returns the (max, min) strings in effect."""
+    """NCCL_MAX_NCHANNELS := comm_cus (unless the user set it) in `env` (default os.environ) - the bound on every communicator of the
+    process that is not created through vlr_comm_init_cfg (torch.distributed's).  Must run before the first RCCL communicator of the
+    process is created.  Returns the (max, min) strings in effect (min only when the user exported one)."""
     e = os.environ if env is None else env
     k = comm_cus_default() if comm_cus is None else comm_cus
     if k > 0:
         e.setdefault("NCCL_MAX_NCHANNELS", str(k))
-        e.setdefault("NCCL_MIN_NCHANNELS", str(min(k, int(e["NCCL_MAX_NCHANNELS"]))))
     return e.get("NCCL_MAX_NCHANNELS"), e.get("NCCL_MIN_NCHANNELS")
 
 
@@ -54,10 +56,13 @@ class NativeComm:
     rank can never leave the others blocked inside ncclCommInitRank: (1) every rank loads RCCL through the library and the ranks
     agree that all could; (2) rank 0 creates the unique id and its success travels with the id; only then (3) all ranks join."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, channels: Optional[int] = None):
+        """channels: bound of this communicator's RCCL channels (= ring-kernel workgroups); None = comm_cus_default(), 0 = unbounded"""
         from . import _hip
         self._hip = _hip
         self.comm = None
+        self.channels = comm_cus_default() if channels is None else int(channels)
+        self.channel_bound = "none"           # how the bound reached RCCL: "config" (ncclConfig_t maxCTAs) | "env" (NCCL_MAX_NCHANNELS) | "none"
         l = _hip.lib()
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         dev = torch.device("cuda", torch.cuda.current_device())
@@ -80,11 +85,40 @@ class NativeComm:
         host_id = idt.cpu()
         if int(host_id[0]) != 1:
             raise _hip.VlrError(f"rank 0 could not create an RCCL unique id ({err or 'see rank 0'})")
-        # (3) join
+        # (3) join - with the channel bound in the communicator's own configuration; a library that does not take it (no
+        # ncclCommInitRankConfig / configuration rejected: an argument error, raised before any rank talks to another) makes ALL ranks
+        # fall back to the plain call under the process-wide NCCL_MAX_NCHANNELS
         host = (C.c_ubyte * nbytes).from_buffer_copy(bytes(host_id[1:].numpy().tobytes()))
         comm = C.c_void_p()
-        rc = l.vlr_comm_init(host, self.rank, self.world, C.byref(comm))
-        err = "" if rc == 0 else l.vlr_last_error().decode()
+        rc, err = 1, ""
+        if self.channels > 0 and os.environ.get("VLR_COMM_CONFIG", "1") != "0":
+            rc = l.vlr_comm_init_cfg(host, self.rank, self.world, 0, self.channels, C.byref(comm))
+            err = "" if rc == 0 else l.vlr_last_error().decode()
+            if _all_ok(rc == 0, group):
+                self.channel_bound = "config"
+            else:
+                if rc == 0:
+                    l.vlr_comm_destroy(comm)
+                    comm = C.c_void_p()
+                rc = 1
+                # a new id: the first one may have been consumed by the ranks whose call went through
+                idt.zero_()
+                if self.rank == 0:
+                    buf = (C.c_ubyte * nbytes)()
+                    if l.vlr_comm_unique_id(buf) == 0:
+                        idt[0] = 1
+                        idt[1:].copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
+                dist.broadcast(idt, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                host_id = idt.cpu()
+                if int(host_id[0]) != 1:
+                    raise _hip.VlrError("rank 0 could not create a second RCCL unique id")
+                host = (C.c_ubyte * nbytes).from_buffer_copy(bytes(host_id[1:].numpy().tobytes()))
+                self.config_error = err or "on another rank"
+        if rc != 0:
+            if self.channels > 0:
+                self.channel_bound = "env" if os.environ.get("NCCL_MAX_NCHANNELS") == str(self.channels) else "none"
+            rc = l.vlr_comm_init(host, self.rank, self.world, C.byref(comm))
+            err = "" if rc == 0 else l.vlr_last_error().decode()
         if rc == 0:
             self.comm = comm
         if not _all_ok(rc == 0, group):
@@ -122,8 +156,7 @@ def make_transport(group=None, cuda=True):
     if dist.get_backend(group) != "nccl":       # e.g. gloo ranks sharing one GPU in the tests: RCCL refuses duplicate devices
         return None, "torch", f"process group backend is {dist.get_backend(group)}"
     # NativeComm's stages are collective and agree on success / failure among themselves: every rank either returns a working
-    # communicator or raises
-    # communicator or raises - and a failure is FATAL (set VLR_COMM=torch to run on torch.distributed's RCCL communicator instead)
+    # communicator or raises - and a failure is FATAL here (VLR_COMM=torch runs on torch.distributed's RCCL communicator instead)
     comm = NativeComm(group)
     return comm, "native", comm.library
 
@@ -146,7 +179,8 @@ class GradReducer:
         # comm_interference.py, DESIGN.md section 5: a 16-workgroup stand-in for the ring kernel cost 13 % of the step against
         # 256-workgroup launches and 5.5 % against 240-workgroup ones); VLR_COMM_CUS overrides, 0 switches it off.
         self.comm_cus = 0
-        self.rccl_channels = (os.environ.get("NCCL_MAX_NCHANNELS"), os.environ.get("NCCL_MIN_NCHANNELS"))      # what RCCL was bounded to
+        self.rccl_channels = (os.environ.get("NCCL_MAX_NCHANNELS"), os.environ.get("NCCL_MIN_NCHANNELS"))      # the process-wide bound (torch's communicator)
+        self.channel_bound = self.native.channel_bound if self.native is not None else ("env" if os.environ.get("NCCL_MAX_NCHANNELS") else "none")
         if self.cuda and self.world > 1:
             from . import _hip
             self.comm_cus = comm_cus_default()
