@@ -157,6 +157,81 @@ def cpu_baseline(budget_s=30.0):
                        f"extrapolated full step {step_s:.0f} s")
 
 
+def rccl_debug_setup():
+    """before the first communicator of a multi-rank run: RCCL's INIT log of this process goes to a file of its own, so that the line can
+    quote the channel counts RCCL ACTUALLY created (not the ones it was asked for).  The user's NCCL_DEBUG settings win."""
+    if "NCCL_DEBUG" in os.environ or "NCCL_DEBUG_FILE" in os.environ:
+        return os.environ.get("NCCL_DEBUG_FILE")
+    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"vlr_rccl_init_{os.getpid()}.log")
+    os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT", NCCL_DEBUG_FILE=path)
+    return path
+
+
+def rccl_debug_channels(path):
+    """channel counts of the communicators this process created so far, in creation order, from RCCL's INIT log ("N coll channels" of
+    init.cc; else the denominators of the "Channel i/N" ring listing); [] when the log says nothing"""
+    import re
+    try:
+        text = open(path).read() if path else ""
+    except OSError:
+        return []
+    got = [int(m) for m in re.findall(r"(\d+) coll channels", text)]
+    if not got:
+        seen = []
+        for m in re.finditer(r"Channel \d+/(\d+)\s*:", text):
+            if not seen or seen[-1] != int(m.group(1)):
+                seen.append(int(m.group(1)))
+        got = seen
+    return got
+
+
+def bucket_probe(world, rank, make_comm, numel, dtype, device, bounds, log_path=None, iters=5):
+    """all-reduce bus bandwidth of ONE gradient bucket (a decoder layer of the 7B model = 0.4 GB of bf16) in front of the timed region, on a
+    communicator of its own per channel bound in `bounds` (0 = RCCL's default) - a single scaling run then says whether the bound that
+    keeps the ring kernels inside the reserved CUs starves xGMI.  make_comm(bound) -> object with all_reduce_(tensor, stream) and close().
+    busbw = algbw x 2 (n - 1) / n (the per-link figure of a ring)."""
+    out = []
+    buf = torch.zeros(numel, dtype=dtype, device=device)
+    cuda = buf.is_cuda
+    for bound in bounds:
+        rec = {"channel_bound": bound}
+        try:
+            comm = make_comm(bound)
+            st = torch.cuda.current_stream() if cuda else None
+            comm.all_reduce_(buf, st)                       # warm-up (connection set-up)
+            if cuda:
+                torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.time()
+            for _ in range(iters):
+                comm.all_reduce_(buf, st)
+            if cuda:
+                torch.cuda.synchronize()
+            t = torch.tensor([(time.time() - t0) / iters], device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            sec = float(t)
+            gb = buf.numel() * buf.element_size() / 1e9
+            rec.update(ms=round(sec * 1e3, 3), bytes=buf.numel() * buf.element_size(), algbw_gbps=round(gb / sec, 1),
+                       busbw_gbps=round(gb / sec * 2 * (world - 1) / world, 1), bound_via=getattr(comm, "channel_bound", None),
+                       channels_created=(rccl_debug_channels(log_path) or [None])[-1])
+            comm.close()
+        except Exception as e:      # noqa: BLE001 - a probe must never take the bench down (NativeComm fails on every rank or on none)
+            rec["error"] = str(e)[:300]
+        out.append(rec)
+    return out
+
+
+class _TorchComm:
+    """the probe's view of torch.distributed's own communicator (gloo in the CPU dry run)"""
+    channel_bound = "process group"
+
+    def all_reduce_(self, t, stream):
+        dist.all_reduce(t)
+
+    def close(self):
+        pass
+
+
 def dry_run_launch(a):
     """CPU-only skeleton of the multi-rank bench (tests/test_bench_launch.py): process group from the launcher's env, the
     barrier / max-over-ranks timing, the metric all-reduce and the ONE JSON line - with a no-op step."""
@@ -173,10 +248,11 @@ def dry_run_launch(a):
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     mean_rank = all_reduce_mean_scalars([float(rank)])[0]
+    probe = bucket_probe(world, rank, lambda bound: _TorchComm(), 1 << 18, torch.float32, "cpu", (0, 16), iters=2) if world > 1 else None
     if rank == 0:
         print(json.dumps({"metric": "dry-run (launcher path only)", "value": 0.0, "unit": "pairs/s", "n_gpus": world, "steps": a.steps,
                           "warmup": a.warmup, "ms_per_step": round(float(tmax) / max(1, a.steps) * 1e3, 3), "rccl_ranks": world,
-                          "mean_rank": mean_rank, "INVALID": "dry run"}), flush=True)
+                          "mean_rank": mean_rank, "comm": {"bucket_probe": probe}, "INVALID": "dry run"}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -202,6 +278,8 @@ def main():
     ap.add_argument("--loss_type", default=None)
     ap.add_argument("--dry_run_launch", action="store_true", help="CPU test of the self-launch path: no model, gloo, no-op steps")
     ap.add_argument("--gradient_checkpointing", action="store_true", help="variant: keep only the layer inputs, re-run each layer's forward in the backward (reference scripts' --gradient_checkpointing True)")
+    ap.add_argument("--fresh_batches", action="store_true", help="SURVEY 8f-3: every step takes a NEW batch from the input pipeline (JPEG files -> PIL decode + CLIP preprocess in the collator, "
+                    "background prefetch, pinned H2D copy, un-memoised concatenated_inputs) instead of rotating four resident ones; reports the host ms per batch")
     ap.add_argument("--lr", type=float, default=2e-8, help="learning rate of the timed steps (kernel arithmetic does not depend on it)")
     a = ap.parse_args()
 
@@ -218,6 +296,7 @@ def main():
     from vlrlhf.utils.synthetic import LLAVA_1_5_7B, init_random_model, synthetic_batch
     from types import SimpleNamespace
 
+    rccl_log = rccl_debug_setup() if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None
     rank, local, world = init_distributed_from_env()
     assert world == max(1, a.gpus), f"--gpus {a.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
@@ -261,7 +340,21 @@ def main():
         tr = Trainer(model, None if a.precomputed_ref else ref, 0.1, 0, loss_type, args, None, -100, pad_id,
                      precompute_ref_log_probs=a.precomputed_ref)
     eng.init_optimizer()
-    reducer = eng.make_reducer() if world > 1 else None
+    reducer, transport_fallback, probe = None, None, None
+    if world > 1:
+        from vlrlhf.parallel import NativeComm, comm_cus_default
+        try:
+            reducer = eng.make_reducer()
+        except _hip.VlrError as e:      # the native transport failed on EVERY rank (its stages agree): measure on torch.distributed's RCCL, and say so
+            transport_fallback = str(e)[:300]
+            os.environ["VLR_COMM"] = "torch"
+            reducer = eng.make_reducer()
+        # one 0.4 GB bucket (a decoder layer's gradients) on communicators of their own: RCCL's default channel count against the bound
+        # that matches the CU reservation
+        n_bucket = 4 * cfg["hidden"] * cfg["hidden"] + 3 * cfg["hidden"] * cfg["inter"]
+        mk = (lambda bound: NativeComm(channels=bound)) if reducer.transport == "native" else (lambda bound: _TorchComm())
+        probe = bucket_probe(world, rank, mk, n_bucket, torch.bfloat16, eng.dev, (0, comm_cus_default()) if reducer.transport == "native" else (comm_cus_default(),),
+                             log_path=rccl_log)
     tr.ref_on_side_stream = not a.no_side_stream
     if a.ref_pipeline:
         tr.ref_pipeline = True
@@ -280,11 +373,61 @@ def main():
         batches.append(b_)
     hp = dict(lr=a.lr, beta1=0.9, beta2=0.98, eps=1e-6, weight_decay=0.0, max_grad_norm=1.0)   # scripts/dpo_llava.sh:35-41 (lr: see docstring)
     n_step = [0]
+    fresh = None
+    if a.fresh_batches:
+        # the reference's per-step host work (its collator runs on the training thread: models/Llava/__init__.py:435-443, base/collator.py:26-68):
+        # image files on disk -> PIL decode -> CLIP resize / crop / normalise -> padded tensors -> pinned -> H2D, here `dataloader_prefetch` = 2
+        # batches ahead on a background thread (base/loader.py).  Tokenised rows as `dataset.map(tokenize_row)` leaves them.
+        assert a.model == "llava" and not a.precomputed_ref, "--fresh_batches: the LLaVA-1.5 pipeline (the headline configuration)"
+        import tempfile
+        import numpy as np
+        from PIL import Image
+        from transformers import CLIPImageProcessor
+        from vlrlhf.base.loader import PrefetchLoader
+        from vlrlhf.models.Llava import LlavaDPODataCollatorWithPadding
+        tmpd = tempfile.mkdtemp(prefix="vlr_fresh_")
+        rng = np.random.Generator(np.random.PCG64(99 + rank))
+        n_img = 64
+        for i in range(n_img):         # VLFeedback-like photographs: 640 x 480 JPEG (smooth content + noise, ~100 KB each)
+            base_ = rng.integers(0, 255, size=(15, 20, 3)).astype(np.uint8)
+            im = Image.fromarray(base_).resize((640, 480), Image.BICUBIC)
+            arr = np.clip(np.asarray(im).astype(np.int16) + rng.integers(-12, 12, size=(480, 640, 3)), 0, 255).astype(np.uint8)
+            Image.fromarray(arr).save(os.path.join(tmpd, f"{i}.jpg"), quality=90)
+        ip = CLIPImageProcessor(size={"shortest_edge": cfg["image_size"]}, crop_size={"height": cfg["image_size"], "width": cfg["image_size"]})
+        coll = LlavaDPODataCollatorWithPadding(pad_token_id=0, label_pad_token_id=-100, processor=SimpleNamespace(image_processor=ip))
+        n_need = a.warmup + a.steps + 4
+
+        def row_batches():
+            g_ = np.random.Generator(np.random.PCG64(777 + rank))
+            lp = a.text_len // 2
+            for b in range(n_need):
+                rows = []
+                for j in range(a.pairs):
+                    prompt = g_.integers(3, 32000, size=lp).tolist()
+                    prompt[0], prompt[4] = 1, cfg["image_token"]
+                    resp = [g_.integers(3, 32000, size=a.text_len - lp).tolist() for _ in range(2)]
+                    rows.append(dict(prompt_input_ids=prompt, prompt_attention_mask=[1] * lp, chosen_input_ids=prompt + resp[0],
+                                     chosen_attention_mask=[1] * a.text_len, chosen_labels=[-100] * lp + resp[0],
+                                     rejected_input_ids=prompt + resp[1], rejected_attention_mask=[1] * a.text_len,
+                                     rejected_labels=[-100] * lp + resp[1], img_path=os.path.join(tmpd, f"{(b * a.pairs + j) % n_img}.jpg")))
+                yield rows
+        # host cost of ONE batch, inline and single-threaded (what the reference pays on its training thread every step)
+        first_rows = next(iter(row_batches()))
+        t_h = time.time()
+        for _ in range(3):
+            coll(first_rows)
+        host_ms = (time.time() - t_h) / 3 * 1e3
+        fresh = dict(it=iter(PrefetchLoader(row_batches, coll, eng.dev, depth=2)), host_ms_per_batch=round(host_ms, 1), files=n_img, dir=tmpd)
 
     def step():
-        loss = tr.training_step(model, batches[n_step[0] % len(batches)])
+        if fresh is not None:
+            batch_ = tr._prepare_inputs(next(fresh["it"]))
+        else:
+            batch_ = batches[n_step[0] % len(batches)]
+        loss = tr.training_step(model, batch_)
         # as VLDPOTrainer.train does; a no-op unless the reference pipeline is switched on (--ref_pipeline / VLR_REF_PIPELINE=1)
-        tr.prefetch_reference(batches[(n_step[0] + 1) % len(batches)])
+        if fresh is None:
+            tr.prefetch_reference(batches[(n_step[0] + 1) % len(batches)])
         eng.optimizer_step(grad_scale=1.0 / world, **hp)
         n_step[0] += 1
         return loss
@@ -383,7 +526,10 @@ def main():
                                    + ("reference log-probs precomputed" if a.precomputed_ref else
                                       "one reference forward per step" + (", issued for the next batch under the update (prefetch_reference)" if tr.ref_pipeline else ", inside the step")),
                        "global_batch_pairs": world * a.pairs, "text_len": a.text_len, "parallelism": f"dp{world}",
-                       "layers": cfg["layers"], "lr": a.lr, "resident_batches": len(batches), "loss_first_step": loss_first,
+                       "layers": cfg["layers"], "lr": a.lr, "resident_batches": 0 if fresh is not None else len(batches),
+                       "fresh_batches": None if fresh is None else {"host_ms_per_batch_inline": fresh["host_ms_per_batch"], "jpeg_files": fresh["files"], "prefetch_depth": 2,
+                                                                     "pipeline": "640x480 JPEG -> PIL decode -> CLIPImageProcessor(336) -> LlavaDPODataCollatorWithPadding -> pinned -> copy-stream H2D -> _prepare_inputs -> un-memoised concatenated_inputs, a NEW batch every step (SURVEY 8f-3)"},
+                       "loss_first_step": loss_first,
                        "loss_last_step": loss_last, "grad_norm_last_step": float(eng.norm_out[0]),
                        "residual_stream": "fp32" if eng.resid_f32 else "bf16", "gradient_checkpointing": bool(eng.gradient_checkpointing),
                        "peak_allocated_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},      # every device buffer of the path is a torch allocation
@@ -392,8 +538,12 @@ def main():
                      "library": (reducer.transport_note if reducer is not None and reducer.transport == "native" else
                                  ("torch.distributed backend " + dist.get_backend()) if world > 1 else None),
                      "transport_note": reducer.transport_note if reducer is not None else None,     # why the native transport was not used, when it was not
+                     "native_transport_error": transport_fallback,       # non-null: vlr_comm_* could not be initialised and the line was measured on torch.distributed's communicator
+                     "channel_bound_via": reducer.channel_bound if reducer is not None else None,     # "config" = ncclConfig_t maxCTAs of our communicator, "env" = NCCL_MAX_NCHANNELS
+                     "rccl_channels_created": rccl_debug_channels(rccl_log) if world > 1 else None,     # per communicator of rank 0 in creation order (torch's, ours, the probe's), from RCCL's own INIT log
+                     "bucket_probe": probe,
                      "comm_cus": reducer.comm_cus if reducer is not None else 0, "compute_cus": _hip.helper("vlr_compute_cus"),
-                     "rccl_max_min_nchannels": list(reducer.rccl_channels) if reducer is not None else None,     # NCCL_MAX / MIN_NCHANNELS := comm_cus (parallel.rccl_channel_env)
+                     "rccl_max_min_nchannels": list(reducer.rccl_channels) if reducer is not None else None,     # NCCL_MAX_NCHANNELS := comm_cus for torch's communicator (parallel.rccl_channel_env); MIN only if the user set it
                      "exposed_ms_per_step": exposed_ms, "bytes_per_step": 2 * (eng.lora_layout.numel if a.lora else eng.layout.numel)},
             "roofline": {"bound": "mfma", "kernel": "gemm256p_kernel<A_KS,B_KS> (8-phase 256x256x64 bf16 GEMM: NT/NN/TN)", "achieved": round(achieved, 1),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
@@ -444,6 +594,10 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
+    if fresh is not None:
+        import shutil
+        fresh["it"].close()                 # stops the prefetch thread
+        shutil.rmtree(fresh["dir"], ignore_errors=True)
     if world > 1:
         dist.barrier()
         if reducer is not None and reducer.native is not None:

@@ -27,6 +27,31 @@ def test_bench_self_launches_two_ranks():
     assert abs(line["mean_rank"] - 0.5) < 1e-9          # the metric all-reduce saw both ranks
 
 
+def test_bench_self_launches_eight_ranks():
+    """the driver's largest scaling point, as far as a CPU can take it: 8 gloo ranks through the same self-launch, barrier / max-over-ranks
+    timing, metric all-reduce and bucket probe (bound 0 and 16: two records), ONE JSON line"""
+    line = _run(["--gpus", "8", "--steps", "2", "--warmup", "1", "--dry_run_launch"], env={"OMP_NUM_THREADS": "1"})
+    assert line["n_gpus"] == 8 and line["rccl_ranks"] == 8
+    assert abs(line["mean_rank"] - 3.5) < 1e-9
+    probe = line["comm"]["bucket_probe"]
+    assert [p["channel_bound"] for p in probe] == [0, 16] and all("error" not in p and p["busbw_gbps"] > 0 for p in probe), probe
+
+
+def test_rccl_init_log_parsing(tmp_path):
+    """bench.rccl_debug_channels reads the channel counts RCCL says it created, per communicator, from its INIT log"""
+    sys.path[:0] = [ROOT]
+    import importlib
+    bench = importlib.import_module("bench")
+    log = tmp_path / "rccl.log"
+    log.write_text("h:1:1 [0] NCCL INFO comm 0x1 rank 0 nRanks 8 nNodes 1 localRanks 8 localRank 0 MNNVL 0\n"
+                   "h:1:1 [0] NCCL INFO 32 coll channels, 0 collnet channels, 0 nvls channels, 32 p2p channels, 4 p2p channels per peer\n"
+                   "h:1:1 [0] NCCL INFO 16 coll channels, 0 collnet channels, 0 nvls channels, 16 p2p channels, 2 p2p channels per peer\n")
+    assert bench.rccl_debug_channels(str(log)) == [32, 16]
+    log.write_text("NCCL INFO Channel 00/24 : 0 1 2 3\nNCCL INFO Channel 01/24 : 0 1 2 3\nNCCL INFO Channel 00/16 : 0 1\n")
+    assert bench.rccl_debug_channels(str(log)) == [24, 16]
+    assert bench.rccl_debug_channels(str(tmp_path / "missing")) == [] and bench.rccl_debug_channels(None) == []
+
+
 def test_bench_single_rank_needs_no_launcher():
     line = _run(["--gpus", "1", "--steps", "2", "--warmup", "0", "--dry_run_launch"])
     assert line["n_gpus"] == 1

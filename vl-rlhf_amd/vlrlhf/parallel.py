@@ -17,8 +17,8 @@ CUs for RCCL: the ring kernels of RCCL run one workgroup per CHANNEL beside the 
 `comm_cus` CUs free (vlr_set_comm_cus; VLR_COMM_CUS, default 16 = two per XCD) and RCCL is bounded to that many channels so that the ring
 kernels fit the reservation instead of displacing persistent workgroups (13 % of the step in the single-GPU interference bench,
 profiles/r03_comm_cus_interference_1gpu.txt): our own communicator PER COMMUNICATOR (vlr_comm_init_cfg: ncclConfig_t maxCTAs / minCTAs,
-ABI v8), torch's through the process-wide NCCL_MAX_NCHANNELS (rccl_channel_env(), set before the first communicator exists; only the
-maximum is forced - a floor would take CUs the reservation does not cover)."""
+ABI v8), torch's - only when it carries the buckets, VLR_COMM=torch - through the process-wide NCCL_MAX_NCHANNELS (rccl_channel_env(), set
+before the first communicator exists; only the maximum is forced - a floor would take CUs the reservation does not cover)."""
 import ctypes as C
 import os
 import subprocess
@@ -246,7 +246,9 @@ def init_distributed_from_env(backend: Optional[str] = None):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (a launcher that did not export it: read when the HSA runtime starts, i.e. below)
     if torch.cuda.is_available():
         torch.cuda.set_device(local)
-        rccl_channel_env()               # before the first communicator (torch's process group, then NativeComm)
+        if os.environ.get("VLR_COMM", "auto").lower() == "torch":
+            rccl_channel_env()           # the buckets travel on torch's communicator: bound it, before it is created.  (Native transport: our
+                                         # communicator carries its bound in its own configuration and torch's only sees barriers and scalars.)
     if not dist.is_initialized():
         dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank, world_size=world)
     return rank, local, world
@@ -266,7 +268,7 @@ def relaunch_under_torchrun(script: str, argv, nproc: int, env=None) -> int:
     e = dict(os.environ if env is None else env)
     e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # the host driver only supports dmabuf IPC (RCCL needs it)
     e.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, nproc))))
-    if nproc > 1:
+    if nproc > 1 and e.get("VLR_COMM", "auto").lower() == "torch":
         rccl_channel_env(e)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), script] + list(argv)
