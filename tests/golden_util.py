@@ -59,11 +59,13 @@ MEASURED_TOL = {
 }
 
 
-def within(name, measured, tol=None):
+def within(name, measured, tol=None, default=None):
     """assert measured < tol; with VLR_MARGINS=<file> the (name, measured, tol) triple is appended to that file first - the tolerances of
-    the per-pair loss tests are 1.5 x what an MI355X run of the committed binary measured (profiles/r04_parity_margins.txt)"""
+    the per-pair loss tests are 1.5 x what an MI355X run of the committed binary measured (profiles/r04_parity_margins.txt,
+    profiles/r05_parity_margins.txt); `default`: the bound of a name that has no measured entry yet"""
     measured = float(measured)
-    tol = MEASURED_TOL[name] if tol is None else tol
+    tol = MEASURED_TOL.get(name, default) if tol is None else tol
+    assert tol is not None, f"no tolerance for {name}"
     f = os.environ.get("VLR_MARGINS")
     if f:
         with open(f, "a") as fh:

@@ -358,3 +358,56 @@ def test_sampling_filter_matches_the_hf_warpers():
         assert torch.equal(torch.isfinite(out), kept), (c["temperature"], c["top_k"], c["top_p"])
         want = torch.tensor([[v if v is not None else 0.0 for v in row] for row in c["scores"]], dtype=torch.float32)
         assert torch.allclose(out[kept], want[kept], rtol=1e-6, atol=1e-6), (c["temperature"], c["top_k"], c["top_p"])
+
+
+def _stub_trainer(n_batches, ga, **args):
+    """VLDPOTrainer.train's control flow without a model: a stub engine, `n_batches` micro-batches per epoch, checkpoints recorded"""
+    from types import SimpleNamespace
+    from vlrlhf.base.trainer import VLDPOTrainer
+
+    class Eng:
+        master, reducer = object(), None
+
+        def zero_grad(self): pass
+        def optimizer_step(self, **kw): pass
+        def grad_norm(self): return 0.0
+
+    class T(VLDPOTrainer):
+        def __init__(self):      # noqa: super().__init__ needs a real model
+            self.args = SimpleNamespace(gradient_accumulation_steps=ga, num_train_epochs=1.0, max_steps=-1, logging_steps=1000, save_strategy="epoch",
+                                        save_steps=500, evaluation_strategy="no", **args)
+            self.model = SimpleNamespace(engine=Eng())
+            self.precompute_ref_log_probs = False
+            self.eval_dataset = None
+            self.state = SimpleNamespace(global_step=0)
+            self.saved = []
+
+        def _batches_per_epoch(self): return n_batches
+        def get_train_batches(self, epoch, skip=0): return iter(range(skip, n_batches))
+        def training_step(self, model, batch): return torch.zeros(())
+        def prefetch_reference(self, b): return b
+        def log(self, logs): return logs
+        def save_checkpoint(self, step, micro, epoch, window_len=0): self.saved.append((step, micro, epoch))
+
+    return T()
+
+
+def test_epoch_save_strategy_always_leaves_a_final_checkpoint():
+    """save_strategy="epoch" (HF fires on_epoch_end - and saves - at the end of the epoch training stops in, whether it was consumed or cut short):
+    a run whose batch count is not a multiple of gradient_accumulation_steps, one that is, and one that max_steps ends mid-epoch all write
+    a checkpoint at their last optimizer step, exactly once"""
+    t = _stub_trainer(10, 4)                   # 10 micro-batches, windows of 4: 2 optimizer steps, 2 micro-batches left over
+    t.train()
+    assert t.saved == [(2, 8, 0)], t.saved
+    t = _stub_trainer(8, 4)
+    t.train()
+    assert t.saved == [(2, 8, 0)], t.saved
+    t = _stub_trainer(8, 2)
+    t.args.max_steps = 3                       # stops inside the epoch
+    t.train()
+    assert t.saved == [(3, 6, 0)], t.saved
+    t = _stub_trainer(6, 4)                    # two epochs: the first ends inside a window, its checkpoint is written at the next optimizer step
+    t.args.num_train_epochs = 2.0
+    t.train()
+    assert [s for s, _, _ in t.saved] == [2] or [s for s, _, _ in t.saved] == [1, 2], t.saved
+    assert t.saved[-1][0] == 2

@@ -184,14 +184,10 @@ def _check_grads(model, g, label, qk_cos=0.99, cos_min=0.99, norm_tol=0.03):
             # size ("second-order small"); measured in round 4 they are 0.27 - 0.36 of d v in norm and as well aligned with fp32 autograd
             # as every other gradient: worst probe cosine 0.9993 (2 layers) / 0.9961 (32 layers, layers 17 and 31), norms within 1.3 %
             worst_qk = min(worst_qk, cs)
-            if os.environ.get("VLR_DEPTH_NOASSERT"):
-                continue
             assert cs > qk_cos, f"{label} {name}: gradient probe cosine {cs:.3f} vs the fp32 oracle (q / k bound {qk_cos})"
             assert nr < norm_tol, f"{label} {name}: gradient norm {norm:.4g} vs {e['norm']:.4g}"
             continue
         worst_cos, worst_norm = min(worst_cos, cs), max(worst_norm, nr)
-        if os.environ.get("VLR_DEPTH_NOASSERT"):
-            continue
         assert cs > cos_min, f"{label} {name}: gradient probe cosine {cs:.3f} vs the fp32 oracle"      # measured worst 0.9999 (2 layers) / 0.9973 (32); sharp fixture 0.986
         assert nr < norm_tol, f"{label} {name}: gradient norm {norm:.4g} vs {e['norm']:.4g}"            # measured worst 0.1 % / 0.7 %; sharp fixture 2.2 %
     print(f"[depth grads {label}] {len(g['grads'])} tensors: worst probe cosine {worst_cos:.4f} (q_proj / k_proj {worst_qk:.4f}), worst norm deviation {worst_norm:.3f}")

@@ -360,10 +360,10 @@ def test_lora_step_matches_oracle(gpu, dropout):
     seed = (5 << 40) + (eng._lora_calls << 16)           # the policy pass is the engine's latest adapter forward
     lora["seed"] = seed
     l16, m16, g16 = _lora_oracle_grads(W, cfg, batch, lora)
-    assert abs(float(loss) - float(l16)) < TOL_LOSS_BF16, (float(loss), float(l16))
+    within(f"llava.lora.loss.p{dropout}", abs(float(loss) - float(l16)), default=TOL_LOSS_BF16)
     # reference pass = base weights only: rewards are relative to the adapter-free policy
     logs = tr.log({"loss": float(loss)})
-    assert abs(logs["rewards/margins"] - float(m16["rewards/margins"])) < 3e-2
+    within(f"llava.lora.margin.p{dropout}", abs(logs["rewards/margins"] - float(m16["rewards/margins"])), default=3e-2)
     named = dict(model.named_parameters())
     worst = 1.0
     for k, g in g16.items():
@@ -373,6 +373,7 @@ def test_lora_step_matches_oracle(gpu, dropout):
         worst = min(worst, c)
         assert c > 0.97, (k, c)
         assert abs(float(hip.float().norm().cpu()) / float(g.norm()) - 1) < 0.08, k
+    within(f"llava.lora.one_minus_worst_cosine.p{dropout}", 1.0 - worst, default=0.03)
     # optimizer: only the adapters move
     o = cfg["optim"]
     eng.optimizer_step(o["lr"], o["beta1"], o["beta2"], o["eps"], o["weight_decay"], o["max_grad_norm"])

@@ -95,3 +95,49 @@ def test_internlm_xcomposer2_7b_full_size_properties():
     assert float((r1[[1, 0, 3, 2]] - r2).abs().max()) < 2e-3 * float(r1.abs().max())
     del model, ref, tr
     torch.cuda.empty_cache()
+
+
+def test_internlm_xcomposer2_7b_full_size_lora_properties():
+    """the SHIPPED configuration at full width (scripts/dpo_internlmxc2vl7b.sh: --use_lora True - peft LoRA r 64 / alpha 64 / dropout 0.05 stacked
+    on the frozen PLoRA r 256 of models/InternLMXC2/build_mlp.py:158-203): the two-adapter layer passes
+    (vlr_decoder_layer_fwd_lora2 / bwd_lora2: the [B_lora 64 | B_plora 256] K segment at H = 4096 / I = 14336, the PLoRA row-set skips)
+    at 7B widths.  peft init (lora_B = 0) => the policy IS the reference although PLoRA is active in both passes: loss = ln 2 with a finite
+    NON-zero adapter gradient; the update moves only the adapters (base + PLoRA weights untouched); a permutation of the pairs permutes the
+    log-probs (PLoRA's row set moves with the images)."""
+    if not torch.cuda.is_available() or torch.cuda.mem_get_info()[1] < 250 * (1 << 30):
+        pytest.skip("needs a 288 GB device")
+    from vlrlhf.models.InternLMXC2 import INTERNLM_XC2_VL_7B, InternLMXC2DPOTrainer, InternLMXC2ForRL
+    from vlrlhf.utils.synthetic import init_random_model, synthetic_batch
+    cfg = dict(INTERNLM_XC2_VL_7B, plora_dropout=0.0)      # (PLoRA's own dropout draws a fresh mask per pass: with it on, policy and reference differ and ln 2 is not exact)
+    model = InternLMXC2ForRL(cfg)
+    ref = init_random_model(model, seed=0, std=0.02, policy_delta=0.0)
+    del ref                                                # under LoRA the frozen base doubles as the reference (adapters disabled)
+    tr = InternLMXC2DPOTrainer(model, None, 0.1, 0, "sigmoid", SimpleNamespace(gradient_accumulation_steps=1), None, -100, cfg["model_pad_token_id"],
+                               peft_config=dict(r=64, lora_alpha=64, lora_dropout=0.05, target_modules="auto", bias="none", seed=1))
+    eng = model.engine
+    assert tr.ref_model is None and tr.is_peft_model and eng.lora_fused and eng.resid_f32
+    batch = tr._prepare_inputs(synthetic_batch(4, 1024, cfg["image_token"], 32000, cfg["image_size"], seed=9, ragged=True))
+    base_before = eng.policy.flat.clone()
+    eng.init_optimizer()
+    loss = tr.training_step(model, batch)
+    torch.cuda.synchronize()
+    assert int(model._last_ctx["extra"]["R"]) == 8 * 1225 and model._last_ctx["S"] == 2248
+    assert abs(float(loss) - math.log(2.0)) < 1e-6, float(loss)
+    g = eng.lora_grads.float()
+    assert torch.isfinite(g).all() and float(g.abs().max()) > 0, "adapter gradient"
+    # lora_B = 0: d lora_A = 0 exactly (it is multiplied by B), d lora_B carries the whole gradient
+    ga = {k: float(v.float().abs().max()) for k, v in eng.lgv.items()}
+    assert any(v > 0 for k, v in ga.items() if ".b_" in k) and all(v == 0 for k, v in ga.items() if ".a_" in k), "peft init: only lora_B receives a gradient"
+    eng.optimizer_step(1e-5, 0.9, 0.95, 1e-6, 0.1, 1.0)
+    norm = eng.grad_norm()
+    assert math.isfinite(norm) and norm > 1e-6, norm
+    assert torch.equal(eng.policy.flat, base_before), "base + PLoRA weights must not move under LoRA"
+    model.eval()                                           # eval: no dropout of either adapter
+    with torch.no_grad(), tr.null_ref_context():
+        c1, r1, _, _ = tr.concatenated_forward(model, batch)
+        c2, r2, _, _ = tr.concatenated_forward(model, _permuted(batch, [1, 0, 3, 2]))
+    torch.cuda.synchronize()
+    assert float((c1[[1, 0, 3, 2]] - c2).abs().max()) < 2e-3 * float(c1.abs().max())
+    assert float((r1[[1, 0, 3, 2]] - r2).abs().max()) < 2e-3 * float(r1.abs().max())
+    del model, tr
+    torch.cuda.empty_cache()
