@@ -150,7 +150,10 @@ def build(force=False, verbose=True, defines=(), tag=""):
 
 
 if __name__ == "__main__":
-    if "--trace" in sys.argv:      # tile-timeline diagnostics of the persistent GEMM (tools/gemm_tile_trace.py)
+    if "--define" in sys.argv:     # any A/B variant: build_hip.py --define NAME=VALUE [--define ...] --tag _suffix  -> libvlr_hip_suffix.so (VLR_LIB)
+        defs = tuple(sys.argv[i + 1] for i, a_ in enumerate(sys.argv) if a_ == "--define")
+        build(force="--force" in sys.argv, defines=defs, tag=sys.argv[sys.argv.index("--tag") + 1])
+    elif "--trace" in sys.argv:      # tile-timeline diagnostics of the persistent GEMM (tools/gemm_tile_trace.py)
         build(force="--force" in sys.argv, defines=("VLR_GEMM_TRACE",), tag="_trace")
     elif "--classic" in sys.argv:  # the round-3 K loop of the persistent GEMM (12 / 4 / 8 / 0 fragment reads per phase), for A/B through VLR_LIB
         build(force="--force" in sys.argv, defines=("VLR_KLOOP_BAL=0",), tag="_classic")

@@ -34,6 +34,23 @@
 #ifndef VLR_KLOOP_BAL
 #define VLR_KLOOP_BAL 1        // balanced fragment reads per phase (6 / 6 / 6 / 6 instead of the template's 12 / 4 / 8 / 0); 0: the round-3 K loop (A/B builds)
 #endif
+#ifndef VLR_EPI_NT
+#define VLR_EPI_NT 0           // 1: the continuous-pipeline epilogues store with the non-temporal hint (A/B build, `build_hip.py --define VLR_EPI_NT=1 --tag _nt`)
+#endif
+#if VLR_EPI_NT
+#define EPI_GST(T_, addr_, val_) __builtin_nontemporal_store((T_)(val_), reinterpret_cast<T_*>(addr_))
+#else
+#define EPI_GST(T_, addr_, val_) (*reinterpret_cast<T_*>(addr_) = (val_))
+#endif
+#ifndef VLR_KLOOP_NT6
+#define VLR_KLOOP_NT6 1        // NT launches: the 18-fragment split of the TN loop, 6 / 6 / 6 / 6 ds_read_b128 per phase (0: 8 / 4 / 8 / 4)
+#endif
+#ifndef VLR_KLOOP_NN8
+#define VLR_KLOOP_NN8 1        // NN launches: the whole next A0 read in phase 4 (8 / 8 / 8 / 8 LDS instructions per phase; 0: 12 / 8 / 8 / 4)
+#endif
+#ifndef VLR_KLOOP_TN12
+#define VLR_KLOOP_TN12 1       // TN launches: 12 / 12 / 12 / 12 transposing reads per phase (0: the 16 / 8 / 16 / 8 of the NT split; A/B builds)
+#endif
 #define PT 256
 #define PK 64
 #define HALF_BYTES (128 * PK * 2)    // 16 KiB
@@ -672,6 +689,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     using I0_ = std::integral_constant<int, 0>;
     using I1_ = std::integral_constant<int, 1>;
     using I2_ = std::integral_constant<int, 2>;
+    using I3_ = std::integral_constant<int, 3>;
     using I4_ = std::integral_constant<int, 4>;
 #endif
 #define PMFMA(A_, B_, a_, b_)                                                                                            \
@@ -689,7 +707,12 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     const int lim = ((SEG && ((p.K2 % PK) != 0 || (p.sched & 8))) ? nt1 : nt) - ((p.K & (PK - 1)) != 0 ? 1 : 0) - kb;
     const int n_fast = (ntp < lim ? ntp : lim) - 2;
 #if VLR_KLOOP_BAL
-    if (n_fast > 0) rdAr(LO{}, I0_{}, I2_{}, fa0, 0);      // first half of A-lo of K tile 0 (inside the steady state phase 4 reads the next K tile's)
+    // (TN - both operands K-strided, two transposing reads per fragment - takes the 12 / 12 / 12 / 12 split of ktile_bal below: A0[0..2] ahead)
+    if (n_fast > 0) {
+        if constexpr ((A_KS && VLR_KLOOP_TN12) || (!A_KS && !B_KS && VLR_KLOOP_NT6)) rdAr(LO{}, I0_{}, I3_{}, fa0, 0);
+        else if constexpr (!A_KS && B_KS && VLR_KLOOP_NN8) rdAr(LO{}, I0_{}, I4_{}, fa0, 0);
+        else rdAr(LO{}, I0_{}, I2_{}, fa0, 0);
+    }      // first part of A-lo of K tile 0 (inside the steady state phase 4 reads the next K tile's)
 #endif
     in_loop = true;
 #if VLR_KLOOP_BAL
@@ -714,14 +737,65 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
         const fastc_t fastc{};
         const bool rd = !abl_rd || kt == 0;
         constexpr bool more = true;
+        constexpr bool bal18 = (A_KS && VLR_KLOOP_TN12) || (!A_KS && !B_KS && VLR_KLOOP_NT6);
+        if constexpr (bal18) {
+            // TN (round 5): every fragment is TWO ds_read_b64_tr_b16, so the split above is 16 / 8 / 16 / 8 LDS instructions per phase and the
+            // load sections of phases 1 and 3 (16 reads + one half tile of LDS-DMA) outlast the partner group's 16 MFMAs - 2570 cycles per
+            // K tile against 2200 for NT (tools/gemm_tile_trace.py with VLR_GEMM_TRACE_CLK=1).  Here 12 / 12 / 12 / 12: A1[0] moves into phase
+            // 2 (its registers are free since phase 4 of the previous K tile) and the next K tile's A0[2] into phase 4; 18 fragments live
+            // instead of 16 (+8 registers of the 15 this instantiation has left).
+            //   phase 1  B0 (4 fragments, retired first), A0[3] (2)      | stage A-hi(kt+1)            | MFMA A0 x B0
+            //   phase 2  B1 (4), A1[0] (2)                               | stage B-lo(kt+2)            | MFMA A0 x B1
+            //   phase 3  A1[1..3] (6)                                    | stage A-lo(kt+2); vmcnt(8)  | MFMA A1 x B1
+            //   phase 4  A0(kt+1)[0..2] (6)                              | stage B-hi(kt+2); vmcnt(6)  | MFMA A1 x B0
+            // RAW / WAR as above: A-hi(kt) was waited for in phase 4 of kt-1 and is re-staged in phase 1 of kt+1; A-lo(kt+1) is waited for in
+            // phase 3 (before its first barrier) and read in phase 4.
+            if (rd) rdB(LO{}, fb0);
+            PFENCE();
+            if (rd) rdAr(LO{}, I3_{}, I4_{}, fa0, 0);
+            PFENCE();
+            stage(kt + 1, H_AHI{}, fastc);
+            PFENCE();
+            if constexpr (A_KS) PWAIT_LGKM(4); else PWAIT_LGKM(2);      // the B reads are retired (B-lo is re-staged in phase 2); the A reads (TN: 4, NT: 2 instructions) may be in flight
+            LBAR();
+            PMFMA(fa0, fb0, 0, 0);
+            LBAR();
+            if (rd) rdB(HI{}, fb1);
+            PFENCE();
+            if (rd) rdAr(HI{}, I0_{}, I1_{}, fa1, 0);
+            PFENCE();
+            stage(kt + 2, H_BLO{}, fastc);
+            LBAR();
+            PMFMA(fa0, fb1, 0, 1);
+            LBAR();
+            if (rd) rdAr(HI{}, I1_{}, I4_{}, fa1, 0);
+            PFENCE();
+            stage(kt + 2, H_ALO{}, fastc);
+            PFENCE();
+            PWAIT_VM(8);
+            LBAR();
+            PMFMA(fa1, fb1, 1, 1);
+            LBAR();
+            if constexpr (decltype(prec)::value) { if (rd) rdAr(LO{}, I0_{}, I3_{}, fa0, flip); }
+            PFENCE();
+            stage(kt + 2, H_BHI{}, fastc);
+            PFENCE();
+            PWAIT_VM(6);
+            LBAR();
+            PMFMA(fa1, fb0, 1, 0);
+            LBAR();
+        } else {
         // ---------------- phase 1
+        // (NN, VLR_KLOOP_NN8: B is K-strided - 8 transposing reads per B half - so the whole next A0 is read in phase 4 and phase 1 keeps only
+        // B0: 8 / 8 / 8 / 8 LDS instructions instead of 12 / 8 / 8 / 4; 20 fragments live in phase 4)
+        constexpr bool nn8 = !A_KS && B_KS && VLR_KLOOP_NN8;
         if (rd) rdB(LO{}, fb0);
         PFENCE();
-        if (rd) rdAr(LO{}, I2_{}, I4_{}, fa0, 0);
+        if constexpr (!nn8) { if (rd) rdAr(LO{}, I2_{}, I4_{}, fa0, 0); }
         PFENCE();
         stage(kt + 1, H_AHI{}, fastc);
         PFENCE();
-        if constexpr (A_KS) PWAIT_LGKM(8); else PWAIT_LGKM(4);      // the B reads are retired (B-lo is re-staged in phase 2); the A reads may be in flight
+        if constexpr (nn8) PWAIT_LGKM(0); else if constexpr (A_KS) PWAIT_LGKM(8); else PWAIT_LGKM(4);      // the B reads are retired (B-lo is re-staged in phase 2); the A reads may be in flight
         LBAR();
         PMFMA(fa0, fb0, 0, 0);
         LBAR();
@@ -742,7 +816,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
         PMFMA(fa1, fb1, 1, 1);
         LBAR();
         // ---------------- phase 4
-        if constexpr (decltype(prec)::value) { if (rd) rdAr(LO{}, I0_{}, I2_{}, fa0, flip); }      // (not in the last steady-state iteration: the classic body that follows reads A0 itself)
+        if constexpr (decltype(prec)::value) {      // (not in the last steady-state iteration: the classic body that follows reads A0 itself)
+            if constexpr (nn8) { if (rd) rdAr(LO{}, I0_{}, I4_{}, fa0, flip); } else { if (rd) rdAr(LO{}, I0_{}, I2_{}, fa0, flip); }
+        }
         PFENCE();
         stage(kt + 2, H_BHI{}, fastc);
         PFENCE();
@@ -750,6 +826,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
         LBAR();
         PMFMA(fa1, fb0, 1, 0);
         LBAR();
+        }
 #pragma unroll
         for (int q = 0; q < NPA; ++q) pa[q] += flip;
 #pragma unroll
@@ -861,8 +938,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                     const int gm = m0 + a * 128 + wr * 64 + i * 16 + (ln >> 2);
                     const int gn = n0 + wc * 32 + (ln & 3) * 8;
                     if (gm < tp.M && gn + 8 <= I) {
-                        if constexpr (kind == 0) *reinterpret_cast<u32x4*>(C2 + (size_t)gm * p.ldc2 + gn) = pend[c & 1];
-                        else *reinterpret_cast<u32x4*>(C + (size_t)gm * tp.ldc + (kind - 1) * I + gn) = pend[c & 1];
+                        if constexpr (kind == 0) EPI_GST(u32x4, C2 + (size_t)gm * p.ldc2 + gn, pend[c & 1]);
+                        else EPI_GST(u32x4, C + (size_t)gm * tp.ldc + (kind - 1) * I + gn, pend[c & 1]);
                     }
                 }
             });
@@ -937,7 +1014,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                     }
                     const int gn = n0 + b * 128 + wc * 32 + widen_col(lq_);
                     const u32x4 w = widen_pair(d[0], d[1]);
-                    if (gm < tp.M && gn + 8 <= tp.N) *reinterpret_cast<u32x4*>(C + (size_t)gm * tp.ldc + gn) = w;
+                    if (gm < tp.M && gn + 8 <= tp.N) EPI_GST(u32x4, C + (size_t)gm * tp.ldc + gn, w);
                 }
             }
     } else if constexpr (CONT && FUSE == 3) {
@@ -995,8 +1072,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                     dg[e] = d[e] * u[e] * sg * (1.f + g[e] * (1.f - sg));
                 }
                 if (EPI_ST_ON && ok) {
-                    *reinterpret_cast<u32x4*>(GU + (size_t)gm * p.ldc2 + gn) = pack8(dg);
-                    *reinterpret_cast<u32x4*>(GU + (size_t)gm * p.ldc2 + I + gn) = pack8(du);
+                    EPI_GST(u32x4, GU + (size_t)gm * p.ldc2 + gn, pack8(dg));
+                    EPI_GST(u32x4, GU + (size_t)gm * p.ldc2 + I + gn, pack8(du));
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
@@ -1066,8 +1143,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                             }
                         }
                     if (gm < tp.M) {
-                        *reinterpret_cast<u32x4*>(C + (size_t)gm * tp.ldc + hc) = pack8(y1);
-                        *reinterpret_cast<u32x4*>(C + (size_t)gm * tp.ldc + hc + 64) = pack8(y2);
+                        EPI_GST(u32x4, C + (size_t)gm * tp.ldc + hc, pack8(y1));
+                        EPI_GST(u32x4, C + (size_t)gm * tp.ldc + hc + 64, pack8(y2));
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });
@@ -1120,7 +1197,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                         const int gm = m0 + a * 128 + wr * 64 + i * 16 + er + 8 * k;
                         const int gn = n0 + b * 128 + wc * 32 + ec;
                         const f32x4 v = p.alpha * o[k] + rv[c][k];
-                        if (EPI_ST_ON && gm < tp.M && gn + 4 <= tp.N) *reinterpret_cast<f32x4*>(C + (size_t)gm * tp.ldc + gn) = v;
+                        if (EPI_ST_ON && gm < tp.M && gn + 4 <= tp.N) EPI_GST(f32x4, C + (size_t)gm * tp.ldc + gn, v);
                     }
                     __builtin_amdgcn_sched_barrier(0);      // one chunk's addresses at a time
                 });
@@ -1136,7 +1213,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                 for (int k = 0; k < 2; ++k) {
                     const int gm = m0 + a * 128 + wr * 64 + i * 16 + er + 8 * k;
                     const int gn = n0 + b * 128 + wc * 32 + ec;
-                    if (gm < tp.M && gn + 4 <= tp.N) *reinterpret_cast<f32x4*>(C + (size_t)gm * tp.ldc + gn) = p.alpha * o[k];
+                    if (gm < tp.M && gn + 4 <= tp.N) EPI_GST(f32x4, C + (size_t)gm * tp.ldc + gn, p.alpha * o[k]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
@@ -1184,7 +1261,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                 constexpr int c = n - 1, a = c >> 3, i = (c >> 1) & 3, b = c & 1;
                 const int gm = m0 + a * 128 + wr * 64 + i * 16 + (lane >> 2);
                 const int gn = n0 + b * 128 + wc * 32 + (lane & 3) * 8;
-                if (gm < tp.M && gn + 8 <= tp.N) *reinterpret_cast<u32x4*>(C + (size_t)gm * tp.ldc + gn) = pend[c & 1];
+                if (gm < tp.M && gn + 8 <= tp.N) EPI_GST(u32x4, C + (size_t)gm * tp.ldc + gn, pend[c & 1]);
             }
         });
       }
