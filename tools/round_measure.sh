@@ -2,7 +2,7 @@
 # the measurements quoted in DESIGN.md section 6 for one round: tools/round_measure.sh r04   (writes gpurun_out/<tag>_*; copy to profiles/)
 # Order: the PMC passes FIRST (they record the source digest of the library they ran with), their JSON is put where bench.py looks for it,
 # so the default-command line quotes roofline.traffic of the SAME binary - bench.py refuses a file taken with another digest.
-tag=${1:-r04}
+tag=${1:-r05}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 mkdir -p gpurun_out

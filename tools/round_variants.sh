@@ -1,6 +1,6 @@
 #!/bin/bash
 # the variant bench lines quoted in DESIGN.md section 6 (one JSON line each): tools/round_variants.sh r04
-tag=${1:-r04}
+tag=${1:-r05}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 mkdir -p gpurun_out

@@ -711,7 +711,8 @@ extern "C" int vlr_gemm_bf16_tn_pair(const void* A0, const void* B0, void* C0, i
         }
     static int pair_on = -1;
     if (pair_on < 0) { const char* e = getenv("VLR_GEMM_PAIR"); pair_on = (e && e[0] == '0') ? 0 : 1; }
-    if (pair_on && !accumulate && best < (double)sep - 0.25 && K % 8 == 0) {
+    // (equal round counts still pair: one persistent launch instead of a persistent one plus a cold one - dW_qkv + dW_o = 3 + 1 rounds)
+    if (pair_on && !accumulate && best < (double)sep + 1e-9 && K % 8 == 0) {
         GemmParams p[2] = {fused_params(A0, B0, C0, M0, N0, K, lda0, ldb0, ldc0), fused_params(A1, B1, C1, M1, N1, K, lda1, ldb1, ldc1)};
         GemmParams rest = p[bq];
         if (br) {

@@ -178,8 +178,14 @@ extern "C" int vlr_decoder_layer_bwd(const vlr_llama_cfg* cfg, const vlr_layer_w
     else
         CHECK(norm_bwd(cfg->resid_f32, ws->dxn, a->x_mid, w->ln2, a->rstd2, dx_out, ws->dx_mid, g->ln2, accumulate, ws->norm_ws, M, H, st));
     // ---- attention
+    // dW_o is one round of 256 tiles on its own; together with dW_qkv it would be 768 + 256 = 4 whole rounds of ONE persistent launch
+    // (vlr_gemm_bf16_tn_pair below; both operands - dx_mid, attn - stay untouched until the end of this call).  Measured NEUTRAL in round 5
+    // (565.9 vs 565.9 ms, same box, twice each): off unless VLR_PAIR_QKVO=1
+    static int pair_qkvo = -1;
+    if (pair_qkvo < 0) { const char* e = getenv("VLR_PAIR_QKVO"); pair_qkvo = (e && e[0] == '1') ? 1 : 0; }
+    const bool pair_o = pair_qkvo && !two && !accumulate;
     if (two) { sd = fork_side(st); }
-    CHECK(vlr_gemm_bf16(2, ws->dx_mid, a->attn, g->wo, nullptr, nullptr, H, Nq, M, H, Nq, Nq, 0, 0, accumulate, 0, sd));
+    if (!pair_o) CHECK(vlr_gemm_bf16(2, ws->dx_mid, a->attn, g->wo, nullptr, nullptr, H, Nq, M, H, Nq, Nq, 0, 0, accumulate, 0, sd));
     if (two) side_done(2);
     CHECK(vlr_gemm_bf16(1, ws->dx_mid, w->wo, ws->dattn, nullptr, nullptr, M, Nq, H, H, Nq, Nq, 0, 0, 0, 0, st));
     if (two) wait_side(3, st);                           // previous layer's dWqkv GEMM still reads ws->dqkv
@@ -189,7 +195,8 @@ extern "C" int vlr_decoder_layer_bwd(const vlr_llama_cfg* cfg, const vlr_layer_w
     // transpose of the rotation on the q and k column blocks ((Nq + Nkv) / head_dim consecutive heads)
     CHECK(vlr_rope_heads(ws->dqkv, pos, cfg->rope_cos, cfg->rope_sin, M, cfg->heads + kvh, cfg->head_dim, N, cfg->max_pos, 1, st));
     if (two) { sd = fork_side(st); }
-    CHECK(vlr_gemm_bf16(2, ws->dqkv, a->xn1, g->wqkv, nullptr, nullptr, N, H, M, N, H, H, 0, 0, accumulate, 0, sd));
+    if (pair_o) CHECK(vlr_gemm_bf16_tn_pair(ws->dqkv, a->xn1, g->wqkv, N, H, N, H, H, ws->dx_mid, a->attn, g->wo, H, Nq, H, Nq, Nq, M, 0, st));
+    else CHECK(vlr_gemm_bf16(2, ws->dqkv, a->xn1, g->wqkv, nullptr, nullptr, N, H, M, N, H, H, 0, 0, accumulate, 0, sd));
     if (two) side_done(3);
     tl = two ? nullptr : tail_for(st, &tl_);
     vlr_internal_set_gemm_tail(tl);
