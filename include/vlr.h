@@ -154,6 +154,15 @@ int vlr_gemm_grouped_bits_rows(int layout, const void* A, const void* B, void* C
  *                          caller guarantees that every other row contributes zero (PLoRA's dB = dy^T u, dA = v^T drop(x)).  The list
  *                          is read on the device; split-K slices cut the LIST, so the summation order differs from the dense call. */
 int vlr_rows_tile_list(const unsigned char* rowmask, int M, int* out, vlr_stream_t stream);
+/* (ABI v8) vlr_rows_tile_flags: flags[t] = 1 when NO row of the tile_rows-row tile t of [0, M) is marked (ceil(M / tile_rows) bytes).
+ * vlr_gemm_seg_rowskip(tile_flags, keep): the NEXT adapter-segment GEMM call of this thread (vlr_gemm_lora[_f32res] / vlr_gemm_swiglu_lora /
+ * vlr_gemm_qkv_rope_lora) may run the 256-row tiles whose flag is set over only the first `keep` (multiple of 64; 0 = none) K elements of
+ * every sub-target's r-wide block of the segment - the caller guarantees that the REST of u is zero on the rows of those tiles, so the
+ * result is bit-identical to the full segment.  InternLM-XComposer2: the [u_lora | u_plora] segment of the two-adapter passes with keep =
+ * r_lora (PLoRA acts on the image rows only: reference models/InternLMXC2/build_mlp.py:194-202), and PLoRA alone with keep = 0.
+ * tile_flags = NULL clears a pending setting. */
+int vlr_rows_tile_flags(const unsigned char* rowmask, int M, int tile_rows, unsigned char* flags, vlr_stream_t stream);
+int vlr_gemm_seg_rowskip(const unsigned char* tile_flags, int keep);
 int vlr_gemm_grouped_bits_ktiles(int layout, const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int groups,
                                  long gA, long gB, long gC, float alpha, int accumulate, int mask_on, uint64_t seed, float p_drop,
                                  int mask_ld, const void* mask_bits, long mask_gstride, const int* ktlist, vlr_stream_t stream);

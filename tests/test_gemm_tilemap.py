@@ -16,12 +16,13 @@ PROGRAM = r"""
 #include "gemm_tilemap.h"
 int main() {
     // 1. bijective on every grid
+    for (int rot = 0; rot < 2; ++rot)      // both forms of the map: rows rotating with the super-column (unequal tiles) or not
     for (int tm = 1; tm <= 90; ++tm)
         for (int tn = 1; tn <= 90; ++tn) {
             std::vector<char> seen((size_t)tm * tn, 0);
             for (int pl = 0; pl < tm * tn; ++pl) {
                 int r = -1, c = -1;
-                vlr_tile_of_shared(pl, tm, tn, &r, &c);
+                vlr_tile_of_shared(pl, tm, tn, &r, &c, rot);
                 if (r < 0 || r >= tm || c < 0 || c >= tn) { printf("tile %d of %d x %d out of range: (%d, %d)\n", pl, tm, tn, r, c); return 1; }
                 if (seen[(size_t)r * tn + c]++) { printf("tile (%d, %d) of %d x %d visited twice\n", r, c, tm, tn); return 1; }
             }

@@ -897,6 +897,92 @@ def test_gemm_qkv_rope_lora_segment(hip, shape):
     check(out, ref, 8e-3, f"qkv rope lora {shape}")
 
 
+@pytest.mark.parametrize("keep", [64, 0])
+def test_adapter_segment_row_tile_skip(hip, keep):
+    """vlr_gemm_seg_rowskip / vlr_rows_tile_flags (ABI v8): 256-row tiles without a marked row run only the first `keep` K elements of every
+    sub-target's block of the adapter segment ([u_lora 64 | u_plora 128] per sub-target here; keep = 0: the whole segment is skipped - PLoRA
+    alone).  The rest of u is zero on those rows by contract, so the result is BIT-IDENTICAL to the full segment; NaNs planted in that
+    part of u on the flagged tiles prove that it is not read there (without the flags they come out).  All three fused entry points;
+    ragged M (a partial last tile), a peeled tail included."""
+    from vlrlhf import _hip as HH
+    HH.ensure_splitk_workspace(DEV, force=True)
+    rl, rp = (64, 128) if keep else (0, 192)
+    R = rl + rp
+    M, K, hd = 12792, 512, 128                      # 50 row tiles
+    g = torch.Generator().manual_seed(3)
+    marked = torch.zeros(M, dtype=torch.uint8)
+    for t in range(0, 50, 3):                       # tiles 0, 3, 6, ... hold marked rows (a run in the middle of the tile)
+        marked[t * 256 + 40: t * 256 + 200] = 1
+    marked[49 * 256 + 5] = 1                        # the partial last tile is marked too
+    marked = marked.to(DEV)
+    flags = torch.full((50,), 7, dtype=torch.uint8, device=DEV)
+    hip.call("vlr_rows_tile_flags", marked, M, 256, flags)
+    torch.cuda.synchronize()
+    want_flags = torch.tensor([0 if (t % 3 == 0 or t == 49) else 1 for t in range(50)], dtype=torch.uint8)
+    assert torch.equal(flags.cpu(), want_flags)
+    rows_flagged = (want_flags.repeat_interleave(256)[:M] == 1).to(DEV)
+
+    def make_u(nsub, poison):
+        u = rnd(M, nsub * R, scale=0.5, seed=11)
+        for t in range(nsub):
+            blk = u[:, t * R + rl:(t + 1) * R]
+            blk[marked == 0] = 0                     # the row-restricted adapter's block: zero on the unmarked rows
+            if poison:
+                blk[rows_flagged] = float("nan")     # ... and poisoned where the kernel must not look
+        return u
+
+    def run(fn, nsub):
+        outs = []
+        for poison, use_flags in ((False, False), (False, True), (True, True), (True, False)):
+            u = make_u(nsub, poison)
+            assert hip.helper("vlr_gemm_seg_rowskip", flags.data_ptr() if use_flags else None, keep) == 0
+            outs.append(fn(u))
+            torch.cuda.synchronize()
+        full, skip, skip_poisoned, noskip_poisoned = outs
+        for a_, b_, c_ in zip(full, skip, skip_poisoned):
+            assert torch.isfinite(a_.float()).all()
+            assert torch.equal(a_, b_), "row-tile skip changed the result"
+            assert torch.equal(a_, c_), "the skipped part of u was read"
+        assert not all(torch.isfinite(t_.float()).all() for t_ in noskip_poisoned), "the poison never reached a kernel: the test proves nothing"
+
+    # plain + residual (bf16) and fp32 residual stream
+    N = 4352
+    x, W, Bl = rnd(M, K, seed=1), rnd(N, K, scale=0.05, seed=2), rnd(N, R, scale=0.05, seed=4)
+    resid = rnd(M, N, seed=5, dtype=torch.float32)
+
+    def f_lora(u):
+        y = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+        hip.call("vlr_gemm_lora_f32res", x, K, W, y, N, resid, N, M, N, K, u, R, Bl, R)
+        return (y,)
+    run(f_lora, 1)
+    # SwiGLU: two sub-targets (gate, up)
+    I = 2176
+    wgu, Bgu = rnd(2 * I, K, scale=0.05, seed=6), rnd(2 * I, R, scale=0.05, seed=7)
+
+    def f_swiglu(u):
+        gu = torch.full((M, 2 * I), float("nan"), dtype=torch.bfloat16, device=DEV)
+        act = torch.full((M, I), float("nan"), dtype=torch.bfloat16, device=DEV)
+        hip.call("vlr_gemm_swiglu_lora", x, wgu, gu, act, M, I, K, K, u, 2 * R, Bgu, R)
+        return gu, act
+    run(f_swiglu, 2)
+    # qkv + RoPE: three sub-targets
+    nh = nkv = 8
+    Nq = Nkv = nh * hd
+    Nqkv, rope_cols, max_pos = Nq + 2 * Nkv, Nq + Nkv, 700
+    wq, Bq = rnd(Nqkv, K, scale=0.05, seed=8), rnd(Nqkv, R, scale=0.05, seed=9)
+    pos = torch.randint(0, max_pos, (M,), generator=g, dtype=torch.int32).to(DEV)
+    cos = torch.empty(max_pos, hd // 2, dtype=torch.float32, device=DEV)
+    sin = torch.empty_like(cos)
+    hip.call("vlr_rope_table", cos, sin, max_pos, hd, 10000.0)
+
+    def f_qkv(u):
+        out = torch.full((M, Nqkv), float("nan"), dtype=torch.bfloat16, device=DEV)
+        hip.call("vlr_gemm_qkv_rope_lora", x, wq, None, out, pos, cos, sin, M, Nqkv, rope_cols, K, K, hd, max_pos, u, 3 * R, Bq, R, Nq, Nkv)
+        return (out,)
+    run(f_qkv, 3)
+    assert hip.helper("vlr_gemm_seg_rowskip", None, 0) == 0
+
+
 @pytest.mark.parametrize("shape", [(4352, 4352, 512), (12792, 4096, 256), (4104, 4360, 320)])
 def test_gemm_residual_continuous(hip, shape):
     """NT GEMM with a residual add at shapes the persistent kernels take (o_proj / down_proj of the forward), out of place and in

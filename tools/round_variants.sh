@@ -1,10 +1,10 @@
 #!/bin/bash
-# the variant bench lines quoted in DESIGN.md section 6 (one JSON line each): tools/round_variants.sh r04
+# the variant bench lines quoted in DESIGN.md section 6 (one JSON line each): tools/round_variants.sh r05
 tag=${1:-r05}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 mkdir -p gpurun_out
-run() { name=$1; shift; python bench.py --steps 8 --warmup 2 --no_cpu_baseline "$@" 2>/dev/null | tail -1 > gpurun_out/${tag}_variant_${name}.json; }
+run() { name=$1; shift; python bench.py --steps 6 --warmup 2 --no_cpu_baseline "$@" 2>/dev/null | tail -1 > gpurun_out/${tag}_variant_${name}.json; }
 run full
 run lora --lora
 run precomputed_ref --precomputed_ref
@@ -17,6 +17,4 @@ run internlm_xc2 --model internlm_xc2
 run internlm_xc2_lora --model internlm_xc2 --lora
 run internlm_xc2_t512 --model internlm_xc2 --text_len 512
 run internlm_xc2_t512_lora --model internlm_xc2 --text_len 512 --lora
-VLR_ATTN_FWD3=1 run full_attn_fwd3
-VLR_ATTN_FWD3=1 run llava_next_2x1024_attn_fwd3 --model llava_next --pairs 2
 echo variants done

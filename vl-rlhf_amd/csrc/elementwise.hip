@@ -951,6 +951,19 @@ extern "C" int vlr_rows_tile_list(const unsigned char* rowmask, int M, int* out,
     hipLaunchKernelGGL(rows_tile_list_kernel, dim3(1), dim3(64), 0, st, rowmask, M, out);
     return vlr_check_launch("vlr_rows_tile_list");
 }
+// flags[t] = 1 when NO row of the `tile_rows`-row tile t of [0, M) is marked (the tiles an adapter-segment GEMM may run short: vlr_gemm_seg_rowskip)
+__global__ __launch_bounds__(256) void rows_tile_flags_kernel(const unsigned char* __restrict__ mask, int M, int tile_rows, unsigned char* __restrict__ flags) {
+    const int t = blockIdx.x, r0 = t * tile_rows, r1 = min(M, r0 + tile_rows);
+    int any = 0;
+    for (int r = r0 + threadIdx.x; r < r1; r += 256) any |= mask[r] != 0;
+    any = __syncthreads_or(any);
+    if (threadIdx.x == 0) flags[t] = any ? 0 : 1;
+}
+extern "C" int vlr_rows_tile_flags(const unsigned char* rowmask, int M, int tile_rows, unsigned char* flags, hipStream_t st) {
+    VLR_REQUIRE(rowmask && flags && M > 0 && tile_rows > 0, "vlr_rows_tile_flags: bad arguments");
+    hipLaunchKernelGGL(rows_tile_flags_kernel, dim3((M + tile_rows - 1) / tile_rows), dim3(256), 0, st, rowmask, M, tile_rows, flags);
+    return vlr_check_launch("vlr_rows_tile_flags");
+}
 extern "C" int vlr_rows_mask(void* x, int ld, int cols, const unsigned char* rowmask, int M, hipStream_t st) {
     VLR_REQUIRE(x && rowmask && M > 0 && cols > 0 && cols % 8 == 0 && ld % 8 == 0 && ld >= cols, "vlr_rows_mask: bad arguments");
     hipLaunchKernelGGL(rows_mask_kernel, dim3(M), dim3(256), 0, st, (bf16_t*)x, ld, cols, rowmask);

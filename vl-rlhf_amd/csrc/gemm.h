@@ -68,6 +68,11 @@ struct GemmParams {
     const bf16_t* B1;
     void* C1;
     int M1, N1, lda1, ldb1, ldc1;
+    // ---- adapter segment, row-tile skip (round 5; two-adapter launches [u_keep | u_rest] per sub-target, u_rest ZERO on the rows of a tile
+    // whose flag is set - InternLM-XComposer2's PLoRA block on all-text row tiles): seg_skip [ceil(M / 256)] bytes (device; 1 = the tile
+    // runs only the first seg_keep K elements of every sub-target's K2-wide block) or null.  seg_keep % 64 == 0 and K2 % 64 == 0.
+    const unsigned char* seg_skip;
+    int seg_keep;
     // ---- A/B switches of the continuous-pipeline kernels (vlr_gemm_set_sched): bit 3 = adapter K tiles on the general staging path,
     // bit 4 = the two wave groups run their epilogues one after the other (the order before round 4), bit 5 (32) = the shared-panel tile
     // map of gemm_tilemap.h (round 5; off = the per-XCD contiguous tile ranges of rounds 1-4).  32 in production.

@@ -781,7 +781,7 @@ static int gemm_impl_ex(int layout, const void* A, const void* B, void* C, const
     p.sched = 0;
     p.A1 = p.B1 = nullptr; p.C1 = nullptr; p.M1 = p.N1 = p.lda1 = p.ldb1 = p.ldc1 = 0;
     p.groups = 1; p.gA = p.gB = p.gC = 0; p.mask_on = 0; p.mask_seed = 0; p.mask_thr = 0; p.mask_ld = 0;
-    p.mask_bits = nullptr; p.gMask = 0; p.drop_bits = nullptr; p.rowskip = nullptr; p.ktlist = nullptr;
+    p.mask_bits = nullptr; p.gMask = 0; p.drop_bits = nullptr; p.rowskip = nullptr; p.ktlist = nullptr; p.seg_skip = nullptr; p.seg_keep = 0;
     const int pi = vlr_prof_begin(layout, 2.0 * M * N * K, stream);
     // ---- split-K for problems whose output is a handful of tiles but whose reduction is long: the LoRA adapter gradients
     // (TN: dB = dy^T u [out x r], dA = v^T x [r x in], reduction over all tokens) - 32..96 workgroups would leave most CUs idle
@@ -871,17 +871,33 @@ static GemmParams fused_params(const void* A, const void* B, void* C, int M, int
     p.sched = 0;
     p.A1 = p.B1 = nullptr; p.C1 = nullptr; p.M1 = p.N1 = p.lda1 = p.ldb1 = p.ldc1 = 0;
     p.groups = 1; p.gA = p.gB = p.gC = 0; p.mask_on = 0; p.mask_seed = 0; p.mask_thr = 0; p.mask_ld = 0;
-    p.mask_bits = nullptr; p.gMask = 0; p.drop_bits = nullptr; p.rowskip = nullptr; p.ktlist = nullptr;
+    p.mask_bits = nullptr; p.gMask = 0; p.drop_bits = nullptr; p.rowskip = nullptr; p.ktlist = nullptr; p.seg_skip = nullptr; p.seg_keep = 0;
     return p;
 }
 
 // LoRA adapter segment of a fused linear group (GemmParams::A2...): u = s * dropout_t(x) A_t^T of the group's targets side by
 // side [M][ldu] (r columns each), Bl = lora_B rows [N][r]; the output blocks are [0,b0) [b0,b1) [b1,N).  u == nullptr: none.
 struct SegArgs { const void* u; int ldu; const void* Bl; int r; int b0, b1; };
-static void seg_set(GemmParams& p, const SegArgs* sg) {
+// Row-tile skip of the NEXT adapter-segment GEMM call of this thread (vlr_gemm_seg_rowskip, include/vlr.h): flags [ceil(M / 256)] (1 = the 256-row
+// tile runs only the first `keep` K elements of every sub-target's r-wide block - the caller guarantees that the rest of u is ZERO on
+// those rows), consumed by the call whatever path it takes (only the persistent segment kernel uses it; every other path computes the
+// same sums over the zeros).
+static const unsigned char* g_seg_skip = nullptr;
+static int g_seg_keep = 0;
+extern "C" int vlr_gemm_seg_rowskip(const unsigned char* tile_flags, int keep) {
+    VLR_REQUIRE(!tile_flags || (keep >= 0 && keep % 64 == 0), "vlr_gemm_seg_rowskip: keep must be a multiple of 64 (0 = the whole segment is skipped), got %d", keep);
+    g_seg_skip = tile_flags; g_seg_keep = tile_flags ? keep : 0;
+    return VLR_OK;
+}
+struct SegSkip {     // taken once per public call, handed to the launches of that call (main rows / peeled rows)
+    const unsigned char* flags; int keep;
+    SegSkip() : flags(g_seg_skip), keep(g_seg_keep) { g_seg_skip = nullptr; g_seg_keep = 0; }
+};
+static void seg_set(GemmParams& p, const SegArgs* sg, const SegSkip* sk = nullptr, int row0 = 0) {
     if (!sg || !sg->u) return;
     p.A2 = (const bf16_t*)sg->u; p.lda2 = sg->ldu; p.B2 = (const bf16_t*)sg->Bl; p.ldb2 = sg->r; p.K2 = sg->r;
     p.seg_b0 = sg->b0; p.seg_b1 = sg->b1;
+    if (sk && sk->flags && sk->keep < sg->r && sg->r % 64 == 0 && row0 % 256 == 0) { p.seg_skip = sk->flags + row0 / 256; p.seg_keep = sk->keep; }
 }
 // rows [row0, row0 + Mr) that the segment kernel did not take: y[:, block t] += u_t Bl_t^T, one skinny GEMM per block
 static int seg_fallback_add(const SegArgs* sg, void* y, int ldy, int row0, int Mr, int N, hipStream_t stream, int y_f32 = 0) {
@@ -910,13 +926,14 @@ static int gemm_swiglu_impl(const void* x, const void* wgu, void* gu, void* act,
     VLR_REQUIRE(M > 0 && I > 0 && K > 0 && I % 8 == 0 && K % 8 == 0 && ldx % 8 == 0, "vlr_gemm_swiglu: bad shape M=%d I=%d K=%d ldx=%d", M, I, K, ldx);
     { int rc = seg_check("vlr_gemm_swiglu_lora", sg); if (rc != VLR_OK) return rc; }
     const bool seg = sg && sg->u;
+    const SegSkip skp;
     const int tn = (I + 127) / 128;
     const int peel = choose_peel(M, 2 * I, tn, seg ? 0 : K, stream, true);
     const int tm256 = (M + 255) / 256;
     const int M1 = peel ? (tm256 - peel) * 256 : M;
     GemmParams p = fused_params(x, wgu, gu, M1, 2 * I, K, ldx, K, 2 * I);
     p.fuse = 1; p.store_c = store_gu; p.C2 = act; p.ldc2 = I;
-    seg_set(p, sg);
+    seg_set(p, sg, &skp, 0);
     int done = 0;
     const int pi_ = vlr_prof_begin(VLR_K_GEMM_NT, 2.0 * M1 * 2 * I * K, stream);    // per-layout totals of the bench line (the fallback rows below are counted by gemm_impl)
     const bool took_ = seg ? vlr_gemm256p_seg_try_launch(p, stream) : vlr_gemm256p_fused_try_launch(p, stream);
@@ -931,7 +948,7 @@ static int gemm_swiglu_impl(const void* x, const void* wgu, void* gu, void* act,
         // arithmetic - act from the fp32 accumulators - whatever the batch size
         GemmParams p2 = fused_params((const bf16_t*)x + (size_t)done * ldx, wgu, (bf16_t*)gu + (size_t)done * 2 * I, M - done, 2 * I, K, ldx, K, 2 * I);
         p2.fuse = 1; p2.store_c = store_gu; p2.C2 = (bf16_t*)act + (size_t)done * I; p2.ldc2 = I;
-        if (seg) { SegArgs s2 = *sg; s2.u = (const bf16_t*)sg->u + (size_t)done * sg->ldu; seg_set(p2, &s2); }
+        if (seg) { SegArgs s2 = *sg; s2.u = (const bf16_t*)sg->u + (size_t)done * sg->ldu; seg_set(p2, &s2, &skp, done); }
         const int pj_ = vlr_prof_begin(VLR_K_GEMM_NT, 2.0 * (M - done) * 2 * I * K, stream);
         const bool took2_ = seg ? vlr_gemm256p_seg_try_launch(p2, stream) : vlr_gemm256p_fused_try_launch(p2, stream);
         vlr_prof_end(took2_ ? pj_ : -1, stream);
@@ -973,6 +990,7 @@ static int gemm_qkv_rope_impl(const void* x, const void* wqkv, void* qkv, const 
     VLR_REQUIRE(head_dim % 16 == 0 && rope_cols % head_dim == 0 && rope_cols <= N, "vlr_gemm_qkv_rope: rope_cols %d / head_dim %d / N %d", rope_cols, head_dim, N);
     { int rc = seg_check("vlr_gemm_qkv_rope_lora", sg); if (rc != VLR_OK) return rc; }
     const bool seg = sg && sg->u;
+    const SegSkip skp;
     int done = 0;
     if (head_dim == 128 && (!bias || !((uintptr_t)bias & 7))) {
         const int tn = (N + 255) / 256;
@@ -982,7 +1000,7 @@ static int gemm_qkv_rope_impl(const void* x, const void* wqkv, void* qkv, const 
         GemmParams p = fused_params(x, wqkv, qkv, M1, N, K, ldx, K, N);
         p.fuse = 2; p.pos = pos; p.rope_cos = cos_t; p.rope_sin = sin_t; p.max_pos = max_pos; p.rope_cols = rope_cols;
         p.bias = (const bf16_t*)bias;
-        seg_set(p, sg);
+        seg_set(p, sg, &skp, 0);
         const int pi_ = vlr_prof_begin(VLR_K_GEMM_NT, 2.0 * M1 * N * K, stream);
         const bool took_ = seg ? vlr_gemm256p_seg_try_launch(p, stream) : vlr_gemm256p_fused_try_launch(p, stream);
         vlr_prof_end(took_ ? pi_ : -1, stream);
@@ -996,7 +1014,7 @@ static int gemm_qkv_rope_impl(const void* x, const void* wqkv, void* qkv, const 
         GemmParams p2 = fused_params((const bf16_t*)x + (size_t)done * ldx, wqkv, (bf16_t*)qkv + (size_t)done * N, M - done, N, K, ldx, K, N);
         p2.fuse = 2; p2.pos = pos + done; p2.rope_cos = cos_t; p2.rope_sin = sin_t; p2.max_pos = max_pos; p2.rope_cols = rope_cols;
         p2.bias = (const bf16_t*)bias;
-        if (seg) { SegArgs s2 = *sg; s2.u = (const bf16_t*)sg->u + (size_t)done * sg->ldu; seg_set(p2, &s2); }
+        if (seg) { SegArgs s2 = *sg; s2.u = (const bf16_t*)sg->u + (size_t)done * sg->ldu; seg_set(p2, &s2, &skp, done); }
         const int pj_ = vlr_prof_begin(VLR_K_GEMM_NT, 2.0 * (M - done) * N * K, stream);
         const bool took2_ = seg ? vlr_gemm256p_seg_try_launch(p2, stream) : vlr_gemm256p_fused_try_launch(p2, stream);
         vlr_prof_end(took2_ ? pj_ : -1, stream);
@@ -1093,6 +1111,7 @@ static int gemm_lora_impl(const void* x, int ldx, const void* W, void* y, int ld
     VLR_REQUIRE(x && W && y && u && Bl, "vlr_gemm_lora: null operand");
     VLR_REQUIRE(M > 0 && N > 0 && K > 0 && N % 8 == 0 && K % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "vlr_gemm_lora: bad shape M=%d N=%d K=%d", M, N, K);
     const SegArgs sg = {u, ldu, Bl, r, 0x7fffffff, 0x7fffffff};
+    const SegSkip skp;
     VLR_REQUIRE(r > 0 && r % 8 == 0 && ldu % 8 == 0 && ldu >= r, "vlr_gemm_lora: adapter segment r=%d ldu=%d", r, ldu);
     const int tn = (N + 255) / 256;
     const int peel = choose_peel(M, N, tn);          // (adapter-segment kernels run plain rounds)
@@ -1101,7 +1120,7 @@ static int gemm_lora_impl(const void* x, int ldx, const void* W, void* y, int ld
     GemmParams p = fused_params(x, W, y, M1, N, K, ldx, K, ldy);
     p.residual = (const bf16_t*)residual; p.ldr = ldr;
     p.out_f32 = f32; p.res_f32 = (f32 && residual) ? 1 : 0;
-    seg_set(p, &sg);
+    seg_set(p, &sg, &skp, 0);
     int done = 0;
     const int pi_ = vlr_prof_begin(VLR_K_GEMM_NT, 2.0 * M1 * N * K, stream);
     const bool took_ = vlr_gemm256p_seg_try_launch(p, stream);

@@ -407,7 +407,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
             const int pl = g1 ? pid - nwg0 : pid, tm = g1 ? tiles_m1 : tiles_m, tn_ = g1 ? tiles_n1 : tiles_n;
             int trow, tcol;
             if (shared_map) {
-                vlr_tile_of_shared(pl, tm, tn_, &trow, &tcol);
+                vlr_tile_of_shared(pl, tm, tn_, &trow, &tcol, (SEG && p.seg_skip) ? 1 : 0);      // rows rotate only where tiles differ in length
             } else {
                 const int GROUP = 8;
                 const int per_group = GROUP * tn_;
@@ -419,6 +419,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
             ptab[i * 8 + 0] = trow * PT;
             ptab[i * 8 + 1] = tcol * NW;
             ptab[i * 8 + 2] = g1 ? 1 : 0;
+            if constexpr (SEG) ptab[i * 8 + 3] = (p.seg_skip && p.seg_skip[trow]) ? 1 : 0;      // this row tile holds no row of the segment's second adapter
         }
     }
     __syncthreads();
@@ -438,7 +439,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     asm volatile("" : "+v"(lane));
 #define RFL(x) __builtin_amdgcn_readfirstlane(x)
     const int m0 = RFL(ptab[titer * 8 + 0]), n0 = RFL(ptab[titer * 8 + 1]);
-    const int kb = 0, ntp = nt;                    // a piece is a whole tile: K tiles [0, nt)
+    // a piece is a whole tile: K tiles [0, nt) - or, SEG with the row tile's skip flag set, the base K tiles and the first seg_keep / 64 K tiles
+    // of every sub-target's block of the segment (K tile s of the short list = K tile (s / kl) * (K2 / 64) + s % kl of the segment)
+    const bool seg_short = SEG && RFL(ptab[titer * 8 + 3]) != 0;
+    const int seg_kl = SEG ? p.seg_keep / PK : 0, seg_kf = SEG ? p.K2 / PK : 0;
+    const int kb = 0, ntp = seg_short ? nt1 + (FUSE == 1 ? 2 : 1) * seg_kl : nt;
     const bool has_next = CONT && titer + 1 < npieces;
     const int tni = has_next ? titer + 1 : titer;
     const int m0n = RFL(ptab[tni * 8 + 0]), n0n = RFL(ptab[tni * 8 + 1]);
@@ -515,7 +520,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                 int ln = lane;                       // opaque per call: keeps the adapter-segment addresses out of the loop-invariant
                 asm volatile("" : "+v"(ln));         // set hipcc would otherwise carry (and spill) through the whole K loop
                 char* dst = smem + ((tile + parb) & 1) * BUF_BYTES + h * HALF_BYTES;
-                const int k0 = (kb + tile - nt1) * PK;
+                int sx = kb + tile - nt1;
+                if (seg_short) sx = (sx / seg_kl) * seg_kf + sx % seg_kl;
+                const int k0 = sx * PK;
                 if constexpr (h < 2) stage_kc(p.A2 + a2off, p.lda2, m0 + h * 128, tp.M, k0, k2t, zero16, dst, wave, ln);
                 else stage_seg_b<FUSE>(p.B2, p.ldb2, n0, h - 2, tp.N, k0, p.K2, zero16, dst, wave, ln);
                 return;
@@ -529,7 +536,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                 int ln = lane;
                 asm volatile("" : "+v"(ln));
                 const uint32_t dst = lds_wave + ((tile + parb) & 1) * BUF_BYTES + h * HALF_BYTES;
-                const int s_ = kb + tile - nt1;
+                int s_ = kb + tile - nt1;
+                if (seg_short) s_ = (s_ / seg_kl) * seg_kf + s_ % seg_kl;
                 uint32_t o2[2];
                 if constexpr (h < 2) {
                     piece_off_kc(p.lda2, m0 + h * 128, tp.M, wave, ln, o2);

@@ -240,6 +240,20 @@ static int* row_tiles_buf(hipStream_t st, int ints) {
     }
     return s->p;
 }
+// 256-row tile flags of a row-restricted adapter (1 = no marked row in the tile) for the adapter-segment GEMMs of a layer pass
+// (vlr_gemm_seg_rowskip): per-stream device bytes behind the K-tile list of row_tiles_buf; NULL: VLR_SEG_SKIP=0, M % 256 != 0 never matters
+// (the last tile is simply partial), or no memory
+static const unsigned char* seg_skip_flags(hipStream_t st, const unsigned char* rowmask, int M) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("VLR_SEG_SKIP"); on = (e && e[0] == '0') ? 0 : 1; }
+    if (!on || !rowmask) return nullptr;
+    const int tiles = (M + 255) / 256;
+    int* buf = row_tiles_buf(st, M / 64 + 2 + (tiles + 3) / 4);
+    if (!buf) return nullptr;
+    unsigned char* flags = (unsigned char*)(buf + M / 64 + 2);
+    if (vlr_rows_tile_flags(rowmask, M, 256, flags, st) != VLR_OK) return nullptr;
+    return flags;
+}
 static bool row_tiles_on() {      // VLR_ROW_TILES=0: the K reductions of a row-restricted adapter read all token rows (A/B)
     static int on = -1;
     if (on < 0) { const char* e = getenv("VLR_ROW_TILES"); on = (e && e[0] == '0') ? 0 : 1; }
@@ -372,21 +386,27 @@ extern "C" int vlr_decoder_layer_fwd_lora_ex(const vlr_llama_cfg* cfg, const vlr
 #define MB(t) (lw->mask_bits && p > 0.f ? (unsigned char*)lw->mask_bits + (size_t)(t) * ((size_t)M * H / 8) : nullptr)      // packed keep mask of target t
 #define MT(t) (lw->mask_bits && p > 0.f ? (unsigned char*)lw->mask_bits + lora_rowmajor_bytes(H, I, M) + (size_t)(t) * (size_t)vlr_dropout_bits_kt_bytes(M, H) : nullptr)   // ... K-tile-blocked transposed
     const int rf = cfg->resid_f32;
+    // a row-restricted adapter (PLoRA alone): row tiles without a marked row skip the WHOLE segment (u is zero there)
+    const unsigned char* skipf = (r % 64 == 0) ? seg_skip_flags(st, rowmask, M) : nullptr;
     CHECK(norm_fwd(rf, x_in, w->ln1, a->xn1, a->rstd1, M, H, cfg->rms_eps, st));
     const int nq = lw->qkv_targets == 1 ? 1 : 3;             // one adapter over the fused projection (Qwen c_attn) or q, k, v separately
     CHECK(lora_group_a(nq, r, H, a->xn1, H, lw->a_qkv, u, ldu, sc, p, seed + 0, ws_xd, M, st, rowmask, MB(0), MT(0)));
+    CHECK(vlr_gemm_seg_rowskip(skipf, 0));
     CHECK(vlr_gemm_qkv_rope_lora(a->xn1, w->wqkv, w->bqkv, a->qkv, pos, cfg->rope_cos, cfg->rope_sin, M, N, Nq + Nkv, H, H,
                                  cfg->head_dim, cfg->max_pos, u, ldu, lw->b_qkv, r, nq == 1 ? N : Nq, nq == 1 ? 0 : Nkv, st));
     CHECK(vlr_attn_fwd_gqa(a->qkv, off(a->qkv, Nq), off(a->qkv, (size_t)Nq + Nkv), N, a->attn, Nq, a->lse, key_mask, batch, S,
                            cfg->heads, kvh, cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));
     CHECK(lora_group_a(1, r, H, a->attn, H, lw->a_o, off(u, 3 * (size_t)r), ldu, sc, p, seed + 3, XD(3), M, st, rowmask, MB(3), MT(3)));
+    CHECK(vlr_gemm_seg_rowskip(skipf, 0));
     if (rf) CHECK(vlr_gemm_lora_f32res(a->attn, H, w->wo, (float*)a->x_mid, H, (const float*)x_in, H, M, H, H, off(u, 3 * (size_t)r), ldu, lw->b_o, r, st));
     else CHECK(vlr_gemm_lora(a->attn, H, w->wo, a->x_mid, H, x_in, H, M, H, H, off(u, 3 * (size_t)r), ldu, lw->b_o, r, st));
     CHECK(norm_fwd(rf, a->x_mid, w->ln2, a->xn2, a->rstd2, M, H, cfg->rms_eps, st));
     CHECK(lora_group_a(2, r, H, a->xn2, H, lw->a_gu, off(u, 4 * (size_t)r), ldu, sc, p, seed + 4, XD(4), M, st, rowmask, MB(4), MT(4)));
+    CHECK(vlr_gemm_seg_rowskip(skipf, 0));
     CHECK(vlr_gemm_swiglu_lora(a->xn2, w->wgu, a->gu, a->act, M, I, H, H, off(u, 4 * (size_t)r), ldu, lw->b_gu, r, st));
     if (lw->a_down) {
         CHECK(lora_group_a(1, r, I, a->act, I, lw->a_down, off(u, 6 * (size_t)r), ldu, sc, p, seed + 6, XD(6), M, st, rowmask, MB(6), MT(6)));
+        CHECK(vlr_gemm_seg_rowskip(skipf, 0));
         if (rf) CHECK(vlr_gemm_lora_f32res(a->act, I, w->wdown, (float*)a->x_out, H, (const float*)a->x_mid, H, M, H, I, off(u, 6 * (size_t)r), ldu, lw->b_down, r, st));
         else CHECK(vlr_gemm_lora(a->act, I, w->wdown, a->x_out, H, a->x_mid, H, M, H, I, off(u, 6 * (size_t)r), ldu, lw->b_down, r, st));
     } else {
@@ -575,20 +595,27 @@ extern "C" int vlr_decoder_layer_fwd_lora2(const vlr_llama_cfg* cfg, const vlr_l
         CHECK(lora_group_a(n, rp, in, x, in, Ap, off(u, c + rl), ldu, pw->scale, pw->dropout, seed_p + t0, nullptr, M, st, rowmask, MB2(pw, t0), MT2(pw, t0), R));
         return VLR_OK;
     };
+    // row tiles without an image row run only the LoRA part (the first rl of every sub-target's R K elements) of the [B_lora | B_plora]
+    // segment: the PLoRA block of u is zero there (45 % of the row tiles at 490 x 490 / max_length 1024)
+    const unsigned char* skipf = (rl % 64 == 0 && R % 64 == 0) ? seg_skip_flags(st, rowmask, M) : nullptr;
     CHECK(norm_fwd(rf, x_in, w->ln1, a->xn1, a->rstd1, M, H, cfg->rms_eps, st));
     CHECK(both(nq, H, a->xn1, lw->a_qkv, pw->a_qkv, 0, 0));
+    CHECK(vlr_gemm_seg_rowskip(skipf, rl));
     CHECK(vlr_gemm_qkv_rope_lora(a->xn1, w->wqkv, w->bqkv, a->qkv, pos, cfg->rope_cos, cfg->rope_sin, M, N, Nq + Nkv, H, H,
                                  cfg->head_dim, cfg->max_pos, u, ldu, bc->qkv, R, nq == 1 ? N : Nq, nq == 1 ? 0 : Nkv, st));
     CHECK(vlr_attn_fwd_gqa(a->qkv, off(a->qkv, Nq), off(a->qkv, (size_t)Nq + Nkv), N, a->attn, Nq, a->lse, key_mask, batch, S,
                            cfg->heads, kvh, cfg->head_dim, 1, 1.0f / sqrtf((float)cfg->head_dim), st));
     CHECK(both(1, H, a->attn, lw->a_o, pw->a_o, 3 * (size_t)R, 3));
+    CHECK(vlr_gemm_seg_rowskip(skipf, rl));
     if (rf) CHECK(vlr_gemm_lora_f32res(a->attn, H, w->wo, (float*)a->x_mid, H, (const float*)x_in, H, M, H, H, off(u, 3 * (size_t)R), ldu, bc->o, R, st));
     else CHECK(vlr_gemm_lora(a->attn, H, w->wo, a->x_mid, H, x_in, H, M, H, H, off(u, 3 * (size_t)R), ldu, bc->o, R, st));
     CHECK(norm_fwd(rf, a->x_mid, w->ln2, a->xn2, a->rstd2, M, H, cfg->rms_eps, st));
     CHECK(both(2, H, a->xn2, lw->a_gu, pw->a_gu, 4 * (size_t)R, 4));
+    CHECK(vlr_gemm_seg_rowskip(skipf, rl));
     CHECK(vlr_gemm_swiglu_lora(a->xn2, w->wgu, a->gu, a->act, M, I, H, H, off(u, 4 * (size_t)R), ldu, bc->gu, R, st));
     if (lw->a_down) {
         CHECK(both(1, I, a->act, lw->a_down, pw->a_down, 6 * (size_t)R, 6));
+        CHECK(vlr_gemm_seg_rowskip(skipf, rl));
         if (rf) CHECK(vlr_gemm_lora_f32res(a->act, I, w->wdown, (float*)a->x_out, H, (const float*)a->x_mid, H, M, H, I, off(u, 6 * (size_t)R), ldu, bc->down, R, st));
         else CHECK(vlr_gemm_lora(a->act, I, w->wdown, a->x_out, H, a->x_mid, H, M, H, I, off(u, 6 * (size_t)R), ldu, bc->down, R, st));
     } else {

@@ -121,6 +121,8 @@ _SIGS = {
     "vlr_gemm_dropout_acc_multi_bits": [I, P, I, P, P, I, I, I, F, U64, F, I, P, L, P],
     "vlr_gemm_grouped_bits_rows": [I, P, P, P, I, I, I, I, I, I, I, L, L, L, F, I, I, U64, F, I, P, L, P, P],
     "vlr_rows_tile_list": [P, I, P, P],
+    "vlr_rows_tile_flags": [P, I, I, P, P],
+    "vlr_gemm_seg_rowskip": [P, I],
     "vlr_gemm_grouped_bits_ktiles": [I, P, P, P, I, I, I, I, I, I, I, L, L, L, F, I, I, U64, F, I, P, L, P, P],
     "vlr_gemm_dropout_acc_multi_rows": [I, P, I, P, P, I, I, I, F, U64, F, I, P, L, P, P],
     "vlr_gemm_swiglu_bwd_add": [P, P, P, P, P, I, I, I, P],
