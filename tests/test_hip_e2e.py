@@ -615,6 +615,17 @@ def test_evaluate_reports_eval_metrics(gpu):
               "logits/chosen", "logits/rejected"):
         assert f"eval_{k}" in out, k
     assert torch.equal(before, model.engine.policy.flat) and model.training
+    # generate_during_eval (trl 0.8.1 evaluation_loop): one random eval batch is sampled from policy and reference and logged as a table
+    tr.generate_during_eval = True
+    tr.max_length = max(len(r["prompt_input_ids"]) for r in rows) + 3
+    tr.tokenizer = SimpleNamespace(pad_token_id=0, eos_token_id=10 ** 6,
+                                   batch_decode=lambda t_, skip_special_tokens=True: [" ".join(map(str, (r.tolist() if hasattr(r, "tolist") else r))) for r in t_])
+    n_before = len(tr.log_history)
+    out2 = tr.evaluate()
+    assert "eval_loss" in out2
+    games = [e for e in tr.log_history[n_before:] if "game_log" in e]
+    assert len(games) == 1 and games[0]["game_log"]["columns"] == ["Prompt", "Policy", "Ref Model"] and len(games[0]["game_log"]["rows"]) == 2
+    assert torch.equal(before, model.engine.policy.flat) and model.training
 
 
 def test_generate_and_get_batch_samples(gpu):

@@ -567,7 +567,8 @@ class VLDPOTrainer:
             pick = random.sample(range(len(rows)), k=min(bs, len(rows)))
             sample = self._prepare_inputs(self.data_collator([rows[i] for i in pick]))
             policy_txt, ref_txt = self.get_batch_samples(self.model, sample)
-            table = [[pr, po[len(pr):], rf[len(pr):]] for pr, po, rf in zip(sample["prompt"], policy_txt, ref_txt)]
+            prompts = sample.get("prompt") or self.tokenizer.batch_decode(sample["prompt_input_ids"], skip_special_tokens=True)
+            table = [[pr, po[len(pr):], rf[len(pr):]] for pr, po, rf in zip(prompts, policy_txt, ref_txt)]
             if _rank() == 0:
                 self.log_history.append({"game_log": {"columns": ["Prompt", "Policy", "Ref Model"], "rows": table}, "step": self.state.global_step})
                 for row in table:
