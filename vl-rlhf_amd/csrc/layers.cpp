@@ -447,11 +447,12 @@ extern "C" int vlr_decoder_layer_bwd_lora_ex(const vlr_llama_cfg* cfg, const vlr
 #define MB(t) (lw->mask_bits && p > 0.f ? (unsigned char*)lw->mask_bits + (size_t)(t) * ((size_t)M * H / 8) : nullptr)      // packed keep mask of target t
 #define MT(t) (lw->mask_bits && p > 0.f ? (unsigned char*)lw->mask_bits + lora_rowmajor_bytes(H, I, M) + (size_t)(t) * (size_t)vlr_dropout_bits_kt_bytes(M, H) : nullptr)   // ... K-tile-blocked transposed
     // ---- MLP
-    static int fuse_down = -1;     // VLR_LORA_FUSE_DOWN=1: adapter term of down_proj first, then the dgrad GEMM with the SwiGLU backward in its epilogue
-    if (fuse_down < 0) { const char* e = getenv("VLR_LORA_FUSE_DOWN"); fuse_down = (e && e[0] == '1') ? 1 : 0; }
+    static int fuse_down = -1;     // adapter term of down_proj first, then the dgrad GEMM with the SwiGLU backward in its epilogue (VLR_LORA_FUSE_DOWN=0: three separate kernels)
+    if (fuse_down < 0) { const char* e = getenv("VLR_LORA_FUSE_DOWN"); fuse_down = (e && e[0] == '0') ? 0 : 1; }
     if (lw->a_down && fuse_down) {
-        // measured SLOWER than the three separate kernels (38.8 ms against 25.5 + 7.7 per step: the addend is a third 16-byte load stream
-        // in an epilogue that already reads gate | up) - kept behind the switch
+        // history: SLOWER than the three separate kernels in round 3 (38.8 ms against 25.5 + 7.7 per step: the addend is a third 16-byte
+        // load stream in an epilogue that already reads gate | up), equal in round 4 after the epilogue staging, 1.7 ms FASTER in round 5
+        // (482.3 against 484.1 ms, same box, twice each): the default now - no swiglu_bwd_kernel launch under LoRA
         CHECK(lora_group_bwd(1, r, I, o_h, a->act, dx_out, H, lw->a_down, lw->b_down, lg->a_down, lg->b_down, off(u, 6 * (size_t)r), ldu, ws_v,
                              ws->dact, sc, p, seed + 6, XD(6), accumulate, M, st, 1, rowmask, MB(6), MT(6), ktl));
         CHECK(vlr_gemm_swiglu_bwd_add(dx_out, w->wdown, a->gu, ws->dact, ws->dact, M, I, H, st));   // gu now holds [dgate | dup]
