@@ -56,6 +56,20 @@ __device__ __forceinline__ bf16x8 dx_frag_ks(const char* tile, int cbase, int s,
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
+#ifndef VLR_DX_WIDE
+#define VLR_DX_WIDE 1      // the dx tile is read and written as 16-byte accesses of 16 consecutive columns per lane (round 5); 0: 8 bytes = 4 columns per lane and tile
+#endif
+// x[j] (j = 0..3) holds, in the lanes of 16-lane row q, element (j, q) of a 4 x 4 matrix per lane column; afterwards x[c] holds element
+// (q, c): the transpose across the four lane rows.  Two exchange stages (v_permlane16_swap: odd rows of the first operand <-> even rows of
+// the second; v_permlane32_swap: upper half of the first <-> lower half of the second) as INLINE ASM - hipcc 7.2 folds several calls of the
+// builtins on related values into one (gemm256p.hip history).  Its own inverse.
+__device__ __forceinline__ void dx_xpose4(uint32_t (&x)[4]) {
+    asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(x[0]), "+v"(x[1]));
+    asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(x[2]), "+v"(x[3]));
+    asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(x[0]), "+v"(x[2]));
+    asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(x[1]), "+v"(x[3]));
+}
+
 // NT targets, KT = r / 64 K tiles per target, MASK: 0 no dropout, 1 keep masks (packed bits when p.bits, else hashed)
 template <int NT, int KT, int MASK>
 __global__ __launch_bounds__(256) void lora_dx_kernel(LoraDxParams p) {
@@ -118,15 +132,31 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(LoraDxParams p) {
     // prefetched per-unit / per-tile registers
     u32x2 dxr[2][4];                           // the dx tile of the CURRENT column tile (accumulate)
     uint32_t kb[2][4];                         // keep nibbles of the CURRENT unit
+    // VLR_DX_WIDE: lane (lm, lq) reads / writes the 16 consecutive columns of 16-column tile j = lq of its row - two 16-byte accesses, a row's
+    // four lanes = one 128-byte line - where the accumulator layout (4 columns of each of the four tiles) made it four 8-byte accesses of 32
+    // bytes per row and instruction.  d[i][j] stays in the ACCUMULATOR layout for the arithmetic: the loaded words are regrouped by
+    // dx_xpose4 (word w of the lane's 16 columns = (column group w >> 1, half w & 1)), the rounded results regrouped back before the store.
+    const int clw = wc * 64 + 16 * lq;         // first of this lane's 16 consecutive columns inside the column tile
     auto load_dx = [&](int c, u32x2 (&d)[2][4]) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) {
+#if VLR_DX_WIDE
+            u32x4 a = {0u, 0u, 0u, 0u}, b = a;
+            if (rowv[i] < p.M) {
+                const bf16_t* src = p.dx + (size_t)rowv[i] * p.in + c * 128 + clw;
+                a = *reinterpret_cast<const u32x4*>(src);
+                b = *reinterpret_cast<const u32x4*>(src + 8);
+            }
+            d[i][0] = u32x2{a[0], a[1]}; d[i][1] = u32x2{a[2], a[3]}; d[i][2] = u32x2{b[0], b[1]}; d[i][3] = u32x2{b[2], b[3]};      // (column group g of tile lq) - regrouped at use
+#else
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 u32x2 w = {0u, 0u};
                 if (rowv[i] < p.M) w = *reinterpret_cast<const u32x2*>(p.dx + (size_t)rowv[i] * p.in + c * 128 + cl + j * 16);
                 d[i][j] = w;
             }
+#endif
+        }
     };
     // keep masks of unit u.  Packed bits: wave 0 moves the [64 rows][16 B] tile of (column tile, target) into LDS with ONE LDS-DMA
     // instruction (lane = row) a unit ahead - visible to every wave after the next vmcnt(0) + barrier - and a lane reads its eight nibbles
@@ -232,7 +262,28 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(LoraDxParams p) {
             }
         if (last_t) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i) {
+#if VLR_DX_WIDE
+                // loaded words: lane row q holds (tile q, column group g) in d[i][g]; the accumulators hold (tile j, column group q) in sum[i][j]:
+                // transpose the loaded words to the accumulator layout, add in fp32, round, transpose back, store 2 x 16 bytes
+                uint32_t lo[4], hi[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) { lo[g] = dxr[i][g][0]; hi[g] = dxr[i][g][1]; }
+                if (p.accumulate) { dx_xpose4(lo); dx_xpose4(hi); }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 o = sum[i][j];
+                    if (p.accumulate) { o[0] += bf16lo(lo[j]); o[1] += bf16hi(lo[j]); o[2] += bf16lo(hi[j]); o[3] += bf16hi(hi[j]); }
+                    lo[j] = pack_bf16(o[0], o[1]);
+                    hi[j] = pack_bf16(o[2], o[3]);
+                }
+                dx_xpose4(lo); dx_xpose4(hi);
+                if (rowv[i] < p.M) {
+                    bf16_t* dst = p.dx + (size_t)rowv[i] * p.in + c * 128 + clw;
+                    *reinterpret_cast<u32x4*>(dst) = u32x4{lo[0], hi[0], lo[1], hi[1]};
+                    *reinterpret_cast<u32x4*>(dst + 8) = u32x4{lo[2], hi[2], lo[3], hi[3]};
+                }
+#else
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     f32x4 o = sum[i][j];
@@ -245,6 +296,8 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(LoraDxParams p) {
                     w[1] = pack_bf16(o[2], o[3]);
                     if (rowv[i] < p.M) *reinterpret_cast<u32x2*>(p.dx + (size_t)rowv[i] * p.in + c * 128 + cl + j * 16) = w;
                 }
+#endif
+            }
         }
         if (u + 1 < nunits) {
 #pragma unroll
