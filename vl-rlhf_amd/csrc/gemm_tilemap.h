@@ -42,19 +42,20 @@ VLR_HD inline void vlr_tile_of_shared(int pl, int tm, int tn, int* row, int* col
     const int s = rotate ? s0 : 0;         // (rotation of the rows, below)
     const int c0 = s0 * W, ws = (tn - c0) < W ? (tn - c0) : W;
     const int fb = ws >> 3, fullt = fb * h * 8;
-    // rotate = 1: rows rotate with the super-column (block rows by s, the 4 rows inside a block by s too).  The k-th run of a round always
+    // rotate = 1: rows rotate with the super-column (block rows by s, the 4 rows inside a block by s too) and the 4 rows of an XCD block are
+    // nr apart instead of adjacent (short tiles come in runs - the text rows of a sequence - and a block of adjacent rows is all short or all long).  The k-th run of a round always
     // goes to the same XCD and its j-th tile to the same workgroup, so WITHOUT the rotation a workgroup computes the same tile row in every
     // round of a band - fine when all tiles are equally long (and measured 1-3 ms better on the default step: the XCD's A panels survive
     // partly in its L2), wrong when they are not: adapter-segment launches whose all-text row tiles skip K tiles (vlr_gemm_seg_rowskip)
     // would last as long as the workgroups that own the long rows (the skip gained 0.7 ms without the rotation, 3-4 ms with it).
     if (l2 < fullt) {
         const int blk = l2 >> 5, t = l2 & 31;
-        *row = r0 + ((blk + s) % nr) * 4 + ((t + s) & 3);
+        *row = rotate ? r0 + (blk + s) % nr + nr * ((t + s) & 3) : r0 + (blk % nr) * 4 + (t & 3);      // rotating form: an XCD block's 4 rows are nr apart
         *col = c0 + (blk / nr) * 8 + (t >> 2);
     } else {                               // the narrow last block column of the band (1 .. 7 columns)
         const int l3 = l2 - fullt, bs = 4 * (ws - fb * 8);
         const int t = l3 % bs;
-        *row = r0 + ((l3 / bs + s) % nr) * 4 + ((t + s) & 3);
+        *row = rotate ? r0 + (l3 / bs + s) % nr + nr * ((t + s) & 3) : r0 + (l3 / bs) * 4 + (t & 3);
         *col = c0 + fb * 8 + (t >> 2);
     }
 }
