@@ -28,8 +28,8 @@ def _digest():
     return h.hexdigest()
 
 
-def kernel_digest(sources=("gemm256p.hip", "gemm.h", "common.h")):
-    """digest of the translation unit of ONE kernel family (default: the dominant 256x256 GEMM, gemm256p.hip and the two headers it
+def kernel_digest(sources=("gemm256p.hip", "gemm_tilemap.h", "gemm.h", "common.h")):
+    """digest of the translation unit of ONE kernel family (default: the dominant 256x256 GEMM, gemm256p.hip and the three headers it
     includes) + the compiler flags: what tools/pmc_traffic.sh records next to the counters it collects and bench.py compares before it
     quotes them - a change to another kernel's source does not make the GEMM's counters stale, a change to the GEMM's does."""
     h = hashlib.sha256()

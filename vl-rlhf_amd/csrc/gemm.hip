@@ -922,11 +922,11 @@ static int seg_check(const char* who, const SegArgs* sg) {
 
 static int gemm_swiglu_impl(const void* x, const void* wgu, void* gu, void* act, int M, int I, int K, int ldx, int store_gu,
                             const SegArgs* sg, hipStream_t stream) {
+    const SegSkip skp;       // (taken first: a pending vlr_gemm_seg_rowskip must not survive a call that fails its argument checks)
     VLR_REQUIRE(x && wgu && gu && act, "vlr_gemm_swiglu: null operand");
     VLR_REQUIRE(M > 0 && I > 0 && K > 0 && I % 8 == 0 && K % 8 == 0 && ldx % 8 == 0, "vlr_gemm_swiglu: bad shape M=%d I=%d K=%d ldx=%d", M, I, K, ldx);
     { int rc = seg_check("vlr_gemm_swiglu_lora", sg); if (rc != VLR_OK) return rc; }
     const bool seg = sg && sg->u;
-    const SegSkip skp;
     const int tn = (I + 127) / 128;
     const int peel = choose_peel(M, 2 * I, tn, seg ? 0 : K, stream, true);
     const int tm256 = (M + 255) / 256;
@@ -985,12 +985,12 @@ extern "C" int vlr_gemm_swiglu_lora(const void* x, const void* wgu, void* gu, vo
 static int gemm_qkv_rope_impl(const void* x, const void* wqkv, void* qkv, const int* pos, const float* cos_t, const float* sin_t,
                               int M, int N, int rope_cols, int K, int ldx, int head_dim, int max_pos, const SegArgs* sg, const void* bias,
                               hipStream_t stream) {
+    const SegSkip skp;
     VLR_REQUIRE(x && wqkv && qkv && pos && cos_t && sin_t, "vlr_gemm_qkv_rope: null operand");
     VLR_REQUIRE(M > 0 && N > 0 && K > 0 && N % 8 == 0 && K % 8 == 0 && ldx % 8 == 0, "vlr_gemm_qkv_rope: bad shape M=%d N=%d K=%d", M, N, K);
     VLR_REQUIRE(head_dim % 16 == 0 && rope_cols % head_dim == 0 && rope_cols <= N, "vlr_gemm_qkv_rope: rope_cols %d / head_dim %d / N %d", rope_cols, head_dim, N);
     { int rc = seg_check("vlr_gemm_qkv_rope_lora", sg); if (rc != VLR_OK) return rc; }
     const bool seg = sg && sg->u;
-    const SegSkip skp;
     int done = 0;
     if (head_dim == 128 && (!bias || !((uintptr_t)bias & 7))) {
         const int tn = (N + 255) / 256;
@@ -1108,10 +1108,10 @@ extern "C" int vlr_gemm_lora_f32res(const void* x, int ldx, const void* W, float
 }
 static int gemm_lora_impl(const void* x, int ldx, const void* W, void* y, int ldy, const void* residual, int ldr, int M, int N, int K,
                           const void* u, int ldu, const void* Bl, int r, int f32, hipStream_t stream) {
+    const SegSkip skp;
     VLR_REQUIRE(x && W && y && u && Bl, "vlr_gemm_lora: null operand");
     VLR_REQUIRE(M > 0 && N > 0 && K > 0 && N % 8 == 0 && K % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "vlr_gemm_lora: bad shape M=%d N=%d K=%d", M, N, K);
     const SegArgs sg = {u, ldu, Bl, r, 0x7fffffff, 0x7fffffff};
-    const SegSkip skp;
     VLR_REQUIRE(r > 0 && r % 8 == 0 && ldu % 8 == 0 && ldu >= r, "vlr_gemm_lora: adapter segment r=%d ldu=%d", r, ldu);
     const int tn = (N + 255) / 256;
     const int peel = choose_peel(M, N, tn);          // (adapter-segment kernels run plain rounds)
