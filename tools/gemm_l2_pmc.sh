@@ -5,13 +5,14 @@
 #   pass 2  GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 # The ideal hit rate of the 8 x 4 tile footprint of an XCD (32 workgroups share 8 A panels and 4 B panels in its 4 MB L2) is
 # 1 - 12 / 64 = 81 %: every panel line is fetched from the fabric once and hit by the other 3 (A) / 7 (B) workgroups.
+# MODES=0 bash tools/gemm_l2_pmc.sh: the tile map of rounds 1-4 (default 32: the shared-panel map).
 # Writes gpurun_out/gemm_l2_pmc.txt; copy to profiles/ to have it judged.
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 rm -rf /tmp/pmc_l2_1 /tmp/pmc_l2_2
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --kernel-trace -d /tmp/pmc_l2_1 -o r -f csv -- python tools/gemm_sched_bench.py --rounds 1 --iters 1 > /tmp/pmc_l2_1.log 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -d /tmp/pmc_l2_2 -o r -f csv -- python tools/gemm_sched_bench.py --rounds 1 --iters 1 > /tmp/pmc_l2_2.log 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --kernel-trace -d /tmp/pmc_l2_1 -o r -f csv -- python tools/gemm_sched_bench.py --rounds 1 --iters 1 --modes ${MODES:-32} > /tmp/pmc_l2_1.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -d /tmp/pmc_l2_2 -o r -f csv -- python tools/gemm_sched_bench.py --rounds 1 --iters 1 --modes ${MODES:-32} > /tmp/pmc_l2_2.log 2>&1
 python - <<'PY'
 import csv, glob, collections
 NAMES = ["qkv+rope NT [M,12288,4096]", "o_proj f32res NT [M,4096,4096]", "swiglu NT [M,22016,4096]", "down f32res NT [M,4096,11008]", "dgrad qkv NN [M,4096,12288]",

@@ -22,7 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=8)
-    ap.add_argument("--modes", default="0")
+    ap.add_argument("--modes", default="32", help="vlr_gemm_set_sched values to compare (32 = the production default since round 5: shared-panel tile map; 0 = the tile map of rounds 1-4)")
     ap.add_argument("--M", type=int, default=12792)
     a = ap.parse_args()
     modes = [int(m) for m in a.modes.split(",")]
