@@ -543,6 +543,7 @@ def main():
                      "rccl_channels_created": rccl_debug_channels(rccl_log) if world > 1 else None,     # per communicator of rank 0 in creation order (torch's, ours, the probe's), from RCCL's own INIT log
                      "bucket_probe": probe,
                      "comm_cus": reducer.comm_cus if reducer is not None else 0, "compute_cus": _hip.helper("vlr_compute_cus"),
+                     "comm_cus_scope": reducer.reserve_scope if reducer is not None else None,      # "backward": the CUs are given up only while buckets are in flight (compute_cus above = outside that window)
                      "rccl_max_min_nchannels": list(reducer.rccl_channels) if reducer is not None else None,     # NCCL_MAX_NCHANNELS := comm_cus for torch's communicator (parallel.rccl_channel_env); MIN only if the user set it
                      "exposed_ms_per_step": exposed_ms, "bytes_per_step": 2 * (eng.lora_layout.numel if a.lora else eng.layout.numel)},
             "roofline": {"bound": "mfma", "kernel": "gemm256p_kernel<A_KS,B_KS> (8-phase 256x256x64 bf16 GEMM: NT/NN/TN)", "achieved": round(achieved, 1),

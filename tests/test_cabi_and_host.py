@@ -323,6 +323,27 @@ def test_rccl_channel_bounds_follow_the_cu_reservation(monkeypatch):
     assert P.rccl_channel_env(e) == (None, None) and e == {}
 
 
+def test_cus_are_given_up_only_while_buckets_are_in_flight(monkeypatch):
+    """GradReducer: vlr_set_comm_cus(k) with the first bucket of a backward, vlr_set_comm_cus(0) at wait() - the forward passes and a step
+    without an exchange (gradient-accumulation micro-step, world 1) keep the whole chip; VLR_COMM_CUS_SCOPE=step holds them all along."""
+    from vlrlhf import _hip, parallel as P
+    calls = []
+    monkeypatch.setattr(_hip, "helper", lambda name, *a: calls.append((name,) + a) or 0)
+    flat = torch.zeros(64)
+    for scope, expect in (("backward", [16, 0, 16, 0]), ("step", [16])):
+        monkeypatch.setenv("VLR_COMM_CUS_SCOPE", scope)
+        r = P.GradReducer(flat, {"a": (0, 32), "b": (32, 64)})
+        assert r.comm_cus == 0 and r.reserve_scope == scope          # world 1 / CPU: nothing reserved
+        r.cuda, r.comm_cus = True, 16                                  # the bookkeeping alone, as on a GPU rank of a data-parallel run
+        del calls[:]
+        if scope == "step":
+            r._reserve(True)                                           # (GradReducer.__init__ on a GPU rank)
+        for _ in range(2):                                             # two steps
+            r._reserve(True); r._reserve(True)                         # buckets "a", "b"
+            r._reserve(False)                                          # wait()
+        assert calls == [("vlr_set_comm_cus", k) for k in expect]
+
+
 def test_sampling_filter_follows_the_logits_warpers():
     """LlavaForRL.generate's temperature / top-k / top-p filter against a plain restatement of transformers' warpers"""
     from vlrlhf.models.Llava import sampling_filter

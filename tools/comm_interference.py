@@ -6,7 +6,7 @@ One MI355X cannot run a multi-rank RCCL ring, and a 1-rank ncclAllReduce launche
 footprint: after every gradient bucket of the real backward (lm_head, 32 decoder layers, tail - the 34 buckets of GradReducer) the
 communication stream runs `vlr_comm_probe` - `wgs` workgroups streaming 2 x bucket bytes (a ring all-reduce reads and writes every
 element about twice) - exactly where vlr_allreduce_bucket would run.  Reported: ms/step for wgs in {0, 16, 32} x comm_cus in
-{0, 8, 16, 32}.
+{0, 8, 16, 32} x the window the CUs are given up for (while buckets are in flight - GradReducer's default since round 5 - or the whole step).
 
     python tools/comm_interference.py [--steps 4]
 """
@@ -29,15 +29,22 @@ from vlrlhf.parallel import GradReducer  # noqa: E402
 class ProbeReducer(GradReducer):
     """GradReducer whose transport is the probe kernel (same stream, same events, same bucket order)"""
 
-    def __init__(self, flat, buckets, wgs):
+    def __init__(self, flat, buckets, wgs, comm_cus=0, scope="backward"):
         super().__init__(flat, buckets)
         self.world = 2                  # pretend: the buckets are issued
         self.wgs = wgs
+        self.comm_cus, self.reserve_scope = comm_cus, scope
+        if scope == "step":
+            self._reserve(True)
         self.scratch = torch.empty(max(hi - lo for lo, hi in buckets.values()), dtype=flat.dtype, device=flat.device)
 
     def bucket_ready(self, name):
         lo, hi = self.buckets[name]
-        if hi <= lo or not self.wgs:
+        if hi <= lo:
+            return
+        self._reserve(True)             # as GradReducer.bucket_ready: the launches after the first bucket leave comm_cus CUs free
+        self._issued = True
+        if not self.wgs:
             return
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
@@ -54,6 +61,7 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--wgs", default="0,16,32")
     ap.add_argument("--cus", default="0,8,16,32")
+    ap.add_argument("--scopes", default="backward,step", help="when the CUs are given up: while buckets are in flight (GradReducer's default) / the whole step")
     a = ap.parse_args()
     from vlrlhf.models.Llava import LlavaDPOTrainer, LlavaForRL
     from vlrlhf.utils.synthetic import LLAVA_1_5_7B, init_random_model, synthetic_batch
@@ -74,9 +82,9 @@ def main():
 
     out = {}
     for wgs in [int(v) for v in a.wgs.split(",")]:
-        for k in [int(v) for v in a.cus.split(",")]:
-            _hip.helper("vlr_set_comm_cus", k)
-            eng.reducer = ProbeReducer(eng.grads, eng.layout.bucket_after, wgs)
+        for k, scope in [(int(v), sc) for v in a.cus.split(",") for sc in (a.scopes.split(",") if int(v) else ["-"])]:
+            _hip.helper("vlr_set_comm_cus", 0)
+            eng.reducer = ProbeReducer(eng.grads, eng.layout.bucket_after, wgs, k, scope)
             step()
             torch.cuda.synchronize()
             t0 = time.time()
@@ -84,8 +92,8 @@ def main():
                 step()
             torch.cuda.synchronize()
             ms = (time.time() - t0) / a.steps * 1e3
-            out[f"probe_wgs={wgs},comm_cus={k}"] = round(ms, 2)
-            print(f"probe workgroups {wgs:3d}  comm_cus {k:3d} (compute grid {_hip.helper('vlr_compute_cus')}): {ms:8.2f} ms/step", flush=True)
+            out[f"probe_wgs={wgs},comm_cus={k},scope={scope}"] = round(ms, 2)
+            print(f"probe workgroups {wgs:3d}  comm_cus {k:3d}  scope {scope:8s}: {ms:8.2f} ms/step", flush=True)
     _hip.helper("vlr_set_comm_cus", -1)
     print(json.dumps(out))
 

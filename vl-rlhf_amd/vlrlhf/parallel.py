@@ -176,15 +176,27 @@ class GradReducer:
         self.native, self.transport, self.transport_note = make_transport(group, self.cuda)
         # CUs left to the RCCL ring kernels that run beside the backward: the persistent GEMM / attention launches size their grids to
         # (CUs - comm_cus).  Default 16 under data parallelism (2 per XCD), from the single-GPU interference bench (tools/
-        # comm_interference.py, DESIGN.md section 5: a 16-workgroup stand-in for the ring kernel cost 13 % of the step against
-        # 256-workgroup launches and 5.5 % against 240-workgroup ones); VLR_COMM_CUS overrides, 0 switches it off.
+        # comm_interference.py); VLR_COMM_CUS overrides, 0 switches it off.  The CUs are given up only WHILE BUCKETS
+        # ARE IN FLIGHT - from the first bucket of a backward to wait() - so the two forward passes (a third of the step, no exchange
+        # beside them) and the whole of a LoRA step (one bucket, issued after the backward) keep the full chip; both forward passes of a
+        # step see the same grid, which the policy == reference => loss == ln 2 identity needs.  VLR_COMM_CUS_SCOPE=step: the whole step
+        # (rounds 3-5a).
         self.comm_cus = 0
+        self.reserve_scope = os.environ.get("VLR_COMM_CUS_SCOPE", "backward").lower()
+        self._reserved = False
         self.rccl_channels = (os.environ.get("NCCL_MAX_NCHANNELS"), os.environ.get("NCCL_MIN_NCHANNELS"))      # the process-wide bound (torch's communicator)
         self.channel_bound = self.native.channel_bound if self.native is not None else ("env" if os.environ.get("NCCL_MAX_NCHANNELS") else "none")
         if self.cuda and self.world > 1:
-            from . import _hip
             self.comm_cus = comm_cus_default()
-            _hip.helper("vlr_set_comm_cus", self.comm_cus)
+            if self.reserve_scope == "step":
+                self._reserve(True)
+
+    def _reserve(self, on: bool):
+        """give `comm_cus` CUs up to / take them back from the ring kernels: the grids of the launches that FOLLOW on the host"""
+        if self.cuda and self.comm_cus and on != self._reserved and (on or self.reserve_scope != "step"):
+            from . import _hip
+            _hip.helper("vlr_set_comm_cus", self.comm_cus if on else 0)
+            self._reserved = on
 
     def bucket_ready(self, name: str):
         if not self.enabled or self.world == 1:
@@ -197,6 +209,7 @@ class GradReducer:
             ev.record(torch.cuda.current_stream())
             self.stream.wait_event(ev)
             self._issued = True
+            self._reserve(True)
             if self.native is not None:
                 for a in range(lo, hi, self.max_elems):
                     self.native.all_reduce_(self.grads[a:min(hi, a + self.max_elems)], self.stream)
@@ -219,6 +232,7 @@ class GradReducer:
             for w in self._pending:
                 w.wait()
             torch.cuda.current_stream().wait_stream(self.stream)
+            self._reserve(False)
         self._pending = []
         self._issued = False
 
