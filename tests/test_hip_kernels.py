@@ -1557,7 +1557,19 @@ def test_persistent_kernels_with_comm_cus(hip, k):
         o = torch.full((B * S, H), float("nan"), dtype=torch.bfloat16, device=DEV)
         lse = torch.zeros(B, nh, (S + 63) // 64 * 64, dtype=torch.float32, device=DEV)
         hip.call("vlr_attn_fwd", qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, o, H, lse, None, B, S, nh, hd, 1, 1 / math.sqrt(hd))
+        # the backward's launches in the bucket window: a data-gradient GEMM (NN; at 240 CUs 5 tile rows go to the 128x128 kernel: 45 x 16 tiles
+        # = 3 rounds) and the weight-gradient pair dW_qkv + dW_o (TN; 4 + 2 rounds apart, 4 + 4 peeled tile rows together)
+        bn = rnd(K, N, seed=6, scale=0.5)
+        cn = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        hip.call("vlr_gemm_bf16", 1, a, bn, cn, None, None, M, N, K, K, N, N, 0, 0, 0, 0)
+        dy, xn, dm, at = rnd(K, 3 * N, seed=7, scale=0.5), rnd(K, N, seed=8, scale=0.5), rnd(K, N, seed=9, scale=0.5), rnd(K, N, seed=10, scale=0.5)
+        w0 = torch.full((3 * N, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        w1 = torch.full((N, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        hip.call("vlr_gemm_bf16_tn_pair", dy, xn, w0, 3 * N, N, 3 * N, N, N, dm, at, w1, N, N, N, N, N, K, 0)
         torch.cuda.synchronize()
+        check(cn, a.float() @ bn.float(), 8e-3, "NN gemm on a reduced grid")
+        check(w0, dy.float().t() @ xn.float(), 8e-3, "TN pair, first problem, on a reduced grid")
+        check(w1, dm.float().t() @ at.float(), 8e-3, "TN pair, second problem, on a reduced grid")
         ref = a.float() @ b.float().t()
         check(c, ref, 8e-3, "gemm on a reduced grid")
         check(cf, ref + res, 2e-5, "f32res gemm on a reduced grid")

@@ -653,6 +653,17 @@ static int gemm_impl(int layout, const void* A, const void* B, void* C, const vo
 
 // wave quantisation (see gemm_impl): how many of the last 256-row tile rows to peel off so that the 256x256-tile part is a
 // whole number of rounds on the 256 CUs; tn = workgroup tiles per tile row
+// most tile rows a launch may give to the 128x128 kernel: 3 on the whole chip (the shapes of the path were tuned with it), 6 when CUs are left
+// to RCCL - 240-CU rounds fit the 7B shapes worse (12792 x 4096: 800 tiles = 3.33 rounds; 45 tile rows = 3 rounds exactly + 1272 rows peeled)
+static int peel_max(int ncu) {
+    static int env = -1;
+    if (env < 0) { const char* e = getenv("VLR_PEEL_MAX"); env = e ? atoi(e) : 0; if (env < 0 || env > 8) env = 0; }
+    if (env) return env;
+    int dev = 0, cus = 0;
+    static int dev_cus = 0;
+    if (!dev_cus) dev_cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 8) ? (cus & ~7) : 256;
+    return ncu < dev_cus ? 6 : 3;
+}
 static int choose_peel(int M, int N, int tn, int K = 0, hipStream_t stream = nullptr, bool tail256 = false) {
     const int tm256 = (M + 255) / 256;
     int peel = 0;
@@ -661,7 +672,8 @@ static int choose_peel(int M, int N, int tn, int K = 0, hipStream_t stream = nul
         const int full = tm256 * tn;
         const double base = (double)((full + ncu - 1) / ncu);
         double best = base;
-        for (int r = 1; r <= 3 && tm256 - r >= 2; ++r) {
+        const int rmax = peel_max(ncu);
+        for (int r = 1; r <= rmax && tm256 - r >= 2; ++r) {
             const int t1 = (tm256 - r) * tn;
             const int rem_rows = M - (tm256 - r) * 256;
             const long t128 = (long)((rem_rows + 127) / 128) * ((N + 127) / 128);
@@ -690,25 +702,40 @@ extern "C" int vlr_gemm_bf16_scaled(int layout, const void* A, const void* B, vo
 // Two weight-gradient GEMMs of one layer (TN: C_i [M_i][N_i] = A_i^T B_i over the same K token rows) as ONE persistent launch: their tile
 // counts add up before they are rounded to whole rounds of the CUs (LLaVA-1.5-7B: dW_gate|up 1376 tiles + dW_down 688 = 8.06 rounds
 // instead of 6 + 3; one tile row of 16 tiles goes to the 128x128 kernel split along K and 8 rounds remain).  Falls back to two calls.
-extern "C" int vlr_gemm_bf16_tn_pair(const void* A0, const void* B0, void* C0, int M0, int N0, int lda0, int ldb0, int ldc0,
-                                     const void* A1, const void* B1, void* C1, int M1, int N1, int lda1, int ldb1, int ldc1, int K,
-                                     int accumulate, hipStream_t stream) {
-    VLR_REQUIRE(A0 && B0 && C0 && A1 && B1 && C1 && M0 > 0 && N0 > 0 && M1 > 0 && N1 > 0 && K > 0, "vlr_gemm_bf16_tn_pair: bad arguments");
+// rounds of the two launches apart, and the best (problem, tile rows peeled to the 128x128 kernel) for the joint launch, priced like choose_peel
+static double tn_pair_plan(int M0, int N0, int M1, int N1, int* sep_out, int* bq_out, int* br_out) {
     const int ncu = vlr_compute_cus();
     const int tm[2] = {(M0 + 255) / 256, (M1 + 255) / 256}, tn[2] = {(N0 + 255) / 256, (N1 + 255) / 256};
     const int Ms[2] = {M0, M1}, Ns[2] = {N0, N1};
-    const int sep = (tm[0] * tn[0] + ncu - 1) / ncu + (tm[1] * tn[1] + ncu - 1) / ncu;       // rounds of two launches
-    // best (problem, tile rows peeled to the 128x128 kernel) for the joint launch, priced like choose_peel
+    *sep_out = (tm[0] * tn[0] + ncu - 1) / ncu + (tm[1] * tn[1] + ncu - 1) / ncu;
     double best = 1e30;
-    int bq = -1, br = 0;
+    const int rmax = peel_max(ncu);
+    *bq_out = -1; *br_out = 0;
     for (int q = 0; q < 2; ++q)
-        for (int r = 0; r <= 3 && tm[q] - r >= 1; ++r) {
+        for (int r = 0; r <= rmax && tm[q] - r >= 1; ++r) {
             const int t = tm[0] * tn[0] + tm[1] * tn[1] - r * tn[q];
             const int rem_rows = r ? Ms[q] - (tm[q] - r) * 256 : 0;
             const long t128 = (long)((rem_rows + 127) / 128) * ((Ns[q] + 127) / 128);
             const double est = (double)((t + ncu - 1) / ncu) + 0.7 * (double)((t128 + 2 * ncu - 1) / (2 * ncu));
-            if (est < best - 1e-9) { best = est; bq = q; br = r; }
+            if (est < best - 1e-9) { best = est; *bq_out = q; *br_out = r; }
         }
+    return best;
+}
+// rounds the joint launch of two TN problems saves over two launches on the CUs the compute kernels have NOW (layers.cpp: dW_qkv + dW_o are
+// 3 + 1 rounds of 256 CUs either way, but 4 + 2 against 5 of 240)
+double vlr_internal_tn_pair_saves(int M0, int N0, int M1, int N1) {
+    int sep, bq, br;
+    const double best = tn_pair_plan(M0, N0, M1, N1, &sep, &bq, &br);
+    return (double)sep - best;
+}
+extern "C" int vlr_gemm_bf16_tn_pair(const void* A0, const void* B0, void* C0, int M0, int N0, int lda0, int ldb0, int ldc0,
+                                     const void* A1, const void* B1, void* C1, int M1, int N1, int lda1, int ldb1, int ldc1, int K,
+                                     int accumulate, hipStream_t stream) {
+    VLR_REQUIRE(A0 && B0 && C0 && A1 && B1 && C1 && M0 > 0 && N0 > 0 && M1 > 0 && N1 > 0 && K > 0, "vlr_gemm_bf16_tn_pair: bad arguments");
+    const int tm[2] = {(M0 + 255) / 256, (M1 + 255) / 256};
+    const int Ms[2] = {M0, M1};
+    int sep, bq, br;
+    const double best = tn_pair_plan(M0, N0, M1, N1, &sep, &bq, &br);
     static int pair_on = -1;
     if (pair_on < 0) { const char* e = getenv("VLR_GEMM_PAIR"); pair_on = (e && e[0] == '0') ? 0 : 1; }
     // (equal round counts still pair: one persistent launch instead of a persistent one plus a cold one - dW_qkv + dW_o = 3 + 1 rounds)

@@ -141,6 +141,7 @@ extern "C" int vlr_decoder_layer_fwd(const vlr_llama_cfg* cfg, const vlr_layer_w
     return vlr_decoder_layer_fwd_ex(cfg, w, a, x_in, pos, key_mask, batch, S, 1, st);
 }
 
+double vlr_internal_tn_pair_saves(int M0, int N0, int M1, int N1);      // gemm.hip: rounds vlr_gemm_bf16_tn_pair saves over two launches on the compute CUs of the moment
 extern "C" int vlr_decoder_layer_bwd(const vlr_llama_cfg* cfg, const vlr_layer_weights* w, const vlr_layer_grads* g,
                                      int accumulate, const vlr_layer_acts* a, const vlr_layer_bwd_ws* ws,
                                      const void* x_in, const void* dx_out, void* dx_in, const int* pos,
@@ -180,10 +181,11 @@ extern "C" int vlr_decoder_layer_bwd(const vlr_llama_cfg* cfg, const vlr_layer_w
     // ---- attention
     // dW_o is one round of 256 tiles on its own; together with dW_qkv it would be 768 + 256 = 4 whole rounds of ONE persistent launch
     // (vlr_gemm_bf16_tn_pair below; both operands - dx_mid, attn - stay untouched until the end of this call).  Measured NEUTRAL in round 5
-    // (565.9 vs 565.9 ms, same box, twice each): off unless VLR_PAIR_QKVO=1
+    // (565.9 vs 565.9 ms, same box, twice each) on the whole chip; with CUs left to RCCL (240-CU rounds: 4 + 2 apart, 5 together) it saves a
+    // round - so: paired when the joint launch saves rounds on the CUs the launches have now (VLR_PAIR_QKVO=1 always, =0 never)
     static int pair_qkvo = -1;
-    if (pair_qkvo < 0) { const char* e = getenv("VLR_PAIR_QKVO"); pair_qkvo = (e && e[0] == '1') ? 1 : 0; }
-    const bool pair_o = pair_qkvo && !two && !accumulate;
+    if (pair_qkvo < 0) { const char* e = getenv("VLR_PAIR_QKVO"); pair_qkvo = !e ? 2 : (e[0] == '1' ? 1 : 0); }
+    const bool pair_o = !two && !accumulate && (pair_qkvo == 1 || (pair_qkvo == 2 && vlr_internal_tn_pair_saves(N, H, H, Nq) >= 0.25));
     if (two) { sd = fork_side(st); }
     if (!pair_o) CHECK(vlr_gemm_bf16(2, ws->dx_mid, a->attn, g->wo, nullptr, nullptr, H, Nq, M, H, Nq, Nq, 0, 0, accumulate, 0, sd));
     if (two) side_done(2);
