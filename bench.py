@@ -350,10 +350,10 @@ def main():
             os.environ["VLR_COMM"] = "torch"
             reducer = eng.make_reducer()
         # one 0.4 GB bucket (a decoder layer's gradients) on communicators of their own: RCCL's default channel count against the bound
-        # that matches the CU reservation
+        # that matches the CU reservation, and against half of it (would 8 CUs do?)
         n_bucket = 4 * cfg["hidden"] * cfg["hidden"] + 3 * cfg["hidden"] * cfg["inter"]
         mk = (lambda bound: NativeComm(channels=bound)) if reducer.transport == "native" else (lambda bound: _TorchComm())
-        probe = bucket_probe(world, rank, mk, n_bucket, torch.bfloat16, eng.dev, (0, comm_cus_default()) if reducer.transport == "native" else (comm_cus_default(),),
+        probe = bucket_probe(world, rank, mk, n_bucket, torch.bfloat16, eng.dev, tuple(sorted({0, 8, comm_cus_default()})) if reducer.transport == "native" else (comm_cus_default(),),
                              log_path=rccl_log)
     tr.ref_on_side_stream = not a.no_side_stream
     if a.ref_pipeline:
