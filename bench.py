@@ -458,7 +458,8 @@ def main():
     import math
     assert math.isfinite(loss_first) and math.isfinite(loss_last), (loss_first, loss_last)
     assert torch.isfinite(eng.norm_out).all(), "non-finite gradient norm in the timed region"
-    # exposed communication: the same steps with the gradient exchange switched off (ranks diverge afterwards - timing only)
+    # exposed communication: the same steps with the gradient exchange switched off (ranks diverge afterwards - timing only); no bucket is
+    # issued, so no CUs are given up either: the difference is everything the exchange costs (its exposed part + the bucket-window reservation)
     exposed_ms = None
     if reducer is not None:
         reducer.enabled = False
