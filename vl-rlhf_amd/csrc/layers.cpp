@@ -523,9 +523,11 @@ struct Lora2Side {          // one adapter's view of a group
     int r; float scale, p; uint64_t seed; const void* A; void* dA; void* dB; const unsigned char* bits; const unsigned char* bits_kt;
 };
 // dx [M][in] already holds dy W.  L: the trainable adapter (dA / dB written), P: the frozen row-masked one (dA = dB = NULL).
+// dx_fresh = 1: dx is WRITTEN (the adapter terms alone - the first one, LoRA's, covers every row; the caller adds dy W afterwards)
 static int lora2_group_bwd(int n, int in, const int* outs, const void* x, const void* dy, int lddy, const Lora2Side& L, const Lora2Side& P,
                            const void* Bcomb, const void* u, int ldu, void* v, void* dx, int accumulate, int M, const unsigned char* rowmask,
-                           hipStream_t st) {
+                           hipStream_t st, int dx_fresh = 0) {
+    int acc_dx = dx_fresh ? 0 : 1;
     const int R = L.r + P.r, nR = n * R;
     const long gstride = (long)M * in / 8;
     size_t ofs[4] = {0, 0, 0, 0};
@@ -558,12 +560,13 @@ static int lora2_group_bwd(int n, int in, const int* outs, const void* x, const 
                     else CHECK(vlr_gemm_grouped_bits(2, vt, x, off(a.dA, (size_t)t * a.r * in), a.r, in, M, nR, in, in, 1, 0L, 0L, 0L,
                                                      a.scale / (1.f - a.p), accumulate, 2, a.seed + t, a.p, in, bt, 0L, st));
                 }
-                CHECK(vlr_gemm_dropout_acc_multi_rows(1, vt, nR, At, dx, M, in, a.r, a.p, a.seed + t, a.scale, 1, bt, gstride, side == 1 ? rowmask : nullptr, st));
+                CHECK(vlr_gemm_dropout_acc_multi_rows(1, vt, nR, At, dx, M, in, a.r, a.p, a.seed + t, a.scale, acc_dx, bt, gstride, side == 1 ? rowmask : nullptr, st));
             } else {
                 if (a.dA) CHECK(vlr_gemm_bf16_scaled(2, vt, x, off(a.dA, (size_t)t * a.r * in), nullptr, nullptr, a.r, in, M, nR, in, in, 0, 0,
                                                      accumulate, 0, a.scale, st));
-                CHECK(vlr_gemm_bf16_scaled(1, vt, At, dx, nullptr, nullptr, M, in, a.r, nR, in, in, 0, 0, 1, 0, a.scale, st));
+                CHECK(vlr_gemm_bf16_scaled(1, vt, At, dx, nullptr, nullptr, M, in, a.r, nR, in, in, 0, 0, acc_dx, 0, a.scale, st));
             }
+            acc_dx = 1;
         }
     }
     return VLR_OK;
@@ -644,7 +647,16 @@ extern "C" int vlr_decoder_layer_bwd_lora2(const vlr_llama_cfg* cfg, const vlr_l
         return Lora2Side{x_->r, x_->scale, x_->dropout, seed + (uint64_t)t0, A, dA, dB, MB2(x_, t0), MT2(x_, t0)};
     };
     // ---- MLP
-    if (lw->a_down) {
+    // (as vlr_decoder_layer_bwd_lora_ex: the adapter terms of down_proj first, then the dgrad GEMM with the SwiGLU backward in its epilogue and
+    // those terms as its addend - no separate pass over [M][2I]; VLR_LORA_FUSE_DOWN=0: three kernels)
+    static int fuse_down = -1;
+    if (fuse_down < 0) { const char* e = getenv("VLR_LORA_FUSE_DOWN"); fuse_down = (e && e[0] == '0') ? 0 : 1; }
+    if (lw->a_down && fuse_down) {
+        CHECK(lora2_group_bwd(1, I, o_h, a->act, dx_out, H, side(lw, lw->a_down, lg->a_down, lg->b_down, seed_l, 6),
+                              side(pw, pw->a_down, nullptr, nullptr, seed_p, 6), bc->down, off(u, 6 * (size_t)R), ldu, ws_v, ws->dact, accumulate, M,
+                              rowmask, st, 1));
+        CHECK(vlr_gemm_swiglu_bwd_add(dx_out, w->wdown, a->gu, ws->dact, ws->dact, M, I, H, st));   // gu now holds [dgate | dup]
+    } else if (lw->a_down) {
         CHECK(vlr_gemm_bf16(1, dx_out, w->wdown, ws->dact, nullptr, nullptr, M, I, H, H, I, I, 0, 0, 0, 0, st));
         CHECK(lora2_group_bwd(1, I, o_h, a->act, dx_out, H, side(lw, lw->a_down, lg->a_down, lg->b_down, seed_l, 6),
                               side(pw, pw->a_down, nullptr, nullptr, seed_p, 6), bc->down, off(u, 6 * (size_t)R), ldu, ws_v, ws->dact, accumulate, M,
