@@ -138,17 +138,16 @@ def cpu_baseline(budget_s=30.0):
     # the sample is checked against ONE full 32-layer step of the same oracle on the GPU box's host (tools/cpu_baseline_full_step.py, offline:
     # ~11 minutes of CPU work, profiles/r04_cpu_baseline_full_step.json)
     check = None
-    value, how = 4.0 / step_s, "the sample's extrapolation"
+    value, how = 4.0 / step_s, "the live sample's extrapolation (timed in this run, on this host)"
     fp = os.path.join(ROOT, "profiles", "r04_cpu_baseline_full_step.json")
     if os.path.exists(fp):
         full = json.load(open(fp))
         check = dict(full_step_s=full["seconds"]["step"], full_step_threads=full["threads"], full_step_pairs_per_s=full["pairs_per_s"],
                      sample_pairs_per_s=round(4.0 / step_s, 6), sample_extrapolation_over_full_step=round(step_s / full["seconds"]["step"], 3),
                      file="profiles/r04_cpu_baseline_full_step.json")
-        if int(full["threads"]) == int(n_thr):
-            # `value` is the MEASURED full step of the same oracle on this host class (the sample is 11 % optimistic: it does not see the
-            # cache pressure of 32 layers' activations); the live sample above is kept beside it as the check that this host behaves alike
-            value, how = float(full["pairs_per_s"]), "one full 32-layer step measured offline on this host class (tools/cpu_baseline_full_step.py)"
+        # `value` stays the LIVE sample of this run on this host; the one full 32-layer step measured offline on this host
+        # class stands beside it in `checked_against` (the sample is 11 - 18 % optimistic: it does not see the cache pressure of 32 layers'
+        # activations)
     return dict(value=value, unit="pairs/s", cores=n_thr, kind="port", value_is=how, checked_against=check,
                 sample=f"configs[0] shape (4 pairs, T=256, S=831), fp32, {time.time() - t_start:.0f} s of CPU work: one LLaMA-7B decoder layer "
                        f"fwd+bwd {t_layer:.2f} s and reference fwd {t_fwd:.2f} s (x32); lm-head + log-probs over all 8x831 positions "
@@ -281,6 +280,9 @@ def main():
     ap.add_argument("--fresh_batches", action="store_true", help="SURVEY 8f-3: every step takes a NEW batch from the input pipeline (JPEG files -> PIL decode + CLIP preprocess in the collator, "
                     "background prefetch, pinned H2D copy, un-memoised concatenated_inputs) instead of rotating four resident ones; reports the host ms per batch")
     ap.add_argument("--lr", type=float, default=2e-8, help="learning rate of the timed steps (kernel arithmetic does not depend on it)")
+    ap.add_argument("--no_variants", action="store_true", help="default command at 1 GPU only: skip the driver-clocked variants behind the timed region "
+                    "(precomputed reference log-probs in-process, LoRA as a child process of this script)")
+    ap.add_argument("--variant_steps", type=int, default=5)
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -289,7 +291,41 @@ def main():
         sys.exit(relaunch_under_torchrun(os.path.abspath(__file__), sys.argv[1:], a.gpus))
     if a.dry_run_launch:
         return dry_run_launch(a)
+    line = run(a)
+    if line is None:
+        return
+    if line.pop("_want_variants", False):
+        # SURVEY 8f rows 1-2 on the DRIVER's clock: the LoRA recipe of scripts/ddpo_llava.sh as a child process of this very script (the
+        # full fine-tune's 177 GiB are released first; the child builds its own model, warms up and times `variant_steps` steps)
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        line["variants"]["parent_allocated_gib_before_child"] = round(torch.cuda.memory_allocated() / 2 ** 30, 2)
+        line["variants"]["lora"] = variant_child(["--lora"], a, line["ms_per_step"])
+    if "_cpu_baseline" in line:
+        line.pop("_cpu_baseline")
+        line["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(line), flush=True)
 
+
+def variant_child(flags, a, full_ms):
+    """one variant of the default command as a child process (same script, same box, right behind the timed region of the parent):
+    {"ms_per_step", "pairs_per_s", "ratio_to_full", "steps", "seconds"} or {"error"}"""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), *flags, "--steps", str(a.variant_steps), "--warmup", "2", "--no_cpu_baseline", "--no_variants",
+           "--pairs", str(a.pairs), "--text_len", str(a.text_len)]
+    t0 = time.time()
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        return {"ms_per_step": d["ms_per_step"], "pairs_per_s": d["value"], "ratio_to_full": round(d["ms_per_step"] / full_ms, 4), "steps": d["steps"],
+                "warmup": d["warmup"], "loss_first_step": d["config"].get("loss_first_step"), "workload": d["config"]["workload"],
+                "peak_allocated_gib": d["config"].get("peak_allocated_gib"), "seconds": round(time.time() - t0, 1), "command": " ".join(cmd[1:])}
+    except Exception as e:      # noqa: BLE001 - a failed variant must not take the headline line down
+        return {"error": f"{type(e).__name__}: {e}"[:300], "seconds": round(time.time() - t0, 1)}
+
+
+def run(a):
     from vlrlhf import _hip
     from vlrlhf.models.Llava import LlavaDPOTrainer, LlavaForRL
     from vlrlhf.parallel import init_distributed_from_env
@@ -475,13 +511,13 @@ def main():
         exposed_ms = round((dt / a.steps - float(t2)) * 1e3, 2)
         reducer.enabled = True
     # HBM traffic of the dominant kernel: PMC passes cannot run inside the timed region; the committed rocprofv3 --pmc
-    # result (tools/pmc_traffic.sh -> profiles/r04_pmc_hbm_traffic.json) is quoted ONLY when it was taken with the library
+    # result (tools/pmc_traffic.sh -> profiles/rNN_pmc_hbm_traffic.json, newest first) is quoted ONLY when it was taken with the library
     # built from the GEMM sources this run uses (build_hip.kernel_digest() recorded in the file) - a stale file is refused
     import build_hip as _bh
     lib_digest = _bh.kernel_digest()[:16]       # gemm256p.hip + gemm.h + common.h + flags
     traffic = None
     traffic_file = None
-    for tag in ("r05", "r04"):      # the newest counter file taken with THIS library's GEMM sources
+    for tag in ("r06", "r05", "r04"):      # the newest counter file taken with THIS library's GEMM sources
         tf = os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_traffic.json")
         if not os.path.exists(tf):
             continue
@@ -594,8 +630,29 @@ def main():
             line["config"]["variant"] = "lora (not the headline configuration)"
             line["roofline"]["step_frac"] = None
         if not a.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line), flush=True)
+            line["_cpu_baseline"] = True
+        plain = world == 1 and a.model == "llava" and not (a.lora or a.precomputed_ref or a.layers or a.gradient_checkpointing or a.fresh_batches or a.ref_pipeline)
+        if plain and not a.no_variants:
+            # SURVEY 8f row 1 on the driver's clock, in-process: the same engine and batches, the reference log-probs stored on the batches
+            # (what trl's precompute_ref_log_probs leaves on the dataset rows) - the trainer then runs no reference forward
+            for b_ in batches:
+                with torch.no_grad():
+                    rc, rr, _, _ = tr.concatenated_forward(ref, b_)
+                b_["reference_chosen_logps"], b_["reference_rejected_logps"] = rc, rr
+            step()
+            barrier()
+            t1 = time.time()
+            for _ in range(a.variant_steps):
+                lv = step()
+            barrier()
+            ms = (time.time() - t1) / a.variant_steps * 1e3
+            line["variants"] = {"note": "timed behind the headline region of this same run (same box, same process unless `command` is given); not part of `value`",
+                                "precomputed_ref": {"ms_per_step": round(ms, 2), "pairs_per_s": round(a.pairs / ms * 1e3, 4), "ratio_to_full": round(ms / line["ms_per_step"], 4),
+                                                    "steps": a.variant_steps, "warmup": 1, "loss_last_step": float(lv),
+                                                    "how": "reference_chosen/rejected_logps stored on the resident batches: no reference forward in the step (--precomputed_ref)"}}
+            line["_want_variants"] = True
+    else:
+        line = None
     if fresh is not None:
         import shutil
         fresh["it"].close()                 # stops the prefetch thread
@@ -605,6 +662,12 @@ def main():
         if reducer is not None and reducer.native is not None:
             reducer.native.close()
         dist.destroy_process_group()
+        if rccl_log and os.path.basename(rccl_log).startswith("vlr_rccl_init_"):      # our own per-process INIT log: parsed above, not left in /tmp
+            try:
+                os.remove(rccl_log)
+            except OSError:
+                pass
+    return line
 
 
 if __name__ == "__main__":

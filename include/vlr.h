@@ -169,6 +169,20 @@ int vlr_gemm_grouped_bits_ktiles(int layout, const void* A, const void* B, void*
 int vlr_gemm_dropout_acc_multi_rows(int n, const void* v, int ldv, const void* A, void* dx, int M, int in, int r, float p, uint64_t seed,
                                     float scale, int accumulate, const void* bits, long bits_gstride, const unsigned char* rowmask,
                                     vlr_stream_t stream);
+/* (ABI v9) The row-slab adapter products, streamed (csrc/lora_rows.hip): a workgroup owns 64 token rows and reads its rows of the
+ * activation ONCE at HBM rate straight into MFMA fragments, the small matrix travels through an LDS ring; no split-K partials, no
+ * reduction launch, bit-reproducible.  r in {64, 128, 256}; in / outs multiples of 64; rows 16-byte aligned.
+ *  vlr_lora_rows_u: u [M][t * ustride .. + r] = alpha * (keep_t . x [M][in]) . A_t [r][in]^T for the n <= 4 targets that share x (A = the
+ *                   stacked A_t; peft lora.Linear.forward: lora_A(dropout(x)) * scaling, reference utils/auto_load.py:559-571).  bits = the
+ *                   packed keep masks of vlr_dropout_bits (target t at bits + t * bits_gstride; x dense, ldx == in) or NULL (no dropout).
+ *  vlr_lora_rows_v: v [M][t * r .. + r] = dy [M][ofs_t .. + outs[t]] . B_t [outs[t]][r], B = the stacked B_t, ofs_t = outs[0] + .. + outs[t-1]
+ *                   (outs: HOST array) - the input of the dA / dx terms of the backward.
+ *  rowmask [M] bytes or NULL: a row-restricted adapter (InternLM-XComposer2's PLoRA, reference models/InternLMXC2/build_mlp.py:194-202) -
+ *                   unmarked rows come out ZERO, 64-row slabs without a marked row are not read. */
+int vlr_lora_rows_u(int n, const void* x, int ldx, const void* A, void* u, int ldu, int ustride, int M, int in, int r, float alpha,
+                    const void* bits, long bits_gstride, const unsigned char* rowmask, vlr_stream_t stream);
+int vlr_lora_rows_v(int n, const void* dy, int lddy, const int* outs, const void* B, void* v, int ldv, int M, int r,
+                    const unsigned char* rowmask, vlr_stream_t stream);
 /*  vlr_gemm_swiglu_bwd_add: vlr_gemm_swiglu_bwd with an addend on d act before the SwiGLU backward (d act = dy . wdown + dact_add, bf16
  *                          [M][I]; may be the dact_ws buffer) - the LoRA adapter term of down_proj */
 int vlr_gemm_swiglu_bwd_add(const void* dy, const void* wdown, void* gu_inout, void* dact_ws, const void* dact_add, int M, int I, int H,
@@ -481,6 +495,7 @@ int vlr_comm_init(const void* id_host, int rank, int world, void** comm_out);
  * (vlrlhf/parallel.py NativeComm) then agrees with the other ranks and falls back to vlr_comm_init under the environment bound.
  * vlr_comm_rccl_version: ncclGetVersion of the library in use (major * 10000 + minor * 100 + patch; 0: unknown). */
 int vlr_comm_init_cfg(const void* id_host, int rank, int world, int min_ctas, int max_ctas, void** comm_out);
+int vlr_comm_has_config(void);      /* (ABI v9) 1: the loaded RCCL exports ncclCommInitRankConfig - agreed on by all ranks before vlr_comm_init_cfg is called */
 int vlr_comm_rccl_version(void);
 int vlr_comm_destroy(void* comm);
 int vlr_allreduce_bucket(void* comm, void* buf, long n, int dtype, vlr_stream_t stream);

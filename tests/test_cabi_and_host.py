@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(l, name), f"{name} declared in include/vlr.h but not exported by libvlr_hip.so"
     for name in _hip.exported_symbols():
         assert name in declared, f"{name} bound in _hip.py but not declared in include/vlr.h"
-    assert _hip.helper("vlr_abi_version") == 8
+    assert _hip.helper("vlr_abi_version") == 9
 
 
 def test_argument_errors_without_gpu():

@@ -1660,6 +1660,77 @@ def test_dropout_bits_and_masked_gemms_with_bits(hip, M, in_, r, n, p):
     assert torch.equal(a2, a3), "dropout-accumulate, one pass"
 
 
+# ---------------------------------------------------------------------------------------------------- streaming row-slab adapter products (ABI v9)
+@pytest.mark.parametrize("M,in_,r,n,p,rows", [(1406, 1024, 64, 3, 0.25, False), (12792, 4096, 128, 3, 0.05, False), (1353, 1408, 256, 1, 0.05, True),
+                                              (700, 128, 128, 2, 0.0, False), (12792, 11008, 128, 1, 0.05, False), (517, 768, 64, 1, 0.0, True)])
+def test_lora_rows_u(hip, M, in_, r, n, p, rows):
+    """vlr_lora_rows_u: u_t = alpha (keep_t . x) A_t^T for the targets that share x, against fp32 torch with the SAME packed masks; the
+    unmarked rows of a row-restricted adapter (PLoRA) come out zero; ragged last slab; u block stride wider than r (the two-adapter layout);
+    the kernel is deterministic (bit-identical twice)."""
+    seed, alpha = 77, (2.0 / (1 - p) if p > 0 else 2.0)
+    gstride = M * in_ // 8
+    bits = None
+    if p > 0:
+        bits = torch.zeros(n * gstride, dtype=torch.uint8, device=DEV)
+        for t in range(n):
+            hip.call("vlr_dropout_bits", bits[t * gstride:], M * in_, p, seed + t)
+    x = rnd(M, in_, seed=1)
+    A = rnd(n * r, in_, seed=2, scale=0.05)
+    ustride, ldu = r + 64, n * (r + 64) + 8
+    rowmask = None
+    if rows:
+        g = torch.Generator().manual_seed(5)
+        rm = (torch.rand(M, generator=g) < 0.4)
+        rm[64:256] = False                       # whole slabs without a marked row
+        rowmask = rm.to(torch.uint8).to(DEV)
+    outs = []
+    for _ in range(2):
+        u = torch.full((M, ldu), float("nan"), dtype=torch.bfloat16, device=DEV)
+        hip.call("vlr_lora_rows_u", n, x, in_, A, u, ldu, ustride, M, in_, r, alpha, bits, gstride, rowmask)
+        torch.cuda.synchronize()
+        outs.append(u)
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), "not deterministic"
+    u = outs[0]
+    for t in range(n):
+        xm = x.float()
+        if p > 0:
+            mk = ((bits[t * gstride:(t + 1) * gstride].view(-1, 1) >> torch.arange(8, device=DEV, dtype=torch.uint8)) & 1).reshape(M, in_).float()
+            xm = xm * mk
+        ref = alpha * xm @ A[t * r:(t + 1) * r].float().t()
+        if rows:
+            ref = ref * rowmask.float().view(-1, 1)
+            assert float(u[:, t * ustride:t * ustride + r][~rowmask.bool()].float().abs().max()) == 0.0
+        check(u[:, t * ustride:t * ustride + r], ref, 8e-3, f"u of target {t}")
+        assert torch.isnan(u[:, t * ustride + r:(t + 1) * ustride].float()).all(), "wrote outside its block"
+
+
+@pytest.mark.parametrize("M,outs,r,rows", [(1406, [1024, 256, 256], 64, False), (12792, [4096, 4096, 4096], 128, False), (1353, [1408], 256, True),
+                                           (12792, [11008, 11008], 128, False), (700, [128], 128, False), (517, [768, 640], 64, True)])
+def test_lora_rows_v(hip, M, outs, r, rows):
+    """vlr_lora_rows_v: v_t = dy[:, ofs_t .. + out_t] B_t (grouped-query widths differ per target), fp32 torch reference."""
+    n, tot = len(outs), sum(outs)
+    dy = rnd(M, tot, seed=3)
+    B = rnd(tot, r, seed=4, scale=0.05)
+    rowmask = None
+    if rows:
+        g = torch.Generator().manual_seed(6)
+        rm = (torch.rand(M, generator=g) < 0.5)
+        rm[0:128] = False
+        rowmask = rm.to(torch.uint8).to(DEV)
+    v = torch.full((M, n * r), float("nan"), dtype=torch.bfloat16, device=DEV)
+    o = torch.tensor(outs, dtype=torch.int32)          # host array
+    hip.call("vlr_lora_rows_v", n, dy, tot, o, B, v, n * r, M, r, rowmask)
+    torch.cuda.synchronize()
+    ofs = 0
+    for t in range(n):
+        ref = dy[:, ofs:ofs + outs[t]].float() @ B[ofs:ofs + outs[t]].float()
+        if rows:
+            ref = ref * rowmask.float().view(-1, 1)
+        check(v[:, t * r:(t + 1) * r], ref, 8e-3, f"v of target {t}")
+        ofs += outs[t]
+    assert torch.isfinite(v.float()).all()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,in_,r,n,p", [(1000, 512, 64, 2, 0.25), (1353, 1024, 256, 1, 0.05)])
 def test_adapter_products_restricted_to_a_row_set(hip, M, in_, r, n, p):

@@ -1,5 +1,4 @@
-#!/bin/bash
-cd "$(dirname "$0")/.."
+cd /root/repo
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
-for v in 0 1; do VLR_NORM_BWD_EARLY=$v timeout 100 python tools/norm_time.py 2>/dev/null | tail -1; done
-timeout 100 python -m pytest tests/test_hip_kernels.py -q -k "rmsnorm" 2>&1 | tail -1
+O=gpurun_out/r06_lora3; mkdir -p $O
+bash tools/gpu_lora.sh $O step "VLR_LORA_ROWS=0" "VLR_LORA_ROWS=1"

@@ -20,6 +20,10 @@ import torch  # noqa: E402
 from vlrlhf import _hip  # noqa: E402
 
 
+REPS = 1      # --reps N: N back-to-back calls between one pair of events (no idle gap in front of a call: the clock the power manager grants
+              # inside a training step, not the dip behind an idle gap - profiles/r05_gemm_ktile_cycles_and_clock.txt; launch latency overlapped)
+
+
 def timeit(fn, iters):
     for _ in range(2):
         fn()
@@ -28,10 +32,11 @@ def timeit(fn, iters):
     for _ in range(iters):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        fn()
+        for _ in range(REPS):
+            fn()
         e.record()
         torch.cuda.synchronize()
-        ts.append(s.elapsed_time(e) * 1e3)
+        ts.append(s.elapsed_time(e) * 1e3 / REPS)
     ts.sort()
     return ts[len(ts) // 2]
 
@@ -44,7 +49,10 @@ def main():
     ap.add_argument("--M", type=int, default=None)
     ap.add_argument("--dx_ablate", action="store_true", help="extra rows: the streaming dx kernel without its dx read / without the mask")
     ap.add_argument("--hash", action="store_true", help="the masked kernels hash in the kernel (ABI v4 behaviour) instead of reading packed masks")
+    ap.add_argument("--reps", type=int, default=1, help="back-to-back calls per timed interval (20: sustained clock, launch latency hidden)")
     a = ap.parse_args()
+    global REPS
+    REPS = max(1, a.reps)
     dev = "cuda"
     _hip.ensure_splitk_workspace(dev, force=True)
     H, I = 4096, 11008
@@ -92,6 +100,12 @@ def main():
             rec(f"{gname:8s} draw the packed masks x{n}", us, 1.0 * n * gst, 0.0)
         us = timeit(lambda: _hip.call("vlr_gemm_grouped_bits", 0, x, A, u, M, r, din, din, din, ldu, n, 0, r * din, r, sc / (1 - p), 0, 1, seed, p, din, bits, gst), a.iters)
         rec(f"{gname:8s} u = drop(x) A^T  [M,{nr},{din}]", us, 2.0 * M * din + 2.0 * M * nr, 2.0 * M * nr * din)
+        if bits is not None:
+            us = timeit(lambda: _hip.call("vlr_lora_rows_u", n, x, din, A, u, ldu, r, M, din, r, sc / (1 - p), bits, gst, None), a.iters)
+            rec(f"{gname:8s} u, streaming row slabs (r06)", us, 2.0 * M * din + 2.0 * M * nr, 2.0 * M * nr * din)
+        outs_h = torch.tensor(outs, dtype=torch.int32)
+        us = timeit(lambda: _hip.call("vlr_lora_rows_v", n, dy, lddy, outs_h, B, v, nr, M, r, None), a.iters)
+        rec(f"{gname:8s} v, streaming row slabs (r06)", us, 2.0 * M * out * n + 2.0 * M * nr, 2.0 * M * nr * out)
         us = timeit(lambda: _hip.call("vlr_gemm_grouped", 1, dy, B, v, M, r, out, lddy, r, nr, n, out, out * r, r, 1.0, 0, 0, 0, 0.0, 0), a.iters)
         rec(f"{gname:8s} v = dy B         [M,{nr},{out}]", us, 2.0 * M * out * n + 2.0 * M * nr, 2.0 * M * nr * out)
         us = timeit(lambda: _hip.call("vlr_gemm_grouped", 2, dy, u, dB, out, r, M, lddy, ldu, r, n, out, r, out * r, 1.0, 0, 0, 0, 0.0, 0), a.iters)
@@ -140,7 +154,7 @@ def main():
     tot = fl = 0.0
     for name, us, gbs, floor, tf in rows:
         print(f"{name:52s} {us:8.1f} {gbs:8.0f} {floor:9.1f} {us / floor:8.2f} {tf:7.1f}")
-        if "multi" not in name:
+        if "multi" not in name and "r06" not in name:
             tot += us
             fl += floor
     print(f"{'sum (per layer, without the multi rows)':52s} {tot:8.1f} {'':8s} {fl:9.1f} {tot / fl:8.2f}")

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libvlr_hip.so")
-SOURCES = ["api.cpp", "layers.cpp", "comm.cpp", "gemm.hip", "gemm128p.hip", "lora_dx.hip", "gemm256p.hip", "attention.hip", "elementwise.hip", "dpo_ops.hip"]
+SOURCES = ["api.cpp", "layers.cpp", "comm.cpp", "gemm.hip", "gemm128p.hip", "lora_dx.hip", "lora_rows.hip", "gemm256p.hip", "attention.hip", "elementwise.hip", "dpo_ops.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-I/opt/rocm/include"]
 
 

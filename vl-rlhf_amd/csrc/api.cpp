@@ -24,7 +24,7 @@ int vlr_check_launch(const char* what) {
 }
 
 extern "C" const char* vlr_last_error(void) { return g_err; }
-extern "C" int vlr_abi_version(void) { return 8; }
+extern "C" int vlr_abi_version(void) { return 9; }
 
 // ---- in-library kernel timing (bench.py roofline leg): HIP events on the launch stream around selected kernels -------
 #include <vector>

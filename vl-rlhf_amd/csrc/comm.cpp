@@ -137,6 +137,9 @@ extern "C" int vlr_comm_init_cfg(const void* id_host, int rank, int world, int m
     return VLR_OK;
 }
 // version code of the RCCL library in use (ncclGetVersion: major * 10000 + minor * 100 + patch), 0 when it cannot be asked
+// 1 when the loaded library exports ncclCommInitRankConfig (the ranks agree on this BEFORE any of them calls vlr_comm_init_cfg: a rank
+// that fails there while the others are already inside the bootstrap would leave them waiting for it)
+extern "C" int vlr_comm_has_config(void) { return load_api() == VLR_OK && g_api.CommInitRankConfig ? 1 : 0; }
 extern "C" int vlr_comm_rccl_version(void) {
     int v = 0;
     if (load_api() != VLR_OK || !g_api.GetVersion || g_api.GetVersion(&v) != ncclSuccess) return 0;

@@ -129,6 +129,9 @@ bool vlr_gemm256p_dropacc_try_launch(const GemmParams& p, hipStream_t stream);
 // streaming LoRA input-gradient kernel (lora_dx.hip); false: shape not taken
 bool vlr_lora_dx_try_launch(int n, const void* v, int ldv, const void* A, void* dx, int M, int in, int r, float p_drop, uint64_t seed,
                             float scale, int accumulate, const void* bits, long bits_gstride, hipStream_t stream, const unsigned char* rowskip = nullptr);
+// streaming row-slab adapter products (lora_rows.hip): mode 0 u = alpha (keep . x) A^T, mode 1 v = dy B; false: shape not taken
+bool vlr_lora_rows_try_launch(int mode, int n, const void* X, int ldx, const int* Ks, const void* W, int ldw, void* out, int ldo, int ostride,
+                              int M, int r, float alpha, const void* bits, long gbits, int bits_ld, const unsigned char* rowmask, hipStream_t st, bool force = false);
 bool vlr_gemm256p_seg_try_launch(const GemmParams& p, hipStream_t stream);
 bool vlr_gemm256p_fused_try_launch(const GemmParams& p, hipStream_t stream);
 // two TN problems of equal K (the weight gradients of two linears of one layer) as ONE persistent launch; false: shapes it does not take

@@ -262,6 +262,10 @@ static bool row_tiles_on() {      // VLR_ROW_TILES=0: the K reductions of a row-
     return on != 0;
 }
 
+// lora_rows.hip: the streaming row-slab adapter products (mode 0: u = alpha (keep . x) A^T, mode 1: v = dy B); false = shape not taken
+bool vlr_lora_rows_try_launch(int mode, int n, const void* X, int ldx, const int* Ks, const void* W, int ldw, void* out, int ldo, int ostride,
+                              int M, int r, float alpha, const void* bits, long gbits, int bits_ld, const unsigned char* rowmask, hipStream_t st, bool force = false);
+
 static int lora_group_a(int n, int r, int in, const void* x, int ldx, const void* A, void* u, int ldu, float scale, float p,
                         uint64_t seed, void* ws_xd, int M, hipStream_t st, const unsigned char* rowmask = nullptr, unsigned char* bits = nullptr,
                         unsigned char* bits_kt = nullptr, int ustride = 0) {
@@ -276,17 +280,26 @@ static int lora_group_a(int n, int r, int in, const void* x, int ldx, const void
             return VLR_OK;
         }
     } after = {u, ldu, n, r, ustride, M, rowmask, st};
+    if (p > 0.f && bits) {      // row-major masks (the streaming u kernel, the dx kernel) and the K-tile-blocked transposed ones (dA) in one draw per target
+        VLR_REQUIRE(ldx == in, "lora: the dropout mask is indexed over [M][in]; x must be dense (ldx %d, in %d)", ldx, in);
+        VLR_REQUIRE(((long)M * in) % 32 == 0, "lora: packed dropout masks need M * in %% 32 == 0 (M %d, in %d)", M, in);
+        const long tstride = vlr_dropout_bits_kt_bytes(M, in);
+        for (int t = 0; t < n; ++t)
+            CHECK(vlr_dropout_bits2(bits + (size_t)t * ((long)M * in / 8), bits_kt ? bits_kt + (size_t)t * tstride : nullptr, M, in, p, seed + t, st));
+    }
+    // the streaming row-slab kernel (lora_rows.hip): x read once per target at HBM rate, the text rows of a row-restricted adapter zeroed on
+    // the way out; shapes it does not take (and the hashing form without packed masks) run the grouped tile GEMMs below
+    if (p == 0.f || bits) {
+        const int Ks[4] = {in, in, in, in};
+        if (n <= 4 && vlr_lora_rows_try_launch(0, n, x, ldx, Ks, A, in, u, ldu, ustride, M, r, p > 0.f ? scale / (1.f - p) : scale, p > 0.f ? bits : nullptr,
+                                               (long)M * in / 8, in, rowmask, st))
+            return vlr_check_launch("lora_rows(u)");
+    }
     if (p > 0.f) {
         // ONE grouped launch for the n sub-targets: target t = group t reads the SAME x with its own keep mask (vlr_dropout(seed + t),
         // zeroed while the operand is staged - drop(x) is never written) against its own A_t; 1 / (1 - p) rides in alpha
         VLR_REQUIRE(ldx == in, "lora: the dropout mask is indexed over [M][in]; x must be dense (ldx %d, in %d)", ldx, in);
         const long gstride = (long)M * in / 8;
-        if (bits) {      // row-major masks (this launch, the dx kernel) and the K-tile-blocked transposed ones (dA) in one draw per target
-            VLR_REQUIRE(((long)M * in) % 32 == 0, "lora: packed dropout masks need M * in %% 32 == 0 (M %d, in %d)", M, in);
-            const long tstride = vlr_dropout_bits_kt_bytes(M, in);
-            for (int t = 0; t < n; ++t)
-                CHECK(vlr_dropout_bits2(bits + (size_t)t * gstride, bits_kt ? bits_kt + (size_t)t * tstride : nullptr, M, in, p, seed + t, st));
-        }
         if (rowmask) CHECK(vlr_gemm_grouped_bits_rows(0, x, A, u, M, r, in, ldx, in, ldu, n, 0L, (long)r * in, (long)ustride, scale / (1.f - p), 0, 1, seed, p,
                                                       in, bits, gstride, rowmask, st));      // all-text tiles are skipped; `after` zeroes the text rows
         else CHECK(vlr_gemm_grouped_bits(0, x, A, u, M, r, in, ldx, in, ldu, n, 0L, (long)r * in, (long)ustride, scale / (1.f - p), 0, 1, seed, p, in, bits,
@@ -313,6 +326,9 @@ static int lora_group_bwd(int n, int r, int in, const int* outs, const void* x, 
     // dB_t = dy_t^T (s u_t) and v_t = dy_t B_t: the n sub-targets as the groups of one launch each when their widths agree (multi-head
     // attention; grouped-query k / v are narrower than q: one launch per target then)
     const int ng = same ? 1 : n, gs = same ? n : 1;
+    // v_t = dy_t B_t for all targets of the group in ONE pass over dy on the streaming row-slab kernel (lora_rows.hip; unmarked rows of a
+    // row-restricted adapter come out zero); else per group on the tile GEMMs
+    const bool v_done = n <= 4 && vlr_lora_rows_try_launch(1, n, dy, lddy, outs, B, r, v, nr, r, M, r, 1.f, nullptr, 0L, 0, rowmask, st);
     for (int g = 0; g < ng; ++g) {
         const int out = outs[g];
         // (ktl: PLoRA - u and v are zero on the text rows, the K reductions over the token rows read only the 64-row tiles with an image row)
@@ -320,12 +336,13 @@ static int lora_group_bwd(int n, int r, int in, const int* outs, const void* x, 
                                                     (long)r, (long)out * r, 1.f, accumulate, 0, 0, 0.f, 0, nullptr, 0L, ktl, st));
         else CHECK(vlr_gemm_grouped(2, off(dy, ofs[g]), off(u, (size_t)g * r), off(dB, ofs[g] * r), out, r, M, lddy, ldu, r, gs, (long)out, (long)r,
                                     (long)out * r, 1.f, accumulate, 0, 0, 0.f, 0, st));                  // u is stored scaled
+        if (v_done) continue;
         if (rowmask) CHECK(vlr_gemm_grouped_bits_rows(1, off(dy, ofs[g]), off(B, ofs[g] * r), off(v, (size_t)g * r), M, r, out, lddy, r, nr, gs, (long)out,
                                                       (long)out * r, (long)r, 1.f, 0, 0, 0, 0.f, 0, nullptr, 0L, rowmask, st));
         else CHECK(vlr_gemm_grouped(1, off(dy, ofs[g]), off(B, ofs[g] * r), off(v, (size_t)g * r), M, r, out, lddy, r, nr, gs, (long)out,
                                     (long)out * r, (long)r, 1.f, 0, 0, 0, 0.f, 0, st));
     }
-    if (rowmask) CHECK(vlr_rows_mask(v, nr, nr, rowmask, M, st));      // PLoRA: no gradient flows through the adapter on the text rows
+    if (rowmask && !v_done) CHECK(vlr_rows_mask(v, nr, nr, rowmask, M, st));      // PLoRA: no gradient flows through the adapter on the text rows
     if (p > 0.f) {
         // dA_t = s / (1 - p) v_t^T (mask_t . x): the n targets as groups, x masked while it is staged (the mask of the forward, regenerated)
         if (bits_kt && ktl) CHECK(vlr_gemm_grouped_bits_ktiles(2, v, x, dA, r, in, M, nr, in, in, n, (long)r, 0L, (long)r * in, scale / (1.f - p), accumulate, 3,

@@ -115,6 +115,8 @@ _SIGS = {
     "vlr_gemm_lora": [P, I, P, P, I, P, I, I, I, I, P, I, P, I, P],
     "vlr_gemm_dropout_acc": [P, I, P, P, P, I, I, I, F, U64, F, P],
     "vlr_gemm_grouped": [I, P, P, P, I, I, I, I, I, I, I, L, L, L, F, I, I, U64, F, I, P],
+    "vlr_lora_rows_u": [I, P, I, P, P, I, I, I, I, I, F, P, L, P, P],
+    "vlr_lora_rows_v": [I, P, I, P, P, P, I, I, I, P, P],
     "vlr_gemm_dropout_acc_multi": [I, P, I, P, P, I, I, I, F, U64, F, I, P],
     "vlr_gemm_grouped_bits": [I, P, P, P, I, I, I, I, I, I, I, L, L, L, F, I, I, U64, F, I, P, L, P],
     "vlr_gemm_dropout_acc_bits": [P, I, P, P, P, I, I, I, F, U64, F, P, P],
@@ -165,6 +167,7 @@ _INT_HELPERS = {
     "vlr_comm_init": [P, I, I, P],
     "vlr_comm_init_cfg": [P, I, I, I, I, P],
     "vlr_comm_rccl_version": [],
+    "vlr_comm_has_config": [],
     "vlr_comm_destroy": [P],
 }
 

@@ -91,7 +91,19 @@ class NativeComm:
         host = (C.c_ubyte * nbytes).from_buffer_copy(bytes(host_id[1:].numpy().tobytes()))
         comm = C.c_void_p()
         rc, err = 1, ""
-        if self.channels > 0 and os.environ.get("VLR_COMM_CONFIG", "1") != "0":
+        #  whether the configured call can be made at all is agreed on BEFORE any rank enters it: the entry point exists and every
+        # rank loaded the same RCCL version - a rank that failed there alone would leave the others waiting inside the bootstrap
+        want_cfg = self.channels > 0 and os.environ.get("VLR_COMM_CONFIG", "1") != "0"
+        if want_cfg:
+            ver = torch.tensor([_hip.helper("vlr_comm_rccl_version")], dtype=torch.int64, device=dev)
+            lo, hi = ver.clone(), ver.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+            same = int(lo) == int(hi)
+            if not _all_ok(bool(_hip.helper("vlr_comm_has_config")) and same, group):
+                want_cfg = False
+                self.config_error = "ncclCommInitRankConfig missing on a rank" if same else f"RCCL versions differ across the ranks ({int(lo)} .. {int(hi)})"
+        if want_cfg:
             rc = l.vlr_comm_init_cfg(host, self.rank, self.world, 0, self.channels, C.byref(comm))
             err = "" if rc == 0 else l.vlr_last_error().decode()
             if _all_ok(rc == 0, group):
