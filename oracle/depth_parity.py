@@ -4,6 +4,7 @@
     python oracle/depth_parity.py small      # 1 pair, T = 128 (S = 703), ragged: fp32 + bf16 error budget
     python oracle/depth_parity.py configs0   # BASELINE.json configs[0]: 4 pairs, T = 256 (S = 831): fp32 + bf16-emulated
     python oracle/depth_parity.py grads | grads_sharp   # fp32 autograd of the `small` case (VLR_DEPTH_LAYERS=2|32); _sharp: q / k weights x 2
+    python oracle/depth_parity.py outliers   # (round 6) the `small` case on one hashed model with planted outlier channels: fp32 + the floor model
     python oracle/depth_parity.py seeds      # (round 4) the `small` case under 16 (round 4: 8) hashed models / batches: fp32 + the floor model
 
 The weights are the machine-independent hashed weights of oracle.llava_dpo_oracle.HashedWeights (reference = seed 0,
@@ -153,6 +154,53 @@ def run_seeds(cfg, log):
         del Wr, Wp
 
 
+OUTLIERS = dict(layers=[1, 2], channels=[7, 1415, 2533], scale=32.0)
+
+
+class _StreamStats:
+    """list-like `collect` sink of llama_hidden: per decoder layer, mean |x| of the planted channels and the rms over all features"""
+
+    def __init__(self, channels):
+        self.channels, self.rows = list(channels), []
+
+    def append(self, x):
+        x = x.reshape(-1, x.shape[-1]).float()
+        self.rows.append(dict(mean_abs_planted=x[:, self.channels].abs().mean().item(), rms_all=x.pow(2).mean().sqrt().item()))
+
+
+def run_outliers(cfg, log):
+    """(round 6) the `small` case on ONE hashed model with planted outlier channels (HashedWeights(outliers=OUTLIERS): three features of the
+    residual stream receive 32 x larger MLP outputs in layers 1 and 2 - the massive-activation channels of a trained checkpoint, which a
+    std-0.02 random model does not have): fp32 and the floor model -> tests/golden/llava7b_depth<L>_outliers.json, compared by
+    tests/test_hip_depth.py::test_depth32_planted_outlier_channels.  Also records how large the planted channels are in the stream."""
+    L = cfg["layers"]
+    s = 17
+    spec = dict(CASES["small"], seed=20 + s)
+    batch = O.synthetic_batch(spec["pairs"], spec["text_len"], cfg["image_token"], 32000, cfg["image_size"], spec["seed"], ragged=spec["ragged"])
+    Wr = O.HashedWeights(cfg, seed=s, cache=True, outliers=OUTLIERS)
+    Wp = O.HashedWeights(cfg, seed=s, delta=1e-3, seed_delta=100 + s, cache=True, outliers=OUTLIERS)
+    floor = [v for v in VARIANTS if v[0] in FLOOR_TAGS][0]
+    rec = dict(seed=s, seed_delta=100 + s, spec=spec, outliers=OUTLIERS)
+    for tag, emu in (("fp32", False), ("floor", floor[1])):
+        t0 = time.time()
+        col = _StreamStats(OUTLIERS["channels"]) if tag == "fp32" else None
+        with torch.no_grad():
+            pc, pr, _, _ = O.concatenated_forward(Wp, cfg, batch, "sigmoid", emu, collect=col)
+            rc, rr, _, _ = O.concatenated_forward(Wr, cfg, batch, "sigmoid", emu)
+            losses, _, _ = O.dpo_loss(pc, pr, rc, rr, 0.1)
+        rec[tag] = dict(loss=float(losses.mean()), policy_chosen_logps=pc.tolist(), policy_rejected_logps=pr.tolist(),
+                        reference_chosen_logps=rc.tolist(), reference_rejected_logps=rr.tolist())
+        if col is not None:      # the residual stream behind every layer: |planted channels| against the rms of all features
+            rec["stream"] = col.rows
+        log(f"outliers L{L} {tag}: loss {rec[tag]['loss']:.7f} [{time.time() - t0:.0f} s]")
+    rec["weight_probe"] = {k: Wp[k].double().sum().item() for k in ("language_model.model.layers.1.mlp.down_proj.weight",
+                                                                      f"language_model.model.layers.{L - 1}.mlp.down_proj.weight")}
+    path = os.path.join(ROOT, "tests", "golden", f"llava7b_depth{L}_outliers.json")
+    with open(path, "w") as f:
+        json.dump(dict(layers=L, cfg="LLAVA_1_5_7B", beta=0.1, floor=FLOOR_TAGS[0], record=rec), f)
+    log(f"wrote {path}")
+
+
 def run_grads(cfg, log, qk_scale=1.0):
     """fp32 gradients of the DPO loss of the `small` case w.r.t. every weight of decoder layers 0, 17, 31, the final norm and the
     lm-head: per tensor the Frobenius norm and a 256-element probe -> tests/golden/llava7b_depth<L>_small_grads.json
@@ -192,6 +240,9 @@ def main():
     if case in ("grads", "grads_sharp"):
         layers = int(os.environ.get("VLR_DEPTH_LAYERS", "32"))
         return run_grads(dict(O.LLAVA_1_5_7B, layers=layers), lambda s_: print(s_, flush=True), qk_scale=SHARP_QK if case == "grads_sharp" else 1.0)
+    if case == "outliers":
+        layers = int(os.environ.get("VLR_DEPTH_LAYERS", "32"))
+        return run_outliers(dict(O.LLAVA_1_5_7B, layers=layers), lambda s_: print(s_, flush=True))
     if case == "seeds":
         layers = int(os.environ.get("VLR_DEPTH_LAYERS", "32"))
         return run_seeds(dict(O.LLAVA_1_5_7B, layers=layers), lambda s_: print(s_, flush=True))

@@ -866,8 +866,13 @@ class HashedWeights:
     """Lazy mapping name -> fp32 tensor with transformers==4.41.0 LLaVA checkpoint names; nothing is stored.
     `delta` > 0: value = bf16(base(seed) + delta * n(seed_delta)) - a policy that differs from the reference `base`."""
 
-    def __init__(self, cfg, seed=0, std=0.02, delta=0.0, seed_delta=1, device="cpu", cache=False, qk_scale=1.0):
+    def __init__(self, cfg, seed=0, std=0.02, delta=0.0, seed_delta=1, device="cpu", cache=False, qk_scale=1.0, outliers=None):
         self.cfg, self.seed, self.std, self.delta, self.seed_delta, self.device = cfg, seed, std, delta, seed_delta, device
+        # planted outlier channels (round 6; VERDICT r05 weak 1c: a trained checkpoint's massive-activation channels are where bf16 operand
+        # rounding bites, a std-0.02 random model has none): dict(layers=[..], channels=[..], scale=2^k) multiplies the rows `channels` of
+        # mlp.down_proj.weight of those layers (= those features of the residual stream) by `scale` AFTER the bf16 rounding - exact for a
+        # power of two, so both sides still build bit-identical models (vlrlhf.utils.synthetic.init_hashed_model restates it)
+        self.outliers = outliers
         self.qk_scale = qk_scale     # > 1: the decoder's q_proj / k_proj weights are drawn qk_scale times larger (sharper softmax: the
                                      # "sharp" depth fixtures, whose q / k gradients are large enough to be compared by direction)
         self._cache = {} if cache else None          # bf16 copies (2 B / parameter) for multi-pass runs
@@ -928,6 +933,10 @@ class HashedWeights:
         t = hashed_tensor(shape, self.seed, name, self.std * (self.qk_scale if qk else 1.0), gain, self.device)
         if self.delta > 0 and not name.startswith("vision_tower."):
             t = (t + hashed_normal(t.numel(), self.seed_delta, name, self.device).view(*shape) * self.delta).to(torch.bfloat16).to(torch.float32)
+        o = self.outliers
+        if o and name.endswith("mlp.down_proj.weight") and name.startswith("language_model.model.layers.") and int(name.split(".")[3]) in o["layers"]:
+            t = t.clone()
+            t[list(o["channels"])] *= float(o["scale"])
         return t
 
 

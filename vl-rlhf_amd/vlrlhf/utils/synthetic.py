@@ -39,7 +39,7 @@ def hashed_normal(n, seed, name, device):
     return out
 
 
-def init_hashed_model(model, seed=0, std=0.02, policy_delta=1e-3, seed_delta=1, qk_scale=1.0, ref=None):
+def init_hashed_model(model, seed=0, std=0.02, policy_delta=1e-3, seed_delta=1, qk_scale=1.0, ref=None, outliers=None):
     """Weights named by their HF checkpoint keys and drawn by hashed_normal: reference = bf16(std * n) (norm gains
     1 + 0.05 n), policy = bf16(reference + policy_delta * n').  Returns the reference model."""
     from ..engine import VisionWeights
@@ -56,6 +56,9 @@ def init_hashed_model(model, seed=0, std=0.02, policy_delta=1e-3, seed_delta=1, 
         t = ((n * 0.05 + 1.0) if gain else n * (std * qk_scale if qk else std)).to(torch.bfloat16)      # (qk_scale: oracle.HashedWeights)
         if delta > 0 and not name.startswith(("vision_tower.", "vit.", "vision_proj.")):
             t = (t.float() + hashed_normal(numel, seed_delta, name, dev).view(*shape) * delta).to(torch.bfloat16)
+        # planted outlier channels (oracle.HashedWeights(outliers=...)): rows of mlp.down_proj of the named layers x a power of two - exact in bf16
+        if outliers and name.endswith("mlp.down_proj.weight") and name.startswith("language_model.model.layers.") and int(name.split(".")[3]) in outliers["layers"]:
+            t[list(outliers["channels"])] *= float(outliers["scale"])
         return t
 
     if ref is None:
