@@ -1,10 +1,11 @@
 #!/bin/bash
-# the variant bench lines quoted in DESIGN.md section 6 (one JSON line each): tools/round_variants.sh r05
-tag=${1:-r05}
+# the variant bench lines quoted in DESIGN.md section 6 (one JSON line each): tools/round_variants.sh r06 [name ...]   (names: a subset to run)
+tag=${1:-r06}; shift
+only=" $* "
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 mkdir -p gpurun_out
-run() { name=$1; shift; python bench.py --steps 6 --warmup 2 --no_cpu_baseline "$@" 2>/dev/null | tail -1 > gpurun_out/${tag}_variant_${name}.json; }
+run() { name=$1; shift; [ "$only" != "  " ] && [[ "$only" != *" $name "* ]] && return; python bench.py --steps 6 --warmup 2 --no_cpu_baseline --no_variants "$@" 2>/dev/null | tail -1 > gpurun_out/${tag}_variant_${name}.json; }
 run full
 run lora --lora
 run precomputed_ref --precomputed_ref
