@@ -7,7 +7,7 @@ for rep in 1 2; do
   for lib in "$@"; do
     tag=$(basename $lib .so)
     if [ "$lib" = default ]; then unset VLR_LIB; else export VLR_LIB=$lib; fi
-    timeout 300 python bench.py --steps 8 --warmup 2 --no_cpu_baseline $AB_ARGS 2>/dev/null | tail -1 > $O/bench_${tag}_$rep.json
+    timeout 300 python bench.py --steps 8 --warmup 2 --no_cpu_baseline --no_variants $AB_ARGS 2>/dev/null | tail -1 > $O/bench_${tag}_$rep.json
     python - <<PY
 import json
 try:

@@ -8,7 +8,7 @@ for rep in 1 2; do
   for sw in "$@"; do
     i=$((i+1))
     if [ "$sw" = "-" ]; then pre=""; else pre="$sw"; fi
-    env $pre timeout 300 python bench.py --steps 8 --warmup 2 --no_cpu_baseline $AB_ARGS 2>/dev/null | tail -1 > $O/bench_${i}_$rep.json
+    env $pre timeout 300 python bench.py --steps 8 --warmup 2 --no_cpu_baseline --no_variants $AB_ARGS 2>/dev/null | tail -1 > $O/bench_${i}_$rep.json
     python - <<PY
 import json
 try:

@@ -23,7 +23,7 @@
 //      tile kernel 2 + partials - which is why both land at 3.3 - 3.5 TB/s of activation and why this kernel measures 0.3 - 0.4 % SLOWER
 //      in the step (484.5 - 485.1 against 482.8 - 483.0 ms, LLaVA-1.5-7B LoRA r 128, same box).  The lever is bytes of the small operand per
 //      activation byte (taller slabs + a K split across CUs), not pipeline depth.
-// The layer passes therefore keep the tile GEMMs unless VLR_LORA_ROWS=1; the C-ABI entry points always run this kernel (tests).
+// The layer passes therefore take it where it wins (a row-restricted adapter, rank <= 64: lr_mode below) and keep the tile GEMMs elsewhere.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -278,13 +278,15 @@ static void lr_launch(const LoraRowsParams& p, int wgs, hipStream_t st) {
     hipLaunchKernelGGL((lora_rows_kernel<MODE, CT, MASK>), dim3(wgs), dim3(512), LDS, st, p);
 }
 
-// The layer passes (layers.cpp) use the kernel only under VLR_LORA_ROWS=1: in-step it measured 0.3 - 0.4 % SLOWER than the split-K tile
-// GEMMs it replaces (LLaVA-1.5-7B LoRA r 128: 484.5 - 485.1 against 482.8 - 483.0 ms, same box; profiles/r06_lora_rows_ablation.txt) - see
-// the header.  The C-ABI entry points below always run it.
-static int lr_enabled() {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("VLR_LORA_ROWS"); on = (e && e[0] == '1') ? 1 : 0; }
-    return on;
+// Which adapter products of the layer passes (layers.cpp) take this kernel - VLR_LORA_ROWS: unset = where it measured faster in the step
+// (profiles/r06_lora_rows_ablation.txt): a row-restricted adapter (PLoRA: all-text slabs are not read, no vlr_rows_mask launch - InternLM-
+// XComposer2 LoRA 845.6 / 840.3 -> 837.2 / 834.5 ms, full fine-tune 1040.9 / 1040.3 -> 1029.7 / 1030.1 ms, same box) and rank <= 64 (the
+// small operand's slice is then no larger than the activation tile: 2 bytes through LDS-DMA per activation byte instead of 3); 1 = every
+// product it can take (LLaVA r 128: 0.3 - 0.4 % slower than the split-K tile GEMMs); 0 = none.  The C-ABI entry points always run it.
+static int lr_mode() {
+    static int m = -1;
+    if (m < 0) { const char* e = getenv("VLR_LORA_ROWS"); m = !e ? 2 : (e[0] == '1' ? 1 : (e[0] == '0' ? 0 : 2)); }
+    return m;
 }
 
 // mode 0: out[:, ocol_t ..] = alpha * (keep_t . X) A_t^T with A_t = W + t * r * ldw rows (K = the common `in`), bits + t * gbits (or null)
@@ -292,7 +294,11 @@ static int lr_enabled() {
 // false: a shape the kernel does not take (the caller runs the tile GEMMs)
 bool vlr_lora_rows_try_launch(int mode, int n, const void* X, int ldx, const int* Ks, const void* W, int ldw, void* out, int ldo, int ostride,
                               int M, int r, float alpha, const void* bits, long gbits, int bits_ld, const unsigned char* rowmask, hipStream_t st, bool force) {
-    if ((!force && !lr_enabled()) || n < 1 || M < 1) return false;
+    if (n < 1 || M < 1) return false;
+    if (!force) {
+        const int m = lr_mode();
+        if (m == 0 || (m == 2 && !(rowmask || r <= 64))) return false;
+    }
     if (r != 64 && r != 128 && r != 256) return false;
     const int parts = r == 256 ? 2 : 1, rc = r == 256 ? 128 : r;
     if (n * parts > LR_MAXT) return false;
