@@ -36,7 +36,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2516.6          # 256 CU x 4096 FLOP/clk/CU x 2.4 GHz (MI355X_MICROARCH.md: ~2.5 PF dense)
-PROFILE_FILE = "profiles/r05_rocprofv3_kernel_stats_bench.csv"   # rocprofv3 --kernel-trace --stats of this command; `frac` can be recomputed from it
+PROFILE_FILE = "profiles/r06_rocprofv3_kernel_stats_bench.csv"   # rocprofv3 --kernel-trace --stats of this command; `frac` can be recomputed from it
 TFLOP_PER_PAIR = {"ref_in_step": 174.87, "ref_precomputed": 131.24}
 
 
