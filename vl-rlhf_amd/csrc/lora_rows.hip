@@ -239,7 +239,7 @@ __global__ __launch_bounds__(512) void lora_rows_kernel(LoraRowsParams p) {
     }
     if (tau + 1 < nt) { hand(S1{}, tau + 1); mma(S0{}); mma(S1{}); }
     else mma(S0{});
-    LR_WAIT(0);      // the tail's re-reads are still in flight: their registers are dead to the compiler, not to the hardware
+    LR_WAIT(0);      // the tail's re-reads are still in flight: they must have landed before the stages are reused for the exchange below
     // ---- sum the two k halves through LDS: wave (wr, kp) keeps row tile kp and hands the other one to its partner
     __builtin_amdgcn_s_waitcnt(0xc07f);
     LR_BARRIER();
