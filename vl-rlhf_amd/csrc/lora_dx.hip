@@ -71,9 +71,12 @@ __device__ __forceinline__ void dx_xpose4(uint32_t (&x)[4]) {
 }
 
 // NT targets, KT = r / 64 K tiles per target, MASK: 0 no dropout, 1 keep masks (packed bits when p.bits, else hashed)
-template <int NT, int KT, int MASK>
-__global__ __launch_bounds__(256) void lora_dx_kernel(LoraDxParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // 2 units x KT x 16 KiB | 2 x 1 KiB packed-mask tiles
+// RW = row waves: 2 = a workgroup owns 64 rows (4 waves), 4 = 128 rows (8 waves share every A slice: half the LDS-DMA per row of dx -
+// round 6: LDS-DMA is bound at ~40 B/clk per CU, and a unit stages 16 r / 64 KiB of A for 16 KiB of dx)
+template <int NT, int KT, int MASK, int RW = 2>
+__global__ __launch_bounds__(RW * 128) void lora_dx_kernel(LoraDxParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // 2 units x KT x 16 KiB | 2 x (RW / 2) KiB packed-mask tiles
+    constexpr int ROWS = 32 * RW, NWAVE = 2 * RW, NPW = 16 / NWAVE;  // rows per workgroup, waves, A-slice pieces per wave and K tile
     constexpr int KS = 2 * KT;                                        // k slices of 32 per target
     constexpr int UNIT_BYTES = KT * 16384;
     const int t_ = threadIdx.x;
@@ -81,14 +84,18 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(LoraDxParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(t_ >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int lm = lane & 15, lq = lane >> 4;
-    const int m0 = blockIdx.x * 64;
+    const int m0 = blockIdx.x * ROWS;
     const int tiles_n = p.in >> 7;
     const int c_lo = blockIdx.y * p.ct_per_wg;
     const int c_hi = min(tiles_n, c_lo + p.ct_per_wg);
     if (c_lo >= c_hi) return;
     if (p.rowskip) {              // (accumulate launches only: the host passes it with accumulate = 1)
-        const int row = m0 + lane;
-        const bool any = row < p.M && p.rowskip[row] != 0;
+        bool any = false;
+#pragma unroll
+        for (int h = 0; h < ROWS / 64; ++h) {
+            const int row = m0 + h * 64 + lane;
+            any = any || (row < p.M && p.rowskip[row] != 0);
+        }
         if (__ballot(any) == 0) return;
     }
     const int nunits = (c_hi - c_lo) * NT;
@@ -106,10 +113,10 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(LoraDxParams p) {
                 vf[t][i][ks] = *reinterpret_cast<const bf16x8*>(p.v + (size_t)row * p.ldv + t * p.r + ks * 32 + lq * 8);
         }
     // ---- DMA of one unit = the [r][128] slice of A_t: KT tiles of [64 k][256 B], 4 wave instructions per tile and wave
-    uint32_t offB[4];
+    uint32_t offB[NPW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r_ = (wave + 4 * i) * 4 + (lane >> 4);
+    for (int i = 0; i < NPW; ++i) {
+        const int r_ = (wave + NWAVE * i) * 4 + (lane >> 4);
         const int chunk = (lane & 15) ^ (((r_ & 3) << 2) | (((r_ >> 3) & 1) << 1));
         offB[i] = (uint32_t)(((size_t)r_ * p.in + chunk * 8) * 2);
     }
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(LoraDxParams p) {
         for (int kt = 0; kt < KT; ++kt) {
             const char* b = reinterpret_cast<const char*>(p.A + ((size_t)(t * p.r + kt * 64)) * p.in + c * 128);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) dx_dma16_s(b, offB[i], l + kt * 16384 + i * 4096);
+            for (int i = 0; i < NPW; ++i) dx_dma16_s(b, offB[i], l + kt * 16384 + i * NWAVE * 1024);
         }
     };
     // rows / first column of this lane's 2 x 4 accumulator tiles
@@ -165,12 +172,12 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(LoraDxParams p) {
     const uint32_t lbits = (uint32_t)(uintptr_t)(dx_lvoid_t*)smem + 2 * UNIT_BYTES;
     auto stage_keep = [&](int u) {
         if constexpr (MASK) {
-            if (p.bits && wave == 0) {
+            if (p.bits && wave < ROWS / 64) {
                 const int c = c_lo + u / NT, t = u % NT;
-                int row = m0 + lane;
+                int row = m0 + wave * 64 + lane;
                 row = row < p.M ? row : p.M - 1;
                 const unsigned char* g = p.bits + (size_t)t * p.gbits + (((size_t)row * p.in + c * 128) >> 3);
-                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lbits + (u & 1) * 1024) : "memory", "m0");
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lbits + (u & 1) * (ROWS * 16) + wave * 1024) : "memory", "m0");
             }
         }
     };
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(LoraDxParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         const char* tile = smem + (u & 1) * UNIT_BYTES;
-        const unsigned char* bt_lds = reinterpret_cast<const unsigned char*>(smem) + 2 * UNIT_BYTES + (u & 1) * 1024;
+        const unsigned char* bt_lds = reinterpret_cast<const unsigned char*>(smem) + 2 * UNIT_BYTES + (u & 1) * (ROWS * 16);
         // (static dispatch on the target: the v fragments are a register array)
         auto run = [&](auto tc) {
             constexpr int T = decltype(tc)::value;
@@ -311,26 +318,30 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(LoraDxParams p) {
     }
 }
 
-template <int NT, int KT>
+template <int NT, int KT, int RW>
 static void dx_launch_m(const LoraDxParams& p, int mask, dim3 grid, hipStream_t stream) {
-    const int lds = 2 * KT * 16384 + 2048;
+    const int lds = 2 * KT * 16384 + 2 * (32 * RW * 16);
     if (mask) {
         static bool a1 = false;
-        if (!a1) { hipFuncSetAttribute((const void*)lora_dx_kernel<NT, KT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); a1 = true; }
-        hipLaunchKernelGGL((lora_dx_kernel<NT, KT, 1>), grid, dim3(256), lds, stream, p);
+        if (!a1) { hipFuncSetAttribute((const void*)lora_dx_kernel<NT, KT, 1, RW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); a1 = true; }
+        hipLaunchKernelGGL((lora_dx_kernel<NT, KT, 1, RW>), grid, dim3(RW * 128), lds, stream, p);
     } else {
         static bool a0 = false;
-        if (!a0) { hipFuncSetAttribute((const void*)lora_dx_kernel<NT, KT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); a0 = true; }
-        hipLaunchKernelGGL((lora_dx_kernel<NT, KT, 0>), grid, dim3(256), lds, stream, p);
+        if (!a0) { hipFuncSetAttribute((const void*)lora_dx_kernel<NT, KT, 0, RW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); a0 = true; }
+        hipLaunchKernelGGL((lora_dx_kernel<NT, KT, 0, RW>), grid, dim3(RW * 128), lds, stream, p);
     }
 }
-template <int NT>
+// (8-wave workgroups hold two waves per SIMD = 256 registers each: the v fragments of NT x KT > 4 do not fit - those shapes keep 64 rows)
+template <int NT, int KT> constexpr bool dx_fits128() { return NT * KT <= 4; }
+template <int NT, int RW>
 static bool dx_launch_k(const LoraDxParams& p, int mask, dim3 grid, hipStream_t stream) {
     switch (p.r) {
-        case 64: dx_launch_m<NT, 1>(p, mask, grid, stream); return true;
-        case 128: dx_launch_m<NT, 2>(p, mask, grid, stream); return true;
+        case 64: dx_launch_m<NT, 1, RW>(p, mask, grid, stream); return true;
+        case 128:
+            if constexpr (RW == 2 || dx_fits128<NT, 2>()) { dx_launch_m<NT, 2, RW>(p, mask, grid, stream); return true; }
+            return false;
         case 256:
-            if constexpr (NT <= 2) { dx_launch_m<NT, 4>(p, mask, grid, stream); return true; }      // (3 x 2 x 8 v fragments do not fit the register file)
+            if constexpr (NT <= 2 && (RW == 2 || dx_fits128<NT, 4>())) { dx_launch_m<NT, 4, RW>(p, mask, grid, stream); return true; }      // (3 x 2 x 8 v fragments do not fit the register file)
             return false;
         default: return false;
     }
@@ -354,7 +365,17 @@ bool vlr_lora_dx_try_launch(int n, const void* v, int ldv, const void* A, void* 
     q.alpha = scale / (1.f - p_drop); q.accumulate = accumulate;
     q.bits = (const unsigned char*)bits; q.gbits = bits_gstride; q.seed = seed; q.thr = vlr_dropout_thr(p_drop);
     q.rowskip = accumulate ? rowskip : nullptr;
-    const int rb = (M + 63) / 64, tiles_n = in / 128;
+    // 128-row workgroups (8 waves share every A slice) where the registers allow it (n x r / 64 <= 4) AND it measured faster
+    // (tools/lora_gemm_bench.py --reps 20, round 6): rank 256 (InternLM-XComposer2's PLoRA: qkv 88.8 -> 78.0, o 88.6 -> 77.2, down 386 -> 258 us)
+    // and wide inputs (LLaVA down_proj, in = 11008: 178.7 -> 167.7 us); at r = 128 / in = 4096 the 64-row workgroups win (o 51.0 against
+    // 57.9, gate | up 77.7 against 93.7 us: two independent workgroups per CU de-phase, eight waves behind one barrier do not).
+    // VLR_LORA_DX_ROWS=64 | 128 forces one form (A/B).
+    static int rows_env = -1;
+    if (rows_env < 0) { const char* e = getenv("VLR_LORA_DX_ROWS"); rows_env = e ? atoi(e) : 0; }
+    const int kt_ = r / 64;
+    const bool rows128 = n * kt_ <= 4 && (rows_env == 128 || (rows_env != 64 && (kt_ == 4 || in >= 8192)));
+    const int rows = rows128 ? 128 : 64;
+    const int rb = (M + rows - 1) / rows, tiles_n = in / 128;
     int splits = (wg_per_cu * vlr_compute_cus() + rb - 1) / rb;
     if (splits < 1) splits = 1;
     if (splits > tiles_n) splits = tiles_n;
@@ -362,7 +383,12 @@ bool vlr_lora_dx_try_launch(int n, const void* v, int ldv, const void* A, void* 
     splits = (tiles_n + q.ct_per_wg - 1) / q.ct_per_wg;
     const dim3 grid(rb, splits);
     const int mask = p_drop > 0.f ? 1 : 0;
-    if (n == 1) return dx_launch_k<1>(q, mask, grid, stream);
-    if (n == 2) return dx_launch_k<2>(q, mask, grid, stream);
-    return dx_launch_k<3>(q, mask, grid, stream);
+    if (rows128) {
+        if (n == 1) return dx_launch_k<1, 4>(q, mask, grid, stream);
+        if (n == 2) return dx_launch_k<2, 4>(q, mask, grid, stream);
+        return dx_launch_k<3, 4>(q, mask, grid, stream);
+    }
+    if (n == 1) return dx_launch_k<1, 2>(q, mask, grid, stream);
+    if (n == 2) return dx_launch_k<2, 2>(q, mask, grid, stream);
+    return dx_launch_k<3, 2>(q, mask, grid, stream);
 }
