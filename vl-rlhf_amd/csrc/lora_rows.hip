@@ -33,7 +33,7 @@
 
 #define LR_NS 6                 // LDS stages: LR_NS - 1 steps in flight
 #define LR_MAXT 8
-#define LR_XS (8192 + 512)      // activation tile [64 rows][64 k] | packed keep masks [64 rows][8 B]  (+ the small operand's 64 k slice = one stage)
+// a stage = activation tile [ROWS rows][64 k] | packed keep masks [ROWS rows][8 B] | the small operand's 64 k slice
 
 typedef __attribute__((address_space(3))) void lr_lvoid_t;
 typedef __attribute__((ext_vector_type(4))) short lr_s16x4_t;
@@ -99,25 +99,35 @@ __device__ __forceinline__ bf16x8 lr_mask8(bf16x8 f, uint32_t keep) {
     return __builtin_bit_cast(bf16x8, w);
 }
 
-template <int MODE, int CT, bool MASK>
+// RW = MFMA wave rows: 2 = a workgroup owns 64 rows (waves 0-3 do the MFMAs, waves 4-7 only feed the ring, six stages); 4 = 128 rows (all
+// eight waves do MFMAs: the small operand's slice is shared by twice the rows - 2 bytes through LDS-DMA per activation byte instead of 3 -
+// four stages)
+template <int MODE, int CT, bool MASK, int RW = 2>
 __global__ __launch_bounds__(512) void lora_rows_kernel(LoraRowsParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // LR_NS stages of (activation tile | keep bytes | small-operand slice)
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // NS stages of (activation tile | keep bytes | small-operand slice)
+    constexpr int ROWS = 32 * RW, XT = ROWS * 128, XS = XT + ROWS * 8;
+    constexpr int NS = RW == 2 ? LR_NS : 4;
     constexpr int WS = MODE == 0 ? CT * 16 * 128 : 64 * 256;         // the small operand's slice of a stage (64 k)
-    constexpr int NW = WS / 4096;                                     // its 1 KiB pieces per wave (4, or 2 at r = 64 in mode U)
-    constexpr int SS = LR_XS + WS;                                    // bytes per stage
+    constexpr int NW = WS / 4096;                                     // its 1 KiB pieces per wave of four (4, or 2 at r = 64 in mode U)
+    constexpr int SS = XS + WS;                                       // bytes per stage
+    constexpr int NMW = 2 * RW;                                       // waves that do MFMAs
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // (slab, target): the targets of a slab are neighbours in one XCD's dispatch order - the activation's other reads hit that L2
     const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
     const int t = idx % p.n, slab = (idx / p.n) * 8 + xcd;
-    const int m0 = slab * 64;
+    const int m0 = slab * ROWS;
     if (m0 >= p.M) return;
     bf16_t* out = p.out + p.ocol[t];
     if (p.rowmask) {
-        const int row = m0 + lane;
-        const bool any = row < p.M && p.rowmask[row] != 0;
+        bool any = false;
+#pragma unroll
+        for (int h = 0; h < ROWS / 64; ++h) {
+            const int row = m0 + h * 64 + lane;
+            any = any || (row < p.M && p.rowmask[row] != 0);
+        }
         if (__ballot(any) == 0) {       // no marked row: the slab's block of the output is zero (wave-uniform, the same in every wave)
-            for (int i = tid; i < 64 * CT * 4; i += 512) {
+            for (int i = tid; i < ROWS * CT * 4; i += 512) {
                 const int r_ = i / (CT * 4), c4 = i % (CT * 4);
                 if (m0 + r_ < p.M) *reinterpret_cast<u32x2*>(out + (size_t)(m0 + r_) * p.ldo + c4 * 4) = u32x2{0u, 0u};
             }
@@ -128,16 +138,18 @@ __global__ __launch_bounds__(512) void lora_rows_kernel(LoraRowsParams p) {
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lr_lvoid_t*)smem;
     const int wr = wave >> 1, kp = wave & 1, lm = lane & 15, q = lane >> 4;
 
-    // ---- LDS-DMA is ISSUE bound (~100 cycles per 1 KiB piece and wave, profiles/r06_lora_rows_ablation.txt): the 8 + 4 NW pieces of a step
-    // are dealt to EIGHT waves - four of them (0-3) also do the MFMAs, the other four only feed the ring.  Piece g of the step: g < 8 the
-    // activation tile's 8-row piece g, else piece g - 8 of the small operand's slice; wave w takes g = w, w + 8, (w + 16).  Keep bytes: waves 0-3.
-    constexpr int NP = (8 + 4 * NW) / 8;                             // pieces per wave (3, or 2 at r = 64 in mode U)
+    // ---- the ROWS / 8 + 4 NW one-KiB pieces of a step are dealt to the EIGHT waves (piece g: g < ROWS / 8 = the activation tile's 8-row
+    // piece g, else piece g - ROWS / 8 of the small operand's slice; wave w takes g = w, w + 8, ...).  Keep bytes: waves 0-3.
+    constexpr int NXP = ROWS / 8;
+    constexpr int NP = (NXP + 4 * NW) / 8;                           // pieces per wave
     uint32_t offP[NP], offB;
     uint32_t ldsP[NP];                                                // LDS offset of the piece inside a stage
+    bool isx[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const int g = wave + 8 * i;
-        if (g < 8) {
+        isx[i] = g < NXP;
+        if (g < NXP) {
             const int r_ = g * 8 + (lane >> 3);
             const int c = (lane & 7) ^ ((r_ >> 1) & 7);
             int row = m0 + r_;
@@ -145,7 +157,7 @@ __global__ __launch_bounds__(512) void lora_rows_kernel(LoraRowsParams p) {
             offP[i] = (uint32_t)(((size_t)row * p.ldx + p.xofs[t] + c * 8) * 2);
             ldsP[i] = g * 1024;
         } else {
-            const int jj = g - 8;
+            const int jj = g - NXP;
             if constexpr (MODE == 0) {
                 const int r_ = jj * 8 + (lane >> 3);
                 const int c = (lane & 7) ^ ((r_ >> 1) & 7);
@@ -156,11 +168,12 @@ __global__ __launch_bounds__(512) void lora_rows_kernel(LoraRowsParams p) {
                 if (c >= 2 * CT) c &= 2 * CT - 1;          // r = 64: the image's unused chunk slots re-read a used chunk of the row
                 offP[i] = (uint32_t)(((size_t)kr * p.ldw + c * 8) * 2);
             }
-            ldsP[i] = LR_XS + jj * 1024;
+            ldsP[i] = XS + jj * 1024;
         }
     }
-    {
-        int row = m0 + (wave & 3) * 16 + ((lane & 31) >> 1);
+    {   // keep bytes [ROWS rows][8 B]: waves 0-3, one dword per lane; 64 rows: lanes 0-31 of each (16 rows x 2 halves), 128 rows: all 64 lanes
+        constexpr int RPWV = ROWS / 4;
+        int row = m0 + (wave & 3) * RPWV + ((lane & (2 * RPWV - 1)) >> 1);
         row = row < p.M ? row : p.M - 1;
         offB = (uint32_t)((size_t)row * (p.bits_ld >> 3) + (lane & 1) * 4);
     }
@@ -174,14 +187,13 @@ __global__ __launch_bounds__(512) void lora_rows_kernel(LoraRowsParams p) {
         const int src = step < nt ? step : nt - 1;
         const char* xb = xbase + (size_t)((p.dbg & 1) ? 0 : src) * 128;
         const char* wb = wbase + (size_t)((p.dbg & 2) ? 0 : src) * wstep;
-        const uint32_t l = lds_base + (step % LR_NS) * SS;
-        lr_dma16_s(xb, offP[0], l + ldsP[0]);                 // (piece 0 of every wave is an activation piece: g = wave < 8)
+        const uint32_t l = lds_base + (step % NS) * SS;
 #pragma unroll
-        for (int i = 1; i < NP; ++i) lr_dma16_s(wb, offP[i], l + ldsP[i]);
+        for (int i = 0; i < NP; ++i) lr_dma16_s((8 * i + 7 < NXP || (8 * i < NXP && isx[i])) ? xb : wb, offP[i], l + ldsP[i]);
         if constexpr (MASK) {
             if (wave < 4) {
                 const char* kbp = bbase + (size_t)src * 8;
-                if (lane < 32) lr_dma4_s(kbp, offB, l + 8192 + wave * 128);
+                if (lane < ROWS / 2) lr_dma4_s(kbp, offB, l + XT + wave * (ROWS * 2));
             }
         }
     };
@@ -194,12 +206,12 @@ __global__ __launch_bounds__(512) void lora_rows_kernel(LoraRowsParams p) {
     uint32_t kb[2][2];
     auto load = [&](auto sc, int step) {
         constexpr int S = decltype(sc)::value;
-        const char* xt = smem + (step % LR_NS) * SS;
-        const char* wt = xt + LR_XS;
+        const char* xt = smem + (step % NS) * SS;
+        const char* wt = xt + XS;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             xa[S][i] = lr_frag_kc(xt, wr * 32 + i * 16, kp, lane);
-            if constexpr (MASK) kb[S][i] = reinterpret_cast<const unsigned char*>(xt)[8192 + (wr * 32 + i * 16 + lm) * 8 + kp * 4 + q];
+            if constexpr (MASK) kb[S][i] = reinterpret_cast<const unsigned char*>(xt)[XT + (wr * 32 + i * 16 + lm) * 8 + kp * 4 + q];
         }
 #pragma unroll
         for (int j = 0; j < CT; ++j) {
@@ -209,7 +221,7 @@ __global__ __launch_bounds__(512) void lora_rows_kernel(LoraRowsParams p) {
     };
     auto mma = [&](auto sc) {
         constexpr int S = decltype(sc)::value;
-        if ((p.dbg & 4) || wave >= 4) return;
+        if ((p.dbg & 4) || wave >= NMW) return;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             bf16x8 x = xa[S][i];
@@ -222,15 +234,15 @@ __global__ __launch_bounds__(512) void lora_rows_kernel(LoraRowsParams p) {
     // reads of the step before; one barrier; the stage of the step before is refilled LR_NS - 1 steps ahead; the step's fragments are
     // read into set F - in FRONT of the MFMAs of the step before (an LDS read stream of 40 KiB per step is as long as the step's MFMAs)
     auto hand = [&](auto fc, int step) {
-        if (MASK && wave < 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((LR_NS - 2) * (NP + 1)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((LR_NS - 2) * NP) : "memory");
+        if (MASK && wave < 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * (NP + 1)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * NP) : "memory");
         LR_BARRIER();
-        issue(step + LR_NS - 1);
-        if (wave < 4) load(fc, step);
+        issue(step + NS - 1);
+        if (wave < NMW) load(fc, step);
     };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
-    for (int s_ = 0; s_ < LR_NS - 1; ++s_) issue(s_);
+    for (int s_ = 0; s_ < NS - 1; ++s_) issue(s_);
     hand(S0{}, 0);
     int tau = 0;
     for (; tau + 2 < nt; tau += 2) {      // branch-free body: two steps
@@ -243,7 +255,7 @@ __global__ __launch_bounds__(512) void lora_rows_kernel(LoraRowsParams p) {
     // ---- sum the two k halves through LDS: wave (wr, kp) keeps row tile kp and hands the other one to its partner
     __builtin_amdgcn_s_waitcnt(0xc07f);
     LR_BARRIER();
-    if (wave >= 4) {      // the feeding waves: one more barrier (the exchange below) and out
+    if (wave >= NMW) {      // the feeding waves (64-row form): one more barrier (the exchange below) and out
         LR_BARRIER();
         return;
     }
@@ -269,13 +281,13 @@ __global__ __launch_bounds__(512) void lora_rows_kernel(LoraRowsParams p) {
     }
 }
 
-template <int MODE, int CT, bool MASK>
+template <int MODE, int CT, bool MASK, int RW>
 static void lr_launch(const LoraRowsParams& p, int wgs, hipStream_t st) {
     constexpr int WS = MODE == 0 ? CT * 16 * 128 : 64 * 256;
-    constexpr int LDS = LR_NS * (LR_XS + WS);      // (>= the 2 * 2 * CT * 64 * 16 bytes of the final exchange)
+    constexpr int LDS = (RW == 2 ? LR_NS : 4) * (32 * RW * 136 + WS);      // (>= the RW * 2 * CT * 64 * 16 bytes of the final exchange)
     static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)lora_rows_kernel<MODE, CT, MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
-    hipLaunchKernelGGL((lora_rows_kernel<MODE, CT, MASK>), dim3(wgs), dim3(512), LDS, st, p);
+    if (!attr) { hipFuncSetAttribute((const void*)lora_rows_kernel<MODE, CT, MASK, RW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
+    hipLaunchKernelGGL((lora_rows_kernel<MODE, CT, MASK, RW>), dim3(wgs), dim3(512), LDS, st, p);
 }
 
 // Which adapter products of the layer passes (layers.cpp) take this kernel - VLR_LORA_ROWS: unset = where it measured faster in the step
@@ -330,15 +342,22 @@ bool vlr_lora_rows_try_launch(int mode, int n, const void* X, int ldx, const int
         if (mode == 1 && ofs % 8 != 0) return false;
         ofs += Ks[t];
     }
-    const int slabs = (M + 63) / 64;
+    // 128-row workgroups where they measured faster (rank 256 = two column halves of 128 that share the activation's lines; VLR_LORA_ROWS_R=64 | 128 forces one form)
+    static int rows_env = -1;
+    if (rows_env < 0) { const char* e = getenv("VLR_LORA_ROWS_R"); rows_env = e ? atoi(e) : 0; }
+    const bool big = rc == 128 && (rows_env == 128 || (rows_env != 64 && r == 256));
+    const int rows = big ? 128 : 64;
+    const int slabs = (M + rows - 1) / rows;
     const int wgs = ((slabs + 7) / 8) * 8 * p.n;
     const bool mask = bits != nullptr;
     if (mode == 0) {
-        if (rc == 128) { if (mask) lr_launch<0, 8, true>(p, wgs, st); else lr_launch<0, 8, false>(p, wgs, st); }
-        else { if (mask) lr_launch<0, 4, true>(p, wgs, st); else lr_launch<0, 4, false>(p, wgs, st); }
+        if (rc == 128) {
+            if (big) { if (mask) lr_launch<0, 8, true, 4>(p, wgs, st); else lr_launch<0, 8, false, 4>(p, wgs, st); }
+            else { if (mask) lr_launch<0, 8, true, 2>(p, wgs, st); else lr_launch<0, 8, false, 2>(p, wgs, st); }
+        } else { if (mask) lr_launch<0, 4, true, 2>(p, wgs, st); else lr_launch<0, 4, false, 2>(p, wgs, st); }
     } else {
-        if (rc == 128) lr_launch<1, 8, false>(p, wgs, st);
-        else lr_launch<1, 4, false>(p, wgs, st);
+        if (rc == 128) { if (big) lr_launch<1, 8, false, 4>(p, wgs, st); else lr_launch<1, 8, false, 2>(p, wgs, st); }
+        else lr_launch<1, 4, false, 2>(p, wgs, st);
     }
     return true;
 }
