@@ -376,7 +376,9 @@ bool vlr_lora_dx_try_launch(int n, const void* v, int ldv, const void* A, void* 
     const bool rows128 = n * kt_ <= 4 && (rows_env == 128 || (rows_env != 64 && (kt_ == 4 || in >= 8192)));
     const int rows = rows128 ? 128 : 64;
     const int rb = (M + rows - 1) / rows, tiles_n = in / 128;
-    int splits = (wg_per_cu * vlr_compute_cus() + rb - 1) / rb;
+    static bool wgs_forced = getenv("VLR_LORA_DX_WGS") != nullptr;
+    const int wpc = (rows128 && in < 8192 && !wgs_forced) ? 2 : wg_per_cu;      // 128-row workgroups at in = 4096: 2 per CU in the grid (73 / 71 us against 77 at 4, InternLM qkv / o)
+    int splits = (wpc * vlr_compute_cus() + rb - 1) / rb;
     if (splits < 1) splits = 1;
     if (splits > tiles_n) splits = tiles_n;
     q.ct_per_wg = (tiles_n + splits - 1) / splits;
