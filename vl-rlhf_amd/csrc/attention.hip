@@ -343,6 +343,18 @@ __device__ __forceinline__ void attn_tile_masks(unsigned long long* tilemask, co
 #define ATTN_SETPRIO 1
 #endif
 #define ATTN_PRIO(n) do { if (ATTN_SETPRIO) __builtin_amdgcn_s_setprio(n); } while (0)
+#ifndef ATTN_SGB
+#define ATTN_SGB 4           // forward: K fragment reads in flight ahead of the K . Q^T MFMAs (sched_group_barrier pipeline); 0: hipcc's own order
+#endif
+#ifndef ATTN_SGB_PV
+#define ATTN_SGB_PV 2        // forward: V fragments in flight ahead of the V^T . P^T MFMAs; 0: hipcc's own order
+#endif
+#ifndef ATTN_SGB_DQ
+#define ATTN_SGB_DQ 4        // dQ kernel: fragment reads in flight ahead of the dP / S MFMAs; 0: hipcc's own order
+#endif
+#ifndef ATTN_SGB_DQ2
+#define ATTN_SGB_DQ2 2       // dQ kernel: transposed K fragments in flight ahead of the dQ MFMAs; 0: hipcc's own order
+#endif
 #define ATTN_MAX_TILES 128   // S <= 8192
 template <int D>
 struct AttnFwd2 {
@@ -441,6 +453,18 @@ __device__ __forceinline__ unsigned attn_fwd2_block(const bf16_t* __restrict__ q
         }
         // masks only where a tile needs them: diagonal tiles (causal) and tiles holding padded / out-of-range keys
         const unsigned long long mk = tilemask[it];
+#if ATTN_SGB
+        // issue order of the K . Q^T product (round 6): ATTN_SGB fragment reads ahead of their MFMAs.  Left alone hipcc reads one
+        // key block's fragment into ONE temporary right in front of its MFMA (ds_read; s_waitcnt lgkmcnt(0); v_mfma, eight times per
+        // tile): an LDS round trip per two MFMAs that only the SIMD's other wave can cover
+        __builtin_amdgcn_sched_group_barrier(0x100, ATTN_SGB, 0);
+#pragma unroll
+        for (int i = 0; i < 2 * (D / 16) - ATTN_SGB; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, ATTN_SGB, 0);
+#endif
         if (CAUSAL && mk == 0ull) {
             if (k0 + KV_TILE - 1 > qw0) {
                 // diagonal tile, no padded key (one per wave and block): key kk = c(kb, r) + 4g is in the query's future iff
@@ -499,6 +523,16 @@ __device__ __forceinline__ unsigned attn_fwd2_block(const bf16_t* __restrict__ q
             for (int db = 0; db < D / 32; ++db)
                 acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(v_lds, db * 32, ks, lane), pf, acc[db], 0, 0, 0);
         }
+#if ATTN_SGB_PV
+        // ... and of the V^T . P^T product: ATTN_SGB_PV fragments (two transposing reads each) ahead
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * ATTN_SGB_PV, 1);
+#pragma unroll
+        for (int i = 0; i < 4 * (D / 32) - ATTN_SGB_PV; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, ATTN_SGB_PV, 1);
+#endif
     }
 #if ATTN_SWAP
     l += __shfl_xor(l, 32);
@@ -888,6 +922,16 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 1) void attn_bwd_dq2_kernel(const
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(v_lds, kb * 32, 2 * st, lane), dof[st], dp, 0, 0, 0);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(k_lds, kb * 32, 2 * st, lane), qf[st], s, 0, 0, 0);
             }
+#if ATTN_SGB_DQ
+            // ATTN_SGB_DQ fragment reads ahead of the sixteen dP / S MFMAs (see the forward kernel)
+            __builtin_amdgcn_sched_group_barrier(0x100, ATTN_SGB_DQ, 0);
+#pragma unroll
+            for (int i = 0; i < 16 - ATTN_SGB_DQ; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, ATTN_SGB_DQ, 0);
+#endif
             ATTN_PRIO(0);
             if (need_mask) {
                 // a REAL branch: hipcc if-converted this wave-uniform block into 80 predicated instructions per key block that every
@@ -916,6 +960,16 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 1) void attn_bwd_dq2_kernel(const
                 for (int db = 0; db < 4; ++db)
                     acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(k_lds, db * 32, ks, lane), dsf, acc[db], 0, 0, 0);
             }
+#if ATTN_SGB_DQ2
+            // ... and ATTN_SGB_DQ2 transposed K fragments (two reads each) ahead of the eight dQ MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * ATTN_SGB_DQ2, 1);
+#pragma unroll
+            for (int i = 0; i < 8 - ATTN_SGB_DQ2; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, ATTN_SGB_DQ2, 1);
+#endif
             ATTN_PRIO(0);
         }
     }
