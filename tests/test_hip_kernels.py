@@ -457,6 +457,53 @@ def test_merge_matches_oracle(hip):
     assert int(info[0]) != (Bh - 1) * P * 2
 
 
+_MERGE_EMBED_CHILD = r"""
+import os, sys, torch
+root = sys.argv[1]
+sys.path.insert(0, os.path.join(root, "vl-rlhf_amd"))
+from vlrlhf import _hip
+g = torch.Generator().manual_seed(11)
+Bn, T, P, H, V, image_token, pad = 4, 300, 20, 256, 50, 48, 49
+ids = torch.randint(0, 48, (Bn, T), generator=g)
+ids[:, 5] = image_token
+ids[1, 250:] = pad
+am = (ids != pad).long()
+lab = ids.clone()
+S = T - 1 + P
+dev = "cuda"
+src = torch.empty(Bn, S, dtype=torch.int32, device=dev); omask = torch.empty(Bn, S, dtype=torch.int32, device=dev)
+olab = torch.empty(Bn, S, dtype=torch.int64, device=dev); opos = torch.empty(Bn, S, dtype=torch.int32, device=dev)
+imap = torch.empty(Bn, S, dtype=torch.uint8, device=dev); inv = torch.empty(1, Bn * P, dtype=torch.int32, device=dev)
+info = torch.zeros(2, dtype=torch.int32, device=dev)
+idd = ids.to(dev)
+_hip.call("vlr_merge_index", idd, am.to(dev), lab.to(dev), Bn, T, S, P, image_token, pad, Bn * P, 1, src, omask, olab, opos, imap, inv, info)
+dm = (torch.randn(Bn, S, H, generator=g) * 0.5).bfloat16().to(dev)
+dtab = (torch.randn(V, H, generator=g) * 0.1).bfloat16().to(dev)       # read-modify-write: a non-zero table
+_hip.call("vlr_merge_bwd", dm, src, inv, idd, None, dtab, Bn, T, S, H, Bn * P, 1)
+torch.cuda.synchronize()
+torch.save(dtab.cpu(), sys.argv[2])
+"""
+
+
+def test_merge_bwd_embed_lds_kernel_is_bit_identical_to_the_global_walk(hip, tmp_path):
+    """merge_bwd_embed2_kernel (the positions' token ids in LDS, wave-level ballots) adds the same rows in the same order as
+    merge_bwd_embed_kernel (VLR_MERGE_EMBED2=0, read once per process): 48 ids on 1276 positions - every id is held by dozens of
+    positions in several 64-position groups and workgroups -, a padded tail, a non-zero table."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("1", "0"):
+        f = str(tmp_path / f"dtab_{flag}.pt")
+        r = subprocess.run([sys.executable, "-c", _MERGE_EMBED_CHILD, root, f], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, VLR_MERGE_EMBED2=flag))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append(torch.load(f))
+    assert torch.equal(outs[0], outs[1])
+    assert float(outs[0].float().abs().max()) > 1.0       # dozens of rows were added per id
+
+
 # ---------------------------------------------------------------------------------------------------- logps / loss
 @pytest.mark.parametrize("average", [0, 1])
 def test_logps_pipeline(hip, average):
