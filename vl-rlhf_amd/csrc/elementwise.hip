@@ -152,12 +152,22 @@ __global__ void reduce_partials_kernel(const float* __restrict__ part, int P, in
     out[c] = f32_to_bf16(s);
 }
 
-// stage 1 of a two-stage reduction: out[y][c] = sum of part[p][c] for p = y, y + gridDim.y, ...
-__global__ void reduce_partials_stage_kernel(const float* __restrict__ part, int P, int C, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// stage 1 of a two-stage reduction: out[y][c] = sum of part[p][c] for p = y, y + gridDim.y, ... in that order, SIXTEEN rows requested before the
+// first add: with one load in flight per thread the 16 MiB of RMSNorm's 1024 partial rows moved at 0.9 TB/s (19 us per launch, 65 per step)
+__global__ __launch_bounds__(256) void reduce_partials_stage16_kernel(const float* __restrict__ part, int P, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     float s = 0.f;
-    for (int p = blockIdx.y; p < P; p += gridDim.y) s += part[(size_t)p * C + c];
+    const int G = gridDim.y;
+    int p = blockIdx.y;
+    for (; p + 15 * G < P; p += 16 * G) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = part[(size_t)(p + u * G) * C + c];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += v[u];
+    }
+    for (; p < P; p += G) s += part[(size_t)p * C + c];
     out[(size_t)blockIdx.y * C + c] = s;
 }
 
@@ -723,7 +733,7 @@ static int rmsnorm_bwd_impl(const void* dy, const void* x, int x_f32, const void
     if (dw) {
         float* part2 = (float*)workspace + (size_t)VLR_NORM_BWD_BLOCKS * H;
         const int S2 = G < VLR_NORM_BWD_STAGE2 ? 1 : VLR_NORM_BWD_STAGE2;
-        hipLaunchKernelGGL(reduce_partials_stage_kernel, dim3((H + 255) / 256, S2), dim3(256), 0, st, (const float*)workspace, G, H, part2);
+        hipLaunchKernelGGL(reduce_partials_stage16_kernel, dim3((H + 255) / 256, S2), dim3(256), 0, st, (const float*)workspace, G, H, part2);
         hipLaunchKernelGGL(reduce_partials_kernel, dim3((H + 255) / 256), dim3(256), 0, st, (const float*)part2, S2, H,
                            (bf16_t*)dw, dw_accumulate);
     }
