@@ -336,9 +336,15 @@ __global__ __launch_bounds__(256) void merge_bwd_embed2_kernel(const bf16_t* __r
                                                                int H, int npos) {
     extern __shared__ int pid[];                           // token id per position, -1 = image feature row / zero row
     const int t = threadIdx.x, lane = t & 63;
-    for (int q = t; q < npos; q += 256) {
-        const int sq = src[q];
-        pid[q] = sq < 0 ? -1 : (int)ids[(size_t)(q / S) * T + sq];
+    for (int q = t; q < npos; q += 1024) {                 // four positions per thread and trip: the id load depends on the src load
+        int sq[4], id4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sq[u] = q + 256 * u < npos ? src[q + 256 * u] : -1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) id4[u] = sq[u] < 0 ? -1 : (int)ids[(size_t)((q + 256 * u) / S) * T + sq[u]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (q + 256 * u < npos) pid[q + 256 * u] = id4[u];
     }
     __syncthreads();
     const int p0 = blockIdx.x * EMB_PB;
