@@ -463,10 +463,11 @@ root = sys.argv[1]
 sys.path.insert(0, os.path.join(root, "vl-rlhf_amd"))
 from vlrlhf import _hip
 g = torch.Generator().manual_seed(11)
-Bn, T, P, H, V, image_token, pad = 4, 300, 20, 256, 50, 48, 49
+Bn, T, H = (int(x) for x in sys.argv[3:6])
+P, V, image_token, pad = 20, 50, 48, 49
 ids = torch.randint(0, 48, (Bn, T), generator=g)
 ids[:, 5] = image_token
-ids[1, 250:] = pad
+ids[1, T - 50:] = pad
 am = (ids != pad).long()
 lab = ids.clone()
 S = T - 1 + P
@@ -488,20 +489,22 @@ torch.save(dtab.cpu(), sys.argv[2])
 def test_merge_bwd_embed_lds_kernel_is_bit_identical_to_the_global_walk(hip, tmp_path):
     """merge_bwd_embed2_kernel (the positions' token ids in LDS, wave-level ballots) adds the same rows in the same order as
     merge_bwd_embed_kernel (VLR_MERGE_EMBED2=0, read once per process): 48 ids on 1276 positions - every id is held by dozens of
-    positions in several 64-position groups and workgroups -, a padded tail, a non-zero table."""
+    positions in several 64-position groups and workgroups -, a padded tail, a non-zero table; and 19 352 positions (more than the 60 KiB
+    of LDS a kernel gets without asking: the attribute path)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for flag in ("1", "0"):
-        f = str(tmp_path / f"dtab_{flag}.pt")
-        r = subprocess.run([sys.executable, "-c", _MERGE_EMBED_CHILD, root, f], capture_output=True, text=True, timeout=600,
-                           env=dict(os.environ, VLR_MERGE_EMBED2=flag))
-        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-        outs.append(torch.load(f))
-    assert torch.equal(outs[0], outs[1])
-    assert float(outs[0].float().abs().max()) > 1.0       # dozens of rows were added per id
+    for shape in (("4", "300", "256"), ("8", "2400", "64")):
+        outs = []
+        for flag in ("1", "0"):
+            f = str(tmp_path / f"dtab_{flag}_{shape[1]}.pt")
+            r = subprocess.run([sys.executable, "-c", _MERGE_EMBED_CHILD, root, f, *shape], capture_output=True, text=True, timeout=600,
+                               env=dict(os.environ, VLR_MERGE_EMBED2=flag))
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+            outs.append(torch.load(f))
+        assert torch.equal(outs[0], outs[1])
+        assert float(outs[0].float().abs().max()) > 1.0       # dozens of rows were added per id
 
 
 # ---------------------------------------------------------------------------------------------------- logps / loss

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void merge_bwd_embed_kernel(const bf16_t* __re
 // id - 82 M of them at 8 x 1599 positions, 1.4 ms of a step for a 0.05 ms gather.  Here a workgroup takes EMB_PB consecutive positions,
 // loads the token id of every position into LDS once, and each WAVE scans that array by itself (64 positions per ds_read + ballot, no
 // barrier): first for an earlier holder of the id, then - owners only - for the later positions to add, in position order; a thread
-// accumulates its own columns, so the four waves never have to meet.  npos ids must fit the dynamic LDS (vlr_merge_bwd falls back).
+// accumulates its own columns, so the four waves never have to meet.  npos ids must fit 156 KiB of dynamic LDS (vlr_merge_bwd falls back).
 #define EMB_PB 16
 __global__ __launch_bounds__(256) void merge_bwd_embed2_kernel(const bf16_t* __restrict__ dmerged, const int* __restrict__ src,
                                                                const long* __restrict__ ids, bf16_t* __restrict__ dtable, int T, int S,
@@ -685,8 +685,13 @@ extern "C" int vlr_merge_bwd(const void* dmerged, const int* src, const int* inv
     if (dembed_table) {
         const int npos = Bn * S;
         static int emb2 = -1;
-        if (emb2 < 0) { const char* e = getenv("VLR_MERGE_EMBED2"); emb2 = (e && e[0] == '0') ? 0 : 1; }
-        if (emb2 && (size_t)npos * sizeof(int) <= 60 * 1024)      // the positions' ids in LDS (the default limit of dynamic LDS: no attribute call)
+        constexpr size_t EMB2_LDS = 156 * 1024;                   // the positions' ids in LDS: up to 39936 positions (LLaVA-Next recipe: 8 x 4814)
+        if (emb2 < 0) {
+            const char* e = getenv("VLR_MERGE_EMBED2");
+            emb2 = (e && e[0] == '0') ? 0 : 1;
+            if (hipFuncSetAttribute((const void*)merge_bwd_embed2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EMB2_LDS) != hipSuccess) emb2 = 0;
+        }
+        if (emb2 && (size_t)npos * sizeof(int) <= EMB2_LDS)
             hipLaunchKernelGGL(merge_bwd_embed2_kernel, dim3((npos + EMB_PB - 1) / EMB_PB), dim3(256), (size_t)npos * sizeof(int), st,
                                (const bf16_t*)dmerged, src, input_ids, (bf16_t*)dembed_table, T, S, H, npos);
         else
