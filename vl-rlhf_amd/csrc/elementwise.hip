@@ -74,15 +74,16 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const XT* __restrict__
 // Workgroup b walks rows b, b+G, ...; its dw partial goes to dw_part[b][H] (reduced by reduce_partials_kernel).
 // EARLY: the residual-gradient addend of a row is loaded with dy / x, in front of the block reduction, instead of behind it (one exposed
 // memory latency per row less; the same values in the same operations)
-template <typename XT, bool EARLY>
+// MAXC: 8-column chunks per thread the register arrays are sized for (H <= 2048 MAXC): with 4 for every H the 7B width (2 used) cost 150
+// registers = 3 waves per SIMD; MAXC = 2 leaves room for more rows in flight per CU (the same instructions on the same values)
+template <typename XT, bool EARLY, int MAXC>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const XT* __restrict__ x,
                                                           const bf16_t* __restrict__ w, const float* __restrict__ rstd,
                                                           const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
                                                           float* __restrict__ dw_part, int M, int H, int row0, int part0) {
     // rows [row0, M); the workgroup's dw partial goes to row part0 + blockIdx.x of dw_part (two launches over two row ranges share one reduction)
     __shared__ float red[16];
-    constexpr int MAXC = 4;  // H <= 256*8*MAXC = 8192
-    float dwacc[MAXC][8];
+    float dwacc[MAXC][8];      // H <= 256*8*MAXC
 #pragma unroll
     for (int i = 0; i < MAXC; ++i)
 #pragma unroll
@@ -713,8 +714,12 @@ static int rmsnorm_bwd_impl(const void* dy, const void* x, int x_f32, const void
         static int early = -1;      // VLR_NORM_BWD_EARLY=0: the addend loaded behind the reduction (A/B; bit-identical)
         if (early < 0) { const char* e = getenv("VLR_NORM_BWD_EARLY"); early = (e && e[0] == '0') ? 0 : 1; }
 #define NORM_BWD_LAUNCH(XT_, E_)                                                                                                       \
-    hipLaunchKernelGGL((rmsnorm_bwd_kernel<XT_, E_>), dim3(G), dim3(256), 0, st, (const bf16_t*)dy, (const XT_*)x, (const bf16_t*)w, rstd, \
-                       (const bf16_t*)dres, (bf16_t*)dx, (float*)workspace, rows_end, H, row0, part0)
+    do {                                                                                                                               \
+        if (H <= 4096) hipLaunchKernelGGL((rmsnorm_bwd_kernel<XT_, E_, 2>), dim3(G), dim3(256), 0, st, (const bf16_t*)dy, (const XT_*)x,  \
+                                          (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, (float*)workspace, rows_end, H, row0, part0); \
+        else hipLaunchKernelGGL((rmsnorm_bwd_kernel<XT_, E_, 4>), dim3(G), dim3(256), 0, st, (const bf16_t*)dy, (const XT_*)x,          \
+                                (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, (float*)workspace, rows_end, H, row0, part0); \
+    } while (0)
         if (x_f32) { if (early) NORM_BWD_LAUNCH(float, true); else NORM_BWD_LAUNCH(float, false); }
         else { if (early) NORM_BWD_LAUNCH(bf16_t, true); else NORM_BWD_LAUNCH(bf16_t, false); }
 #undef NORM_BWD_LAUNCH
