@@ -42,8 +42,11 @@
 #else
 #define EPI_GST(T_, addr_, val_) (*reinterpret_cast<T_*>(addr_) = (val_))
 #endif
+#ifndef VLR_EPI_FAST
+#define VLR_EPI_FAST 1         // the SwiGLU-backward epilogue as straight-line code on buffer addressing (exact vmcnt bookkeeping, loads a ring of chunks ahead of the stores); 0: the round-5 epilogue (A/B builds)
+#endif
 #ifndef VLR_KLOOP_NT6
-#define VLR_KLOOP_NT6 1        // NT launches: the 18-fragment split of the TN loop, 6 / 6 / 6 / 6 ds_read_b128 per phase (0: 8 / 4 / 8 / 4)
+#define VLR_KLOOP_NT6 1       // NT launches: the 18-fragment split of the TN loop, 6 / 6 / 6 / 6 ds_read_b128 per phase (0: 8 / 4 / 8 / 4)
 #endif
 #ifndef VLR_KLOOP_NN8
 #define VLR_KLOOP_NN8 1        // NN launches: the whole next A0 read in phase 4 (8 / 8 / 8 / 8 LDS instructions per phase; 0: 12 / 8 / 8 / 4)
@@ -70,6 +73,10 @@ typedef __attribute__((address_space(3))) void lvoid_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
 
+// The lane id, computed where it is needed (two VALU instructions) instead of carried from threadIdx.x: a copy that lives across the K
+// loop is one VGPR of a kernel that has none to spare (round 6: it was the first value hipcc spilled), and an asm result is opaque -
+// nothing derived from it is hoisted out of the tile loop.
+#define LANE_FRESH(v_) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(v_))
 // compile-time loop: f(std::integral_constant<int, B>{}) ... f(<E - 1>) - software-pipelined epilogues index their register windows statically
 template <int B, int E, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -435,8 +442,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     for (int titer = 0;; ++titer) {
     // per-tile opaque copy of the lane id: keeps hipcc from hoisting every lane-derived address out of the tile loop (it did,
     // and spilled 100-200 bytes per lane into the K loop)
-    int lane = lane0;
-    asm volatile("" : "+v"(lane));
+    int lane;
+    LANE_FRESH(lane);
 #define RFL(x) __builtin_amdgcn_readfirstlane(x)
     const int m0 = RFL(ptab[titer * 8 + 0]), n0 = RFL(ptab[titer * 8 + 1]);
     // a piece is a whole tile: K tiles [0, nt) - or, SEG with the row tile's skip flag set, the base K tiles and the first seg_keep / 64 K tiles
@@ -461,6 +468,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
     parb = RFL(parb);
 
     f32x4 acc[2][4][2][2];   // [A half a][16-row tile i][B half b][16-col tile j]
+    float zero_;             // an opaque zero per tile: the constant was kept as a 4-register tuple across the tile loop (and spilled, round 6)
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zero_));
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -470,7 +479,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[a][i][b][j][r] = 0.f;
+                    for (int r = 0; r < 4; ++r) acc[a][i][b][j][r] = zero_;
 
     const int a2off = (!SEG || FUSE == 1) ? 0 : (n0 >= p.seg_b0 ? (n0 >= p.seg_b1 ? 2 : 1) : 0) * p.K2;
     // half h of K tile `tile`: 0 A-lo, 1 A-hi, 2 B-lo, 3 B-hi
@@ -500,8 +509,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
             if (tile >= ntp) {
                 if constexpr (CONT) {      // the K loop runs on into the next piece: its first K tiles, general path
                     if (!has_next) return;
-                    int lane = lane0;                    // opaque per call (shadows the tile's copy): hipcc hoisted the general path's 64-bit
-                    asm volatile("" : "+v"(lane));       // source addresses out of the slow K loop and spilled them around it
+                    int lane;                            // opaque per call (shadows the tile's copy): hipcc hoisted the general path's 64-bit
+                    LANE_FRESH(lane);                    // source addresses out of the slow K loop and spilled them around it
                     char* dst = smem + ((tile + parb) & 1) * BUF_BYTES + h * HALF_BYTES;
                     const int k0 = (kbn + tile - ntp) * PK;
                     if constexpr (h < 2) {
@@ -562,8 +571,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
             }
         }
         if (!fast && (p.K & (PK - 1)) != 0 && kb + tile == nt - 1) {      // only the last K tile can be partial: it takes the general (zero-filling) path
-            int lane = lane0;
-            asm volatile("" : "+v"(lane));
+            int lane;
+            LANE_FRESH(lane);
             char* dst = smem + ((tile + parb) & 1) * BUF_BYTES + h * HALF_BYTES;
             const int k0 = (kb + tile) * PK;
             if constexpr (h < 2) {
@@ -1037,6 +1046,85 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
         // per A half: the gate | up loads of its 8 chunks together (16 bytes = 8 columns per lane: row lane >> 2), then transposition,
         // arithmetic and two 16-byte stores chunk by chunk
         const int ec8 = (lane & 3) * 8, er8 = lane >> 2;
+        // Round 6: every tile as straight-line code with BUFFER addressing (VLR_EPI_FAST; 0 = the round-5 body below).  A predicated store
+        // is a branch, and where it joins hipcc has to assume the store was not issued: the counted waits of the round-5 body (vmcnt(15),
+        // (14), (13), ...) reach into the stores of earlier chunks, and the second A half's loads were only issued behind all sixteen
+        // stores of the first (two exposed round trips per tile, ISA of round 5).  Here the edges cost no predicate: the tile's
+        // descriptor ends behind the last valid row (rows past M: loads return 0, stores are dropped by the range check) and a lane
+        // whose 8 columns lie past I carries an offset beyond every descriptor.  So the bookkeeping is exact, and the loads run as a
+        // RING D chunks ahead - chunk n + D is requested into the registers chunk n has just given up, in front of chunk n's stores:
+        // no wait of the tile ever covers a store.  D = 7 (gate | up: 56 registers; 8 spilled one chunk) without an addend, 5 (gate | up | addend: 60) with
+        // the LoRA term of down_proj.  In place: a chunk's loads precede its own stores in program order.
+        if (VLR_EPI_FAST) {
+            auto ring = [&](auto addc) {
+                constexpr bool ADD = decltype(addc)::value;
+                constexpr int D = ADD ? 5 : 7;
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                const int rows_v = min(tp.M - m0, PT);                               // >= 1: valid rows of this tile
+                const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(GU + (size_t)m0 * p.ldc2, 0, rows_v * p.ldc2 * 2, 0x00020000);
+                const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(ADD ? p.residual + (size_t)m0 * p.ldr : GU), 0,
+                                                                                    ADD ? rows_v * p.ldr * 2 : 0, 0x00020000);
+                const int row_l = wr * 64 + (ln >> 2), col_l = n0 + wc * 32 + (ln & 3) * 8;
+                // per-lane byte offsets: gate / up of the two B halves (+ addend); 0x80000000 = past every descriptor, no wrap with soffset
+                uint32_t vg[2], vu[2], va[2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const bool okc = col_l + b * 128 + 8 <= I;
+                    vg[b] = okc ? (uint32_t)((row_l * p.ldc2 + col_l + b * 128) * 2) : 0x80000000u;
+                    vu[b] = okc ? vg[b] + (uint32_t)(I * 2) : 0x80000000u;
+                    va[b] = okc && ADD ? (uint32_t)((row_l * p.ldr + col_l + b * 128) * 2) : 0x80000000u;
+                }
+                // the chunk's row offset rides soffset (uniform), clamped to num_records: the range check compares the VGPR part with
+                // num_records - soffset, UNSIGNED - a chunk wholly past the last valid row must not wrap it
+                const uint32_t nrg = (uint32_t)(rows_v * p.ldc2 * 2), nra = ADD ? (uint32_t)(rows_v * p.ldr * 2) : 0u;
+                u32x4 gq[D], uq[D], aq[ADD ? D : 1];
+                auto request = [&](auto nc) {
+                    constexpr int n = decltype(nc)::value;
+                    constexpr int a = n >> 3, c = n & 7, i = c >> 1, b = c & 1, sl = n % D;
+                    const uint32_t sg_ = min((uint32_t)((a * 128 + i * 16) * p.ldc2 * 2), nrg);
+                    gq[sl] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+                    uq[sl] = gq[sl];
+                    if (EPI_LD_ON) {
+                        gq[sl] = __builtin_amdgcn_raw_buffer_load_b128(rg, vg[b], sg_, 0);
+                        uq[sl] = __builtin_amdgcn_raw_buffer_load_b128(rg, vu[b], sg_, 0);
+                    }
+                    if constexpr (ADD) aq[sl] = __builtin_amdgcn_raw_buffer_load_b128(ra, va[b], min((uint32_t)((a * 128 + i * 16) * p.ldr * 2), nra), 0);
+                };
+                static_for<0, D>(request);
+                static_for<0, 16>([&](auto nc) {
+                    constexpr int n = decltype(nc)::value;
+                    constexpr int a = n >> 3, c = n & 7, i = c >> 1, b = c & 1, sl = n % D;
+                    f32x4 o[2];
+                    EPI_XPOSE_F32_8(acc[a][i][b][0], acc[a][i][b][1], o);
+                    float d[8] = {o[0][0], o[0][1], o[0][2], o[0][3], o[1][0], o[1][1], o[1][2], o[1][3]};
+                    if constexpr (ADD) {      // + addend on d act (the LoRA term of down_proj)
+                        float ad[8];
+                        unpack8(aq[sl], ad);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) d[e] += ad[e];
+                    }
+                    float g[8], u[8], dg[8], du[8];
+                    unpack8(gq[sl], g);
+                    unpack8(uq[sl], u);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float sg = fast_sigmoid(g[e]);
+                        du[e] = d[e] * g[e] * sg;
+                        dg[e] = d[e] * u[e] * sg * (1.f + g[e] * (1.f - sg));
+                    }
+                    const u32x4 wg = pack8(dg), wu = pack8(du);
+                    if constexpr (n + D < 16) request(std::integral_constant<int, n + D>{});
+                    if (EPI_ST_ON) {
+                        const uint32_t sg_ = min((uint32_t)((a * 128 + i * 16) * p.ldc2 * 2), nrg);
+                        __builtin_amdgcn_raw_buffer_store_b128(wg, rg, vg[b], sg_, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(wu, rg, vu[b], sg_, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            };
+            if (p.residual) ring(std::true_type{}); else ring(std::false_type{});
+        } else
         static_for<0, 2>([&](auto ac) {
             constexpr int a = decltype(ac)::value;
             u32x4 gq[8], uq[8];
@@ -1060,8 +1148,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, const bf16_
                 f32x4 o[2];
                 EPI_XPOSE_F32_8(acc[a][i][b][0], acc[a][i][b][1], o);
                 EPI_USE(gq[c]); EPI_USE(uq[c]);
-                const int gm = m0 + a * 128 + wr * 64 + i * 16 + er8;
-                const int gn = n0 + b * 128 + wc * 32 + ec8;
+                int lc = lane;                        // opaque per chunk: the chunks' addresses are recomputed, not carried (they spilled beside the interior body)
+                asm volatile("" : "+v"(lc));
+                const int gm = m0 + a * 128 + wr * 64 + i * 16 + (lc >> 2);
+                const int gn = n0 + b * 128 + wc * 32 + (lc & 3) * 8;
                 const bool ok = gm < tp.M && gn + 8 <= I;
                 float d[8] = {o[0][0], o[0][1], o[0][2], o[0][3], o[1][0], o[1][1], o[1][2], o[1][3]};
                 if (p.residual && ok) {     // + addend on d act (the LoRA term of down_proj)
