@@ -1,8 +1,9 @@
 // Forward attention, D = 128, 64 queries per wave (included by attention.hip after the fwd2 kernel: shares its tile layout, DMA and mask
 // helpers).  Replaces flash-attn 2.5.8 at /root/reference/src/vlrlhf/utils/auto_load.py:49-56,534 for the decoder's forward passes.
 //
-// Why: with 32 queries per wave every v_mfma_f32_32x32x16_bf16 needs one fresh 1-KiB fragment from LDS (32 B/clk per SIMD = the whole
-// 128 B/clk of the CU), so the matrix pipe, the LDS port and the softmax VALU of attn_fwd2_kernel each sit at ~1/3.
+// Why: with 32 queries per wave every v_mfma_f32_32x32x16_bf16 needs one fresh 1-KiB fragment from LDS, and the matrix pipe, the LDS array
+// and the softmax VALU of attn_fwd2_kernel each sit well below half (round 6 counters: 42 / 23 / 55 % busy - no unit is the bound, the
+// phases of the two waves of a SIMD do not overlap; the "128 B/clk = LDS-bound" this header used to quote was wrong by a factor of two).
 // Here a wave owns TWO 32-query halves: every K / V fragment feeds two MFMAs (half the LDS bytes per FLOP).  That costs ~420 registers,
 // i.e. ONE wave per SIMD, so nothing but the wave's own instruction order can put the softmax beside the matrix work.  A first version
 // that left the order to hipcc ran at 0.7x of fwd2 (DESIGN.md "tried and reverted"); this one spells the issue order out:
