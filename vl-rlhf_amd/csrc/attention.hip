@@ -356,6 +356,14 @@ __device__ __forceinline__ void attn_tile_masks(unsigned long long* tilemask, co
 #define ATTN_SGB_DQ2 2       // dQ kernel: transposed K fragments in flight ahead of the dQ MFMAs; 0: hipcc's own order
 #endif
 #define ATTN_MAX_TILES 128   // S <= 8192
+#ifdef ATTN_TRACE2
+// timing probe of attn_fwd2_kernel (diagnostics build only: build_hip.py --define ATTN_TRACE2=1 --tag _tr2, tools/attn_fwd2_trace.py): wave 0 of
+// the workgroup that takes work item 0 stamps s_memtime at fixed points of its tiles (a stamp costs ~200 cycles itself)
+__device__ unsigned long long a2_trace_buf[4096];
+#define A2_STAMP(slot) do { if (a2_on && a2_n < 4000) { a2_trace_buf[a2_n++] = ((unsigned long long)(slot) << 56) | (__builtin_amdgcn_s_memtime() & 0xffffffffffffffull); } } while (0)
+#else
+#define A2_STAMP(slot) do {} while (0)
+#endif
 template <int D>
 struct AttnFwd2 {
     static constexpr int TILE_BYTES = KV_TILE * D * 2;
@@ -428,16 +436,23 @@ __device__ __forceinline__ unsigned attn_fwd2_block(const bf16_t* __restrict__ q
 #pragma unroll
     for (int st = 0; st < D / 16; ++st) ATTN_RETIRE(qf[st]);
 
+#ifdef ATTN_TRACE2
+    const bool a2_on = (L == 0) && wave == 0;
+    int a2_n = 0;
+#endif
     for (int it = 0; it < nkv; ++it) {
         const int k0 = it * KV_TILE;
+        A2_STAMP(1);
         // tile `it` has landed (own pieces: vmcnt, everybody's: barrier) and nobody still reads the other buffer
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        A2_STAMP(2);
         if (it + 1 < nkv) issue_tile(it + 1);
         else if (ctr && t == 0) nxt = atomicAdd(ctr, 1u);  // late, so that the blocks stay dynamically balanced to the end
+        A2_STAMP(3);
         if (CAUSAL && k0 > qw0 + 31) continue;             // wave-uniform: whole tile is in this wave's future
         const char* k_lds = smem + (it & 1) * 2 * CF::TILE_BYTES;
         const char* v_lds = k_lds + CF::TILE_BYTES;
@@ -491,6 +506,7 @@ __device__ __forceinline__ unsigned attn_fwd2_block(const bf16_t* __restrict__ q
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
         mx = attn_pair_max(mx);
+        A2_STAMP(4);
         const float m_new = fmaxf(m, mx * scale_log2);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
         const float alpha = __builtin_amdgcn_exp2f(m - m_use);
@@ -510,6 +526,10 @@ __device__ __forceinline__ unsigned attn_fwd2_block(const bf16_t* __restrict__ q
         l = l * alpha + rs;
 #endif
         m = m_new;
+#ifdef ATTN_TRACE2
+        asm volatile("" : "+v"(l));
+        A2_STAMP(5);
+#endif
         if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {   // the running max moved for some query of this wave
 #pragma unroll
             for (int i = 0; i < D / 32; ++i)
@@ -532,6 +552,10 @@ __device__ __forceinline__ unsigned attn_fwd2_block(const bf16_t* __restrict__ q
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
         }
         __builtin_amdgcn_sched_group_barrier(0x008, ATTN_SGB_PV, 1);
+#endif
+#ifdef ATTN_TRACE2
+        asm volatile("" : "+v"(acc[0]));
+        A2_STAMP(6);
 #endif
     }
 #if ATTN_SWAP
@@ -1411,6 +1435,11 @@ static int attn_dma_on() {
     return on;
 }
 
+#ifdef ATTN_TRACE2
+extern "C" int vlr_attn_fwd2_trace(unsigned long long* host, int n) {      // diagnostics build: the s_memtime stamps of attn_fwd2_block
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(a2_trace_buf), (size_t)n * 8) == hipSuccess ? 0 : 1;
+}
+#endif
 #ifdef F3_TRACE
 extern "C" int vlr_attn_fwd3_trace(unsigned long long* host, int n) {      // diagnostics build: the s_memtime stamps of attn_fwd3.h
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(f3_trace_buf), (size_t)n * 8) == hipSuccess ? 0 : 1;
