@@ -180,6 +180,37 @@ __global__ void reduce_partials_f32_kernel(const float* __restrict__ part, int P
     out[c] = s;
 }
 
+// the same partials, 8 columns per thread (16-byte loads) and four rows requested before the first add - same rows in the same order per
+// column.  The 4-byte, one-load-in-flight form below ran at 1.2 TB/s (Qwen-VL: 0.2 ms per biased c_attn gradient x 32 layers, 1 ms for the
+// lm-head's column sums).  C % 8 == 0, ld % 8 == 0, X 16-byte aligned.
+__global__ __launch_bounds__(64) void colsum_partial8_kernel(const bf16_t* __restrict__ X, int R, int C, int ld, float* __restrict__ part) {
+    const int c = (blockIdx.x * 64 + threadIdx.x) * 8;
+    if (c >= C) return;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int G = gridDim.y;
+    int r = blockIdx.y;
+    for (; r + 3 * G < R; r += 4 * G) {
+        u32x4 w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = *reinterpret_cast<const u32x4*>(X + (size_t)(r + u * G) * ld + c);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float v[8];
+            unpack8(w[u], v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += v[e];
+        }
+    }
+    for (; r < R; r += G) {
+        float v[8];
+        unpack8(*reinterpret_cast<const u32x4*>(X + (size_t)r * ld + c), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += v[e];
+    }
+    float* d = part + (size_t)blockIdx.y * C + c;
+    *reinterpret_cast<f32x4*>(d) = f32x4{s[0], s[1], s[2], s[3]};
+    *reinterpret_cast<f32x4*>(d + 4) = f32x4{s[4], s[5], s[6], s[7]};
+}
 // column-sum partials of a bf16 matrix X[R][C] (ld): workgroup (bx, by) sums rows by, by+Gy, ... of 512 columns
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* __restrict__ X, int R, int C, int ld,
                                                              float* __restrict__ part) {
@@ -755,8 +786,11 @@ extern "C" int vlr_colsum(const void* X, int R, int C, int ld, void* out, int ac
                           hipStream_t st) {
     VLR_REQUIRE(R > 0 && C > 0 && C % 2 == 0 && ld % 2 == 0 && workspace, "vlr_colsum: bad args R=%d C=%d", R, C);
     const int gy = R < VLR_COLSUM_ROWS ? R : VLR_COLSUM_ROWS;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((C / 2 + 255) / 256, gy), dim3(256), 0, st, (const bf16_t*)X, R, C, ld,
-                       (float*)workspace);
+    if (C % 8 == 0 && ld % 8 == 0 && !((uintptr_t)X & 15))
+        hipLaunchKernelGGL(colsum_partial8_kernel, dim3((C / 8 + 63) / 64, gy), dim3(64), 0, st, (const bf16_t*)X, R, C, ld, (float*)workspace);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3((C / 2 + 255) / 256, gy), dim3(256), 0, st, (const bf16_t*)X, R, C, ld,
+                           (float*)workspace);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)workspace, gy, C,
                        (bf16_t*)out, accumulate);
     return vlr_check_launch("vlr_colsum");
@@ -765,8 +799,11 @@ extern "C" int vlr_colsum(const void* X, int R, int C, int ld, void* out, int ac
 extern "C" int vlr_colsum_f32(const void* X, int R, int C, int ld, float* out, void* workspace, hipStream_t st) {
     VLR_REQUIRE(R > 0 && C > 0 && C % 2 == 0 && ld % 2 == 0 && workspace, "vlr_colsum_f32: bad args R=%d C=%d", R, C);
     const int gy = R < VLR_COLSUM_ROWS ? R : VLR_COLSUM_ROWS;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((C / 2 + 255) / 256, gy), dim3(256), 0, st, (const bf16_t*)X, R, C, ld,
-                       (float*)workspace);
+    if (C % 8 == 0 && ld % 8 == 0 && !((uintptr_t)X & 15))
+        hipLaunchKernelGGL(colsum_partial8_kernel, dim3((C / 8 + 63) / 64, gy), dim3(64), 0, st, (const bf16_t*)X, R, C, ld, (float*)workspace);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3((C / 2 + 255) / 256, gy), dim3(256), 0, st, (const bf16_t*)X, R, C, ld,
+                           (float*)workspace);
     hipLaunchKernelGGL(reduce_partials_f32_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)workspace, gy, C, out);
     return vlr_check_launch("vlr_colsum_f32");
 }
